@@ -1,0 +1,89 @@
+// Shared device helpers for the espresso_amd HIP kernels (gfx950 / CDNA4 only).
+// Wavefront = 64 lanes; all reductions below are written for that width.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EA_WAVE 64
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16))
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x a multiple of 64 (<= 1024). `sm` needs 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sm[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float r = -INFINITY;
+  for (int i = 0; i < nw; ++i) r = fmaxf(r, sm[i]);
+  return r;
+}
+
+// Counter-based dropout RNG: a 64-bit mix of (seed, element index) -> uniform [0,1).
+// The same (seed, idx) is re-evaluated in the backward kernels, so no mask is ever stored.
+__device__ __forceinline__ uint32_t ea_hash(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// keep-scale: returns 0 if dropped, 1/(1-p) if kept.  thr = p * 2^32 (host computed).
+__device__ __forceinline__ float ea_keep(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+  return ea_hash(seed, idx) >= thr ? inv_keep : 0.f;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+
+__device__ __forceinline__ float log_add(float a, float b) {
+  // log(exp(a)+exp(b)) robust to -inf
+  float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + log1pf(__expf(-fabsf(a - b)));
+}
+
+#define EA_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -1)

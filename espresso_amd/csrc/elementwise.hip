@@ -1,0 +1,156 @@
+// Streaming element-wise / column-reduction kernels (HBM-bound, 16-byte accesses).
+//  - fp32 -> bf16 cast of master weights (the per-step AMP cast the reference gets from
+//    torch.cuda.amp.autocast, fairseq/tasks/fairseq_task.py:516)
+//  - scale + dropout (backward of "dropout(x) * s" epilogues; FairseqDropout,
+//    fairseq/modules/fairseq_dropout.py:23-25)
+//  - column sums for bias gradients (autograd of nn.Linear bias)
+//  - axpby for residual adds that cannot ride a GEMM epilogue.
+#include "common.h"
+#include "espresso_amd.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src,
+                                                            bf16_t* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *reinterpret_cast<const float4*>(src + i);
+      const float4 b = *reinterpret_cast<const float4*>(src + i + 4);
+      uint4 u;
+      u.x = pack_bf2(a.x, a.y);
+      u.y = pack_bf2(a.z, a.w);
+      u.z = pack_bf2(b.x, b.y);
+      u.w = pack_bf2(b.z, b.w);
+      *reinterpret_cast<uint4*>(dst + i) = u;
+    } else {
+      for (long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src,
+                                                            float* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = bf2f(src[i]);
+}
+
+// out = a*x*keep(idx) + b*y   (x,y,out bf16; y optional)
+__global__ __launch_bounds__(256) void scale_dropout_kernel(const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ y,
+                                                            bf16_t* __restrict__ out, long n, float a,
+                                                            float b, uint64_t seed, uint32_t thr,
+                                                            float inv_keep) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const uint4 ux = *reinterpret_cast<const uint4*>(x + i);
+      uint4 uy = make_uint4(0, 0, 0, 0);
+      if (y) uy = *reinterpret_cast<const uint4*>(y + i);
+      const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
+      const uint32_t wy[4] = {uy.x, uy.y, uy.z, uy.w};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
+        const float yv = (e & 1) ? __uint_as_float(wy[e >> 1] & 0xffff0000u) : __uint_as_float(wy[e >> 1] << 16);
+        float k = 1.f;
+        if (thr) k = ea_keep(seed, (uint64_t)(i + e), thr, inv_keep);
+        o[e] = a * xv * k + b * yv;
+      }
+      uint4 u;
+      u.x = pack_bf2(o[0], o[1]);
+      u.y = pack_bf2(o[2], o[3]);
+      u.z = pack_bf2(o[4], o[5]);
+      u.w = pack_bf2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(out + i) = u;
+    } else {
+      for (long j = i; j < n; ++j) {
+        float k = 1.f;
+        if (thr) k = ea_keep(seed, (uint64_t)j, thr, inv_keep);
+        out[j] = f2bf(a * bf2f(x[j]) * k + (y ? b * bf2f(y[j]) : 0.f));
+      }
+    }
+  }
+}
+
+// out[n] (+)= sum_m X[m*ld + n]   ; block = 256 threads = 32 column-pairs x 8 row-lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, float* __restrict__ out,
+                                                     int M, int N, long ld, int rows_per_block) {
+  __shared__ float sm[8][64];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 64 + cx * 2;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f;
+  if (c0 + 1 < N && (ld & 1) == 0) {
+    for (int r = r0 + ry; r < r1; r += 8) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(X + (long)r * ld + c0);
+      a0 += __uint_as_float(w << 16);
+      a1 += __uint_as_float(w & 0xffff0000u);
+    }
+  } else {
+    for (int r = r0 + ry; r < r1; r += 8) {
+      if (c0 < N) a0 += bf2f(X[(long)r * ld + c0]);
+      if (c0 + 1 < N) a1 += bf2f(X[(long)r * ld + c0 + 1]);
+    }
+  }
+  sm[ry][cx * 2] = a0;
+  sm[ry][cx * 2 + 1] = a1;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += sm[i][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) atomicAdd(out + c, s);
+  }
+}
+
+// zero rows of a bf16 [M][C] matrix where row_zero[m] != 0
+__global__ __launch_bounds__(256) void zero_rows_kernel(bf16_t* __restrict__ x, const uint8_t* __restrict__ row_zero,
+                                                        int M, int C) {
+  const int row = blockIdx.x;
+  if (!row_zero[row]) return;
+  for (int c = threadIdx.x; c < C; c += 256) x[(long)row * C + c] = 0;
+}
+
+}  // namespace
+
+static inline int grid_for(long n, int per_thread) {
+  long b = (n + 256L * per_thread - 1) / (256L * per_thread);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int ea_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 8)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_cast_bf16_to_f32(const void* src, float* dst, long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 1)), dim3(256), 0, stream, (const bf16_t*)src, dst, n);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_scale_dropout_bf16(const void* x, const void* y, void* out, long n, float a, float b,
+                                     uint64_t seed, uint32_t thr, float inv_keep, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scale_dropout_kernel, dim3(grid_for(n, 8)), dim3(256), 0, stream, (const bf16_t*)x,
+                     (const bf16_t*)y, (bf16_t*)out, n, a, b, seed, thr, inv_keep);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_colsum_bf16(const void* X, float* out, int M, int N, long ld, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return 0;
+  int rpb = (M + 255) / 256;
+  if (rpb < 64) rpb = 64;
+  dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, (const bf16_t*)X, out, M, N, ld, rpb);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_zero_rows_bf16(void* x, const uint8_t* row_zero, int M, int C, hipStream_t stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(M), dim3(256), 0, stream, (bf16_t*)x, row_zero, M, C);
+  return EA_CHECK_LAUNCH();
+}

@@ -1,0 +1,184 @@
+// On-the-fly Kaldi-compatible log-mel filterbank + global CMVN + SpecAugment + batch padding
+// (K1-K4 of SURVEY.md) as one fused front-end for gfx950.
+//
+// Replaces: espresso/tools/utils.py:426-454 (get_torchaudio_fbank_or_mfcc ->
+//   torchaudio.compliance.kaldi.fbank(waveform, num_mel_bins=80, sample_frequency=sr), all other
+//   arguments default: 25 ms / 10 ms, dither 0, remove_dc_offset, preemphasis 0.97 with replicate
+//   pad, povey window, FFT 512, power spectrum, mel 20 Hz..Nyquist, log floored at fp32 eps,
+//   snip_edges) called per utterance on CPU from espresso/data/feat_text_dataset.py:128-155;
+//   fairseq/data/audio/feature_transforms/global_cmvn.py:26-29;
+//   espresso/data/feature_transforms/adaptive_specaugment.py:77-136 (mask *positions* are drawn on
+//   the host from the reference's numpy stream and shipped here as index lists);
+//   espresso/tools/utils.py:97-113 collate_frames (zero padding to (B, Tmax, F)).
+//
+// HBM-bound streaming op (96 KB per audio-second, ~1.3 MFLOP): one wavefront per frame, the 400-sample
+// frame and its 512-point FFT live in LDS (4 KB per wave), frames are written straight into the
+// padded batch tensor.  Overlapping frame reads (hop 160 of 400) are served by L2.
+#include "common.h"
+#include "espresso_amd.h"
+
+namespace {
+
+constexpr int NFFT = 512, LOG2N = 9, WAVES = 4;
+
+__device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> (32 - LOG2N)); }
+
+// wav: concatenated fp32 samples; off[b]..off[b+1] = utterance b.  feat: [B][Tmax][nmel]
+__global__ __launch_bounds__(256) void fbank_kernel(
+    const float* __restrict__ wav, const long* __restrict__ off, const float* __restrict__ window /*[flen]*/,
+    const float2* __restrict__ twiddle /*[256] (cos,-sin)(2*pi*k/512)*/, const int* __restrict__ mel_start,
+    const int* __restrict__ mel_len, const int* __restrict__ mel_woff, const float* __restrict__ mel_w,
+    const float* __restrict__ cmvn_mean, const float* __restrict__ cmvn_std, float* __restrict__ feat,
+    float* __restrict__ utt_sum, int* __restrict__ out_len, int Tmax, int nmel, int flen, int fshift, float preemph,
+    float log_floor, int frames_per_block) {
+  __shared__ float s_re[WAVES][NFFT];
+  __shared__ float s_im[WAVES][NFFT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const long s0 = off[b];
+  const long nsamp = off[b + 1] - s0;
+  const int nfr = nsamp < flen ? 0 : (int)(1 + (nsamp - flen) / fshift);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = nfr;
+  float* re = s_re[wv];
+  float* im = s_im[wv];
+  const int f_begin = blockIdx.x * frames_per_block;
+  float acc_sum = 0.f;
+  for (int it = 0; it < frames_per_block; it += WAVES) {
+    const int f = f_begin + it + wv;
+    const bool in_batch = f < Tmax;
+    const bool valid = in_batch && f < nfr;
+    // ---- load frame, remove DC ----
+    float x[8];
+    float sum = 0.f;
+    const float* src = wav + s0 + (long)f * fshift;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = lane + 64 * k;
+      x[k] = (valid && i < flen) ? src[i] : 0.f;
+      sum += x[k];
+    }
+    const float mean = wave_sum(sum) / (float)flen;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = lane + 64 * k;
+      re[i] = (i < flen) ? x[k] - mean : 0.f;  // natural order, reused below for the pre-emphasis neighbour
+    }
+    __syncthreads();
+    // ---- pre-emphasis (replicate pad), window, scatter to bit-reversed order ----
+    float y[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = lane + 64 * k;
+      float v = 0.f;
+      if (i < flen) {
+        const float cur = re[i];
+        const float prev = re[i > 0 ? i - 1 : 0];
+        v = (cur - preemph * prev) * window[i];
+      }
+      y[k] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = lane + 64 * k;
+      const int r = bitrev9(i);
+      re[r] = y[k];
+      im[r] = 0.f;
+    }
+    __syncthreads();
+    // ---- radix-2 DIT FFT, 4 butterflies per lane per stage ----
+#pragma unroll
+    for (int st = 0; st < LOG2N; ++st) {
+      const int half = 1 << st;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;          // butterfly id 0..255
+        const int pos = j & (half - 1);       // position within the half-block
+        const int i0 = ((j >> st) << (st + 1)) + pos;
+        const int i1 = i0 + half;
+        const float2 w = twiddle[pos << (LOG2N - 1 - st)];
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        const float tr = br * w.x - bi * w.y;
+        const float ti = br * w.y + bi * w.x;
+        re[i0] = ar + tr; im[i0] = ai + ti;
+        re[i1] = ar - tr; im[i1] = ai - ti;
+      }
+      __syncthreads();
+    }
+    // ---- power spectrum (bins 0..255 carry mel weight; Nyquist bin has weight 0) ----
+    float pw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = lane + 64 * k;
+      const float mag = sqrtf(re[i] * re[i] + im[i] * im[i]);
+      pw[k] = mag * mag;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) re[lane + 64 * k] = pw[k];
+    __syncthreads();
+    // ---- mel bank, log, CMVN, store ----
+    float rowsum = 0.f;
+    for (int m = lane; m < nmel; m += 64) {
+      const int st = mel_start[m], ln = mel_len[m], wo = mel_woff[m];
+      float e = 0.f;
+      for (int q = 0; q < ln; ++q) e += re[st + q] * mel_w[wo + q];
+      float v = logf(fmaxf(e, log_floor));
+      if (cmvn_mean) v = (v - cmvn_mean[m]) / cmvn_std[m];
+      if (!valid) v = 0.f;
+      if (in_batch) feat[((long)b * Tmax + f) * nmel + m] = v;
+      rowsum += v;
+    }
+    acc_sum += wave_sum(rowsum);
+    __syncthreads();
+  }
+  if (utt_sum && lane == 0 && acc_sum != 0.f) atomicAdd(utt_sum + b, acc_sum);
+}
+
+// masks: fmask[b][nf][2] = (f0, f), tmask[b][ntmax][2] = (t0, t) ; entries with width 0 are skipped.
+__global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ feat, const int* __restrict__ len,
+                                                      const float* __restrict__ utt_sum, const int* __restrict__ fmask,
+                                                      const int* __restrict__ tmask, int nf, int nt, int Tmax, int nmel,
+                                                      int use_mean, float mask_value) {
+  const int b = blockIdx.x;
+  const int n = len[b];
+  if (n <= 0) return;
+  const float val = use_mean ? utt_sum[b] / ((float)n * (float)nmel) : mask_value;
+  float* fb = feat + (long)b * Tmax * nmel;
+  for (int i = 0; i < nf; ++i) {
+    const int f0 = fmask[((long)b * nf + i) * 2], fw = fmask[((long)b * nf + i) * 2 + 1];
+    if (fw <= 0) continue;
+    for (int e = threadIdx.x; e < n * fw; e += 256) fb[(long)(e / fw) * nmel + f0 + e % fw] = val;
+  }
+  for (int i = 0; i < nt; ++i) {
+    const int t0 = tmask[((long)b * nt + i) * 2], tw = tmask[((long)b * nt + i) * 2 + 1];
+    if (tw <= 0) continue;
+    for (int e = threadIdx.x; e < tw * nmel; e += 256) fb[(long)t0 * nmel + e] = val;
+  }
+}
+
+}  // namespace
+
+extern "C" int ea_fbank_batch(const float* wav, const long* offsets, int B, const float* window,
+                              const float* twiddle, const int* mel_start, const int* mel_len, const int* mel_woff,
+                              const float* mel_w, const float* cmvn_mean, const float* cmvn_std, float* feat,
+                              float* utt_sum, int* out_len, int Tmax, int nmel, int frame_len, int frame_shift,
+                              float preemph, float log_floor, hipStream_t stream) {
+  if (B <= 0 || Tmax <= 0) return 0;
+  if (frame_len > NFFT || nmel > 128) return -2;
+  const int fpb = 16;
+  dim3 grid((Tmax + fpb - 1) / fpb, B);
+  hipLaunchKernelGGL(fbank_kernel, grid, dim3(256), 0, stream, wav, offsets, window, (const float2*)twiddle, mel_start,
+                     mel_len, mel_woff, mel_w, cmvn_mean, cmvn_std, feat, utt_sum, out_len, Tmax, nmel, frame_len,
+                     frame_shift, preemph, log_floor, fpb);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_specaugment(float* feat, const int* lengths, const float* utt_sum, const int* fmask,
+                              const int* tmask, int nf, int nt, int B, int Tmax, int nmel, int use_mean,
+                              float mask_value, hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(specaug_kernel, dim3(B), dim3(256), 0, stream, feat, lengths, utt_sum, fmask, tmask, nf, nt,
+                     Tmax, nmel, use_mean, mask_value);
+  return EA_CHECK_LAUNCH();
+}

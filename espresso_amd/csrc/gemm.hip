@@ -1,0 +1,254 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950 (MI355X).
+//
+//   C[z][m][n] = epilogue( alpha * sum_k A(z; m,k) * B(z; n,k) )
+//
+// Every dense product on the ASR hot path goes through this kernel: the Linear layers of the
+// Conformer/Transformer blocks (reference: fairseq/modules/conformer_layer.py:134-146 FFN,
+// fairseq/modules/multihead_attention.py:650-688 q/k/v/out/pos projections, pointwise convs
+// conformer_layer.py:79-101), fc0/fc_out (espresso/models/transformer/speech_transformer_encoder.py:341-343,
+// speech_transformer_encoder_model.py:207-208), the attention products QK^T / Q P^T / P V
+// (multihead_attention.py:788-831, 884-907) and the im2col form of the conv2d sub-sampler
+// (espresso/modules/speech_convolutions.py:78-102) — forward, dgrad and wgrad.
+//
+// Design (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves, each 64x64 = 4x4 MFMA
+// 16x16x32 bf16 tiles, fp32 accumulators in AGPR/VGPR), BK = 64.  Operands are staged
+// global -> registers -> LDS; the next K-tile's global loads are issued before the MFMAs of the
+// current one so HBM latency hides under the matrix pipe.  The LDS image is always
+// [row][k] (k contiguous, 128 B rows) with a 16-B-chunk XOR swizzle (chunk ^= row & 7) so the
+// ds_read_b128 fragment reads are bank-conflict free.  An operand may be stored "k-strided"
+// in memory (element (row,k) at ptr[k*ld + row]); it is then transposed in registers while
+// being staged (4x8 block per thread -> eight ds_write_b64), which is what lets dgrad / wgrad /
+// P·V run without materialising transposed copies in HBM.
+#include "common.h"
+#include "espresso_amd.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
+
+__device__ __forceinline__ uint32_t lds_off(int row, int chunk) {
+  return (uint32_t)(row * ROW_BYTES + ((chunk ^ (row & 7)) << 4));
+}
+
+// ---- global -> register staging -------------------------------------------------------------
+// K-contiguous operand: element (row,k) at p[row*ld + k]. Thread owns 4 chunks of 8 k.
+__device__ __forceinline__ void load_kc(const bf16_t* __restrict__ p, long ld, int rows, int K,
+                                        int row0, int k0, int tid, uint4 (&r)[4]) {
+  const int c = tid & 7;
+  const int gk = k0 + c * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + (tid >> 3) + 32 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < rows && gk < K) {
+      const bf16_t* q = p + (long)row * ld + gk;
+      if (gk + 8 <= K && (((uintptr_t)q) & 15) == 0) {
+        v = *reinterpret_cast<const uint4*>(q);
+      } else {
+        bf16_t t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (gk + e < K) ? q[e] : (bf16_t)0;
+        v.x = t[0] | ((uint32_t)t[1] << 16);
+        v.y = t[2] | ((uint32_t)t[3] << 16);
+        v.z = t[4] | ((uint32_t)t[5] << 16);
+        v.w = t[6] | ((uint32_t)t[7] << 16);
+      }
+    }
+    r[i] = v;
+  }
+}
+__device__ __forceinline__ void store_kc(char* __restrict__ s, int tid, const uint4 (&r)[4]) {
+  const int c = tid & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    *reinterpret_cast<uint4*>(s + lds_off(row, c)) = r[i];
+  }
+}
+// K-strided operand: element (row,k) at p[k*ld + row]. Thread owns a 4(k) x 8(row) block.
+__device__ __forceinline__ void load_ks(const bf16_t* __restrict__ p, long ld, int rows, int K,
+                                        int row0, int k0, int tid, uint4 (&r)[4]) {
+  const int grow = row0 + (tid & 15) * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gk = k0 + (tid >> 4) * 4 + j;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gk < K && grow < rows) {
+      const bf16_t* q = p + (long)gk * ld + grow;
+      if (grow + 8 <= rows && (((uintptr_t)q) & 15) == 0) {
+        v = *reinterpret_cast<const uint4*>(q);
+      } else {
+        bf16_t t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (grow + e < rows) ? q[e] : (bf16_t)0;
+        v.x = t[0] | ((uint32_t)t[1] << 16);
+        v.y = t[2] | ((uint32_t)t[3] << 16);
+        v.z = t[4] | ((uint32_t)t[5] << 16);
+        v.w = t[6] | ((uint32_t)t[7] << 16);
+      }
+    }
+    r[j] = v;
+  }
+}
+__device__ __forceinline__ void store_ks(char* __restrict__ s, int tid, const uint4 (&r)[4]) {
+  const int kk0 = (tid >> 4) * 4;
+  const int r0 = (tid & 15) * 8;
+  const uint32_t w0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
+  const uint32_t w1[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
+  const uint32_t w2[4] = {r[2].x, r[2].y, r[2].z, r[2].w};
+  const uint32_t w3[4] = {r[3].x, r[3].y, r[3].z, r[3].w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    // even row 2d : low halves ; odd row 2d+1 : high halves
+    uint2 lo, hi;
+    lo.x = (w0[d] & 0xffffu) | (w1[d] << 16);
+    lo.y = (w2[d] & 0xffffu) | (w3[d] << 16);
+    hi.x = (w0[d] >> 16) | (w1[d] & 0xffff0000u);
+    hi.y = (w2[d] >> 16) | (w3[d] & 0xffff0000u);
+    const int ra = r0 + 2 * d, rb = ra + 1;
+    *reinterpret_cast<uint2*>(s + lds_off(ra, kk0 >> 3) + (kk0 & 4) * 2) = lo;
+    *reinterpret_cast<uint2*>(s + lds_off(rb, kk0 >> 3) + (kk0 & 4) * 2) = hi;
+  }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == EA_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == EA_ACT_SILU) return silu_f(v);
+  return v;
+}
+__device__ __forceinline__ float apply_dact(float z, int act) {
+  if (act == EA_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == EA_ACT_SILU) return dsilu_f(z);
+  return 1.f;
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BM * ROW_BYTES];
+  char* sA = smem;
+  char* sB = smem + BM * ROW_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int z = blockIdx.z;
+  const int zhi = z / p.zdiv, zlo = z % p.zdiv;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)zhi * p.sA_hi + (long)zlo * p.sA_lo;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long)zhi * p.sB_hi + (long)zlo * p.sB_lo;
+  const long coff = (long)zhi * p.sC_hi + (long)zlo * p.sC_lo;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  const int nk = (p.K + BK - 1) / BK;
+  if (A_KS) load_ks(A, p.lda, p.M, p.K, m0, 0, tid, ra); else load_kc(A, p.lda, p.M, p.K, m0, 0, tid, ra);
+  if (B_KS) load_ks(B, p.ldb, p.N, p.K, n0, 0, tid, rb); else load_kc(B, p.ldb, p.N, p.K, n0, 0, tid, rb);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (A_KS) store_ks(sA, tid, ra); else store_kc(sA, tid, ra);
+    if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int k0 = (kt + 1) * BK;
+      if (A_KS) load_ks(A, p.lda, p.M, p.K, m0, k0, tid, ra); else load_kc(A, p.lda, p.M, p.K, m0, k0, tid, ra);
+      if (B_KS) load_ks(B, p.ldb, p.N, p.K, n0, k0, tid, rb); else load_kc(B, p.ldb, p.N, p.K, n0, k0, tid, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + (lane >> 4);
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + (lane & 15);
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(row, c));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + (lane & 15);
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(row, c));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wn*64 + j*16 + (lane&15)]
+  const bool has_drop = p.drop_thr != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (n >= p.N) continue;
+        float v = p.alpha * acc[i][j][r];
+        if (p.bias) v += p.bias[n];
+        const uint64_t didx = ((uint64_t)z * (uint64_t)p.M + (uint64_t)m) * (uint64_t)p.N + (uint64_t)n;
+        if (p.aux) {
+          // backward-through-activation: v is d(out of dropout(act(z))) ; aux holds z
+          const float zz = bf2f(reinterpret_cast<const bf16_t*>(p.aux)[(long)zhi * p.sX_hi + (long)zlo * p.sX_lo + (long)m * p.ldaux + n]);
+          if (has_drop) v *= ea_keep(p.drop_seed, didx, p.drop_thr, p.drop_scale);
+          v *= apply_dact(zz, p.act);
+        } else {
+          if (p.C2) {
+            // C keeps the pre-activation, C2 the activated (+dropout) value
+            reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n] = f2bf(v);
+            float y = apply_act(v, p.act);
+            if (has_drop) y *= ea_keep(p.drop_seed, didx, p.drop_thr, p.drop_scale);
+            reinterpret_cast<bf16_t*>(p.C2)[coff + (long)m * p.ldc2 + n] = f2bf(y);
+            continue;
+          }
+          v = apply_act(v, p.act);
+          if (has_drop) v *= ea_keep(p.drop_seed, didx, p.drop_thr, p.drop_scale);
+        }
+        v *= p.out_scale;
+        if (p.resid) {
+          const long ro = (long)zhi * p.sR_hi + (long)zlo * p.sR_lo + (long)m * p.ldr + n;
+          v += p.resid_f32 ? reinterpret_cast<const float*>(p.resid)[ro]
+                           : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[ro]);
+        }
+        const long co = coff + (long)m * p.ldc + n;
+        if (p.c_f32) {
+          float* C = reinterpret_cast<float*>(p.C);
+          C[co] = p.accumulate ? C[co] + v : v;
+        } else {
+          reinterpret_cast<bf16_t*>(p.C)[co] = f2bf(v);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
+  const EaGemmParams& p = *pp;
+  if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
+  if (p.K <= 0 || p.zdiv <= 0) return -2;
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch), block(256);
+  if (p.a_kstrided) {
+    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, stream, p);
+  } else {
+    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, p);
+  }
+  return EA_CHECK_LAUNCH();
+}

@@ -1,0 +1,213 @@
+// LayerNorm forward/backward (eps 1e-5, affine) for gfx950.
+// Replaces fairseq/modules/layer_norm.py:28-33 (apex FusedLayerNorm / torch.nn.LayerNorm) as used
+// by every Conformer/Transformer block (fairseq/modules/conformer_layer.py:86,141;
+// espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:46,70) and by
+// layernorm_embedding + dropout + pad-zeroing in
+// espresso/models/transformer/speech_transformer_encoder.py:348-357.
+//
+// HBM-bound: one wavefront per row, 16-byte loads (8 bf16 per lane per pass), fp32 statistics via
+// 64-lane butterfly reductions, no LDS.  Backward re-reads x and dy once, writes dx once, and
+// accumulates dgamma/dbeta per block in registers -> LDS -> one atomicAdd per column per block.
+#include "common.h"
+#include "espresso_amd.h"
+
+namespace {
+
+constexpr int MAXC8 = 4;  // supports C <= 64*8*4 = 2048
+
+// rows are processed one per wave. C % 8 == 0 required.
+__global__ __launch_bounds__(256) void ln_fwd_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C,
+    float eps, const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C >> 3;  // 16-byte chunks per row
+  float v[MAXC8][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][2 * e] = __uint_as_float(w[e] << 16);
+        v[i][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        s += v[i][2 * e] + v[i][2 * e + 1];
+      }
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  const bool zero = row_zero && row_zero[row];
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = ch * 8 + e;
+        float t = (v[i][e] - mean) * rstd * gamma[c] + beta[c];
+        if (thr) t *= ea_keep(seed, (uint64_t)row * C + c, thr, inv_keep);
+        o[e] = zero ? 0.f : t;
+      }
+      uint4 u;
+      u.x = pack_bf2(o[0], o[1]);
+      u.y = pack_bf2(o[2], o[3]);
+      u.z = pack_bf2(o[4], o[5]);
+      u.w = pack_bf2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(y + (long)row * C + ch * 8) = u;
+    }
+  }
+}
+
+// Each block owns ROWS_PER_BLOCK consecutive rows (4 waves round-robin), accumulates dgamma/dbeta
+// partials per lane-column, reduces across the 4 waves through LDS and issues atomics.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int rows_per_block,
+    const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep,
+    const bf16_t* __restrict__ dx_add) {
+  extern __shared__ float red[];  // [4][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float dg[MAXC8][8], db[MAXC8][8];
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = 0.f;
+
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const bool zero = row_zero && row_zero[row];
+    float xh[MAXC8][8], g[MAXC8][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC8; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
+        const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * C + ch * 8);
+        const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
+        const uint32_t wd[4] = {ud.x, ud.y, ud.z, ud.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = ch * 8 + e;
+          const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
+          float dv = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
+          if (zero) dv = 0.f;
+          if (thr) dv *= ea_keep(seed, (uint64_t)row * C + c, thr, inv_keep);
+          const float h = (xv - mean) * rstd;
+          xh[i][e] = h;
+          dg[i][e] += dv * h;
+          db[i][e] += dv;
+          const float gv = dv * gamma[c];
+          g[i][e] = gv;
+          s1 += gv;
+          s2 += gv * h;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < MAXC8; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+        if (dx_add) {
+          const uint4 ua = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
+          const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o[e] += (e & 1) ? __uint_as_float(wa[e >> 1] & 0xffff0000u) : __uint_as_float(wa[e >> 1] << 16);
+        }
+        uint4 u;
+        u.x = pack_bf2(o[0], o[1]);
+        u.y = pack_bf2(o[2], o[3]);
+        u.z = pack_bf2(o[4], o[5]);
+        u.w = pack_bf2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(dx + (long)row * C + ch * 8) = u;
+      }
+    }
+  }
+  // cross-wave reduction of dgamma/dbeta
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * C + ch * 8 + e] = dg[i][e];
+        red[(wave * 2 + 1) * C + ch * 8 + e] = db[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[(w * 2 + 0) * C + c];
+      b += red[(w * 2 + 1) * C + c];
+    }
+    atomicAdd(dgamma + c, a);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
+}  // namespace
+
+extern "C" int ea_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                                float* mean, float* rstd, int M, int C, float eps,
+                                const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                                float drop_scale, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 8 != 0 || C > 64 * 8 * MAXC8) return -2;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, stream,
+                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps, row_zero,
+                     drop_seed, drop_thr, drop_scale);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean,
+                                const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C,
+                                const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                                float drop_scale, const void* dx_add, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 8 != 0 || C > 64 * 8 * MAXC8) return -2;
+  // ~2048 blocks max so the atomics stay cheap while the chip is filled
+  int rpb = (M + 2047) / 2048;
+  rpb = ((rpb + 3) / 4) * 4;
+  if (rpb < 4) rpb = 4;
+  const int nblk = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,
+                     (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta,
+                     M, C, rpb, row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add);
+  return EA_CHECK_LAUNCH();
+}

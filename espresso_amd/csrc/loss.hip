@@ -1,0 +1,328 @@
+// Loss kernels for gfx950: fp32 log-softmax, CTC forward-backward, label-smoothed cross-entropy.
+//
+// CTC — reference: espresso/criterions/ctc_loss.py:59-100 -> torch.nn.functional.ctc_loss with
+//   blank = index of "<s>" (0), reduction="sum", zero_infinity, cuDNN disabled (:85) i.e. ATen's
+//   native alpha/beta recursion over log_softmax(logits.float())
+//   (espresso/models/transformer/speech_transformer_encoder_model.py:141-150).
+// Label-smoothed CE — reference: espresso/criterions/label_smoothed_cross_entropy_v2.py:94-119
+//   (uniform smoothing: eps_i = eps/(V-1), loss = (1-eps-eps_i)*nll + eps_i*smooth, pad rows zeroed).
+//
+// CTC design: the loss is a tiny part of the flops but touches the (T',B,V) posteriors, so it is
+// organised around HBM traffic: (1) log-softmax writes lprobs once; (2) a fully parallel gather
+// pulls the 2U+1 needed columns per frame into a compact lattice G[b][t][s]; (3) one workgroup per
+// utterance runs the alpha scan and the beta scan CONCURRENTLY (two halves of the workgroup, one
+// state per lane, lattice rows double-buffered in LDS, next rows prefetched); (4) one workgroup
+// per frame turns alpha+beta into d(loss)/d(logits) by building the sparse posterior row in LDS
+// and streaming exp(lprobs) once — no dense gradient-of-lprobs tensor, no global atomics.
+#include "common.h"
+#include "espresso_amd.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// log_softmax over the last dim: in [M][ld_in] (fp32 or bf16) -> out fp32 [M][V]
+template <typename TIn>
+__global__ __launch_bounds__(256) void log_softmax_kernel(const TIn* __restrict__ in, long ld_in,
+                                                          float* __restrict__ out, int V) {
+  __shared__ float sm[16];
+  const long row = blockIdx.x;
+  const TIn* x = in + row * ld_in;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float v;
+    if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max(mx, sm);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float v;
+    if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
+    s += expf(v - mx);
+  }
+  s = block_sum(s, sm);
+  const float lse = mx + logf(s);
+  float* o = out + row * (long)V;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float v;
+    if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
+    o[c] = v - lse;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CTC.  lprobs [B][T][V] fp32 ; targets [B][Lmax] int32 ; in_len[B], tgt_len[B]
+// lattice buffers G, A(lpha), Bt(beta): [B][T][Smax] fp32, Smax = 2*Lmax+1
+__device__ __forceinline__ int ctc_label(const int* tg, int s, int blank) { return (s & 1) ? tg[s >> 1] : blank; }
+
+__global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict__ lprobs, const int* __restrict__ targets,
+                                                         const int* __restrict__ in_len, const int* __restrict__ tgt_len,
+                                                         float* __restrict__ G, int T, int V, int Lmax, int blank) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  if (t >= in_len[b]) return;
+  const int S = 2 * tgt_len[b] + 1, Smax = 2 * Lmax + 1;
+  const float* lp = lprobs + ((long)b * T + t) * V;
+  const int* tg = targets + (long)b * Lmax;
+  float* g = G + ((long)b * T + t) * Smax;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) g[s] = lp[ctc_label(tg, s, blank)];
+}
+
+// blockDim = 2*SP (SP = Smax rounded up to 64).  threads [0,SP): alpha ; [SP,2SP): beta.
+__global__ void ctc_scan_kernel(const float* __restrict__ G, const int* __restrict__ targets,
+                                const int* __restrict__ in_len, const int* __restrict__ tgt_len,
+                                float* __restrict__ A, float* __restrict__ Bt, float* __restrict__ nll_out,
+                                int T, int Lmax, int blank, int SP) {
+  extern __shared__ float sh[];  // [2 dir][2 buf][SP + 2]
+  const int b = blockIdx.x;
+  const int Tb = in_len[b], L = tgt_len[b];
+  const int S = 2 * L + 1, Smax = 2 * Lmax + 1;
+  const int dir = threadIdx.x >= SP ? 1 : 0;
+  const int s = threadIdx.x - dir * SP;
+  float* buf0 = sh + (dir * 2 + 0) * (SP + 2) + (dir ? 0 : 2);  // alpha reads s-1,s-2 ; beta reads s+1,s+2
+  float* buf1 = sh + (dir * 2 + 1) * (SP + 2) + (dir ? 0 : 2);
+  const int* tg = targets + (long)b * Lmax;
+  if (Tb <= 0) {
+    if (threadIdx.x == 0) nll_out[b] = (L == 0) ? 0.f : INFINITY;
+    return;
+  }
+  // skip transition allowed?  alpha: from s-2 if label(s) != blank and != label(s-2)
+  //                           beta : to   s+2 if label(s+2) != blank and != label(s)
+  bool skip = false;
+  if (s < S) {
+    if (!dir) { if ((s & 1) && s >= 2) skip = tg[s >> 1] != tg[(s >> 1) - 1]; }
+    else      { if ((s & 1) && s + 2 < S) skip = tg[(s >> 1) + 1] != tg[s >> 1]; }
+  }
+  // pads of the LDS rows are -inf
+  if (threadIdx.x < 2) {
+    sh[(0 * 2 + 0) * (SP + 2) + threadIdx.x] = -INFINITY;
+    sh[(0 * 2 + 1) * (SP + 2) + threadIdx.x] = -INFINITY;
+    sh[(1 * 2 + 0) * (SP + 2) + SP + threadIdx.x] = -INFINITY;
+    sh[(1 * 2 + 1) * (SP + 2) + SP + threadIdx.x] = -INFINITY;
+  }
+  const float* Gb = G + (long)b * T * Smax;
+  float* Ob = (dir ? Bt : A) + (long)b * T * Smax;
+  // t = first frame of this direction
+  int t = dir ? Tb - 1 : 0;
+  const int step = dir ? -1 : 1;
+  float cur;
+  {
+    float v = -INFINITY;
+    if (s < S) {
+      const float lp = Gb[(long)t * Smax + s];
+      if (!dir) { if (s == 0 || s == 1) v = lp; }
+      else      { if (s == S - 1 || s == S - 2) v = lp; }
+    }
+    cur = v;
+    buf0[s] = v;
+    if (s < S) Ob[(long)t * Smax + s] = v;
+  }
+  float lp_next = -INFINITY;
+  if (Tb > 1 && s < S) lp_next = Gb[(long)(t + step) * Smax + s];
+  __syncthreads();
+  float* rd = buf0;
+  float* wr = buf1;
+  for (int it = 1; it < Tb; ++it) {
+    t += step;
+    const float lp = lp_next;
+    if (it + 1 < Tb && s < S) lp_next = Gb[(long)(t + step) * Smax + s];
+    float v = -INFINITY;
+    if (s < S) {
+      const float a0 = rd[s];
+      const float a1 = dir ? rd[s + 1] : rd[s - 1];
+      const float a2 = skip ? (dir ? rd[s + 2] : rd[s - 2]) : -INFINITY;
+      const float m = fmaxf(a0, fmaxf(a1, a2));
+      if (m > -INFINITY) v = m + logf(expf(a0 - m) + expf(a1 - m) + expf(a2 - m)) + lp;
+      Ob[(long)t * Smax + s] = v;
+    }
+    wr[s] = v;
+    cur = v;
+    __syncthreads();
+    float* tmp = rd; rd = wr; wr = tmp;
+  }
+  (void)cur;
+  if (threadIdx.x == 0) {
+    // alpha direction finished at t = Tb-1 in rd (threads of dir 0)
+    const float l1 = rd[S - 1];
+    const float l2 = S >= 2 ? rd[S - 2] : -INFINITY;
+    const float m = fmaxf(l1, l2);
+    nll_out[b] = (m == -INFINITY) ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+  }
+}
+
+// One block per (t, b): dlogits[b,t,:] = scale * ( exp(lp)*sumpost - post_by_class )  (bf16 or fp32 out)
+template <typename TOut>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lprobs, const float* __restrict__ G,
+                                                       const float* __restrict__ A, const float* __restrict__ Bt,
+                                                       const float* __restrict__ nll, const int* __restrict__ targets,
+                                                       const int* __restrict__ in_len, const int* __restrict__ tgt_len,
+                                                       TOut* __restrict__ dlogits, long ld_out, int T, int V, int Lmax,
+                                                       int blank, float scale, const float* __restrict__ scale_dev,
+                                                       int zero_infinity) {
+  extern __shared__ float post[];  // [V]
+  __shared__ float sm[16];
+  const int b = blockIdx.y, t = blockIdx.x;
+  TOut* out = dlogits + ((long)b * T + t) * ld_out;
+  const float nl = nll[b];
+  if (scale_dev) scale *= scale_dev[0];
+  const bool dead = t >= in_len[b] || (zero_infinity && !(nl < INFINITY));
+  for (int c = V + threadIdx.x; c < ld_out; c += 256) {
+    if constexpr (sizeof(TOut) == 2) out[c] = 0; else out[c] = 0.f;
+  }
+  if (dead) {
+    for (int c = threadIdx.x; c < V; c += 256) {
+      if constexpr (sizeof(TOut) == 2) out[c] = 0; else out[c] = 0.f;
+    }
+    return;
+  }
+  for (int c = threadIdx.x; c < V; c += 256) post[c] = 0.f;
+  __syncthreads();
+  const int S = 2 * tgt_len[b] + 1, Smax = 2 * Lmax + 1;
+  const long lo = ((long)b * T + t) * Smax;
+  const int* tg = targets + (long)b * Lmax;
+  float part = 0.f, blank_part = 0.f;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const float ab = A[lo + s] + Bt[lo + s];
+    // alpha and beta both include the emission at t -> subtract it once
+    const float p = (ab == -INFINITY) ? 0.f : expf(ab + nl - G[lo + s]);
+    part += p;
+    if (s & 1) atomicAdd(&post[tg[s >> 1]], p); else blank_part += p;
+  }
+  const float sumpost = block_sum(part, sm);
+  const float bsum = block_sum(blank_part, sm);
+  if (threadIdx.x == 0) post[blank] += bsum;
+  __syncthreads();
+  const float* lp = lprobs + ((long)b * T + t) * V;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float g = scale * (expf(lp[c]) * sumpost - post[c]);
+    if constexpr (sizeof(TOut) == 2) out[c] = f2bf(g); else out[c] = g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Label-smoothed CE (uniform).  logits [M][ld] (bf16 or fp32), target[M] int64-as-int32 pairs -> we take int32.
+// out_loss[0] += sum loss, out_loss[1] += sum nll ; optional dlogits = scale * dloss/dlogits ; optional lprobs
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void lsce_kernel(const TIn* __restrict__ logits, long ld, const int* __restrict__ target,
+                                                   float* __restrict__ out_loss, TOut* __restrict__ dlogits, long ld_out,
+                                                   int V, int pad_idx, float eps, float scale) {
+  __shared__ float sm[16];
+  const long row = blockIdx.x;
+  const TIn* x = logits + row * ld;
+  const int tgt = target[row];
+  TOut* dl = dlogits ? dlogits + row * ld_out : nullptr;
+  if (tgt == pad_idx) {
+    if (dl) for (int c = threadIdx.x; c < V; c += 256) { if constexpr (sizeof(TOut) == 2) dl[c] = 0; else dl[c] = 0.f; }
+    return;
+  }
+  float mx = -INFINITY, tot = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float v; if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
+    mx = fmaxf(mx, v);
+    tot += v;
+  }
+  mx = block_max(mx, sm);
+  tot = block_sum(tot, sm);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float v; if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
+    s += expf(v - mx);
+  }
+  s = block_sum(s, sm);
+  const float lse = mx + logf(s);
+  float xt; if constexpr (sizeof(TIn) == 2) xt = bf2f(x[tgt]); else xt = x[tgt];
+  const float nll = lse - xt;
+  const float smooth = (float)V * lse - tot;  // -sum_c lprob_c
+  const float eps_i = eps / (float)(V - 1);
+  const float wn = 1.f - eps - eps_i;
+  if (threadIdx.x == 0) {
+    atomicAdd(out_loss + 0, wn * nll + eps_i * smooth);
+    atomicAdd(out_loss + 1, nll);
+  }
+  if (dl) {
+    const float k = wn + eps_i * (float)V;
+    for (int c = threadIdx.x; c < V; c += 256) {
+      float v; if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
+      float g = expf(v - lse) * k - eps_i - (c == tgt ? wn : 0.f);
+      g *= scale;
+      if constexpr (sizeof(TOut) == 2) dl[c] = f2bf(g); else dl[c] = g;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ea_log_softmax_f32(const float* in, long ld_in, float* out, long M, int V, hipStream_t stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL((log_softmax_kernel<float>), dim3((unsigned)M), dim3(256), 0, stream, in, ld_in, out, V);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_log_softmax_bf16(const void* in, long ld_in, float* out, long M, int V, hipStream_t stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL((log_softmax_kernel<bf16_t>), dim3((unsigned)M), dim3(256), 0, stream, (const bf16_t*)in, ld_in, out, V);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" long ea_ctc_workspace_bytes(int B, int T, int Lmax) {
+  return 3L * B * T * (2L * Lmax + 1) * (long)sizeof(float);
+}
+
+extern "C" int ea_ctc_loss(const float* lprobs, const int* targets, const int* in_len, const int* tgt_len,
+                           float* nll /*[B]*/, void* workspace, int B, int T, int V, int Lmax, int blank,
+                           hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (T <= 0 || V <= 0 || Lmax < 0) return -2;
+  const int Smax = 2 * Lmax + 1;
+  const int SP = ((Smax + 63) / 64) * 64;
+  if (2 * SP > 1024) return -3;  // Lmax <= 255 (max_target_positions 200 in the recipes)
+  float* G = (float*)workspace;
+  float* A = G + (long)B * T * Smax;
+  float* Bt = A + (long)B * T * Smax;
+  hipLaunchKernelGGL(ctc_gather_kernel, dim3(T, B), dim3(256), 0, stream, lprobs, targets, in_len, tgt_len, G, T, V,
+                     Lmax, blank);
+  hipLaunchKernelGGL(ctc_scan_kernel, dim3(B), dim3(2 * SP), (size_t)4 * (SP + 2) * sizeof(float), stream, G, targets,
+                     in_len, tgt_len, A, Bt, nll, T, Lmax, blank, SP);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_ctc_grad(const float* lprobs, const void* workspace, const float* nll, const int* targets,
+                           const int* in_len, const int* tgt_len, void* dlogits, long ld_out, int dlogits_bf16, int B,
+                           int T, int V, int Lmax, int blank, float grad_scale, const float* grad_scale_dev,
+                           int zero_infinity, hipStream_t stream) {
+  if (B <= 0) return 0;
+  const int Smax = 2 * Lmax + 1;
+  const float* G = (const float*)workspace;
+  const float* A = G + (long)B * T * Smax;
+  const float* Bt = A + (long)B * T * Smax;
+  if (dlogits_bf16)
+    hipLaunchKernelGGL((ctc_grad_kernel<bf16_t>), dim3(T, B), dim3(256), (size_t)V * sizeof(float), stream, lprobs, G, A,
+                       Bt, nll, targets, in_len, tgt_len, (bf16_t*)dlogits, ld_out, T, V, Lmax, blank, grad_scale,
+                       grad_scale_dev, zero_infinity);
+  else
+    hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(T, B), dim3(256), (size_t)V * sizeof(float), stream, lprobs, G, A,
+                       Bt, nll, targets, in_len, tgt_len, (float*)dlogits, ld_out, T, V, Lmax, blank, grad_scale,
+                       grad_scale_dev, zero_infinity);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_label_smoothed_ce(const void* logits, long ld, int logits_bf16, const int* target,
+                                    float* out_loss /*[2] zeroed*/, void* dlogits, long ld_out, int dlogits_bf16, long M,
+                                    int V, int pad_idx, float eps, float grad_scale, hipStream_t stream) {
+  if (M <= 0) return 0;
+  dim3 g((unsigned)M), blk(256);
+  if (logits_bf16) {
+    if (dlogits_bf16 || !dlogits)
+      hipLaunchKernelGGL((lsce_kernel<bf16_t, bf16_t>), g, blk, 0, stream, (const bf16_t*)logits, ld, target, out_loss,
+                         (bf16_t*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
+    else
+      hipLaunchKernelGGL((lsce_kernel<bf16_t, float>), g, blk, 0, stream, (const bf16_t*)logits, ld, target, out_loss,
+                         (float*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
+  } else {
+    if (dlogits_bf16 && dlogits)
+      hipLaunchKernelGGL((lsce_kernel<float, bf16_t>), g, blk, 0, stream, (const float*)logits, ld, target, out_loss,
+                         (bf16_t*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
+    else
+      hipLaunchKernelGGL((lsce_kernel<float, float>), g, blk, 0, stream, (const float*)logits, ld, target, out_loss,
+                         (float*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
+  }
+  return EA_CHECK_LAUNCH();
+}

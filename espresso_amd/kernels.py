@@ -1,0 +1,403 @@
+"""Thin, typed Python wrappers over the C ABI (include/espresso_amd.h).
+
+Every function takes CUDA(=HIP) torch tensors, checks dtype/contiguity, and launches the HIP kernel
+on torch's current stream.  torch is used here ONLY for device memory and streams.  Nothing in this
+module computes on the host and nothing falls back to eager PyTorch: a missing library or a CPU
+tensor raises.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EaGemmParams, check
+
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+_ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "swish": 2}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("espresso_amd kernels need device tensors (no CPU path)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def drop_params(p: float):
+    """(threshold, keep-scale) for dropout probability p as the kernels expect them."""
+    if p <= 0.0:
+        return 0, 1.0
+    thr = min(int(p * 4294967296.0), 4294967295)
+    return thr, 1.0 / (1.0 - p)
+
+
+def gemm(
+    A: torch.Tensor,
+    B: torch.Tensor,
+    C: torch.Tensor,
+    M: int,
+    N: int,
+    K: int,
+    *,
+    lda: int,
+    ldb: int,
+    ldc: int,
+    a_kstrided: bool = False,
+    b_kstrided: bool = False,
+    batch: int = 1,
+    zdiv: int = 1,
+    sA=(0, 0),
+    sB=(0, 0),
+    sC=(0, 0),
+    a_off: int = 0,
+    b_off: int = 0,
+    c_off: int = 0,
+    bias: Optional[torch.Tensor] = None,
+    act=None,
+    alpha: float = 1.0,
+    out_scale: float = 1.0,
+    resid: Optional[torch.Tensor] = None,
+    ldr: int = 0,
+    sR=(0, 0),
+    r_off: int = 0,
+    C2: Optional[torch.Tensor] = None,
+    ldc2: int = 0,
+    aux: Optional[torch.Tensor] = None,
+    ldaux: int = 0,
+    sX=(0, 0),
+    accumulate: bool = False,
+    drop_p: float = 0.0,
+    drop_seed: int = 0,
+):
+    """C[z][m][n] = epi(alpha * sum_k A(z;m,k) B(z;n,k)).  Offsets (a_off, ...) are in elements."""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
+    assert C.dtype in (torch.bfloat16, torch.float32)
+    p = EaGemmParams()
+    p.A = A.data_ptr() + 2 * a_off
+    p.B = B.data_ptr() + 2 * b_off
+    p.C = C.data_ptr() + C.element_size() * c_off
+    p.C2 = (C2.data_ptr() + 2 * c_off) if C2 is not None else None
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        p.bias = bias.data_ptr()
+    if resid is not None:
+        assert resid.dtype in (torch.bfloat16, torch.float32)
+        p.resid = resid.data_ptr() + resid.element_size() * r_off
+        p.resid_f32 = 1 if resid.dtype == torch.float32 else 0
+    if aux is not None:
+        assert aux.dtype == torch.bfloat16
+        p.aux = aux.data_ptr()
+    p.M, p.N, p.K, p.batch, p.zdiv = M, N, K, batch, zdiv
+    p.a_kstrided, p.b_kstrided = int(a_kstrided), int(b_kstrided)
+    p.c_f32 = 1 if C.dtype == torch.float32 else 0
+    p.accumulate = int(accumulate)
+    p.act = _ACT[act] if not isinstance(act, int) else act
+    p.lda, p.ldb, p.ldc, p.ldc2, p.ldr, p.ldaux = lda, ldb, ldc, ldc2, ldr, ldaux
+    p.sA_hi, p.sA_lo = sA
+    p.sB_hi, p.sB_lo = sB
+    p.sC_hi, p.sC_lo = sC
+    p.sR_hi, p.sR_lo = sR
+    p.sX_hi, p.sX_lo = sX
+    p.alpha, p.out_scale = alpha, out_scale
+    thr, scale = drop_params(drop_p)
+    p.drop_seed, p.drop_thr, p.drop_scale = drop_seed, thr, scale
+    check(_lib.lib().ea_gemm_bf16(ctypes.byref(p), _stream()), "ea_gemm_bf16")
+    return C
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, row_zero=None, drop_p=0.0, drop_seed=0, save_stats=True):
+    M, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    thr, scale = drop_params(drop_p)
+    check(
+        _lib.lib().ea_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, C, eps, _p(row_zero),
+                                    drop_seed, thr, scale, _stream()),
+        "ea_layernorm_fwd",
+    )
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgamma, dbeta, row_zero=None, drop_p=0.0, drop_seed=0, dx_add=None):
+    M, C = x.shape
+    assert dy.is_contiguous() and dy.dtype == torch.bfloat16
+    dx = torch.empty_like(x)
+    thr, scale = drop_params(drop_p)
+    check(
+        _lib.lib().ea_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), M, C,
+                                    _p(row_zero), drop_seed, thr, scale, _p(dx_add), _stream()),
+        "ea_layernorm_bwd",
+    )
+    return dx
+
+
+def cast_f32_to_bf16(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().ea_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "ea_cast_f32_to_bf16")
+    return dst
+
+
+def cast_bf16_to_f32(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(_lib.lib().ea_cast_bf16_to_f32(_p(src), _p(dst), src.numel(), _stream()), "ea_cast_bf16_to_f32")
+    return dst
+
+
+def scale_dropout(x, a=1.0, y=None, b=0.0, drop_p=0.0, drop_seed=0, out=None):
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    thr, scale = drop_params(drop_p)
+    check(_lib.lib().ea_scale_dropout_bf16(_p(x), _p(y), _p(out), x.numel(), a, b, drop_seed, thr, scale, _stream()),
+          "ea_scale_dropout_bf16")
+    return out
+
+
+def colsum(X, out, M, N, ld):
+    """out[n] += sum_m X[m*ld + n]  (fp32 accumulate into `out`)."""
+    assert X.dtype == torch.bfloat16 and out.dtype == torch.float32
+    check(_lib.lib().ea_colsum_bf16(_p(X), _p(out), M, N, ld, _stream()), "ea_colsum_bf16")
+    return out
+
+
+def colsum_ptr(X_ptr: int, out, M, N, ld):
+    check(_lib.lib().ea_colsum_bf16(ctypes.c_void_p(X_ptr), _p(out), M, N, ld, _stream()), "ea_colsum_bf16")
+    return out
+
+
+def zero_rows(x, row_zero):
+    M, C = x.shape
+    check(_lib.lib().ea_zero_rows_bf16(_p(x), _p(row_zero), M, C, _stream()), "ea_zero_rows_bf16")
+    return x
+
+
+def relpos_q_prep(qkv, ldq, u, v, M, C, scaling, want_qv=True):
+    qu = torch.empty(M, C, dtype=torch.bfloat16, device=qkv.device)
+    qv = torch.empty(M, C, dtype=torch.bfloat16, device=qkv.device) if want_qv else None
+    check(_lib.lib().ea_relpos_q_prep(_p(qkv), ldq, _p(u), _p(v), _p(qu), _p(qv), M, C, scaling, _stream()),
+          "ea_relpos_q_prep")
+    return qu, qv
+
+
+def relpos_softmax_fwd(ac, bd, key_len, attn_mask, H, B, T, S, ld_ac, ld_bd, ld_p, causal=False, drop_p=0.0,
+                       drop_seed=0):
+    P = torch.empty(H * B * T, ld_p, dtype=torch.bfloat16, device=ac.device)
+    Pd = torch.empty_like(P) if drop_p > 0 else None
+    thr, scale = drop_params(drop_p)
+    check(
+        _lib.lib().ea_relpos_softmax_fwd(_p(ac), _p(bd), _p(key_len), _p(attn_mask), _p(P), _p(Pd), H, B, T, S, ld_ac,
+                                         ld_bd, ld_p, int(causal), drop_seed, thr, scale, _stream()),
+        "ea_relpos_softmax_fwd",
+    )
+    return P, (Pd if Pd is not None else P)
+
+
+def relpos_softmax_bwd(P, dPd, H, B, T, S, ld_p, ld_dp, ld_bd, want_bd=True, drop_p=0.0, drop_seed=0):
+    dAC = torch.empty(H * B * T, ld_p, dtype=torch.bfloat16, device=P.device)
+    dBD = torch.empty(H * B * T, ld_bd, dtype=torch.bfloat16, device=P.device) if want_bd else None
+    thr, scale = drop_params(drop_p)
+    check(
+        _lib.lib().ea_relpos_softmax_bwd(_p(P), _p(dPd), _p(dAC), _p(dBD), H, B, T, S, ld_p, ld_dp, ld_bd, drop_seed,
+                                         thr, scale, _stream()),
+        "ea_relpos_softmax_bwd",
+    )
+    return dAC, dBD
+
+
+def add2_strided(a, lda, b, ldb, out, ldo, M, C, out_off=0):
+    check(
+        _lib.lib().ea_add2_strided_bf16(_p(a), lda, _p(b), ldb, ctypes.c_void_p(out.data_ptr() + 2 * out_off), ldo, M,
+                                        C, _stream()),
+        "ea_add2_strided_bf16",
+    )
+    return out
+
+
+def glu_dwconv_fwd(Y, w, B, T, C, KW, stats):
+    U = torch.empty(B * T, C, dtype=torch.bfloat16, device=Y.device)
+    Z = torch.empty(B * T, C, dtype=torch.bfloat16, device=Y.device)
+    check(_lib.lib().ea_glu_dwconv_fwd(_p(Y), _p(w), _p(U), _p(Z), _p(stats), B, T, C, KW, _stream()),
+          "ea_glu_dwconv_fwd")
+    return U, Z
+
+
+def bn_finalize(stats, C, n, eps, momentum, running_mean=None, running_var=None):
+    mean_rstd = torch.empty(2, C, dtype=torch.float32, device=stats.device)
+    check(_lib.lib().ea_bn_finalize(_p(stats), _p(mean_rstd), _p(running_mean), _p(running_var), C, float(n), eps,
+                                    momentum, _stream()), "ea_bn_finalize")
+    return mean_rstd
+
+
+def bn_from_running(running_mean, running_var, eps):
+    C = running_mean.numel()
+    mean_rstd = torch.empty(2, C, dtype=torch.float32, device=running_mean.device)
+    check(_lib.lib().ea_bn_from_running(_p(running_mean), _p(running_var), _p(mean_rstd), C, eps, _stream()),
+          "ea_bn_from_running")
+    return mean_rstd
+
+
+def bn_act_fwd(Z, mean_rstd, gamma, beta, act):
+    M, C = Z.shape
+    H = torch.empty_like(Z)
+    check(_lib.lib().ea_bn_act_fwd(_p(Z), _p(mean_rstd), _p(gamma), _p(beta), _p(H), M, C, _ACT[act], _stream()),
+          "ea_bn_act_fwd")
+    return H
+
+
+def bn_act_bwd(Z, dH, mean_rstd, gamma, beta, dgamma, dbeta, act, training=True):
+    M, C = Z.shape
+    red = torch.zeros(2, C, dtype=torch.float32, device=Z.device)
+    dZ = torch.empty_like(Z)
+    check(
+        _lib.lib().ea_bn_act_bwd(_p(Z), _p(dH), _p(mean_rstd), _p(gamma), _p(beta), _p(red), _p(dZ), _p(dgamma),
+                                 _p(dbeta), M, C, _ACT[act], int(training), _stream()),
+        "ea_bn_act_bwd",
+    )
+    return dZ
+
+
+def glu_dwconv_bwd(dZ, Y, U, w, dw, B, T, C, KW):
+    dY = torch.empty(B * T, 2 * C, dtype=torch.bfloat16, device=Y.device)
+    check(_lib.lib().ea_glu_dwconv_bwd(_p(dZ), _p(Y), _p(U), _p(w), _p(dY), _p(dw), B, T, C, KW, _stream()),
+          "ea_glu_dwconv_bwd")
+    return dY
+
+
+def conv1_fwd(X, W, bias, B, T, F, CO, sy, sx, stats):
+    To, Fo = (T - 1) // sy + 1, (F - 1) // sx + 1
+    Z = torch.empty(B * To * Fo, CO, dtype=torch.bfloat16, device=X.device)
+    check(_lib.lib().ea_conv1_fwd(_p(X), _p(W), _p(bias), _p(Z), _p(stats), B, T, F, CO, sy, sx, _stream()),
+          "ea_conv1_fwd")
+    return Z
+
+
+def conv1_wgrad(X, dZ, dW, dbias, B, T, F, CO, sy, sx):
+    check(_lib.lib().ea_conv1_wgrad(_p(X), _p(dZ), _p(dW), _p(dbias), B, T, F, CO, sy, sx, _stream()), "ea_conv1_wgrad")
+
+
+def im2col3x3(A, B, T, F, C, sy, sx):
+    To, Fo = (T - 1) // sy + 1, (F - 1) // sx + 1
+    col = torch.empty(B * To * Fo, 9 * C, dtype=torch.bfloat16, device=A.device)
+    check(_lib.lib().ea_im2col3x3(_p(A), _p(col), B, T, F, C, sy, sx, _stream()), "ea_im2col3x3")
+    return col
+
+
+def col2im3x3(dcol, B, T, F, C, sy, sx):
+    dA = torch.empty(B * T * F, C, dtype=torch.bfloat16, device=dcol.device)
+    check(_lib.lib().ea_col2im3x3(_p(dcol), _p(dA), B, T, F, C, sy, sx, _stream()), "ea_col2im3x3")
+    return dA
+
+
+def colstats(X, stats):
+    M, C = X.shape
+    check(_lib.lib().ea_colstats_bf16(_p(X), _p(stats), M, C, _stream()), "ea_colstats_bf16")
+    return stats
+
+
+def log_softmax(x, M, V, ld):
+    out = torch.empty(M, V, dtype=torch.float32, device=x.device)
+    if x.dtype == torch.float32:
+        check(_lib.lib().ea_log_softmax_f32(_p(x), ld, _p(out), M, V, _stream()), "ea_log_softmax_f32")
+    else:
+        assert x.dtype == torch.bfloat16
+        check(_lib.lib().ea_log_softmax_bf16(_p(x), ld, _p(out), M, V, _stream()), "ea_log_softmax_bf16")
+    return out
+
+
+def ctc_loss_fwd(lprobs, targets, in_len, tgt_len, B, T, V, Lmax, blank):
+    """lprobs fp32 [B][T][V] -> (nll[B], workspace holding the gathered lattice + alpha + beta)."""
+    assert lprobs.dtype == torch.float32 and lprobs.is_contiguous()
+    assert targets.dtype == torch.int32 and in_len.dtype == torch.int32 and tgt_len.dtype == torch.int32
+    dev = lprobs.device
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(_lib.lib().ea_ctc_workspace_bytes(B, T, Lmax)), dtype=torch.uint8, device=dev)
+    check(
+        _lib.lib().ea_ctc_loss(_p(lprobs), _p(targets), _p(in_len), _p(tgt_len), _p(nll), _p(ws), B, T, V, Lmax, blank,
+                               _stream()),
+        "ea_ctc_loss",
+    )
+    return nll, ws
+
+
+def ctc_loss_grad(lprobs, ws, nll, targets, in_len, tgt_len, B, T, V, Lmax, blank, ld_out=None, grad_bf16=True,
+                  grad_scale=1.0, grad_scale_dev=None, zero_infinity=True):
+    ld_out = V if ld_out is None else ld_out
+    dl = torch.empty(B * T, ld_out, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=lprobs.device)
+    check(
+        _lib.lib().ea_ctc_grad(_p(lprobs), _p(ws), _p(nll), _p(targets), _p(in_len), _p(tgt_len), _p(dl), ld_out,
+                               int(grad_bf16), B, T, V, Lmax, blank, grad_scale, _p(grad_scale_dev),
+                               int(zero_infinity), _stream()),
+        "ea_ctc_grad",
+    )
+    return dl
+
+
+def label_smoothed_ce(logits, ld, target, M, V, pad_idx, eps, want_grad=True, grad_bf16=True, grad_scale=1.0):
+    assert target.dtype == torch.int32
+    dev = logits.device
+    out = torch.zeros(2, dtype=torch.float32, device=dev)
+    dl = None
+    if want_grad:
+        dl = torch.empty(M, V, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=dev)
+    check(
+        _lib.lib().ea_label_smoothed_ce(_p(logits), ld, int(logits.dtype == torch.bfloat16), _p(target), _p(out),
+                                        _p(dl), V, int(grad_bf16), M, V, pad_idx, eps, grad_scale, _stream()),
+        "ea_label_smoothed_ce",
+    )
+    return out, dl
+
+
+def fbank_batch(wav, offsets, B, tables, cmvn_mean, cmvn_std, Tmax, nmel=80, frame_len=400, frame_shift=160,
+                preemph=0.97, log_floor=1.1920928955078125e-07, want_sum=True):
+    dev = wav.device
+    feat = torch.empty(B, Tmax, nmel, dtype=torch.float32, device=dev)
+    utt_sum = torch.zeros(B, dtype=torch.float32, device=dev) if want_sum else None
+    out_len = torch.empty(B, dtype=torch.int32, device=dev)
+    check(
+        _lib.lib().ea_fbank_batch(_p(wav), _p(offsets), B, _p(tables["window"]), _p(tables["twiddle"]),
+                                  _p(tables["mel_start"]), _p(tables["mel_len"]), _p(tables["mel_woff"]),
+                                  _p(tables["mel_w"]), _p(cmvn_mean), _p(cmvn_std), _p(feat), _p(utt_sum), _p(out_len),
+                                  Tmax, nmel, frame_len, frame_shift, preemph, log_floor, _stream()),
+        "ea_fbank_batch",
+    )
+    return feat, out_len, utt_sum
+
+
+def specaugment(feat, lengths, utt_sum, fmask, tmask, use_mean=True, mask_value=0.0):
+    B, Tmax, nmel = feat.shape
+    nf = fmask.shape[1] if fmask is not None else 0
+    nt = tmask.shape[1] if tmask is not None else 0
+    check(
+        _lib.lib().ea_specaugment(_p(feat), _p(lengths), _p(utt_sum), _p(fmask), _p(tmask), nf, nt, B, Tmax, nmel,
+                                  int(use_mean), mask_value, _stream()),
+        "ea_specaugment",
+    )
+    return feat
+
+
+def grad_sumsq(g, out):
+    check(_lib.lib().ea_grad_sumsq(_p(g), g.numel(), _p(out), _stream()), "ea_grad_sumsq")
+    return out
+
+
+def clip_coef(sumsq, pre_scale, max_norm, coef):
+    check(_lib.lib().ea_clip_coef(_p(sumsq), pre_scale, max_norm, _p(coef), _stream()), "ea_clip_coef")
+    return coef
+
+
+def adam_step(p, g, m, v, p_bf16, coef, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True):
+    check(
+        _lib.lib().ea_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(coef), lr, beta1, beta2, eps,
+                                weight_decay, step, int(zero_grad), _stream()),
+        "ea_adam_step",
+    )

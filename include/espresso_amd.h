@@ -1,0 +1,198 @@
+/* espresso_amd — C ABI of the MI355X (gfx950) hot path of freewym/espresso.
+ *
+ * The reference has no FFI on this path: its boundary is fairseq's Python plugin registry
+ * (SURVEY.md §8b), and all compute below it is ATen/cuDNN/torchaudio calls.  This header is the
+ * boundary this framework introduces UNDER that registry: one entry point per reference
+ * function on the hot path, plain device pointers + sizes + a HIP stream, no torch types.  The
+ * host-side mirror of the reference interface (espresso_amd/{data,modules,models,criterions,
+ * tasks,tools}) binds these through ctypes (espresso_amd/_lib.py); INTEGRATION.md shows the stub
+ * a reference maintainer would add.  Each declaration cites the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions: every function returns 0 on success, a negative value on a launch/argument
+ * error; all pointers are DEVICE pointers unless the name ends in _host; `stream` is a
+ * hipStream_t (0 = default stream); kernels are asynchronous with respect to the host.
+ * bf16 tensors are raw uint16 bit patterns.  "TBC" = (time, batch, channel) row-major.
+ */
+#ifndef ESPRESSO_AMD_H
+#define ESPRESSO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ea_stream_t;
+
+int ea_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense products (MFMA).  Replaces torch.nn.functional.linear / torch.bmm / conv1d(k=1) /
+ * im2col-conv2d calls at: fairseq/modules/conformer_layer.py:79-101,134-146;
+ * fairseq/modules/multihead_attention.py:650-688,788-831,884-907;
+ * espresso/models/transformer/speech_transformer_encoder.py:341-343;
+ * espresso/models/transformer/speech_transformer_encoder_model.py:207-208;
+ * espresso/modules/speech_convolutions.py:78-102.
+ *
+ *   C[z][m][n] = epi( alpha * sum_k A(z;m,k) * B(z;n,k) ),  z in [0,batch)
+ *   A(z;m,k) = A[(z/zdiv)*sA_hi + (z%zdiv)*sA_lo + (a_kstrided ? k*lda + m : m*lda + k)]  (bf16)
+ *   B likewise with n.                                                                    (bf16)
+ *   epi(v):  v += bias[n]
+ *            if aux:  v *= keep(drop) * act'(aux[m][n])                 (backward through act)
+ *            elif C2: C = bf16(v);  C2 = bf16(keep(drop) * act(v));     (two outputs) done
+ *            else:    v = keep(drop) * act(v)
+ *            v = v * out_scale + resid[m][n]
+ *            C = c_f32 ? (accumulate ? C + v : v) : bf16(v)
+ */
+enum { EA_ACT_NONE = 0, EA_ACT_RELU = 1, EA_ACT_SILU = 2 };
+
+typedef struct EaGemmParams {
+  const void* A;
+  const void* B;
+  void* C;
+  void* C2;           /* optional bf16 second output, leading dim ldc2, same batch offsets as C */
+  const float* bias;  /* [N] fp32 or NULL */
+  const void* resid;  /* bf16 (or fp32 if resid_f32) [M][ldr] or NULL */
+  const void* aux;    /* bf16 pre-activation [M][ldaux] or NULL */
+  int M, N, K, batch, zdiv;
+  int a_kstrided, b_kstrided, c_f32, accumulate, resid_f32, act;
+  long lda, ldb, ldc, ldc2, ldr, ldaux;
+  long sA_hi, sA_lo, sB_hi, sB_lo, sC_hi, sC_lo, sR_hi, sR_lo, sX_hi, sX_lo;
+  float alpha, out_scale;
+  /* dropout: element dropped when hash(seed, z*M*N + m*N + n) < drop_thr; kept * drop_scale */
+  uint64_t drop_seed;
+  uint32_t drop_thr;
+  float drop_scale;
+} EaGemmParams;
+
+int ea_gemm_bf16(const EaGemmParams* p, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused
+ * "dropout then zero padded rows" of espresso/models/transformer/speech_transformer_encoder.py:348-357.
+ * x,y,dy,dx: bf16 [M][C]; gamma,beta,mean,rstd,dgamma,dbeta: fp32.  row_zero: uint8 [M] or NULL.
+ * bwd accumulates (+=) into dgamma/dbeta; dx_add (bf16 [M][C] or NULL) is added to dx. */
+int ea_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     int M, int C, float eps, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                     float drop_scale, ea_stream_t stream);
+int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero,
+                     uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* dx_add,
+                     ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Streaming helpers (AMP weight cast fairseq/tasks/fairseq_task.py:516; FairseqDropout backward
+ * fairseq/modules/fairseq_dropout.py:23-25; nn.Linear bias gradient). */
+int ea_cast_f32_to_bf16(const float* src, void* dst, long n, ea_stream_t stream);
+int ea_cast_bf16_to_f32(const void* src, float* dst, long n, ea_stream_t stream);
+/* out = a*x*keep(idx) + b*y  (bf16; y may be NULL) */
+int ea_scale_dropout_bf16(const void* x, const void* y, void* out, long n, float a, float b, uint64_t seed,
+                          uint32_t thr, float inv_keep, ea_stream_t stream);
+/* out[n] += sum_m X[m*ld+n]  (X bf16, out fp32) */
+int ea_colsum_bf16(const void* X, float* out, int M, int N, long ld, ea_stream_t stream);
+int ea_zero_rows_bf16(void* x, const uint8_t* row_zero, int M, int C, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Relative-position attention glue — fairseq/modules/multihead_attention.py:679-688 (q+u, q+v,
+ * scaling), :788-831 (skew), :835-874 (masks, fp32 softmax, dropout).  Score tensors are
+ * [H][B][T][ld] fp32 (ac: ld_ac, bd: ld_bd >= T+S-1); probabilities bf16 [H][B][T][ld_p].
+ * bd == NULL: plain attention (decoder self/cross attention); causal != 0 adds the future mask
+ * (fairseq/models/transformer/transformer_decoder.py:386-398). */
+int ea_relpos_q_prep(const void* qkv, long ldq, const float* u, const float* v, void* qu, void* qv, int M,
+                     int C, float scaling, ea_stream_t stream);
+int ea_relpos_softmax_fwd(const float* ac, const float* bd, const int* key_len, const float* attn_mask, void* P,
+                          void* Pd, int H, int B, int T, int S, int ld_ac, int ld_bd, int ld_p, int causal,
+                          uint64_t drop_seed, uint32_t drop_thr, float drop_scale, ea_stream_t stream);
+int ea_relpos_softmax_bwd(const void* P, const float* dPd, void* dAC, void* dBD, int H, int B, int T, int S,
+                          int ld_p, int ld_dp, int ld_bd, uint64_t drop_seed, uint32_t drop_thr,
+                          float drop_scale, ea_stream_t stream);
+int ea_add2_strided_bf16(const void* a, long lda, const void* b, long ldb, void* out, long ldo, int M, int C,
+                         ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conformer convolution module middle — fairseq/modules/conformer_layer.py:79-101:
+ * GLU -> depthwise Conv1d (k in {3,7,15,31}, pad (k-1)/2, no bias) -> BatchNorm1d -> SiLU.
+ * Y: bf16 [B*T][2C] (pointwise_conv1 output); U,Z,H: bf16 [B*T][C]; w: fp32 [C][KW];
+ * stats/red: fp32 [2][C] zeroed by the caller; mean_rstd: fp32 [2][C].
+ * ea_bn_act_* are also used for BatchNorm2d+ReLU of the sub-sampler (act = EA_ACT_RELU). */
+int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z, float* stats, int B, int T, int C, int KW,
+                      ea_stream_t stream);
+int ea_bn_finalize(const float* stats, float* mean_rstd, float* running_mean, float* running_var, int C, float n,
+                   float eps, float momentum, ea_stream_t stream);
+int ea_bn_from_running(const float* running_mean, const float* running_var, float* mean_rstd, int C, float eps,
+                       ea_stream_t stream);
+int ea_bn_act_fwd(const void* Z, const float* mean_rstd, const float* gamma, const float* beta, void* H, long M,
+                  int C, int act, ea_stream_t stream);
+int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
+                  float* red, void* dZ, float* dgamma, float* dbeta, long M, int C, int act, int training,
+                  ea_stream_t stream);
+int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float* w, void* dY, float* dw, int B,
+                      int T, int C, int KW, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv2d sub-sampler — espresso/modules/speech_convolutions.py:78-102.  Channels-last bf16
+ * activations [B][T][F][C]; first conv (C_in=1) direct from fp32 features [B][T][F]; later convs
+ * via im2col (k = (ky*3+kx)*C + c) + ea_gemm_bf16.  Output sizes: To=(T-1)/sy+1, Fo=(F-1)/sx+1. */
+int ea_conv1_fwd(const float* X, const float* W, const float* bias, void* Z, float* stats, int B, int T, int F,
+                 int CO, int sy, int sx, ea_stream_t stream);
+int ea_conv1_wgrad(const float* X, const void* dZ, float* dW, float* dbias, int B, int T, int F, int CO, int sy,
+                   int sx, ea_stream_t stream);
+int ea_im2col3x3(const void* A, void* col, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
+int ea_col2im3x3(const void* dcol, void* dA, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
+int ea_colstats_bf16(const void* X, float* stats, long M, int C, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses.
+ * log-softmax: espresso/models/transformer/speech_transformer_encoder_model.py:141-150.
+ * CTC: espresso/criterions/ctc_loss.py:59-100 (F.ctc_loss, blank=<s>, sum, zero_infinity).
+ *   lprobs fp32 [B][T][V]; targets int32 [B][Lmax]; nll fp32 [B] (per-utterance -log p);
+ *   ea_ctc_grad: dlogits = grad_scale * d(sum nll)/d(logits), bf16 or fp32 [B][T][ld_out], columns
+ *   [V, ld_out) zeroed; workspace: ea_ctc_workspace_bytes(B,T,Lmax) bytes, kept between the two calls.
+ * Label-smoothed CE: espresso/criterions/label_smoothed_cross_entropy_v2.py:94-119 (uniform).
+ *   out_loss[0] += sum loss, out_loss[1] += sum nll over non-pad rows. */
+int ea_log_softmax_f32(const float* in, long ld_in, float* out, long M, int V, ea_stream_t stream);
+int ea_log_softmax_bf16(const void* in, long ld_in, float* out, long M, int V, ea_stream_t stream);
+long ea_ctc_workspace_bytes(int B, int T, int Lmax);
+int ea_ctc_loss(const float* lprobs, const int* targets, const int* in_len, const int* tgt_len, float* nll,
+                void* workspace, int B, int T, int V, int Lmax, int blank, ea_stream_t stream);
+/* backward of ea_ctc_loss: reads the lattice left in `workspace`; grad_scale_dev (device fp32 scalar,
+ * may be NULL) multiplies grad_scale — the autograd grad_output, without a host sync. */
+int ea_ctc_grad(const float* lprobs, const void* workspace, const float* nll, const int* targets,
+                const int* in_len, const int* tgt_len, void* dlogits, long ld_out, int dlogits_bf16, int B, int T,
+                int V, int Lmax, int blank, float grad_scale, const float* grad_scale_dev, int zero_infinity,
+                ea_stream_t stream);
+int ea_label_smoothed_ce(const void* logits, long ld, int logits_bf16, const int* target, float* out_loss,
+                         void* dlogits, long ld_out, int dlogits_bf16, long M, int V, int pad_idx, float eps,
+                         float grad_scale, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Front-end: Kaldi fbank + global CMVN + SpecAugment + padding — espresso/tools/utils.py:426-454
+ * (torchaudio.compliance.kaldi.fbank defaults), fairseq/data/audio/feature_transforms/global_cmvn.py:26-29,
+ * espresso/data/feature_transforms/adaptive_specaugment.py:77-136, espresso/tools/utils.py:97-113.
+ * wav: concatenated fp32 samples (int16 scale), offsets int64 [B+1]; feat fp32 [B][Tmax][nmel]
+ * (rows >= n_frames(b) are written as 0); utt_sum fp32 [B] zeroed by caller (sum of features, for
+ * the mean mask value); out_len int32 [B] = 1+(N-frame_len)/frame_shift.  window/twiddle/mel_* are
+ * host-built tables (espresso_amd/data/fbank_tables.py).  Mask lists: int32 [B][n][2] = (start,width). */
+int ea_fbank_batch(const float* wav, const long* offsets, int B, const float* window, const float* twiddle,
+                   const int* mel_start, const int* mel_len, const int* mel_woff, const float* mel_w,
+                   const float* cmvn_mean, const float* cmvn_std, float* feat, float* utt_sum, int* out_len,
+                   int Tmax, int nmel, int frame_len, int frame_shift, float preemph, float log_floor,
+                   ea_stream_t stream);
+int ea_specaugment(float* feat, const int* lengths, const float* utt_sum, const int* fmask, const int* tmask,
+                   int nf, int nt, int B, int Tmax, int nmel, int use_mean, float mask_value, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer on flat fp32 buffers — fairseq/utils.py:347-397 (clip_grad_norm_),
+ * fairseq/optim/adam.py:215-240.  coef[0] multiplies every gradient (pre_scale * clip), coef[1]
+ * receives the (pre-scaled) gradient norm; both stay on the device. */
+int ea_grad_sumsq(const float* g, long n, float* out, ea_stream_t stream);
+int ea_clip_coef(const float* sumsq, float pre_scale, float max_norm, float* coef, ea_stream_t stream);
+int ea_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long n, const float* coef, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad,
+                 ea_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESPRESSO_AMD_H */
