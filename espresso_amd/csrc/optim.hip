@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 
 // coef[0] = pre_scale * min(1, max_norm / (norm + 1e-6)),  coef[1] = norm = sqrt(sumsq) * pre_scale
-__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float pre_scale, float max_norm,
-                                 float* __restrict__ coef) {
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float pre_scale, const float* __restrict__ denom,
+                                 float max_norm, float* __restrict__ coef) {
+  if (denom) pre_scale = pre_scale / denom[0];
   const float norm = sqrtf(sumsq[0]) * pre_scale;
   float c = 1.f;
   if (max_norm > 0.f) c = fminf(1.f, max_norm / (norm + 1e-6f));
@@ -96,9 +97,9 @@ extern "C" int ea_grad_sumsq(const float* g, long n, float* out /*zeroed by call
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, n, out);
   return EA_CHECK_LAUNCH();
 }
-extern "C" int ea_clip_coef(const float* sumsq, float pre_scale, float max_norm, float* coef /*[2]*/,
-                            hipStream_t stream) {
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, pre_scale, max_norm, coef);
+extern "C" int ea_clip_coef(const float* sumsq, float pre_scale, const float* denom_dev, float max_norm,
+                            float* coef /*[2]*/, hipStream_t stream) {
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, pre_scale, denom_dev, max_norm, coef);
   return EA_CHECK_LAUNCH();
 }
 extern "C" int ea_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long n, const float* coef,

@@ -1,0 +1,521 @@
+"""Module-level autograd functions composed from the HIP kernels (espresso_amd/kernels.py).
+
+Each function here is ONE autograd node that mirrors one reference sub-module, with an explicit
+hand-scheduled backward (no autograd tracing inside):
+
+  ffn_module        fairseq/modules/conformer_layer.py:134-146 + the 0.5*x + residual of
+                    espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:112-114,136-139
+  relpos_mhsa       LN + fairseq/modules/multihead_attention.py:544-917 (rel-pos branch) + dropout + residual
+  conv_module       fairseq/modules/conformer_layer.py:79-101 + residual
+  layer_norm        fairseq/modules/layer_norm.py
+  linear            torch.nn.Linear
+  ctc_loss          espresso/criterions/ctc_loss.py:61-94
+
+Internal activation layout is [B*T][C] (batch-major rows, bf16); weights are fp32 master copies
+with a bf16 shadow (see FlatParams in espresso_amd/optim/flat.py).  Dropout masks are never stored:
+a per-call 64-bit seed is saved and the kernels re-derive the mask from (seed, element index).
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import kernels as K
+
+_seed_state = {"base": 0x5EED, "counter": 0}
+
+
+def set_dropout_seed(seed: int):
+    _seed_state["base"] = int(seed) & 0xFFFFFFFF
+    _seed_state["counter"] = 0
+
+
+def _next_seed() -> int:
+    _seed_state["counter"] += 1
+    return ((_seed_state["base"] << 32) | (_seed_state["counter"] & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+
+
+def bf16_weight(p: torch.Tensor) -> torch.Tensor:
+    """bf16 shadow of an fp32 parameter: the FlatParams view when attached and current, else a HIP cast."""
+    sh = getattr(p, "_ea_bf16", None)
+    if sh is not None:
+        return sh
+    return K.cast_f32_to_bf16(p.detach().contiguous())
+
+
+def _new(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None):
+    """dW[N_out][K_in] (fp32) = dy[M][N_out]^T x[M][K_in]"""
+    dW = _new((N_out, K_in), torch.float32, dy)
+    K.gemm(dy, x, dW, N_out, K_in, M, lda=ld_dy or N_out, ldb=ld_x or K_in, ldc=K_in, a_kstrided=True, b_kstrided=True)
+    return dW
+
+
+def _zeros_f32(n, like):
+    return torch.zeros(n, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, w16, out_f32):
+        M, Kin = x.shape
+        N = w.shape[0]
+        # rows are padded to a multiple of 8 elements so that every later 16-byte access (dgrad /
+        # wgrad of a vocabulary-sized N such as 5004) stays aligned; the result is a [M][N] view.
+        ld = _pad8(N)
+        buf = _new((M, ld), torch.float32 if out_f32 else torch.bfloat16, x)
+        K.gemm(x, w16, buf, M, N, Kin, lda=Kin, ldb=Kin, ldc=ld, bias=b)
+        ctx.save_for_backward(x, w16)
+        ctx.has_bias = b is not None
+        return buf if ld == N else buf[:, :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        M, Kin = x.shape
+        N = w16.shape[0]
+        if dy.dtype != torch.bfloat16:
+            dy = K.cast_f32_to_bf16(dy.contiguous())
+        if dy.stride(1) != 1 or dy.stride(0) % 8 != 0:
+            dy = dy.contiguous()
+        ld = dy.stride(0)
+        dW = _wgrad(dy, x, M, N, Kin, ld_dy=ld)
+        db = None
+        if ctx.has_bias:
+            db = K.colsum(dy, _zeros_f32(N, dy), M, N, ld)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new((M, Kin), torch.bfloat16, x)
+            K.gemm(dy, w16, dx, M, Kin, N, lda=ld, ldb=Kin, ldc=Kin, b_kstrided=True)
+        return dx, dW, db, None, None
+
+
+def linear(x, w, b=None, out_f32=False):
+    """y = x w^T + b ; x bf16 [M][K], w fp32 [N][K] (bf16 shadow used on the MFMA)."""
+    return _Linear.apply(x, w, b, bf16_weight(w), out_f32)
+
+
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps, row_zero, drop_p):
+        seed = _next_seed() if drop_p > 0 else 0
+        y, mean, rstd = K.layernorm_fwd(x, g, b, eps, row_zero, drop_p, seed)
+        ctx.save_for_backward(x, g, mean, rstd, row_zero)
+        ctx.drop = (drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd, row_zero = ctx.saved_tensors
+        C = x.shape[1]
+        dg, db = _zeros_f32(C, x), _zeros_f32(C, x)
+        dx = K.layernorm_bwd(x, dy.contiguous(), g, mean, rstd, dg, db, row_zero, ctx.drop[0], ctx.drop[1])
+        return dx, dg, db, None, None, None
+
+
+def layer_norm(x, g, b, eps=1e-5, row_zero=None, drop_p=0.0):
+    """y = zero_rows(dropout(LN(x)))  (row_zero: uint8 [M] marks padded frames)."""
+    return _LayerNorm.apply(x, g, b, eps, row_zero, drop_p)
+
+
+# ------------------------------------------------------------------------------------------------
+class _FFN(torch.autograd.Function):
+    """y = out_scale * drop2(W2 drop1(act(W1 LN(x) + b1)) + b2) + x   (pre_ln=True)
+       y = out_scale * drop2(W2 drop1(act(W1 x + b1)) + b2) + x        (pre_ln=False, x already normalised... not used)"""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, w1_16, w2_16, act, p_act, p_out, out_scale, eps):
+        M, C = x.shape
+        Fd = w1.shape[0]
+        xn, mean, rstd = K.layernorm_fwd(x, ln_g, ln_b, eps)
+        s1 = _next_seed() if p_act > 0 else 0
+        s2 = _next_seed() if p_out > 0 else 0
+        z = _new((M, Fd), torch.bfloat16, x)
+        h = _new((M, Fd), torch.bfloat16, x)
+        K.gemm(xn, w1_16, z, M, Fd, C, lda=C, ldb=C, ldc=Fd, bias=b1, act=act, C2=h, ldc2=Fd, drop_p=p_act, drop_seed=s1)
+        y = _new((M, C), torch.bfloat16, x)
+        K.gemm(h, w2_16, y, M, C, Fd, lda=Fd, ldb=Fd, ldc=C, bias=b2, drop_p=p_out, drop_seed=s2, out_scale=out_scale,
+               resid=x, ldr=C)
+        ctx.save_for_backward(x, ln_g, mean, rstd, xn, z, h, w1_16, w2_16)
+        ctx.cfg = (act, p_act, p_out, out_scale, s1, s2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_g, mean, rstd, xn, z, h, w1_16, w2_16 = ctx.saved_tensors
+        act, p_act, p_out, out_scale, s1, s2 = ctx.cfg
+        M, C = x.shape
+        Fd = z.shape[1]
+        dy = dy.contiguous()
+        g2 = K.scale_dropout(dy, a=out_scale, drop_p=p_out, drop_seed=s2)
+        dW2 = _wgrad(g2, h, M, C, Fd)
+        db2 = K.colsum(g2, _zeros_f32(C, x), M, C, C)
+        dz = _new((M, Fd), torch.bfloat16, x)
+        K.gemm(g2, w2_16, dz, M, Fd, C, lda=C, ldb=Fd, ldc=Fd, b_kstrided=True, aux=z, ldaux=Fd, act=act, drop_p=p_act,
+               drop_seed=s1)
+        dW1 = _wgrad(dz, xn, M, Fd, C)
+        db1 = K.colsum(dz, _zeros_f32(Fd, x), M, Fd, Fd)
+        dxn = _new((M, C), torch.bfloat16, x)
+        K.gemm(dz, w1_16, dxn, M, C, Fd, lda=Fd, ldb=C, ldc=C, b_kstrided=True)
+        dg, db = _zeros_f32(C, x), _zeros_f32(C, x)
+        dx = K.layernorm_bwd(x, dxn, ln_g, mean, rstd, dg, db, dx_add=dy)
+        return dx, dg, db, dW1, db1, dW2, db2, None, None, None, None, None, None, None
+
+
+def ffn_module(x, ln_g, ln_b, w1, b1, w2, b2, act="silu", p_act=0.0, p_out=0.0, out_scale=0.5, eps=1e-5):
+    return _FFN.apply(x, ln_g, ln_b, w1, b1, w2, b2, bf16_weight(w1), bf16_weight(w2), act, p_act, p_out, out_scale, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class _RelPosMHSA(torch.autograd.Function):
+    """y = drop(out_proj(Attn(LN(x)))) + x with Transformer-XL relative logits.
+
+    wqkv/bqkv: fused [3C][C] / [3C] in (q, k, v) order.  pe: bf16 [2T-1][C] sinusoidal table slice
+    (None -> plain attention, no u/v/pos_proj)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, wqkv16, wo16, wpos16, pe, key_len, attn_mask, B, T,
+                H, p_attn, p_out, eps, pre_ln):
+        M, C = x.shape
+        dh = C // H
+        scaling = dh ** -0.5
+        if pre_ln:
+            xn, mean, rstd = K.layernorm_fwd(x, ln_g, ln_b, eps)
+        else:
+            xn, mean, rstd = x, None, None
+        qkv = _new((M, 3 * C), torch.bfloat16, x)
+        K.gemm(xn, wqkv16, qkv, M, 3 * C, C, lda=C, ldb=C, ldc=3 * C, bias=bqkv)
+        relpos = pe is not None
+        qu, qv = K.relpos_q_prep(qkv, 3 * C, u if relpos else None, v if relpos else None, M, C, scaling, want_qv=relpos)
+        Z = H * B
+        Sp = _pad8(T)
+        ac = _new((Z * T, Sp), torch.float32, x)
+        K.gemm(qu, qkv, ac, T, T, dh, lda=C, ldb=3 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, T * 3 * C),
+               b_off=C, sC=(B * T * Sp, T * Sp))
+        bd = None
+        pp = None
+        R = 2 * T - 1
+        Rp = _pad8(R)
+        if relpos:
+            pp = _new((R, C), torch.bfloat16, x)
+            K.gemm(pe, wpos16, pp, R, C, C, lda=C, ldb=C, ldc=C)
+            bd = _new((Z * T, Rp), torch.float32, x)
+            K.gemm(qv, pp, bd, T, R, dh, lda=C, ldb=C, ldc=Rp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, 0),
+                   sC=(B * T * Rp, T * Rp))
+        sa = _next_seed() if p_attn > 0 else 0
+        P, Pd = K.relpos_softmax_fwd(ac, bd, key_len, attn_mask, H, B, T, T, Sp, Rp, Sp, False, p_attn, sa)
+        del ac, bd
+        o = _new((M, C), torch.bfloat16, x)
+        K.gemm(Pd, qkv, o, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
+               sB=(dh, T * 3 * C), b_off=2 * C, sC=(dh, T * C))
+        so = _next_seed() if p_out > 0 else 0
+        y = _new((M, C), torch.bfloat16, x)
+        K.gemm(o, wo16, y, M, C, C, lda=C, ldb=C, ldc=C, bias=bo, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
+        ctx.save_for_backward(x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe)
+        ctx.cfg = (B, T, H, p_attn, p_out, sa, so, pre_ln, relpos)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe) = ctx.saved_tensors
+        B, T, H, p_attn, p_out, sa, so, pre_ln, relpos = ctx.cfg
+        M, C = x.shape
+        dh = C // H
+        scaling = dh ** -0.5
+        Z = H * B
+        Sp, R = _pad8(T), 2 * T - 1
+        Rp = _pad8(R)
+        dy = dy.contiguous()
+        g = K.scale_dropout(dy, a=1.0, drop_p=p_out, drop_seed=so) if p_out > 0 else dy
+        dWo = _wgrad(g, o, M, C, C)
+        dbo = K.colsum(g, _zeros_f32(C, x), M, C, C)
+        do = _new((M, C), torch.bfloat16, x)
+        K.gemm(g, wo16, do, M, C, C, lda=C, ldb=C, ldc=C, b_kstrided=True)
+        # dPd[z][i][j] = sum_d do[(b,i),h,d] v[(b,j),h,d]
+        dPd = _new((Z * T, Sp), torch.float32, x)
+        K.gemm(do, qkv, dPd, T, T, dh, lda=C, ldb=3 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, T * 3 * C),
+               b_off=2 * C, sC=(B * T * Sp, T * Sp))
+        dqkv = _new((M, 3 * C), torch.bfloat16, x)
+        # dV[(b,j),h,d] = sum_i Pd[z][i][j] do[(b,i),h,d]
+        K.gemm(Pd, do, dqkv, T, dh, T, lda=Sp, ldb=C, ldc=3 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
+               sA=(B * T * Sp, T * Sp), sB=(dh, T * C), sC=(dh, T * 3 * C), c_off=2 * C)
+        dAC, dBD = K.relpos_softmax_bwd(P, dPd, H, B, T, T, Sp, Sp, Rp, want_bd=relpos, drop_p=p_attn, drop_seed=sa)
+        del dPd
+        # dK[(b,j),h,d] = sum_i dAC[z][i][j] qu[(b,i),h,d]
+        K.gemm(dAC, qu, dqkv, T, dh, T, lda=Sp, ldb=C, ldc=3 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
+               sA=(B * T * Sp, T * Sp), sB=(dh, T * C), sC=(dh, T * 3 * C), c_off=C)
+        # dq (through qu): s * sum_j dAC[z][i][j] k[(b,j),h,d]
+        t1 = _new((M, C), torch.bfloat16, x)
+        K.gemm(dAC, qkv, t1, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
+               sB=(dh, T * 3 * C), b_off=C, sC=(dh, T * C), alpha=scaling)
+        du = dv = dWpos = None
+        if relpos:
+            t2 = _new((M, C), torch.bfloat16, x)
+            K.gemm(dBD, pp, t2, T, dh, R, lda=Rp, ldb=C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Rp, T * Rp),
+                   sB=(dh, 0), sC=(dh, T * C), alpha=scaling)
+            # dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]
+            dpp = _new((R, C), torch.bfloat16, x)
+            K.gemm(dBD, qv, dpp, R, dh, B * T, lda=Rp, ldb=C, ldc=C, a_kstrided=True, b_kstrided=True, batch=H, zdiv=1,
+                   sA=(B * T * Rp, 0), sB=(dh, 0), sC=(dh, 0))
+            dWpos = _wgrad(dpp, pe, R, C, C)
+            du = K.colsum(t1, _zeros_f32(C, x), M, C, C)
+            dv = K.colsum(t2, _zeros_f32(C, x), M, C, C)
+            K.add2_strided(t1, C, t2, C, dqkv, 3 * C, M, C)
+        else:
+            K.add2_strided(t1, C, torch.zeros_like(t1), C, dqkv, 3 * C, M, C)
+        dWqkv = _wgrad(dqkv, xn, M, 3 * C, C)
+        dbqkv = K.colsum(dqkv, _zeros_f32(3 * C, x), M, 3 * C, 3 * C)
+        dxn = _new((M, C), torch.bfloat16, x)
+        K.gemm(dqkv, wqkv16, dxn, M, C, 3 * C, lda=3 * C, ldb=C, ldc=C, b_kstrided=True)
+        if pre_ln:
+            dg, db = _zeros_f32(C, x), _zeros_f32(C, x)
+            dx = K.layernorm_bwd(x, dxn, ln_g, mean, rstd, dg, db, dx_add=dy)
+        else:
+            dg = db = None
+            dx = K.scale_dropout(dxn, a=1.0, y=dy, b=1.0)
+        return (dx, dg, db, dWqkv, dbqkv, dWo, dbo, du, dv, dWpos) + (None,) * 13
+
+
+def relpos_mhsa(x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, pe, key_len, attn_mask, B, T, H, p_attn=0.0, p_out=0.0,
+                eps=1e-5, pre_ln=True, wqkv16=None):
+    return _RelPosMHSA.apply(
+        x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, wqkv16 if wqkv16 is not None else bf16_weight(wqkv),
+        bf16_weight(wo), bf16_weight(wpos) if wpos is not None else None, pe, key_len, attn_mask, B, T, H, p_attn, p_out,
+        eps, pre_ln)
+
+
+# ------------------------------------------------------------------------------------------------
+class _ConvModule(torch.autograd.Function):
+    """y = drop(PW2(SiLU(BN(DWConv(GLU(PW1(LN(x))))))) ) + x"""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, wpw1, wdw, bn_g, bn_b, wpw2, wpw1_16, wpw2_16, running_mean, running_var, B, T, KW,
+                p_out, eps, bn_eps, bn_momentum, training):
+        M, C = x.shape
+        xn, mean, rstd = K.layernorm_fwd(x, ln_g, ln_b, eps)
+        Y = _new((M, 2 * C), torch.bfloat16, x)
+        K.gemm(xn, wpw1_16, Y, M, 2 * C, C, lda=C, ldb=C, ldc=2 * C)
+        wdw2 = wdw.detach().reshape(C, KW).contiguous()
+        stats = _zeros_f32(2 * C, x) if training else None
+        U, Zt = K.glu_dwconv_fwd(Y, wdw2, B, T, C, KW, stats)
+        if training:
+            mr = K.bn_finalize(stats, C, M, bn_eps, bn_momentum, running_mean, running_var)
+        else:
+            mr = K.bn_from_running(running_mean, running_var, bn_eps)
+        Hh = K.bn_act_fwd(Zt, mr, bn_g, bn_b, "silu")
+        so = _next_seed() if p_out > 0 else 0
+        y = _new((M, C), torch.bfloat16, x)
+        K.gemm(Hh, wpw2_16, y, M, C, C, lda=C, ldb=C, ldc=C, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
+        ctx.save_for_backward(x, ln_g, mean, rstd, xn, Y, U, Zt, mr, Hh, bn_g, bn_b, wdw2, wpw1_16, wpw2_16)
+        ctx.cfg = (B, T, KW, p_out, so, training)
+        ctx.wdw_shape = wdw.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, ln_g, mean, rstd, xn, Y, U, Zt, mr, Hh, bn_g, bn_b, wdw2, wpw1_16, wpw2_16) = ctx.saved_tensors
+        B, T, KW, p_out, so, training = ctx.cfg
+        M, C = x.shape
+        dy = dy.contiguous()
+        g = K.scale_dropout(dy, a=1.0, drop_p=p_out, drop_seed=so) if p_out > 0 else dy
+        dWpw2 = _wgrad(g, Hh, M, C, C)
+        dH = _new((M, C), torch.bfloat16, x)
+        K.gemm(g, wpw2_16, dH, M, C, C, lda=C, ldb=C, ldc=C, b_kstrided=True)
+        dbn_g, dbn_b = _zeros_f32(C, x), _zeros_f32(C, x)
+        dZ = K.bn_act_bwd(Zt, dH, mr, bn_g, bn_b, dbn_g, dbn_b, "silu", training)
+        dwdw = _zeros_f32(C * KW, x)
+        dY = K.glu_dwconv_bwd(dZ, Y, U, wdw2, dwdw, B, T, C, KW)
+        dWpw1 = _wgrad(dY, xn, M, 2 * C, C)
+        dxn = _new((M, C), torch.bfloat16, x)
+        K.gemm(dY, wpw1_16, dxn, M, C, 2 * C, lda=2 * C, ldb=C, ldc=C, b_kstrided=True)
+        dg, db = _zeros_f32(C, x), _zeros_f32(C, x)
+        dx = K.layernorm_bwd(x, dxn, ln_g, mean, rstd, dg, db, dx_add=dy)
+        return (dx, dg, db, dWpw1.view(2 * C, C, 1), dwdw.view(ctx.wdw_shape), dbn_g, dbn_b, dWpw2.view(C, C, 1)) + (None,) * 12
+
+
+def conv_module(x, ln_g, ln_b, wpw1, wdw, bn_g, bn_b, wpw2, running_mean, running_var, B, T, p_out=0.0, eps=1e-5,
+                bn_eps=1e-5, bn_momentum=0.1, training=True):
+    C = x.shape[1]
+    KW = wdw.shape[-1]
+    return _ConvModule.apply(x, ln_g, ln_b, wpw1, wdw, bn_g, bn_b, wpw2, bf16_weight(wpw1).view(2 * C, C),
+                             bf16_weight(wpw2).view(C, C), running_mean, running_var, B, T, KW, p_out, eps, bn_eps,
+                             bn_momentum, training)
+
+
+# ------------------------------------------------------------------------------------------------
+class _CTCLoss(torch.autograd.Function):
+    """Per-utterance -log p(target | logits).  logits: bf16 or fp32 [B*T][V] (batch-major rows; may be
+    a row-padded view).  Returns (nll [B] fp32, lprobs fp32 [B*T][V]); d/dlogits comes from the
+    alpha/beta lattice kept in the workspace."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, in_len, tgt_len, B, T, blank, zero_infinity):
+        M, V = logits.shape
+        assert M == B * T
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        Lmax = targets.shape[1]
+        lprobs = K.log_softmax(logits, M, V, logits.stride(0))
+        nll, ws = K.ctc_loss_fwd(lprobs, targets, in_len, tgt_len, B, T, V, Lmax, blank)
+        ctx.save_for_backward(lprobs, ws, nll, targets, in_len, tgt_len)
+        ctx.cfg = (B, T, V, Lmax, blank, zero_infinity, logits.dtype)
+        ctx.mark_non_differentiable(lprobs)
+        return nll, lprobs
+
+    @staticmethod
+    def backward(ctx, dnll, _dlp):
+        lprobs, ws, nll, targets, in_len, tgt_len = ctx.saved_tensors
+        B, T, V, Lmax, blank, zero_infinity, dt = ctx.cfg
+        # The criterion reduces nll with a plain sum, so dnll is one scalar broadcast over B; it is
+        # applied on the device from dnll[0] (no host sync).
+        scale_dev = dnll.float().contiguous()
+        bf = dt == torch.bfloat16
+        ld = _pad8(V) if bf else V
+        dl = K.ctc_loss_grad(lprobs, ws, nll, targets, in_len, tgt_len, B, T, V, Lmax, blank, ld_out=ld, grad_bf16=bf,
+                             grad_scale=1.0, grad_scale_dev=scale_dev, zero_infinity=zero_infinity)
+        return (dl if ld == V else dl[:, :V]), None, None, None, None, None, None, None
+
+
+def ctc_loss(logits, targets, in_len, tgt_len, B, T, blank=0, zero_infinity=True):
+    """(nll [B], lprobs [B*T][V]).  NOTE: backward assumes a uniform upstream weight over utterances
+    (reduction='sum' as in espresso/criterions/ctc_loss.py:85-94)."""
+    return _CTCLoss.apply(logits, targets, in_len, tgt_len, B, T, blank, zero_infinity)
+
+
+class _LabelSmoothedCE(torch.autograd.Function):
+    """(sum loss, sum nll) over non-pad rows — espresso/criterions/label_smoothed_cross_entropy_v2.py:94-119."""
+
+    @staticmethod
+    def forward(ctx, logits, target, pad_idx, eps):
+        M, V = logits.shape
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        out, _ = K.label_smoothed_ce(logits, logits.stride(0), target, M, V, pad_idx, eps, want_grad=False)
+        ctx.save_for_backward(logits, target)
+        ctx.cfg = (pad_idx, eps)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, dloss, _dnll):
+        logits, target = ctx.saved_tensors
+        pad_idx, eps = ctx.cfg
+        M, V = logits.shape
+        bf = logits.dtype == torch.bfloat16
+        # grad scale read on the host would sync; the loss scale is 1 in fp32/bf16 training, so apply
+        # it lazily with the streaming kernel only when a non-unit scale tensor is passed.
+        _, dl = K.label_smoothed_ce(logits, logits.stride(0), target, M, V, pad_idx, eps, want_grad=True, grad_bf16=bf,
+                                    grad_ld=_pad8(V) if bf else V)
+        g = dl if dl.shape[1] == V else dl[:, :V]
+        return g * dloss.to(g.dtype), None, None, None
+
+
+def label_smoothed_ce(logits, target, pad_idx, eps):
+    return _LabelSmoothedCE.apply(logits, target, pad_idx, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+class _ConvSubsample(torch.autograd.Function):
+    """ConvBNReLU stack of espresso/modules/speech_convolutions.py:78-102 in channels-last form.
+
+    X fp32 [B][T][F] (in_channels == 1) -> bf16 [B*T'][F'*C_last] with feature index f*C_last + c, padded
+    frames zeroed and (training) input dropout of fc0 applied
+    (espresso/models/transformer/speech_transformer_encoder.py:341-342).
+    params: flat list [w_1, b_1, g_1, beta_1, ..., w_L, b_L, g_L, beta_L]; bufs: [rm_1, rv_1, ...]."""
+
+    @staticmethod
+    def forward(ctx, X, row_zero, strides, bufs, p_drop, training, bn_eps, bn_momentum, *params):
+        B, T, F = X.shape
+        L = len(params) // 4
+        saved = []
+        cfgs = []
+        A = None
+        Tc, Fc, Cc = T, F, 1
+        for i in range(L):
+            w, b, g, beta = params[4 * i: 4 * i + 4]
+            rm, rv = bufs[2 * i], bufs[2 * i + 1]
+            sy, sx = strides[i]
+            Co = w.shape[0]
+            To, Fo = (Tc - 1) // sy + 1, (Fc - 1) // sx + 1
+            stats = _zeros_f32(2 * Co, X) if training else None
+            if i == 0:
+                assert w.shape[1] == 1 and tuple(w.shape[2:]) == (3, 3)
+                Zi = K.conv1_fwd(X, w.detach().reshape(Co, 9).contiguous(), b, B, Tc, Fc, Co, sy, sx, stats)
+                col, w16 = None, None
+            else:
+                col = K.im2col3x3(A, B, Tc, Fc, Cc, sy, sx)
+                w16 = K.cast_f32_to_bf16(w.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Cc).contiguous())
+                Zi = _new((B * To * Fo, Co), torch.bfloat16, X)
+                K.gemm(col, w16, Zi, B * To * Fo, Co, 9 * Cc, lda=9 * Cc, ldb=9 * Cc, ldc=Co, bias=b)
+                if training:
+                    K.colstats(Zi, stats)
+            n = B * To * Fo
+            mr = K.bn_finalize(stats, Co, n, bn_eps, bn_momentum, rm, rv) if training else K.bn_from_running(rm, rv, bn_eps)
+            A = K.bn_act_fwd(Zi, mr, g, beta, "relu")
+            saved += [Zi, mr, col, w16, g, beta]
+            cfgs.append((Tc, Fc, Cc, To, Fo, Co, sy, sx))
+            Tc, Fc, Cc = To, Fo, Co
+        out = A.view(B * Tc, Fc * Cc)
+        seed = _next_seed() if (training and p_drop > 0) else 0
+        if seed:
+            out = K.scale_dropout(out, a=1.0, drop_p=p_drop, drop_seed=seed)
+        if row_zero is not None:
+            K.zero_rows(out, row_zero)
+        ctx.save_for_backward(X, row_zero, *[t for t in saved if t is not None])
+        ctx.layout = [[t is not None for t in saved[6 * i: 6 * i + 6]] for i in range(L)]
+        ctx.cfg = (B, cfgs, p_drop, seed, training, [tuple(p.shape) for p in params[0::4]])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        X, row_zero, *flat = ctx.saved_tensors
+        B, cfgs, p_drop, seed, training, wshapes = ctx.cfg
+        L = len(cfgs)
+        it = iter(flat)
+        per = []
+        for i in range(L):
+            per.append([next(it) if has else None for has in ctx.layout[i]])
+        dout = dout.contiguous()
+        if seed:
+            dout = K.scale_dropout(dout, a=1.0, drop_p=p_drop, drop_seed=seed)
+        elif row_zero is not None:
+            dout = dout.clone()
+        if row_zero is not None:
+            K.zero_rows(dout, row_zero)
+        grads = [None] * (4 * L)
+        Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[-1]
+        dA = dout.view(B * To * Fo, Co)
+        for i in range(L - 1, -1, -1):
+            Zi, mr, col, w16, g, beta = per[i]
+            Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[i]
+            dg, dbeta = _zeros_f32(Co, X), _zeros_f32(Co, X)
+            dZ = K.bn_act_bwd(Zi, dA, mr, g, beta, dg, dbeta, "relu", training)
+            n = B * To * Fo
+            if i == 0:
+                dW = _zeros_f32(Co * 9, X)
+                db = _zeros_f32(Co, X)
+                K.conv1_wgrad(X, dZ, dW, db, B, Tc, Fc, Co, sy, sx)
+                grads[0] = dW.view(wshapes[0])
+            else:
+                dWp = _wgrad(dZ, col, n, Co, 9 * Cc)
+                db = K.colsum(dZ, _zeros_f32(Co, X), n, Co, Co)
+                grads[4 * i] = dWp.view(Co, 3, 3, Cc).permute(0, 3, 1, 2)
+                dcol = _new((n, 9 * Cc), torch.bfloat16, X)
+                K.gemm(dZ, w16, dcol, n, 9 * Cc, Co, lda=Co, ldb=9 * Cc, ldc=9 * Cc, b_kstrided=True)
+                dA = K.col2im3x3(dcol, B, Tc, Fc, Cc, sy, sx)
+            grads[4 * i + 1] = db
+            grads[4 * i + 2] = dg
+            grads[4 * i + 3] = dbeta
+        return (None,) * 8 + tuple(grads)
+
+
+def conv_subsample(X, row_zero, strides, params, bufs, p_drop=0.0, training=True, bn_eps=1e-5, bn_momentum=0.1):
+    return _ConvSubsample.apply(X, row_zero, tuple(strides), list(bufs), p_drop, training, bn_eps, bn_momentum, *params)

@@ -342,16 +342,18 @@ def ctc_loss_grad(lprobs, ws, nll, targets, in_len, tgt_len, B, T, V, Lmax, blan
     return dl
 
 
-def label_smoothed_ce(logits, ld, target, M, V, pad_idx, eps, want_grad=True, grad_bf16=True, grad_scale=1.0):
+def label_smoothed_ce(logits, ld, target, M, V, pad_idx, eps, want_grad=True, grad_bf16=True, grad_scale=1.0,
+                      grad_ld=None):
     assert target.dtype == torch.int32
     dev = logits.device
     out = torch.zeros(2, dtype=torch.float32, device=dev)
     dl = None
+    grad_ld = V if grad_ld is None else grad_ld
     if want_grad:
-        dl = torch.empty(M, V, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=dev)
+        dl = torch.zeros(M, grad_ld, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=dev)
     check(
         _lib.lib().ea_label_smoothed_ce(_p(logits), ld, int(logits.dtype == torch.bfloat16), _p(target), _p(out),
-                                        _p(dl), V, int(grad_bf16), M, V, pad_idx, eps, grad_scale, _stream()),
+                                        _p(dl), grad_ld, int(grad_bf16), M, V, pad_idx, eps, grad_scale, _stream()),
         "ea_label_smoothed_ce",
     )
     return out, dl
@@ -390,8 +392,8 @@ def grad_sumsq(g, out):
     return out
 
 
-def clip_coef(sumsq, pre_scale, max_norm, coef):
-    check(_lib.lib().ea_clip_coef(_p(sumsq), pre_scale, max_norm, _p(coef), _stream()), "ea_clip_coef")
+def clip_coef(sumsq, pre_scale, max_norm, coef, denom_dev=None):
+    check(_lib.lib().ea_clip_coef(_p(sumsq), pre_scale, _p(denom_dev), max_norm, _p(coef), _stream()), "ea_clip_coef")
     return coef
 
 

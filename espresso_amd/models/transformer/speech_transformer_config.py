@@ -1,0 +1,82 @@
+"""Model configuration with the reference's field names and defaults
+(espresso/models/transformer/speech_transformer_config.py:28-365, fairseq/models/transformer/transformer_config.py).
+Only fields that affect the ASR hot path are carried; YAML keys of the recipes map 1:1."""
+from dataclasses import dataclass, field
+from typing import Optional
+
+DEFAULT_MAX_SOURCE_POSITIONS = 10240
+DEFAULT_MAX_TARGET_POSITIONS = 1024
+
+
+@dataclass
+class SpeechEncoderConfig:
+    embed_dim: int = 512
+    ffn_embed_dim: int = 2048
+    layers: int = 6
+    attention_heads: int = 8
+    normalize_before: bool = False
+    learned_pos: bool = False
+    layerdrop: float = 0.0
+    relative_positional_embeddings: bool = False
+    share_learned_relative_positional_embeddings_across_layers: bool = False
+    share_learned_relative_positional_embeddings_across_heads: bool = False
+    conv_channels: str = "[64, 64, 128, 128]"
+    conv_kernel_sizes: str = "[(3, 3), (3, 3), (3, 3), (3, 3)]"
+    conv_strides: str = "[(1, 1), (2, 2), (1, 1), (2, 2)]"
+    conv_apply_batchnorm: bool = True
+    transformer_context: Optional[str] = None
+    layer_type: str = "transformer"
+    chunk_size: int = 0
+    chunk_left_window: int = 0
+    chunk_right_window: int = 0
+    depthwise_conv_kernel_size: int = 31
+
+
+@dataclass
+class SpeechDecoderConfig:
+    embed_dim: int = 512
+    ffn_embed_dim: int = 2048
+    layers: int = 6
+    attention_heads: int = 8
+    normalize_before: bool = False
+    learned_pos: bool = False
+    layerdrop: float = 0.0
+    relative_positional_embeddings: bool = False
+    input_dim: Optional[int] = None
+    output_dim: Optional[int] = None
+    relaxed_attention_weight: float = 0.0
+
+    def __post_init__(self):
+        if self.input_dim is None:
+            self.input_dim = self.embed_dim
+        if self.output_dim is None:
+            self.output_dim = self.embed_dim
+
+
+@dataclass
+class SpeechTransformerConfig:
+    activation_fn: str = "relu"
+    dropout: float = 0.1
+    attention_dropout: float = 0.0
+    activation_dropout: float = 0.0
+    adaptive_input: bool = False
+    encoder: SpeechEncoderConfig = field(default_factory=SpeechEncoderConfig)
+    decoder: SpeechDecoderConfig = field(default_factory=SpeechDecoderConfig)
+    max_source_positions: int = DEFAULT_MAX_SOURCE_POSITIONS
+    max_target_positions: int = DEFAULT_MAX_TARGET_POSITIONS
+    share_decoder_input_output_embed: bool = False
+    no_token_positional_embeddings: bool = False
+    layernorm_embedding: bool = False
+    no_scale_embedding: bool = False
+    scheduled_sampling_probs: str = "1.0"
+    scheduled_sampling_start_epoch: int = 1
+
+    @classmethod
+    def from_dict(cls, d):
+        """Build from a nested dict with the recipe YAML's `model:` layout."""
+        d = dict(d or {})
+        d.pop("_name", None)
+        enc = SpeechEncoderConfig(**{k: v for k, v in dict(d.pop("encoder", {}) or {}).items()})
+        dec = SpeechDecoderConfig(**{k: v for k, v in dict(d.pop("decoder", {}) or {}).items()})
+        known = {f for f in cls.__dataclass_fields__}
+        return cls(encoder=enc, decoder=dec, **{k: v for k, v in d.items() if k in known})

@@ -1,0 +1,250 @@
+"""`speech_transformer_encoder_model` — encoder-only ASR model for CTC
+(espresso/models/transformer/speech_transformer_encoder_model.py:35-210) on top of the HIP encoder
+(espresso/models/transformer/speech_transformer_encoder.py:44-453 semantics).
+
+State-dict keys match the reference (`encoder.pre_encoder.convolutions.N.*`, `encoder.fc0.*`,
+`encoder.layernorm_embedding.*`, `encoder.layers.N.*`, `encoder.fc_out.*`, `encoder.version`), so
+reference checkpoints load and vice versa."""
+import torch
+import torch.nn as nn
+
+from ... import functional as F
+from ... import kernels as K
+from ...modules.conformer_layer import ConformerWithRelativePositionalEmbeddingEncoderLayer
+from ...modules.params import LayerNormParams, LinearParams
+from ...modules.sinusoidal_relative_positional_embedding import SinusoidalRelativePositionalEmbedding
+from ...modules.speech_convolutions import ConvBNReLU
+from ...modules.transformer_layer import TransformerWithRelativePositionalEmbeddingEncoderLayer
+from ...registry import register_model, register_model_architecture
+from ...tools import utils as speech_utils
+from .speech_transformer_config import DEFAULT_MAX_SOURCE_POSITIONS, SpeechTransformerConfig
+
+
+class SpeechTransformerEncoderBase(nn.Module):
+    def __init__(self, cfg, pre_encoder=None, input_size=83):
+        super().__init__()
+        self.cfg = cfg
+        self.register_buffer("version", torch.Tensor([3]))
+        d = cfg.encoder.embed_dim
+        self.embed_dim = d
+        self.max_source_positions = cfg.max_source_positions
+        self.pre_encoder = pre_encoder
+        self.fc0 = LinearParams(input_size, d) if input_size != d else None
+        self.embed_scale = 1.0 if (cfg.no_scale_embedding or self.fc0 is not None) else d ** 0.5
+        if not cfg.encoder.relative_positional_embeddings and not cfg.no_token_positional_embeddings:
+            raise NotImplementedError("absolute positional embeddings: the ASR recipes use relative positions")
+        if cfg.encoder.learned_pos and cfg.encoder.relative_positional_embeddings:
+            raise NotImplementedError("learned relative positions (recipes use sinusoidal: learned_pos false)")
+        self.layernorm_embedding = LayerNormParams(d) if cfg.layernorm_embedding else None
+        rel = SinusoidalRelativePositionalEmbedding(d) if cfg.encoder.relative_positional_embeddings else None
+        self.rel_pos_embed = [rel]
+        if cfg.encoder.layer_type == "conformer":
+            layer_cls = ConformerWithRelativePositionalEmbeddingEncoderLayer
+        elif cfg.encoder.layer_type == "transformer":
+            layer_cls = TransformerWithRelativePositionalEmbeddingEncoderLayer
+        else:
+            raise NotImplementedError(cfg.encoder.layer_type)
+        self.layers = nn.ModuleList([layer_cls(cfg, positional_embedding=rel) for _ in range(cfg.encoder.layers)])
+        self.num_layers = len(self.layers)
+        if cfg.encoder.normalize_before and cfg.encoder.layer_type != "conformer":
+            self.layer_norm = LayerNormParams(d)
+        else:
+            self.layer_norm = None
+        self.transformer_context = speech_utils.eval_str_nested_list_or_tuple(cfg.encoder.transformer_context, type=int)
+        if cfg.encoder.chunk_size > 0:
+            raise NotImplementedError("chunk-streaming masks (not used by the LibriSpeech recipes)")
+        self.num_updates = 0
+
+    def set_num_updates(self, num_updates):
+        self.num_updates = num_updates
+
+    def output_lengths(self, in_lengths):
+        return in_lengths if self.pre_encoder is None else self.pre_encoder.output_lengths(in_lengths)
+
+    def get_attn_mask(self, max_len, device):
+        """Additive fp32 [T][T] mask from `transformer_context` (speech_transformer_encoder.py:250-263),
+        already filled with -1e8 where masked (conformer layer :107-110), or None."""
+        tc = self.transformer_context
+        if tc is None or (tc[0] is None and tc[1] is None):
+            return None
+        ones = torch.ones(max_len, max_len, dtype=torch.bool, device=device)
+        if tc[0] is None:
+            m = ones.triu(tc[1] + 1)
+        elif tc[1] is None:
+            m = ones.tril(-tc[0] - 1)
+        else:
+            m = ones.triu(tc[1] + 1) | ones.tril(-tc[0] - 1)
+        return torch.zeros(max_len, max_len, device=device).masked_fill(m, -1e8).contiguous()
+
+    def _fc0_weight(self):
+        """fc0 consumes (c*F' + f)-ordered features in the reference; the channels-last sub-sampler
+        emits f*C + c, so the weight's input axis is permuted once per call (autograd un-permutes)."""
+        w = self.fc0.weight
+        C = self.pre_encoder.out_channels[-1]
+        Fp = w.shape[1] // C
+        return w.view(w.shape[0], C, Fp).permute(0, 2, 1).reshape(w.shape[0], Fp * C)
+
+    def encode(self, src_tokens, src_lengths, return_all_hiddens=False):
+        """-> (x bf16 [B*T'][C] batch-major, lengths' [B], padding_mask [B][T'], B, T')"""
+        cfg = self.cfg
+        tr = self.training
+        B = src_tokens.shape[0]
+        p = cfg.dropout if tr else 0.0
+        x, x_lengths, padding_mask, row_zero = self.pre_encoder(src_tokens, src_lengths, p_drop=p if self.fc0 is not None else 0.0)
+        Tp = padding_mask.shape[1]
+        if self.fc0 is not None:
+            x = F.linear(x, self._fc0_weight(), self.fc0.bias)
+        if self.layernorm_embedding is not None:
+            x = F.layer_norm(x, self.layernorm_embedding.weight, self.layernorm_embedding.bias, row_zero=row_zero, drop_p=p)
+        else:
+            raise NotImplementedError("layernorm_embedding=false (all recipes set it true)")
+        key_len = x_lengths.to(torch.int32).contiguous()
+        attn_mask = self.get_attn_mask(Tp, x.device)
+        states = [x] if return_all_hiddens else []
+        for layer in self.layers:
+            x = layer(x, B, Tp, key_len=key_len, attn_mask=attn_mask)
+            if return_all_hiddens:
+                states.append(x)
+        if self.layer_norm is not None:
+            x = F.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias)
+        return x, x_lengths, padding_mask, B, Tp, states
+
+    def forward(self, src_tokens, src_lengths, return_all_hiddens=False):
+        x, x_lengths, padding_mask, B, Tp, states = self.encode(src_tokens, src_lengths, return_all_hiddens)
+        C = x.shape[1]
+        return {
+            "encoder_out": [x.view(B, Tp, C).transpose(0, 1)],  # T x B x C (view of the batch-major buffer)
+            "encoder_padding_mask": [padding_mask],
+            "encoder_embedding": [],
+            "encoder_states": [s.view(B, Tp, C).transpose(0, 1) for s in states],
+            "fc_results": [],
+            "src_tokens": [],
+            "src_lengths": [x_lengths],
+            "_x_bt": [x],
+        }
+
+    def max_positions(self):
+        return self.max_source_positions
+
+    def reorder_encoder_out(self, encoder_out, new_order):
+        out = dict(encoder_out)
+        out["encoder_out"] = [e.index_select(1, new_order) for e in encoder_out["encoder_out"]]
+        out["encoder_padding_mask"] = [m.index_select(0, new_order) for m in encoder_out["encoder_padding_mask"]]
+        out["src_lengths"] = [l.index_select(0, new_order) for l in encoder_out["src_lengths"]]
+        out["encoder_states"] = [s.index_select(1, new_order) for s in encoder_out["encoder_states"]]
+        out.pop("_x_bt", None)
+        return out
+
+
+class SpeechTransformerEncoderForPrediction(SpeechTransformerEncoderBase):
+    """Encoder + optional output layer `fc_out` (speech_transformer_encoder_model.py:153-210)."""
+
+    def __init__(self, cfg, pre_encoder=None, input_size=83, vocab_size=None):
+        super().__init__(cfg, pre_encoder=pre_encoder, input_size=input_size)
+        self.fc_out = LinearParams(cfg.encoder.embed_dim, vocab_size) if vocab_size is not None else None
+
+    def forward(self, src_tokens, src_lengths, return_all_hiddens=False):
+        out = super().forward(src_tokens, src_lengths, return_all_hiddens=return_all_hiddens)
+        if self.fc_out is not None:
+            x = out.pop("_x_bt")[0]
+            B, Tp = out["encoder_padding_mask"][0].shape
+            logits = F.linear(x, self.fc_out.weight, self.fc_out.bias)  # bf16 [B*T'][V] (row-padded view)
+            V = logits.shape[1]
+            out["encoder_out"] = [logits.view(B, Tp, V).transpose(0, 1)]  # T x B x V
+            out["_logits_bt"] = [logits]
+        return out
+
+
+@register_model("speech_transformer_encoder_model", dataclass=SpeechTransformerConfig)
+class SpeechTransformerEncoderModel(nn.Module):
+    def __init__(self, cfg, encoder):
+        super().__init__()
+        self.cfg = cfg
+        self.encoder = encoder
+        self.num_updates = 0
+
+    @classmethod
+    def build_model(cls, cfg, task):
+        if cfg.max_source_positions is None:
+            cfg.max_source_positions = DEFAULT_MAX_SOURCE_POSITIONS
+        ev = speech_utils.eval_str_nested_list_or_tuple
+        out_channels = ev(cfg.encoder.conv_channels, type=int)
+        kernel_sizes = ev(cfg.encoder.conv_kernel_sizes, type=int)
+        strides = ev(cfg.encoder.conv_strides, type=int)
+        assert task.feat_dim % task.feat_in_channels == 0
+        conv_layers = ConvBNReLU(out_channels, kernel_sizes, strides, in_channels=task.feat_in_channels) if out_channels is not None else None
+        in_size = task.feat_dim // task.feat_in_channels
+        if conv_layers is not None:
+            in_size = conv_layers.output_feat_dim(in_size)
+        else:
+            in_size = task.feat_dim
+        vocab = len(task.target_dictionary) if task.target_dictionary is not None else None
+        encoder = cls.build_encoder(cfg, pre_encoder=conv_layers, input_size=in_size, vocab_size=vocab)
+        return cls(cfg, encoder)
+
+    @classmethod
+    def build_encoder(cls, cfg, pre_encoder=None, input_size=83, vocab_size=None):
+        return SpeechTransformerEncoderForPrediction(cfg, pre_encoder=pre_encoder, input_size=input_size, vocab_size=vocab_size)
+
+    def set_num_updates(self, num_updates):
+        self.num_updates = num_updates
+        self.encoder.set_num_updates(num_updates)
+
+    def forward(self, src_tokens, src_lengths, **kwargs):
+        return self.encoder(src_tokens, src_lengths, **kwargs)
+
+    def output_lengths(self, in_lengths):
+        return self.encoder.output_lengths(in_lengths)
+
+    def max_positions(self):
+        return self.encoder.max_positions()
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        """(T x B x V) fp32 (log-)probabilities — speech_transformer_encoder_model.py:141-150."""
+        lg = net_output.get("_logits_bt")
+        if lg:
+            logits = lg[0]
+            B, Tp = net_output["encoder_padding_mask"][0].shape
+        else:
+            e = net_output["encoder_out"][0]
+            Tp, B, V = e.shape
+            logits = e.transpose(0, 1).reshape(B * Tp, V)
+        M, V = logits.shape
+        lp = K.log_softmax(logits.detach(), M, V, logits.stride(0))
+        if not log_probs:
+            lp = lp.exp_()
+        return lp.view(B, Tp, V).transpose(0, 1)
+
+    def get_targets(self, sample, net_output):
+        return sample["target"]
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        """Accept reference checkpoints: rename conv_layers_before -> pre_encoder
+        (speech_transformer_encoder.py:415-428) and drop the positional-embedding dummy buffers."""
+        for k in list(state_dict.keys()):
+            if "conv_layers_before" in k:
+                state_dict[k.replace("conv_layers_before", "pre_encoder")] = state_dict.pop(k)
+        for k in list(state_dict.keys()):
+            if k.endswith("positional_embedding._float_tensor"):
+                state_dict.pop(k)
+        return state_dict
+
+
+@register_model_architecture("speech_transformer_encoder_model", "speech_transformer_encoder_model")
+def base_architecture(cfg):
+    return cfg
+
+
+@register_model_architecture("speech_transformer_encoder_model", "speech_conformer_encoder_model_librispeech")
+def conformer_ctc_librispeech(cfg=None):
+    """examples/asr_librispeech/config/transformer_ctc_librispeech.yaml:66-85 + `model.encoder.layer_type=conformer`."""
+    cfg = cfg or SpeechTransformerConfig()
+    e = cfg.encoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, 12, 8
+    e.normalize_before, e.learned_pos, e.relative_positional_embeddings = True, False, True
+    e.layer_type = "conformer"
+    cfg.attention_dropout = cfg.activation_dropout = cfg.dropout = 0.1
+    cfg.activation_fn = "relu"
+    cfg.layernorm_embedding = True
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    return cfg

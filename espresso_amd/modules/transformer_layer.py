@@ -1,0 +1,45 @@
+"""Transformer encoder layer with optional relative positions — storage and forward order of
+fairseq/modules/transformer_layer.py:19-226 as specialised by
+espresso/modules/transformer_with_relative_positional_embedding_layer.py:17-43
+(self_attn, self_attn_layer_norm, fc1, fc2, final_layer_norm; pre-LN when normalize_before)."""
+import torch.nn as nn
+
+from .. import functional as F
+from .conformer_layer import MultiheadAttentionParams
+from .params import LayerNormParams, LinearParams
+
+
+class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
+    def __init__(self, cfg, positional_embedding=None):
+        super().__init__()
+        self.cfg = cfg
+        d = cfg.encoder.embed_dim
+        self.embed_dim = d
+        self.num_heads = cfg.encoder.attention_heads
+        self.normalize_before = cfg.encoder.normalize_before
+        if not self.normalize_before:
+            raise NotImplementedError("post-LN encoder layers (the recipes set normalize_before: true)")
+        self.positional_embedding = [positional_embedding]
+        self.self_attn = MultiheadAttentionParams(d, self.num_heads, relpos=positional_embedding is not None)
+        self.self_attn_layer_norm = LayerNormParams(d)
+        self.fc1 = LinearParams(d, cfg.encoder.ffn_embed_dim)
+        self.fc2 = LinearParams(cfg.encoder.ffn_embed_dim, d)
+        self.final_layer_norm = LayerNormParams(d)
+        self.activation_fn = cfg.activation_fn
+
+    def forward(self, x, B, T, key_len=None, attn_mask=None):
+        cfg = self.cfg
+        tr = self.training
+        p_drop = cfg.dropout if tr else 0.0
+        p_act = cfg.activation_dropout if tr else 0.0
+        p_att = cfg.attention_dropout if tr else 0.0
+        a = self.self_attn
+        pe = self.positional_embedding[0]
+        wqkv, bqkv, wqkv16 = a.fused_qkv()
+        x = F.relpos_mhsa(x, self.self_attn_layer_norm.weight, self.self_attn_layer_norm.bias, wqkv, bqkv,
+                          a.out_proj.weight, a.out_proj.bias, a.pos_bias_u, a.pos_bias_v,
+                          a.pos_proj.weight if a.pos_proj is not None else None,
+                          pe.table(T, x.device) if pe is not None else None, key_len, attn_mask, B, T, self.num_heads,
+                          p_attn=p_att, p_out=p_drop, wqkv16=wqkv16)
+        return F.ffn_module(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
+                            self.fc2.weight, self.fc2.bias, act=self.activation_fn, p_act=p_act, p_out=p_drop, out_scale=1.0)

@@ -187,7 +187,9 @@ int ea_specaugment(float* feat, const int* lengths, const float* utt_sum, const 
  * fairseq/optim/adam.py:215-240.  coef[0] multiplies every gradient (pre_scale * clip), coef[1]
  * receives the (pre-scaled) gradient norm; both stay on the device. */
 int ea_grad_sumsq(const float* g, long n, float* out, ea_stream_t stream);
-int ea_clip_coef(const float* sumsq, float pre_scale, float max_norm, float* coef, ea_stream_t stream);
+/* scale = pre_scale / denom_dev[0] (denom_dev: device fp32 scalar such as the all-reduced sample_size; may be NULL) */
+int ea_clip_coef(const float* sumsq, float pre_scale, const float* denom_dev, float max_norm, float* coef,
+                 ea_stream_t stream);
 int ea_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long n, const float* coef, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad,
                  ea_stream_t stream);

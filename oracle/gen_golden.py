@@ -1,0 +1,177 @@
+"""Generate golden fixtures under tests/golden/ by running the REFERENCE's own code
+(/root/reference, imported through the stub packages in oracle/ref_stubs) on seeded inputs.
+
+Runs only in the build container (the GPU box has no /root/reference); the fixtures it writes are
+committed.  Usage:  python oracle/gen_golden.py
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "ref_stubs"))
+sys.path.insert(1, "/root/reference")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def ref_config(layer_type="conformer", d=64, heads=4, ffn=128, layers=2, conv_channels="[64, 64, 16, 16]"):
+    import fairseq  # noqa: F401
+    import espresso  # noqa: F401
+    from espresso.models.transformer.speech_transformer_config import SpeechTransformerConfig
+
+    cfg = SpeechTransformerConfig()
+    e = cfg.encoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = d, ffn, layers, heads
+    e.normalize_before, e.learned_pos, e.relative_positional_embeddings = True, False, True
+    e.layer_type = layer_type
+    e.depthwise_conv_kernel_size = 31
+    e.conv_channels = conv_channels
+    e.xformers_att_config = None
+    e.layerdrop = 0.0
+    e.transformer_context = None
+    e.chunk_size = 0
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    cfg.tpu = False
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.activation_fn = "relu"
+    cfg.layernorm_embedding = True
+    cfg.no_scale_embedding = False
+    cfg.no_token_positional_embeddings = False
+    cfg.adaptive_input = False
+    cfg.quant_noise.pq = 0.0
+    cfg.quant_noise.pq_block_size = 8
+    cfg.export = False
+    cfg.checkpoint_activations = False
+    cfg.offload_activations = False
+    cfg.min_params_to_wrap = int(1e8)
+    return cfg
+
+
+def build_ref_encoder(cfg, vocab):
+    from espresso.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderForPrediction
+    from espresso.modules.speech_convolutions import ConvBNReLU
+    import ast
+
+    ch = ast.literal_eval(cfg.encoder.conv_channels)
+    pre = ConvBNReLU(ch, [(3, 3)] * 4, [(1, 1), (2, 2), (1, 1), (2, 2)], in_channels=1)
+    return SpeechTransformerEncoderForPrediction(cfg, pre_encoder=pre, input_size=20 * ch[-1], vocab_size=vocab)
+
+
+def encoder_fixture(layer_type, name):
+    torch.manual_seed(1234)
+    V = 40
+    cfg = ref_config(layer_type)
+    enc = build_ref_encoder(cfg, V)
+    # make BN affine / running stats and biases non-trivial so the check exercises them
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+        for n, b in enc.named_buffers():
+            if "running_mean" in n:
+                b.copy_(0.1 * torch.randn_like(b))
+            if "running_var" in n:
+                b.copy_(1.0 + 0.2 * torch.rand_like(b))
+    B, T = 3, 70
+    lengths = torch.tensor([70, 61, 37])
+    feats = torch.randn(B, T, 80)
+    for b in range(B):
+        feats[b, lengths[b]:] = 0.0
+    targets = [torch.randint(4, V, (int(L),)) for L in (7, 5, 3)]
+    tgt = torch.full((B, 7), 1, dtype=torch.long)
+    for b, t in enumerate(targets):
+        tgt[b, : len(t)] = t
+    out = {}
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    # ---- eval mode ----
+    enc.eval()
+    with torch.no_grad():
+        o = enc(feats, lengths)
+    out["eval_logits"] = o["encoder_out"][0].numpy()  # T' x B x V
+    out["out_lengths"] = o["src_lengths"][0].numpy()
+    # ---- train mode (dropout 0): BN uses batch statistics ; loss + grads ----
+    enc.train()
+    o = enc(feats, lengths)
+    logits = o["encoder_out"][0]
+    lprobs = torch.log_softmax(logits.float(), dim=-1)
+    in_len = o["src_lengths"][0]
+    tl = torch.tensor([len(t) for t in targets])
+    flat = torch.cat(targets)
+    with torch.backends.cudnn.flags(enabled=False):
+        loss = torch.nn.functional.ctc_loss(lprobs, flat, in_len, tl, blank=0, reduction="sum", zero_infinity=True)
+    loss.backward()
+    out["train_logits"] = logits.detach().numpy()
+    out["train_loss"] = np.array(loss.item(), dtype=np.float64)
+    grads = {}
+    for n, p in enc.named_parameters():
+        grads[n] = p.grad.detach().numpy()
+    sd_after = {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        feats=feats.numpy(), lengths=lengths.numpy(), targets=tgt.numpy(),
+        **{"sd::" + k: v.numpy() for k, v in sd.items()},
+        **{"out::" + k: v for k, v in out.items()},
+        **{"grad::" + k: v for k, v in grads.items()},
+        **{"bn_after::" + k: v.numpy() for k, v in sd_after.items()},
+    )
+    print(name, "loss", loss.item(), "params", sum(p.numel() for p in enc.parameters()))
+
+
+def label_smoothing_fixture():
+    from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
+
+    torch.manual_seed(7)
+    V, M = 37, 23
+    logits = torch.randn(M, V) * 2
+    target = torch.randint(2, V, (M,))
+    target[[3, 11]] = 1  # pad
+    lprobs = torch.log_softmax(logits, -1)
+    res = {}
+    for eps in (0.0, 0.1):
+        loss, nll = label_smoothed_nll_loss(lprobs, target.unsqueeze(-1), eps, ignore_index=1, reduce=True)
+        res[f"loss_{eps}"] = loss.item()
+        res[f"nll_{eps}"] = nll.item()
+    lg = logits.clone().requires_grad_(True)
+    loss, _ = label_smoothed_nll_loss(torch.log_softmax(lg, -1), target.unsqueeze(-1), 0.1, ignore_index=1, reduce=True)
+    loss.backward()
+    np.savez(os.path.join(OUT, "label_smoothing.npz"), logits=logits.numpy(), target=target.numpy(),
+             dlogits=lg.grad.numpy(), **{k: np.array(v) for k, v in res.items()})
+    print("label smoothing", res)
+
+
+def specaug_fixture():
+    """AdaptiveSpecAugment mask parameters + result under numpy_seed(seed, epoch, index)."""
+    from espresso.data.feature_transforms.adaptive_specaugment import AdaptiveSpecAugmentTransform
+    from fairseq.data import data_utils
+
+    tr = AdaptiveSpecAugmentTransform.from_config_dict(
+        {"freq_mask_N": 2, "freq_mask_F": 27, "time_mask_pm": 0.04, "time_mask_ps": 0.04})
+    rng = np.random.default_rng(3)
+    outs = {}
+    for k, (M, idx) in enumerate([(313, 5), (1000, 17), (40, 2)]):
+        spec = rng.standard_normal((M, 80))
+        with data_utils.numpy_seed(1, 2, idx):
+            o = tr(spec)
+        outs[f"in_{k}"] = spec
+        outs[f"out_{k}"] = o
+        outs[f"meta_{k}"] = np.array([M, idx])
+    np.savez_compressed(os.path.join(OUT, "specaug.npz"), **outs)
+    print("specaug ok")
+
+
+def batch_by_size_fixture():
+    """The reference's slow python baseline (tests/test_data_utils.py:15-41 semantics) is not importable as a
+    module function; use fairseq.data.data_utils.batch_by_size with the pure-python fallback path if available."""
+    pass
+
+
+if __name__ == "__main__":
+    encoder_fixture("conformer", "ref_conformer_ctc_tiny")
+    encoder_fixture("transformer", "ref_transformer_ctc_tiny")
+    label_smoothing_fixture()
+    specaug_fixture()

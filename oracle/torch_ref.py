@@ -1,0 +1,207 @@
+"""TEST INFRASTRUCTURE ONLY — fp32 CPU restatement of the reference's encoder arithmetic, driven by a
+reference-format state_dict.  Pinned against the golden fixtures produced by the reference's own
+modules (tests/golden/ref_*_ctc_tiny.npz, see oracle/gen_golden.py) in tests/test_oracle.py.
+
+Each function cites the reference code it follows (paths relative to the reference root)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def sinusoidal_rel_pe(seq_len, dim):
+    """espresso/modules/sinusoidal_relative_positional_embedding.py:46-71,112-124 with
+    scale_embedding (relative_positional_embedding.py:28-34): rows = offsets -(L-1)..(L-1)."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+    e = torch.arange(seq_len, dtype=torch.float).unsqueeze(1) * e.unsqueeze(0)
+    pos = torch.cat([torch.sin(e), torch.cos(e)], 1)
+    neg = torch.cat([torch.sin(-e), torch.cos(-e)], 1)
+    neg = torch.flip(neg, [0])
+    return dim ** -0.5 * torch.cat([neg, pos[1:]], 0)
+
+
+def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
+    """fairseq/modules/multihead_attention.py:650-907 (rel-pos branch).  x: (T, B, C)."""
+    T, B, C = x.shape
+    dh = C // H
+    scaling = dh ** -0.5
+    q = F.linear(x, sd[prefix + "q_proj.weight"], sd[prefix + "q_proj.bias"])
+    k = F.linear(x, sd[prefix + "k_proj.weight"], sd[prefix + "k_proj.bias"])
+    v = F.linear(x, sd[prefix + "v_proj.weight"], sd[prefix + "v_proj.bias"])
+    relpos = (prefix + "pos_bias_u") in sd
+    if relpos:
+        qv = ((q + sd[prefix + "pos_bias_v"]) * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
+        q = q + sd[prefix + "pos_bias_u"]
+    q = (q * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
+    k = k.contiguous().view(T, B * H, dh).transpose(0, 1)
+    v = v.contiguous().view(T, B * H, dh).transpose(0, 1)
+    w = torch.bmm(q, k.transpose(1, 2))
+    if relpos:
+        pe = sinusoidal_rel_pe(T, C)
+        pe = F.linear(pe, sd[prefix + "pos_proj.weight"])  # (2T-1, C), same for every batch element
+        pe = pe.view(1, 2 * T - 1, H, dh).expand(B, -1, -1, -1).transpose(1, 2).reshape(B * H, 2 * T - 1, dh)
+        raw = torch.bmm(qv, pe.transpose(1, 2))  # (BH, T, 2T-1)
+        i = torch.arange(T).unsqueeze(1)
+        j = torch.arange(T).unsqueeze(0)
+        w = w + raw.gather(2, ((T - 1) - i + j).unsqueeze(0).expand(B * H, -1, -1))
+    if attn_mask is not None:
+        w = w + attn_mask.unsqueeze(0)
+    if key_padding_mask is not None:
+        w = w.view(B, H, T, T).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(B * H, T, T)
+    p = torch.softmax(w.float(), dim=-1)
+    a = torch.bmm(p, v).transpose(0, 1).contiguous().view(T, B, C)
+    return F.linear(a, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+
+
+def _ln(x, sd, prefix):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + "weight"], sd[prefix + "bias"], 1e-5)
+
+
+def _ffn_conformer(x, sd, p):
+    """fairseq/modules/conformer_layer.py:134-146 (swish)."""
+    y = _ln(x, sd, p + "layer_norm.")
+    y = F.linear(y, sd[p + "w_1.weight"], sd[p + "w_1.bias"])
+    y = F.silu(y)
+    return F.linear(y, sd[p + "w_2.weight"], sd[p + "w_2.bias"])
+
+
+def _bn(x, sd, p, training, dim_c=1, momentum=0.1, eps=1e-5, update=None):
+    rm, rv = sd[p + "running_mean"].clone(), sd[p + "running_var"].clone()
+    y = F.batch_norm(x, rm, rv, sd[p + "weight"], sd[p + "bias"], training, momentum, eps)
+    if update is not None and training:
+        update[p + "running_mean"], update[p + "running_var"] = rm, rv
+    return y
+
+
+def conv_module(x_btc, sd, p, training, update=None):
+    """fairseq/modules/conformer_layer.py:79-101.  x: (B, T, C)."""
+    y = _ln(x_btc, sd, p + "layer_norm.").transpose(1, 2)
+    y = F.conv1d(y, sd[p + "pointwise_conv1.weight"])
+    y = F.glu(y, dim=1)
+    w = sd[p + "depthwise_conv.weight"]
+    y = F.conv1d(y, w, padding=(w.shape[-1] - 1) // 2, groups=w.shape[0])
+    y = _bn(y, sd, p + "batch_norm.", training, update=update)
+    y = F.silu(y)
+    y = F.conv1d(y, sd[p + "pointwise_conv2.weight"])
+    return y.transpose(1, 2)
+
+
+def conformer_layer(x, sd, p, H, key_padding_mask, training, update=None, attn_mask=None):
+    """espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:112-141.  x: (T,B,C)."""
+    x = 0.5 * _ffn_conformer(x, sd, p + "ffn1.") + x
+    x = relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x
+    x = conv_module(x.transpose(0, 1), sd, p + "conv_module.", training, update).transpose(0, 1) + x
+    x = 0.5 * _ffn_conformer(x, sd, p + "ffn2.") + x
+    return _ln(x, sd, p + "final_layer_norm.")
+
+
+def transformer_layer(x, sd, p, H, key_padding_mask, activation="relu", attn_mask=None):
+    """fairseq/modules/transformer_layer.py:163-226 with normalize_before=True."""
+    x = relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x
+    y = _ln(x, sd, p + "final_layer_norm.")
+    y = F.linear(y, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
+    y = F.relu(y) if activation == "relu" else F.silu(y)
+    y = F.linear(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return x + y
+
+
+def conv_bn_relu(feats, lengths, sd, p, strides, training, update=None):
+    """espresso/modules/speech_convolutions.py:78-102."""
+    B, T, Fd = feats.shape
+    x = feats.view(B, T, 1, Fd).transpose(1, 2)
+    out_len = lengths.clone()
+    i = 0
+    while (p + f"convolutions.{i}.weight") in sd:
+        s = strides[i]
+        x = F.conv2d(x, sd[p + f"convolutions.{i}.weight"], sd[p + f"convolutions.{i}.bias"], stride=s, padding=1)
+        x = F.relu(_bn(x, sd, p + f"batchnorms.{i}.", training, update=update))
+        out_len = torch.div(out_len + s[0] - 1, s[0], rounding_mode="floor")
+        i += 1
+    x = x.transpose(1, 2).contiguous()
+    x = x.view(x.size(0), x.size(1), -1)
+    pad = torch.arange(x.size(1)).unsqueeze(0) >= out_len.unsqueeze(1)
+    x = x.masked_fill(pad.unsqueeze(-1), 0.0)
+    return x, out_len, pad
+
+
+def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activation="relu",
+            strides=((1, 1), (2, 2), (1, 1), (2, 2)), update=None):
+    """espresso/models/transformer/speech_transformer_encoder.py:298-409 + fc_out
+    (speech_transformer_encoder_model.py:207-208), dropout = 0.  Returns (logits (T',B,V), out_lengths)."""
+    def _t(v):
+        if not torch.is_tensor(v):
+            v = torch.from_numpy(np.asarray(v))
+        return v.float() if v.is_floating_point() and v.dtype != torch.float32 else v
+
+    sd = {k: _t(v) for k, v in sd.items()}
+    x, out_len, pad = conv_bn_relu(feats.float(), lengths, sd, "pre_encoder.", strides, training, update)
+    x = F.linear(x, sd["fc0.weight"], sd["fc0.bias"])
+    x = _ln(x, sd, "layernorm_embedding.")
+    x = x * (1 - pad.unsqueeze(-1).float())
+    x = x.transpose(0, 1)
+    kpm = pad if bool(pad.any()) else None
+    i = 0
+    while f"layers.{i}.final_layer_norm.weight" in sd:
+        p = f"layers.{i}."
+        if layer_type == "conformer":
+            x = conformer_layer(x, sd, p, H, kpm, training, update)
+        else:
+            x = transformer_layer(x, sd, p, H, kpm, activation)
+        i += 1
+    if "layer_norm.weight" in sd:
+        x = _ln(x, sd, "layer_norm.")
+    if "fc_out.weight" in sd:
+        x = F.linear(x, sd["fc_out.weight"], sd["fc_out.bias"])
+    return x, out_len
+
+
+def ctc_loss_sum(logits_tbv, targets_padded, in_len, tgt_len, blank=0):
+    """espresso/criterions/ctc_loss.py:85-94 (sum, zero_infinity) on fp32 log-softmax."""
+    lp = torch.log_softmax(logits_tbv.float(), -1)
+    flat = torch.cat([targets_padded[b, : int(tgt_len[b])] for b in range(targets_padded.shape[0])])
+    with torch.backends.cudnn.flags(enabled=False):
+        return F.ctc_loss(lp, flat, in_len, tgt_len, blank=blank, reduction="sum", zero_infinity=True)
+
+
+def ctc_nll_numpy(lprobs_tv, target, blank=0):
+    """Plain alpha recursion (Graves 2006) in float64 for one utterance — an independent check of
+    the ATen kernel the reference calls.  lprobs_tv: (T, V) log-probabilities."""
+    T = lprobs_tv.shape[0]
+    ext = [blank]
+    for t in target:
+        ext += [int(t), blank]
+    S = len(ext)
+    a = np.full(S, -np.inf)
+    a[0] = lprobs_tv[0, blank]
+    if S > 1:
+        a[1] = lprobs_tv[0, ext[1]]
+    for t in range(1, T):
+        n = np.full(S, -np.inf)
+        for s in range(S):
+            c = [a[s]]
+            if s >= 1:
+                c.append(a[s - 1])
+            if s >= 2 and ext[s] != blank and ext[s] != ext[s - 2]:
+                c.append(a[s - 2])
+            m = max(c)
+            if m > -np.inf:
+                n[s] = m + np.log(sum(np.exp(v - m) for v in c)) + lprobs_tv[t, ext[s]]
+        a = n
+    tail = [a[S - 1]] + ([a[S - 2]] if S > 1 else [])
+    m = max(tail)
+    return np.inf if m == -np.inf else -(m + np.log(sum(np.exp(v - m) for v in tail)))
+
+
+def label_smoothed_nll(logits, target, eps, pad_idx):
+    """espresso/criterions/label_smoothed_cross_entropy_v2.py:94-119 (uniform)."""
+    lp = torch.log_softmax(logits.float(), -1)
+    nll = -lp.gather(-1, target.unsqueeze(-1)).squeeze(-1)
+    smooth = -lp.sum(-1)
+    m = target.eq(pad_idx)
+    nll = nll.masked_fill(m, 0.0)
+    smooth = smooth.masked_fill(m, 0.0)
+    eps_i = eps / (lp.size(-1) - 1)
+    return (1.0 - eps - eps_i) * nll.sum() + eps_i * smooth.sum(), nll.sum()

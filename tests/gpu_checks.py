@@ -1,0 +1,264 @@
+"""Parity checks of the HIP path against the oracle (oracle/) and the golden fixtures produced by
+the reference's own code (tests/golden/).  Shared by the `-m gpu` tests and __graft_entry__.smoke().
+Every HIP call goes through the C ABI (espresso_amd/_lib.py -> libespresso_amd.so)."""
+import math
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ------------------------------------------------------------------ GEMM
+def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, c_f32=False, seed=0):
+    from espresso_amd import kernels as Kk
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = bf(torch.randn(batch, K, M, generator=g) if a_ks else torch.randn(batch, M, K, generator=g)).to(DEV)
+    B = bf(torch.randn(batch, K, N, generator=g) if b_ks else torch.randn(batch, N, K, generator=g)).to(DEV)
+    Af = A.float().transpose(1, 2) if a_ks else A.float()
+    Bf = B.float().transpose(1, 2) if b_ks else B.float()
+    ref = torch.bmm(Af, Bf.transpose(1, 2))
+    bvec = torch.randn(N, generator=g).to(DEV) if bias else None
+    if bias:
+        ref = ref + bvec
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "silu":
+        ref = torch.nn.functional.silu(ref)
+    R = None
+    if resid:
+        R = bf(torch.randn(batch, M, N, generator=g)).to(DEV)
+        ref = ref * 0.5 + R.float()
+    C = torch.full((batch, M, N), float("nan"), dtype=torch.float32 if c_f32 else torch.bfloat16, device=DEV)
+    Kk.gemm(A, B, C, M, N, K, lda=M if a_ks else K, ldb=N if b_ks else K, ldc=N, a_kstrided=a_ks, b_kstrided=b_ks,
+            batch=batch, zdiv=1, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0), bias=bvec, act=act,
+            out_scale=0.5 if resid else 1.0, resid=R, ldr=N, sR=(M * N, 0))
+    torch.cuda.synchronize()
+    return rel_err(C, ref)
+
+
+# ------------------------------------------------------------------ model-level parity vs the reference fixture
+def load_fixture(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    grads = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad::")}
+    bn_after = {k[10:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("bn_after::")}
+    return g, sd, grads, bn_after
+
+
+class _Task:
+    feat_dim, feat_in_channels = 80, 1
+    blank_symbol = "<s>"
+
+    def __init__(self, V):
+        from espresso_amd.data.asr_dictionary import AsrDictionary
+
+        self.target_dictionary = AsrDictionary.from_symbols([f"t{i}" for i in range(V - 5)], enable_bos=True)
+        assert len(self.target_dictionary) == V
+
+
+def build_tiny_model(layer_type, V=40):
+    from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
+    from espresso_amd.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderModel
+
+    cfg = SpeechTransformerConfig()
+    e = cfg.encoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 64, 128, 2, 4
+    e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, layer_type
+    e.conv_channels = "[64, 64, 16, 16]"
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.layernorm_embedding = True
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    return SpeechTransformerEncoderModel.build_model(cfg, _Task(V))
+
+
+def load_ref_state(model, sd):
+    sd = {"encoder." + k: v for k, v in sd.items()}
+    sd = model.upgrade_state_dict_named(sd, "")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert not missing, missing
+
+
+def check_encoder_vs_reference(layer_type="conformer"):
+    """Load the reference's weights into the HIP model; compare eval logits, train logits (BN batch
+    stats), CTC loss and every parameter gradient with what the reference's own modules produced."""
+    from espresso_amd import functional as F
+
+    name = f"ref_{layer_type}_ctc_tiny"
+    g, sd, grads, bn_after = load_fixture(name)
+    model = build_tiny_model(layer_type).to(DEV)
+    load_ref_state(model, sd)
+    feats = torch.from_numpy(g["feats"]).to(DEV)
+    lengths = torch.from_numpy(g["lengths"]).to(DEV)
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        out = model(feats, lengths)
+    lo = out["encoder_out"][0].float().cpu()
+    ref = torch.from_numpy(g["out::eval_logits"])
+    res["eval_logits_abs"] = float((lo - ref).abs().max())
+    res["eval_lengths_equal"] = bool((out["src_lengths"][0].cpu().numpy() == g["out::out_lengths"]).all())
+    # greedy ids over valid frames
+    ol = g["out::out_lengths"]
+    agree = []
+    for b in range(lo.shape[1]):
+        agree.append(float((lo[: ol[b], b].argmax(-1) == ref[: ol[b], b].argmax(-1)).float().mean()))
+    res["eval_greedy_agree"] = min(agree)
+    # train mode
+    model.train()
+    out = model(feats, lengths)
+    lo = out["encoder_out"][0].float().cpu()
+    res["train_logits_abs"] = float((lo.detach() - torch.from_numpy(g["out::train_logits"])).abs().max())
+    tgt = torch.from_numpy(g["targets"]).to(DEV)
+    tl = (tgt != 1).sum(-1)
+    B, Tp = out["encoder_padding_mask"][0].shape
+    nll, _ = F.ctc_loss(out["_logits_bt"][0], tgt.to(torch.int32).contiguous(), out["src_lengths"][0].to(torch.int32),
+                        tl.to(torch.int32), B, Tp, blank=0)
+    loss = nll.sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    res["train_loss"] = float(loss)
+    res["ref_loss"] = float(g["out::train_loss"])
+    worst = ("", 0.0)
+    for n, p in model.encoder.named_parameters():
+        r = grads[n]
+        gr = p.grad.float().cpu()
+        e = float((gr - r).abs().max() / (r.abs().max() + 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    res["worst_grad"] = worst
+    bn = 0.0
+    msd = model.encoder.state_dict()
+    for k, v in bn_after.items():
+        bn = max(bn, float((msd[k].float().cpu() - v).abs().max()))
+    res["bn_running_abs"] = bn
+    return res
+
+
+# ------------------------------------------------------------------ CTC alone (fp32 path, 1e-3 bar)
+def check_ctc(B=5, T=60, V=57, Lmax=9, seed=0):
+    from espresso_amd import functional as F
+
+    g = torch.Generator().manual_seed(seed)
+    logits = (torch.randn(B, T, V, generator=g) * 2).float()
+    in_len = torch.tensor([T, T - 7, T // 2, 11, T][:B])
+    tgt_len = torch.tensor([Lmax, 3, 5, 1, 0][:B])
+    tgt = torch.ones(B, Lmax, dtype=torch.long)
+    for b in range(B):
+        tgt[b, : tgt_len[b]] = torch.randint(1, V, (int(tgt_len[b]),), generator=g)
+    tgt[0, 1] = tgt[0, 0]  # repeated label
+    lg = logits.clone().requires_grad_(True)
+    lp = torch.log_softmax(lg, -1).transpose(0, 1)
+    flat = torch.cat([tgt[b, : tgt_len[b]] for b in range(B)])
+    ref = torch.nn.functional.ctc_loss(lp, flat, in_len, tgt_len, blank=0, reduction="none", zero_infinity=True)
+    ref.sum().backward()
+    x = logits.to(DEV).reshape(B * T, V).clone().requires_grad_(True)
+    nll, lprobs = F.ctc_loss(x, tgt.to(torch.int32).to(DEV), in_len.to(torch.int32).to(DEV), tgt_len.to(torch.int32).to(DEV), B, T, 0)
+    nll2 = torch.where(torch.isinf(nll), torch.zeros_like(nll), nll)
+    nll2.sum().backward()
+    torch.cuda.synchronize()
+    return {
+        "nll_abs": float((nll2.cpu() - ref.detach()).abs().max()),
+        "grad_abs": float((x.grad.cpu().view(B, T, V) - lg.grad).abs().max()),
+        "lprobs_abs": float((lprobs.cpu().view(B, T, V) - torch.log_softmax(logits, -1)).abs().max()),
+    }
+
+
+# ------------------------------------------------------------------ fbank + CMVN + SpecAugment vs numpy oracle
+def check_frontend(seed=0):
+    from espresso_amd.data.feature_transforms import AdaptiveSpecAugmentTransform, GlobalCMVN, numpy_seed_value
+    from espresso_amd.data.gpu_frontend import GpuFbankFrontend
+    from oracle import fbank_ref
+
+    rng = np.random.default_rng(seed)
+    ns = [16000 * 3 + 123, 399, 400, 16000, 16000 * 5 + 7]
+    wavs = [(rng.standard_normal(n) * 3000).astype(np.float32) for n in ns]
+    mean = rng.standard_normal(80) * 2 + 8
+    std = rng.random(80) + 2.0
+    sa = AdaptiveSpecAugmentTransform.from_config_dict({"freq_mask_N": 2, "freq_mask_F": 27, "time_mask_pm": 0.04, "time_mask_ps": 0.04})
+    fe = GpuFbankFrontend(DEV, cmvn=GlobalCMVN(mean=mean, std=std), specaug=sa, seed=1)
+    off = np.zeros(len(ns) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(ns)
+    wav = torch.from_numpy(np.concatenate(wavs)).to(DEV)
+    offs = torch.from_numpy(off).to(DEV)
+    res = {}
+    feat, lens, frames = fe(wav, offs, ns, train=False)
+    torch.cuda.synchronize()
+    feat = feat.cpu().numpy()
+    worst = 0.0
+    for b, w in enumerate(wavs):
+        ref = fbank_ref.global_cmvn(fbank_ref.fbank(w), mean, std)
+        assert ref.shape[0] == frames[b] == int(lens[b])
+        if ref.shape[0]:
+            worst = max(worst, float(np.abs(feat[b, : ref.shape[0]] - ref).max()))
+        assert np.all(feat[b, ref.shape[0]:] == 0)
+    res["fbank_cmvn_abs"] = worst
+    # SpecAugment with the reference's RNG stream
+    idx = [5, 17, 2, 9, 11]
+    feat2, lens, frames = fe(wav, offs, ns, train=True, epoch=2, indices=idx)
+    torch.cuda.synchronize()
+    feat2 = feat2.cpu().numpy()
+    worst = 0.0
+    for b, w in enumerate(wavs):
+        ref = fbank_ref.global_cmvn(fbank_ref.fbank(w), mean, std)
+        if ref.shape[0] == 0:
+            continue
+        state = np.random.get_state()
+        np.random.seed(numpy_seed_value(1, 2, idx[b]))
+        fm, tm = sa.draw_masks(ref.shape[0], 80)
+        np.random.set_state(state)
+        ref2 = fbank_ref.specaugment_apply(ref.astype(np.float64), fm, tm, None)
+        worst = max(worst, float(np.abs(feat2[b, : ref.shape[0]] - ref2).max()))
+    res["specaug_abs"] = worst
+    return res
+
+
+# ------------------------------------------------------------------ Adam / clip
+def check_adam(n=100003, steps=3):
+    from espresso_amd import kernels as Kk
+
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-2, betas=(0.9, 0.98), eps=1e-8)
+    dp, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p16 = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    sumsq = torch.zeros(1, device=DEV)
+    coef = torch.zeros(2, device=DEV)
+    for s in range(1, steps + 1):
+        grad = torch.randn(n, generator=g) * 3
+        ref_p.grad = grad.clone() / 4.0
+        torch.nn.utils.clip_grad_norm_([ref_p], 2.0)
+        opt.step()
+        dg = grad.to(DEV)
+        sumsq.zero_()
+        Kk.grad_sumsq(dg, sumsq)
+        Kk.clip_coef(sumsq, 1.0, 2.0, coef, torch.tensor([4.0], device=DEV))
+        Kk.adam_step(dp, dg, m, v, p16, coef, 1e-2, 0.9, 0.98, 1e-8, 0.0, s, zero_grad=True)
+        assert float(dg.abs().max()) == 0.0
+    torch.cuda.synchronize()
+    return {"param_abs": float((dp.cpu() - ref_p.detach()).abs().max()),
+            "bf16_abs": float((p16.float().cpu() - ref_p.detach().to(torch.bfloat16).float()).abs().max())}
+
+
+# ------------------------------------------------------------------ smoke
+def smoke_check():
+    r = check_encoder_vs_reference("conformer")
+    print("smoke:", r)
+    assert abs(r["train_loss"] - r["ref_loss"]) / r["ref_loss"] < 2e-2, r
+    assert r["eval_lengths_equal"]
+    return r

@@ -1,0 +1,65 @@
+"""`-m gpu` parity tests: HIP path (through the C ABI) vs the oracle / reference golden fixtures."""
+import pytest
+import torch
+
+from tests import gpu_checks as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from espresso_amd import _lib
+
+    _lib.lib()  # the HIP library must be the thing under test — fail loudly if it is missing
+
+
+@pytest.mark.parametrize("a_ks,b_ks", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (257, 190, 100), (77, 40, 16), (300, 513, 333)])
+def test_gemm_modes(a_ks, b_ks, shape):
+    M, N, K = shape
+    if (a_ks and M % 8) or (b_ks and N % 8):
+        pass  # unaligned leading dims exercise the guarded scalar path
+    e = G.check_gemm(M, N, K, a_ks, b_ks, batch=2)
+    assert e < 1e-2, e
+
+
+def test_gemm_epilogues():
+    assert G.check_gemm(200, 136, 72, False, False, bias=True, act="silu") < 1e-2
+    assert G.check_gemm(200, 136, 72, False, False, bias=True, act="relu", resid=True) < 1e-2
+    assert G.check_gemm(130, 64, 520, True, True, c_f32=True) < 2e-3
+
+
+def test_ctc_fp32():
+    r = G.check_ctc()
+    assert r["lprobs_abs"] < 1e-4, r
+    assert r["nll_abs"] < 1e-3, r
+    assert r["grad_abs"] < 1e-3, r
+
+
+def test_frontend_fbank_specaug():
+    r = G.check_frontend()
+    assert r["fbank_cmvn_abs"] < 1e-3, r
+    assert r["specaug_abs"] < 1e-3, r
+
+
+def test_adam_clip():
+    r = G.check_adam()
+    assert r["param_abs"] < 1e-5, r
+    assert r["bf16_abs"] < 1e-2, r
+
+
+@pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
+def test_encoder_vs_reference_fixture(layer_type):
+    r = G.check_encoder_vs_reference(layer_type)
+    print(r)
+    assert r["eval_lengths_equal"]
+    # bf16 compute vs the reference's fp32 run: north_star tolerance 1e-2 on log-probs/losses (relative for the loss)
+    assert abs(r["train_loss"] - r["ref_loss"]) / r["ref_loss"] < 1e-2, r
+    assert r["eval_logits_abs"] < 6e-2, r
+    assert r["train_logits_abs"] < 6e-2, r
+    assert r["eval_greedy_agree"] > 0.9, r
+    assert r["worst_grad"][1] < 8e-2, r
+    assert r["bn_running_abs"] < 2e-2, r
