@@ -48,7 +48,7 @@ def test_frontend_fbank_specaug():
 def test_adam_clip():
     r = G.check_adam()
     assert r["param_abs"] < 1e-5, r
-    assert r["bf16_abs"] < 1e-2, r
+    assert r["bf16_exact"], r
 
 
 @pytest.mark.parametrize("layer_type", ["conformer", "transformer"])

@@ -1,0 +1,91 @@
+"""CPU tests that PIN the oracle: the restatements in oracle/ must reproduce what the reference's own
+modules produced (golden fixtures written by oracle/gen_golden.py from /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fbank_ref, torch_ref
+
+
+def _load(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    return g, sd
+
+
+@pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
+def test_encoder_restatement_matches_reference(golden_dir, layer_type):
+    g, sd = _load(golden_dir, f"ref_{layer_type}_ctc_tiny")
+    feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=4, layer_type=layer_type, training=False)
+    assert ol.tolist() == g["out::out_lengths"].tolist()
+    assert float((lo - torch.from_numpy(g["out::eval_logits"])).abs().max()) < 1e-5
+    upd = {}
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=4, layer_type=layer_type, training=True, update=upd)
+    assert float((lo - torch.from_numpy(g["out::train_logits"])).abs().max()) < 1e-5
+    tgt = torch.from_numpy(g["targets"])
+    tl = (tgt != 1).sum(-1)
+    loss = torch_ref.ctc_loss_sum(lo, tgt, ol, tl)
+    assert float(loss) == pytest.approx(float(g["out::train_loss"]), rel=1e-6)
+    for k, v in upd.items():
+        assert float((v - torch.from_numpy(g["bn_after::" + k])).abs().max()) < 1e-5
+    # independent float64 alpha recursion agrees with the ATen kernel the reference calls
+    lp = torch.log_softmax(lo.float(), -1).numpy()
+    tot = sum(torch_ref.ctc_nll_numpy(lp[: int(ol[b]), b], tgt[b, : int(tl[b])].tolist()) for b in range(tgt.shape[0]))
+    assert tot == pytest.approx(float(g["out::train_loss"]), rel=1e-5)
+
+
+def test_encoder_restatement_gradients(golden_dir):
+    g, sd = _load(golden_dir, "ref_conformer_ctc_tiny")
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and k != "version":
+            v.requires_grad_(True)
+    feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=4, layer_type="conformer", training=True)
+    tgt = torch.from_numpy(g["targets"])
+    torch_ref.ctc_loss_sum(lo, tgt, ol, (tgt != 1).sum(-1)).backward()
+    for name in ("fc_out.weight", "layers.0.self_attn.pos_bias_u", "layers.1.conv_module.depthwise_conv.weight",
+                 "pre_encoder.convolutions.0.weight", "fc0.weight"):
+        ref = torch.from_numpy(g["grad::" + name])
+        assert float((sd[name].grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6, name
+
+
+def test_label_smoothing_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "label_smoothing.npz"))
+    logits, target = torch.from_numpy(g["logits"]), torch.from_numpy(g["target"])
+    for eps in (0.0, 0.1):
+        loss, nll = torch_ref.label_smoothed_nll(logits, target, eps, pad_idx=1)
+        assert float(loss) == pytest.approx(float(g[f"loss_{eps}"]), rel=1e-6)
+        assert float(nll) == pytest.approx(float(g[f"nll_{eps}"]), rel=1e-6)
+
+
+def test_fbank_frame_count_matches_reference_formula():
+    """espresso/tools/utils.py:457-486 pins only the frame count of the torchaudio fbank."""
+    from espresso_amd.tools.utils import num_samples_to_num_frames
+
+    rng = np.random.default_rng(0)
+    for n in (0, 399, 400, 401, 559, 560, 16000, 16000 * 3 + 77):
+        w = (rng.standard_normal(n) * 1000).astype(np.float32)
+        assert fbank_ref.fbank(w).shape == (num_samples_to_num_frames([n], 16000)[0], 80)
+
+
+def test_fbank_closed_form_properties():
+    """Analytic checks of the restatement: a DC signal has zero energy after DC removal (log floor),
+    and a pure tone peaks in the mel bin that contains it."""
+    x = np.full(16000, 1234.0, dtype=np.float32)
+    f = fbank_ref.fbank(x)
+    assert np.allclose(f, np.log(np.finfo(np.float32).eps), atol=1e-3)
+    t = np.arange(16000) / 16000.0
+    tone = (8000 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
+    f = fbank_ref.fbank(tone)
+    bank = fbank_ref.mel_banks()
+    expect = int(np.argmax(bank[:, 32]))  # 1000 Hz = FFT bin 32
+    assert abs(int(np.argmax(f.mean(0))) - expect) <= 1
+
+
+def test_product_mel_tables_equal_oracle_bank():
+    from espresso_amd.data.fbank_tables import build_mel_bank
+
+    np.testing.assert_array_equal(build_mel_bank(), fbank_ref.mel_banks())
