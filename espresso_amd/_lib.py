@@ -59,6 +59,8 @@ class EaGemmParams(ctypes.Structure):
         ("drop_seed", ctypes.c_uint64),
         ("drop_thr", ctypes.c_uint32),
         ("drop_scale", ctypes.c_float),
+        ("splitk", ctypes.c_int),
+        ("kchunk", ctypes.c_int),
     ]
 
 

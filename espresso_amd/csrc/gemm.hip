@@ -123,6 +123,107 @@ __device__ __forceinline__ float apply_dact(float z, int act) {
   return 1.f;
 }
 
+// ---- epilogue on 8 consecutive output columns of one row --------------------------------------
+__device__ __forceinline__ void load8_bf16(const bf16_t* q, bool vec, int cnt, float (&o)[8]) {
+  if (vec) {
+    const uint4 u = *reinterpret_cast<const uint4*>(q);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = __uint_as_float(w[e] << 16);
+      o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = e < cnt ? bf2f(q[e]) : 0.f;
+  }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* q, bool vec, int cnt, const float (&v)[8]) {
+  if (vec) {
+    uint4 u;
+    u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(q) = u;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < cnt) q[e] = f2bf(v[e]);
+  }
+}
+
+__device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int zhi, int zlo, long coff, int m, int n,
+                                               float (&v)[8], bool vec_ok) {
+  const int cnt = min(8, p.N - n);
+  const bool vec = vec_ok && cnt == 8;
+  const bool has_drop = p.drop_thr != 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] *= p.alpha;
+    if (p.bias && e < cnt) v[e] += p.bias[n + e];
+  }
+  const uint64_t didx = ((uint64_t)z * (uint64_t)p.M + (uint64_t)m) * (uint64_t)p.N + (uint64_t)n;
+  const long co = coff + (long)m * p.ldc + n;
+  if (p.splitk > 1) {  // split-K partial: fp32 accumulate only (host enforces no other epilogue)
+    float* C = reinterpret_cast<float*>(p.C) + co;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < cnt) atomicAdd(C + e, v[e]);
+    return;
+  }
+  if (p.aux) {
+    float zz[8];
+    load8_bf16(reinterpret_cast<const bf16_t*>(p.aux) + (long)zhi * p.sX_hi + (long)zlo * p.sX_lo + (long)m * p.ldaux + n,
+               vec && (p.ldaux & 7) == 0 && ((((uintptr_t)p.aux) & 15) == 0) && (((p.sX_hi | p.sX_lo) & 7) == 0), cnt, zz);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (has_drop) v[e] *= ea_keep(p.drop_seed, didx + e, p.drop_thr, p.drop_scale);
+      v[e] *= apply_dact(zz[e], p.act);
+    }
+  } else {
+    if (p.C2) {
+      store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = apply_act(v[e], p.act);
+        if (has_drop) v[e] *= ea_keep(p.drop_seed, didx + e, p.drop_thr, p.drop_scale);
+      }
+      store8_bf16(reinterpret_cast<bf16_t*>(p.C2) + coff + (long)m * p.ldc2 + n,
+                  vec && (p.ldc2 & 7) == 0 && ((((uintptr_t)p.C2) & 15) == 0), cnt, v);
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = apply_act(v[e], p.act);
+      if (has_drop) v[e] *= ea_keep(p.drop_seed, didx + e, p.drop_thr, p.drop_scale);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+  if (p.resid) {
+    const long ro = (long)zhi * p.sR_hi + (long)zlo * p.sR_lo + (long)m * p.ldr + n;
+    if (p.resid_f32) {
+      const float* r = reinterpret_cast<const float*>(p.resid) + ro;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (e < cnt) v[e] += r[e];
+    } else {
+      float rr[8];
+      load8_bf16(reinterpret_cast<const bf16_t*>(p.resid) + ro,
+                 vec && (p.ldr & 7) == 0 && ((((uintptr_t)p.resid) & 15) == 0) && (((p.sR_hi | p.sR_lo) & 7) == 0), cnt, rr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rr[e];
+    }
+  }
+  if (p.c_f32) {
+    float* C = reinterpret_cast<float*>(p.C) + co;
+    if (vec_ok && cnt == 8 && !p.accumulate && (p.ldc & 3) == 0 && ((((uintptr_t)C) & 15) == 0)) {
+      *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (e < cnt) C[e] = p.accumulate ? C[e] + v[e] : v[e];
+    }
+  } else {
+    store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v);
+  }
+}
+
 template <bool A_KS, bool B_KS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BM * ROW_BYTES];
@@ -133,12 +234,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int z = blockIdx.z;
+  const int z = blockIdx.z / p.splitk;
+  const int ks_id = blockIdx.z % p.splitk;
   const int zhi = z / p.zdiv, zlo = z % p.zdiv;
 
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)zhi * p.sA_hi + (long)zlo * p.sA_lo;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long)zhi * p.sB_hi + (long)zlo * p.sB_lo;
   const long coff = (long)zhi * p.sC_hi + (long)zlo * p.sC_lo;
+
+  // split-K: this block reduces k in [kbeg, kend)
+  const int kbeg = ks_id * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -147,9 +253,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[4], rb[4];
-  const int nk = (p.K + BK - 1) / BK;
-  if (A_KS) load_ks(A, p.lda, p.M, p.K, m0, 0, tid, ra); else load_kc(A, p.lda, p.M, p.K, m0, 0, tid, ra);
-  if (B_KS) load_ks(B, p.ldb, p.N, p.K, n0, 0, tid, rb); else load_kc(B, p.ldb, p.N, p.K, n0, 0, tid, rb);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  if (nk > 0) {
+    if (A_KS) load_ks(A, p.lda, p.M, kend, m0, kbeg, tid, ra); else load_kc(A, p.lda, p.M, kend, m0, kbeg, tid, ra);
+    if (B_KS) load_ks(B, p.ldb, p.N, kend, n0, kbeg, tid, rb); else load_kc(B, p.ldb, p.N, kend, n0, kbeg, tid, rb);
+  }
 
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
@@ -157,9 +265,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
     if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
     __syncthreads();
     if (kt + 1 < nk) {
-      const int k0 = (kt + 1) * BK;
-      if (A_KS) load_ks(A, p.lda, p.M, p.K, m0, k0, tid, ra); else load_kc(A, p.lda, p.M, p.K, m0, k0, tid, ra);
-      if (B_KS) load_ks(B, p.ldb, p.N, p.K, n0, k0, tid, rb); else load_kc(B, p.ldb, p.N, p.K, n0, k0, tid, rb);
+      const int k0 = kbeg + (kt + 1) * BK;
+      if (A_KS) load_ks(A, p.lda, p.M, kend, m0, k0, tid, ra); else load_kc(A, p.lda, p.M, kend, m0, k0, tid, ra);
+      if (B_KS) load_ks(B, p.ldb, p.N, kend, n0, k0, tid, rb); else load_kc(B, p.ldb, p.N, kend, n0, k0, tid, rb);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -185,51 +293,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
     }
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------
+  // ---- epilogue: accumulators -> fp32 LDS tile (64 rows at a time) -> coalesced 16/32-byte stores ----
   // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wn*64 + j*16 + (lane&15)]
-  const bool has_drop = p.drop_thr != 0;
+  float* sC = reinterpret_cast<float*>(smem);  // [64][128] fp32 = 32 KiB
+  const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wm == half) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-      if (m >= p.M) continue;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-        if (n >= p.N) continue;
-        float v = p.alpha * acc[i][j][r];
-        if (p.bias) v += p.bias[n];
-        const uint64_t didx = ((uint64_t)z * (uint64_t)p.M + (uint64_t)m) * (uint64_t)p.N + (uint64_t)n;
-        if (p.aux) {
-          // backward-through-activation: v is d(out of dropout(act(z))) ; aux holds z
-          const float zz = bf2f(reinterpret_cast<const bf16_t*>(p.aux)[(long)zhi * p.sX_hi + (long)zlo * p.sX_lo + (long)m * p.ldaux + n]);
-          if (has_drop) v *= ea_keep(p.drop_seed, didx, p.drop_thr, p.drop_scale);
-          v *= apply_dact(zz, p.act);
-        } else {
-          if (p.C2) {
-            // C keeps the pre-activation, C2 the activated (+dropout) value
-            reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n] = f2bf(v);
-            float y = apply_act(v, p.act);
-            if (has_drop) y *= ea_keep(p.drop_seed, didx, p.drop_thr, p.drop_scale);
-            reinterpret_cast<bf16_t*>(p.C2)[coff + (long)m * p.ldc2 + n] = f2bf(y);
-            continue;
-          }
-          v = apply_act(v, p.act);
-          if (has_drop) v *= ea_keep(p.drop_seed, didx, p.drop_thr, p.drop_scale);
-        }
-        v *= p.out_scale;
-        if (p.resid) {
-          const long ro = (long)zhi * p.sR_hi + (long)zlo * p.sR_lo + (long)m * p.ldr + n;
-          v += p.resid_f32 ? reinterpret_cast<const float*>(p.resid)[ro]
-                           : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[ro]);
-        }
-        const long co = coff + (long)m * p.ldc + n;
-        if (p.c_f32) {
-          float* C = reinterpret_cast<float*>(p.C);
-          C[co] = p.accumulate ? C[co] + v : v;
-        } else {
-          reinterpret_cast<bf16_t*>(p.C)[co] = f2bf(v);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (m0 + half * 64 < p.M) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int rl = pass * 16 + (tid >> 4);
+        const int m = m0 + half * 64 + rl;
+        const int n = n0 + (tid & 15) * 8;
+        if (m < p.M && n < p.N) {
+          float v[8];
+          const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
+          const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          epilogue_chunk(p, z, zhi, zlo, coff, m, n, v, vec_ok);
         }
       }
     }
@@ -242,13 +334,25 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   const EaGemmParams& p = *pp;
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
   if (p.K <= 0 || p.zdiv <= 0) return -2;
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch), block(256);
-  if (p.a_kstrided) {
-    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, stream, p);
+  EaGemmParams q = p;
+  if (q.splitk < 1) q.splitk = 1;
+  if (q.splitk > 1) {
+    // partial sums are combined with fp32 atomics: only the plain accumulate epilogue is legal
+    if (!q.c_f32 || q.bias || q.resid || q.aux || q.C2 || q.act != EA_ACT_NONE || q.drop_thr) return -4;
+    int chunk = (q.K + q.splitk - 1) / q.splitk;
+    chunk = (chunk + BK - 1) / BK * BK;
+    q.kchunk = chunk;
+    q.splitk = (q.K + chunk - 1) / chunk;
   } else {
-    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, p);
+    q.kchunk = q.K;
+  }
+  dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, q.batch * q.splitk), block(256);
+  if (p.a_kstrided) {
+    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, q);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, stream, q);
+  } else {
+    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, q);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, q);
   }
   return EA_CHECK_LAUNCH();
 }

@@ -74,6 +74,7 @@ def gemm(
     accumulate: bool = False,
     drop_p: float = 0.0,
     drop_seed: int = 0,
+    splitk: int = 1,
 ):
     """C[z][m][n] = epi(alpha * sum_k A(z;m,k) B(z;n,k)).  Offsets (a_off, ...) are in elements."""
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
@@ -107,6 +108,7 @@ def gemm(
     p.alpha, p.out_scale = alpha, out_scale
     thr, scale = drop_params(drop_p)
     p.drop_seed, p.drop_thr, p.drop_scale = drop_seed, thr, scale
+    p.splitk = max(1, int(splitk))
     check(_lib.lib().ea_gemm_bf16(ctypes.byref(p), _stream()), "ea_gemm_bf16")
     return C
 

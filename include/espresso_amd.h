@@ -44,6 +44,7 @@ int ea_version(void);
  *            else:    v = keep(drop) * act(v)
  *            v = v * out_scale + resid[m][n]
  *            C = c_f32 ? (accumulate ? C + v : v) : bf16(v)
+ *   splitk > 1: C += alpha * partial sums (fp32 atomics), wgrad with a long reduction and few output tiles.
  */
 enum { EA_ACT_NONE = 0, EA_ACT_RELU = 1, EA_ACT_SILU = 2 };
 
@@ -64,6 +65,10 @@ typedef struct EaGemmParams {
   uint64_t drop_seed;
   uint32_t drop_thr;
   float drop_scale;
+  /* split-K: the k range is cut into `splitk` chunks reduced by different workgroups and combined with fp32
+   * atomics INTO C (C must hold the value to accumulate onto, e.g. zeros or a running gradient); requires
+   * c_f32 and no other epilogue.  kchunk is filled in by the library. */
+  int splitk, kchunk;
 } EaGemmParams;
 
 int ea_gemm_bf16(const EaGemmParams* p, ea_stream_t stream);
