@@ -134,33 +134,46 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
 }
 
 // BN backward pass 1: red[0][c] += sum dy, red[1][c] += sum dy*xhat, dy = dH * act'(y)
+// block = 256 threads = TC channel pairs x (256/TC) row lanes; rows split over blockIdx.y
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16_t* __restrict__ Z, const bf16_t* __restrict__ dH,
                                                                 const float* __restrict__ mean_rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ red, long M, int C, int act,
-                                                                int rows_per_block) {
-  // thread -> channel pair; blockDim.x*2 channels per block.x ; rows split over blockIdx.y
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
-  if (c >= C) return;
+                                                                int rows_per_block, int TC) {
+  __shared__ float sm[2][256][2];
+  const int cx = threadIdx.x % TC, ry = threadIdx.x / TC, TR = 256 / TC;
+  const int c = (blockIdx.x * TC + cx) * 2;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = min(M, r0 + rows_per_block);
-  const float m0 = mean_rstd[c], m1 = mean_rstd[c + 1], i0 = mean_rstd[C + c], i1 = mean_rstd[C + c + 1];
-  const float g0 = gamma[c], g1 = gamma[c + 1], b0 = beta[c], b1 = beta[c + 1];
   float sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f;
-  for (long m = r0; m < r1; ++m) {
-    const uint32_t zz = *reinterpret_cast<const uint32_t*>(Z + m * C + c);
-    const uint32_t dd = *reinterpret_cast<const uint32_t*>(dH + m * C + c);
-    const float xh0 = (__uint_as_float(zz << 16) - m0) * i0, xh1 = (__uint_as_float(zz & 0xffff0000u) - m1) * i1;
-    const float y0 = xh0 * g0 + b0, y1 = xh1 * g1 + b1;
-    float d0 = __uint_as_float(dd << 16), d1 = __uint_as_float(dd & 0xffff0000u);
-    d0 *= act == 2 ? dsilu_f(y0) : (act == 1 ? (y0 > 0.f ? 1.f : 0.f) : 1.f);
-    d1 *= act == 2 ? dsilu_f(y1) : (act == 1 ? (y1 > 0.f ? 1.f : 0.f) : 1.f);
-    sa0 += d0; sa1 += d1; sb0 += d0 * xh0; sb1 += d1 * xh1;
+  if (c < C) {
+    const float m0 = mean_rstd[c], m1 = mean_rstd[c + 1], i0 = mean_rstd[C + c], i1 = mean_rstd[C + c + 1];
+    const float g0 = gamma[c], g1 = gamma[c + 1], b0 = beta[c], b1 = beta[c + 1];
+    for (long m = r0 + ry; m < r1; m += TR) {
+      const uint32_t zz = *reinterpret_cast<const uint32_t*>(Z + m * C + c);
+      const uint32_t dd = *reinterpret_cast<const uint32_t*>(dH + m * C + c);
+      const float xh0 = (__uint_as_float(zz << 16) - m0) * i0, xh1 = (__uint_as_float(zz & 0xffff0000u) - m1) * i1;
+      const float y0 = xh0 * g0 + b0, y1 = xh1 * g1 + b1;
+      float d0 = __uint_as_float(dd << 16), d1 = __uint_as_float(dd & 0xffff0000u);
+      d0 *= act == 2 ? dsilu_f(y0) : (act == 1 ? (y0 > 0.f ? 1.f : 0.f) : 1.f);
+      d1 *= act == 2 ? dsilu_f(y1) : (act == 1 ? (y1 > 0.f ? 1.f : 0.f) : 1.f);
+      sa0 += d0; sa1 += d1; sb0 += d0 * xh0; sb1 += d1 * xh1;
+    }
   }
-  atomicAdd(red + c, sa0);
-  atomicAdd(red + c + 1, sa1);
-  atomicAdd(red + C + c, sb0);
-  atomicAdd(red + C + c + 1, sb1);
+  sm[0][threadIdx.x][0] = sa0; sm[0][threadIdx.x][1] = sa1;
+  sm[1][threadIdx.x][0] = sb0; sm[1][threadIdx.x][1] = sb1;
+  __syncthreads();
+  if (threadIdx.x < TC && c < C) {
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    for (int r = 0; r < TR; ++r) {
+      a0 += sm[0][r * TC + cx][0]; a1 += sm[0][r * TC + cx][1];
+      b0 += sm[1][r * TC + cx][0]; b1 += sm[1][r * TC + cx][1];
+    }
+    atomicAdd(red + c, a0);
+    atomicAdd(red + c + 1, a1);
+    atomicAdd(red + C + c, b0);
+    atomicAdd(red + C + c + 1, b1);
+  }
 }
 
 // BN backward pass 2: dZ = rstd*gamma*(dy - sum_dy/n - xhat*sum_dyxh/n)   (training)
@@ -253,10 +266,12 @@ __global__ __launch_bounds__(128) void glu_dwconv_bwd_data_kernel(const bf16_t* 
 }
 
 // dw[c][k] += sum_{b,t} dZ[b,t,c] * U[b,t-PAD+k,c]
+constexpr int TTW = 128;  // time tile of the weight-gradient kernel (31*2 atomics per thread per tile)
 template <int KW>
 __global__ __launch_bounds__(128) void dwconv_bwd_weight_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ U,
                                                                 float* __restrict__ dw, int T, int C) {
   constexpr int PAD = (KW - 1) / 2;
+  constexpr int TT = TTW;
   const int c = (blockIdx.x * 128 + threadIdx.x) * 2;
   if (c >= C) return;
   const int b = blockIdx.z;
@@ -378,11 +393,14 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
                              int act, int training, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 8) return -2;
-  int rpb = (int)((M + 511) / 512);
-  if (rpb < 32) rpb = 32;
-  dim3 g1((C / 2 + 255) / 256, (unsigned)((M + rpb - 1) / rpb));
+  int TC = 1;
+  while (TC < 256 && TC * 2 < C) TC <<= 1;  // channel-pair threads per block (power of two <= 256)
+  int rpb = (int)((M + 1023) / 1024);
+  const int TR = 256 / TC;
+  if (rpb < 8 * TR) rpb = 8 * TR;
+  dim3 g1((C / 2 + TC - 1) / TC, (unsigned)((M + rpb - 1) / rpb));
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, g1, dim3(256), 0, stream, (const bf16_t*)Z, (const bf16_t*)dH,
-                     mean_rstd, gamma, beta, red, M, C, act, rpb);
+                     mean_rstd, gamma, beta, red, M, C, act, rpb, TC);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid(M * (C / 8))), dim3(256), 0, stream, (const bf16_t*)Z,
                      (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, M, C, act,
                      training ? (float)M : 0.f);
@@ -396,6 +414,7 @@ extern "C" int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, c
   if (C % 2) return -2;
   dim3 grid((C / 2 + 127) / 128, (T + TT - 1) / TT, B);
   EA_KW_DISPATCH(KW, launch_glu_dwconv_bwd_data, grid, stream, (const bf16_t*)dZ, (const bf16_t*)Y, w, (bf16_t*)dY, T, C);
-  EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, grid, stream, (const bf16_t*)dZ, (const bf16_t*)U, dw, T, C);
+  dim3 gridw((C / 2 + 127) / 128, (T + TTW - 1) / TTW, B);
+  EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, gridw, stream, (const bf16_t*)dZ, (const bf16_t*)U, dw, T, C);
   return EA_CHECK_LAUNCH();
 }

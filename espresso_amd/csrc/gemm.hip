@@ -27,8 +27,12 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
 
+// 16-byte chunk c of LDS row r lives at chunk (c ^ (r&7) ^ ((r>>4)&7)).  The (r&7) term makes the ds_read_b128
+// fragment reads (16 consecutive rows, fixed c) conflict-free; the (r>>4) term is constant inside such a
+// 16-row group (reads unaffected) and spreads the transposing ds_write_b64 of the k-strided staging path,
+// whose 16 lanes hit rows 8 apart (same r&7), over 8 different bank slots instead of one.
 __device__ __forceinline__ uint32_t lds_off(int row, int chunk) {
-  return (uint32_t)(row * ROW_BYTES + ((chunk ^ (row & 7)) << 4));
+  return (uint32_t)(row * ROW_BYTES + ((chunk ^ (row & 7) ^ ((row >> 4) & 7)) << 4));
 }
 
 // ---- global -> register staging -------------------------------------------------------------

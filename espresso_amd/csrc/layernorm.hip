@@ -201,8 +201,8 @@ extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamm
                                 float drop_scale, const void* dx_add, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 8 != 0 || C > 64 * 8 * MAXC8) return -2;
-  // ~2048 blocks max so the atomics stay cheap while the chip is filled
-  int rpb = (M + 2047) / 2048;
+  // ~512 blocks: enough to fill 256 CUs while keeping the dgamma/dbeta atomics (2*C per block) cheap
+  int rpb = (M + 511) / 512;
   rpb = ((rpb + 3) / 4) * 4;
   if (rpb < 4) rpb = 4;
   const int nblk = (M + rpb - 1) / rpb;

@@ -32,6 +32,12 @@ def test_gemm_epilogues():
     assert G.check_gemm(130, 64, 520, True, True, c_f32=True) < 2e-3
 
 
+def test_gemm_splitk():
+    assert G.check_gemm(130, 200, 5000, True, True, c_f32=True, splitk=7) < 2e-3
+    assert G.check_gemm(64, 576, 20011, True, True, c_f32=True, splitk=33, batch=1) < 2e-3
+    assert G.check_gemm(128, 128, 640, False, False, c_f32=True, splitk=64) < 2e-3
+
+
 def test_ctc_fp32():
     r = G.check_ctc()
     assert r["lprobs_abs"] < 1e-4, r
