@@ -61,6 +61,7 @@ class EaGemmParams(ctypes.Structure):
         ("drop_scale", ctypes.c_float),
         ("splitk", ctypes.c_int),
         ("kchunk", ctypes.c_int),
+        ("workspace", ctypes.c_void_p),
     ]
 
 

@@ -153,8 +153,8 @@ __device__ __forceinline__ void store8_bf16(bf16_t* q, bool vec, int cnt, const 
   }
 }
 
-__device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int zhi, int zlo, long coff, int m, int n,
-                                               float (&v)[8], bool vec_ok) {
+__device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int ks_id, int zhi, int zlo, long coff, int m,
+                                               int n, float (&v)[8], bool vec_ok) {
   const int cnt = min(8, p.N - n);
   const bool vec = vec_ok && cnt == 8;
   const bool has_drop = p.drop_thr != 0;
@@ -165,10 +165,15 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
   }
   const uint64_t didx = ((uint64_t)z * (uint64_t)p.M + (uint64_t)m) * (uint64_t)p.N + (uint64_t)n;
   const long co = coff + (long)m * p.ldc + n;
-  if (p.splitk > 1) {  // split-K partial: fp32 accumulate only (host enforces no other epilogue)
-    float* C = reinterpret_cast<float*>(p.C) + co;
+  if (p.splitk > 1) {  // split-K partial slab [ks][batch][M][N] fp32 (dense, ld = N); combined by splitk_reduce_kernel
+    float* W = reinterpret_cast<float*>(p.workspace) + (((long)ks_id * p.batch + z) * p.M + m) * (long)p.N + n;
+    if (cnt == 8 && (p.N & 3) == 0) {
+      *reinterpret_cast<float4*>(W) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(W + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < cnt) atomicAdd(C + e, v[e]);
+      for (int e = 0; e < 8; ++e) if (e < cnt) W[e] = v[e];
+    }
     return;
   }
   if (p.aux) {
@@ -325,14 +330,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, zhi, zlo, coff, m, n, v, vec_ok);
+          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, vec_ok);
         }
       }
     }
   }
 }
 
+// C[z][m][n] (+)= sum_s W[s][z][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const EaGemmParams p) {
+  const long per = (long)p.batch * p.M * p.N;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float* W = reinterpret_cast<const float*>(p.workspace);
+  float* C = reinterpret_cast<float*>(p.C);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += stride) {
+    float a = 0.f;
+    for (int s = 0; s < p.splitk; ++s) a += W[(long)s * per + i];
+    const int n = (int)(i % p.N);
+    const long t = i / p.N;
+    const int m = (int)(t % p.M);
+    const int z = (int)(t / p.M);
+    const long co = (long)(z / p.zdiv) * p.sC_hi + (long)(z % p.zdiv) * p.sC_lo + (long)m * p.ldc + n;
+    C[co] = p.accumulate ? C[co] + a : a;
+  }
+}
+
 }  // namespace
+
+extern "C" long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk) {
+  return splitk > 1 ? (long)splitk * batch * M * N * (long)sizeof(float) : 0;
+}
 
 extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   const EaGemmParams& p = *pp;
@@ -342,7 +369,7 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   if (q.splitk < 1) q.splitk = 1;
   if (q.splitk > 1) {
     // partial sums are combined with fp32 atomics: only the plain accumulate epilogue is legal
-    if (!q.c_f32 || q.bias || q.resid || q.aux || q.C2 || q.act != EA_ACT_NONE || q.drop_thr) return -4;
+    if (!q.c_f32 || q.bias || q.resid || q.aux || q.C2 || q.act != EA_ACT_NONE || q.drop_thr || !q.workspace) return -4;
     int chunk = (q.K + q.splitk - 1) / q.splitk;
     chunk = (chunk + BK - 1) / BK * BK;
     q.kchunk = chunk;
@@ -357,6 +384,12 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   } else {
     if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, q);
     else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, q);
+  }
+  if (q.splitk > 1) {
+    long per = (long)q.batch * q.M * q.N;
+    long blocks = (per + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q);
   }
   return EA_CHECK_LAUNCH();
 }

@@ -49,14 +49,14 @@ def _new(shape, dtype, like):
 
 def _auto_splitk(tiles, Kred):
     """Enough workgroups to fill 256 CUs a few times over when the output has few 128x128 tiles."""
-    if tiles >= 512 or Kred < 1024:
+    if tiles >= 384 or Kred < 1024:
         return 1
-    return max(1, min((1024 + tiles - 1) // tiles, Kred // 256))
+    return max(1, min((768 + tiles - 1) // tiles, Kred // 256))
 
 
 def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None):
     """dW[N_out][K_in] (fp32) = dy[M][N_out]^T x[M][K_in]   (split-K over the long M reduction)"""
-    dW = torch.zeros((N_out, K_in), dtype=torch.float32, device=dy.device)
+    dW = torch.empty((N_out, K_in), dtype=torch.float32, device=dy.device)
     tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
     K.gemm(dy, x, dW, N_out, K_in, M, lda=ld_dy or N_out, ldb=ld_x or K_in, ldc=K_in, a_kstrided=True, b_kstrided=True,
            splitk=_auto_splitk(tiles, M))

@@ -109,6 +109,10 @@ def gemm(
     thr, scale = drop_params(drop_p)
     p.drop_seed, p.drop_thr, p.drop_scale = drop_seed, thr, scale
     p.splitk = max(1, int(splitk))
+    ws = None
+    if p.splitk > 1:
+        ws = torch.empty(p.splitk * batch * M * N, dtype=torch.float32, device=C.device)
+        p.workspace = ws.data_ptr()
     check(_lib.lib().ea_gemm_bf16(ctypes.byref(p), _stream()), "ea_gemm_bf16")
     return C
 

@@ -44,7 +44,7 @@ int ea_version(void);
  *            else:    v = keep(drop) * act(v)
  *            v = v * out_scale + resid[m][n]
  *            C = c_f32 ? (accumulate ? C + v : v) : bf16(v)
- *   splitk > 1: C += alpha * partial sums (fp32 atomics), wgrad with a long reduction and few output tiles.
+ *   splitk > 1: two-pass split-K (fp32 slabs + reduce) for wgrad: long reduction, few output tiles.
  */
 enum { EA_ACT_NONE = 0, EA_ACT_RELU = 1, EA_ACT_SILU = 2 };
 
@@ -65,13 +65,15 @@ typedef struct EaGemmParams {
   uint64_t drop_seed;
   uint32_t drop_thr;
   float drop_scale;
-  /* split-K: the k range is cut into `splitk` chunks reduced by different workgroups and combined with fp32
-   * atomics INTO C (C must hold the value to accumulate onto, e.g. zeros or a running gradient); requires
-   * c_f32 and no other epilogue.  kchunk is filled in by the library. */
+  /* split-K: the k range is cut into `splitk` chunks reduced by different workgroups; the fp32 partial
+   * slabs go to `workspace` (ea_gemm_splitk_workspace_bytes) and a second kernel sums them into C
+   * (honouring `accumulate`).  Requires c_f32 and no other epilogue.  kchunk is filled in by the library. */
   int splitk, kchunk;
+  void* workspace;
 } EaGemmParams;
 
 int ea_gemm_bf16(const EaGemmParams* p, ea_stream_t stream);
+long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused

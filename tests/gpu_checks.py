@@ -141,6 +141,8 @@ def check_encoder_vs_reference(layer_type="conformer"):
     for n, p in model.encoder.named_parameters():
         if n.startswith("pre_encoder.convolutions.") and n.endswith(".bias"):
             continue
+        if n.endswith("self_attn.k_proj.bias"):
+            continue  # softmax is invariant to a constant added to every key: true gradient is exactly zero
         r = grads[n]
         gr = p.grad.float().cpu()
         errs.append((float((gr - r).abs().max() / (float(r.abs().max()) + 1e-12)), n))
