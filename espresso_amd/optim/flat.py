@@ -60,8 +60,11 @@ class FlatParams:
         self.sync_bf16()
 
     def sync_bf16(self):
-        """Refresh the bf16 shadow from the fp32 master (after init / checkpoint load)."""
-        K.cast_f32_to_bf16(self.p32, self.p16)
+        """Refresh the bf16 shadow from the fp32 master (after init / checkpoint load).  The shadow only
+        feeds the HIP GEMMs; on a CPU buffer (host-logic tests of bucketing / hooks under gloo) there is
+        nothing to feed and the shadow is left untouched."""
+        if self.p32.is_cuda:
+            K.cast_f32_to_bf16(self.p32, self.p16)
 
     def rebind_grads(self):
         """Point every .grad back at the flat gradient buffer (after anything set them to None)."""
