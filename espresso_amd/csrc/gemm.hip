@@ -116,6 +116,17 @@ __device__ __forceinline__ void store_ks(char* __restrict__ s, int tid, const ui
   }
 }
 
+// Fast paths: whole tile in bounds and 16-byte aligned -> unconditional vector loads from per-thread base
+// pointers that only advance along k (no per-load bounds / alignment logic in the K loop).
+__device__ __forceinline__ void load_kc_fast(const bf16_t* __restrict__ base, long ld, int k0, uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(base + (long)(32 * i) * ld + k0);
+}
+__device__ __forceinline__ void load_ks_fast(const bf16_t* __restrict__ base, long ld, int k0, uint4 (&r)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const uint4*>(base + (long)(k0 + j) * ld);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == EA_ACT_RELU) return fmaxf(v, 0.f);
   if (act == EA_ACT_SILU) return silu_f(v);
@@ -233,9 +244,10 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
   }
 }
 
-template <bool A_KS, bool B_KS>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * BM * ROW_BYTES];
+template <bool A_KS, bool B_KS, bool DB>
+__global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p) {
+  // DB: two LDS stages (64 KiB) and ONE barrier per K-step; !DB: one stage (32 KiB), two barriers.
+  __shared__ __attribute__((aligned(16))) char smem[(DB ? 4 : 2) * BM * ROW_BYTES];
   char* sA = smem;
   char* sB = smem + BM * ROW_BYTES;
 
@@ -263,35 +275,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
 
   uint4 ra[4], rb[4];
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  // block-uniform fast-path predicates (tile fully inside the matrix, rows 16-byte aligned)
+  const bool a_ok = (m0 + BM <= p.M) && (p.lda & 7) == 0 && ((uintptr_t)A & 15) == 0 && (!A_KS || (m0 & 7) == 0);
+  const bool b_ok = (n0 + BN <= p.N) && (p.ldb & 7) == 0 && ((uintptr_t)B & 15) == 0 && (!B_KS || (n0 & 7) == 0);
+  const bf16_t* a_base = A_KS ? A + (long)((tid >> 4) * 4) * p.lda + m0 + (tid & 15) * 8
+                              : A + (long)(m0 + (tid >> 3)) * p.lda + (tid & 7) * 8;
+  const bf16_t* b_base = B_KS ? B + (long)((tid >> 4) * 4) * p.ldb + n0 + (tid & 15) * 8
+                              : B + (long)(n0 + (tid >> 3)) * p.ldb + (tid & 7) * 8;
+  auto loadA = [&](int k0) {
+    if (a_ok && k0 + BK <= kend) { if (A_KS) load_ks_fast(a_base, p.lda, k0, ra); else load_kc_fast(a_base, p.lda, k0, ra); }
+    else { if (A_KS) load_ks(A, p.lda, p.M, kend, m0, k0, tid, ra); else load_kc(A, p.lda, p.M, kend, m0, k0, tid, ra); }
+  };
+  auto loadB = [&](int k0) {
+    if (b_ok && k0 + BK <= kend) { if (B_KS) load_ks_fast(b_base, p.ldb, k0, rb); else load_kc_fast(b_base, p.ldb, k0, rb); }
+    else { if (B_KS) load_ks(B, p.ldb, p.N, kend, n0, k0, tid, rb); else load_kc(B, p.ldb, p.N, kend, n0, k0, tid, rb); }
+  };
   if (nk > 0) {
-    if (A_KS) load_ks(A, p.lda, p.M, kend, m0, kbeg, tid, ra); else load_kc(A, p.lda, p.M, kend, m0, kbeg, tid, ra);
-    if (B_KS) load_ks(B, p.ldb, p.N, kend, n0, kbeg, tid, rb); else load_kc(B, p.ldb, p.N, kend, n0, kbeg, tid, rb);
+    loadA(kbeg);
+    loadB(kbeg);
   }
-
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    if (A_KS) store_ks(sA, tid, ra); else store_kc(sA, tid, ra);
-    if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      if (A_KS) load_ks(A, p.lda, p.M, kend, m0, k0, tid, ra); else load_kc(A, p.lda, p.M, kend, m0, k0, tid, ra);
-      if (B_KS) load_ks(B, p.ldb, p.N, kend, n0, k0, tid, rb); else load_kc(B, p.ldb, p.N, kend, n0, k0, tid, rb);
+  // fragment read offsets are loop invariant
+  uint32_t a_off[2][4], b_off[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_off[ks][i] = lds_off(wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+      b_off[ks][i] = lds_off(wn * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
     }
+
+  auto compute = [&](const char* cA, const char* cB) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int c = ks * 4 + (lane >> 4);
       bf16x8_t af[4], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + (lane & 15);
-        af[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(row, c));
-      }
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(cA + a_off[ks][i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wn * 64 + j * 16 + (lane & 15);
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(row, c));
-      }
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(cB + b_off[ks][j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -299,6 +319,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const EaGemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]), acc[i][j], 0, 0, 0);
+    }
+  };
+  if constexpr (DB) {
+    constexpr int STAGE = 2 * BM * ROW_BYTES;
+    if (nk > 0) {
+      if (A_KS) store_ks(sA, tid, ra); else store_kc(sA, tid, ra);
+      if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
+      if (nk > 1) { loadA(kbeg + BK); loadB(kbeg + BK); }
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      compute(sA + cur * STAGE, sB + cur * STAGE);
+      if (kt + 1 < nk) {
+        char* nA = sA + (cur ^ 1) * STAGE;
+        char* nB = sB + (cur ^ 1) * STAGE;
+        if (A_KS) store_ks(nA, tid, ra); else store_kc(nA, tid, ra);
+        if (B_KS) store_ks(nB, tid, rb); else store_kc(nB, tid, rb);
+      }
+      __syncthreads();
+      if (kt + 2 < nk) { loadA(kbeg + (kt + 2) * BK); loadB(kbeg + (kt + 2) * BK); }
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      if (A_KS) store_ks(sA, tid, ra); else store_kc(sA, tid, ra);
+      if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
+      __syncthreads();
+      if (kt + 1 < nk) { loadA(kbeg + (kt + 1) * BK); loadB(kbeg + (kt + 1) * BK); }
+      compute(sA, sB);
     }
   }
 
@@ -357,6 +407,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const EaGemmParams p
 
 }  // namespace
 
+static int g_gemm_variant = 0;  // 0: single LDS stage, 1: double-buffered LDS
+extern "C" int ea_set_gemm_variant(int v) {
+  const int old = g_gemm_variant;
+  g_gemm_variant = v;
+  return old;
+}
+
+template <bool A_KS, bool B_KS>
+static void launch_gemm(dim3 grid, hipStream_t stream, const EaGemmParams& q) {
+  if (g_gemm_variant == 1) hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, true>), grid, dim3(256), 0, stream, q);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, false>), grid, dim3(256), 0, stream, q);
+}
+
 extern "C" long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk) {
   return splitk > 1 ? (long)splitk * batch * M * N * (long)sizeof(float) : 0;
 }
@@ -379,11 +442,9 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   }
   dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, q.batch * q.splitk), block(256);
   if (p.a_kstrided) {
-    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, q);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, stream, q);
+    if (p.b_kstrided) launch_gemm<true, true>(grid, stream, q); else launch_gemm<true, false>(grid, stream, q);
   } else {
-    if (p.b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, q);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, q);
+    if (p.b_kstrided) launch_gemm<false, true>(grid, stream, q); else launch_gemm<false, false>(grid, stream, q);
   }
   if (q.splitk > 1) {
     long per = (long)q.batch * q.M * q.N;

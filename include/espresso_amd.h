@@ -74,6 +74,9 @@ typedef struct EaGemmParams {
 
 int ea_gemm_bf16(const EaGemmParams* p, ea_stream_t stream);
 long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk);
+/* tuning hook: 0 = single LDS stage (32 KiB, two barriers per K-step), 1 = double-buffered LDS (64 KiB, one barrier);
+ * returns the previous value. */
+int ea_set_gemm_variant(int v);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused
