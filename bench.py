@@ -178,6 +178,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, need):
         trainer.train_step([samples[i]])
+    host_enqueue = time.perf_counter() - t0  # time for the host to enqueue all steps (diagnostic only)
     sync()
     elapsed = time.perf_counter() - t0
     audio = sum(s["audio_seconds"] for s in samples[args.warmup:])
@@ -244,7 +245,8 @@ def main():
             "config": {"workload": "LibriSpeech 960h Conformer-12 + CTC update step, <=26000 frames & <=24 utts per GPU, "
                                    "V=5004, on-GPU fbank+CMVN+SpecAugment, dropout 0.1, clip 2.0, Adam",
                        "parallelism": f"dp{world}", "audio_seconds_per_step_per_gpu": audio / args.steps / world,
-                       "last_loss_per_sentence": float(loss_stats[1] / max(1.0, float(loss_stats[0])))},
+                       "last_loss_per_sentence": float(loss_stats[1] / max(1.0, float(loss_stats[0]))),
+                       "host_enqueue_ms_per_step": host_enqueue * 1e3 / args.steps},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
