@@ -65,6 +65,37 @@ class EaGemmParams(ctypes.Structure):
     ]
 
 
+_F, _V = ctypes.c_void_p, ctypes.c_void_p
+
+
+def _mk(name, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": [(f, ctypes.c_void_p) for f in fields]})
+
+
+EaFfnParams = _mk("EaFfnParams", ["ln_g", "ln_b", "w1", "b1", "w2", "b2"])
+EaFfnGrads = _mk("EaFfnGrads", ["ln_g", "ln_b", "w1", "b1", "w2", "b2"])
+EaAttnParams = _mk("EaAttnParams", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "pos_u", "pos_v", "wpos"])
+EaAttnGrads = _mk("EaAttnGrads", ["ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo", "pos_u", "pos_v", "wpos"])
+EaConvParams = _mk("EaConvParams", ["ln_g", "ln_b", "pw1", "dw", "bn_g", "bn_b", "bn_rm", "bn_rv", "pw2"])
+EaConvGrads = _mk("EaConvGrads", ["ln_g", "ln_b", "pw1", "dw", "bn_g", "bn_b", "pw2"])
+
+
+class EaLayerGrads(ctypes.Structure):
+    _fields_ = [("ffn1", EaFfnGrads), ("attn", EaAttnGrads), ("conv", EaConvGrads), ("ffn2", EaFfnGrads),
+                ("final_ln_g", ctypes.c_void_p), ("final_ln_b", ctypes.c_void_p)]
+
+
+class EaConformerLayer(ctypes.Structure):
+    _fields_ = [("ffn1", EaFfnParams), ("attn", EaAttnParams), ("conv", EaConvParams), ("ffn2", EaFfnParams),
+                ("final_ln_g", ctypes.c_void_p), ("final_ln_b", ctypes.c_void_p), ("grads", EaLayerGrads)]
+
+
+class EaLayerShape(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("T", ctypes.c_int), ("C", ctypes.c_int), ("H", ctypes.c_int), ("F", ctypes.c_int),
+                ("KW", ctypes.c_int), ("training", ctypes.c_int), ("p_drop", ctypes.c_float), ("p_act", ctypes.c_float),
+                ("p_attn", ctypes.c_float), ("seed", ctypes.c_uint64)]
+
+
 _SCALARS = {
     "int": ctypes.c_int,
     "long": ctypes.c_long,

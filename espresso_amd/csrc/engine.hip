@@ -1,0 +1,428 @@
+// Native layer runtime: one C-ABI call runs a whole Conformer encoder layer forward (≈30 kernel launches)
+// or backward (≈65 launches) back-to-back on a HIP stream, with activations in caller-provided arenas
+// and parameter gradients accumulated straight into the flat fp32 gradient buffer.
+//
+// Why: with one Python/ctypes call per kernel the host needed ≈43 ms to enqueue a 40 ms GPU step
+// (≈1400 launches); the reference has the same structure (eager PyTorch, ~20 kernels per layer forward,
+// SURVEY §8a8).  The sequence below is the hand-scheduled composition of
+// espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:81-145 (ffn1 -> rel-pos MHSA ->
+// conv module -> ffn2 -> final LayerNorm) and its analytic backward; it is identical, launch for launch, to
+// the Python composition in espresso_amd/functional.py (which remains as the reference for tests).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "espresso_amd.h"
+
+namespace {
+
+struct Arena {
+  char* base;
+  size_t off;
+  size_t peak;
+  template <typename T>
+  T* get(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    if (off > peak) peak = off;
+    return p;
+  }
+};
+
+inline int pad8(int n) { return (n + 7) / 8 * 8; }
+
+struct Ctx {
+  hipStream_t s;
+  bool dry;  // size computation only: walk the arenas, launch nothing
+  int rc;
+  Arena* scratch;
+};
+
+#define RUN(call)                         \
+  do {                                    \
+    if (!c.dry && c.rc == 0) c.rc = (call); \
+  } while (0)
+
+inline uint32_t drop_thr(float p) {
+  if (p <= 0.f) return 0;
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
+inline float drop_scale(float p) { return p <= 0.f ? 1.f : 1.f / (1.f - p); }
+
+// plain GEMM helper: C = A B^T style with the flags used on the path
+struct G {
+  EaGemmParams p;
+  G(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc) {
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.batch = 1; p.zdiv = 1; p.alpha = 1.f; p.out_scale = 1.f; p.splitk = 1; p.drop_scale = 1.f;
+  }
+  G& aks() { p.a_kstrided = 1; return *this; }
+  G& bks() { p.b_kstrided = 1; return *this; }
+  G& f32() { p.c_f32 = 1; return *this; }
+  G& acc() { p.accumulate = 1; return *this; }
+  G& bias(const float* b) { p.bias = b; return *this; }
+  G& act(int a) { p.act = a; return *this; }
+  G& alpha(float a) { p.alpha = a; return *this; }
+  G& scale(float a) { p.out_scale = a; return *this; }
+  G& resid(const void* r, long ldr) { p.resid = r; p.ldr = ldr; return *this; }
+  G& c2(void* c, long ld) { p.C2 = c; p.ldc2 = ld; return *this; }
+  G& aux(const void* x, long ld) { p.aux = x; p.ldaux = ld; return *this; }
+  G& drop(float pr, uint64_t seed) { p.drop_thr = drop_thr(pr); p.drop_scale = drop_scale(pr); p.drop_seed = seed; return *this; }
+  G& batch(int b, int zdiv, long ahi, long alo, long bhi, long blo, long chi, long clo) {
+    p.batch = b; p.zdiv = zdiv; p.sA_hi = ahi; p.sA_lo = alo; p.sB_hi = bhi; p.sB_lo = blo; p.sC_hi = chi; p.sC_lo = clo;
+    return *this;
+  }
+};
+
+inline void gemm(Ctx& c, G& g) { RUN(ea_gemm_bf16(&g.p, c.s)); }
+
+// dW[N_out][K_in] += dy^T x with two-pass split-K; workspace from the scratch arena
+inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, float* dW, int M, int N_out, int K_in) {
+  const int tiles = ((N_out + 127) / 128) * ((K_in + 127) / 128);
+  int sk = 1;
+  if (tiles < 384 && M >= 1024) {
+    sk = (768 + tiles - 1) / tiles;
+    if (sk > M / 256) sk = M / 256;
+    if (sk < 1) sk = 1;
+  }
+  G g(dy, x, dW, N_out, K_in, M, ld_dy, ld_x, K_in);
+  g.aks().bks().f32().acc();
+  g.p.splitk = sk;
+  if (sk > 1) g.p.workspace = c.scratch->get<float>((size_t)sk * N_out * K_in);
+  gemm(c, g);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+struct FfnSaved {
+  float *mean, *rstd;
+  uint16_t *xn, *z, *h;
+};
+static FfnSaved ffn_saved(Arena& sv, const EaLayerShape& sh) {
+  const int M = sh.B * sh.T, C = sh.C, F = sh.F;
+  FfnSaved f;
+  f.mean = sv.get<float>(M);
+  f.rstd = sv.get<float>(M);
+  f.xn = sv.get<uint16_t>((size_t)M * C);
+  f.z = sv.get<uint16_t>((size_t)M * F);
+  f.h = sv.get<uint16_t>((size_t)M * F);
+  return f;
+}
+
+static void ffn_fwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaFfnParams& w, const void* x, void* y,
+                    uint64_t seed, float out_scale, int act) {
+  const int M = sh.B * sh.T, C = sh.C, F = sh.F;
+  float *mean = f.mean, *rstd = f.rstd;
+  uint16_t *xn = f.xn, *z = f.z, *h = f.h;
+  RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, xn, mean, rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  G g1(xn, w.w1, z, M, F, C, C, C, F);
+  g1.bias(w.b1).act(act).c2(h, F).drop(sh.p_act, seed + 1);
+  gemm(c, g1);
+  G g2(h, w.w2, y, M, C, F, F, F, C);
+  g2.bias(w.b2).drop(sh.p_drop, seed + 2).scale(out_scale).resid(x, C);
+  gemm(c, g2);
+}
+
+static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaFfnParams& w, const EaFfnGrads& gw, const void* x,
+                    const void* dy, void* dx, uint64_t seed, float out_scale, int act) {
+  const int M = sh.B * sh.T, C = sh.C, F = sh.F;
+  Arena& sc = *c.scratch;
+  const size_t mark = sc.off;
+  float *mean = f.mean, *rstd = f.rstd;
+  uint16_t *xn = f.xn, *z = f.z, *h = f.h;
+  uint16_t* g2 = sc.get<uint16_t>((size_t)M * C);
+  RUN(ea_scale_dropout_bf16(dy, nullptr, g2, (long)M * C, out_scale, 0.f, seed + 2, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+  wgrad(c, g2, C, h, F, gw.w2, M, C, F);
+  RUN(ea_colsum_bf16(g2, gw.b2, M, C, C, c.s));
+  uint16_t* dz = sc.get<uint16_t>((size_t)M * F);
+  G gd(g2, w.w2, dz, M, F, C, C, F, F);
+  gd.bks().aux(z, F).act(act).drop(sh.p_act, seed + 1);
+  gemm(c, gd);
+  wgrad(c, dz, F, xn, C, gw.w1, M, F, C);
+  RUN(ea_colsum_bf16(dz, gw.b1, M, F, F, c.s));
+  uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
+  G gx(dz, w.w1, dxn, M, C, F, F, C, C);
+  gx.bks();
+  gemm(c, gx);
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, c.s));
+  sc.off = mark;
+}
+
+// saved layout of the attention block is produced by the same get<> sequence in fwd and bwd
+struct AttnSaved {
+  float *mean, *rstd;
+  uint16_t *xn, *qkv, *qu, *qv, *pp, *P, *Pd, *o;
+};
+static AttnSaved attn_saved(Arena& sv, const EaLayerShape& sh) {
+  const int M = sh.B * sh.T, C = sh.C, T = sh.T, Z = sh.H * sh.B, Sp = pad8(T), R = 2 * T - 1;
+  AttnSaved a;
+  a.mean = sv.get<float>(M);
+  a.rstd = sv.get<float>(M);
+  a.xn = sv.get<uint16_t>((size_t)M * C);
+  a.qkv = sv.get<uint16_t>((size_t)M * 3 * C);
+  a.qu = sv.get<uint16_t>((size_t)M * C);
+  a.qv = sv.get<uint16_t>((size_t)M * C);
+  a.pp = sv.get<uint16_t>((size_t)R * C);
+  a.P = sv.get<uint16_t>((size_t)Z * T * Sp);
+  a.Pd = sh.p_attn > 0.f ? sv.get<uint16_t>((size_t)Z * T * Sp) : a.P;
+  a.o = sv.get<uint16_t>((size_t)M * C);
+  return a;
+}
+
+static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const void* x, void* y,
+                     const int* key_len, const float* attn_mask, const void* pe, uint64_t seed) {
+  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
+  const float scaling = 1.0f / sqrtf((float)dh);
+  Arena& sc = *c.scratch;
+  const size_t mark = sc.off;
+  RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, a.xn, a.mean, a.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  G gq(a.xn, w.wqkv, a.qkv, M, 3 * C, C, C, C, 3 * C);
+  gq.bias(w.bqkv);
+  gemm(c, gq);
+  RUN(ea_relpos_q_prep(a.qkv, 3 * C, w.pos_u, w.pos_v, a.qu, a.qv, M, C, scaling, c.s));
+  float* ac = sc.get<float>((size_t)Z * T * Sp);
+  float* bd = sc.get<float>((size_t)Z * T * Rp);
+  G gac(a.qu, a.qkv + C, ac, T, T, dh, C, 3 * C, Sp);
+  gac.f32().batch(Z, B, dh, (long)T * C, dh, (long)T * 3 * C, (long)B * T * Sp, (long)T * Sp);
+  gemm(c, gac);
+  G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
+  gemm(c, gpp);
+  G gbd(a.qv, a.pp, bd, T, R, dh, C, C, Rp);
+  gbd.f32().batch(Z, B, dh, (long)T * C, dh, 0, (long)B * T * Rp, (long)T * Rp);
+  gemm(c, gbd);
+  RUN(ea_relpos_softmax_fwd(ac, bd, key_len, attn_mask, a.P, sh.p_attn > 0.f ? a.Pd : nullptr, H, B, T, T, Sp, Rp, Sp, 0,
+                            seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+  G gpv(a.Pd, a.qkv + 2 * C, a.o, T, dh, T, Sp, 3 * C, C);
+  gpv.bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * 3 * C, dh, (long)T * C);
+  gemm(c, gpv);
+  G go(a.o, w.wo, y, M, C, C, C, C, C);
+  go.bias(w.bo).drop(sh.p_drop, seed + 4).resid(x, C);
+  gemm(c, go);
+  sc.off = mark;
+}
+
+static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
+                     const void* dy, void* dx, const void* pe, uint64_t seed) {
+  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
+  const float scaling = 1.0f / sqrtf((float)dh);
+  Arena& sc = *c.scratch;
+  const size_t mark = sc.off;
+  const void* g = dy;
+  if (sh.p_drop > 0.f) {
+    uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
+    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 4, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+    g = gg;
+  }
+  wgrad(c, g, C, a.o, C, gw.wo, M, C, C);
+  RUN(ea_colsum_bf16(g, gw.bo, M, C, C, c.s));
+  uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
+  G gdo(g, w.wo, dO, M, C, C, C, C, C);
+  gdo.bks();
+  gemm(c, gdo);
+  float* dPd = sc.get<float>((size_t)Z * T * Sp);
+  G gdp(dO, a.qkv + 2 * C, dPd, T, T, dh, C, 3 * C, Sp);
+  gdp.f32().batch(Z, B, dh, (long)T * C, dh, (long)T * 3 * C, (long)B * T * Sp, (long)T * Sp);
+  gemm(c, gdp);
+  uint16_t* dqkv = sc.get<uint16_t>((size_t)M * 3 * C);
+  G gdv(a.Pd, dO, dqkv + 2 * C, T, dh, T, Sp, C, 3 * C);
+  gdv.aks().bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * C, dh, (long)T * 3 * C);
+  gemm(c, gdv);
+  uint16_t* dAC = sc.get<uint16_t>((size_t)Z * T * Sp);
+  uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
+  RUN(ea_relpos_softmax_bwd(a.P, dPd, dAC, dBD, H, B, T, T, Sp, Sp, Rp, seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+  G gdk(dAC, a.qu, dqkv + C, T, dh, T, Sp, C, 3 * C);
+  gdk.aks().bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * C, dh, (long)T * 3 * C);
+  gemm(c, gdk);
+  uint16_t* t1 = sc.get<uint16_t>((size_t)M * C);
+  G gt1(dAC, a.qkv + C, t1, T, dh, T, Sp, 3 * C, C);
+  gt1.bks().alpha(scaling).batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * 3 * C, dh, (long)T * C);
+  gemm(c, gt1);
+  uint16_t* t2 = sc.get<uint16_t>((size_t)M * C);
+  G gt2(dBD, a.pp, t2, T, dh, R, Rp, C, C);
+  gt2.bks().alpha(scaling).batch(Z, B, (long)B * T * Rp, (long)T * Rp, dh, 0, dh, (long)T * C);
+  gemm(c, gt2);
+  uint16_t* dpp = sc.get<uint16_t>((size_t)R * C);
+  G gpp(dBD, a.qv, dpp, R, dh, B * T, Rp, C, C);
+  gpp.aks().bks().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
+  gemm(c, gpp);
+  wgrad(c, dpp, C, pe, C, gw.wpos, R, C, C);
+  RUN(ea_colsum_bf16(t1, gw.pos_u, M, C, C, c.s));
+  RUN(ea_colsum_bf16(t2, gw.pos_v, M, C, C, c.s));
+  RUN(ea_add2_strided_bf16(t1, C, t2, C, dqkv, 3 * C, M, C, c.s));
+  wgrad(c, dqkv, 3 * C, a.xn, C, gw.wqkv, M, 3 * C, C);
+  RUN(ea_colsum_bf16(dqkv, gw.bqkv, M, 3 * C, 3 * C, c.s));
+  uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
+  G gx(dqkv, w.wqkv, dxn, M, C, 3 * C, 3 * C, C, C);
+  gx.bks();
+  gemm(c, gx);
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, c.s));
+  sc.off = mark;
+}
+
+struct ConvSaved {
+  float *mean, *rstd, *mr;
+  uint16_t *xn, *Y, *U, *Z, *Hh;
+};
+static ConvSaved conv_saved(Arena& sv, const EaLayerShape& sh) {
+  const int M = sh.B * sh.T, C = sh.C;
+  ConvSaved s;
+  s.mean = sv.get<float>(M);
+  s.rstd = sv.get<float>(M);
+  s.mr = sv.get<float>(2 * C);
+  s.xn = sv.get<uint16_t>((size_t)M * C);
+  s.Y = sv.get<uint16_t>((size_t)M * 2 * C);
+  s.U = sv.get<uint16_t>((size_t)M * C);
+  s.Z = sv.get<uint16_t>((size_t)M * C);
+  s.Hh = sv.get<uint16_t>((size_t)M * C);
+  return s;
+}
+
+static void conv_fwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const EaConvParams& w, const void* x, void* y, uint64_t seed) {
+  const int B = sh.B, T = sh.T, C = sh.C, M = B * T;
+  Arena& sc = *c.scratch;
+  const size_t mark = sc.off;
+  RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, s.xn, s.mean, s.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  G g1(s.xn, w.pw1, s.Y, M, 2 * C, C, C, C, 2 * C);
+  gemm(c, g1);
+  float* stats = nullptr;
+  if (sh.training) {
+    stats = sc.get<float>(2 * C);
+    if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(stats, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
+  }
+  RUN(ea_glu_dwconv_fwd(s.Y, w.dw, s.U, s.Z, stats, B, T, C, sh.KW, c.s));
+  if (sh.training) RUN(ea_bn_finalize(stats, s.mr, w.bn_rm, w.bn_rv, C, (float)M, 1e-5f, 0.1f, c.s));
+  else RUN(ea_bn_from_running(w.bn_rm, w.bn_rv, s.mr, C, 1e-5f, c.s));
+  RUN(ea_bn_act_fwd(s.Z, s.mr, w.bn_g, w.bn_b, s.Hh, M, C, EA_ACT_SILU, c.s));
+  G g2(s.Hh, w.pw2, y, M, C, C, C, C, C);
+  g2.drop(sh.p_drop, seed + 5).resid(x, C);
+  gemm(c, g2);
+  sc.off = mark;
+}
+
+static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const EaConvParams& w, const EaConvGrads& gw, const void* x,
+                     const void* dy, void* dx, uint64_t seed) {
+  const int B = sh.B, T = sh.T, C = sh.C, M = B * T;
+  Arena& sc = *c.scratch;
+  const size_t mark = sc.off;
+  const void* g = dy;
+  if (sh.p_drop > 0.f) {
+    uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
+    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 5, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+    g = gg;
+  }
+  wgrad(c, g, C, s.Hh, C, gw.pw2, M, C, C);
+  uint16_t* dH = sc.get<uint16_t>((size_t)M * C);
+  G gh(g, w.pw2, dH, M, C, C, C, C, C);
+  gh.bks();
+  gemm(c, gh);
+  float* red = sc.get<float>(2 * C);
+  if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(red, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
+  uint16_t* dZ = sc.get<uint16_t>((size_t)M * C);
+  RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, gw.bn_g, gw.bn_b, M, C, EA_ACT_SILU, sh.training, c.s));
+  uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
+  RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, gw.dw, B, T, C, sh.KW, c.s));
+  wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);
+  uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
+  G gx(dY, w.pw1, dxn, M, C, 2 * C, 2 * C, C, C);
+  gx.bks();
+  gemm(c, gx);
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, c.s));
+  sc.off = mark;
+}
+
+// Saved-activation arena order: [x1][ffn1][x2][attn][x3][conv][x4][ffn2][final LN stats]
+struct LayerSaved {
+  uint16_t *x1, *x2, *x3, *x4;
+  FfnSaved f1, f2;
+  AttnSaved at;
+  ConvSaved cv;
+  float *fmean, *frstd;
+};
+static LayerSaved layer_saved(Arena& sv, const EaLayerShape& sh) {
+  const size_t MC = (size_t)sh.B * sh.T * sh.C;
+  LayerSaved L;
+  L.x1 = sv.get<uint16_t>(MC);
+  L.f1 = ffn_saved(sv, sh);
+  L.x2 = sv.get<uint16_t>(MC);
+  L.at = attn_saved(sv, sh);
+  L.x3 = sv.get<uint16_t>(MC);
+  L.cv = conv_saved(sv, sh);
+  L.x4 = sv.get<uint16_t>(MC);
+  L.f2 = ffn_saved(sv, sh);
+  L.fmean = sv.get<float>((size_t)sh.B * sh.T);
+  L.frstd = sv.get<float>((size_t)sh.B * sh.T);
+  return L;
+}
+
+static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, const void* x_in, void* x_out, const int* key_len,
+                     const float* attn_mask, const void* pe, Arena& sv) {
+  const int M = sh.B * sh.T, C = sh.C;
+  LayerSaved S = layer_saved(sv, sh);
+  const uint64_t seed = sh.seed;
+  ffn_fwd(c, S.f1, sh, L->ffn1, x_in, S.x1, seed + 0, 0.5f, EA_ACT_SILU);
+  attn_fwd(c, S.at, sh, L->attn, S.x1, S.x2, key_len, attn_mask, pe, seed + 16);
+  conv_fwd(c, S.cv, sh, L->conv, S.x2, S.x3, seed + 32);
+  ffn_fwd(c, S.f2, sh, L->ffn2, S.x3, S.x4, seed + 48, 0.5f, EA_ACT_SILU);
+  RUN(ea_layernorm_fwd(S.x4, L->final_ln_g, L->final_ln_b, x_out, S.fmean, S.frstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  return c.rc;
+}
+
+static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, const void* x_in, const void* dy, void* dx,
+                     const void* pe, Arena& sv) {
+  const int M = sh.B * sh.T, C = sh.C;
+  LayerSaved S = layer_saved(sv, sh);
+  Arena& sc = *c.scratch;
+  const uint64_t seed = sh.seed;
+  uint16_t* d4 = sc.get<uint16_t>((size_t)M * C);
+  uint16_t* d3 = sc.get<uint16_t>((size_t)M * C);
+  RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, d4, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
+                       1.f, nullptr, c.s));
+  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, d4, d3, seed + 48, 0.5f, EA_ACT_SILU);
+  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, d3, d4, seed + 32);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, d4, d3, pe, seed + 16);
+  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, d3, dx, seed + 0, 0.5f, EA_ACT_SILU);
+  return c.rc;
+}
+
+static bool shape_ok(const EaLayerShape& sh) {
+  return sh.B > 0 && sh.T > 0 && sh.C % 8 == 0 && sh.H > 0 && sh.C % sh.H == 0 && sh.F % 8 == 0 && sh.T <= 1024;
+}
+
+int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes) {
+  if (!shape_ok(*shape)) return -2;
+  EaConformerLayer L;
+  memset(&L, 0, sizeof(L));
+  Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
+  Ctx c{nullptr, true, 0, &sc};
+  layer_fwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+  Arena sv2{nullptr, 0, 0};
+  layer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, sv2);
+  *saved_bytes = (long)sv.peak + 256;
+  *scratch_bytes = (long)sc.peak + 256;
+  return 0;
+}
+
+int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
+                           const int* key_len, const float* attn_mask, const void* pe, void* saved, void* scratch,
+                           hipStream_t stream) {
+  if (!shape_ok(*shape)) return -2;
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
+  Ctx c{stream, false, 0, &sc};
+  return layer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
+}
+
+int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy, void* dx,
+                           const void* pe, void* saved, void* scratch, hipStream_t stream) {
+  if (!shape_ok(*shape)) return -2;
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
+  Ctx c{stream, false, 0, &sc};
+  return layer_bwd(c, layer, *shape, x_in, dy, dx, pe, sv);
+}
+
+}  // extern "C"

@@ -46,9 +46,15 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self._pending = list(self._bucket_total)
         self._works: List = []
         self._launched = [False] * len(self.buckets)
+        self._hooks = {id(p): self._make_hook(p) for p in flat.params}
         if self.world_size > 1:
             for p in flat.params:
-                p.register_post_accumulate_grad_hook(self._make_hook(p))
+                p.register_post_accumulate_grad_hook(self._hooks[id(p)])
+            # gradients written directly by the native layer runtime never pass through autograd's
+            # AccumulateGrad, so the runtime reports them here
+            from .. import functional as F
+
+            F.set_grad_ready_callback(self._native_ready)
 
     def _make_hook(self, p):
         ids = self._param_buckets[id(p)]
@@ -62,6 +68,12 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
                     self._launch(i)
 
         return hook
+
+    def _native_ready(self, params):
+        for p in params:
+            h = self._hooks.get(id(p))
+            if h is not None:
+                h(p)
 
     def _launch(self, i):
         if self._launched[i]:

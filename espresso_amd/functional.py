@@ -528,3 +528,192 @@ class _ConvSubsample(torch.autograd.Function):
 
 def conv_subsample(X, row_zero, strides, params, bufs, p_drop=0.0, training=True, bn_eps=1e-5, bn_momentum=0.1):
     return _ConvSubsample.apply(X, row_zero, tuple(strides), list(bufs), p_drop, training, bn_eps, bn_momentum, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# Native layer runtime (csrc/engine.hip): the whole Conformer layer forward / backward as ONE C-ABI call.
+_grad_ready_callback = None
+
+
+def set_grad_ready_callback(fn):
+    """fn(list_of_parameters) is invoked when a native backward has finished accumulating the gradients
+    of those parameters (the data-parallel wrapper uses it to launch bucket all-reduces)."""
+    global _grad_ready_callback
+    _grad_ready_callback = fn
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _LayerBinding:
+    """ctypes view of one ConformerWithRelativePositionalEmbeddingEncoderLayer's parameters / gradients.
+    Keeps the tensors it points to alive; rebuilt when the underlying storage changes."""
+
+    def __init__(self, m):
+        import ctypes
+
+        from ._lib import EaConformerLayer
+
+        self.keep = []
+        L = EaConformerLayer()
+
+        def w16(p, shape=None):
+            t = bf16_weight(p)
+            t = t.reshape(shape) if shape is not None else t
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def grad(p):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            return p.grad.data_ptr()
+
+        def ffn(dst, gdst, f):
+            dst.ln_g, dst.ln_b = _ptr(f.layer_norm.weight), _ptr(f.layer_norm.bias)
+            dst.w1, dst.b1, dst.w2, dst.b2 = w16(f.w_1.weight), _ptr(f.w_1.bias), w16(f.w_2.weight), _ptr(f.w_2.bias)
+            gdst.ln_g, gdst.ln_b = grad(f.layer_norm.weight), grad(f.layer_norm.bias)
+            gdst.w1, gdst.b1, gdst.w2, gdst.b2 = grad(f.w_1.weight), grad(f.w_1.bias), grad(f.w_2.weight), grad(f.w_2.bias)
+
+        ffn(L.ffn1, L.grads.ffn1, m.ffn1)
+        ffn(L.ffn2, L.grads.ffn2, m.ffn2)
+        a = m.self_attn
+        qw, kw, vw = a.q_proj.weight, a.k_proj.weight, a.v_proj.weight
+        qb, kb, vb = a.q_proj.bias, a.k_proj.bias, a.v_proj.bias
+        for p in (qw, kw, vw, qb, kb, vb):
+            grad(p)
+        fused16 = getattr(qw, "_ea_fused_qkv", None)
+        n = qw.numel()
+        grads_contig = (qw.grad is not None and kw.grad is not None and vw.grad is not None
+                        and kw.grad.data_ptr() == qw.grad.data_ptr() + 4 * n and vw.grad.data_ptr() == kw.grad.data_ptr() + 4 * n)
+        if fused16 is not None and grads_contig:
+            wqkv16, self.split_w = fused16, None
+            gw = qw.grad.data_ptr()
+        else:  # unfused storage: work on packed copies, scatter the gradient back after backward
+            wqkv16 = torch.cat([bf16_weight(qw), bf16_weight(kw), bf16_weight(vw)], 0)
+            gbuf = torch.zeros(3 * qw.shape[0], qw.shape[1], dtype=torch.float32, device=qw.device)
+            self.split_w = (gbuf, (qw, kw, vw))
+            gw = gbuf.data_ptr()
+        self.keep.append(wqkv16)
+        nb = qb.numel()
+        bias_contig = (kb.data_ptr() == qb.data_ptr() + 4 * nb and vb.data_ptr() == kb.data_ptr() + 4 * nb
+                       and qb.grad is not None and kb.grad is not None and vb.grad is not None
+                       and kb.grad.data_ptr() == qb.grad.data_ptr() + 4 * nb and vb.grad.data_ptr() == kb.grad.data_ptr() + 4 * nb)
+        if bias_contig:
+            self.split_b = None
+            bq_ptr, gb_ptr = qb.data_ptr(), qb.grad.data_ptr()
+        else:
+            bq = torch.cat([qb.detach(), kb.detach(), vb.detach()], 0)
+            gb = torch.zeros_like(bq)
+            self.split_b = (gb, (qb, kb, vb))
+            self.keep += [bq, gb]
+            bq_ptr, gb_ptr = bq.data_ptr(), gb.data_ptr()
+        self.cacheable = self.split_w is None and self.split_b is None
+        self.key = (qw.data_ptr(), qw.grad.data_ptr() if qw.grad is not None else 0)
+        A, GA = L.attn, L.grads.attn
+        A.ln_g, A.ln_b = _ptr(m.self_attn_layer_norm.weight), _ptr(m.self_attn_layer_norm.bias)
+        A.wqkv, A.bqkv, A.wo, A.bo = wqkv16.data_ptr(), bq_ptr, w16(a.out_proj.weight), _ptr(a.out_proj.bias)
+        A.pos_u, A.pos_v, A.wpos = _ptr(a.pos_bias_u), _ptr(a.pos_bias_v), w16(a.pos_proj.weight)
+        GA.ln_g, GA.ln_b = grad(m.self_attn_layer_norm.weight), grad(m.self_attn_layer_norm.bias)
+        GA.wqkv, GA.bqkv, GA.wo, GA.bo = gw, gb_ptr, grad(a.out_proj.weight), grad(a.out_proj.bias)
+        GA.pos_u, GA.pos_v, GA.wpos = grad(a.pos_bias_u), grad(a.pos_bias_v), grad(a.pos_proj.weight)
+        for p in (qw, kw, vw, qb, kb, vb):
+            grad(p)
+        cm = m.conv_module
+        Cc, GC = L.conv, L.grads.conv
+        Cdim = m.embed_dim
+        Cc.ln_g, Cc.ln_b = _ptr(cm.layer_norm.weight), _ptr(cm.layer_norm.bias)
+        Cc.pw1 = w16(cm.pointwise_conv1.weight, (2 * Cdim, Cdim))
+        Cc.dw = _ptr(cm.depthwise_conv.weight)
+        Cc.bn_g, Cc.bn_b = _ptr(cm.batch_norm.weight), _ptr(cm.batch_norm.bias)
+        Cc.bn_rm, Cc.bn_rv = _ptr(cm.batch_norm.running_mean), _ptr(cm.batch_norm.running_var)
+        Cc.pw2 = w16(cm.pointwise_conv2.weight, (Cdim, Cdim))
+        GC.ln_g, GC.ln_b = grad(cm.layer_norm.weight), grad(cm.layer_norm.bias)
+        GC.pw1, GC.dw = grad(cm.pointwise_conv1.weight), grad(cm.depthwise_conv.weight)
+        GC.bn_g, GC.bn_b, GC.pw2 = grad(cm.batch_norm.weight), grad(cm.batch_norm.bias), grad(cm.pointwise_conv2.weight)
+        L.final_ln_g, L.final_ln_b = _ptr(m.final_layer_norm.weight), _ptr(m.final_layer_norm.bias)
+        L.grads.final_ln_g, L.grads.final_ln_b = grad(m.final_layer_norm.weight), grad(m.final_layer_norm.bias)
+        self.L = L
+        self.params = [p for p in m.parameters()]
+
+    def finish_backward(self):
+        """Scatter packed q/k/v gradients back to their parameters and signal readiness."""
+        if self.split_w is not None:
+            gbuf, ps = self.split_w
+            n = ps[0].shape[0]
+            for i, p in enumerate(ps):
+                p.grad += gbuf[i * n:(i + 1) * n]
+        if self.split_b is not None:
+            gb, ps = self.split_b
+            n = ps[0].shape[0]
+            for i, p in enumerate(ps):
+                p.grad += gb[i * n:(i + 1) * n]
+        if _grad_ready_callback is not None:
+            _grad_ready_callback(self.params)
+
+
+class _ConformerLayerNative(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
+        import ctypes
+
+        from . import _lib
+        from ._lib import EaLayerShape
+
+        bind = getattr(module, "_ea_binding", None)
+        qw = module.self_attn.q_proj.weight
+        if bind is None or bind.key != (qw.data_ptr(), qw.grad.data_ptr() if qw.grad is not None else 0):
+            bind = _LayerBinding(module)
+            module._ea_binding = bind if bind.cacheable else None
+        sh = EaLayerShape()
+        sh.B, sh.T, sh.C, sh.H = B, T, module.embed_dim, module.num_heads
+        sh.F = module.ffn1.w_1.weight.shape[0]
+        sh.KW = module.conv_module.depthwise_conv.weight.shape[-1]
+        sh.training = int(training)
+        sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
+        sh.seed = _next_seed() * 64 % (1 << 63)
+        nb_saved, nb_scratch = ctypes.c_long(0), ctypes.c_long(0)
+        lib = _lib.lib()
+        _lib.check(lib.ea_conformer_layer_workspace(ctypes.byref(sh), ctypes.byref(nb_saved), ctypes.byref(nb_scratch)), "workspace")
+        saved = torch.empty(nb_saved.value, dtype=torch.uint8, device=x.device)
+        scratch = _scratch_buffer(nb_scratch.value, x.device)
+        y = torch.empty_like(x)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.ea_conformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
+                                              _ptr(pe), _ptr(saved), _ptr(scratch), stream), "ea_conformer_layer_fwd")
+        ctx.save_for_backward(x, saved, pe)
+        ctx.bind, ctx.sh, ctx.nb_scratch = bind, sh, nb_scratch.value
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+
+        from . import _lib
+
+        x, saved, pe = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        scratch = _scratch_buffer(ctx.nb_scratch, x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(pe),
+                                                     _ptr(saved), _ptr(scratch), stream), "ea_conformer_layer_bwd")
+        ctx.bind.finish_backward()
+        return (dx,) + (None,) * 10
+
+
+_scratch = {}
+
+
+def _scratch_buffer(nbytes, device):
+    """One reusable scratch arena per device (kernels of consecutive layers run in stream order)."""
+    key = str(device)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def conformer_layer_native(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
+    return _ConformerLayerNative.apply(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training)

@@ -98,6 +98,8 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         self.ffn2 = FeedForwardModule(d, cfg.encoder.ffn_embed_dim)
         self.final_layer_norm = LayerNormParams(d)
 
+    use_native_runtime = True  # whole layer per C-ABI call (csrc/engine.hip); False: per-kernel composition
+
     def forward(self, x, B, T, key_len=None, attn_mask=None):
         """x: bf16 [B*T][C] (batch-major rows).  key_len: int32 [B] valid lengths or None.
         attn_mask: fp32 additive [T][T] or None (already -1e8 / -1e4 filled as in the reference :107-110)."""
@@ -106,6 +108,12 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         p_drop = cfg.dropout if tr else 0.0
         p_act = cfg.activation_dropout if tr else 0.0
         p_att = cfg.attention_dropout if tr else 0.0
+        if self.use_native_runtime and self.positional_embedding[0] is not None:
+            y = F.conformer_layer_native(x, self, key_len, attn_mask, self.positional_embedding[0].table(T, x.device), B, T,
+                                         p_drop, p_act, p_att, tr)
+            if tr:
+                self.conv_module.batch_norm.num_batches_tracked += 1
+            return y
         f = self.ffn1
         x = F.ffn_module(x, f.layer_norm.weight, f.layer_norm.bias, f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias,
                          act="silu", p_act=p_act, p_out=p_drop, out_scale=0.5)

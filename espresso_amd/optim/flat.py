@@ -31,6 +31,11 @@ class FlatParams:
                     for p in grp:
                         seen.add(id(p))
                         params.append(p)
+                bgrp = [m.q_proj.bias, m.k_proj.bias, m.v_proj.bias]
+                if all(b is not None and id(b) not in seen for b in bgrp) and bgrp[0].numel() % _ALIGN == 0:
+                    for p in bgrp:  # adjacent, no padding: the runtime reads them as one [3C] vector
+                        seen.add(id(p))
+                        params.append(p)
         for p in module.parameters():
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))

@@ -204,6 +204,39 @@ int ea_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long n, c
                  float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad,
                  ea_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Native layer runtime (csrc/engine.hip): a whole Conformer encoder layer per call —
+ * espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:81-145 forward and its
+ * backward — as one back-to-back launch sequence on `stream`.  Weights: bf16 matrices (w1, w2, wqkv =
+ * [q;k;v] rows, wo, wpos, pw1, pw2) + fp32 vectors; gradients are ACCUMULATED (+=) into the fp32
+ * buffers in `grads` (the flat gradient buffer).  x: bf16 [B*T][C] batch-major rows.  `pe`: bf16
+ * [2T-1][C] sinusoidal table.  `saved` carries activations from fwd to bwd, `scratch` is reusable;
+ * sizes from ea_conformer_layer_workspace.  Dropout masks are re-derived from `seed`. */
+typedef struct EaFfnParams { const float *ln_g, *ln_b; const void* w1; const float* b1; const void* w2; const float* b2; } EaFfnParams;
+typedef struct EaFfnGrads { float *ln_g, *ln_b, *w1, *b1, *w2, *b2; } EaFfnGrads;
+typedef struct EaAttnParams {
+  const float *ln_g, *ln_b; const void* wqkv; const float* bqkv; const void* wo; const float* bo;
+  const float *pos_u, *pos_v; const void* wpos;
+} EaAttnParams;
+typedef struct EaAttnGrads { float *ln_g, *ln_b, *wqkv, *bqkv, *wo, *bo, *pos_u, *pos_v, *wpos; } EaAttnGrads;
+typedef struct EaConvParams {
+  const float *ln_g, *ln_b; const void* pw1; const float* dw; const float *bn_g, *bn_b; float *bn_rm, *bn_rv; const void* pw2;
+} EaConvParams;
+typedef struct EaConvGrads { float *ln_g, *ln_b, *pw1, *dw, *bn_g, *bn_b, *pw2; } EaConvGrads;
+typedef struct EaLayerGrads { EaFfnGrads ffn1; EaAttnGrads attn; EaConvGrads conv; EaFfnGrads ffn2; float *final_ln_g, *final_ln_b; } EaLayerGrads;
+typedef struct EaConformerLayer {
+  EaFfnParams ffn1; EaAttnParams attn; EaConvParams conv; EaFfnParams ffn2; const float *final_ln_g, *final_ln_b;
+  EaLayerGrads grads;
+} EaConformerLayer;
+typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; } EaLayerShape;
+
+int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
+int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
+                           const int* key_len, const float* attn_mask, const void* pe, void* saved, void* scratch,
+                           ea_stream_t stream);
+int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
+                           void* dx, const void* pe, void* saved, void* scratch, ea_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,3 +69,10 @@ def test_encoder_vs_reference_fixture(layer_type):
     assert r["eval_greedy_agree"] > 0.9, r
     assert r["worst_grad"][1] < 0.2, r
     assert r["bn_running_abs"] < 2e-2, r
+
+
+def test_native_layer_runtime_matches_kernel_composition():
+    r = G.check_native_layer()
+    print(r)
+    assert r["out_abs"] < 1e-6, r          # identical launch sequence -> bit-identical output
+    assert r["worst_grad"][1] < 2e-3, r    # only the summation order of split-K / atomics differs
