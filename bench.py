@@ -193,34 +193,24 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # Instrumented replay of timed-region steps: HIP events around every launch of the dominant
-        # kernel (the bf16 MFMA GEMM) on the stream it is launched on; flops = 2*M*N*K*batch per launch.
-        rec = []
-        orig = K.gemm
-
-        def timed_gemm(A, B, C, M, N, Kd, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(A, B, C, M, N, Kd, **kw)
-            e1.record()
-            rec.append((e0, e1, 2.0 * M * N * Kd * kw.get("batch", 1)))
-            return r
-
-        import espresso_amd.functional as Fm
-        K.gemm = timed_gemm
-        Fm.K.gemm = timed_gemm
+        # Instrumented replay of timed-region steps: the library records one HIP-event pair around every
+        # launch of the dominant kernel (the bf16 MFMA GEMM) on its launch stream; flops = 2*M*N*K*batch.
+        import ctypes
+        from espresso_amd import _lib
+        lib = _lib.lib()
         nrep = min(2, args.steps)
+        lib.ea_gemm_profile_enable(1)
         for i in range(args.warmup, args.warmup + nrep):
             trainer.train_step([samples[i]])
         torch.cuda.synchronize()
-        K.gemm = orig
-        Fm.K.gemm = orig
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-        tot_fl = sum(f for _, _, f in rec)
+        ms, fl = ctypes.c_double(0), ctypes.c_double(0)
+        n = lib.ea_gemm_profile_read(ctypes.byref(ms), ctypes.byref(fl))
+        lib.ea_gemm_profile_enable(0)
+        tot_ms, tot_fl = ms.value, fl.value
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                    "launches_per_step": len(rec) / nrep, "avg_launch_us": tot_ms * 1e3 / len(rec),
+                    "launches_per_step": n / nrep, "avg_launch_us": tot_ms * 1e3 / max(n, 1),
                     "gemm_ms_per_step": tot_ms / nrep, "gemm_flop_per_step": tot_fl / nrep}
 
     cpu = None

@@ -407,6 +407,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const EaGemmParams p
 
 }  // namespace
 
+// ---- optional live profiling of the dominant kernel (bench.py roofline): HIP events around every launch on
+// the launch stream; flops = 2*M*N*K*batch per launch.
+#include <vector>
+struct GemmProf { hipEvent_t e0, e1; double flops; };
+static bool g_prof_on = false;
+static std::vector<GemmProf> g_prof;
+
+extern "C" int ea_gemm_profile_enable(int on) {
+  g_prof_on = on != 0;
+  if (on) {
+    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.clear();
+  }
+  return 0;
+}
+// total_ms / total_flops over the launches recorded since enable(1); returns the number of launches
+extern "C" long ea_gemm_profile_read(double* total_ms, double* total_flops) {
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : g_prof) {
+    hipEventSynchronize(r.e1);
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.e0, r.e1);
+    ms += t;
+    fl += r.flops;
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  return (long)g_prof.size();
+}
+
 static int g_gemm_variant = 0;  // 0: single LDS stage, 1: double-buffered LDS
 extern "C" int ea_set_gemm_variant(int v) {
   const int old = g_gemm_variant;
@@ -441,10 +471,21 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     q.kchunk = q.K;
   }
   dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, q.batch * q.splitk), block(256);
+  GemmProf pr;
+  if (g_prof_on) {
+    hipEventCreate(&pr.e0);
+    hipEventCreate(&pr.e1);
+    pr.flops = 2.0 * q.M * q.N * (double)q.K * q.batch;
+    hipEventRecord(pr.e0, stream);
+  }
   if (p.a_kstrided) {
     if (p.b_kstrided) launch_gemm<true, true>(grid, stream, q); else launch_gemm<true, false>(grid, stream, q);
   } else {
     if (p.b_kstrided) launch_gemm<false, true>(grid, stream, q); else launch_gemm<false, false>(grid, stream, q);
+  }
+  if (g_prof_on) {  // the split-K reduce pass is a separate (HBM-bound) kernel and is not counted
+    hipEventRecord(pr.e1, stream);
+    g_prof.push_back(pr);
   }
   if (q.splitk > 1) {
     long per = (long)q.batch * q.M * q.N;

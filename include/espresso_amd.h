@@ -77,6 +77,10 @@ long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk);
 /* tuning hook: 0 = single LDS stage (32 KiB, two barriers per K-step), 1 = double-buffered LDS (64 KiB, one barrier);
  * returns the previous value. */
 int ea_set_gemm_variant(int v);
+/* live profiling of ea_gemm_bf16 for roofline reports: enable(1) clears and starts recording one HIP-event
+ * pair per launch on the launch stream; read() synchronises and returns launches, summed ms and flops. */
+int ea_gemm_profile_enable(int on);
+long ea_gemm_profile_read(double* total_ms, double* total_flops);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused
