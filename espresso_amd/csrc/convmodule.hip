@@ -114,17 +114,25 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
                                                          bf16_t* __restrict__ Hout, long M, int C, int act) {
   const int nch = C >> 3;
   const long total = M * nch;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  // host guarantees stride % nch == 0: the channel chunk of a thread never changes -> hoist its constants
+  const int ch = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % nch);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = ch * 8 + e;
+    sc[e] = mean_rstd[C + c] * gamma[c];
+    sh[e] = beta[c] - mean_rstd[c] * sc[e];
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const long m = i / nch;
-    const int ch = (int)(i % nch);
     const uint4 u = *reinterpret_cast<const uint4*>(Z + m * C + ch * 8);
     const uint32_t wv[4] = {u.x, u.y, u.z, u.w};
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = ch * 8 + e;
       const float z = (e & 1) ? __uint_as_float(wv[e >> 1] & 0xffff0000u) : __uint_as_float(wv[e >> 1] << 16);
-      const float y = (z - mean_rstd[c]) * mean_rstd[C + c] * gamma[c] + beta[c];
+      const float y = z * sc[e] + sh[e];
       o[e] = act == 2 ? silu_f(y) : (act == 1 ? fmaxf(y, 0.f) : y);
     }
     uint4 r;
@@ -186,23 +194,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16_t* __r
   const int nch = C >> 3;
   const long total = M * nch;
   const float invn = n > 0.f ? 1.f / n : 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int ch = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % nch);  // constant per thread (stride % nch == 0)
+  float mu[8], rs[8], ga[8], be[8], r0[8], r1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = ch * 8 + e;
+    mu[e] = mean_rstd[c]; rs[e] = mean_rstd[C + c]; ga[e] = gamma[c]; be[e] = beta[c];
+    r0[e] = red[c] * invn; r1[e] = red[C + c] * invn;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const long m = i / nch;
-    const int ch = (int)(i % nch);
     const uint4 uz = *reinterpret_cast<const uint4*>(Z + m * C + ch * 8);
     const uint4 ud = *reinterpret_cast<const uint4*>(dH + m * C + ch * 8);
     const uint32_t wz[4] = {uz.x, uz.y, uz.z, uz.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = ch * 8 + e;
       const float z = (e & 1) ? __uint_as_float(wz[e >> 1] & 0xffff0000u) : __uint_as_float(wz[e >> 1] << 16);
       float d = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
-      const float rstd = mean_rstd[C + c];
-      const float xh = (z - mean_rstd[c]) * rstd;
-      const float y = xh * gamma[c] + beta[c];
+      const float xh = (z - mu[e]) * rs[e];
+      const float y = xh * ga[e] + be[e];
       d *= act == 2 ? dsilu_f(y) : (act == 1 ? (y > 0.f ? 1.f : 0.f) : 1.f);
-      o[e] = rstd * gamma[c] * (d - red[c] * invn - xh * red[C + c] * invn);
+      o[e] = rs[e] * ga[e] * (d - r0[e] - xh * r1[e]);
     }
     uint4 r;
     r.x = pack_bf2(o[0], o[1]); r.y = pack_bf2(o[2], o[3]); r.z = pack_bf2(o[4], o[5]); r.w = pack_bf2(o[6], o[7]);
@@ -266,56 +280,57 @@ __global__ __launch_bounds__(128) void glu_dwconv_bwd_data_kernel(const bf16_t* 
 }
 
 // dw[c][k] += sum_{b,t} dZ[b,t,c] * U[b,t-PAD+k,c]
-constexpr int TTW = 128;  // time tile of the weight-gradient kernel (31*2 atomics per thread per tile)
+// Weight gradient of the depthwise conv: one channel per thread, 32-step time tiles -> many wavefronts to hide the
+// dependent-load latency; each block writes its partial [C][KW] slab (no atomics), a second kernel sums slabs.
+constexpr int TTW = 32;
 template <int KW>
 __global__ __launch_bounds__(128) void dwconv_bwd_weight_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ U,
-                                                                float* __restrict__ dw, int T, int C) {
+                                                                float* __restrict__ part, int T, int C) {
   constexpr int PAD = (KW - 1) / 2;
-  constexpr int TT = TTW;
-  const int c = (blockIdx.x * 128 + threadIdx.x) * 2;
+  const int c = blockIdx.x * 128 + threadIdx.x;
   if (c >= C) return;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.y * TT;
-  float a0[KW], a1[KW], x0[KW], x1[KW];
+  const int t0 = blockIdx.y * TTW;
+  float a0[KW], x0[KW];
 #pragma unroll
-  for (int k = 0; k < KW; ++k) a0[k] = a1[k] = x0[k] = x1[k] = 0.f;
+  for (int k = 0; k < KW; ++k) a0[k] = x0[k] = 0.f;
   const long rowbase = (long)b * T;
-  for (int tin = t0 - PAD; tin < t0 + TT + PAD; ++tin) {
-    float u0 = 0.f, u1 = 0.f;
-    if (tin >= 0 && tin < T) {
-      const uint32_t uu = *reinterpret_cast<const uint32_t*>(U + (rowbase + tin) * C + c);
-      u0 = __uint_as_float(uu << 16);
-      u1 = __uint_as_float(uu & 0xffff0000u);
-    }
+  for (int tin = t0 - PAD; tin < t0 + TTW + PAD; ++tin) {
+    float u0 = 0.f;
+    if (tin >= 0 && tin < T) u0 = bf2f(U[(rowbase + tin) * C + c]);
 #pragma unroll
-    for (int k = 0; k < KW - 1; ++k) {
-      x0[k] = x0[k + 1];
-      x1[k] = x1[k + 1];
-    }
+    for (int k = 0; k < KW - 1; ++k) x0[k] = x0[k + 1];
     x0[KW - 1] = u0;
-    x1[KW - 1] = u1;
     const int tout = tin - PAD;
     if (tout >= t0 && tout < T) {
-      const uint32_t dd = *reinterpret_cast<const uint32_t*>(dZ + (rowbase + tout) * C + c);
-      const float d0 = __uint_as_float(dd << 16), d1 = __uint_as_float(dd & 0xffff0000u);
+      const float d0 = bf2f(dZ[(rowbase + tout) * C + c]);
 #pragma unroll
-      for (int k = 0; k < KW; ++k) {
-        a0[k] += d0 * x0[k];
-        a1[k] += d1 * x1[k];
-      }
+      for (int k = 0; k < KW; ++k) a0[k] += d0 * x0[k];
     }
   }
+  float* out = part + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * C + c) * KW;
 #pragma unroll
-  for (int k = 0; k < KW; ++k) {
-    atomicAdd(dw + (long)c * KW + k, a0[k]);
-    atomicAdd(dw + (long)(c + 1) * KW + k, a1[k]);
-  }
+  for (int k = 0; k < KW; ++k) out[k] = a0[k];
+}
+__global__ __launch_bounds__(256) void dwconv_weight_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nslab,
+                                                                   int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < nslab; ++s) a += part[(long)s * n + i];
+  dw[i] += a;
 }
 
 static inline int egrid(long n) {
   long b = (n + 255) / 256;
   if (b > 8192) b = 8192;
   if (b < 1) b = 1;
+  return (int)b;
+}
+// grid whose total thread count is a multiple of nch (so a thread keeps one channel chunk)
+static inline int egrid_ch(long n, int nch) {
+  long b = egrid(n);
+  while ((b * 256) % nch) ++b;
   return (int)b;
 }
 
@@ -371,7 +386,7 @@ extern "C" int ea_bn_act_fwd(const void* Z, const float* mean_rstd, const float*
                              long M, int C, int act, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 8) return -2;
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(egrid(M * (C / 8))), dim3(256), 0, stream, (const bf16_t*)Z, mean_rstd,
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z, mean_rstd,
                      gamma, beta, (bf16_t*)H, M, C, act);
   return EA_CHECK_LAUNCH();
 }
@@ -401,20 +416,27 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
   dim3 g1((C / 2 + TC - 1) / TC, (unsigned)((M + rpb - 1) / rpb));
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, g1, dim3(256), 0, stream, (const bf16_t*)Z, (const bf16_t*)dH,
                      mean_rstd, gamma, beta, red, M, C, act, rpb, TC);
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid(M * (C / 8))), dim3(256), 0, stream, (const bf16_t*)Z,
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z,
                      (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, M, C, act,
                      training ? (float)M : 0.f);
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, C);
   return EA_CHECK_LAUNCH();
 }
 
+extern "C" long ea_dwconv_wgrad_workspace_bytes(int B, int T, int C, int KW) {
+  return (long)B * ((T + TTW - 1) / TTW) * C * KW * (long)sizeof(float);
+}
+
 extern "C" int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float* w, void* dY, float* dw,
-                                 int B, int T, int C, int KW, hipStream_t stream) {
+                                 void* wgrad_ws, int B, int T, int C, int KW, hipStream_t stream) {
   if (B <= 0 || T <= 0) return 0;
   if (C % 2) return -2;
   dim3 grid((C / 2 + 127) / 128, (T + TT - 1) / TT, B);
   EA_KW_DISPATCH(KW, launch_glu_dwconv_bwd_data, grid, stream, (const bf16_t*)dZ, (const bf16_t*)Y, w, (bf16_t*)dY, T, C);
-  dim3 gridw((C / 2 + 127) / 128, (T + TTW - 1) / TTW, B);
-  EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, gridw, stream, (const bf16_t*)dZ, (const bf16_t*)U, dw, T, C);
+  dim3 gridw((C + 127) / 128, (T + TTW - 1) / TTW, B);
+  float* part = (float*)wgrad_ws;
+  EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, gridw, stream, (const bf16_t*)dZ, (const bf16_t*)U, part, T, C);
+  hipLaunchKernelGGL(dwconv_weight_reduce_kernel, dim3((C * KW + 255) / 256), dim3(256), 0, stream, part, dw,
+                     (int)(gridw.y * gridw.z), C * KW);
   return EA_CHECK_LAUNCH();
 }

@@ -247,10 +247,22 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   G gt2(dBD, a.pp, t2, T, dh, R, Rp, C, C);
   gt2.bks().alpha(scaling).batch(Z, B, (long)B * T * Rp, (long)T * Rp, dh, 0, dh, (long)T * C);
   gemm(c, gt2);
+  // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames
+  // -> split-K into fp32, then one cast to bf16 for the pos_proj weight gradient
   uint16_t* dpp = sc.get<uint16_t>((size_t)R * C);
-  G gpp(dBD, a.qv, dpp, R, dh, B * T, Rp, C, C);
-  gpp.aks().bks().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
-  gemm(c, gpp);
+  {
+    float* dpp32 = sc.get<float>((size_t)R * C);
+    const int tiles = ((R + 127) / 128) * H;
+    int sk = (768 + tiles - 1) / tiles;
+    if (sk > (B * T) / 256) sk = (B * T) / 256;
+    if (sk < 1) sk = 1;
+    G gpp(dBD, a.qv, dpp32, R, dh, B * T, Rp, C, C);
+    gpp.aks().bks().f32().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
+    gpp.p.splitk = sk;
+    if (sk > 1) gpp.p.workspace = sc.get<float>((size_t)sk * H * R * dh);
+    gemm(c, gpp);
+    RUN(ea_cast_f32_to_bf16(dpp32, dpp, (long)R * C, c.s));
+  }
   wgrad(c, dpp, C, pe, C, gw.wpos, R, C, C);
   RUN(ea_colsum_bf16(t1, gw.pos_u, M, C, C, c.s));
   RUN(ea_colsum_bf16(t2, gw.pos_v, M, C, C, c.s));
@@ -326,7 +338,8 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   uint16_t* dZ = sc.get<uint16_t>((size_t)M * C);
   RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, gw.bn_g, gw.bn_b, M, C, EA_ACT_SILU, sh.training, c.s));
   uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
-  RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, gw.dw, B, T, C, sh.KW, c.s));
+  char* wws = sc.get<char>((size_t)ea_dwconv_wgrad_workspace_bytes(B, T, C, sh.KW));
+  RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, gw.dw, wws, B, T, C, sh.KW, c.s));
   wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   G gx(dY, w.pw1, dxn, M, C, 2 * C, 2 * C, C, C);

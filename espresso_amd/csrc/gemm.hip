@@ -116,6 +116,75 @@ __device__ __forceinline__ void store_ks(char* __restrict__ s, int tid, const ui
   }
 }
 
+// k-strided 4(k) x 8(row) block at an explicit (row, k) position (guarded)
+__device__ __forceinline__ void load_ks_at(const bf16_t* __restrict__ p, long ld, int rows, int K, int grow, int gk0,
+                                           uint4 (&r)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gk = gk0 + j;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gk < K && grow < rows) {
+      const bf16_t* q = p + (long)gk * ld + grow;
+      if (grow + 8 <= rows && (((uintptr_t)q) & 15) == 0) {
+        v = *reinterpret_cast<const uint4*>(q);
+      } else {
+        bf16_t t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (grow + e < rows) ? q[e] : (bf16_t)0;
+        v.x = t[0] | ((uint32_t)t[1] << 16);
+        v.y = t[2] | ((uint32_t)t[3] << 16);
+        v.z = t[4] | ((uint32_t)t[5] << 16);
+        v.w = t[6] | ((uint32_t)t[7] << 16);
+      }
+    }
+    r[j] = v;
+  }
+}
+__device__ __forceinline__ void store_ks_at(char* __restrict__ s, int r0, int kk0, const uint4 (&r)[4]) {
+  const uint32_t w0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
+  const uint32_t w1[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
+  const uint32_t w2[4] = {r[2].x, r[2].y, r[2].z, r[2].w};
+  const uint32_t w3[4] = {r[3].x, r[3].y, r[3].z, r[3].w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint2 lo, hi;
+    lo.x = (w0[d] & 0xffffu) | (w1[d] << 16);
+    lo.y = (w2[d] & 0xffffu) | (w3[d] << 16);
+    hi.x = (w0[d] >> 16) | (w1[d] & 0xffff0000u);
+    hi.y = (w2[d] >> 16) | (w3[d] & 0xffff0000u);
+    const int ra = r0 + 2 * d, rb = ra + 1;
+    *reinterpret_cast<uint2*>(s + lds_off(ra, kk0 >> 3) + (kk0 & 4) * 2) = lo;
+    *reinterpret_cast<uint2*>(s + lds_off(rb, kk0 >> 3) + (kk0 & 4) * 2) = hi;
+  }
+}
+// guarded k-contiguous load of NI row groups (32 rows each)
+template <int NI>
+__device__ __forceinline__ void load_kc_n(const bf16_t* __restrict__ p, long ld, int rows, int K, int row0, int k0, int tid,
+                                          uint4 (&r)[4]) {
+  const int c = tid & 7;
+  const int gk = k0 + c * 8;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = row0 + (tid >> 3) + 32 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < rows && gk < K) {
+      const bf16_t* q = p + (long)row * ld + gk;
+      if (gk + 8 <= K && (((uintptr_t)q) & 15) == 0) {
+        v = *reinterpret_cast<const uint4*>(q);
+      } else {
+        bf16_t t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (gk + e < K) ? q[e] : (bf16_t)0;
+        v.x = t[0] | ((uint32_t)t[1] << 16);
+        v.y = t[2] | ((uint32_t)t[3] << 16);
+        v.z = t[4] | ((uint32_t)t[5] << 16);
+        v.w = t[6] | ((uint32_t)t[7] << 16);
+      }
+    }
+    r[i] = v;
+  }
+}
+
 // Fast paths: whole tile in bounds and 16-byte aligned -> unconditional vector loads from per-thread base
 // pointers that only advance along k (no per-load bounds / alignment logic in the K loop).
 __device__ __forceinline__ void load_kc_fast(const bf16_t* __restrict__ base, long ld, int k0, uint4 (&r)[4]) {
@@ -244,17 +313,20 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
   }
 }
 
-template <bool A_KS, bool B_KS, bool DB>
+// BM_ = 128: 2x2 wavefronts of 64x64 (acc 4x4 MFMA tiles).  BM_ = 64: 1x4 wavefronts of 64x32 (acc 4x2) — twice
+// as many workgroups for GEMMs whose output has too few 128x128 tiles to fill 256 CUs (N = 512 projections).
+template <bool A_KS, bool B_KS, int BM_>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p) {
-  // DB: two LDS stages (64 KiB) and ONE barrier per K-step; !DB: one stage (32 KiB), two barriers.
-  __shared__ __attribute__((aligned(16))) char smem[(DB ? 4 : 2) * BM * ROW_BYTES];
+  constexpr int NJ = BM_ == 128 ? 4 : 2;  // n-tiles per wave
+  __shared__ __attribute__((aligned(16))) char smem[2 * BM * ROW_BYTES];  // A tile (<=128 rows) + B tile ; reused as fp32 C tile
   char* sA = smem;
   char* sB = smem + BM * ROW_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wm = BM_ == 128 ? (wave >> 1) : 0;
+  const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;  // first column of this wave's sub-tile
+  const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN;
   const int z = blockIdx.z / p.splitk;
   const int ks_id = blockIdx.z % p.splitk;
   const int zhi = z / p.zdiv, zlo = z % p.zdiv;
@@ -263,110 +335,103 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p)
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long)zhi * p.sB_hi + (long)zlo * p.sB_lo;
   const long coff = (long)zhi * p.sC_hi + (long)zlo * p.sC_lo;
 
-  // split-K: this block reduces k in [kbeg, kend)
   const int kbeg = ks_id * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[4], rb[4];
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-  // block-uniform fast-path predicates (tile fully inside the matrix, rows 16-byte aligned)
-  const bool a_ok = (m0 + BM <= p.M) && (p.lda & 7) == 0 && ((uintptr_t)A & 15) == 0 && (!A_KS || (m0 & 7) == 0);
+  const bool a_ok = (m0 + BM_ <= p.M) && (p.lda & 7) == 0 && ((uintptr_t)A & 15) == 0 && (!A_KS || (m0 & 7) == 0);
   const bool b_ok = (n0 + BN <= p.N) && (p.ldb & 7) == 0 && ((uintptr_t)B & 15) == 0 && (!B_KS || (n0 & 7) == 0);
-  const bf16_t* a_base = A_KS ? A + (long)((tid >> 4) * 4) * p.lda + m0 + (tid & 15) * 8
-                              : A + (long)(m0 + (tid >> 3)) * p.lda + (tid & 7) * 8;
+  // thread -> staging role.  A tile with 64 rows: k-contiguous uses i < 2 ; k-strided uses threads 0..127 only.
+  const int a_kq = BM_ == 128 ? (tid >> 4) : (tid >> 3);       // k-quad of the k-strided A block
+  const int a_rc = BM_ == 128 ? (tid & 15) : (tid & 7);        // 8-row chunk of the k-strided A block
+  const bool a_ks_active = BM_ == 128 || tid < 128;
+  const bf16_t* a_base = A_KS ? A + (long)(a_kq * 4) * p.lda + m0 + a_rc * 8 : A + (long)(m0 + (tid >> 3)) * p.lda + (tid & 7) * 8;
   const bf16_t* b_base = B_KS ? B + (long)((tid >> 4) * 4) * p.ldb + n0 + (tid & 15) * 8
                               : B + (long)(n0 + (tid >> 3)) * p.ldb + (tid & 7) * 8;
   auto loadA = [&](int k0) {
-    if (a_ok && k0 + BK <= kend) { if (A_KS) load_ks_fast(a_base, p.lda, k0, ra); else load_kc_fast(a_base, p.lda, k0, ra); }
-    else { if (A_KS) load_ks(A, p.lda, p.M, kend, m0, k0, tid, ra); else load_kc(A, p.lda, p.M, kend, m0, k0, tid, ra); }
+    if (A_KS) {
+      if (!a_ks_active) return;
+      if (a_ok && k0 + BK <= kend) load_ks_fast(a_base, p.lda, k0, ra);
+      else load_ks_at(A, p.lda, p.M, kend, m0 + a_rc * 8, k0 + a_kq * 4, ra);
+    } else {
+      if (a_ok && k0 + BK <= kend) {
+#pragma unroll
+        for (int i = 0; i < BM_ / 32; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_base + (long)(32 * i) * p.lda + k0);
+      } else {
+        load_kc_n<BM_ / 32>(A, p.lda, p.M, kend, m0, k0, tid, ra);
+      }
+    }
   };
   auto loadB = [&](int k0) {
     if (b_ok && k0 + BK <= kend) { if (B_KS) load_ks_fast(b_base, p.ldb, k0, rb); else load_kc_fast(b_base, p.ldb, k0, rb); }
     else { if (B_KS) load_ks(B, p.ldb, p.N, kend, n0, k0, tid, rb); else load_kc(B, p.ldb, p.N, kend, n0, k0, tid, rb); }
   };
+  auto storeA = [&]() {
+    if (A_KS) {
+      if (a_ks_active) store_ks_at(sA, a_rc * 8, a_kq * 4, ra);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BM_ / 32; ++i) *reinterpret_cast<uint4*>(sA + lds_off((tid >> 3) + 32 * i, tid & 7)) = ra[i];
+    }
+  };
   if (nk > 0) {
     loadA(kbeg);
     loadB(kbeg);
   }
-  // fragment read offsets are loop invariant
-  uint32_t a_off[2][4], b_off[2][4];
+  uint32_t a_off[2][4], b_off[2][NJ];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a_off[ks][i] = lds_off(wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
-      b_off[ks][i] = lds_off(wn * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
-    }
+    for (int i = 0; i < 4; ++i) a_off[ks][i] = lds_off(wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b_off[ks][j] = lds_off(wcol + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+  }
 
-  auto compute = [&](const char* cA, const char* cB) {
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    storeA();
+    if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
+    __syncthreads();
+    if (kt + 1 < nk) { loadA(kbeg + (kt + 1) * BK); loadB(kbeg + (kt + 1) * BK); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], bfr[4];
+      bf16x8_t af[4], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(cA + a_off[ks][i]);
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[ks][i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(cB + b_off[ks][j]);
+      for (int j = 0; j < NJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + b_off[ks][j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]), acc[i][j], 0, 0, 0);
     }
-  };
-  if constexpr (DB) {
-    constexpr int STAGE = 2 * BM * ROW_BYTES;
-    if (nk > 0) {
-      if (A_KS) store_ks(sA, tid, ra); else store_kc(sA, tid, ra);
-      if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
-      if (nk > 1) { loadA(kbeg + BK); loadB(kbeg + BK); }
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      compute(sA + cur * STAGE, sB + cur * STAGE);
-      if (kt + 1 < nk) {
-        char* nA = sA + (cur ^ 1) * STAGE;
-        char* nB = sB + (cur ^ 1) * STAGE;
-        if (A_KS) store_ks(nA, tid, ra); else store_kc(nA, tid, ra);
-        if (B_KS) store_ks(nB, tid, rb); else store_kc(nB, tid, rb);
-      }
-      __syncthreads();
-      if (kt + 2 < nk) { loadA(kbeg + (kt + 2) * BK); loadB(kbeg + (kt + 2) * BK); }
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      __syncthreads();
-      if (A_KS) store_ks(sA, tid, ra); else store_kc(sA, tid, ra);
-      if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
-      __syncthreads();
-      if (kt + 1 < nk) { loadA(kbeg + (kt + 1) * BK); loadB(kbeg + (kt + 1) * BK); }
-      compute(sA, sB);
-    }
   }
 
   // ---- epilogue: accumulators -> fp32 LDS tile (64 rows at a time) -> coalesced 16/32-byte stores ----
-  // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wn*64 + j*16 + (lane&15)]
+  // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wcol + j*16 + (lane&15)]
   float* sC = reinterpret_cast<float*>(smem);  // [64][128] fp32 = 32 KiB
   const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < BM_ / 64; ++half) {
     __syncthreads();
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
     }
     __syncthreads();
     if (m0 + half * 64 < p.M) {
@@ -437,7 +502,7 @@ extern "C" long ea_gemm_profile_read(double* total_ms, double* total_flops) {
   return (long)g_prof.size();
 }
 
-static int g_gemm_variant = 0;  // 0: single LDS stage, 1: double-buffered LDS
+static int g_gemm_variant = 0;  // 0: automatic tile height, 1: always 128-row tiles, 2: always 64-row tiles
 extern "C" int ea_set_gemm_variant(int v) {
   const int old = g_gemm_variant;
   g_gemm_variant = v;
@@ -445,9 +510,9 @@ extern "C" int ea_set_gemm_variant(int v) {
 }
 
 template <bool A_KS, bool B_KS>
-static void launch_gemm(dim3 grid, hipStream_t stream, const EaGemmParams& q) {
-  if (g_gemm_variant == 1) hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, true>), grid, dim3(256), 0, stream, q);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, false>), grid, dim3(256), 0, stream, q);
+static void launch_gemm(dim3 grid, bool bm64, hipStream_t stream, const EaGemmParams& q) {
+  if (bm64) hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 64>), grid, dim3(256), 0, stream, q);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 128>), grid, dim3(256), 0, stream, q);
 }
 
 extern "C" long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk) {
@@ -470,7 +535,11 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   } else {
     q.kchunk = q.K;
   }
-  dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, q.batch * q.splitk), block(256);
+  // tile-height choice: 64-row tiles when 128-row tiles would leave the 256 CUs (x3 resident workgroups) under-filled
+  const long tiles128 = (long)((q.N + BN - 1) / BN) * ((q.M + BM - 1) / BM) * q.batch * q.splitk;
+  const bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < 512 && q.M > 64));
+  const int bm = bm64 ? 64 : BM;
+  dim3 grid((q.N + BN - 1) / BN, (q.M + bm - 1) / bm, q.batch * q.splitk), block(256);
   GemmProf pr;
   if (g_prof_on) {
     hipEventCreate(&pr.e0);
@@ -479,9 +548,9 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     hipEventRecord(pr.e0, stream);
   }
   if (p.a_kstrided) {
-    if (p.b_kstrided) launch_gemm<true, true>(grid, stream, q); else launch_gemm<true, false>(grid, stream, q);
+    if (p.b_kstrided) launch_gemm<true, true>(grid, bm64, stream, q); else launch_gemm<true, false>(grid, bm64, stream, q);
   } else {
-    if (p.b_kstrided) launch_gemm<false, true>(grid, stream, q); else launch_gemm<false, false>(grid, stream, q);
+    if (p.b_kstrided) launch_gemm<false, true>(grid, bm64, stream, q); else launch_gemm<false, false>(grid, bm64, stream, q);
   }
   if (g_prof_on) {  // the split-K reduce pass is a separate (HBM-bound) kernel and is not counted
     hipEventRecord(pr.e1, stream);

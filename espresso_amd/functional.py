@@ -272,9 +272,10 @@ class _RelPosMHSA(torch.autograd.Function):
             K.gemm(dBD, pp, t2, T, dh, R, lda=Rp, ldb=C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Rp, T * Rp),
                    sB=(dh, 0), sC=(dh, T * C), alpha=scaling)
             # dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]
-            dpp = _new((R, C), torch.bfloat16, x)
-            K.gemm(dBD, qv, dpp, R, dh, B * T, lda=Rp, ldb=C, ldc=C, a_kstrided=True, b_kstrided=True, batch=H, zdiv=1,
-                   sA=(B * T * Rp, 0), sB=(dh, 0), sC=(dh, 0))
+            dpp32 = _new((R, C), torch.float32, x)
+            K.gemm(dBD, qv, dpp32, R, dh, B * T, lda=Rp, ldb=C, ldc=C, a_kstrided=True, b_kstrided=True, batch=H, zdiv=1,
+                   sA=(B * T * Rp, 0), sB=(dh, 0), sC=(dh, 0), splitk=_auto_splitk(((R + 127) // 128) * H, B * T))
+            dpp = K.cast_f32_to_bf16(dpp32)
             dWpos = _wgrad(dpp, pe, R, C, C)
             du = K.colsum(t1, _zeros_f32(C, x), M, C, C)
             dv = K.colsum(t2, _zeros_f32(C, x), M, C, C)

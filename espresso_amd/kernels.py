@@ -274,7 +274,8 @@ def bn_act_bwd(Z, dH, mean_rstd, gamma, beta, dgamma, dbeta, act, training=True)
 
 def glu_dwconv_bwd(dZ, Y, U, w, dw, B, T, C, KW):
     dY = torch.empty(B * T, 2 * C, dtype=torch.bfloat16, device=Y.device)
-    check(_lib.lib().ea_glu_dwconv_bwd(_p(dZ), _p(Y), _p(U), _p(w), _p(dY), _p(dw), B, T, C, KW, _stream()),
+    ws = torch.empty(int(_lib.lib().ea_dwconv_wgrad_workspace_bytes(B, T, C, KW)), dtype=torch.uint8, device=Y.device)
+    check(_lib.lib().ea_glu_dwconv_bwd(_p(dZ), _p(Y), _p(U), _p(w), _p(dY), _p(dw), _p(ws), B, T, C, KW, _stream()),
           "ea_glu_dwconv_bwd")
     return dY
 

@@ -74,8 +74,8 @@ typedef struct EaGemmParams {
 
 int ea_gemm_bf16(const EaGemmParams* p, ea_stream_t stream);
 long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk);
-/* tuning hook: 0 = single LDS stage (32 KiB, two barriers per K-step), 1 = double-buffered LDS (64 KiB, one barrier);
- * returns the previous value. */
+/* tuning hook: 0 = automatic tile height (64-row tiles when 128x128 tiles under-fill the chip), 1 = always 128,
+ * 2 = always 64; returns the previous value. */
 int ea_set_gemm_variant(int v);
 /* live profiling of ea_gemm_bf16 for roofline reports: enable(1) clears and starts recording one HIP-event
  * pair per launch on the launch stream; read() synchronises and returns launches, summed ms and flops. */
@@ -141,8 +141,10 @@ int ea_bn_act_fwd(const void* Z, const float* mean_rstd, const float* gamma, con
 int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
                   float* red, void* dZ, float* dgamma, float* dbeta, long M, int C, int act, int training,
                   ea_stream_t stream);
-int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float* w, void* dY, float* dw, int B,
-                      int T, int C, int KW, ea_stream_t stream);
+/* dw += ... ; wgrad_ws: ea_dwconv_wgrad_workspace_bytes(B,T,C,KW) bytes of scratch (per-block partial slabs) */
+long ea_dwconv_wgrad_workspace_bytes(int B, int T, int C, int KW);
+int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float* w, void* dY, float* dw,
+                      void* wgrad_ws, int B, int T, int C, int KW, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conv2d sub-sampler — espresso/modules/speech_convolutions.py:78-102.  Channels-last bf16

@@ -22,8 +22,11 @@ def rel_err(a, b):
 
 
 # ------------------------------------------------------------------ GEMM
-def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, c_f32=False, seed=0, splitk=1):
+def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, c_f32=False, seed=0, splitk=1, variant=0):
+    from espresso_amd import _lib
     from espresso_amd import kernels as Kk
+
+    _lib.lib().ea_set_gemm_variant(variant)
 
     g = torch.Generator(device="cpu").manual_seed(seed)
     A = bf(torch.randn(batch, K, M, generator=g) if a_ks else torch.randn(batch, M, K, generator=g)).to(DEV)
@@ -47,6 +50,7 @@ def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, 
             batch=batch, zdiv=1, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0), bias=bvec, act=act,
             out_scale=0.5 if resid else 1.0, resid=R, ldr=N, sR=(M * N, 0), splitk=splitk)
     torch.cuda.synchronize()
+    _lib.lib().ea_set_gemm_variant(0)
     return rel_err(C, ref)
 
 

@@ -16,13 +16,12 @@ def _need_gpu():
     _lib.lib()  # the HIP library must be the thing under test — fail loudly if it is missing
 
 
+@pytest.mark.parametrize("variant", [1, 2])  # 128-row and 64-row tiles
 @pytest.mark.parametrize("a_ks,b_ks", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (257, 190, 100), (77, 40, 16), (300, 513, 333)])
-def test_gemm_modes(a_ks, b_ks, shape):
-    M, N, K = shape
-    if (a_ks and M % 8) or (b_ks and N % 8):
-        pass  # unaligned leading dims exercise the guarded scalar path
-    e = G.check_gemm(M, N, K, a_ks, b_ks, batch=2)
+def test_gemm_modes(a_ks, b_ks, shape, variant):
+    M, N, K = shape  # unaligned leading dims exercise the guarded scalar path
+    e = G.check_gemm(M, N, K, a_ks, b_ks, batch=2, variant=variant)
     assert e < 1e-2, e
 
 
@@ -30,6 +29,8 @@ def test_gemm_epilogues():
     assert G.check_gemm(200, 136, 72, False, False, bias=True, act="silu") < 1e-2
     assert G.check_gemm(200, 136, 72, False, False, bias=True, act="relu", resid=True) < 1e-2
     assert G.check_gemm(130, 64, 520, True, True, c_f32=True) < 2e-3
+    assert G.check_gemm(200, 136, 72, False, False, bias=True, act="silu", variant=1) < 1e-2
+    assert G.check_gemm(200, 136, 72, True, False, bias=True, act="relu", resid=True, variant=2) < 1e-2
 
 
 def test_gemm_splitk():
