@@ -29,7 +29,7 @@ def run(name, M, N, Kd, a_ks=False, b_ks=False, batch=1, c_f32=False, splitk=1, 
 
 if __name__ == "__main__":
   from espresso_amd import _lib
-  for variant in (1, 2):
+  for variant in (0,):
     _lib.lib().ea_set_gemm_variant(variant)
     print("=== gemm variant", variant)
     M = 6468
