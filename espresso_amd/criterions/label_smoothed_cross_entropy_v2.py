@@ -1,0 +1,54 @@
+"""`label_smoothed_cross_entropy_v2` (uniform smoothing) — interface and bookkeeping of
+espresso/criterions/label_smoothed_cross_entropy_v2.py:158-243 on the fused HIP kernel
+(log-sum-exp + target gather + row sum + gradient in one pass per row; pad rows zeroed).
+Unigram / temporal smoothing (:49-92) are not implemented yet (recipes use `uniform`)."""
+import math
+
+import torch
+
+from .. import functional as F
+from ..registry import register_criterion
+
+
+@register_criterion("label_smoothed_cross_entropy_v2")
+class LabelSmoothedCrossEntropyV2Criterion:
+    def __init__(self, task, sentence_avg=True, label_smoothing=0.1, smoothing_type="uniform", **unused):
+        if smoothing_type != "uniform":
+            raise NotImplementedError(f"smoothing_type={smoothing_type}")
+        self.task = task
+        self.sentence_avg = sentence_avg
+        self.eps = label_smoothing
+        self.padding_idx = task.target_dictionary.pad()
+        self.epoch = 1
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __call__(self, model, sample, reduce=True):
+        return self.forward(model, sample, reduce)
+
+    def forward(self, model, sample, reduce=True):
+        net_output = model(**sample["net_input"])
+        logits3 = net_output[0]
+        logits = net_output[1].get("_logits_bu") if isinstance(net_output[1], dict) else None
+        if logits is None:
+            logits = logits3.reshape(-1, logits3.shape[-1])
+        target = sample["target"].reshape(-1).to(torch.int32).contiguous()
+        loss, nll = F.label_smoothed_ce(logits, target, self.padding_idx, self.eps)
+        sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        logging_output = {"loss": loss.detach(), "nll_loss": nll.detach(), "ntokens": sample["ntokens"],
+                          "nsentences": sample["target"].size(0), "sample_size": sample_size}
+        return loss, sample_size, logging_output
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        loss_sum = float(sum(float(l.get("loss", 0)) for l in logging_outputs))
+        nll_sum = float(sum(float(l.get("nll_loss", 0)) for l in logging_outputs))
+        ntokens = sum(l.get("ntokens", 0) for l in logging_outputs)
+        sample_size = sum(l.get("sample_size", 0) for l in logging_outputs)
+        return {"loss": loss_sum / max(sample_size, 1) / math.log(2), "nll_loss": nll_sum / max(ntokens, 1) / math.log(2),
+                "ppl": 2 ** (nll_sum / max(ntokens, 1) / math.log(2)), "ntokens": ntokens, "sample_size": sample_size}
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True

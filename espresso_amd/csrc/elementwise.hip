@@ -115,6 +115,31 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(bf16_t* __restrict__ x, 
   for (int c = threadIdx.x; c < C; c += 256) x[(long)row * C + c] = 0;
 }
 
+// out[m][:] = scale * W[tok[m]][:] + pos[position[m]][:]   (W, pos fp32; out bf16; one row per wave)
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int* __restrict__ tok, const int* __restrict__ position,
+                                                            const float* __restrict__ W, const float* __restrict__ pos,
+                                                            bf16_t* __restrict__ out, int M, int C, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* w = W + (long)tok[row] * C;
+  const float* pe = pos ? pos + (long)position[row] * C : nullptr;
+  for (int c = (threadIdx.x & 63) * 2; c < C; c += 128) {
+    float a = scale * w[c], b = scale * w[c + 1];
+    if (pe) { a += pe[c]; b += pe[c + 1]; }
+    *reinterpret_cast<uint32_t*>(out + (long)row * C + c) = pack_bf2(a, b);
+  }
+}
+// dW[tok[m]][:] += scale * dy[m][:]
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int* __restrict__ tok, const bf16_t* __restrict__ dy,
+                                                            float* __restrict__ dW, int M, int C, float scale, int pad_idx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int t = tok[row];
+  if (t == pad_idx) return;  // nn.Embedding(padding_idx): no gradient to the pad row
+  float* w = dW + (long)t * C;
+  for (int c = (threadIdx.x & 63); c < C; c += 64) atomicAdd(w + c, scale * bf2f(dy[(long)row * C + c]));
+}
+
 }  // namespace
 
 static inline int grid_for(long n, int per_thread) {
@@ -152,5 +177,19 @@ extern "C" int ea_colsum_bf16(const void* X, float* out, int M, int N, long ld, 
 extern "C" int ea_zero_rows_bf16(void* x, const uint8_t* row_zero, int M, int C, hipStream_t stream) {
   if (M <= 0) return 0;
   hipLaunchKernelGGL(zero_rows_kernel, dim3(M), dim3(256), 0, stream, (bf16_t*)x, row_zero, M, C);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_embedding_fwd(const int* tokens, const int* positions, const float* W, const float* pos_table, void* out,
+                                int M, int C, float scale, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 2) return -2;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, positions, W, pos_table, (bf16_t*)out, M, C, scale);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_embedding_bwd(const int* tokens, const void* dy, float* dW, int M, int C, float scale, int pad_idx,
+                                hipStream_t stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, (const bf16_t*)dy, dW, M, C, scale, pad_idx);
   return EA_CHECK_LAUNCH();
 }

@@ -199,6 +199,61 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// CTC greedy decoding (espresso/tools/ctc_decoder.py:172-188): per-frame argmax, collapse repeats, drop blanks.
+// x: [B][T][ld] logits or log-probs (argmax is invariant); best[b][t] = argmax index (lowest index on ties),
+// bestv[b][t] = max value.
+template <typename TIn>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const TIn* __restrict__ x, long ld, int V, int* __restrict__ best,
+                                                          float* __restrict__ bestv) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const long row = blockIdx.x;
+  const TIn* r = x + row * ld;
+  float mv = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float v;
+    if constexpr (sizeof(TIn) == 2) v = bf2f(r[c]); else v = r[c];
+    if (v > mv || (v == mv && c < mi)) { mv = v; mi = c; }
+  }
+  sv[threadIdx.x] = mv;
+  si[threadIdx.x] = mi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float ov = sv[threadIdx.x + s];
+      const int oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { best[row] = si[0]; bestv[row] = sv[0]; }
+}
+// one thread per utterance: tokens[b][0..n) (collapsed, blank removed), align[b][u] = first frame of token u
+__global__ void ctc_collapse_kernel(const int* __restrict__ best, const float* __restrict__ bestv, const int* __restrict__ in_len,
+                                    int* __restrict__ tokens, int* __restrict__ align, int* __restrict__ out_len,
+                                    float* __restrict__ score, int B, int T, int blank, int pad) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = in_len[b];
+  int u = 0, prev = -1;
+  float s = 0.f;
+  for (int t = 0; t < n; ++t) {
+    const int k = best[(long)b * T + t];
+    s += bestv[(long)b * T + t];
+    if (k != blank && k != prev) {
+      tokens[(long)b * T + u] = k;
+      if (align) align[(long)b * T + u] = t;
+      ++u;
+    }
+    prev = k;
+  }
+  for (int t = u; t < T; ++t) tokens[(long)b * T + t] = pad;
+  out_len[b] = u;
+  score[b] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Label-smoothed CE (uniform).  logits [M][ld] (bf16 or fp32), target[M] int64-as-int32 pairs -> we take int32.
 // out_loss[0] += sum loss, out_loss[1] += sum nll ; optional dlogits = scale * dloss/dlogits ; optional lprobs
 template <typename TIn, typename TOut>
@@ -259,6 +314,19 @@ extern "C" int ea_log_softmax_f32(const float* in, long ld_in, float* out, long 
 extern "C" int ea_log_softmax_bf16(const void* in, long ld_in, float* out, long M, int V, hipStream_t stream) {
   if (M <= 0) return 0;
   hipLaunchKernelGGL((log_softmax_kernel<bf16_t>), dim3((unsigned)M), dim3(256), 0, stream, (const bf16_t*)in, ld_in, out, V);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_ctc_greedy_decode(const void* x, long ld, int x_bf16, const int* in_len, int* best /*[B*T]*/,
+                                    float* bestv /*[B*T]*/, int* tokens /*[B][T]*/, int* align /*[B][T] or NULL*/,
+                                    int* out_len, float* score, int B, int T, int V, int blank, int pad, hipStream_t stream) {
+  if (B <= 0 || T <= 0) return 0;
+  if (x_bf16)
+    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3((unsigned)((long)B * T)), dim3(256), 0, stream, (const bf16_t*)x, ld, V, best, bestv);
+  else
+    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3((unsigned)((long)B * T)), dim3(256), 0, stream, (const float*)x, ld, V, best, bestv);
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, best, bestv, in_len, tokens, align, out_len, score,
+                     B, T, blank, pad);
   return EA_CHECK_LAUNCH();
 }
 

@@ -193,7 +193,7 @@ class _RelPosMHSA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, wqkv16, wo16, wpos16, pe, key_len, attn_mask, B, T,
-                H, p_attn, p_out, eps, pre_ln):
+                H, p_attn, p_out, eps, pre_ln, causal=False):
         M, C = x.shape
         dh = C // H
         scaling = dh ** -0.5
@@ -221,7 +221,7 @@ class _RelPosMHSA(torch.autograd.Function):
             K.gemm(qv, pp, bd, T, R, dh, lda=C, ldb=C, ldc=Rp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, 0),
                    sC=(B * T * Rp, T * Rp))
         sa = _next_seed() if p_attn > 0 else 0
-        P, Pd = K.relpos_softmax_fwd(ac, bd, key_len, attn_mask, H, B, T, T, Sp, Rp, Sp, False, p_attn, sa)
+        P, Pd = K.relpos_softmax_fwd(ac, bd, key_len, attn_mask, H, B, T, T, Sp, Rp, Sp, causal, p_attn, sa)
         del ac, bd
         o = _new((M, C), torch.bfloat16, x)
         K.gemm(Pd, qkv, o, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
@@ -292,15 +292,15 @@ class _RelPosMHSA(torch.autograd.Function):
         else:
             dg = db = None
             dx = K.scale_dropout(dxn, a=1.0, y=dy, b=1.0)
-        return (dx, dg, db, dWqkv, dbqkv, dWo, dbo, du, dv, dWpos) + (None,) * 13
+        return (dx, dg, db, dWqkv, dbqkv, dWo, dbo, du, dv, dWpos) + (None,) * 14
 
 
 def relpos_mhsa(x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, pe, key_len, attn_mask, B, T, H, p_attn=0.0, p_out=0.0,
-                eps=1e-5, pre_ln=True, wqkv16=None):
+                eps=1e-5, pre_ln=True, wqkv16=None, causal=False):
     return _RelPosMHSA.apply(
         x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, wqkv16 if wqkv16 is not None else bf16_weight(wqkv),
         bf16_weight(wo), bf16_weight(wpos) if wpos is not None else None, pe, key_len, attn_mask, B, T, H, p_attn, p_out,
-        eps, pre_ln)
+        eps, pre_ln, causal)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -718,3 +718,129 @@ def _scratch_buffer(nbytes, device):
 
 def conformer_layer_native(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
     return _ConformerLayerNative.apply(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training)
+
+
+# ------------------------------------------------------------------------------------------------
+class _CrossMHA(torch.autograd.Function):
+    """Encoder-decoder attention of fairseq/modules/transformer_layer.py:470-497 with its pre-LayerNorm, dropout and
+    residual: y = drop(out_proj(Attn(q = LN(x), k = v = enc))) + x.   x: [B*U][C], enc: [B*S][C] (batch-major rows).
+    wkv/bkv: fused [2C][C] / [2C] in (k, v) order."""
+
+    @staticmethod
+    def forward(ctx, x, enc, ln_g, ln_b, wq, bq, wkv, bkv, wo, bo, wq16, wkv16, wo16, key_len, B, U, S, H, p_attn, p_out, eps):
+        M, C = x.shape
+        Ms = enc.shape[0]
+        dh = C // H
+        scaling = dh ** -0.5
+        xn, mean, rstd = K.layernorm_fwd(x, ln_g, ln_b, eps)
+        q = _new((M, C), torch.bfloat16, x)
+        K.gemm(xn, wq16, q, M, C, C, lda=C, ldb=C, ldc=C, bias=bq)
+        qs, _ = K.relpos_q_prep(q, C, None, None, M, C, scaling, want_qv=False)
+        kv = _new((Ms, 2 * C), torch.bfloat16, x)
+        K.gemm(enc, wkv16, kv, Ms, 2 * C, C, lda=C, ldb=C, ldc=2 * C, bias=bkv)
+        Z = H * B
+        Sp = _pad8(S)
+        ac = _new((Z * U, Sp), torch.float32, x)
+        K.gemm(qs, kv, ac, U, S, dh, lda=C, ldb=2 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, U * C), sB=(dh, S * 2 * C),
+               sC=(B * U * Sp, U * Sp))
+        sa = _next_seed() if p_attn > 0 else 0
+        P, Pd = K.relpos_softmax_fwd(ac, None, key_len, None, H, B, U, S, Sp, 0, Sp, False, p_attn, sa)
+        del ac
+        o = _new((M, C), torch.bfloat16, x)
+        K.gemm(Pd, kv, o, U, dh, S, lda=Sp, ldb=2 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * U * Sp, U * Sp),
+               sB=(dh, S * 2 * C), b_off=C, sC=(dh, U * C))
+        so = _next_seed() if p_out > 0 else 0
+        y = _new((M, C), torch.bfloat16, x)
+        K.gemm(o, wo16, y, M, C, C, lda=C, ldb=C, ldc=C, bias=bo, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
+        ctx.save_for_backward(x, enc, ln_g, mean, rstd, xn, qs, kv, P, Pd, o, wq16, wkv16, wo16)
+        ctx.cfg = (B, U, S, H, p_attn, p_out, sa, so)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, enc, ln_g, mean, rstd, xn, qs, kv, P, Pd, o, wq16, wkv16, wo16 = ctx.saved_tensors
+        B, U, S, H, p_attn, p_out, sa, so = ctx.cfg
+        M, C = x.shape
+        Ms = enc.shape[0]
+        dh = C // H
+        scaling = dh ** -0.5
+        Z = H * B
+        Sp = _pad8(S)
+        dy = dy.contiguous()
+        g = K.scale_dropout(dy, a=1.0, drop_p=p_out, drop_seed=so) if p_out > 0 else dy
+        dWo = _wgrad(g, o, M, C, C)
+        dbo = K.colsum(g, _zeros_f32(C, x), M, C, C)
+        do = _new((M, C), torch.bfloat16, x)
+        K.gemm(g, wo16, do, M, C, C, lda=C, ldb=C, ldc=C, b_kstrided=True)
+        dPd = _new((Z * U, Sp), torch.float32, x)
+        K.gemm(do, kv, dPd, U, S, dh, lda=C, ldb=2 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, U * C), sB=(dh, S * 2 * C),
+               b_off=C, sC=(B * U * Sp, U * Sp))
+        dkv = _new((Ms, 2 * C), torch.bfloat16, x)
+        # dV[(b,j),h,d] = sum_i Pd[z][i][j] do[(b,i),h,d]
+        K.gemm(Pd, do, dkv, S, dh, U, lda=Sp, ldb=C, ldc=2 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
+               sA=(B * U * Sp, U * Sp), sB=(dh, U * C), sC=(dh, S * 2 * C), c_off=C)
+        dAC, _ = K.relpos_softmax_bwd(P, dPd, H, B, U, S, Sp, Sp, 0, want_bd=False, drop_p=p_attn, drop_seed=sa)
+        del dPd
+        # dK[(b,j),h,d] = sum_i dAC[z][i][j] qs[(b,i),h,d]
+        K.gemm(dAC, qs, dkv, S, dh, U, lda=Sp, ldb=C, ldc=2 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
+               sA=(B * U * Sp, U * Sp), sB=(dh, U * C), sC=(dh, S * 2 * C))
+        # dq = s * sum_j dAC[z][i][j] k[(b,j),h,d]
+        dq = _new((M, C), torch.bfloat16, x)
+        K.gemm(dAC, kv, dq, U, dh, S, lda=Sp, ldb=2 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * U * Sp, U * Sp),
+               sB=(dh, S * 2 * C), sC=(dh, U * C), alpha=scaling)
+        dWq = _wgrad(dq, xn, M, C, C)
+        dbq = K.colsum(dq, _zeros_f32(C, x), M, C, C)
+        dWkv = _wgrad(dkv, enc, Ms, 2 * C, C)
+        dbkv = K.colsum(dkv, _zeros_f32(2 * C, x), Ms, 2 * C, 2 * C)
+        denc = _new((Ms, C), torch.bfloat16, x)
+        K.gemm(dkv, wkv16, denc, Ms, C, 2 * C, lda=2 * C, ldb=C, ldc=C, b_kstrided=True)
+        dxn = _new((M, C), torch.bfloat16, x)
+        K.gemm(dq, wq16, dxn, M, C, C, lda=C, ldb=C, ldc=C, b_kstrided=True)
+        dg, db = _zeros_f32(C, x), _zeros_f32(C, x)
+        dx = K.layernorm_bwd(x, dxn, ln_g, mean, rstd, dg, db, dx_add=dy)
+        return (dx, denc, dg, db, dWq, dbq, dWkv, dbkv, dWo, dbo) + (None,) * 11
+
+
+def cross_mha(x, enc, ln_g, ln_b, wq, bq, wkv, bkv, wo, bo, key_len, B, U, S, H, p_attn=0.0, p_out=0.0, eps=1e-5):
+    return _CrossMHA.apply(x, enc, ln_g, ln_b, wq, bq, wkv, bkv, wo, bo, bf16_weight(wq), bf16_weight(wkv), bf16_weight(wo),
+                           key_len, B, U, S, H, p_attn, p_out, eps)
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, tokens, positions, pos_table, scale, pad_idx):
+        out = K.embedding_fwd(tokens, positions, W, pos_table, scale)
+        ctx.save_for_backward(tokens)
+        ctx.cfg = (W.shape, scale, pad_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tokens,) = ctx.saved_tensors
+        shape, scale, pad_idx = ctx.cfg
+        dW = torch.zeros(shape, dtype=torch.float32, device=dy.device)
+        K.embedding_bwd(tokens, dy.contiguous(), dW, scale, pad_idx)
+        return dW, None, None, None, None, None
+
+
+def embedding(W, tokens, positions=None, pos_table=None, scale=1.0, pad_idx=-1):
+    """bf16 [M][C] = scale * W[tokens] + pos_table[positions] ; tokens/positions int32 [M]."""
+    return _Embedding.apply(W, tokens, positions, pos_table, scale, pad_idx)
+
+
+def dropout(x, p):
+    """FairseqDropout on a bf16 activation (mask re-derived from the seed in backward)."""
+    return _Dropout.apply(x, p)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        seed = _next_seed()
+        ctx.cfg = (p, seed)
+        return K.scale_dropout(x.contiguous(), a=1.0, drop_p=p, drop_seed=seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        return K.scale_dropout(dy.contiguous(), a=1.0, drop_p=p, drop_seed=seed), None

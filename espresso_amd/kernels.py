@@ -410,3 +410,35 @@ def adam_step(p, g, m, v, p_bf16, coef, lr, beta1, beta2, eps, weight_decay, ste
                                 weight_decay, step, int(zero_grad), _stream()),
         "ea_adam_step",
     )
+
+
+def ctc_greedy_decode(x, in_len, B, T, V, blank, pad, ld=None, want_align=True):
+    """x: [B*T][V] fp32/bf16 log-probs (batch-major).  Returns tokens [B][T] (pad filled), lengths [B], scores [B], align [B][T]."""
+    dev = x.device
+    ld = x.stride(0) if ld is None else ld
+    best = torch.empty(B * T, dtype=torch.int32, device=dev)
+    bestv = torch.empty(B * T, dtype=torch.float32, device=dev)
+    tokens = torch.empty(B, T, dtype=torch.int32, device=dev)
+    align = torch.zeros(B, T, dtype=torch.int32, device=dev) if want_align else None
+    out_len = torch.empty(B, dtype=torch.int32, device=dev)
+    score = torch.empty(B, dtype=torch.float32, device=dev)
+    check(
+        _lib.lib().ea_ctc_greedy_decode(_p(x), ld, int(x.dtype == torch.bfloat16), _p(in_len), _p(best), _p(bestv), _p(tokens),
+                                        _p(align), _p(out_len), _p(score), B, T, V, blank, pad, _stream()),
+        "ea_ctc_greedy_decode",
+    )
+    return tokens, out_len, score, align
+
+
+def embedding_fwd(tokens, positions, W, pos_table, scale):
+    M, C = tokens.numel(), W.shape[1]
+    out = torch.empty(M, C, dtype=torch.bfloat16, device=W.device)
+    check(_lib.lib().ea_embedding_fwd(_p(tokens), _p(positions), _p(W), _p(pos_table), _p(out), M, C, scale, _stream()),
+          "ea_embedding_fwd")
+    return out
+
+
+def embedding_bwd(tokens, dy, dW, scale, pad_idx):
+    M, C = dy.shape
+    check(_lib.lib().ea_embedding_bwd(_p(tokens), _p(dy), _p(dW), M, C, scale, pad_idx, _stream()), "ea_embedding_bwd")
+    return dW

@@ -105,6 +105,12 @@ int ea_scale_dropout_bf16(const void* x, const void* y, void* out, long n, float
                           uint32_t thr, float inv_keep, ea_stream_t stream);
 /* out[n] += sum_m X[m*ld+n]  (X bf16, out fp32) */
 int ea_colsum_bf16(const void* X, float* out, int M, int N, long ld, ea_stream_t stream);
+/* Token + positional embedding of the decoder — fairseq/models/transformer/transformer_decoder.py:296-330
+ * (embed_scale * embed_tokens(prev_output_tokens) + embed_positions); bwd accumulates into dW (pad row skipped). */
+int ea_embedding_fwd(const int* tokens, const int* positions, const float* W, const float* pos_table, void* out, int M,
+                     int C, float scale, ea_stream_t stream);
+int ea_embedding_bwd(const int* tokens, const void* dy, float* dW, int M, int C, float scale, int pad_idx,
+                     ea_stream_t stream);
 int ea_zero_rows_bf16(void* x, const uint8_t* row_zero, int M, int C, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -178,6 +184,11 @@ int ea_ctc_grad(const float* lprobs, const void* workspace, const float* nll, co
                 const int* in_len, const int* tgt_len, void* dlogits, long ld_out, int dlogits_bf16, int B, int T,
                 int V, int Lmax, int blank, float grad_scale, const float* grad_scale_dev, int zero_infinity,
                 ea_stream_t stream);
+/* CTC greedy decoding — espresso/tools/ctc_decoder.py:172-188 (max over V, unique_consecutive, drop blank, score =
+ * sum of per-frame maxima, alignments = first frame of each emitted token).  x: fp32 or bf16 [B][T][ld] log-probs. */
+int ea_ctc_greedy_decode(const void* x, long ld, int x_bf16, const int* in_len, int* best, float* bestv, int* tokens,
+                         int* align, int* out_len, float* score, int B, int T, int V, int blank, int pad,
+                         ea_stream_t stream);
 int ea_label_smoothed_ce(const void* logits, long ld, int logits_bf16, const int* target, float* out_loss,
                          void* dlogits, long ld_out, int dlogits_bf16, long M, int V, int pad_idx, float eps,
                          float grad_scale, ea_stream_t stream);

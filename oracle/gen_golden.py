@@ -122,6 +122,87 @@ def encoder_fixture(layer_type, name):
     print(name, "loss", loss.item(), "params", sum(p.numel() for p in enc.parameters()))
 
 
+def encdec_fixture(name="ref_transformer_encdec_tiny"):
+    """speech_transformer_base (conv front-end + rel-pos Transformer encoder + 2-layer decoder) with
+    label_smoothed_cross_entropy_v2 (uniform, eps 0.1): logits, loss, gradients from the reference's own code."""
+    import ast
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.models.transformer.speech_transformer_base import SpeechTransformerModelBase
+    from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
+
+    torch.manual_seed(4321)
+    V = 40
+    cfg = ref_config("transformer")
+    d = cfg.decoder
+    d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads = 64, 128, 2, 4
+    d.input_dim = d.output_dim = 64
+    d.normalize_before, d.learned_pos, d.relative_positional_embeddings = True, False, False
+    d.layerdrop = 0.0
+    d.xformers_att_config = None
+    d.embed_path = None
+    d.layers_to_keep = None
+    cfg.encoder.layers_to_keep = None
+    cfg.share_decoder_input_output_embed = False
+    cfg.no_cross_attention = False
+    cfg.cross_self_attention = False
+    cfg.adaptive_softmax_cutoff = None
+    cfg.tie_adaptive_weights = False
+    cfg.scheduled_sampling_probs = [1.0]
+    cfg.start_scheduled_sampling_epoch = 1
+    cfg.layernorm_embedding = True
+    cfg.no_decoder_final_norm = False
+    cfg.scale_attn = cfg.scale_heads = cfg.scale_fc = cfg.scale_resids = False
+
+    class T:
+        feat_dim, feat_in_channels = 80, 1
+    dic = AsrDictionary()
+    for i in range(V - len(dic) - 1):
+        dic.add_symbol(f"t{i}")
+    dic.add_symbol("<space>")
+    T.target_dictionary = dic
+    assert len(dic) == V, len(dic)
+    model = SpeechTransformerModelBase.build_model(cfg, T)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    B, Tn = 3, 70
+    lengths = torch.tensor([70, 61, 37])
+    feats = torch.randn(B, Tn, 80)
+    for b in range(B):
+        feats[b, lengths[b]:] = 0.0
+    pad, eos = dic.pad(), dic.eos()
+    tl = [7, 5, 3]
+    target = torch.full((B, 8), pad, dtype=torch.long)
+    prev = torch.full((B, 8), pad, dtype=torch.long)
+    for b, L in enumerate(tl):
+        toks = torch.randint(dic.nspecial, V, (L,))
+        target[b, :L] = toks
+        target[b, L] = eos
+        prev[b, 0] = eos
+        prev[b, 1:L + 1] = toks
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        lo, _ = model(feats, lengths, prev)
+    out["eval_logits"] = lo.numpy()
+    model.train()
+    lo, _ = model(feats, lengths, prev)
+    lprobs = torch.log_softmax(lo.float(), -1).view(-1, V)
+    loss, nll = label_smoothed_nll_loss(lprobs, target.view(-1, 1), 0.1, ignore_index=pad, reduce=True)
+    loss.backward()
+    out["train_logits"] = lo.detach().numpy()
+    out["loss"] = np.array(loss.item())
+    out["nll"] = np.array(nll.item())
+    grads = {n: p.grad.detach().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), feats=feats.numpy(), lengths=lengths.numpy(), prev=prev.numpy(),
+                        target=target.numpy(), **{"sd::" + k: v.numpy() for k, v in sd.items()},
+                        **{"out::" + k: v for k, v in out.items()}, **{"grad::" + k: v for k, v in grads.items()})
+    print(name, "loss", loss.item(), "nll", nll.item(), "params", sum(p.numel() for p in model.parameters()))
+    print([k for k in sd if k.startswith("decoder")][:40])
+
+
 def label_smoothing_fixture():
     from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
 
@@ -171,6 +252,10 @@ def batch_by_size_fixture():
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "encdec":
+        encdec_fixture()
+        sys.exit(0)
     encoder_fixture("conformer", "ref_conformer_ctc_tiny")
     encoder_fixture("transformer", "ref_transformer_ctc_tiny")
     label_smoothing_fixture()

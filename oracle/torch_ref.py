@@ -205,3 +205,79 @@ def label_smoothed_nll(logits, target, eps, pad_idx):
     smooth = smooth.masked_fill(m, 0.0)
     eps_i = eps / (lp.size(-1) - 1)
     return (1.0 - eps - eps_i) * nll.sum() + eps_i * smooth.sum(), nll.sum()
+
+
+# ------------------------------------------------------------------------------------------------
+# Attention encoder-decoder (speech_transformer_base): decoder restatement
+def sinusoidal_abs_pe(num_embeddings, dim, padding_idx):
+    """fairseq/modules/sinusoidal_positional_embedding.py:36-58 (get_embedding)."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+    e = torch.arange(num_embeddings, dtype=torch.float).unsqueeze(1) * e.unsqueeze(0)
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1).view(num_embeddings, -1)
+    if dim % 2 == 1:
+        e = torch.cat([e, torch.zeros(num_embeddings, 1)], dim=1)
+    if padding_idx is not None:
+        e[padding_idx, :] = 0
+    return e
+
+
+def mha(q_in, kv_in, sd, p, H, key_padding_mask=None, causal=False):
+    """fairseq/modules/multihead_attention.py (no positional embedding): q_in (U,B,C), kv_in (S,B,C)."""
+    U, B, C = q_in.shape
+    S = kv_in.shape[0]
+    dh = C // H
+    q = F.linear(q_in, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * dh ** -0.5
+    k = F.linear(kv_in, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
+    v = F.linear(kv_in, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    q = q.contiguous().view(U, B * H, dh).transpose(0, 1)
+    k = k.contiguous().view(S, B * H, dh).transpose(0, 1)
+    v = v.contiguous().view(S, B * H, dh).transpose(0, 1)
+    w = torch.bmm(q, k.transpose(1, 2))
+    if causal:
+        w = w + torch.triu(torch.full((U, S), float("-inf")), 1).unsqueeze(0)
+    if key_padding_mask is not None:
+        w = w.view(B, H, U, S).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(B * H, U, S)
+    a = torch.bmm(torch.softmax(w.float(), -1), v).transpose(0, 1).contiguous().view(U, B, C)
+    return F.linear(a, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+
+
+def decoder(prev_tokens, enc_out, enc_pad, sd, H, pad_idx, p="decoder.", activation="relu"):
+    """espresso/models/transformer/speech_transformer_decoder.py + fairseq transformer_decoder.py:254-370 and
+    transformer_layer.py:384-529 (pre-LN, cross attention, no layerdrop, dropout 0).  Returns logits (B,U,V)."""
+    B, U = prev_tokens.shape
+    W = sd[p + "embed_tokens.weight"]
+    C = W.shape[1]
+    x = math.sqrt(C) * F.embedding(prev_tokens, W)
+    mask = prev_tokens.ne(pad_idx).int()
+    positions = (torch.cumsum(mask, 1) * mask).long() + pad_idx
+    x = x + sinusoidal_abs_pe(pad_idx + 1 + U, C, pad_idx)[positions]
+    if (p + "layernorm_embedding.weight") in sd:
+        x = _ln(x, sd, p + "layernorm_embedding.")
+    x = x.transpose(0, 1)
+    i = 0
+    while (p + f"layers.{i}.fc1.weight") in sd:
+        lp = p + f"layers.{i}."
+        x = mha(_ln(x, sd, lp + "self_attn_layer_norm."), _ln(x, sd, lp + "self_attn_layer_norm."), sd, lp + "self_attn.", H,
+                causal=True) + x
+        y = _ln(x, sd, lp + "encoder_attn_layer_norm.")
+        x = mha(y, enc_out, sd, lp + "encoder_attn.", H, key_padding_mask=enc_pad) + x
+        y = _ln(x, sd, lp + "final_layer_norm.")
+        y = F.linear(y, sd[lp + "fc1.weight"], sd[lp + "fc1.bias"])
+        y = F.relu(y) if activation == "relu" else F.silu(y)
+        x = F.linear(y, sd[lp + "fc2.weight"], sd[lp + "fc2.bias"]) + x
+        i += 1
+    if (p + "layer_norm.weight") in sd:
+        x = _ln(x, sd, p + "layer_norm.")
+    x = x.transpose(0, 1)
+    return F.linear(x, sd[p + "output_projection.weight"])
+
+
+def encdec(feats, lengths, prev_tokens, sd, H, pad_idx, training=False):
+    """speech_transformer_base forward (espresso/models/transformer/speech_transformer_base.py:175-201)."""
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    x, out_len = encoder(feats, lengths, enc_sd, H, layer_type="transformer", training=training)
+    pad = torch.arange(x.shape[0]).unsqueeze(0) >= out_len.unsqueeze(1)
+    sdd = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
+    return decoder(prev_tokens, x, pad if bool(pad.any()) else None, sdd, H, pad_idx)

@@ -320,3 +320,108 @@ def check_native_layer(p_drop=0.0, seed=0):
             worst = (n, e)
     res["worst_grad"] = worst
     return res
+
+
+# ------------------------------------------------------------------ CTC greedy decoding
+def check_ctc_greedy(layer_type="conformer"):
+    """HIP decoder vs the reference procedure (max, unique_consecutive, drop blank — ctc_decoder.py:172-188) applied on
+    the CPU to (a) the same HIP log-probs -> must be bit-exact, (b) the reference's own fp32 logits -> agreement rate."""
+    from espresso_amd.tools.ctc_decoder import CTCDecoder
+
+    g, sd, _, _ = load_fixture(f"ref_{layer_type}_ctc_tiny")
+    model = build_tiny_model(layer_type).to(DEV)
+    load_ref_state(model, sd)
+    model.eval()
+    feats = torch.from_numpy(g["feats"]).to(DEV)
+    lengths = torch.from_numpy(g["lengths"]).to(DEV)
+    sample = {"net_input": {"src_tokens": feats, "src_lengths": lengths}}
+    dec = CTCDecoder([model], _Task(40).target_dictionary)
+    hyps = dec.generate([model], sample)
+    with torch.no_grad():
+        out = model(feats, lengths)
+        lp = model.get_normalized_probs(out, log_probs=True).float().cpu()  # T x B x V
+    ol = g["out::out_lengths"]
+
+    def ref_decode(lprobs_tv):
+        scores, toks = lprobs_tv.max(-1)
+        seq = toks.unique_consecutive()
+        return seq[seq != 0].tolist(), float(scores.sum())
+
+    exact, agree_ref = True, []
+    ref_logits = torch.from_numpy(g["out::eval_logits"])
+    for b in range(feats.shape[0]):
+        want, wscore = ref_decode(lp[: ol[b], b])
+        got = hyps[b][0]["tokens"].tolist()
+        exact &= got == want and abs(float(hyps[b][0]["score"]) - wscore) < 1e-3
+        want_ref, _ = ref_decode(torch.log_softmax(ref_logits[: ol[b], b], -1))
+        agree_ref.append(got == want_ref)
+    toks, scores, _ = dec.decode([model], sample)
+    return {"exact_vs_same_lprobs": bool(exact), "utts_equal_to_reference_fp32_decode": agree_ref, "decode_shape": tuple(toks.shape)}
+
+
+# ------------------------------------------------------------------ attention encoder-decoder + label-smoothed CE
+class _TaskAR:
+    feat_dim, feat_in_channels = 80, 1
+
+    def __init__(self, V):
+        from espresso_amd.data.asr_dictionary import AsrDictionary
+
+        self.target_dictionary = AsrDictionary.from_symbols([f"t{i}" for i in range(V - 4)], enable_bos=False)
+        assert len(self.target_dictionary) == V
+
+
+def build_tiny_encdec(V=40):
+    from espresso_amd.models.transformer.speech_transformer_base import SpeechTransformerModelBase
+    from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
+
+    cfg = SpeechTransformerConfig()
+    e, d = cfg.encoder, cfg.decoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 64, 128, 2, 4
+    e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "transformer"
+    e.conv_channels = "[64, 64, 16, 16]"
+    d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads, d.normalize_before = 64, 128, 2, 4, True
+    d.input_dim = d.output_dim = 64
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.layernorm_embedding = True
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    return SpeechTransformerModelBase.build_model(cfg, _TaskAR(V))
+
+
+def check_encdec_vs_reference():
+    from espresso_amd import functional as F
+
+    g = np.load(os.path.join(GOLD, "ref_transformer_encdec_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    grads = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad::")}
+    model = build_tiny_encdec().to(DEV)
+    sd = model.upgrade_state_dict_named(dict(sd), "")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    feats, lengths = torch.from_numpy(g["feats"]).to(DEV), torch.from_numpy(g["lengths"]).to(DEV)
+    prev, target = torch.from_numpy(g["prev"]).to(DEV), torch.from_numpy(g["target"]).to(DEV)
+    valid = target.ne(0).cpu()
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        lo, _ = model(feats, lengths, prev)
+    ref = torch.from_numpy(g["out::eval_logits"])
+    res["eval_logits_abs_valid"] = float((lo.float().cpu() - ref)[valid].abs().max())
+    res["eval_greedy_agree"] = float((lo.float().cpu().argmax(-1) == ref.argmax(-1))[valid].float().mean())
+    model.train()
+    lo, extra = model(feats, lengths, prev)
+    loss, nll = F.label_smoothed_ce(extra["_logits_bu"], target.reshape(-1).to(torch.int32).contiguous(), 0, 0.1)
+    loss.backward()
+    torch.cuda.synchronize()
+    res["loss"], res["ref_loss"] = float(loss), float(g["out::loss"])
+    res["nll"], res["ref_nll"] = float(nll), float(g["out::nll"])
+    errs = []
+    for n, p in model.named_parameters():
+        if n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias"):
+            continue
+        if n.endswith("attn.k_proj.bias"):
+            continue
+        r = grads[n]
+        errs.append((float((p.grad.float().cpu() - r).abs().max() / (float(r.abs().max()) + 1e-12)), n))
+    errs.sort(reverse=True)
+    res["worst5"] = [(n, round(e, 4)) for e, n in errs[:5]]
+    return res

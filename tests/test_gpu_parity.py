@@ -77,3 +77,20 @@ def test_native_layer_runtime_matches_kernel_composition():
     print(r)
     assert r["out_abs"] < 1e-6, r          # identical launch sequence -> bit-identical output
     assert r["worst_grad"][1] < 2e-3, r    # only the summation order of split-K / atomics differs
+
+
+def test_ctc_greedy_decoder_bit_exact():
+    r = G.check_ctc_greedy("conformer")
+    print(r)
+    assert r["exact_vs_same_lprobs"], r
+    assert all(r["utts_equal_to_reference_fp32_decode"]), r  # greedy ids identical to the reference's fp32 run
+
+
+def test_encdec_label_smoothed_ce_vs_reference_fixture():
+    r = G.check_encdec_vs_reference()
+    print(r)
+    assert abs(r["loss"] - r["ref_loss"]) / r["ref_loss"] < 1e-2, r
+    assert abs(r["nll"] - r["ref_nll"]) / r["ref_nll"] < 1e-2, r
+    assert r["eval_logits_abs_valid"] < 6e-2, r
+    assert r["eval_greedy_agree"] > 0.9, r
+    assert r["worst5"][0][1] < 0.2, r

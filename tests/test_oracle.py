@@ -89,3 +89,18 @@ def test_product_mel_tables_equal_oracle_bank():
     from espresso_amd.data.fbank_tables import build_mel_bank
 
     np.testing.assert_array_equal(build_mel_bank(), fbank_ref.mel_banks())
+
+
+def test_decoder_restatement_matches_reference(golden_dir):
+    """speech_transformer_base: the restated decoder reproduces the reference's logits at every non-pad position and its
+    label-smoothed CE values exactly (pad rows differ: the reference additionally masks padded keys, which no loss sees)."""
+    g = np.load(os.path.join(golden_dir, "ref_transformer_encdec_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    feats, lengths, prev, target = (torch.from_numpy(g[k]) for k in ("feats", "lengths", "prev", "target"))
+    valid = target.ne(0)
+    for training, key in ((False, "out::eval_logits"), (True, "out::train_logits")):
+        lo = torch_ref.encdec(feats, lengths, prev, sd, 4, pad_idx=0, training=training)
+        assert float((lo - torch.from_numpy(g[key]))[valid].abs().max()) < 1e-5
+    loss, nll = torch_ref.label_smoothed_nll(lo.reshape(-1, lo.shape[-1]), target.reshape(-1), 0.1, 0)
+    assert float(loss) == pytest.approx(float(g["out::loss"]), rel=1e-6)
+    assert float(nll) == pytest.approx(float(g["out::nll"]), rel=1e-6)
