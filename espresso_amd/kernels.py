@@ -442,3 +442,42 @@ def embedding_bwd(tokens, dy, dW, scale, pad_idx):
     M, C = dy.shape
     check(_lib.lib().ea_embedding_bwd(_p(tokens), _p(dy), _p(dW), M, C, scale, pad_idx, _stream()), "ea_embedding_bwd")
     return dW
+
+
+def decode_attention(q, Kc, Vc_off, kv_row, lens, N, H, dh, row_stride, ldkv, koff, voff, max_len):
+    """One query per hypothesis.  q bf16 [N][C]; Kc: bf16 cache tensor holding K and V (offsets koff / voff)."""
+    out = torch.empty_like(q)
+    check(
+        _lib.lib().ea_decode_attention(_p(q), _p(Kc), _p(Kc), _p(kv_row), _p(lens), _p(out), N, H, dh, q.stride(0), row_stride,
+                                       ldkv, koff, voff, max_len, _stream()),
+        "ea_decode_attention",
+    )
+    return out
+
+
+def kv_append_reorder(old_cache, new_cache, kv_new, parent, N, L, Lmax, W):
+    check(_lib.lib().ea_kv_append_reorder(_p(old_cache), _p(new_cache), _p(kv_new), _p(parent), N, L, Lmax, W, _stream()),
+          "ea_kv_append_reorder")
+    return new_cache
+
+
+def beam_mask_rows(lprobs, pad, unk, eos, unk_penalty=0.0, only_eos=False, forbid_eos=False, eos_factor=None):
+    N, V = lprobs.shape
+    assert lprobs.dtype == torch.float32 and lprobs.is_contiguous()
+    check(
+        _lib.lib().ea_beam_mask_rows(_p(lprobs), N, V, pad, unk, eos, unk_penalty, int(only_eos), int(forbid_eos),
+                                     0.0 if eos_factor is None else float(eos_factor), int(eos_factor is not None), _stream()),
+        "ea_beam_mask_rows",
+    )
+    return lprobs
+
+
+def beam_topk(lprobs, prev_scores, bsz, beam, nbeam_used, k):
+    V = lprobs.shape[1]
+    dev = lprobs.device
+    cs = torch.empty(bsz, k, dtype=torch.float32, device=dev)
+    ct = torch.empty(bsz, k, dtype=torch.int32, device=dev)
+    cb = torch.empty(bsz, k, dtype=torch.int32, device=dev)
+    check(_lib.lib().ea_beam_topk(_p(lprobs), _p(prev_scores), bsz, beam, nbeam_used, V, k, _p(cs), _p(ct), _p(cb), _stream()),
+          "ea_beam_topk")
+    return cs, ct, cb

@@ -117,6 +117,106 @@ class SpeechTransformerDecoderBase(nn.Module):
     def max_positions(self):
         return self.max_target_positions
 
+    # ------------------------------------------------------------------ incremental decoding (beam search)
+    @torch.no_grad()
+    def init_incremental(self, encoder_out, bsz, beam):
+        """Per-layer state: ping-pong self-attention K/V caches [N][Lmax][2C] and the encoder K/V of every SENTENCE
+        ([B][S][2C], projected once — multihead_attention.py:661-671 static_kv + beam dedup)."""
+        enc = encoder_out["_x_bt"][0] if "_x_bt" in encoder_out else None
+        if enc is None:
+            e = encoder_out["encoder_out"][0]
+            enc = e.transpose(0, 1).reshape(-1, e.shape[-1]).contiguous()
+        dev = enc.device
+        S = encoder_out["encoder_padding_mask"][0].shape[1]
+        C = self.embed_dim
+        N = bsz * beam
+        Lmax = self.max_target_positions + 2
+        st = {"bsz0": bsz, "beam": beam, "S": S, "L": 0, "Lmax": Lmax,
+              "enc_len": encoder_out["src_lengths"][0].to(torch.int32).contiguous(),
+              "kv_row": torch.arange(bsz, device=dev, dtype=torch.int32).repeat_interleave(beam).contiguous(),
+              "layers": []}
+        for layer in self.layers:
+            e = layer.encoder_attn
+            wkv16 = torch.cat([F.bf16_weight(e.k_proj.weight), F.bf16_weight(e.v_proj.weight)], 0)
+            bkv = torch.cat([e.k_proj.bias.detach(), e.v_proj.bias.detach()], 0)
+            enc_kv = torch.empty(enc.shape[0], 2 * C, dtype=torch.bfloat16, device=dev)
+            K.gemm(enc, wkv16, enc_kv, enc.shape[0], 2 * C, enc.shape[1], lda=enc.shape[1], ldb=enc.shape[1], ldc=2 * C, bias=bkv)
+            st["layers"].append({
+                "enc_kv": enc_kv,
+                "cache": [torch.empty(N, Lmax, 2 * C, dtype=torch.bfloat16, device=dev) for _ in range(2)],
+                "cur": 0,
+            })
+        return st
+
+    @torch.no_grad()
+    def step(self, st, tokens, step, parent):
+        """One decoding step for the N live hypotheses.  tokens: [N][step+1] (only the last column is consumed);
+        parent: int64 [N] previous-step hypothesis each row continues (None at step 0).  -> fp32 log-probs [N][V]."""
+        C, H = self.embed_dim, self.layers[0].num_heads
+        dh = C // H
+        scaling = dh ** -0.5
+        N = tokens.shape[0]
+        dev = tokens.device
+        tok = tokens[:, -1].to(torch.int32).contiguous()
+        if parent is not None:
+            par = parent.to(torch.int32).contiguous()
+            st["kv_row"] = st["kv_row"].index_select(0, parent).contiguous()
+        else:
+            par = None
+        L = st["L"]
+        pos = torch.full((N,), self.padding_idx + step + 1, dtype=torch.int32, device=dev)
+        n_tab = self.padding_idx + 2 + step
+        key = (n_tab, str(dev))
+        tab = self._pos_cache.get(key)
+        if tab is None:
+            tab = sinusoidal_positional_table(n_tab, C, self.padding_idx).to(dev).contiguous()
+            self._pos_cache[key] = tab
+        x = K.embedding_fwd(tok, pos, self.embed_tokens.weight, tab, self.embed_scale)
+        if self.layernorm_embedding is not None:
+            x, _, _ = K.layernorm_fwd(x, self.layernorm_embedding.weight, self.layernorm_embedding.bias, save_stats=False)
+        for layer, ls in zip(self.layers, st["layers"]):
+            a = layer.self_attn
+            _, bqkv, wqkv16 = a.fused_qkv()
+            xn, _, _ = K.layernorm_fwd(x, layer.self_attn_layer_norm.weight, layer.self_attn_layer_norm.bias, save_stats=False)
+            q = torch.empty(N, C, dtype=torch.bfloat16, device=dev)
+            kvn = torch.empty(N, 2 * C, dtype=torch.bfloat16, device=dev)
+            K.gemm(xn, wqkv16, q, N, C, C, lda=C, ldb=C, ldc=C, bias=bqkv[:C].contiguous())
+            K.gemm(xn, wqkv16, kvn, N, 2 * C, C, lda=C, ldb=C, ldc=2 * C, b_off=C * C, bias=bqkv[C:].contiguous())
+            qs, _ = K.relpos_q_prep(q, C, None, None, N, C, scaling, want_qv=False)
+            old, new = ls["cache"][ls["cur"]], ls["cache"][1 - ls["cur"]]
+            K.kv_append_reorder(old, new, kvn, par, N, L, st["Lmax"], 2 * C)
+            ls["cur"] = 1 - ls["cur"]
+            att = K.decode_attention(qs, new, None, None, None, N, H, dh, st["Lmax"] * 2 * C, 2 * C, 0, C, L + 1)
+            x2 = torch.empty_like(x)
+            K.gemm(att, F.bf16_weight(a.out_proj.weight), x2, N, C, C, lda=C, ldb=C, ldc=C, bias=a.out_proj.bias, resid=x, ldr=C)
+            x = x2
+            e = layer.encoder_attn
+            xn, _, _ = K.layernorm_fwd(x, layer.encoder_attn_layer_norm.weight, layer.encoder_attn_layer_norm.bias, save_stats=False)
+            q = torch.empty(N, C, dtype=torch.bfloat16, device=dev)
+            K.gemm(xn, F.bf16_weight(e.q_proj.weight), q, N, C, C, lda=C, ldb=C, ldc=C, bias=e.q_proj.bias)
+            qs, _ = K.relpos_q_prep(q, C, None, None, N, C, scaling, want_qv=False)
+            S = st["S"]
+            att = K.decode_attention(qs, ls["enc_kv"], None, st["kv_row"], st["enc_len"], N, H, dh, S * 2 * C, 2 * C, 0, C, S)
+            x2 = torch.empty_like(x)
+            K.gemm(att, F.bf16_weight(e.out_proj.weight), x2, N, C, C, lda=C, ldb=C, ldc=C, bias=e.out_proj.bias, resid=x, ldr=C)
+            x = x2
+            Fd = layer.fc1.weight.shape[0]
+            xn, _, _ = K.layernorm_fwd(x, layer.final_layer_norm.weight, layer.final_layer_norm.bias, save_stats=False)
+            h = torch.empty(N, Fd, dtype=torch.bfloat16, device=dev)
+            K.gemm(xn, F.bf16_weight(layer.fc1.weight), h, N, Fd, C, lda=C, ldb=C, ldc=Fd, bias=layer.fc1.bias, act=layer.activation_fn)
+            x2 = torch.empty_like(x)
+            K.gemm(h, F.bf16_weight(layer.fc2.weight), x2, N, C, Fd, lda=Fd, ldb=Fd, ldc=C, bias=layer.fc2.bias, resid=x, ldr=C)
+            x = x2
+        st["L"] = L + 1
+        if self.layer_norm is not None:
+            x, _, _ = K.layernorm_fwd(x, self.layer_norm.weight, self.layer_norm.bias, save_stats=False)
+        w = self.embed_tokens.weight if self.output_projection is None else self.output_projection.weight
+        V = w.shape[0]
+        Vp = (V + 7) // 8 * 8
+        logits = torch.empty(N, Vp, dtype=torch.bfloat16, device=dev)
+        K.gemm(x, F.bf16_weight(w), logits, N, V, C, lda=C, ldb=C, ldc=Vp)
+        return K.log_softmax(logits, N, V, Vp)
+
 
 @register_model("speech_transformer_base", dataclass=SpeechTransformerConfig)
 class SpeechTransformerModelBase(nn.Module):
@@ -148,6 +248,9 @@ class SpeechTransformerModelBase(nn.Module):
 
     def forward_encoder(self, src_tokens, src_lengths):
         return self.encoder(src_tokens, src_lengths)
+
+    def max_decoder_positions(self):
+        return self.decoder.max_positions()
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
         logits = net_output[1].get("_logits_bu") if isinstance(net_output[1], dict) else None

@@ -254,6 +254,23 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
 int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
                            void* dx, const void* pe, void* saved, void* scratch, ea_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Batched beam-search decoding (csrc/decode.hip) — fairseq/sequence_generator.py:355-609, fairseq/search.py:103-144,
+ * fairseq/modules/multihead_attention.py:716-760,878-897,964-989.
+ * ea_decode_attention: out[n] = softmax(q[n] . K[r]^T) V[r], r = kv_row ? kv_row[n] : n, over len ? len[r] : max_len keys;
+ *   q/out bf16 [N][ldq] (q pre-scaled), K/V bf16 rows of `row_stride` elements, key j at j*ldkv + koff/voff + h*dh.
+ * ea_kv_append_reorder: new[n][0:L] = old[parent[n]][0:L], new[n][L] = kv_new[n]  (rows of W bf16, capacity Lmax).
+ * ea_beam_mask_rows: sequence_generator.py:395-424 on fp32 lprobs [N][V] in place.
+ * ea_beam_topk: per sentence the k (<=128) best of lprobs[(s*beam+b)][v] + prev_scores[s*beam+b], b < nbeam_used. */
+int ea_decode_attention(const void* q, const void* K, const void* V, const int* kv_row, const int* len, void* out, int N, int H,
+                        int dh, long ldq, long row_stride, long ldkv, int koff, int voff, int max_len, ea_stream_t stream);
+int ea_kv_append_reorder(const void* old_cache, void* new_cache, const void* kv_new, const int* parent, int N, int L, int Lmax,
+                         int W, ea_stream_t stream);
+int ea_beam_mask_rows(float* lprobs, int N, int V, int pad, int unk, int eos, float unk_penalty, int only_eos, int forbid_eos,
+                      float eos_factor, int use_eos_factor, ea_stream_t stream);
+int ea_beam_topk(const float* lprobs, const float* prev_scores, int bsz, int beam, int nbeam_used, int V, int k,
+                 float* cand_score, int* cand_tok, int* cand_beam, ea_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,6 +166,9 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
         for n, p in model.named_parameters():
             if p.dim() == 1:
                 p.add_(0.1 * torch.randn_like(p))
+        # a peakier output distribution keeps beam-search decisions away from bf16-sized ties
+        model.decoder.output_projection.weight.mul_(6.0)
+        model.decoder.embed_tokens.weight.mul_(3.0)
     B, Tn = 3, 70
     lengths = torch.tensor([70, 61, 37])
     feats = torch.randn(B, Tn, 80)
@@ -196,8 +199,23 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
     out["loss"] = np.array(loss.item())
     out["nll"] = np.array(nll.item())
     grads = {n: p.grad.detach().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    # ---- beam search with the reference's own SequenceGenerator (fairseq/sequence_generator.py) ----
+    from fairseq.sequence_generator import SequenceGenerator
+    model.eval()
+    beams = {}
+    for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)),
+                    ("b3_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, eos_factor=1.5)),
+                    ("b1", dict(beam_size=1, max_len_a=0.0, max_len_b=12))):
+        gen = SequenceGenerator([model], dic, **kw)
+        hyps = gen.generate([model], {"net_input": {"src_tokens": feats, "src_lengths": lengths}})
+        for bi, hl in enumerate(hyps):
+            for hi, hyp in enumerate(hl):
+                beams[f"beam::{tag}::{bi}::{hi}::tokens"] = hyp["tokens"].numpy()
+                beams[f"beam::{tag}::{bi}::{hi}::score"] = np.array(float(hyp["score"]))
+                beams[f"beam::{tag}::{bi}::{hi}::pos"] = hyp["positional_scores"].numpy()
+        print(tag, [[h["tokens"].tolist() for h in hl] for hl in hyps], [[round(float(h["score"]), 3) for h in hl] for hl in hyps])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), feats=feats.numpy(), lengths=lengths.numpy(), prev=prev.numpy(),
-                        target=target.numpy(), **{"sd::" + k: v.numpy() for k, v in sd.items()},
+                        target=target.numpy(), **beams, **{"sd::" + k: v.numpy() for k, v in sd.items()},
                         **{"out::" + k: v for k, v in out.items()}, **{"grad::" + k: v for k, v in grads.items()})
     print(name, "loss", loss.item(), "nll", nll.item(), "params", sum(p.numel() for p in model.parameters()))
     print([k for k in sd if k.startswith("decoder")][:40])

@@ -425,3 +425,49 @@ def check_encdec_vs_reference():
     errs.sort(reverse=True)
     res["worst5"] = [(n, round(e, 4)) for e, n in errs[:5]]
     return res
+
+
+# ------------------------------------------------------------------ beam search with incremental decoding
+def check_beam_search_vs_reference():
+    """HIP incremental decoder + beam kernels vs what the reference's SequenceGenerator produced with the same weights
+    (tests/golden/ref_transformer_encdec_tiny.npz: beam 3, beam 3 + eos_factor 1.5, beam 1)."""
+    from espresso_amd.sequence_generator import SequenceGenerator
+
+    g = np.load(os.path.join(GOLD, "ref_transformer_encdec_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = build_tiny_encdec().to(DEV)
+    model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    model.eval()
+    d = _TaskAR(40).target_dictionary
+    sample = {"net_input": {"src_tokens": torch.from_numpy(g["feats"]).to(DEV), "src_lengths": torch.from_numpy(g["lengths"]).to(DEV)}}
+    res = {}
+    for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)),
+                    ("b3_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, eos_factor=1.5)),
+                    ("b1", dict(beam_size=1, max_len_a=0.0, max_len_b=12))):
+        gen = SequenceGenerator([model], d, **kw)
+        hyps = gen.generate([model], sample)
+        top_equal, any_rank_equal, score_err = [], [], 0.0
+        for b, hl in enumerate(hyps):
+            ref_tokens = []
+            hi = 0
+            while f"beam::{tag}::{b}::{hi}::tokens" in g.files:
+                ref_tokens.append((g[f"beam::{tag}::{b}::{hi}::tokens"].tolist(), float(g[f"beam::{tag}::{b}::{hi}::score"])))
+                hi += 1
+            top_equal.append(hl[0]["tokens"].tolist() == ref_tokens[0][0])
+            refset = {tuple(t): s for t, s in ref_tokens}
+            any_rank_equal.append(sum(tuple(h["tokens"].tolist()) in refset for h in hl) / len(hl))
+            for h in hl:
+                k = tuple(h["tokens"].tolist())
+                if k in refset:
+                    score_err = max(score_err, abs(float(h["score"]) - refset[k]))
+        res[tag] = {"top1_tokens_equal": top_equal, "frac_hyps_in_reference_beam": any_rank_equal, "score_abs": score_err}
+    # teacher-forced consistency: incremental log-probs == full forward log-probs on the decoded prefix
+    best = hyps[0][0]["tokens"].to(DEV)
+    prev = torch.cat([torch.tensor([d.eos()], device=DEV), best[:-1]]).unsqueeze(0)
+    with torch.no_grad():
+        feats1 = sample["net_input"]["src_tokens"][:1]
+        lo, extra = model(feats1, sample["net_input"]["src_lengths"][:1], prev)
+        lp = torch.log_softmax(lo.float(), -1)[0]
+    pos = lp.gather(-1, best.unsqueeze(-1)).squeeze(-1).cpu()
+    res["incremental_vs_full_forward_abs"] = float((pos - hyps[0][0]["positional_scores"]).abs().max())
+    return res

@@ -97,3 +97,13 @@ def test_encdec_label_smoothed_ce_vs_reference_fixture():
     # heavy cancellation, so their error relative to the tensor maximum is the loosest; everything else is within 20 %.
     for n, e in r["worst5"]:
         assert e < (0.5 if "pre_encoder" in n else 0.2), (n, e, r)
+
+
+def test_beam_search_vs_reference_generator():
+    r = G.check_beam_search_vs_reference()
+    print(r)
+    assert r["incremental_vs_full_forward_abs"] < 5e-2, r  # KV-cache path == teacher-forced path (bf16)
+    for tag in ("b3", "b3_eosf", "b1"):
+        assert r[tag]["score_abs"] < 2e-2, r            # normalised hypothesis scores within the bf16 tolerance
+        assert sum(r[tag]["top1_tokens_equal"]) >= 2, r  # random-weight model has near-ties: allow one re-ordering
+        assert min(r[tag]["frac_hyps_in_reference_beam"]) >= 0.66, r
