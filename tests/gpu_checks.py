@@ -461,6 +461,25 @@ def check_beam_search_vs_reference():
                 if k in refset:
                     score_err = max(score_err, abs(float(h["score"]) - refset[k]))
         res[tag] = {"top1_tokens_equal": top_equal, "frac_hyps_in_reference_beam": any_rank_equal, "score_abs": score_err}
+    # Force-decode the reference's best hypotheses through the INCREMENTAL path (K/V caches, one-query attention) and
+    # compare per-position log-probs with the reference generator's positional scores.
+    ref_best = [torch.from_numpy(g[f"beam::b3::{b}::0::tokens"]) for b in range(3)]
+    ref_pos = torch.stack([torch.from_numpy(g[f"beam::b3::{b}::0::pos"]) for b in range(3)])
+    L = ref_best[0].numel()
+    toks = torch.stack(ref_best).to(DEV)
+    with torch.no_grad():
+        enc_out = model.forward_encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+        st = model.decoder.init_incremental(enc_out, 3, 1)
+        cur = torch.full((3, 1), d.eos(), dtype=torch.long, device=DEV)
+        got = []
+        for step in range(L):
+            lp = model.decoder.step(st, cur, step, None if step == 0 else torch.arange(3, device=DEV))
+            got.append(lp.gather(-1, toks[:, step:step + 1]).squeeze(-1).cpu())
+            cur = torch.cat([cur, toks[:, step:step + 1]], 1)
+    got = torch.stack(got, 1)
+    # the last position of the reference hypotheses is the forced EOS at max_len: its reference score is the raw eos log-prob
+    res["forced_decode_pos_score_abs"] = float((got - ref_pos).abs().max())
+    res["forced_decode_total_abs"] = float((got.sum(1) - ref_pos.sum(1)).abs().max())
     # teacher-forced consistency: incremental log-probs == full forward log-probs on the decoded prefix
     best = hyps[0][0]["tokens"].to(DEV)
     prev = torch.cat([torch.tensor([d.eos()], device=DEV), best[:-1]]).unsqueeze(0)
