@@ -479,6 +479,14 @@ def check_beam_search_vs_reference():
     got = torch.stack(got, 1)
     # the last position of the reference hypotheses is the forced EOS at max_len: its reference score is the raw eos log-prob
     res["forced_decode_pos_score_abs"] = float((got - ref_pos).abs().max())
+    with torch.no_grad():
+        prev3 = torch.cat([torch.full((3, 1), d.eos(), dtype=torch.long, device=DEV), toks[:, :-1]], 1)
+        lo3, _ = model(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"], prev3)
+        full = torch.log_softmax(lo3.float(), -1).gather(-1, toks.unsqueeze(-1)).squeeze(-1).cpu()
+    res["full_forward_vs_ref_per_pos"] = [round(float(x), 3) for x in (full - ref_pos).abs().max(0)[0]]
+    res["incr_vs_ref_per_pos"] = [round(float(x), 3) for x in (got - ref_pos).abs().max(0)[0]]
+    res["ref_pos_row0"] = [round(float(x), 3) for x in ref_pos[0]]
+    res["got_row0"] = [round(float(x), 3) for x in got[0]]
     res["forced_decode_total_abs"] = float((got.sum(1) - ref_pos.sum(1)).abs().max())
     # teacher-forced consistency: incremental log-probs == full forward log-probs on the decoded prefix
     best = hyps[0][0]["tokens"].to(DEV)
