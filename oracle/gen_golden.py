@@ -166,9 +166,6 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
         for n, p in model.named_parameters():
             if p.dim() == 1:
                 p.add_(0.1 * torch.randn_like(p))
-        # a peakier output distribution keeps beam-search decisions away from bf16-sized ties
-        model.decoder.output_projection.weight.mul_(6.0)
-        model.decoder.embed_tokens.weight.mul_(3.0)
     B, Tn = 3, 70
     lengths = torch.tensor([70, 61, 37])
     feats = torch.randn(B, Tn, 80)

@@ -91,7 +91,7 @@ def test_encdec_label_smoothed_ce_vs_reference_fixture():
     print(r)
     assert abs(r["loss"] - r["ref_loss"]) / r["ref_loss"] < 1e-2, r
     assert abs(r["nll"] - r["ref_nll"]) / r["ref_nll"] < 1e-2, r
-    assert r["eval_logits_abs_valid"] < 0.2, r  # logits span ~+-25 in this (peaky) fixture: < 1 % relative
+    assert r["eval_logits_abs_valid"] < 6e-2, r
     assert r["eval_greedy_agree"] > 0.9, r
     # bf16 activations: gradients of the conv front-end (behind 2+2 attention stacks and four BatchNorms) are sums with
     # heavy cancellation, so their error relative to the tensor maximum is the loosest; everything else is within 20 %.
@@ -102,11 +102,10 @@ def test_encdec_label_smoothed_ce_vs_reference_fixture():
 def test_beam_search_vs_reference_generator():
     r = G.check_beam_search_vs_reference()
     print(r)
-    # logits of this fixture span ~+-25, so bf16 (8 mantissa bits) gives ~0.1 absolute on log-probs: <1 % relative
-    assert r["incremental_vs_full_forward_abs"] < 0.15, r   # KV-cache path == teacher-forced path
-    assert r["forced_decode_pos_score_abs"] < 0.25, r        # reference's own positional scores reproduced
+    assert r["incremental_vs_full_forward_abs"] < 5e-2, r   # KV-cache path == teacher-forced path (bf16)
+    assert r["forced_decode_pos_score_abs"] < 0.1, r         # the reference generator's own positional scores reproduced
     # The random-weight fixture has competing hypotheses 0.02 apart in normalised score (see oracle/gen_golden.py output), so
     # token-level agreement of the beams is reported, not asserted; beam-search SEMANTICS are pinned by the scripted
     # known-answer tests (tests/test_sequence_generator.py).
     for tag in ("b3", "b3_eosf", "b1"):
-        assert r[tag]["score_abs"] < 0.15, r
+        assert r[tag]["score_abs"] < 3e-2, r
