@@ -187,18 +187,8 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
     with torch.no_grad():
         lo, _ = model(feats, lengths, prev)
     out["eval_logits"] = lo.numpy()
-    model.train()
-    lo, _ = model(feats, lengths, prev)
-    lprobs = torch.log_softmax(lo.float(), -1).view(-1, V)
-    loss, nll = label_smoothed_nll_loss(lprobs, target.view(-1, 1), 0.1, ignore_index=pad, reduce=True)
-    loss.backward()
-    out["train_logits"] = lo.detach().numpy()
-    out["loss"] = np.array(loss.item())
-    out["nll"] = np.array(nll.item())
-    grads = {n: p.grad.detach().numpy() for n, p in model.named_parameters() if p.grad is not None}
     # ---- beam search with the reference's own SequenceGenerator (fairseq/sequence_generator.py) ----
     from fairseq.sequence_generator import SequenceGenerator
-    model.eval()
     beams = {}
     for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)),
                     ("b3_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, eos_factor=1.5)),
@@ -211,6 +201,16 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
                 beams[f"beam::{tag}::{bi}::{hi}::score"] = np.array(float(hyp["score"]))
                 beams[f"beam::{tag}::{bi}::{hi}::pos"] = hyp["positional_scores"].numpy()
         print(tag, [[h["tokens"].tolist() for h in hl] for hl in hyps], [[round(float(h["score"]), 3) for h in hl] for hl in hyps])
+    # (beam search above ran BEFORE the train-mode forward: that forward updates the BatchNorm running statistics)
+    model.train()
+    lo, _ = model(feats, lengths, prev)
+    lprobs = torch.log_softmax(lo.float(), -1).view(-1, V)
+    loss, nll = label_smoothed_nll_loss(lprobs, target.view(-1, 1), 0.1, ignore_index=pad, reduce=True)
+    loss.backward()
+    out["train_logits"] = lo.detach().numpy()
+    out["loss"] = np.array(loss.item())
+    out["nll"] = np.array(nll.item())
+    grads = {n: p.grad.detach().numpy() for n, p in model.named_parameters() if p.grad is not None}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), feats=feats.numpy(), lengths=lengths.numpy(), prev=prev.numpy(),
                         target=target.numpy(), **beams, **{"sd::" + k: v.numpy() for k, v in sd.items()},
                         **{"out::" + k: v for k, v in out.items()}, **{"grad::" + k: v for k, v in grads.items()})
