@@ -1,0 +1,47 @@
+"""`transducer_loss` criterion — interface and bookkeeping of espresso/criterions/transducer_loss.py:44-192: targets are
+`target[:, :-1]` (EOS stripped) as int32, blank = "<s>" index, per-utterance loss from the RNN-T kernel, sum reduction,
+sentence_avg sample size.  The arithmetic is csrc/rnnt.hip (the reference calls torchaudio.functional.rnnt_loss)."""
+import math
+
+import torch
+
+from .. import functional as F
+from ..registry import register_criterion
+
+
+@register_criterion("transducer_loss")
+class TransducerLossCriterion:
+    def __init__(self, task, sentence_avg=True, print_training_sample_interval=500):
+        self.task = task
+        d = task.target_dictionary
+        self.blank_idx = d.index(task.blank_symbol) if getattr(task, "blank_symbol", None) else d.bos()
+        self.pad_idx, self.eos_idx = d.pad(), d.eos()
+        self.sentence_avg = sentence_avg
+
+    def __call__(self, model, sample, reduce=True):
+        return self.forward(model, sample, reduce)
+
+    def forward(self, model, sample, reduce=True):
+        net_output, encoder_out_lengths = model(**sample["net_input"])  # (B, T', U+1, V), (B,)
+        target = sample["target"][:, :-1].contiguous() if sample["target"].size(1) > 1 else sample["target"]
+        target_lengths = (sample["target"].ne(self.pad_idx) & sample["target"].ne(self.eos_idx)).sum(-1)
+        loss = F.rnnt_loss(net_output, target.to(torch.int32).contiguous(), encoder_out_lengths.to(torch.int32).contiguous(),
+                           target_lengths.to(torch.int32).contiguous(), blank=self.blank_idx).sum()
+        nsentences = sample["target"].size(0)
+        sample_size = nsentences if self.sentence_avg else sample["ntokens"]
+        return loss, sample_size, {"loss": loss.detach(), "ntokens": sample["ntokens"], "nsentences": nsentences,
+                                   "sample_size": sample_size}
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        loss_sum = float(sum(float(l.get("loss", 0)) for l in logging_outputs))
+        ntokens = sum(l.get("ntokens", 0) for l in logging_outputs)
+        sample_size = sum(l.get("sample_size", 0) for l in logging_outputs)
+        out = {"loss": loss_sum / max(sample_size, 1) / math.log(2), "ntokens": ntokens, "sample_size": sample_size}
+        if sample_size != ntokens:
+            out["nll_loss"] = loss_sum / max(ntokens, 1) / math.log(2)
+        return out
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True

@@ -844,3 +844,27 @@ class _Dropout(torch.autograd.Function):
     def backward(ctx, dy):
         p, seed = ctx.cfg
         return K.scale_dropout(dy.contiguous(), a=1.0, drop_p=p, drop_seed=seed), None
+
+
+class _RNNTLoss(torch.autograd.Function):
+    """Per-utterance transducer negative log-likelihood (torchaudio.functional.rnnt_loss semantics, reduction 'none')."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, logit_lengths, target_lengths, blank):
+        logits = logits.float().contiguous()
+        loss, ws = K.rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank)
+        ctx.save_for_backward(logits, targets, logit_lengths, target_lengths, loss, ws)
+        ctx.blank = blank
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, targets, logit_lengths, target_lengths, loss, ws = ctx.saved_tensors
+        # the criterion sums the per-utterance losses: dloss is a broadcast scalar, applied on the device
+        g = K.rnnt_loss_grad(logits, targets, logit_lengths, target_lengths, loss, ws, ctx.blank,
+                             grad_scale_dev=dloss.float().contiguous())
+        return g, None, None, None, None
+
+
+def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=0):
+    return _RNNTLoss.apply(logits, targets, logit_lengths, target_lengths, blank)

@@ -481,3 +481,25 @@ def beam_topk(lprobs, prev_scores, bsz, beam, nbeam_used, k):
     check(_lib.lib().ea_beam_topk(_p(lprobs), _p(prev_scores), bsz, beam, nbeam_used, V, k, _p(cs), _p(ct), _p(cb), _stream()),
           "ea_beam_topk")
     return cs, ct, cb
+
+
+def rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank):
+    """logits fp32 [B][T][U1][V]; returns (loss [B], workspace)."""
+    B, T, U1, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    Umax = targets.shape[1]
+    assert U1 == Umax + 1
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(int(_lib.lib().ea_rnnt_workspace_bytes(B, T, U1)), dtype=torch.uint8, device=logits.device)
+    check(_lib.lib().ea_rnnt_loss(_p(logits), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), B, T, U1, V,
+                                  Umax, blank, _stream()), "ea_rnnt_loss")
+    return loss, ws
+
+
+def rnnt_loss_grad(logits, targets, logit_lengths, target_lengths, loss, ws, blank, grad_scale_dev=None, grad_bf16=False):
+    B, T, U1, V = logits.shape
+    grad = torch.empty(logits.shape, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=logits.device)
+    check(_lib.lib().ea_rnnt_grad(_p(logits), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), _p(grad),
+                                  int(grad_bf16), B, T, U1, V, targets.shape[1], blank, 1.0, _p(grad_scale_dev), _stream()),
+          "ea_rnnt_grad")
+    return grad

@@ -271,6 +271,18 @@ int ea_beam_mask_rows(float* lprobs, int N, int V, int pad, int unk, int eos, fl
 int ea_beam_topk(const float* lprobs, const float* prev_scores, int bsz, int beam, int nbeam_used, int V, int k,
                  float* cand_score, int* cand_tok, int* cand_beam, ea_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * RNN-T loss — torchaudio.functional.rnnt_loss as called at espresso/criterions/transducer_loss.py:130-140
+ * (blank = "<s>", clamp = -1, fused log-softmax).  logits fp32 [B][T][U1][V] (U1 = Umax + 1), targets int32 [B][Umax],
+ * loss fp32 [B] = -log p(y|x); grad = grad_scale * d(sum loss)/d(logits), fp32 or bf16, same shape as logits.
+ * workspace: ea_rnnt_workspace_bytes(B,T,U1) bytes, kept between the two calls. */
+long ea_rnnt_workspace_bytes(int B, int T, int U1);
+int ea_rnnt_loss(const float* logits, const int* targets, const int* logit_lengths, const int* target_lengths, float* loss,
+                 void* workspace, int B, int T, int U1, int V, int Umax, int blank, ea_stream_t stream);
+int ea_rnnt_grad(const float* logits, const int* targets, const int* logit_lengths, const int* target_lengths,
+                 const float* loss, const void* workspace, void* grad, int grad_bf16, int B, int T, int U1, int V, int Umax,
+                 int blank, float grad_scale, const float* grad_scale_dev, ea_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

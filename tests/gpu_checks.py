@@ -498,3 +498,32 @@ def check_beam_search_vs_reference():
     pos = lp.gather(-1, best.unsqueeze(-1)).squeeze(-1).cpu()
     res["incremental_vs_full_forward_abs"] = float((pos - hyps[0][0]["positional_scores"]).abs().max())
     return res
+
+
+# ------------------------------------------------------------------ RNN-T loss
+def check_rnnt(seed=0):
+    from espresso_amd import functional as F
+    from oracle import rnnt_ref
+
+    rng = np.random.default_rng(seed)
+    B, T, Umax, V = 4, 13, 5, 37
+    T_len = [13, 9, 13, 4]
+    U_len = [5, 3, 0, 2]
+    logits = (rng.standard_normal((B, T, Umax + 1, V)) * 2).astype(np.float32)
+    targets = rng.integers(1, V, size=(B, Umax)).astype(np.int32)
+    x = torch.from_numpy(logits).to(DEV).requires_grad_(True)
+    loss = F.rnnt_loss(x, torch.from_numpy(targets).to(DEV), torch.tensor(T_len, dtype=torch.int32, device=DEV),
+                       torch.tensor(U_len, dtype=torch.int32, device=DEV), blank=0)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    gl = x.grad.cpu().numpy()
+    le, ge = 0.0, 0.0
+    for b in range(B):
+        z = logits[b, : T_len[b], : U_len[b] + 1]
+        nll, g = rnnt_ref.rnnt_loss_one(z, targets[b, : U_len[b]].tolist(), want_grad=True)
+        le = max(le, abs(float(loss[b]) - nll) / max(1.0, abs(nll)))
+        ge = max(ge, float(np.abs(gl[b, : T_len[b], : U_len[b] + 1] - g).max()))
+        outside = gl[b].copy()
+        outside[: T_len[b], : U_len[b] + 1] = 0
+        assert float(np.abs(outside).max()) == 0.0
+    return {"loss_rel": le, "grad_abs": ge}

@@ -109,3 +109,10 @@ def test_beam_search_vs_reference_generator():
     # known-answer tests (tests/test_sequence_generator.py).
     for tag in ("b3", "b3_eosf", "b1"):
         assert r[tag]["score_abs"] < 3e-2, r
+
+
+def test_rnnt_loss_fp32():
+    r = G.check_rnnt()
+    print(r)
+    assert r["loss_rel"] < 1e-5, r
+    assert r["grad_abs"] < 1e-4, r

@@ -104,3 +104,26 @@ def test_decoder_restatement_matches_reference(golden_dir):
     loss, nll = torch_ref.label_smoothed_nll(lo.reshape(-1, lo.shape[-1]), target.reshape(-1), 0.1, 0)
     assert float(loss) == pytest.approx(float(g["out::loss"]), rel=1e-6)
     assert float(nll) == pytest.approx(float(g["out::nll"]), rel=1e-6)
+
+
+def test_rnnt_restatement_vs_bruteforce_and_finite_differences():
+    """Pins oracle/rnnt_ref.py: the alpha recursion equals an explicit sum over ALL alignments on tiny lattices, and the
+    analytic gradient equals central finite differences."""
+    from oracle import rnnt_ref
+
+    rng = np.random.default_rng(0)
+    for T, U, V in ((1, 0, 3), (2, 1, 4), (3, 2, 5), (4, 3, 4), (5, 2, 6)):
+        z = rng.standard_normal((T, U + 1, V)) * 2
+        y = rng.integers(1, V, size=U).tolist()
+        nll = rnnt_ref.rnnt_loss_one(z, y)
+        assert nll == pytest.approx(rnnt_ref.rnnt_loss_bruteforce(z, y), rel=1e-10)
+    z = rng.standard_normal((4, 3, 5))
+    y = [2, 4]
+    nll, g = rnnt_ref.rnnt_loss_one(z, y, want_grad=True)
+    eps = 1e-6
+    for idx in [(0, 0, 0), (1, 1, 2), (3, 2, 0), (2, 0, 4), (3, 1, 4)]:
+        zp, zm = z.copy(), z.copy()
+        zp[idx] += eps
+        zm[idx] -= eps
+        fd = (rnnt_ref.rnnt_loss_one(zp, y) - rnnt_ref.rnnt_loss_one(zm, y)) / (2 * eps)
+        assert g[idx] == pytest.approx(fd, abs=1e-6)
