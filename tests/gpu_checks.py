@@ -527,3 +527,28 @@ def check_rnnt(seed=0):
         outside[: T_len[b], : U_len[b] + 1] = 0
         assert float(np.abs(outside).max()) == 0.0
     return {"loss_rel": le, "grad_abs": ge}
+
+
+# ------------------------------------------------------------------ validation-time greedy decoder for attention models
+def check_simple_greedy_decoder():
+    from espresso_amd.tools.simple_greedy_decoder import SimpleGreedyDecoder
+
+    g = np.load(os.path.join(GOLD, "ref_transformer_encdec_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = build_tiny_encdec().to(DEV)
+    model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    model.eval()
+    d = _TaskAR(40).target_dictionary
+    sample = {"net_input": {"src_tokens": torch.from_numpy(g["feats"]).to(DEV), "src_lengths": torch.from_numpy(g["lengths"]).to(DEV)},
+              "target": torch.from_numpy(g["target"]).to(DEV)}
+    dec = SimpleGreedyDecoder([model], d, for_validation=True)
+    tokens, lprobs, _ = dec.decode([model], sample)
+    # self-consistency with the teacher-forced forward on the decoded prefix (same check the reference semantics imply)
+    prev = torch.cat([torch.full((3, 1), d.eos(), dtype=torch.long, device=DEV), tokens[:, :-1]], 1)
+    with torch.no_grad():
+        lo, _ = model(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"], prev)
+    am = lo.float().argmax(-1)
+    U = min(tokens.shape[1], lprobs.shape[1])
+    agree = float((am[:, :U] == tokens[:, :U]).float().mean())
+    return {"tokens_shape": tuple(tokens.shape), "lprobs_shape": tuple(lprobs.shape), "argmax_consistency": agree,
+            "lprobs_normalised": float(torch.logsumexp(lprobs, -1).abs().max())}

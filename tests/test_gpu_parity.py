@@ -116,3 +116,10 @@ def test_rnnt_loss_fp32():
     print(r)
     assert r["loss_rel"] < 1e-5, r
     assert r["grad_abs"] < 1e-4, r
+
+
+def test_simple_greedy_decoder():
+    r = G.check_simple_greedy_decoder()
+    print(r)
+    assert r["lprobs_shape"][1] == 8 and r["lprobs_normalised"] < 1e-3, r
+    assert r["argmax_consistency"] > 0.9, r

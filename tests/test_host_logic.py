@@ -165,3 +165,17 @@ def test_specaugment_rng_order_matches_reference_fixture(golden_dir):
         fm, tm = tr.draw_masks(int(M), 80)
         np.random.set_state(state)
         np.testing.assert_array_equal(fbank_ref.specaugment_apply(spec, fm, tm, None), out)
+
+
+def test_wer_scorer_counts():
+    from espresso_amd.tools.wer import Scorer
+
+    d = AsrDictionary.from_symbols(list("abcdefgh"), enable_bos=False)
+    s = Scorer(d)
+    # reference "ab cd" vs hypothesis "ab ce f": chars a b <space> c d | a b <space> c e <space> f
+    s.add_evaluation("u1", "a b <space> c d", "a b <space> c e <space> f")
+    assert s.char_counter == Counter({"words": 5, "corr": 4, "sub": 1, "ins": 2, "del": 0})
+    assert s.word_counter == Counter({"words": 2, "corr": 1, "sub": 1, "ins": 1, "del": 0})
+    assert s.wer() == 100.0 and s.cer() == 60.0
+    s.add_evaluation("u2", "g h", "g h")
+    assert s.tot_word_count() == 3 and s.wer() == pytest.approx(200.0 / 3)
