@@ -142,7 +142,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--n-utts", type=int, default=20000)
+    ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B switch: keep weight-gradient GEMMs on the main stream")
     args = ap.parse_args()
+    if args.no_bwd_overlap:
+        from espresso_amd._lib import lib as _ealib
+        _ealib().ea_set_backward_overlap(0)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -37,12 +37,48 @@ struct Ctx {
   bool dry;  // size computation only: walk the arenas, launch nothing
   int rc;
   Arena* scratch;
+  // Backward overlap: weight-gradient GEMMs and bias column-sums only feed the optimizer, so they run on a side
+  // stream concurrently with the dgrad chain on `s` (fills the tails of the small launches).  While overlap is on, the
+  // scratch arena is not recycled inside a layer (a side kernel may still be reading a temporary).
+  hipStream_t side;
+  bool overlap;
 };
 
 #define RUN(call)                         \
   do {                                    \
     if (!c.dry && c.rc == 0) c.rc = (call); \
   } while (0)
+
+// process-wide side stream + a small ring of events (created on first use)
+struct SideRes {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[32];
+  int next = 0;
+  bool ok = false;
+};
+static SideRes g_side;
+static bool side_init() {
+  if (g_side.ok) return true;
+  if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return false;
+  for (auto& e : g_side.ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+  g_side.ok = true;
+  return true;
+}
+// make `dst` wait for everything enqueued so far on `src`
+static inline void stream_wait(Ctx& c, hipStream_t dst, hipStream_t src) {
+  if (c.dry || c.rc != 0) return;
+  hipEvent_t e = g_side.ev[g_side.next];
+  g_side.next = (g_side.next + 1) % 32;
+  if (hipEventRecord(e, src) != hipSuccess || hipStreamWaitEvent(dst, e, 0) != hipSuccess) c.rc = -1;
+}
+static inline void* ln_ws(Ctx& c, int M, int C) {
+  return c.scratch->get<char>((size_t)ea_layernorm_bwd_workspace_bytes(M, C));
+}
+// stream for optimizer-only products (wgrad / bias sums)
+static inline hipStream_t wstream(Ctx& c) { return c.overlap ? c.side : c.s; }
+static inline void fork(Ctx& c) { if (c.overlap) stream_wait(c, c.side, c.s); }
+static inline void release(Ctx& c, size_t mark) { if (!c.overlap) c.scratch->off = mark; }
 
 inline uint32_t drop_thr(float p) {
   if (p <= 0.f) return 0;
@@ -78,13 +114,16 @@ struct G {
 };
 
 inline void gemm(Ctx& c, G& g) { RUN(ea_gemm_bf16(&g.p, c.s)); }
+inline void gemm_on(Ctx& c, G& g, hipStream_t st) { RUN(ea_gemm_bf16(&g.p, st)); }
 
 // dW[N_out][K_in] += dy^T x with two-pass split-K; workspace from the scratch arena
 inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, float* dW, int M, int N_out, int K_in) {
-  const int tiles = ((N_out + 127) / 128) * ((K_in + 127) / 128);
+  // 64x128 output tiles; aim at ~512 resident workgroups (2 per CU): deeper splits only add slab traffic for the
+  // reduce pass (measured on the 2048x512 / 512x512 weight gradients at M = 6468)
+  const int tiles = ((N_out + 63) / 64) * ((K_in + 127) / 128);
   int sk = 1;
   if (tiles < 384 && M >= 1024) {
-    sk = (768 + tiles - 1) / tiles;
+    sk = (512 + tiles - 1) / tiles;
     if (sk > M / 256) sk = M / 256;
     if (sk < 1) sk = 1;
   }
@@ -92,8 +131,9 @@ inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, 
   g.aks().bks().f32().acc();
   g.p.splitk = sk;
   if (sk > 1) g.p.workspace = c.scratch->get<float>((size_t)sk * N_out * K_in);
-  gemm(c, g);
+  gemm_on(c, g, wstream(c));
 }
+inline void bias_grad(Ctx& c, const void* X, float* out, int M, int N, long ld) { RUN(ea_colsum_bf16(X, out, M, N, ld, wstream(c))); }
 
 }  // namespace
 
@@ -138,20 +178,22 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   uint16_t *xn = f.xn, *z = f.z, *h = f.h;
   uint16_t* g2 = sc.get<uint16_t>((size_t)M * C);
   RUN(ea_scale_dropout_bf16(dy, nullptr, g2, (long)M * C, out_scale, 0.f, seed + 2, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+  fork(c);
   wgrad(c, g2, C, h, F, gw.w2, M, C, F);
-  RUN(ea_colsum_bf16(g2, gw.b2, M, C, C, c.s));
+  bias_grad(c, g2, gw.b2, M, C, C);
   uint16_t* dz = sc.get<uint16_t>((size_t)M * F);
   G gd(g2, w.w2, dz, M, F, C, C, F, F);
   gd.bks().aux(z, F).act(act).drop(sh.p_act, seed + 1);
   gemm(c, gd);
+  fork(c);
   wgrad(c, dz, F, xn, C, gw.w1, M, F, C);
-  RUN(ea_colsum_bf16(dz, gw.b1, M, F, F, c.s));
+  bias_grad(c, dz, gw.b1, M, F, F);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   G gx(dz, w.w1, dxn, M, C, F, F, C, C);
   gx.bks();
   gemm(c, gx);
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, c.s));
-  sc.off = mark;
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, ln_ws(c, M, C), c.s));
+  release(c, mark);
 }
 
 // saved layout of the attention block is produced by the same get<> sequence in fwd and bwd
@@ -219,8 +261,9 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 4, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
     g = gg;
   }
+  fork(c);
   wgrad(c, g, C, a.o, C, gw.wo, M, C, C);
-  RUN(ea_colsum_bf16(g, gw.bo, M, C, C, c.s));
+  bias_grad(c, g, gw.bo, M, C, C);
   uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
   G gdo(g, w.wo, dO, M, C, C, C, C, C);
   gdo.bks();
@@ -260,21 +303,23 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     gpp.aks().bks().f32().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
     gpp.p.splitk = sk;
     if (sk > 1) gpp.p.workspace = sc.get<float>((size_t)sk * H * R * dh);
-    gemm(c, gpp);
-    RUN(ea_cast_f32_to_bf16(dpp32, dpp, (long)R * C, c.s));
+    fork(c);  // dBD, qv ready: the whole pos_proj gradient chain is optimizer-only
+    gemm_on(c, gpp, wstream(c));
+    RUN(ea_cast_f32_to_bf16(dpp32, dpp, (long)R * C, wstream(c)));
   }
   wgrad(c, dpp, C, pe, C, gw.wpos, R, C, C);
-  RUN(ea_colsum_bf16(t1, gw.pos_u, M, C, C, c.s));
-  RUN(ea_colsum_bf16(t2, gw.pos_v, M, C, C, c.s));
+  bias_grad(c, t1, gw.pos_u, M, C, C);
+  bias_grad(c, t2, gw.pos_v, M, C, C);
   RUN(ea_add2_strided_bf16(t1, C, t2, C, dqkv, 3 * C, M, C, c.s));
+  fork(c);
   wgrad(c, dqkv, 3 * C, a.xn, C, gw.wqkv, M, 3 * C, C);
-  RUN(ea_colsum_bf16(dqkv, gw.bqkv, M, 3 * C, 3 * C, c.s));
+  bias_grad(c, dqkv, gw.bqkv, M, 3 * C, 3 * C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   G gx(dqkv, w.wqkv, dxn, M, C, 3 * C, 3 * C, C, C);
   gx.bks();
   gemm(c, gx);
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, c.s));
-  sc.off = mark;
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, ln_ws(c, M, C), c.s));
+  release(c, mark);
 }
 
 struct ConvSaved {
@@ -328,6 +373,7 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
     RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 5, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
     g = gg;
   }
+  fork(c);
   wgrad(c, g, C, s.Hh, C, gw.pw2, M, C, C);
   uint16_t* dH = sc.get<uint16_t>((size_t)M * C);
   G gh(g, w.pw2, dH, M, C, C, C, C, C);
@@ -340,13 +386,14 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
   char* wws = sc.get<char>((size_t)ea_dwconv_wgrad_workspace_bytes(B, T, C, sh.KW));
   RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, gw.dw, wws, B, T, C, sh.KW, c.s));
+  fork(c);
   wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   G gx(dY, w.pw1, dxn, M, C, 2 * C, 2 * C, C, C);
   gx.bks();
   gemm(c, gx);
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, c.s));
-  sc.off = mark;
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, ln_ws(c, M, C), c.s));
+  release(c, mark);
 }
 
 // Saved-activation arena order: [x1][ffn1][x2][attn][x3][conv][x4][ffn2][final LN stats]
@@ -395,12 +442,20 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   uint16_t* d4 = sc.get<uint16_t>((size_t)M * C);
   uint16_t* d3 = sc.get<uint16_t>((size_t)M * C);
   RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, d4, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
-                       1.f, nullptr, c.s));
+                       1.f, nullptr, ln_ws(c, M, C), c.s));
   ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, d4, d3, seed + 48, 0.5f, EA_ACT_SILU);
   conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, d3, d4, seed + 32);
   attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, d4, d3, pe, seed + 16);
   ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, d3, dx, seed + 0, 0.5f, EA_ACT_SILU);
+  if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
+}
+
+static bool g_overlap_default = true;
+int ea_set_backward_overlap(int on) {
+  const int old = g_overlap_default;
+  g_overlap_default = on != 0;
+  return old;
 }
 
 static bool shape_ok(const EaLayerShape& sh) {
@@ -412,7 +467,7 @@ int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, l
   EaConformerLayer L;
   memset(&L, 0, sizeof(L));
   Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
-  Ctx c{nullptr, true, 0, &sc};
+  Ctx c{nullptr, true, 0, &sc, nullptr, g_overlap_default};
   layer_fwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
   Arena sv2{nullptr, 0, 0};
   layer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, sv2);
@@ -426,7 +481,7 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
                            hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
-  Ctx c{stream, false, 0, &sc};
+  Ctx c{stream, false, 0, &sc, nullptr, false};
   return layer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
 }
 
@@ -434,7 +489,9 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
                            const void* pe, void* saved, void* scratch, hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
-  Ctx c{stream, false, 0, &sc};
+  const bool ov = g_overlap_default && side_init();
+  Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
+  if (ov) stream_wait(c, c.side, c.s);
   return layer_bwd(c, layer, *shape, x_in, dy, dx, pe, sv);
 }
 

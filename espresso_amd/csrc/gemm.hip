@@ -452,21 +452,36 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p)
   }
 }
 
-// C[z][m][n] (+)= sum_s W[s][z][m][n]
+// C[z][m][n] (+)= sum_s W[s][z][m][n]      (VEC: N % 4 == 0 and 16-byte aligned C rows -> float4 per thread)
+template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const EaGemmParams p) {
+  constexpr int W_ = VEC ? 4 : 1;
   const long per = (long)p.batch * p.M * p.N;
-  const long stride = (long)gridDim.x * blockDim.x;
+  const long stride = (long)gridDim.x * blockDim.x * W_;
   const float* W = reinterpret_cast<const float*>(p.workspace);
   float* C = reinterpret_cast<float*>(p.C);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += stride) {
-    float a = 0.f;
-    for (int s = 0; s < p.splitk; ++s) a += W[(long)s * per + i];
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * W_; i < per; i += stride) {
     const int n = (int)(i % p.N);
     const long t = i / p.N;
     const int m = (int)(t % p.M);
     const int z = (int)(t / p.M);
     const long co = (long)(z / p.zdiv) * p.sC_hi + (long)(z % p.zdiv) * p.sC_lo + (long)m * p.ldc + n;
-    C[co] = p.accumulate ? C[co] + a : a;
+    if constexpr (VEC) {
+      float4 a = *reinterpret_cast<const float4*>(W + i);
+      for (int s = 1; s < p.splitk; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(W + (long)s * per + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      if (p.accumulate) {
+        const float4 c = *reinterpret_cast<const float4*>(C + co);
+        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+      }
+      *reinterpret_cast<float4*>(C + co) = a;
+    } else {
+      float a = 0.f;
+      for (int s = 0; s < p.splitk; ++s) a += W[(long)s * per + i];
+      C[co] = p.accumulate ? C[co] + a : a;
+    }
   }
 }
 
@@ -557,10 +572,14 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     g_prof.push_back(pr);
   }
   if (q.splitk > 1) {
-    long per = (long)q.batch * q.M * q.N;
-    long blocks = (per + 255) / 256;
+    const long per = (long)q.batch * q.M * q.N;
+    const bool vec = (q.N % 4 == 0) && (q.ldc % 4 == 0) && (q.sC_hi % 4 == 0) && (q.sC_lo % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(q.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(q.workspace) & 15) == 0);
+    long blocks = (per / (vec ? 4 : 1) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    if (blocks < 1) blocks = 1;
+    if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
   }
   return EA_CHECK_LAUNCH();
 }

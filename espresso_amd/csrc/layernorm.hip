@@ -7,15 +7,18 @@
 //
 // HBM-bound: one wavefront per row, 16-byte loads (8 bf16 per lane per pass), fp32 statistics via
 // 64-lane butterfly reductions, no LDS.  Backward re-reads x and dy once, writes dx once, and
-// accumulates dgamma/dbeta per block in registers -> LDS -> one atomicAdd per column per block.
+// accumulates dgamma/dbeta per block in registers -> LDS -> one partial row per block in a workspace slab that a
+// second small kernel folds into the gradient (fp32 global atomics run at ~33 G/s on gfx950: 2*C atomics per block
+// cost more than the whole streaming pass; the atomic path remains for callers without a workspace).
 #include "common.h"
 #include "espresso_amd.h"
 
 namespace {
 
-constexpr int MAXC8 = 4;  // supports C <= 64*8*4 = 2048
+constexpr int MAXC8_LIMIT = 4;  // supports C <= 64*8*4 = 2048
 
-// rows are processed one per wave. C % 8 == 0 required.
+// rows are processed one per wave. C % 8 == 0 required.  MAXC8 = 16-byte chunks per lane (C <= 512*MAXC8).
+template <int MAXC8>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C,
@@ -82,13 +85,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
 }
 
 // Each block owns ROWS_PER_BLOCK consecutive rows (4 waves round-robin), accumulates dgamma/dbeta
-// partials per lane-column, reduces across the 4 waves through LDS and issues atomics.
+// partials per lane-column, reduces across the 4 waves through LDS and writes one partial row (or issues atomics).
+template <int MAXC8>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int rows_per_block,
     const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep,
-    const bf16_t* __restrict__ dx_add) {
+    const bf16_t* __restrict__ dx_add, float* __restrict__ partial) {
   extern __shared__ float red[];  // [4][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
@@ -176,8 +180,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       a += red[(w * 2 + 0) * C + c];
       b += red[(w * 2 + 1) * C + c];
     }
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
+    if (partial) {
+      partial[(long)blockIdx.x * 2 * C + c] = a;
+      partial[(long)blockIdx.x * 2 * C + C + c] = b;
+    } else {
+      atomicAdd(dgamma + c, a);
+      atomicAdd(dbeta + c, b);
+    }
+  }
+}
+
+// partial: [nrows][2C] -> dgamma[c] += sum partial[:, c], dbeta[c] += sum partial[:, C + c].
+// grid (2C/64, RSPLIT); block 256 = 4 row-lanes x 64 columns.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int nrows, int C) {
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;  // [0, 2C)
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+  float a = 0.f;
+  for (int r = r0 + ry; r < r1; r += 4) a += partial[(long)r * 2 * C + col];
+  sm[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0) {
+    a = sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx];
+    if (col < C) atomicAdd(dgamma + col, a);
+    else atomicAdd(dbeta + col - C, a);
   }
 }
 
@@ -188,26 +217,52 @@ extern "C" int ea_layernorm_fwd(const void* x, const float* gamma, const float* 
                                 const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
                                 float drop_scale, hipStream_t stream) {
   if (M <= 0) return 0;
-  if (C % 8 != 0 || C > 64 * 8 * MAXC8) return -2;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, stream,
-                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps, row_zero,
-                     drop_seed, drop_thr, drop_scale);
+  if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
+#define EA_LN_FWD(NC)                                                                                                  \
+  hipLaunchKernelGGL((ln_fwd_kernel<NC>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta,      \
+                     (bf16_t*)y, mean, rstd, M, C, eps, row_zero, drop_seed, drop_thr, drop_scale)
+  if (C <= 512) EA_LN_FWD(1);
+  else if (C <= 1024) EA_LN_FWD(2);
+  else EA_LN_FWD(4);
+#undef EA_LN_FWD
   return EA_CHECK_LAUNCH();
+}
+
+static inline int ln_bwd_rows_per_block(int M, bool have_ws) {
+  if (have_ws) return 8;
+  // atomic path: ~512 blocks keep the dgamma/dbeta atomics (2*C per block) bounded
+  int rpb = (M + 511) / 512;
+  rpb = ((rpb + 3) / 4) * 4;
+  return rpb < 4 ? 4 : rpb;
+}
+
+extern "C" long ea_layernorm_bwd_workspace_bytes(int M, int C) {
+  const int rpb = ln_bwd_rows_per_block(M, true);
+  return (long)((M + rpb - 1) / rpb) * 2 * C * (long)sizeof(float);
 }
 
 extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C,
                                 const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
-                                float drop_scale, const void* dx_add, hipStream_t stream) {
+                                float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
   if (M <= 0) return 0;
-  if (C % 8 != 0 || C > 64 * 8 * MAXC8) return -2;
-  // ~512 blocks: enough to fill 256 CUs while keeping the dgamma/dbeta atomics (2*C per block) cheap
-  int rpb = (M + 511) / 512;
-  rpb = ((rpb + 3) / 4) * 4;
-  if (rpb < 4) rpb = 4;
+  if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
+  const int rpb = ln_bwd_rows_per_block(M, workspace != nullptr);
   const int nblk = (M + rpb - 1) / rpb;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,
-                     (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta,
-                     M, C, rpb, row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add);
+#define EA_LN_BWD(NC)                                                                                                  \
+  hipLaunchKernelGGL((ln_bwd_kernel<NC>), dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,                \
+                     (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, C, rpb,    \
+                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace)
+  if (C <= 512) EA_LN_BWD(1);
+  else if (C <= 1024) EA_LN_BWD(2);
+  else EA_LN_BWD(4);
+#undef EA_LN_BWD
+  if (workspace) {
+    int rs = nblk / 32;
+    if (rs < 1) rs = 1;
+    if (rs > 32) rs = 32;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(2 * C / 64, rs), dim3(256), 0, stream, (const float*)workspace, dgamma,
+                       dbeta, nblk, C);
+  }
   return EA_CHECK_LAUNCH();
 }

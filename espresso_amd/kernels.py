@@ -137,9 +137,10 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dgamma, dbeta, row_zero=None, drop_p
     assert dy.is_contiguous() and dy.dtype == torch.bfloat16
     dx = torch.empty_like(x)
     thr, scale = drop_params(drop_p)
+    ws = torch.empty(_lib.lib().ea_layernorm_bwd_workspace_bytes(M, C) // 4, dtype=torch.float32, device=x.device)
     check(
         _lib.lib().ea_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), M, C,
-                                    _p(row_zero), drop_seed, thr, scale, _p(dx_add), _stream()),
+                                    _p(row_zero), drop_seed, thr, scale, _p(dx_add), _p(ws), _stream()),
         "ea_layernorm_bwd",
     )
     return dx
@@ -206,6 +207,26 @@ def relpos_softmax_fwd(ac, bd, key_len, attn_mask, H, B, T, S, ld_ac, ld_bd, ld_
         "ea_relpos_softmax_fwd",
     )
     return P, (Pd if Pd is not None else P)
+
+
+def flash_attention_supported(dh, T, S, relpos):
+    return bool(_lib.lib().ea_flash_attention_supported(dh, T, S, int(relpos)))
+
+
+def flash_attention_fwd(qu, qv, k, v, pp, key_len, H, B, T, S, ldq, ldkv, ldpp=0, causal=False, drop_p=0.0, drop_seed=0,
+                        want_lse=True):
+    """Fused attention forward.  qu/qv: [B*T][ldq] bf16; k, v: tensors (views allowed) whose data_ptr is head 0 of row 0,
+    rows ldkv apart.  Returns (out [B*T][H*64] bf16, lse [H*B][T] fp32 or None)."""
+    dh = 64
+    out = torch.empty(B * T, H * dh, dtype=torch.bfloat16, device=qu.device)
+    lse = torch.empty(H * B, T, dtype=torch.float32, device=qu.device) if want_lse else None
+    thr, scale = drop_params(drop_p)
+    check(
+        _lib.lib().ea_flash_attention_fwd(_p(qu), _p(qv), ldq, _p(k), _p(v), ldkv, _p(pp), ldpp, _p(key_len), _p(out),
+                                          H * dh, _p(lse), H, B, T, S, dh, int(causal), drop_seed, thr, scale, _stream()),
+        "ea_flash_attention_fwd",
+    )
+    return out, lse
 
 
 def relpos_softmax_bwd(P, dPd, H, B, T, S, ld_p, ld_dp, ld_bd, want_bd=True, drop_p=0.0, drop_seed=0):

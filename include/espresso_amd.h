@@ -90,10 +90,13 @@ long ea_gemm_profile_read(double* total_ms, double* total_flops);
 int ea_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int M, int C, float eps, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
                      float drop_scale, ea_stream_t stream);
+/* workspace (ea_layernorm_bwd_workspace_bytes, or NULL): per-block dgamma/dbeta partial rows folded by a second small
+ * kernel instead of 2*C global atomics per block. */
+long ea_layernorm_bwd_workspace_bytes(int M, int C);
 int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                      void* dx, float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero,
                      uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* dx_add,
-                     ea_stream_t stream);
+                     void* workspace, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming helpers (AMP weight cast fairseq/tasks/fairseq_task.py:516; FairseqDropout backward
@@ -112,6 +115,24 @@ int ea_embedding_fwd(const int* tokens, const int* positions, const float* W, co
 int ea_embedding_bwd(const int* tokens, const void* dy, float* dW, int M, int C, float scale, int pad_idx,
                      ea_stream_t stream);
 int ea_zero_rows_bf16(void* x, const uint8_t* row_zero, int M, int C, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention (flash_attention.hip): scores + rel-pos skew + key-padding / causal mask + fp32 online softmax +
+ * attention dropout + P.V in one kernel; replaces the bmm / as_strided / softmax / dropout / bmm sequence of
+ * fairseq/modules/multihead_attention.py:788-907 without materialising the (B*H, T, S) tensors.
+ *   qu, qv : bf16 [B*T][ldq], (q + pos_bias_u) * scaling and (q + pos_bias_v) * scaling (ea_relpos_q_prep); qv = NULL
+ *            selects plain attention (absolute positions, decoder self-attention, cross-attention).
+ *   k, v   : bf16, row (b*S + j) * ldkv, head h at column h*dh of the given base pointers
+ *   pp     : bf16 [2T-1][ldpp] projected sinusoidal table (row r <-> relative position, used column r = T-1-i+j)
+ *   key_len: int [B] valid keys per sentence or NULL; causal: mask j > i + (S - T)
+ *   out    : bf16 [B*T][ldo] (head h at column h*dh); lse: fp32 [H*B][T] row logsumexp (NULL to skip)
+ * dropout index of element (z = h*B + b, i, j) is (z*T + i)*S + j, identical to ea_relpos_softmax_fwd.
+ * ea_flash_attention_supported: dh == 64 (and T == S for rel-pos); other shapes use the unfused kernels. */
+int ea_flash_attention_supported(int dh, int T, int S, int relpos);
+int ea_flash_attention_fwd(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldkv,
+                           const void* pp, long ldpp, const int* key_len, void* out, long ldo, float* lse, int H, int B,
+                           int T, int S, int dh, int causal, uint64_t drop_seed, uint32_t drop_thr, float drop_scale,
+                           ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Relative-position attention glue — fairseq/modules/multihead_attention.py:679-688 (q+u, q+v,
@@ -247,6 +268,9 @@ typedef struct EaConformerLayer {
 } EaConformerLayer;
 typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; } EaLayerShape;
 
+/* tuning hook: run weight-gradient GEMMs / bias sums of the layer backward on a side stream (default on); returns the
+ * previous value.  Sizes from ea_conformer_layer_workspace depend on this setting: query them after changing it. */
+int ea_set_backward_overlap(int on);
 int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
                            const int* key_len, const float* attn_mask, const void* pe, void* saved, void* scratch,

@@ -552,3 +552,63 @@ def check_simple_greedy_decoder():
     agree = float((am[:, :U] == tokens[:, :U]).float().mean())
     return {"tokens_shape": tuple(tokens.shape), "lprobs_shape": tuple(lprobs.shape), "argmax_consistency": agree,
             "lprobs_normalised": float(torch.logsumexp(lprobs, -1).abs().max())}
+
+
+def _attn_reference(qu, qv, k, v, pp, klen, H, B, T, S, causal):
+    """fp32 restatement of fairseq/modules/multihead_attention.py:788-907 on the (already biased / scaled) queries."""
+    dh = 64
+    f = lambda x, L: x.float().view(B, L, H, dh).permute(0, 2, 1, 3)  # [B][H][L][dh]
+    s = f(qu, T) @ f(k, S).transpose(-1, -2)
+    if qv is not None:
+        raw = f(qv, T) @ pp.float().view(2 * T - 1, H, dh).permute(1, 0, 2).transpose(-1, -2)  # [B][H][T][2T-1]
+        ii = torch.arange(T, device=qu.device)[:, None]
+        jj = torch.arange(S, device=qu.device)[None, :]
+        s = s + torch.gather(raw, 3, ((T - 1) - ii + jj).expand(B, H, T, S))
+    jj = torch.arange(S, device=qu.device)
+    if klen is not None:
+        s = s.masked_fill(jj[None, None, None, :] >= klen.long()[:, None, None, None], float("-inf"))
+    if causal:
+        ii = torch.arange(T, device=qu.device)
+        s = s.masked_fill(jj[None, :] > ii[:, None] + (S - T), float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return s, p, f(v, S)
+
+
+def check_flash_attention(B=3, H=4, T=150, S=None, relpos=True, causal=False, padded=True, drop_p=0.0, seed=0):
+    """Fused attention forward vs the fp32 restatement (and, with dropout, vs the unfused softmax kernel's mask)."""
+    from espresso_amd import kernels as K
+    dev = "cuda:0"
+    S = S or T
+    dh, C = 64, H * 64
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rnd = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    qu = (rnd(B * T, C) * 0.35).to(torch.bfloat16)
+    qv = (rnd(B * T, C) * 0.35).to(torch.bfloat16) if relpos else None
+    kv = rnd(B * S, 2 * C).to(torch.bfloat16)
+    k, v = kv[:, :C], kv[:, C:]
+    pp = rnd(2 * T - 1, C).to(torch.bfloat16) if relpos else None
+    klen = None
+    if padded:
+        klen = torch.randint(max(1, S // 3), S + 1, (B,), device=dev, generator=g).int()
+        klen[0] = S
+    out, lse = K.flash_attention_fwd(qu, qv, k, v, pp, klen, H, B, T, S, C, 2 * C, C, causal=causal, drop_p=drop_p, drop_seed=1234)
+    s, p, vf = _attn_reference(qu, qv, k.contiguous(), v.contiguous(), pp, klen, H, B, T, S, causal)
+    lse_ref = torch.logsumexp(s, dim=-1)  # [B][H][T]
+    if drop_p > 0:
+        # the unfused kernel applies keep(seed, (z*T+i)*S + j) to the same probabilities: reuse its mask
+        Sp = (S + 7) // 8 * 8
+        ac = torch.zeros(H * B * T, Sp, device=dev)
+        ac[:, :S] = s.permute(1, 0, 2, 3).reshape(H * B * T, S)
+        kl = klen if klen is not None else torch.full((B,), S, dtype=torch.int32, device=dev)
+        P, Pd = K.relpos_softmax_fwd(ac, None, kl, None, H, B, T, S, Sp, 0, Sp, causal=False, drop_p=drop_p, drop_seed=1234)
+        keep = (Pd.float() != 0) | (P.float() == 0)
+        keep = keep[:, :S].view(H, B, T, S).permute(1, 0, 2, 3)
+        p = p * keep / (1.0 - drop_p)
+    o_ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * T, C)
+    torch.cuda.synchronize()
+    lse_got = lse.view(H, B, T).permute(1, 0, 2)
+    return {
+        "out_abs": float((out.float() - o_ref).abs().max()),
+        "out_ref_max": float(o_ref.abs().max()),
+        "lse_abs": float((lse_got - lse_ref).abs().max()),
+    }

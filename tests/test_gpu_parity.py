@@ -123,3 +123,21 @@ def test_simple_greedy_decoder():
     print(r)
     assert r["lprobs_shape"][1] == 8 and r["lprobs_normalised"] < 1e-3, r
     assert r["argmax_consistency"] > 0.9, r
+
+
+@pytest.mark.parametrize("kw", [
+    dict(T=150, relpos=True, padded=True),
+    dict(T=308, B=2, H=8, relpos=True, padded=False),
+    dict(T=64, relpos=True, padded=True),
+    dict(T=37, relpos=True, padded=False),
+    dict(T=150, relpos=False, padded=True),
+    dict(T=100, relpos=False, causal=True, padded=False),
+    dict(T=50, S=170, relpos=False, padded=True),
+    dict(T=150, relpos=True, padded=True, drop_p=0.1),
+])
+def test_flash_attention_forward(kw):
+    """fused scores+skew+softmax+dropout+PV vs fp32 restatement of multihead_attention.py:788-907 (bf16 probabilities:
+    1e-2 of the output range; logsumexp 2e-3 abs — fp32 accumulation of bf16 products)"""
+    r = G.check_flash_attention(**kw)
+    assert r["out_abs"] <= 1.5e-2 * max(1.0, r["out_ref_max"]), r
+    assert r["lse_abs"] <= 2e-3, r
