@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--n-utts", type=int, default=20000)
+    ap.add_argument("--max-tokens", type=int, default=26000, help="diagnostic only: shrink the batches (host-overhead probes)")
     ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B switch: keep weight-gradient GEMMs on the main stream")
     args = ap.parse_args()
     if args.no_bwd_overlap:
@@ -161,7 +162,7 @@ def main():
     from espresso_amd.data import synthetic
 
     task, model, criterion, trainer = build(device)
-    batches, n_samples = synthetic.make_batches(args.n_utts, max_tokens=26000, max_sentences=24, seed=1)
+    batches, n_samples = synthetic.make_batches(args.n_utts, max_tokens=args.max_tokens, max_sentences=24, seed=1)
     need = args.steps + args.warmup
     mine = [batches[(i * world + rank) % len(batches)] for i in range(need)]
     pad = task.target_dictionary.pad()

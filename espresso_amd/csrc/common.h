@@ -15,15 +15,14 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float bf2f(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
-// round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16))
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16)): gfx950 converts in hardware
+// (v_cvt_pk_bf16_f32, one instruction per pair instead of ~6 VALU ops per element in software)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
+  typedef float f32v2_t __attribute__((ext_vector_type(2)));
+  const f32v2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -59,14 +58,21 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
   return r;
 }
 
-// Counter-based dropout RNG: a 64-bit mix of (seed, element index) -> uniform [0,1).
-// The same (seed, idx) is re-evaluated in the backward kernels, so no mask is ever stored.
+// Counter-based dropout RNG: a 32-bit avalanche mix (murmur3 finaliser) of (seed, element index) -> uniform 32 bits.
+// The same (seed, idx) is re-evaluated in the backward kernels, so no mask is ever stored.  All arithmetic is 32-bit
+// (gfx950 has no 64-bit integer multiplier: a splitmix64 costs ~35 VALU ops per element, this one ~10, and the dropout
+// of the attention probabilities made the fused attention kernels VALU-bound); the high halves of seed / idx only
+// enter through a term that is loop invariant in every caller.
 __device__ __forceinline__ uint32_t ea_hash(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t hi = ((uint32_t)(idx >> 32) * 0x85EBCA77u) ^ (uint32_t)(seed >> 32) ^ ((uint32_t)seed * 0xC2B2AE3Du);
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= hi;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
 }
 // keep-scale: returns 0 if dropped, 1/(1-p) if kept.  thr = p * 2^32 (host computed).
 __device__ __forceinline__ float ea_keep(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {

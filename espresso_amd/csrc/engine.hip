@@ -197,13 +197,33 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
 }
 
 // saved layout of the attention block is produced by the same get<> sequence in fwd and bwd
+static bool g_flash = true;
+// fused (flash) attention: head dim 64 and no additive attention mask; decided from the shape alone so that the saved
+// layout of forward and backward agree
+static inline bool attn_fused(const EaLayerShape& sh) {
+  return g_flash && !sh.has_attn_mask && ea_flash_attention_supported(sh.C / sh.H, sh.T, sh.T, 1);
+}
 struct AttnSaved {
-  float *mean, *rstd;
+  float *mean, *rstd, *lse;
   uint16_t *xn, *qkv, *qu, *qv, *pp, *P, *Pd, *o;
 };
 static AttnSaved attn_saved(Arena& sv, const EaLayerShape& sh) {
   const int M = sh.B * sh.T, C = sh.C, T = sh.T, Z = sh.H * sh.B, Sp = pad8(T), R = 2 * T - 1;
   AttnSaved a;
+  if (attn_fused(sh)) {
+    a.mean = sv.get<float>(M);
+    a.rstd = sv.get<float>(M);
+    a.lse = sv.get<float>((size_t)Z * T);
+    a.xn = sv.get<uint16_t>((size_t)M * C);
+    a.qkv = sv.get<uint16_t>((size_t)M * 3 * C);
+    a.qu = sv.get<uint16_t>((size_t)M * C);
+    a.qv = sv.get<uint16_t>((size_t)M * C);
+    a.pp = sv.get<uint16_t>((size_t)R * C);
+    a.P = a.Pd = nullptr;
+    a.o = sv.get<uint16_t>((size_t)M * C);
+    return a;
+  }
+  a.lse = nullptr;
   a.mean = sv.get<float>(M);
   a.rstd = sv.get<float>(M);
   a.xn = sv.get<uint16_t>((size_t)M * C);
@@ -228,6 +248,17 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   gq.bias(w.bqkv);
   gemm(c, gq);
   RUN(ea_relpos_q_prep(a.qkv, 3 * C, w.pos_u, w.pos_v, a.qu, a.qv, M, C, scaling, c.s));
+  if (attn_fused(sh)) {
+    G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
+    gemm(c, gpp);
+    RUN(ea_flash_attention_fwd(a.qu, a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, a.pp, C, key_len, a.o, C, a.lse, H, B, T, T, dh, 0,
+                               seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+    G go(a.o, w.wo, y, M, C, C, C, C, C);
+    go.bias(w.bo).drop(sh.p_drop, seed + 4).resid(x, C);
+    gemm(c, go);
+    sc.off = mark;
+    return;
+  }
   float* ac = sc.get<float>((size_t)Z * T * Sp);
   float* bd = sc.get<float>((size_t)Z * T * Rp);
   G gac(a.qu, a.qkv + C, ac, T, T, dh, C, 3 * C, Sp);
@@ -249,47 +280,12 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   sc.off = mark;
 }
 
-static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
-                     const void* dy, void* dx, const void* pe, uint64_t seed) {
-  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
-  const float scaling = 1.0f / sqrtf((float)dh);
+// shared tail of the attention backward: pos_proj / bias / qkv weight gradients, dq = t1 + t2, dgrad to the block input, LN
+static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw,
+                          const void* x, const void* dy, void* dx, const void* pe, uint16_t* dqkv, uint16_t* t1, uint16_t* t2,
+                          uint16_t* dBD) {
+  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad8(R);
   Arena& sc = *c.scratch;
-  const size_t mark = sc.off;
-  const void* g = dy;
-  if (sh.p_drop > 0.f) {
-    uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
-    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 4, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
-    g = gg;
-  }
-  fork(c);
-  wgrad(c, g, C, a.o, C, gw.wo, M, C, C);
-  bias_grad(c, g, gw.bo, M, C, C);
-  uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
-  G gdo(g, w.wo, dO, M, C, C, C, C, C);
-  gdo.bks();
-  gemm(c, gdo);
-  float* dPd = sc.get<float>((size_t)Z * T * Sp);
-  G gdp(dO, a.qkv + 2 * C, dPd, T, T, dh, C, 3 * C, Sp);
-  gdp.f32().batch(Z, B, dh, (long)T * C, dh, (long)T * 3 * C, (long)B * T * Sp, (long)T * Sp);
-  gemm(c, gdp);
-  uint16_t* dqkv = sc.get<uint16_t>((size_t)M * 3 * C);
-  G gdv(a.Pd, dO, dqkv + 2 * C, T, dh, T, Sp, C, 3 * C);
-  gdv.aks().bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * C, dh, (long)T * 3 * C);
-  gemm(c, gdv);
-  uint16_t* dAC = sc.get<uint16_t>((size_t)Z * T * Sp);
-  uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
-  RUN(ea_relpos_softmax_bwd(a.P, dPd, dAC, dBD, H, B, T, T, Sp, Sp, Rp, seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
-  G gdk(dAC, a.qu, dqkv + C, T, dh, T, Sp, C, 3 * C);
-  gdk.aks().bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * C, dh, (long)T * 3 * C);
-  gemm(c, gdk);
-  uint16_t* t1 = sc.get<uint16_t>((size_t)M * C);
-  G gt1(dAC, a.qkv + C, t1, T, dh, T, Sp, 3 * C, C);
-  gt1.bks().alpha(scaling).batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * 3 * C, dh, (long)T * C);
-  gemm(c, gt1);
-  uint16_t* t2 = sc.get<uint16_t>((size_t)M * C);
-  G gt2(dBD, a.pp, t2, T, dh, R, Rp, C, C);
-  gt2.bks().alpha(scaling).batch(Z, B, (long)B * T * Rp, (long)T * Rp, dh, 0, dh, (long)T * C);
-  gemm(c, gt2);
   // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames
   // -> split-K into fp32, then one cast to bf16 for the pos_proj weight gradient
   uint16_t* dpp = sc.get<uint16_t>((size_t)R * C);
@@ -319,6 +315,63 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   gx.bks();
   gemm(c, gx);
   RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, ln_ws(c, M, C), c.s));
+}
+
+static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
+                     const void* dy, void* dx, const int* key_len, const void* pe, uint64_t seed) {
+  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
+  const float scaling = 1.0f / sqrtf((float)dh);
+  Arena& sc = *c.scratch;
+  const size_t mark = sc.off;
+  const void* g = dy;
+  if (sh.p_drop > 0.f) {
+    uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
+    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 4, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+    g = gg;
+  }
+  fork(c);
+  wgrad(c, g, C, a.o, C, gw.wo, M, C, C);
+  bias_grad(c, g, gw.bo, M, C, C);
+  uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
+  G gdo(g, w.wo, dO, M, C, C, C, C, C);
+  gdo.bks();
+  gemm(c, gdo);
+  if (attn_fused(sh)) {
+    uint16_t* dqkv = sc.get<uint16_t>((size_t)M * 3 * C);
+    uint16_t* t1 = sc.get<uint16_t>((size_t)M * C);
+    uint16_t* t2 = sc.get<uint16_t>((size_t)M * C);
+    uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
+    float* Dd = sc.get<float>((size_t)Z * T);
+    RUN(ea_flash_attention_bwd(a.qu, a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
+                               Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 0, scaling, seed + 3, drop_thr(sh.p_attn),
+                               drop_scale(sh.p_attn), c.s));
+    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD);
+    release(c, mark);
+    return;
+  }
+  float* dPd = sc.get<float>((size_t)Z * T * Sp);
+  G gdp(dO, a.qkv + 2 * C, dPd, T, T, dh, C, 3 * C, Sp);
+  gdp.f32().batch(Z, B, dh, (long)T * C, dh, (long)T * 3 * C, (long)B * T * Sp, (long)T * Sp);
+  gemm(c, gdp);
+  uint16_t* dqkv = sc.get<uint16_t>((size_t)M * 3 * C);
+  G gdv(a.Pd, dO, dqkv + 2 * C, T, dh, T, Sp, C, 3 * C);
+  gdv.aks().bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * C, dh, (long)T * 3 * C);
+  gemm(c, gdv);
+  uint16_t* dAC = sc.get<uint16_t>((size_t)Z * T * Sp);
+  uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
+  RUN(ea_relpos_softmax_bwd(a.P, dPd, dAC, dBD, H, B, T, T, Sp, Sp, Rp, seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+  G gdk(dAC, a.qu, dqkv + C, T, dh, T, Sp, C, 3 * C);
+  gdk.aks().bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * C, dh, (long)T * 3 * C);
+  gemm(c, gdk);
+  uint16_t* t1 = sc.get<uint16_t>((size_t)M * C);
+  G gt1(dAC, a.qkv + C, t1, T, dh, T, Sp, 3 * C, C);
+  gt1.bks().alpha(scaling).batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * 3 * C, dh, (long)T * C);
+  gemm(c, gt1);
+  uint16_t* t2 = sc.get<uint16_t>((size_t)M * C);
+  G gt2(dBD, a.pp, t2, T, dh, R, Rp, C, C);
+  gt2.bks().alpha(scaling).batch(Z, B, (long)B * T * Rp, (long)T * Rp, dh, 0, dh, (long)T * C);
+  gemm(c, gt2);
+  attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD);
   release(c, mark);
 }
 
@@ -434,7 +487,7 @@ static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
 }
 
 static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, const void* x_in, const void* dy, void* dx,
-                     const void* pe, Arena& sv) {
+                     const int* key_len, const void* pe, Arena& sv) {
   const int M = sh.B * sh.T, C = sh.C;
   LayerSaved S = layer_saved(sv, sh);
   Arena& sc = *c.scratch;
@@ -445,7 +498,7 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
                        1.f, nullptr, ln_ws(c, M, C), c.s));
   ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, d4, d3, seed + 48, 0.5f, EA_ACT_SILU);
   conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, d3, d4, seed + 32);
-  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, d4, d3, pe, seed + 16);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, d4, d3, key_len, pe, seed + 16);
   ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, d3, dx, seed + 0, 0.5f, EA_ACT_SILU);
   if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
@@ -470,7 +523,7 @@ int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, l
   Ctx c{nullptr, true, 0, &sc, nullptr, g_overlap_default};
   layer_fwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
   Arena sv2{nullptr, 0, 0};
-  layer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, sv2);
+  layer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv2);
   *saved_bytes = (long)sv.peak + 256;
   *scratch_bytes = (long)sc.peak + 256;
   return 0;
@@ -482,17 +535,24 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
   if (!shape_ok(*shape)) return -2;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, nullptr, false};
+  if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
   return layer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
 }
 
+int ea_set_flash_attention(int on) {
+  const int old = g_flash;
+  g_flash = on != 0;
+  return old;
+}
+
 int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy, void* dx,
-                           const void* pe, void* saved, void* scratch, hipStream_t stream) {
+                           const int* key_len, const void* pe, void* saved, void* scratch, hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   const bool ov = g_overlap_default && side_init();
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
   if (ov) stream_wait(c, c.side, c.s);
-  return layer_bwd(c, layer, *shape, x_in, dy, dx, pe, sv);
+  return layer_bwd(c, layer, *shape, x_in, dy, dx, key_len, pe, sv);
 }
 
 }  // extern "C"

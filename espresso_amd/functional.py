@@ -636,6 +636,7 @@ class _LayerBinding:
         L.grads.final_ln_g, L.grads.final_ln_b = grad(m.final_layer_norm.weight), grad(m.final_layer_norm.bias)
         self.L = L
         self.params = [p for p in m.parameters()]
+        self.saved_buf, self.saved_busy = None, False
 
     def finish_backward(self):
         """Scatter packed q/k/v gradients back to their parameters and signal readiness."""
@@ -673,16 +674,28 @@ class _ConformerLayerNative(torch.autograd.Function):
         sh.training = int(training)
         sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
         sh.seed = _next_seed() * 64 % (1 << 63)
+        sh.has_attn_mask = int(attn_mask is not None)
         nb_saved, nb_scratch = ctypes.c_long(0), ctypes.c_long(0)
         lib = _lib.lib()
         _lib.check(lib.ea_conformer_layer_workspace(ctypes.byref(sh), ctypes.byref(nb_saved), ctypes.byref(nb_scratch)), "workspace")
-        saved = torch.empty(nb_saved.value, dtype=torch.uint8, device=x.device)
+        # saved activations live in a grow-only arena owned by the layer binding: no allocator traffic in steady state
+        # (a fresh private buffer only when the previous forward of this layer is still waiting for its backward)
+        needs_bwd = ctx.needs_input_grad[0]
+        if bind.saved_busy or not bind.cacheable:
+            saved = torch.empty(nb_saved.value, dtype=torch.uint8, device=x.device)
+            ctx.owns_arena = False
+        else:
+            if bind.saved_buf is None or bind.saved_buf.numel() < nb_saved.value or bind.saved_buf.device != x.device:
+                bind.saved_buf = torch.empty(int(nb_saved.value * 1.1) + 4096, dtype=torch.uint8, device=x.device)
+            saved = bind.saved_buf
+            bind.saved_busy = bool(needs_bwd)
+            ctx.owns_arena = bool(needs_bwd)
         scratch = _scratch_buffer(nb_scratch.value, x.device)
         y = torch.empty_like(x)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(lib.ea_conformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
                                               _ptr(pe), _ptr(saved), _ptr(scratch), stream), "ea_conformer_layer_fwd")
-        ctx.save_for_backward(x, saved, pe)
+        ctx.save_for_backward(x, saved, pe, key_len)
         ctx.bind, ctx.sh, ctx.nb_scratch = bind, sh, nb_scratch.value
         return y
 
@@ -692,13 +705,15 @@ class _ConformerLayerNative(torch.autograd.Function):
 
         from . import _lib
 
-        x, saved, pe = ctx.saved_tensors
+        x, saved, pe, key_len = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         scratch = _scratch_buffer(ctx.nb_scratch, x.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(pe),
-                                                     _ptr(saved), _ptr(scratch), stream), "ea_conformer_layer_bwd")
+        _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
+                                                     _ptr(pe), _ptr(saved), _ptr(scratch), stream), "ea_conformer_layer_bwd")
+        if ctx.owns_arena:
+            ctx.bind.saved_busy = False
         ctx.bind.finish_backward()
         return (dx,) + (None,) * 10
 

@@ -229,6 +229,27 @@ def flash_attention_fwd(qu, qv, k, v, pp, key_len, H, B, T, S, ldq, ldkv, ldpp=0
     return out, lse
 
 
+def flash_attention_bwd(qu, qv, k, v, pp, key_len, out, dout, lse, dk, dv, H, B, T, S, ldq, ldkv, lddkv, ldpp=0, causal=False,
+                        scaling=1.0, drop_p=0.0, drop_seed=0):
+    """Fused attention backward.  dk / dv: destination views (row stride lddkv).  Returns (t1, t2, dBD)."""
+    dh = 64
+    C = H * dh
+    relpos = qv is not None
+    t1 = torch.empty(B * T, C, dtype=torch.bfloat16, device=qu.device)
+    t2 = torch.empty_like(t1) if relpos else None
+    Rp = (2 * T - 1 + 7) // 8 * 8
+    dBD = torch.empty(H * B * T, Rp, dtype=torch.bfloat16, device=qu.device) if relpos else None
+    D = torch.empty(H * B, T, dtype=torch.float32, device=qu.device)
+    thr, scale = drop_params(drop_p)
+    check(
+        _lib.lib().ea_flash_attention_bwd(_p(qu), _p(qv), ldq, _p(k), _p(v), ldkv, _p(pp), ldpp, _p(key_len), _p(out), _p(dout),
+                                          C, _p(lse), _p(D), _p(t1), _p(t2), C, _p(dBD), Rp, _p(dk), _p(dv), lddkv, H, B, T, S,
+                                          dh, int(causal), scaling, drop_seed, thr, scale, _stream()),
+        "ea_flash_attention_bwd",
+    )
+    return t1, t2, dBD
+
+
 def relpos_softmax_bwd(P, dPd, H, B, T, S, ld_p, ld_dp, ld_bd, want_bd=True, drop_p=0.0, drop_seed=0):
     dAC = torch.empty(H * B * T, ld_p, dtype=torch.bfloat16, device=P.device)
     dBD = torch.empty(H * B * T, ld_bd, dtype=torch.bfloat16, device=P.device) if want_bd else None

@@ -34,15 +34,18 @@ class SinusoidalRelativePositionalEmbedding:
     def __init__(self, embedding_dim, init_size=1024, scale_embedding=True):
         self.embedding_dim = embedding_dim
         self.embedding_scale = embedding_dim ** -0.5 if scale_embedding else 1.0
+        self.init_size = init_size
         self._cache = {}
 
     def table(self, seq_len: int, device) -> torch.Tensor:
-        """bf16 [2*seq_len-1][dim] for keys of length seq_len."""
-        key = (seq_len, str(device))
-        t = self._cache.get(key)
-        if t is None:
-            # the reference slices a larger table around its centre; values depend only on the offset
-            full = self.embedding_scale * get_embedding(seq_len, self.embedding_dim)
-            t = full.to(device=device, dtype=torch.bfloat16).contiguous()
-            self._cache[key] = t
-        return t
+        """bf16 [2*seq_len-1][dim] for keys of length seq_len: a contiguous row slice around the centre of one cached
+        table per device (the values depend only on the offset, exactly how the reference slices its larger table,
+        :112-124) — no per-length rebuild / host-to-device copy inside the training loop."""
+        ent = self._cache.get(device)
+        if ent is None or ent[0] < seq_len:
+            size = max(self.init_size, seq_len) if ent is None else max(2 * ent[0], seq_len)
+            full = self.embedding_scale * get_embedding(size, self.embedding_dim)
+            ent = (size, full.to(device=device, dtype=torch.bfloat16).contiguous())
+            self._cache[device] = ent
+        size, full = ent
+        return full[(size - 1) - (seq_len - 1): (size - 1) + seq_len]

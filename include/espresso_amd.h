@@ -133,6 +133,18 @@ int ea_flash_attention_fwd(const void* qu, const void* qv, long ldq, const void*
                            const void* pp, long ldpp, const int* key_len, void* out, long ldo, float* lse, int H, int B,
                            int T, int S, int dh, int causal, uint64_t drop_seed, uint32_t drop_thr, float drop_scale,
                            ea_stream_t stream);
+/* Backward of ea_flash_attention_fwd (probabilities recomputed from lse; same dropout stream).
+ *   out, dout : bf16 [B*T][ldo] forward output and its gradient;  D: fp32 [H*B][T] scratch (row dot dO.O)
+ *   t1, t2    : bf16 [B*T][ldt], scaling * dL/dqu and scaling * dL/dqv, i.e. the gradients w.r.t. (q + pos_bias_u) and
+ *               (q + pos_bias_v) before scaling (t2 / dBD / pp unused when qv == NULL)
+ *   dBD       : bf16 [H*B][T][ld_bd] gradient of the raw positional logits (un-skewed, zero outside the band), the
+ *               operand of the pos_proj weight gradient dpp[r] = sum_{b,i} dBD[.,i,r] qv[b,i]
+ *   dk, dv    : bf16, row (b*S + j) * lddkv, head h at column h*dh (e.g. the k / v thirds of a packed dqkv buffer) */
+int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldkv,
+                           const void* pp, long ldpp, const int* key_len, const void* out, const void* dout, long ldo,
+                           const float* lse, float* D, void* t1, void* t2, long ldt, void* dBD, int ld_bd, void* dk,
+                           void* dv, long lddkv, int H, int B, int T, int S, int dh, int causal, float scaling,
+                           uint64_t drop_seed, uint32_t drop_thr, float drop_scale, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Relative-position attention glue — fairseq/modules/multihead_attention.py:679-688 (q+u, q+v,
@@ -266,7 +278,7 @@ typedef struct EaConformerLayer {
   EaFfnParams ffn1; EaAttnParams attn; EaConvParams conv; EaFfnParams ffn2; const float *final_ln_g, *final_ln_b;
   EaLayerGrads grads;
 } EaConformerLayer;
-typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; } EaLayerShape;
+typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; int has_attn_mask; } EaLayerShape;
 
 /* tuning hook: run weight-gradient GEMMs / bias sums of the layer backward on a side stream (default on); returns the
  * previous value.  Sizes from ea_conformer_layer_workspace depend on this setting: query them after changing it. */
@@ -276,7 +288,10 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
                            const int* key_len, const float* attn_mask, const void* pe, void* saved, void* scratch,
                            ea_stream_t stream);
 int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
-                           void* dx, const void* pe, void* saved, void* scratch, ea_stream_t stream);
+                           void* dx, const int* key_len, const void* pe, void* saved, void* scratch, ea_stream_t stream);
+/* tuning / test hook: use the fused attention kernels inside the layer runtime when the shape allows (default on);
+ * returns the previous value.  Workspace sizes depend on it. */
+int ea_set_flash_attention(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Batched beam-search decoding (csrc/decode.hip) — fairseq/sequence_generator.py:355-609, fairseq/search.py:103-144,

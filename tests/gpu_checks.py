@@ -74,13 +74,13 @@ class _Task:
         assert len(self.target_dictionary) == V
 
 
-def build_tiny_model(layer_type, V=40):
+def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
     from espresso_amd.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderModel
 
     cfg = SpeechTransformerConfig()
     e = cfg.encoder
-    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 64, 128, 2, 4
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = embed_dim, ffn, 2, heads
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, layer_type
     e.conv_channels = "[64, 64, 16, 16]"
     cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
@@ -280,7 +280,7 @@ def smoke_check():
 
 
 # ------------------------------------------------------------------ native layer runtime vs per-kernel composition
-def check_native_layer(p_drop=0.0, seed=0):
+def check_native_layer(p_drop=0.0, seed=0, C=64, heads=4, T=37):
     """Same weights, same input: csrc/engine.hip (one call per layer) must reproduce the Python composition
     of the individual kernels (outputs and every gradient), with and without dropout (same seeds -> same masks
     is NOT guaranteed across the two paths, so dropout runs only check finiteness + determinism)."""
@@ -288,11 +288,14 @@ def check_native_layer(p_drop=0.0, seed=0):
     from espresso_amd.modules.conformer_layer import ConformerWithRelativePositionalEmbeddingEncoderLayer as Layer
 
     torch.manual_seed(seed)
-    model = build_tiny_model("conformer").to(DEV)
+    model = build_tiny_model("conformer", embed_dim=C, heads=heads, ffn=2 * C).to(DEV)
     layer = model.encoder.layers[0]
-    B, T, C = 3, 37, 64
+    with torch.no_grad():  # the reference initialises the positional biases to zero: make them count
+        layer.self_attn.pos_bias_u.normal_(0, 0.1)
+        layer.self_attn.pos_bias_v.normal_(0, 0.1)
+    B = 3
     x0 = bf(torch.randn(B * T, C)).to(DEV)
-    key_len = torch.tensor([37, 30, 11], dtype=torch.int32, device=DEV)
+    key_len = torch.tensor([T, T - 7, max(1, T // 3)], dtype=torch.int32, device=DEV)
     model.train()
     outs, grads = [], []
     for native in (False, True):
@@ -314,6 +317,8 @@ def check_native_layer(p_drop=0.0, seed=0):
     res = {"out_abs": float((outs[0] - outs[1]).abs().max())}
     worst = ("", 0.0)
     for n in grads[0]:
+        if n.endswith("k_proj.bias"):
+            continue  # exactly zero in exact arithmetic (softmax is shift invariant): only rounding noise to compare
         a, b = grads[0][n], grads[1][n]
         e = float((a - b).abs().max() / (a.abs().max() + 1e-6))
         if e > worst[1]:
@@ -612,3 +617,59 @@ def check_flash_attention(B=3, H=4, T=150, S=None, relpos=True, causal=False, pa
         "out_ref_max": float(o_ref.abs().max()),
         "lse_abs": float((lse_got - lse_ref).abs().max()),
     }
+
+
+def check_flash_attention_bwd(B=3, H=4, T=150, S=None, relpos=True, causal=False, padded=True, drop_p=0.0, seed=0):
+    """Fused attention backward vs torch autograd through the fp32 restatement."""
+    from espresso_amd import kernels as K
+    dev = "cuda:0"
+    S = S or T
+    dh, C = 64, H * 64
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rnd = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    qu = (rnd(B * T, C) * 0.35).to(torch.bfloat16)
+    qv = (rnd(B * T, C) * 0.35).to(torch.bfloat16) if relpos else None
+    kv = rnd(B * S, 2 * C).to(torch.bfloat16)
+    k, v = kv[:, :C], kv[:, C:]
+    pp = rnd(2 * T - 1, C).to(torch.bfloat16) if relpos else None
+    dout = rnd(B * T, C).to(torch.bfloat16)
+    klen = None
+    if padded:
+        klen = torch.randint(max(1, S // 3), S + 1, (B,), device=dev, generator=g).int()
+        klen[0] = S
+    scaling = 0.125
+    out, lse = K.flash_attention_fwd(qu, qv, k, v, pp, klen, H, B, T, S, C, 2 * C, C, causal=causal, drop_p=drop_p, drop_seed=77)
+    dkv = torch.full((B * S, 2 * C), float("nan"), dtype=torch.bfloat16, device=dev)
+    t1, t2, dBD = K.flash_attention_bwd(qu, qv, k, v, pp, klen, out, dout, lse, dkv[:, :C], dkv[:, C:], H, B, T, S, C, 2 * C, 2 * C,
+                                        ldpp=C, causal=causal, scaling=scaling, drop_p=drop_p, drop_seed=77)
+    # reference
+    leaf = lambda x: x.float().clone().requires_grad_(True) if x is not None else None
+    qu_r, qv_r, k_r, v_r, pp_r = leaf(qu), leaf(qv), leaf(k.contiguous()), leaf(v.contiguous()), leaf(pp)
+    s, p, vf = _attn_reference(qu_r, qv_r, k_r, v_r, pp_r, klen, H, B, T, S, causal)
+    if drop_p > 0:
+        Sp = (S + 7) // 8 * 8
+        ac = torch.zeros(H * B * T, Sp, device=dev)
+        ac[:, :S] = s.detach().permute(1, 0, 2, 3).reshape(H * B * T, S)
+        kl = klen if klen is not None else torch.full((B,), S, dtype=torch.int32, device=dev)
+        P, Pd = K.relpos_softmax_fwd(ac, None, kl, None, H, B, T, S, Sp, 0, Sp, causal=False, drop_p=drop_p, drop_seed=77)
+        keep = ((Pd.float() != 0) | (P.float() == 0))[:, :S].view(H, B, T, S).permute(1, 0, 2, 3)
+        p = p * keep / (1.0 - drop_p)
+    o_ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * T, C)
+    (o_ref * dout.float()).sum().backward()
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max().clamp_min(1e-6))
+    res = {
+        "t1": rel(t1, qu_r.grad * scaling),
+        "dk": rel(dkv[:, :C], k_r.grad),
+        "dv": rel(dkv[:, C:], v_r.grad),
+        "finite": bool(torch.isfinite(dkv.float()).all()),
+    }
+    if relpos:
+        res["t2"] = rel(t2, qv_r.grad * scaling)
+        R = 2 * T - 1
+        d = dBD.float().view(H, B * T, -1)[:, :, :R]                       # [H][(b,i)][r]
+        qvh = qv.float().view(B * T, H, dh).permute(1, 0, 2)               # [H][(b,i)][d]
+        dpp = torch.bmm(d.transpose(1, 2), qvh).permute(1, 0, 2).reshape(R, C)
+        res["dpp"] = rel(dpp, pp_r.grad)
+        res["dBD_pad_zero"] = bool((dBD.float().view(H * B * T, -1)[:, R:] == 0).all())
+    return res
