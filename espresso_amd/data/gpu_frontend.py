@@ -52,6 +52,14 @@ class GpuFbankFrontend:
             np.random.set_state(state)
         return fmask, tmask
 
+    def _to_device_async(self, arr: np.ndarray) -> torch.Tensor:
+        src = torch.from_numpy(arr)
+        if torch.device(self.device).type != "cuda":
+            return src.to(self.device)
+        pinned = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        pinned.copy_(src)
+        return pinned.to(self.device, non_blocking=True)
+
     def __call__(self, wav: torch.Tensor, offsets: torch.Tensor, n_samples: Sequence[int], train=False, epoch=1,
                  indices: Optional[Sequence[int]] = None):
         """wav: device fp32 concatenated samples; offsets: device int64 [B+1]; n_samples: host lengths.
@@ -65,8 +73,9 @@ class GpuFbankFrontend:
                                                want_sum=use_sa)
         if use_sa:
             fmask, tmask = self.draw_specaug(frames, epoch, indices if indices is not None else list(range(B)))
-            fm = torch.from_numpy(fmask).to(self.device, non_blocking=True)
-            tm = torch.from_numpy(tmask).to(self.device, non_blocking=True)
+            # pinned staging: a pageable host-to-device copy drains the stream first, which would stall the GPU at every
+            # step start and stop the host from running ahead (the pinned caching allocator recycles the buffers safely)
+            fm, tm = self._to_device_async(fmask), self._to_device_async(tmask)
             mv = self.specaug.mask_value
             K.specaugment(feat, out_len, utt_sum, fm, tm, use_mean=mv is None, mask_value=0.0 if mv is None else float(mv))
         return feat, out_len, frames
