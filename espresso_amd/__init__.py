@@ -8,6 +8,7 @@ from . import registry  # noqa: F401
 from .criterions import ctc_loss as _ctc, label_smoothed_cross_entropy_v2 as _lsce, transducer_loss as _rnnt  # noqa: F401
 from .data import feature_transforms as _ft  # noqa: F401
 from .models.transformer import speech_transformer_base as _encdec, speech_transformer_encoder_model as _enc_model  # noqa: F401
+from .models.transformer import speech_transformer_transducer_base as _transducer  # noqa: F401
 from .optim import adam as _adam, noam_lr_scheduler as _noam  # noqa: F401
 from .tasks import speech_recognition as _task  # noqa: F401
 

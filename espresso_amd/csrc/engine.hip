@@ -492,14 +492,18 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   LayerSaved S = layer_saved(sv, sh);
   Arena& sc = *c.scratch;
   const uint64_t seed = sh.seed;
-  uint16_t* d4 = sc.get<uint16_t>((size_t)M * C);
-  uint16_t* d3 = sc.get<uint16_t>((size_t)M * C);
-  RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, d4, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
+  // one gradient buffer per stage (no ping-pong): with dropout off a block's side-stream weight-gradient GEMM reads its
+  // incoming gradient in place, so that buffer must stay untouched until the join at the end of the layer
+  uint16_t* dA = sc.get<uint16_t>((size_t)M * C);
+  uint16_t* dB = sc.get<uint16_t>((size_t)M * C);
+  uint16_t* dC = sc.get<uint16_t>((size_t)M * C);
+  uint16_t* dD = sc.get<uint16_t>((size_t)M * C);
+  RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
                        1.f, nullptr, ln_ws(c, M, C), c.s));
-  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, d4, d3, seed + 48, 0.5f, EA_ACT_SILU);
-  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, d3, d4, seed + 32);
-  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, d4, d3, key_len, pe, seed + 16);
-  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, d3, dx, seed + 0, 0.5f, EA_ACT_SILU);
+  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU);
+  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16);
+  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU);
   if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
 }

@@ -19,8 +19,12 @@
 
 namespace {
 
+__device__ __forceinline__ float ldz(const float* p, long i) { return p[i]; }
+__device__ __forceinline__ float ldz(const bf16_t* p, long i) { return bf2f(p[i]); }
+
 // denom-free storage: lpb[b][t][u] = log p(blank | t,u), lpy[b][t][u] = log p(y_{u+1} | t,u) (u < U_b), lse[b][t][u]
-__global__ __launch_bounds__(256) void rnnt_lse_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
+template <typename TIn>
+__global__ __launch_bounds__(256) void rnnt_lse_kernel(const TIn* __restrict__ logits, const int* __restrict__ targets,
                                                        const int* __restrict__ T_len, const int* __restrict__ U_len,
                                                        float* __restrict__ lse, float* __restrict__ lpb, float* __restrict__ lpy,
                                                        int T, int U1, int V, int Umax, int blank, long nnodes) {
@@ -31,18 +35,18 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(const float* __restrict__
   const int t = (int)((node / U1) % T);
   const int b = (int)(node / ((long)U1 * T));
   if (t >= T_len[b] || u > U_len[b]) return;
-  const float* z = logits + node * V;
+  const TIn* z = logits + node * V;
   float mx = -INFINITY;
-  for (int v = lane; v < V; v += 64) mx = fmaxf(mx, z[v]);
+  for (int v = lane; v < V; v += 64) mx = fmaxf(mx, ldz(z, v));
   mx = wave_max(mx);
   float s = 0.f;
-  for (int v = lane; v < V; v += 64) s += expf(z[v] - mx);
+  for (int v = lane; v < V; v += 64) s += expf(ldz(z, v) - mx);
   s = wave_sum(s);
   const float l = mx + logf(s);
   if (lane == 0) {
     lse[node] = l;
-    lpb[node] = z[blank] - l;
-    lpy[node] = (u < U_len[b]) ? z[targets[(long)b * Umax + u]] - l : -INFINITY;
+    lpb[node] = ldz(z, blank) - l;
+    lpy[node] = (u < U_len[b]) ? ldz(z, targets[(long)b * Umax + u]) - l : -INFINITY;
   }
 }
 
@@ -101,8 +105,8 @@ __global__ void rnnt_scan_kernel(const float* __restrict__ lpb, const float* __r
   if (dir == 1 && u == 0) loss[b] = -beta[base];  // beta(0,0) = log P(y|x)
 }
 
-template <typename TOut>
-__global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(const TIn* __restrict__ logits, const int* __restrict__ targets,
                                                         const int* __restrict__ T_len, const int* __restrict__ U_len,
                                                         const float* __restrict__ lse, const float* __restrict__ lpb,
                                                         const float* __restrict__ lpy, const float* __restrict__ alpha,
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
     return;
   }
   if (scale_dev) scale *= scale_dev[0];
-  const float* z = logits + node * V;
+  const TIn* z = logits + node * V;
   const float a = alpha[node];
   const float occ = a + beta[node] + L;  // log occupancy of (t,u)
   const float l = lse[node];
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
     cy = expf(a + lpy[node] + beta[node + 1] + L);
   }
   for (int v = lane; v < V; v += 64) {
-    float gv = expf(z[v] - l + occ);
+    float gv = expf(ldz(z, v) - l + occ);
     if (v == blank) gv -= cb;
     if (v == y) gv -= cy;
     gv *= scale;
@@ -144,13 +148,87 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
   }
 }
 
+// ---- joint network element-wise stages (speech_transformer_transducer_base.py:276-299) --------------------------
+// Z[b][t][u][:] = relu(E[b][t][:] + D[b][u][:])   (bf16, J % 8 == 0); one 16-byte chunk per thread
+__global__ __launch_bounds__(256) void joint_add_relu_kernel(const bf16_t* __restrict__ E, const bf16_t* __restrict__ D,
+                                                             bf16_t* __restrict__ Z, int T, int U1, int J, long nchunks) {
+  const int nch = J >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    const long node = i / nch;
+    const int u = (int)(node % U1);
+    const long bt = node / U1;
+    const long b = bt / T;
+    const uint4 ue = *reinterpret_cast<const uint4*>(E + bt * J + ch * 8);
+    const uint4 ud = *reinterpret_cast<const uint4*>(D + (b * U1 + u) * J + ch * 8);
+    const uint32_t we[4] = {ue.x, ue.y, ue.z, ue.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+    uint32_t wo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = fmaxf(__uint_as_float(we[e] << 16) + __uint_as_float(wd[e] << 16), 0.f);
+      const float hi = fmaxf(__uint_as_float(we[e] & 0xffff0000u) + __uint_as_float(wd[e] & 0xffff0000u), 0.f);
+      wo[e] = pack_bf2(lo, hi);
+    }
+    *reinterpret_cast<uint4*>(Z + node * J + ch * 8) = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+  }
+}
+// dE[b][t][:] = sum_u dZ[b][t][u][:]  (mode 0, rows = B*T, inner = U1 consecutive rows)
+// dD[b][u][:] = sum_t dZ[b][t][u][:]  (mode 1, rows = B*U1, inner = T rows U1*J apart)
+__global__ __launch_bounds__(256) void joint_reduce_kernel(const bf16_t* __restrict__ dZ, bf16_t* __restrict__ out, int T, int U1, int J,
+                                                           int mode, long nrows) {
+  const int nch = J >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nrows * nch; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    const long row = i / nch;
+    const bf16_t* src;
+    long step;
+    int cnt;
+    if (mode == 0) { src = dZ + row * U1 * (long)J + ch * 8; step = J; cnt = U1; }
+    else { const long b = row / U1; const int u = (int)(row % U1); src = dZ + ((b * T) * U1 + u) * (long)J + ch * 8; step = (long)U1 * J; cnt = T; }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < cnt; ++k) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + k * step);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += __uint_as_float(w[e] << 16);
+        acc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+      }
+    }
+    *reinterpret_cast<uint4*>(out + row * J + ch * 8) =
+        make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
+  }
+}
+
 }  // namespace
+
+extern "C" int ea_joint_add_relu(const void* E, const void* D, void* Z, int B, int T, int U1, int J, hipStream_t stream) {
+  const long nchunks = (long)B * T * U1 * (J / 8);
+  if (nchunks <= 0) return 0;
+  if (J % 8) return -2;
+  long blocks = (nchunks + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(joint_add_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)E, (const bf16_t*)D, (bf16_t*)Z, T,
+                     U1, J, nchunks);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_joint_reduce(const void* dZ, void* dE, void* dD, int B, int T, int U1, int J, hipStream_t stream) {
+  if ((long)B * T * U1 <= 0) return 0;
+  if (J % 8) return -2;
+  const long rE = (long)B * T, rD = (long)B * U1;
+  long bE = (rE * (J / 8) + 255) / 256, bD = (rD * (J / 8) + 255) / 256;
+  if (bE > 16384) bE = 16384;
+  if (bD > 16384) bD = 16384;
+  if (dE) hipLaunchKernelGGL(joint_reduce_kernel, dim3((unsigned)bE), dim3(256), 0, stream, (const bf16_t*)dZ, (bf16_t*)dE, T, U1, J, 0, rE);
+  if (dD) hipLaunchKernelGGL(joint_reduce_kernel, dim3((unsigned)bD), dim3(256), 0, stream, (const bf16_t*)dZ, (bf16_t*)dD, T, U1, J, 1, rD);
+  return EA_CHECK_LAUNCH();
+}
 
 extern "C" long ea_rnnt_workspace_bytes(int B, int T, int U1) { return 5L * B * T * U1 * (long)sizeof(float); }
 
-extern "C" int ea_rnnt_loss(const float* logits, const int* targets, const int* logit_lengths, const int* target_lengths,
-                            float* loss /*[B]*/, void* workspace, int B, int T, int U1, int V, int Umax, int blank,
-                            hipStream_t stream) {
+extern "C" int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths,
+                            const int* target_lengths, float* loss /*[B]*/, void* workspace, int B, int T, int U1, int V, int Umax,
+                            int blank, hipStream_t stream) {
   if (B <= 0) return 0;
   if (T <= 0 || U1 <= 0 || U1 > 512) return -2;
   const long n = (long)B * T * U1;
@@ -159,17 +237,22 @@ extern "C" int ea_rnnt_loss(const float* logits, const int* targets, const int* 
   float* lpy = lpb + n;
   float* alpha = lpy + n;
   float* beta = alpha + n;
-  hipLaunchKernelGGL(rnnt_lse_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, logits, targets, logit_lengths,
-                     target_lengths, lse, lpb, lpy, T, U1, V, Umax, blank, n);
+  if (logits_bf16)
+    hipLaunchKernelGGL(rnnt_lse_kernel<bf16_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)logits, targets,
+                       logit_lengths, target_lengths, lse, lpb, lpy, T, U1, V, Umax, blank, n);
+  else
+    hipLaunchKernelGGL(rnnt_lse_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const float*)logits, targets,
+                       logit_lengths, target_lengths, lse, lpb, lpy, T, U1, V, Umax, blank, n);
   const int UP = (U1 + 63) / 64 * 64;
   hipLaunchKernelGGL(rnnt_scan_kernel, dim3(B), dim3(2 * UP), (size_t)4 * (UP + 2) * sizeof(float), stream, lpb, lpy,
                      logit_lengths, target_lengths, alpha, beta, loss, T, U1, UP);
   return EA_CHECK_LAUNCH();
 }
 
-extern "C" int ea_rnnt_grad(const float* logits, const int* targets, const int* logit_lengths, const int* target_lengths,
-                            const float* loss, const void* workspace, void* grad, int grad_bf16, int B, int T, int U1, int V,
-                            int Umax, int blank, float grad_scale, const float* grad_scale_dev, hipStream_t stream) {
+extern "C" int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths,
+                            const int* target_lengths, const float* loss, const void* workspace, void* grad, int grad_bf16, int B,
+                            int T, int U1, int V, int Umax, int blank, float grad_scale, const float* grad_scale_dev,
+                            hipStream_t stream) {
   if (B <= 0) return 0;
   const long n = (long)B * T * U1;
   const float* lse = (const float*)workspace;
@@ -177,13 +260,12 @@ extern "C" int ea_rnnt_grad(const float* logits, const int* targets, const int* 
   const float* lpy = lpb + n;
   const float* alpha = lpy + n;
   const float* beta = alpha + n;
-  if (grad_bf16)
-    hipLaunchKernelGGL((rnnt_grad_kernel<bf16_t>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, logits, targets,
-                       logit_lengths, target_lengths, lse, lpb, lpy, alpha, beta, loss, (bf16_t*)grad, T, U1, V, Umax, blank,
-                       grad_scale, grad_scale_dev, n);
-  else
-    hipLaunchKernelGGL((rnnt_grad_kernel<float>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, logits, targets,
-                       logit_lengths, target_lengths, lse, lpb, lpy, alpha, beta, loss, (float*)grad, T, U1, V, Umax, blank,
-                       grad_scale, grad_scale_dev, n);
+#define EA_RNNT_GRAD(TI, TO)                                                                                              \
+  hipLaunchKernelGGL((rnnt_grad_kernel<TI, TO>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const TI*)logits, targets, \
+                     logit_lengths, target_lengths, lse, lpb, lpy, alpha, beta, loss, (TO*)grad, T, U1, V, Umax, blank,     \
+                     grad_scale, grad_scale_dev, n)
+  if (logits_bf16) { if (grad_bf16) EA_RNNT_GRAD(bf16_t, bf16_t); else EA_RNNT_GRAD(bf16_t, float); }
+  else { if (grad_bf16) EA_RNNT_GRAD(float, bf16_t); else EA_RNNT_GRAD(float, float); }
+#undef EA_RNNT_GRAD
   return EA_CHECK_LAUNCH();
 }

@@ -866,7 +866,7 @@ class _RNNTLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, targets, logit_lengths, target_lengths, blank):
-        logits = logits.float().contiguous()
+        logits = logits.contiguous() if logits.dtype == torch.bfloat16 else logits.float().contiguous()
         loss, ws = K.rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank)
         ctx.save_for_backward(logits, targets, logit_lengths, target_lengths, loss, ws)
         ctx.blank = blank
@@ -877,9 +877,141 @@ class _RNNTLoss(torch.autograd.Function):
         logits, targets, logit_lengths, target_lengths, loss, ws = ctx.saved_tensors
         # the criterion sums the per-utterance losses: dloss is a broadcast scalar, applied on the device
         g = K.rnnt_loss_grad(logits, targets, logit_lengths, target_lengths, loss, ws, ctx.blank,
-                             grad_scale_dev=dloss.float().contiguous())
+                             grad_scale_dev=dloss.float().contiguous(), grad_bf16=logits.dtype == torch.bfloat16)
         return g, None, None, None, None
 
 
 def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=0):
     return _RNNTLoss.apply(logits, targets, logit_lengths, target_lengths, blank)
+
+
+# ------------------------------------------------------------------------------------------------ LSTM
+class _LSTMLayer(torch.autograd.Function):
+    """One LSTM layer over a whole (teacher-forced) sequence — the time loop of
+    espresso/models/speech_lstm.py:846-893 for one `LSTMCell` (fairseq/models/lstm.py:LSTMCell = torch.nn.LSTMCell).
+
+    x: bf16 [U*B][I] time-major rows (t*B + b).  Returns hs bf16 [U*B][H] (and the final (h, c) fp32).
+    The input projection of ALL steps is one GEMM; each step then costs one small recurrent GEMM (fp32 output with the
+    input projection as fp32 residual) + one element-wise cell kernel.  Backward walks the steps in reverse with one
+    recurrent dgrad GEMM per step and computes every weight gradient with a single GEMM over all steps."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih16, w_hh16, h0, c0, B, U):
+        H = w_hh.shape[1]
+        I = w_ih.shape[1]
+        dev = x.device
+        x = x.contiguous()
+        bias = (b_ih + b_hh).detach().float().contiguous() if b_ih is not None else None
+        gx = torch.empty(U * B, 4 * H, dtype=torch.float32, device=dev)
+        K.gemm(x, w_ih16, gx, U * B, 4 * H, I, lda=I, ldb=I, ldc=4 * H, bias=bias)
+        hs = torch.empty(U * B, H, dtype=torch.bfloat16, device=dev)
+        cs = torch.empty(U, B, H, dtype=torch.float32, device=dev)
+        act = torch.empty(U, B, 4 * H, dtype=torch.float32, device=dev)
+        G = torch.empty(B, 4 * H, dtype=torch.float32, device=dev)
+        h_last = torch.empty(B, H, dtype=torch.float32, device=dev)
+        h0_16 = K.cast_f32_to_bf16(h0.float().contiguous()) if h0 is not None else None
+        c0 = c0.float().contiguous() if c0 is not None else None
+        for t in range(U):
+            if t == 0 and h0_16 is None:
+                Gt = gx[0:B]
+            else:
+                hp = h0_16 if t == 0 else hs[(t - 1) * B: t * B]
+                K.gemm(hp, w_hh16, G, B, 4 * H, H, lda=H, ldb=H, ldc=4 * H, resid=gx, ldr=4 * H, r_off=t * B * 4 * H)
+                Gt = G
+            K.lstm_cell_fwd(Gt, c0 if t == 0 else cs[t - 1], cs[t], h_last if t == U - 1 else None, hs[t * B:(t + 1) * B], H, act[t], B, H)
+        ctx.save_for_backward(x, hs, cs, act, w_ih16, w_hh16, h0_16, c0)
+        ctx.dims = (B, U, H, I, b_ih is not None, h0 is not None)
+        return hs, h_last, cs[U - 1]
+
+    @staticmethod
+    def backward(ctx, dhs, dh_last, dc_last):
+        x, hs, cs, act, w_ih16, w_hh16, h0_16, c0 = ctx.saved_tensors
+        B, U, H, I, has_bias, has_h0 = ctx.dims
+        dev = x.device
+        dhs = dhs.contiguous() if dhs is not None else None
+        dG = torch.empty(U * B, 4 * H, dtype=torch.bfloat16, device=dev)
+        dh_rec = dh_last.float().contiguous().clone() if dh_last is not None else None
+        dc = dc_last.float().contiguous().clone() if dc_last is not None else None
+        for t in range(U - 1, -1, -1):
+            dc_new = torch.empty(B, H, dtype=torch.float32, device=dev)
+            K.lstm_cell_bwd(dhs[t * B:(t + 1) * B] if dhs is not None else None, H, dh_rec, dc, act[t],
+                            c0 if t == 0 else cs[t - 1], cs[t], dG[t * B:(t + 1) * B], 4 * H, dc_new, B, H)
+            dc = dc_new
+            if t > 0 or has_h0:
+                # dh_{t-1} (recurrent part) = dG_t W_hh
+                dh_rec = torch.empty(B, H, dtype=torch.float32, device=dev)
+                K.gemm(dG, w_hh16, dh_rec, B, H, 4 * H, lda=4 * H, ldb=H, ldc=H, b_kstrided=True, a_off=t * B * 4 * H)
+        dx = torch.empty(U * B, I, dtype=torch.bfloat16, device=dev)
+        K.gemm(dG, w_ih16, dx, U * B, I, 4 * H, lda=4 * H, ldb=I, ldc=I, b_kstrided=True)
+        dw_ih = _wgrad(dG, x, U * B, 4 * H, I)
+        # dW_hh = sum_t dG_t^T h_{t-1}: steps 1..U-1 pair with hs[0..U-2]; step 0 pairs with h0 (zero when absent)
+        dw_hh = torch.zeros(4 * H, H, dtype=torch.float32, device=dev)
+        if U > 1:
+            K.gemm(dG, hs, dw_hh, 4 * H, H, (U - 1) * B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, a_off=B * 4 * H)
+        if has_h0:
+            K.gemm(dG, h0_16, dw_hh, 4 * H, H, B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, accumulate=True)
+        db = K.colsum(dG, torch.zeros(4 * H, dtype=torch.float32, device=dev), U * B, 4 * H, 4 * H) if has_bias else None
+        return (dx, dw_ih, dw_hh, db, db.clone() if db is not None else None, None, None,
+                dh_rec if has_h0 else None, dc if c0 is not None else None, None, None)
+
+
+def lstm_layer(x, cell, B, U, h0=None, c0=None):
+    """x bf16 [U*B][I] time-major; cell: LSTMCellParams.  Returns (hs bf16 [U*B][H], h_last fp32, c_last fp32)."""
+    return _LSTMLayer.apply(x, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, bf16_weight(cell.weight_ih),
+                            bf16_weight(cell.weight_hh), h0, c0, B, U)
+
+
+def lstm_cell_step(x16, cell, h_prev16, h_prev32, c_prev, keep_row=None):
+    """One inference step (no autograd): x16 bf16 [N][I]; state fp32 [N][H] (+ bf16 copy of h).  Returns (h16, h32, c)."""
+    N, I = x16.shape
+    H = cell.weight_hh.shape[1]
+    dev = x16.device
+    bias = getattr(cell, "_ea_bias_sum", None)
+    if bias is None or bias.device != dev:
+        bias = (cell.bias_ih + cell.bias_hh).detach().float().contiguous()
+        cell._ea_bias_sum = bias
+    G = torch.empty(N, 4 * H, dtype=torch.float32, device=dev)
+    K.gemm(x16.contiguous(), bf16_weight(cell.weight_ih), G, N, 4 * H, I, lda=I, ldb=I, ldc=4 * H, bias=bias)
+    if h_prev16 is not None:
+        K.gemm(h_prev16, bf16_weight(cell.weight_hh), G, N, 4 * H, H, lda=H, ldb=H, ldc=4 * H, resid=G, ldr=4 * H)
+    h16 = torch.empty(N, H, dtype=torch.bfloat16, device=dev)
+    h32 = torch.empty(N, H, dtype=torch.float32, device=dev)
+    c = torch.empty(N, H, dtype=torch.float32, device=dev)
+    K.lstm_cell_fwd(G, c_prev, c, h32, h16, H, None, N, H, keep_row=keep_row, h_prev_f32=h_prev32)
+    return h16, h32, c
+
+
+# ------------------------------------------------------------------------------------------------ transducer joint
+class _TransducerJoint(torch.autograd.Function):
+    """logits[b,t,u,:] = fc_out(relu(E[b,t] + D[b,u]))  — espresso/models/transformer/speech_transformer_transducer_base.py:276-299
+    after the two LayerNorm'd projections.  E bf16 [B*T][J], D bf16 [B*U1][J], w fp32 [V][J] (the effective, weight-normed
+    matrix), returns bf16 [B][T][U1][V] (what the reference's fc_out yields under bf16 autocast)."""
+
+    @staticmethod
+    def forward(ctx, E, D, w, b, w16, B, T, U1):
+        V, J = w.shape
+        Z = K.joint_add_relu(E.contiguous(), D.contiguous(), B, T, U1)
+        n = B * T * U1
+        logits = torch.empty(n, V, dtype=torch.bfloat16, device=E.device)
+        K.gemm(Z, w16, logits, n, V, J, lda=J, ldb=J, ldc=V, bias=b)
+        ctx.save_for_backward(Z, w16)
+        ctx.dims = (B, T, U1, V, J, b is not None)
+        return logits.view(B, T, U1, V)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        Z, w16 = ctx.saved_tensors
+        B, T, U1, V, J, has_bias = ctx.dims
+        n = B * T * U1
+        dl = dlogits.contiguous().view(n, V)
+        dZ = torch.empty(n, J, dtype=torch.bfloat16, device=dl.device)
+        # relu'(pre) == (Z > 0): the post-activation tensor doubles as the derivative mask
+        K.gemm(dl, w16, dZ, n, J, V, lda=V, ldb=J, ldc=J, b_kstrided=True, aux=Z, ldaux=J, act="relu")
+        dE, dD = K.joint_reduce(dZ, B, T, U1)
+        dw = _wgrad(dl, Z, n, V, J)
+        db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, V) if has_bias else None
+        return dE, dD, dw, db, None, None, None, None
+
+
+def transducer_joint(E, D, w, b, B, T, U1):
+    return _TransducerJoint.apply(E, D, w, b, K.cast_f32_to_bf16(w.detach().contiguous()), B, T, U1)

@@ -526,14 +526,14 @@ def beam_topk(lprobs, prev_scores, bsz, beam, nbeam_used, k):
 
 
 def rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank):
-    """logits fp32 [B][T][U1][V]; returns (loss [B], workspace)."""
+    """logits fp32 or bf16 [B][T][U1][V]; returns (loss [B], workspace)."""
     B, T, U1, V = logits.shape
-    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    assert logits.dtype in (torch.float32, torch.bfloat16) and logits.is_contiguous()
     Umax = targets.shape[1]
     assert U1 == Umax + 1
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     ws = torch.empty(int(_lib.lib().ea_rnnt_workspace_bytes(B, T, U1)), dtype=torch.uint8, device=logits.device)
-    check(_lib.lib().ea_rnnt_loss(_p(logits), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), B, T, U1, V,
+    check(_lib.lib().ea_rnnt_loss(_p(logits), int(logits.dtype == torch.bfloat16), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), B, T, U1, V,
                                   Umax, blank, _stream()), "ea_rnnt_loss")
     return loss, ws
 
@@ -541,7 +541,45 @@ def rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank):
 def rnnt_loss_grad(logits, targets, logit_lengths, target_lengths, loss, ws, blank, grad_scale_dev=None, grad_bf16=False):
     B, T, U1, V = logits.shape
     grad = torch.empty(logits.shape, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=logits.device)
-    check(_lib.lib().ea_rnnt_grad(_p(logits), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), _p(grad),
+    check(_lib.lib().ea_rnnt_grad(_p(logits), int(logits.dtype == torch.bfloat16), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), _p(grad),
                                   int(grad_bf16), B, T, U1, V, targets.shape[1], blank, 1.0, _p(grad_scale_dev), _stream()),
           "ea_rnnt_grad")
     return grad
+
+
+# ------------------------------------------------------------------------------------------------ LSTM
+def lstm_cell_fwd(gates_pre, c_prev, c_out, h_f32, h_bf16, ldh, gates_act, B, H, keep_row=None, h_prev_f32=None, ldg=None):
+    check(_lib.lib().ea_lstm_cell_fwd(_p(gates_pre), ldg if ldg is not None else 4 * H, _p(c_prev), _p(c_out), _p(h_f32), _p(h_bf16),
+                                      ldh, _p(gates_act), _p(keep_row), _p(h_prev_f32), B, H, _stream()), "ea_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dh_bf16, ld_dh, dh_f32, dc_in, gates_act, c_prev, c, dgates, lddg, dc_prev, B, H):
+    check(_lib.lib().ea_lstm_cell_bwd(_p(dh_bf16), ld_dh, _p(dh_f32), _p(dc_in), _p(gates_act), _p(c_prev), _p(c), _p(dgates), lddg,
+                                      _p(dc_prev), B, H, _stream()), "ea_lstm_cell_bwd")
+
+
+def gather_rows(src, parent, out=None):
+    """out[n] = src[parent[n]] for a contiguous [N][...] fp32 / bf16 tensor; parent int32 on device."""
+    assert src.is_contiguous() and src.element_size() in (2, 4)
+    N = parent.numel()
+    W = src.numel() // src.shape[0]
+    if out is None:
+        out = torch.empty((N,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    check(_lib.lib().ea_gather_rows(_p(src), _p(out), _p(parent), N, W, src.element_size(), _stream()), "ea_gather_rows")
+    return out
+
+
+def joint_add_relu(E, D, B, T, U1):
+    """Z [B*T*U1][J] bf16 = relu(E[b,t] + D[b,u])."""
+    J = E.shape[1]
+    Z = torch.empty(B * T * U1, J, dtype=torch.bfloat16, device=E.device)
+    check(_lib.lib().ea_joint_add_relu(_p(E), _p(D), _p(Z), B, T, U1, J, _stream()), "ea_joint_add_relu")
+    return Z
+
+
+def joint_reduce(dZ, B, T, U1):
+    J = dZ.shape[1]
+    dE = torch.empty(B * T, J, dtype=torch.bfloat16, device=dZ.device)
+    dD = torch.empty(B * U1, J, dtype=torch.bfloat16, device=dZ.device)
+    check(_lib.lib().ea_joint_reduce(_p(dZ), _p(dE), _p(dD), B, T, U1, J, _stream()), "ea_joint_reduce")
+    return dE, dD

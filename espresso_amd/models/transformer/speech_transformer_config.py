@@ -80,3 +80,41 @@ class SpeechTransformerConfig:
         dec = SpeechDecoderConfig(**{k: v for k, v in dict(d.pop("decoder", {}) or {}).items()})
         known = {f for f in cls.__dataclass_fields__}
         return cls(encoder=enc, decoder=dec, **{k: v for k, v in d.items() if k in known})
+
+
+@dataclass
+class SpeechLSTMPredictorConfig:
+    """espresso/models/transformer/speech_transformer_transducer_config.py:30-54 (the `decoder:` block of the transducer)."""
+    embed_dim: int = 48
+    hidden_size: int = 320
+    layers: int = 3
+    residual: bool = False
+    dropout_in: Optional[float] = None
+    dropout_out: Optional[float] = None
+
+
+@dataclass
+class SpeechTransformerTransducerConfig:
+    """espresso/models/transformer/speech_transformer_transducer_config.py:56-133."""
+    activation_fn: str = "relu"
+    dropout: float = 0.1
+    attention_dropout: float = 0.0
+    activation_dropout: float = 0.0
+    encoder: SpeechEncoderConfig = field(default_factory=SpeechEncoderConfig)
+    decoder: SpeechLSTMPredictorConfig = field(default_factory=SpeechLSTMPredictorConfig)
+    joint_dim: int = 512
+    share_decoder_input_output_embed: bool = False
+    no_token_positional_embeddings: bool = False
+    layernorm_embedding: bool = True
+    no_scale_embedding: bool = False
+    max_source_positions: int = DEFAULT_MAX_SOURCE_POSITIONS
+    max_target_positions: int = DEFAULT_MAX_TARGET_POSITIONS
+
+    @classmethod
+    def from_dict(cls, d):
+        d = dict(d or {})
+        d.pop("_name", None)
+        enc = SpeechEncoderConfig(**dict(d.pop("encoder", {}) or {}))
+        dec = SpeechLSTMPredictorConfig(**dict(d.pop("decoder", {}) or {}))
+        known = {f for f in cls.__dataclass_fields__}
+        return cls(encoder=enc, decoder=dec, **{k: v for k, v in d.items() if k in known})

@@ -1,0 +1,126 @@
+"""`speech_transformer_transducer_base` — espresso/models/transformer/speech_transformer_transducer_base.py:43-330:
+Conformer/Transformer encoder (no output projection) + LSTM predictor (`SpeechLSTMDecoder`, attention-free) + joint
+network  logits[b,t,u] = fc_out(relu(LN(proj_encoder(h_t)) + LN(proj_decoder(g_u))))  with a weight-normalised `fc_out`
+(unless the embeddings are shared).  State-dict names follow the reference (`proj_encoder`, `laynorm_proj_encoder`,
+`proj_decoder`, `laynorm_proj_decoder`, `fc_out.weight_g|weight_v|bias`).
+
+Compute: encoder and predictor run on the HIP kernels (native Conformer runtime, LSTM layer op); the joint is
+functional._TransducerJoint — broadcast add + ReLU kernel, then one MFMA GEMM over all B*T'*(U+1) lattice nodes into bf16
+logits, which csrc/rnnt.hip consumes directly (bf16 in, bf16 gradient out)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import functional as F
+from ...modules.params import LayerNormParams
+from ...modules.speech_convolutions import ConvBNReLU
+from ...registry import register_model
+from ...tools import utils as speech_utils
+from ..speech_lstm import SpeechLSTMDecoder, lstm_linear
+from .speech_transformer_base import EmbeddingParams
+from .speech_transformer_encoder_model import SpeechTransformerEncoderBase
+
+
+class WeightNormLinearParams(nn.Module):
+    """nn.utils.weight_norm(nn.Linear(in, out), name="weight"): weight = weight_v * (weight_g / ||weight_v||_row)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        v = torch.empty(out_features, in_features)
+        nn.init.kaiming_uniform_(v, a=math.sqrt(5))
+        self.weight_g = nn.Parameter(v.norm(dim=1, keepdim=True))
+        self.weight_v = nn.Parameter(v)
+        bound = 1 / math.sqrt(in_features)
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+
+    def effective_weight(self):
+        return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
+
+
+@register_model("speech_transformer_transducer_base")
+class SpeechTransformerTransducerModelBase(nn.Module):
+    def __init__(self, cfg, encoder, decoder):
+        super().__init__()
+        self.cfg, self.encoder, self.decoder = cfg, encoder, decoder
+        J = cfg.joint_dim
+        self.proj_encoder = lstm_linear(cfg.encoder.embed_dim, J)
+        self.laynorm_proj_encoder = LayerNormParams(J)
+        self.proj_decoder = lstm_linear(cfg.decoder.hidden_size, J)
+        self.laynorm_proj_decoder = LayerNormParams(J)
+        V = self.decoder.embed_tokens.weight.shape[0]
+        self.share_embed = bool(cfg.share_decoder_input_output_embed)
+        if self.share_embed:
+            assert J == cfg.decoder.embed_dim, "joint_dim and decoder.embed_dim must be the same if the two embeddings are to be shared"
+            self.fc_out_bias = nn.Parameter(torch.empty(V).uniform_(-1 / math.sqrt(J), 1 / math.sqrt(J)))
+        else:
+            self.fc_out = WeightNormLinearParams(J, V)
+        self.num_updates = 0
+
+    @classmethod
+    def build_model(cls, cfg, task):
+        ev = speech_utils.eval_str_nested_list_or_tuple
+        tgt_dict = task.target_dictionary
+        embed = EmbeddingParams(len(tgt_dict), cfg.decoder.embed_dim, tgt_dict.pad())
+        out_channels = ev(cfg.encoder.conv_channels, type=int)
+        conv = ConvBNReLU(out_channels, ev(cfg.encoder.conv_kernel_sizes, type=int), ev(cfg.encoder.conv_strides, type=int),
+                          in_channels=task.feat_in_channels)
+        in_size = conv.output_feat_dim(task.feat_dim // task.feat_in_channels)
+        encoder = SpeechTransformerEncoderBase(cfg, pre_encoder=conv, input_size=in_size)
+        d = cfg.decoder
+        decoder = SpeechLSTMDecoder(tgt_dict, embed_dim=d.embed_dim, hidden_size=d.hidden_size, out_embed_dim=d.hidden_size,
+                                    num_layers=d.layers, dropout_in=d.dropout_in if d.dropout_in is not None else cfg.dropout,
+                                    dropout_out=d.dropout_out if d.dropout_out is not None else cfg.dropout, residual=d.residual,
+                                    pretrained_embed=embed, share_input_output_embed=True)
+        return cls(cfg, encoder, decoder)
+
+    def set_num_updates(self, n):
+        self.num_updates = n
+        self.encoder.set_num_updates(n)
+
+    def fc_out_params(self):
+        if self.share_embed:
+            return self.decoder.embed_tokens.weight, self.fc_out_bias
+        return self.fc_out.effective_weight(), self.fc_out.bias
+
+    def joint(self, enc_bt, dec_bu, B, T, U1, apply_output_layer=True):
+        """enc_bt bf16 [B*T][C], dec_bu bf16 [B*U1][H] -> bf16 logits [B][T][U1][V] (:276-299)."""
+        E = F.layer_norm(F.linear(enc_bt, self.proj_encoder.weight, self.proj_encoder.bias), self.laynorm_proj_encoder.weight,
+                         self.laynorm_proj_encoder.bias)
+        D = F.layer_norm(F.linear(dec_bu, self.proj_decoder.weight, self.proj_decoder.bias), self.laynorm_proj_decoder.weight,
+                         self.laynorm_proj_decoder.bias)
+        if not apply_output_layer:
+            raise NotImplementedError("joint features without the output layer are never materialised (B*T*U*J)")
+        w, b = self.fc_out_params()
+        return F.transducer_joint(E, D, w, b, B, T, U1)
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
+        """-> (logits bf16 [B][T'][U+1][V], encoder_out_lengths [B])  (:221-243)"""
+        enc = self.encoder(src_tokens, src_lengths)
+        x = enc["_x_bt"][0]
+        B, U1 = prev_output_tokens.shape
+        T = x.shape[0] // B
+        dec, _ = self.decoder.extract_features(prev_output_tokens)
+        logits = self.joint(x, dec.reshape(B * U1, -1), B, T, U1)
+        return logits, enc["src_lengths"][0]
+
+    def forward_encoder(self, src_tokens, src_lengths):
+        return self.encoder(src_tokens, src_lengths)
+
+    def max_positions(self):
+        return (self.encoder.max_positions(), self.decoder.max_positions())
+
+    def max_decoder_positions(self):
+        return self.decoder.max_positions()
+
+    def get_targets(self, sample, net_output):
+        return sample["target"]
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        for k in list(state_dict.keys()):
+            if "conv_layers_before" in k:
+                state_dict[k.replace("conv_layers_before", "pre_encoder")] = state_dict.pop(k)
+        for k in list(state_dict.keys()):
+            if k.endswith("positional_embedding._float_tensor") or k.endswith("embed_positions._float_tensor"):
+                state_dict.pop(k)
+        return state_dict

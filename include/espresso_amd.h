@@ -294,6 +294,24 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
 int ea_set_flash_attention(int on);
 
 /* ------------------------------------------------------------------------------------------
+ * LSTM cell element-wise stages (csrc/lstm.hip) — torch.nn.LSTMCell as driven by espresso/models/speech_lstm.py:846-893
+ * (transducer predictor, LSTM LM, attention decoder).  The packed pre-activations gates_pre = x W_ih^T + b_ih + h W_hh^T
+ * + b_hh ([B][ldg] fp32, gate order i,f,g,o) come from ea_gemm_bf16 (fp32 output, fp32 residual).
+ *   fwd: c_out/h fp32 [B][H]; h_out_bf16 [B][ldh] (GEMM operand of the next step / layer); gates_act fp32 [B][4H] saved for
+ *        bwd (NULL at inference); keep_row uint8 [B] (NULL = none): rows whose state is frozen (h_prev_f32 required).
+ *   bwd: dh = dh_bf16 (from the layer above, [B][ld_dh], may be NULL) + dh_f32 (recurrent, may be NULL); dc_in may be NULL;
+ *        dgates bf16 [B][lddg]; dc_prev fp32 [B][H].
+ * ea_gather_rows: out[n] = in[parent[n]] over rows of W elements of 2 or 4 bytes (beam reorder of cached LSTM states,
+ * speech_lstm.py:981-999). */
+int ea_lstm_cell_fwd(const float* gates_pre, long ldg, const float* c_prev, float* c_out, float* h_out_f32, void* h_out_bf16,
+                     long ldh, float* gates_act, const uint8_t* keep_row, const float* h_prev_f32, int B, int H,
+                     ea_stream_t stream);
+int ea_lstm_cell_bwd(const void* dh_bf16, long ld_dh, const float* dh_f32, const float* dc_in, const float* gates_act,
+                     const float* c_prev, const float* c, void* dgates, long lddg, float* dc_prev, int B, int H,
+                     ea_stream_t stream);
+int ea_gather_rows(const void* in, void* out, const int* parent, int N, int W, int elem_bytes, ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Batched beam-search decoding (csrc/decode.hip) — fairseq/sequence_generator.py:355-609, fairseq/search.py:103-144,
  * fairseq/modules/multihead_attention.py:716-760,878-897,964-989.
  * ea_decode_attention: out[n] = softmax(q[n] . K[r]^T) V[r], r = kv_row ? kv_row[n] : n, over len ? len[r] : max_len keys;
@@ -312,15 +330,21 @@ int ea_beam_topk(const float* lprobs, const float* prev_scores, int bsz, int bea
 
 /* ------------------------------------------------------------------------------------------
  * RNN-T loss — torchaudio.functional.rnnt_loss as called at espresso/criterions/transducer_loss.py:130-140
- * (blank = "<s>", clamp = -1, fused log-softmax).  logits fp32 [B][T][U1][V] (U1 = Umax + 1), targets int32 [B][Umax],
- * loss fp32 [B] = -log p(y|x); grad = grad_scale * d(sum loss)/d(logits), fp32 or bf16, same shape as logits.
+ * (blank = "<s>", clamp = -1, fused log-softmax).  logits fp32 or bf16 (logits_bf16) [B][T][U1][V] (U1 = Umax + 1; bf16 is
+ * what the reference's fc_out produces under bf16 autocast), targets int32 [B][Umax], loss fp32 [B] = -log p(y|x);
+ * grad = grad_scale * d(sum loss)/d(logits), fp32 or bf16, same shape as logits.
  * workspace: ea_rnnt_workspace_bytes(B,T,U1) bytes, kept between the two calls. */
 long ea_rnnt_workspace_bytes(int B, int T, int U1);
-int ea_rnnt_loss(const float* logits, const int* targets, const int* logit_lengths, const int* target_lengths, float* loss,
-                 void* workspace, int B, int T, int U1, int V, int Umax, int blank, ea_stream_t stream);
-int ea_rnnt_grad(const float* logits, const int* targets, const int* logit_lengths, const int* target_lengths,
+int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths, const int* target_lengths,
+                 float* loss, void* workspace, int B, int T, int U1, int V, int Umax, int blank, ea_stream_t stream);
+int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths, const int* target_lengths,
                  const float* loss, const void* workspace, void* grad, int grad_bf16, int B, int T, int U1, int V, int Umax,
                  int blank, float grad_scale, const float* grad_scale_dev, ea_stream_t stream);
+/* Joint network element-wise stages (espresso/models/transformer/speech_transformer_transducer_base.py:276-299):
+ * Z[b][t][u] = relu(E[b][t] + D[b][u]) (bf16, E [B*T][J], D [B*U1][J], Z [B*T*U1][J], J % 8 == 0) and its backward
+ * reductions dE[b][t] = sum_u dZ[b][t][u], dD[b][u] = sum_t dZ[b][t][u] (either output may be NULL). */
+int ea_joint_add_relu(const void* E, const void* D, void* Z, int B, int T, int U1, int J, ea_stream_t stream);
+int ea_joint_reduce(const void* dZ, void* dE, void* dD, int B, int T, int U1, int J, ea_stream_t stream);
 
 #ifdef __cplusplus
 }

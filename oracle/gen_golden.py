@@ -218,6 +218,88 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
     print([k for k in sd if k.startswith("decoder")][:40])
 
 
+def transducer_fixture(name="ref_conformer_transducer_tiny"):
+    """speech_transformer_transducer_base (conv front-end + rel-pos Conformer encoder + 2-layer LSTM predictor + joint with a
+    weight-normed fc_out): logits (B, T', U+1, V) in eval and train mode and every parameter gradient of
+    sum(logits * R) for a fixed random R, all from the reference's own modules.  (torchaudio is not installable here, so the
+    RNN-T loss itself is pinned separately: oracle/rnnt_ref.py against brute-force alignment sums.)"""
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase
+    from espresso.models.transformer.speech_transformer_transducer_config import SpeechTransformerTransducerConfig
+
+    torch.manual_seed(2468)
+    V = 40
+    base = ref_config("conformer")
+    cfg = SpeechTransformerTransducerConfig()
+    cfg.encoder = base.encoder
+    d = cfg.decoder
+    d.embed_dim, d.hidden_size, d.layers, d.residual, d.dropout_in, d.dropout_out = 48, 64, 2, True, 0.0, 0.0
+    d.embed_path = None
+    cfg.encoder.layers_to_keep = None
+    cfg.joint_dim = 64
+    cfg.share_decoder_input_output_embed = False
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    cfg.tpu = False
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.activation_fn = "relu"
+    cfg.layernorm_embedding = True
+    cfg.no_scale_embedding = False
+    cfg.no_token_positional_embeddings = False
+    cfg.adaptive_input = False
+    cfg.quant_noise.pq = 0.0
+    cfg.quant_noise.pq_block_size = 8
+    cfg.export = False
+    cfg.checkpoint_activations = False
+    cfg.offload_activations = False
+    cfg.min_params_to_wrap = int(1e8)
+
+    class T:
+        feat_dim, feat_in_channels = 80, 1
+    dic = AsrDictionary(enable_bos=True)
+    for i in range(V - len(dic) - 1):
+        dic.add_symbol(f"t{i}")
+    dic.add_symbol("<space>")
+    T.target_dictionary = dic
+    assert len(dic) == V, len(dic)
+    model = SpeechTransformerTransducerModelBase.build_model(cfg, T)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "weight_g" not in n:
+                p.add_(0.1 * torch.randn_like(p))
+    B, Tn = 3, 70
+    lengths = torch.tensor([70, 61, 37])
+    feats = torch.randn(B, Tn, 80)
+    for b in range(B):
+        feats[b, lengths[b]:] = 0.0
+    pad, eos = dic.pad(), dic.eos()
+    tl = [7, 5, 3]
+    U1 = 8
+    prev = torch.full((B, U1), pad, dtype=torch.long)
+    for b, L in enumerate(tl):
+        prev[b, 0] = eos
+        prev[b, 1:L + 1] = torch.randint(dic.nspecial, V, (L,))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        lo, olen = model(feats, lengths, prev)
+    out["eval_logits"] = lo.numpy()
+    out["out_lengths"] = olen.numpy()
+    model.train()
+    lo, _ = model(feats, lengths, prev)
+    R = torch.randn_like(lo) * 0.1
+    for b in range(B):  # frames beyond the encoder output length carry implementation-defined values: keep them out of the objective
+        R[b, int(olen[b]):] = 0.0
+    (lo * R).sum().backward()
+    out["train_logits"] = lo.detach().numpy()
+    grads = {n: p.grad.detach().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), feats=feats.numpy(), lengths=lengths.numpy(), prev=prev.numpy(), R=R.numpy(),
+                        **{"sd::" + k: v.numpy() for k, v in sd.items()}, **{"out::" + k: v for k, v in out.items()},
+                        **{"grad::" + k: v for k, v in grads.items()})
+    print(name, "logits", tuple(lo.shape), "params", sum(p.numel() for p in model.parameters()))
+    print([k for k in sd if not k.startswith("encoder")])
+
+
 def label_smoothing_fixture():
     from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
 
@@ -270,6 +352,9 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "encdec":
         encdec_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "transducer":
+        transducer_fixture()
         sys.exit(0)
     encoder_fixture("conformer", "ref_conformer_ctc_tiny")
     encoder_fixture("transformer", "ref_transformer_ctc_tiny")

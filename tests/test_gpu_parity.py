@@ -170,3 +170,35 @@ def test_flash_attention_backward(kw):
         assert r.pop("dBD_pad_zero"), r
     for name, err in r.items():
         assert err <= 2e-2, (name, r)
+
+
+@pytest.mark.parametrize("with_state", [False, True])
+def test_lstm_layer_vs_torch_lstmcell(with_state):
+    """sequence LSTM op (input GEMM + per-step recurrent GEMM + cell kernels, BPTT) vs torch.nn.LSTMCell in fp32 on the same
+    bf16-rounded weights: hidden states are bf16 (4e-3 abs on |h| < 1), gradients 2e-2 of their range"""
+    r = G.check_lstm_layer(with_state=with_state)
+    print(r)
+    assert r["hs_abs"] < 8e-3 and r["c_last_abs"] < 2e-2, r
+    for k, v in r.items():
+        if k.startswith("grad_"):
+            assert v < 2e-2, (k, r)
+
+
+def test_transducer_vs_reference_fixture():
+    """speech_transformer_transducer_base on the HIP kernels vs the reference model's own outputs (fixture generated by
+    oracle/gen_golden.py transducer): bf16 logits within 1e-2 * range (north-star tolerance), gradients 3e-2 of range"""
+    r = G.check_transducer_vs_reference()
+    print(r)
+    assert r["out_lengths_equal"], r
+    tol = 1.5e-2 * max(1.0, r["eval_logits_ref_max"])
+    assert r["eval_logits_abs"] < tol and r["train_logits_abs"] < tol, r
+    assert r["fc_out_max"] < 1e-2, r                       # output layer: no kink upstream of it
+    assert abs(r["worst_scale"][1] - 1.0) < 7e-2, r        # every gradient has the right size and direction ...
+    assert r["worst_l2"][1] < 0.22, r                      # ... up to the ReLU-kink noise of bf16 activations (see check)
+
+
+def test_transducer_loss_end_to_end():
+    r = G.check_transducer_loss_step()
+    print(r)
+    assert r["finite"], r
+    assert abs(r["loss"] - r["oracle_loss"]) <= 1e-2 * abs(r["oracle_loss"]), r

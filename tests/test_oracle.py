@@ -127,3 +127,21 @@ def test_rnnt_restatement_vs_bruteforce_and_finite_differences():
         zm[idx] -= eps
         fd = (rnnt_ref.rnnt_loss_one(zp, y) - rnnt_ref.rnnt_loss_one(zm, y)) / (2 * eps)
         assert g[idx] == pytest.approx(fd, abs=1e-6)
+
+
+def test_transducer_restatement_matches_reference(golden_dir):
+    """encoder + LSTM predictor + joint (weight-normed fc_out) restated in oracle/torch_ref.py vs the reference model's
+    own logits (eval and train mode) and parameter gradients of sum(logits * R)."""
+    g, sd = _load(golden_dir, "ref_conformer_transducer_tiny")
+    feats, lengths, prev = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"])
+    lo, ol = torch_ref.transducer(feats, lengths, prev, sd, H=4, pad_idx=1, residual=True, training=False)
+    assert ol.tolist() == g["out::out_lengths"].tolist()
+    assert float((lo - torch.from_numpy(g["out::eval_logits"])).abs().max()) < 2e-5
+    leaf = {k: v.clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v.clone() for k, v in sd.items()}
+    lo, _ = torch_ref.transducer(feats, lengths, prev, leaf, H=4, pad_idx=1, residual=True, training=True, update={})
+    assert float((lo - torch.from_numpy(g["out::train_logits"])).abs().max()) < 2e-5
+    (lo * torch.from_numpy(g["R"])).sum().backward()
+    for k in ("decoder.layers.0.weight_hh", "decoder.layers.1.weight_ih", "decoder.embed_tokens.weight", "fc_out.weight_g",
+              "fc_out.weight_v", "proj_decoder.weight", "laynorm_proj_encoder.weight", "encoder.fc0.weight"):
+        ref = torch.from_numpy(g["grad::" + k])
+        assert float((leaf[k].grad - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), k
