@@ -94,6 +94,25 @@ class SpeechTransformerTransducerModelBase(nn.Module):
         w, b = self.fc_out_params()
         return F.transducer_joint(E, D, w, b, B, T, U1)
 
+    # ---- inference helpers: the encoder branch of the joint is computed once per utterance batch, the predictor branch
+    # once per expansion (espresso/tools/transducer_greedy_decoder.py:163-176 evaluates joint() on one frame at a time)
+    @torch.no_grad()
+    def joint_encoder_branch(self, enc_bt):
+        return F.layer_norm(F.linear(enc_bt, self.proj_encoder.weight, self.proj_encoder.bias), self.laynorm_proj_encoder.weight,
+                            self.laynorm_proj_encoder.bias)
+
+    @torch.no_grad()
+    def joint_step(self, E_rows, dec_rows):
+        """E_rows bf16 [N][J] (already projected + normalised), dec_rows bf16 [N][H] -> fp32 logits [N][V]."""
+        from ... import kernels as K
+
+        N = E_rows.shape[0]
+        D = F.layer_norm(F.linear(dec_rows, self.proj_decoder.weight, self.proj_decoder.bias), self.laynorm_proj_decoder.weight,
+                         self.laynorm_proj_decoder.bias)
+        Z = K.joint_add_relu(E_rows.contiguous(), D.contiguous(), N, 1, 1)
+        w, b = self.fc_out_params()
+        return F.linear(Z, w.detach(), b, out_f32=True)
+
     def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
         """-> (logits bf16 [B][T'][U+1][V], encoder_out_lengths [B])  (:221-243)"""
         enc = self.encoder(src_tokens, src_lengths)

@@ -266,6 +266,12 @@ def transducer_fixture(name="ref_conformer_transducer_tiny"):
         for n, p in model.named_parameters():
             if p.dim() == 1 and "weight_g" not in n:
                 p.add_(0.1 * torch.randn_like(p))
+        # make the search non-degenerate: input-dependent logits and a competitive blank
+        # (relu output has a large common component: remove it from the output rows, sharpen, and bias towards blank)
+        model.fc_out.weight_v.sub_(model.fc_out.weight_v.mean(dim=1, keepdim=True))
+        model.fc_out.weight_g.copy_(3.0 * model.fc_out.weight_v.norm(dim=1, keepdim=True))
+        model.fc_out.bias.zero_()
+        model.fc_out.bias[dic.bos()] = 1.0
     B, Tn = 3, 70
     lengths = torch.tensor([70, 61, 37])
     feats = torch.randn(B, Tn, 80)
@@ -285,6 +291,14 @@ def transducer_fixture(name="ref_conformer_transducer_tiny"):
         lo, olen = model(feats, lengths, prev)
     out["eval_logits"] = lo.numpy()
     out["out_lengths"] = olen.numpy()
+    # greedy transducer search with the reference's own decoder (espresso/tools/transducer_greedy_decoder.py)
+    from espresso.tools.transducer_greedy_decoder import TransducerGreedyDecoder
+    for tag, kw in (("e2", dict(max_num_expansions_per_step=2)), ("e1_eos", dict(max_num_expansions_per_step=1, model_predicts_eos=True))):
+        dec = TransducerGreedyDecoder([model], dic, print_alignment=True, **kw)
+        toks, scores, ali = dec._generate({"net_input": {"src_tokens": feats, "src_lengths": lengths}})
+        out[f"greedy_{tag}_tokens"] = toks.numpy()
+        out[f"greedy_{tag}_scores"] = scores.numpy()
+        print(tag, [[int(t) for t in row if int(t) != dec.blank] for row in toks], scores.tolist())
     model.train()
     lo, _ = model(feats, lengths, prev)
     R = torch.randn_like(lo) * 0.1

@@ -202,3 +202,12 @@ def test_transducer_loss_end_to_end():
     print(r)
     assert r["finite"], r
     assert abs(r["loss"] - r["oracle_loss"]) <= 1e-2 * abs(r["oracle_loss"]), r
+
+
+def test_transducer_greedy_decoder_vs_reference():
+    """token ids bit-exact at greedy, scores within 1e-2 (north-star tolerance for bf16)"""
+    r = G.check_transducer_greedy_decoder()
+    print(r)
+    for tag, v in r.items():
+        assert v["tokens_equal"], (tag, r)
+        assert v["score_rel"] < 1e-2, (tag, r)
