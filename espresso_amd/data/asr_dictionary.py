@@ -80,11 +80,15 @@ class AsrDictionary:
         return d
 
     @classmethod
-    def from_symbols(cls, symbols, enable_bos=False):
+    def from_symbols(cls, symbols, enable_bos=False, add_space=True):
+        """add_space=False: word-level dictionaries have no <space> symbol (space_index = -1, asr_dictionary.py:86)."""
         d = cls(enable_bos=enable_bos)
         for s in symbols:
             d.add_symbol(s)
-        d.space_index = d.add_symbol(d.space_word) if d.space_word not in d.indices else d.indices[d.space_word]
+        if add_space:
+            d.space_index = d.add_symbol(d.space_word) if d.space_word not in d.indices else d.indices[d.space_word]
+        else:
+            d.space_index = d.indices.get(d.space_word, -1)
         d.non_lang_syms = None
         return d
 

@@ -294,6 +294,24 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
 int ea_set_flash_attention(int on);
 
 /* ------------------------------------------------------------------------------------------
+ * Look-ahead word LM fusion (csrc/lookahead.hip) — espresso/models/tensorized_lookahead_language_model.py:83-269 over the
+ * tensorized prefix tree of espresso/tools/tensorized_prefix_tree.py:14-108 (int32 device copies: children [NN][D],
+ * prev_subword [NN], word_idx [NN], word_set [NN][2]; node 0 = none, node 1 = root).
+ * ea_softmax_cumsum: cumsum[n][v] = sum_{w<=v} softmax(logits[n])[w] (fp32, rows ld apart), lp_tok[n] = log softmax[n][tok];
+ *   rows with row_mask[n] == 0 keep their previous values (row_mask NULL = all rows).
+ * ea_lookahead_advance: nodes[n] <- root if prev_tok[n] == space else the child reached by prev_tok[n] (none if absent).
+ * ea_lookahead_logprobs: out fp32 [N][Vs] = sub-word log-probabilities of Eqn. 15 (floor log(1e-10)); lp_word_eos[n] is used
+ *   as the <eos> score of hypotheses whose last sub-word is <space>. */
+int ea_softmax_cumsum(const float* logits, long ld, const uint8_t* row_mask, float* cumsum, float* lp_tok, int N, int V, int tok,
+                      ea_stream_t stream);
+int ea_lookahead_advance(int* nodes, const int* prev_tok, const int* children, const int* prev_subword, int N, int D,
+                         int space_idx, int root_id, ea_stream_t stream);
+int ea_lookahead_logprobs(const int* nodes, const int* prev_tok, const float* cumsum, const float* lp_word_eos, const int* children,
+                          const int* prev_subword, const int* word_idx, const int* word_set, float* out, int N, int Vw, int Vs,
+                          int D, float oov_penalty, int open_vocab, int word_unk, int sub_space, int sub_eos, int sub_pad,
+                          ea_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * LSTM cell element-wise stages (csrc/lstm.hip) — torch.nn.LSTMCell as driven by espresso/models/speech_lstm.py:846-893
  * (transducer predictor, LSTM LM, attention decoder).  The packed pre-activations gates_pre = x W_ih^T + b_ih + h W_hh^T
  * + b_hh ([B][ldg] fp32, gate order i,f,g,o) come from ea_gemm_bf16 (fp32 output, fp32 residual).

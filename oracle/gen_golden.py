@@ -314,6 +314,80 @@ def transducer_fixture(name="ref_conformer_transducer_tiny"):
     print([k for k in sd if not k.startswith("encoder")])
 
 
+def lookahead_fixture(name="ref_lookahead_wordlm_tiny"):
+    """Look-ahead word LM (espresso/models/tensorized_lookahead_language_model.py) over a tiny character lexicon: the
+    tensorized prefix tree, the word LSTM LM weights, and the sub-word log-probs the reference emits along scripted
+    hypotheses (including an OOV path, word ends and a beam reorder)."""
+    import argparse
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.models.lstm_lm import LSTMLanguageModelEspresso, base_lm_architecture
+    from espresso.models.tensorized_lookahead_language_model import TensorizedLookaheadLanguageModel
+
+    torch.manual_seed(99)
+    words = sorted(["A", "AB", "ABC", "ABD", "B", "BA", "BAD", "BADE", "CAB", "DAD", "DEAD", "DEED", "E", "EBB", "ACE", "BEAD"])
+    chars = ["A", "B", "C", "D", "E", "F"]
+    wd = AsrDictionary()
+    for w in words:
+        wd.add_symbol(w)
+    sd_ = AsrDictionary()
+    for c in chars:
+        sd_.add_symbol(c)
+    sd_.add_symbol("<space>")
+    sd_.space_index = sd_.indices["<space>"]  # AsrDictionary.load sets it (asr_dictionary.py:86)
+    wd.space_index = -1
+
+    class T:
+        pass
+    T.source_dictionary = T.target_dictionary = T.word_dictionary = wd
+    args = argparse.Namespace(decoder_embed_dim=16, decoder_hidden_size=24, decoder_layers=2, decoder_out_embed_dim=24, dropout=0.0,
+                              share_embed=False, is_wordlm=True, criterion_name="cross_entropy", tokens_per_sample=64)
+    base_lm_architecture(args)
+    word_lm = LSTMLanguageModelEspresso.build_model(args, T)
+    with torch.no_grad():
+        for p_ in word_lm.parameters():
+            p_.mul_(4.0)  # U(-0.4, 0.4): a word distribution that is far from uniform
+    word_lm.eval()
+    la = TensorizedLookaheadLanguageModel(word_lm, sd_, oov_penalty=1e-4, open_vocab=True)
+    la.eval()
+    tree = la.decoder.tree
+    sp, eos = sd_.space(), sd_.eos()
+    ci = {c: sd_.index(c) for c in chars}
+    # four hypotheses, 9 steps after the initial <eos>
+    script = [
+        [ci["A"], ci["B"], sp, ci["B"], ci["A"], ci["D"], sp, ci["E"], sp],
+        [ci["D"], ci["E"], ci["E"], ci["D"], sp, ci["A"], ci["C"], ci["E"], sp],
+        [ci["F"], ci["F"], sp, ci["C"], ci["A"], ci["B"], sp, ci["B"], sp],      # OOV word first (F is in no word)
+        [ci["B"], ci["E"], ci["A"], ci["D"], sp, ci["D"], ci["A"], ci["C"], sp],  # leaves the tree at the last letters
+    ]
+    B = len(script)
+    inc = {}
+    toks = torch.full((B, 1), eos, dtype=torch.long)
+    outs, orders, last_tok = [], [], []
+    with torch.no_grad():
+        for step in range(len(script[0]) + 1):
+            lp, _ = la.decoder(toks, incremental_state=inc)
+            outs.append(lp.squeeze(1).numpy().copy())
+            last_tok.append(toks[:, -1].numpy().copy())
+            if step == len(script[0]):
+                break
+            order = torch.arange(B)
+            if step == 4:  # a beam reorder in the middle: hypotheses 0 and 3 swap places, 1 is duplicated over 2
+                order = torch.tensor([3, 1, 1, 0])
+                script = [script[int(i)] for i in order]
+                toks = toks.index_select(0, order)
+                la.decoder.reorder_incremental_state(inc, order)
+                word_lm.decoder.reorder_incremental_state(inc, order)
+            orders.append(order.numpy())
+            toks = torch.cat([toks, torch.tensor([[script[b][step]] for b in range(B)])], 1)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), words=np.array(words), chars=np.array(chars), tokens=toks.numpy(),
+                        orders=np.stack(orders), lprobs=np.stack(outs), last_tok=np.stack(last_tok), tree_children=tree.children.numpy(),
+                        tree_prev_subword_idx=tree.prev_subword_idx.numpy(), tree_word_idx=tree.word_idx.numpy(),
+                        tree_word_set_idx=tree.word_set_idx.numpy(),
+                        **{"sd::" + k: v.numpy() for k, v in word_lm.state_dict().items()})
+    print(name, "nodes", tree.children.shape, "lprobs", np.stack(outs).shape, list(word_lm.state_dict().keys()))
+    print(np.round(outs[1][0], 2))
+
+
 def label_smoothing_fixture():
     from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
 
@@ -366,6 +440,9 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "encdec":
         encdec_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lookahead":
+        lookahead_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "transducer":
         transducer_fixture()

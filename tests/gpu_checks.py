@@ -851,3 +851,44 @@ def check_transducer_greedy_decoder():
                     "score_rel": float(np.abs(scores.cpu().numpy() - ref_s).max() / np.abs(ref_s).max()),
                     "agree": float((toks.cpu().numpy() == ref_t).mean()) if toks.shape == tuple(ref_t.shape) else 0.0}
     return res
+
+
+# ------------------------------------------------------------------ LM fusion
+def build_lookahead_from_fixture(g):
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+    from espresso_amd.models.lstm_lm import LSTMLanguageModelEspresso
+    from espresso_amd.models.tensorized_lookahead_language_model import TensorizedLookaheadLanguageModel
+
+    wd = AsrDictionary.from_symbols([str(w) for w in g["words"]], enable_bos=False, add_space=False)
+    sd_ = AsrDictionary.from_symbols([str(c) for c in g["chars"]], enable_bos=False)
+
+    class T:
+        word_dictionary = target_dictionary = source_dictionary = wd
+    lm = LSTMLanguageModelEspresso.build_model(dict(arch="lstm_lm_wsj", decoder_embed_dim=16, decoder_hidden_size=24, decoder_layers=2,
+                                                    decoder_out_embed_dim=24, dropout=0.0, share_embed=False, is_wordlm=True), T)
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    missing, unexpected = lm.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    lm = lm.to(DEV).eval()
+    return TensorizedLookaheadLanguageModel(lm, sd_, oov_penalty=1e-4, open_vocab=True), wd, sd_
+
+
+def check_lookahead_lm():
+    """Look-ahead word LM on the HIP kernels vs the log-probs the reference's _TensorizedLookaheadLanguageModelDecoder emitted
+    along scripted hypotheses (fixture from oracle/gen_golden.py lookahead): OOV path, word ends, leaving the tree, a reorder."""
+    g = np.load(os.path.join(GOLD, "ref_lookahead_wordlm_tiny.npz"))
+    la, wd, sd_ = build_lookahead_from_fixture(g)
+    ref = g["lprobs"]  # [calls][B][Vs]
+    last = g["last_tok"]
+    orders = g["orders"]
+    B = ref.shape[1]
+    state = la.init_incremental(B, 1)
+    worst, floor_equal = 0.0, True
+    for k in range(ref.shape[0]):
+        toks = torch.from_numpy(last[k]).to(DEV).view(B, 1)
+        parent = torch.from_numpy(orders[k - 1]).to(DEV) if k > 0 else None
+        out = la.step(state, toks, k, parent).cpu().numpy()
+        fl = ref[k] < -20.0  # clamped "zero" entries: log(1e-10)
+        floor_equal = floor_equal and bool(((out < -20.0) == fl).all())
+        worst = max(worst, float(np.abs(out - ref[k])[~fl].max()))
+    return {"max_abs": worst, "floor_pattern_equal": floor_equal}

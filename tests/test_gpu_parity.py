@@ -211,3 +211,12 @@ def test_transducer_greedy_decoder_vs_reference():
     for tag, v in r.items():
         assert v["tokens_equal"], (tag, r)
         assert v["score_rel"] < 1e-2, (tag, r)
+
+
+def test_lookahead_word_lm_vs_reference():
+    """word LSTM LM in bf16 MFMA GEMMs, everything after it fp32: sub-word log-probs within 2e-2 of the reference's fp32 run
+    and the exact same pattern of floored (impossible) continuations"""
+    r = G.check_lookahead_lm()
+    print(r)
+    assert r["floor_pattern_equal"], r
+    assert r["max_abs"] < 2e-2, r

@@ -179,3 +179,22 @@ def test_wer_scorer_counts():
     assert s.wer() == 100.0 and s.cer() == 60.0
     s.add_evaluation("u2", "g h", "g h")
     assert s.tot_word_count() == 3 and s.wer() == pytest.approx(200.0 / 3)
+
+
+def test_tensorized_prefix_tree_matches_reference(golden_dir):
+    """children / prev_subword_idx / word_idx / word_set_idx identical to what espresso/tools/tensorized_prefix_tree.py built
+    for the same word and character dictionaries (fixture written by oracle/gen_golden.py lookahead)."""
+    import os
+
+    import numpy as np
+
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+    from espresso_amd.tools.tensorized_prefix_tree import TensorizedPrefixTree, tokenize
+
+    g = np.load(os.path.join(golden_dir, "ref_lookahead_wordlm_tiny.npz"))
+    wd = AsrDictionary.from_symbols([str(w) for w in g["words"]], enable_bos=False, add_space=False)
+    sd = AsrDictionary.from_symbols([str(c) for c in g["chars"]], enable_bos=False)
+    t = TensorizedPrefixTree.build(wd, sd, lambda x: tokenize(x).split(" "))
+    for k in ("children", "prev_subword_idx", "word_idx", "word_set_idx"):
+        assert np.array_equal(getattr(t, k).numpy(), g["tree_" + k]), k
+    assert tokenize("AB C") == "A B <space> C"
