@@ -314,6 +314,73 @@ def transducer_fixture(name="ref_conformer_transducer_tiny"):
     print([k for k in sd if not k.startswith("encoder")])
 
 
+def lm_fusion_fixture(name="ref_lm_fusion_tiny"):
+    """Shallow fusion inside the reference's SequenceGenerator (fairseq/sequence_generator.py:385-393): the enc-dec model of
+    ref_transformer_encdec_tiny.npz (weights reloaded from that fixture) + a tiny sub-word LSTM LM, beam 3, lm_weight 0.5."""
+    import argparse
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.models.lstm_lm import LSTMLanguageModelEspresso, base_lm_architecture
+    from espresso.models.transformer.speech_transformer_base import SpeechTransformerModelBase
+    from fairseq.sequence_generator import SequenceGenerator
+
+    g = np.load(os.path.join(OUT, "ref_transformer_encdec_tiny.npz"))
+    torch.manual_seed(1357)
+    V = 40
+    cfg = ref_config("transformer")
+    d = cfg.decoder
+    d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads = 64, 128, 2, 4
+    d.input_dim = d.output_dim = 64
+    d.normalize_before, d.learned_pos, d.relative_positional_embeddings = True, False, False
+    d.layerdrop = 0.0
+    d.xformers_att_config = None
+    d.embed_path = None
+    d.layers_to_keep = None
+    cfg.encoder.layers_to_keep = None
+    cfg.share_decoder_input_output_embed = False
+    cfg.no_cross_attention = False
+    cfg.cross_self_attention = False
+    cfg.adaptive_softmax_cutoff = None
+    cfg.tie_adaptive_weights = False
+    cfg.scheduled_sampling_probs = [1.0]
+    cfg.start_scheduled_sampling_epoch = 1
+    cfg.layernorm_embedding = True
+    cfg.no_decoder_final_norm = False
+    cfg.scale_attn = cfg.scale_heads = cfg.scale_fc = cfg.scale_resids = False
+
+    class T:
+        feat_dim, feat_in_channels = 80, 1
+    dic = AsrDictionary()
+    for i in range(V - len(dic) - 1):
+        dic.add_symbol(f"t{i}")
+    dic.add_symbol("<space>")
+    T.target_dictionary = T.source_dictionary = dic
+    model = SpeechTransformerModelBase.build_model(cfg, T)
+    model.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")})
+    model.eval()
+    args = argparse.Namespace(decoder_embed_dim=24, decoder_hidden_size=32, decoder_layers=2, decoder_out_embed_dim=32, dropout=0.0,
+                              share_embed=False, is_wordlm=False, criterion_name="cross_entropy", tokens_per_sample=64)
+    base_lm_architecture(args)
+    from espresso.tasks.speech_recognition import SpeechRecognitionEspressoTask  # noqa: F401 (isinstance check in build_model)
+    lm = LSTMLanguageModelEspresso.build_model(args, T)
+    with torch.no_grad():
+        for p_ in lm.parameters():
+            p_.mul_(3.0)
+    lm.eval()
+    feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
+    beams = {}
+    for tag, kw in (("lm05", dict(beam_size=3, max_len_a=0.0, max_len_b=12, lm_weight=0.5)),
+                    ("lm10_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, lm_weight=1.0, eos_factor=1.5))):
+        gen = SequenceGenerator([model], dic, lm_model=lm, **kw)
+        hyps = gen.generate([model], {"net_input": {"src_tokens": feats, "src_lengths": lengths}})
+        for bi, hl in enumerate(hyps):
+            for hi, hyp in enumerate(hl):
+                beams[f"beam::{tag}::{bi}::{hi}::tokens"] = hyp["tokens"].numpy()
+                beams[f"beam::{tag}::{bi}::{hi}::score"] = np.array(float(hyp["score"]))
+                beams[f"beam::{tag}::{bi}::{hi}::pos"] = hyp["positional_scores"].numpy()
+        print(tag, [[h["tokens"].tolist() for h in hl] for hl in hyps], [[round(float(h["score"]), 3) for h in hl] for hl in hyps])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **beams, **{"lm::" + k: v.numpy() for k, v in lm.state_dict().items()})
+
+
 def lookahead_fixture(name="ref_lookahead_wordlm_tiny"):
     """Look-ahead word LM (espresso/models/tensorized_lookahead_language_model.py) over a tiny character lexicon: the
     tensorized prefix tree, the word LSTM LM weights, and the sub-word log-probs the reference emits along scripted
@@ -440,6 +507,9 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "encdec":
         encdec_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
+        lm_fusion_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lookahead":
         lookahead_fixture()

@@ -892,3 +892,60 @@ def check_lookahead_lm():
         floor_equal = floor_equal and bool(((out < -20.0) == fl).all())
         worst = max(worst, float(np.abs(out - ref[k])[~fl].max()))
     return {"max_abs": worst, "floor_pattern_equal": floor_equal}
+
+
+def check_lm_fusion_beam_search():
+    """Shallow fusion (sequence_generator.py:385-393) with a sub-word LSTM LM: HIP generator vs the reference generator's
+    beams (fixture ref_lm_fusion_tiny.npz, model weights from ref_transformer_encdec_tiny.npz)."""
+    from espresso_amd.models.lstm_lm import LSTMLanguageModelEspresso
+    from espresso_amd.sequence_generator import SequenceGenerator
+
+    g = np.load(os.path.join(GOLD, "ref_transformer_encdec_tiny.npz"))
+    gl = np.load(os.path.join(GOLD, "ref_lm_fusion_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = build_tiny_encdec().to(DEV)
+    model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    model.eval()
+    task = _TaskAR(40)
+    d = task.target_dictionary
+    lm = LSTMLanguageModelEspresso.build_model(dict(arch="lstm_lm_wsj", decoder_embed_dim=24, decoder_hidden_size=32, decoder_layers=2,
+                                                    decoder_out_embed_dim=32, dropout=0.0, share_embed=False), task)
+    missing, unexpected = lm.load_state_dict({k[4:]: torch.from_numpy(gl[k]) for k in gl.files if k.startswith("lm::")}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    lm = lm.to(DEV).eval()
+    sample = {"net_input": {"src_tokens": torch.from_numpy(g["feats"]).to(DEV), "src_lengths": torch.from_numpy(g["lengths"]).to(DEV)}}
+    res = {}
+    for tag, kw in (("lm05", dict(beam_size=3, max_len_a=0.0, max_len_b=12, lm_weight=0.5)),
+                    ("lm10_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, lm_weight=1.0, eos_factor=1.5))):
+        gen = SequenceGenerator([model], d, lm_model=lm, **kw)
+        hyps = gen.generate([model], sample)
+        in_beam, score_err = [], 0.0
+        for b, hl in enumerate(hyps):
+            refset, hi = {}, 0
+            while f"beam::{tag}::{b}::{hi}::tokens" in gl.files:
+                refset[tuple(gl[f"beam::{tag}::{b}::{hi}::tokens"].tolist())] = float(gl[f"beam::{tag}::{b}::{hi}::score"])
+                hi += 1
+            in_beam.append(sum(tuple(h["tokens"].tolist()) in refset for h in hl) / len(hl))
+            for h in hl:
+                k = tuple(h["tokens"].tolist())
+                if k in refset:
+                    score_err = max(score_err, abs(float(h["score"]) - refset[k]))
+        res[tag] = {"frac_hyps_in_reference_beam": in_beam, "score_abs": score_err}
+    # force-decode the reference's best fused hypothesis: per-position fused scores must match its positional scores
+    tag, lmw = "lm05", 0.5
+    toks = torch.stack([torch.from_numpy(gl[f"beam::{tag}::{b}::0::tokens"]) for b in range(3)]).to(DEV)
+    ref_pos = torch.stack([torch.from_numpy(gl[f"beam::{tag}::{b}::0::pos"]) for b in range(3)])
+    with torch.no_grad():
+        enc_out = model.forward_encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+        st = model.decoder.init_incremental(enc_out, 3, 1)
+        lst = lm.init_incremental(3, 1)
+        cur = torch.full((3, 1), d.eos(), dtype=torch.long, device=DEV)
+        got = []
+        for step in range(toks.shape[1]):
+            par = None if step == 0 else torch.arange(3, device=DEV)
+            lp = model.decoder.step(st, cur, step, par) + lmw * lm.step(lst, cur, step, par)
+            got.append(lp.gather(-1, toks[:, step:step + 1]).squeeze(-1).cpu())
+            cur = torch.cat([cur, toks[:, step:step + 1]], 1)
+    got = torch.stack(got, 1)
+    res["forced_decode_pos_score_abs"] = float((got[:, :-1] - ref_pos[:, :-1]).abs().max())  # last = forced EOS at max_len
+    return res

@@ -220,3 +220,13 @@ def test_lookahead_word_lm_vs_reference():
     print(r)
     assert r["floor_pattern_equal"], r
     assert r["max_abs"] < 2e-2, r
+
+
+def test_lm_fusion_beam_search_vs_reference():
+    """acoustic + 0.5 * LSTM-LM log-probs along the reference's best hypotheses (bf16 models: 0.1 abs per position, as for the
+    un-fused generator); hypotheses found by both generators carry the same normalised score"""
+    r = G.check_lm_fusion_beam_search()
+    print(r)
+    assert r["forced_decode_pos_score_abs"] < 0.1, r
+    for tag in ("lm05", "lm10_eosf"):
+        assert r[tag]["score_abs"] < 3e-2, r
