@@ -188,8 +188,12 @@ def _pad8(n):
 class _RelPosMHSA(torch.autograd.Function):
     """y = drop(out_proj(Attn(LN(x)))) + x with Transformer-XL relative logits.
 
-    wqkv/bqkv: fused [3C][C] / [3C] in (q, k, v) order.  pe: bf16 [2T-1][C] sinusoidal table slice
-    (None -> plain attention, no u/v/pos_proj)."""
+    wqkv/bqkv: fused [3C][C] / [3C] in (q, k, v) order.  Positional modes (fairseq/modules/multihead_attention.py:788-831):
+      * pe bf16 [2T-1][C] + wpos: sinusoidal table slice, projected by pos_proj, queries biased by pos_bias_u / pos_bias_v;
+      * pe fp32 [2T-1][C] slice of a LEARNED table (wpos None): used as is, plain scaled queries, gradient returned for the slice;
+      * pe None: plain attention.
+    Head dim 64 without an additive mask runs the fused flash kernels (csrc/flash_attention.hip); anything else the
+    GEMM / softmax / GEMM composition."""
 
     @staticmethod
     def forward(ctx, x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, wqkv16, wo16, wpos16, pe, key_len, attn_mask, B, T,
@@ -204,39 +208,54 @@ class _RelPosMHSA(torch.autograd.Function):
         qkv = _new((M, 3 * C), torch.bfloat16, x)
         K.gemm(xn, wqkv16, qkv, M, 3 * C, C, lda=C, ldb=C, ldc=3 * C, bias=bqkv)
         relpos = pe is not None
-        qu, qv = K.relpos_q_prep(qkv, 3 * C, u if relpos else None, v if relpos else None, M, C, scaling, want_qv=relpos)
+        learned = relpos and wpos is None
+        if learned:
+            qu, _ = K.relpos_q_prep(qkv, 3 * C, None, None, M, C, scaling, want_qv=False)
+            qv = qu
+        else:
+            qu, qv = K.relpos_q_prep(qkv, 3 * C, u if relpos else None, v if relpos else None, M, C, scaling, want_qv=relpos)
         Z = H * B
         Sp = _pad8(T)
-        ac = _new((Z * T, Sp), torch.float32, x)
-        K.gemm(qu, qkv, ac, T, T, dh, lda=C, ldb=3 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, T * 3 * C),
-               b_off=C, sC=(B * T * Sp, T * Sp))
-        bd = None
-        pp = None
         R = 2 * T - 1
         Rp = _pad8(R)
+        pp = None
         if relpos:
-            pp = _new((R, C), torch.bfloat16, x)
-            K.gemm(pe, wpos16, pp, R, C, C, lda=C, ldb=C, ldc=C)
-            bd = _new((Z * T, Rp), torch.float32, x)
-            K.gemm(qv, pp, bd, T, R, dh, lda=C, ldb=C, ldc=Rp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, 0),
-                   sC=(B * T * Rp, T * Rp))
+            if learned:
+                pp = K.cast_f32_to_bf16(pe.detach().contiguous())
+            else:
+                pp = _new((R, C), torch.bfloat16, x)
+                K.gemm(pe, wpos16, pp, R, C, C, lda=C, ldb=C, ldc=C)
         sa = _next_seed() if p_attn > 0 else 0
-        P, Pd = K.relpos_softmax_fwd(ac, bd, key_len, attn_mask, H, B, T, T, Sp, Rp, Sp, causal, p_attn, sa)
-        del ac, bd
-        o = _new((M, C), torch.bfloat16, x)
-        K.gemm(Pd, qkv, o, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
-               sB=(dh, T * 3 * C), b_off=2 * C, sC=(dh, T * C))
+        fused = attn_mask is None and K.flash_attention_supported(dh, T, T, relpos)
+        P = Pd = lse = None
+        if fused:
+            o, lse = K.flash_attention_fwd(qu, qv if relpos else None, qkv[:, C:], qkv[:, 2 * C:], pp, key_len, H, B, T, T, C, 3 * C,
+                                           C, causal=causal, drop_p=p_attn, drop_seed=sa)
+        else:
+            ac = _new((Z * T, Sp), torch.float32, x)
+            K.gemm(qu, qkv, ac, T, T, dh, lda=C, ldb=3 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, T * 3 * C),
+                   b_off=C, sC=(B * T * Sp, T * Sp))
+            bd = None
+            if relpos:
+                bd = _new((Z * T, Rp), torch.float32, x)
+                K.gemm(qv, pp, bd, T, R, dh, lda=C, ldb=C, ldc=Rp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, 0),
+                       sC=(B * T * Rp, T * Rp))
+            P, Pd = K.relpos_softmax_fwd(ac, bd, key_len, attn_mask, H, B, T, T, Sp, Rp, Sp, causal, p_attn, sa)
+            del ac, bd
+            o = _new((M, C), torch.bfloat16, x)
+            K.gemm(Pd, qkv, o, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
+                   sB=(dh, T * 3 * C), b_off=2 * C, sC=(dh, T * C))
         so = _next_seed() if p_out > 0 else 0
         y = _new((M, C), torch.bfloat16, x)
         K.gemm(o, wo16, y, M, C, C, lda=C, ldb=C, ldc=C, bias=bo, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
-        ctx.save_for_backward(x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe)
-        ctx.cfg = (B, T, H, p_attn, p_out, sa, so, pre_ln, relpos)
+        ctx.save_for_backward(x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe, lse, key_len)
+        ctx.cfg = (B, T, H, p_attn, p_out, sa, so, pre_ln, relpos, learned, fused, causal)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe) = ctx.saved_tensors
-        B, T, H, p_attn, p_out, sa, so, pre_ln, relpos = ctx.cfg
+        (x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe, lse, key_len) = ctx.saved_tensors
+        B, T, H, p_attn, p_out, sa, so, pre_ln, relpos, learned, fused, causal = ctx.cfg
         M, C = x.shape
         dh = C // H
         scaling = dh ** -0.5
@@ -249,36 +268,45 @@ class _RelPosMHSA(torch.autograd.Function):
         dbo = K.colsum(g, _zeros_f32(C, x), M, C, C)
         do = _new((M, C), torch.bfloat16, x)
         K.gemm(g, wo16, do, M, C, C, lda=C, ldb=C, ldc=C, b_kstrided=True)
-        # dPd[z][i][j] = sum_d do[(b,i),h,d] v[(b,j),h,d]
-        dPd = _new((Z * T, Sp), torch.float32, x)
-        K.gemm(do, qkv, dPd, T, T, dh, lda=C, ldb=3 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, T * 3 * C),
-               b_off=2 * C, sC=(B * T * Sp, T * Sp))
         dqkv = _new((M, 3 * C), torch.bfloat16, x)
-        # dV[(b,j),h,d] = sum_i Pd[z][i][j] do[(b,i),h,d]
-        K.gemm(Pd, do, dqkv, T, dh, T, lda=Sp, ldb=C, ldc=3 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
-               sA=(B * T * Sp, T * Sp), sB=(dh, T * C), sC=(dh, T * 3 * C), c_off=2 * C)
-        dAC, dBD = K.relpos_softmax_bwd(P, dPd, H, B, T, T, Sp, Sp, Rp, want_bd=relpos, drop_p=p_attn, drop_seed=sa)
-        del dPd
-        # dK[(b,j),h,d] = sum_i dAC[z][i][j] qu[(b,i),h,d]
-        K.gemm(dAC, qu, dqkv, T, dh, T, lda=Sp, ldb=C, ldc=3 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
-               sA=(B * T * Sp, T * Sp), sB=(dh, T * C), sC=(dh, T * 3 * C), c_off=C)
-        # dq (through qu): s * sum_j dAC[z][i][j] k[(b,j),h,d]
-        t1 = _new((M, C), torch.bfloat16, x)
-        K.gemm(dAC, qkv, t1, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
-               sB=(dh, T * 3 * C), b_off=C, sC=(dh, T * C), alpha=scaling)
-        du = dv = dWpos = None
+        t2 = dBD = None
+        if fused:
+            t1, t2, dBD = K.flash_attention_bwd(qu, qv if relpos else None, qkv[:, C:], qkv[:, 2 * C:], pp, key_len, o, do, lse,
+                                                dqkv[:, C:], dqkv[:, 2 * C:], H, B, T, T, C, 3 * C, 3 * C, ldpp=C, causal=causal,
+                                                scaling=scaling, drop_p=p_attn, drop_seed=sa)
+        else:
+            # dPd[z][i][j] = sum_d do[(b,i),h,d] v[(b,j),h,d]
+            dPd = _new((Z * T, Sp), torch.float32, x)
+            K.gemm(do, qkv, dPd, T, T, dh, lda=C, ldb=3 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, T * 3 * C),
+                   b_off=2 * C, sC=(B * T * Sp, T * Sp))
+            # dV[(b,j),h,d] = sum_i Pd[z][i][j] do[(b,i),h,d]
+            K.gemm(Pd, do, dqkv, T, dh, T, lda=Sp, ldb=C, ldc=3 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
+                   sA=(B * T * Sp, T * Sp), sB=(dh, T * C), sC=(dh, T * 3 * C), c_off=2 * C)
+            dAC, dBD = K.relpos_softmax_bwd(P, dPd, H, B, T, T, Sp, Sp, Rp, want_bd=relpos, drop_p=p_attn, drop_seed=sa)
+            del dPd
+            # dK[(b,j),h,d] = sum_i dAC[z][i][j] qu[(b,i),h,d]
+            K.gemm(dAC, qu, dqkv, T, dh, T, lda=Sp, ldb=C, ldc=3 * C, a_kstrided=True, b_kstrided=True, batch=Z, zdiv=B,
+                   sA=(B * T * Sp, T * Sp), sB=(dh, T * C), sC=(dh, T * 3 * C), c_off=C)
+            # dq (through qu): s * sum_j dAC[z][i][j] k[(b,j),h,d]
+            t1 = _new((M, C), torch.bfloat16, x)
+            K.gemm(dAC, qkv, t1, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
+                   sB=(dh, T * 3 * C), b_off=C, sC=(dh, T * C), alpha=scaling)
+            if relpos:
+                t2 = _new((M, C), torch.bfloat16, x)
+                K.gemm(dBD, pp, t2, T, dh, R, lda=Rp, ldb=C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Rp, T * Rp),
+                       sB=(dh, 0), sC=(dh, T * C), alpha=scaling)
+        du = dv = dWpos = dpe = None
         if relpos:
-            t2 = _new((M, C), torch.bfloat16, x)
-            K.gemm(dBD, pp, t2, T, dh, R, lda=Rp, ldb=C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Rp, T * Rp),
-                   sB=(dh, 0), sC=(dh, T * C), alpha=scaling)
             # dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]
             dpp32 = _new((R, C), torch.float32, x)
             K.gemm(dBD, qv, dpp32, R, dh, B * T, lda=Rp, ldb=C, ldc=C, a_kstrided=True, b_kstrided=True, batch=H, zdiv=1,
                    sA=(B * T * Rp, 0), sB=(dh, 0), sC=(dh, 0), splitk=_auto_splitk(((R + 127) // 128) * H, B * T))
-            dpp = K.cast_f32_to_bf16(dpp32)
-            dWpos = _wgrad(dpp, pe, R, C, C)
-            du = K.colsum(t1, _zeros_f32(C, x), M, C, C)
-            dv = K.colsum(t2, _zeros_f32(C, x), M, C, C)
+            if learned:
+                dpe = dpp32
+            else:
+                dWpos = _wgrad(K.cast_f32_to_bf16(dpp32), pe, R, C, C)
+                du = K.colsum(t1, _zeros_f32(C, x), M, C, C)
+                dv = K.colsum(t2, _zeros_f32(C, x), M, C, C)
             K.add2_strided(t1, C, t2, C, dqkv, 3 * C, M, C)
         else:
             K.add2_strided(t1, C, torch.zeros_like(t1), C, dqkv, 3 * C, M, C)
@@ -292,7 +320,7 @@ class _RelPosMHSA(torch.autograd.Function):
         else:
             dg = db = None
             dx = K.scale_dropout(dxn, a=1.0, y=dy, b=1.0)
-        return (dx, dg, db, dWqkv, dbqkv, dWo, dbo, du, dv, dWpos) + (None,) * 14
+        return (dx, dg, db, dWqkv, dbqkv, dWo, dbo, du, dv, dWpos, None, None, None, dpe) + (None,) * 10
 
 
 def relpos_mhsa(x, ln_g, ln_b, wqkv, bqkv, wo, bo, u, v, wpos, pe, key_len, attn_mask, B, T, H, p_attn=0.0, p_out=0.0,

@@ -12,6 +12,7 @@ from ... import functional as F
 from ... import kernels as K
 from ...modules.conformer_layer import ConformerWithRelativePositionalEmbeddingEncoderLayer
 from ...modules.params import LayerNormParams, LinearParams
+from ...modules.learned_relative_positional_embedding import LearnedRelativePositionalEmbedding
 from ...modules.sinusoidal_relative_positional_embedding import SinusoidalRelativePositionalEmbedding
 from ...modules.speech_convolutions import ConvBNReLU
 from ...modules.transformer_layer import TransformerWithRelativePositionalEmbeddingEncoderLayer
@@ -33,18 +34,29 @@ class SpeechTransformerEncoderBase(nn.Module):
         self.embed_scale = 1.0 if (cfg.no_scale_embedding or self.fc0 is not None) else d ** 0.5
         if not cfg.encoder.relative_positional_embeddings and not cfg.no_token_positional_embeddings:
             raise NotImplementedError("absolute positional embeddings: the ASR recipes use relative positions")
-        if cfg.encoder.learned_pos and cfg.encoder.relative_positional_embeddings:
-            raise NotImplementedError("learned relative positions (recipes use sinusoidal: learned_pos false)")
         self.layernorm_embedding = LayerNormParams(d) if cfg.layernorm_embedding else None
-        rel = SinusoidalRelativePositionalEmbedding(d) if cfg.encoder.relative_positional_embeddings else None
-        self.rel_pos_embed = [rel]
+        nl = cfg.encoder.layers
+        if not cfg.encoder.relative_positional_embeddings:
+            rels = [None] * nl
+        elif cfg.encoder.learned_pos:
+            # speech_transformer_encoder.py:121-147: one learned table per layer unless shared across layers; dim = head
+            # dim when shared across heads; max_size = sub-sampled max_source_positions
+            dim = d // cfg.encoder.attention_heads if getattr(cfg.encoder, "share_learned_relative_positional_embeddings_across_heads", False) else d
+            size = int(self.output_lengths(cfg.max_source_positions)) if pre_encoder is not None else cfg.max_source_positions
+            if getattr(cfg.encoder, "share_learned_relative_positional_embeddings_across_layers", False):
+                rels = [LearnedRelativePositionalEmbedding(dim, max_size=size)] * nl
+            else:
+                rels = [LearnedRelativePositionalEmbedding(dim, max_size=size) for _ in range(nl)]
+        else:
+            rels = [SinusoidalRelativePositionalEmbedding(d)] * nl
+        self.rel_pos_embed = [rels[0]]
         if cfg.encoder.layer_type == "conformer":
             layer_cls = ConformerWithRelativePositionalEmbeddingEncoderLayer
         elif cfg.encoder.layer_type == "transformer":
             layer_cls = TransformerWithRelativePositionalEmbeddingEncoderLayer
         else:
             raise NotImplementedError(cfg.encoder.layer_type)
-        self.layers = nn.ModuleList([layer_cls(cfg, positional_embedding=rel) for _ in range(cfg.encoder.layers)])
+        self.layers = nn.ModuleList([layer_cls(cfg, positional_embedding=rels[i]) for i in range(nl)])
         self.num_layers = len(self.layers)
         if cfg.encoder.normalize_before and cfg.encoder.layer_type != "conformer":
             self.layer_norm = LayerNormParams(d)

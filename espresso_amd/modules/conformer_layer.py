@@ -11,6 +11,15 @@ from .. import functional as F
 from .params import BatchNormParams, ConvParams, LayerNormParams, LinearParams
 
 
+def _pe_table(pe, T, device, num_heads, embed_dim):
+    """bf16 constant slice (sinusoidal) or fp32 autograd slice (learned) of the relative table for T keys."""
+    if pe is None:
+        return None
+    if getattr(pe, "learnable", False):
+        return pe.table(T, device, num_heads=num_heads, embed_dim=embed_dim)
+    return pe.table(T, device)
+
+
 class FeedForwardModule(nn.Module):
     """fairseq/modules/conformer_layer.py:104-146 storage (layer_norm, w_1, w_2)."""
 
@@ -25,8 +34,14 @@ class MultiheadAttentionParams(nn.Module):
     """fairseq/modules/multihead_attention.py:66-217 storage in the reference's registration order
     (k_proj, v_proj, q_proj, out_proj, pos_bias_u, pos_bias_v, pos_proj)."""
 
-    def __init__(self, embed_dim, num_heads, relpos=True, kdim=None, vdim=None):
+    def __init__(self, embed_dim, num_heads, relpos=True, kdim=None, vdim=None, positional_embedding=None):
+        """relpos: sinusoidal relative positions (pos_bias_u / pos_bias_v / pos_proj).  positional_embedding: a LEARNED
+        relative table, registered as `positional_embedding` like the reference's nn.Embedding attribute (:149) and used
+        without biases or projection (:150-166)."""
         super().__init__()
+        if positional_embedding is not None and getattr(positional_embedding, "learnable", False):
+            self.positional_embedding = positional_embedding
+            relpos = False
         self.embed_dim, self.num_heads = embed_dim, num_heads
         kdim = embed_dim if kdim is None else kdim
         vdim = embed_dim if vdim is None else vdim
@@ -90,9 +105,10 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         d = cfg.encoder.embed_dim
         self.embed_dim = d
         self.num_heads = cfg.encoder.attention_heads
-        self.positional_embedding = [positional_embedding]  # not registered (shared, constant)
+        self.positional_embedding = [positional_embedding]  # not registered here (sinusoidal: shared constant; learned: owned by self_attn)
         self.ffn1 = FeedForwardModule(d, cfg.encoder.ffn_embed_dim)
-        self.self_attn = MultiheadAttentionParams(d, self.num_heads, relpos=positional_embedding is not None)
+        self.self_attn = MultiheadAttentionParams(d, self.num_heads, relpos=positional_embedding is not None,
+                                                  positional_embedding=positional_embedding)
         self.self_attn_layer_norm = LayerNormParams(d)
         self.conv_module = ConvolutionModule(d, cfg.encoder.depthwise_conv_kernel_size)
         self.ffn2 = FeedForwardModule(d, cfg.encoder.ffn_embed_dim)
@@ -108,7 +124,8 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         p_drop = cfg.dropout if tr else 0.0
         p_act = cfg.activation_dropout if tr else 0.0
         p_att = cfg.attention_dropout if tr else 0.0
-        if self.use_native_runtime and self.positional_embedding[0] is not None:
+        if (self.use_native_runtime and self.positional_embedding[0] is not None
+                and not getattr(self.positional_embedding[0], "learnable", False)):
             y = F.conformer_layer_native(x, self, key_len, attn_mask, self.positional_embedding[0].table(T, x.device), B, T,
                                          p_drop, p_act, p_att, tr)
             if tr:
@@ -123,7 +140,7 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         x = F.relpos_mhsa(x, self.self_attn_layer_norm.weight, self.self_attn_layer_norm.bias, wqkv, bqkv,
                           a.out_proj.weight, a.out_proj.bias, a.pos_bias_u, a.pos_bias_v,
                           a.pos_proj.weight if a.pos_proj is not None else None,
-                          pe.table(T, x.device) if pe is not None else None, key_len, attn_mask, B, T, self.num_heads,
+                          _pe_table(pe, T, x.device, self.num_heads, self.embed_dim), key_len, attn_mask, B, T, self.num_heads,
                           p_attn=p_att, p_out=p_drop, wqkv16=wqkv16)
         c = self.conv_module
         x = F.conv_module(x, c.layer_norm.weight, c.layer_norm.bias, c.pointwise_conv1.weight, c.depthwise_conv.weight,

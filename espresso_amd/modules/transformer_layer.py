@@ -5,7 +5,7 @@ espresso/modules/transformer_with_relative_positional_embedding_layer.py:17-43
 import torch.nn as nn
 
 from .. import functional as F
-from .conformer_layer import MultiheadAttentionParams
+from .conformer_layer import MultiheadAttentionParams, _pe_table
 from .params import LayerNormParams, LinearParams
 
 
@@ -20,7 +20,8 @@ class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         if not self.normalize_before:
             raise NotImplementedError("post-LN encoder layers (the recipes set normalize_before: true)")
         self.positional_embedding = [positional_embedding]
-        self.self_attn = MultiheadAttentionParams(d, self.num_heads, relpos=positional_embedding is not None)
+        self.self_attn = MultiheadAttentionParams(d, self.num_heads, relpos=positional_embedding is not None,
+                                                  positional_embedding=positional_embedding)
         self.self_attn_layer_norm = LayerNormParams(d)
         self.fc1 = LinearParams(d, cfg.encoder.ffn_embed_dim)
         self.fc2 = LinearParams(cfg.encoder.ffn_embed_dim, d)
@@ -39,7 +40,7 @@ class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         x = F.relpos_mhsa(x, self.self_attn_layer_norm.weight, self.self_attn_layer_norm.bias, wqkv, bqkv,
                           a.out_proj.weight, a.out_proj.bias, a.pos_bias_u, a.pos_bias_v,
                           a.pos_proj.weight if a.pos_proj is not None else None,
-                          pe.table(T, x.device) if pe is not None else None, key_len, attn_mask, B, T, self.num_heads,
+                          _pe_table(pe, T, x.device, self.num_heads, self.embed_dim), key_len, attn_mask, B, T, self.num_heads,
                           p_attn=p_att, p_out=p_drop, wqkv16=wqkv16)
         return F.ffn_module(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
                             self.fc2.weight, self.fc2.bias, act=self.activation_fn, p_act=p_act, p_out=p_drop, out_scale=1.0)

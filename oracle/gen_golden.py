@@ -62,10 +62,14 @@ def build_ref_encoder(cfg, vocab):
     return SpeechTransformerEncoderForPrediction(cfg, pre_encoder=pre, input_size=20 * ch[-1], vocab_size=vocab)
 
 
-def encoder_fixture(layer_type, name):
+def encoder_fixture(layer_type, name, learned_pos=False):
     torch.manual_seed(1234)
     V = 40
     cfg = ref_config(layer_type)
+    if learned_pos:  # LibriSpeech enc-dec recipes: learned relative positions, one table per layer, full embedding dim
+        cfg.encoder.learned_pos = True
+        cfg.encoder.share_learned_relative_positional_embeddings_across_layers = False
+        cfg.encoder.share_learned_relative_positional_embeddings_across_heads = False
     enc = build_ref_encoder(cfg, V)
     # make BN affine / running stats and biases non-trivial so the check exercises them
     with torch.no_grad():
@@ -507,6 +511,9 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "encdec":
         encdec_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "learnedpos":
+        encoder_fixture("transformer", "ref_transformer_learnedpos_ctc_tiny", learned_pos=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()

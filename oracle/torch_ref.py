@@ -32,6 +32,9 @@ def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
     k = F.linear(x, sd[prefix + "k_proj.weight"], sd[prefix + "k_proj.bias"])
     v = F.linear(x, sd[prefix + "v_proj.weight"], sd[prefix + "v_proj.bias"])
     relpos = (prefix + "pos_bias_u") in sd
+    learned = (prefix + "positional_embedding.weight") in sd  # learned relative table: used as is, plain queries (:806-815)
+    if learned:
+        qv = (q * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
     if relpos:
         qv = ((q + sd[prefix + "pos_bias_v"]) * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
         q = q + sd[prefix + "pos_bias_u"]
@@ -39,9 +42,16 @@ def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
     k = k.contiguous().view(T, B * H, dh).transpose(0, 1)
     v = v.contiguous().view(T, B * H, dh).transpose(0, 1)
     w = torch.bmm(q, k.transpose(1, 2))
-    if relpos:
-        pe = sinusoidal_rel_pe(T, C)
-        pe = F.linear(pe, sd[prefix + "pos_proj.weight"])  # (2T-1, C), same for every batch element
+    if relpos or learned:
+        if learned:
+            tab = sd[prefix + "positional_embedding.weight"]  # learned_relative_positional_embedding.py:71-80: centre slice
+            start = tab.shape[0] // 2 - T + 1
+            pe = tab[start: start + 2 * T - 1]
+            if pe.shape[1] != C:
+                pe = pe.repeat(1, H)
+        else:
+            pe = sinusoidal_rel_pe(T, C)
+            pe = F.linear(pe, sd[prefix + "pos_proj.weight"])  # (2T-1, C), same for every batch element
         pe = pe.view(1, 2 * T - 1, H, dh).expand(B, -1, -1, -1).transpose(1, 2).reshape(B * H, 2 * T - 1, dh)
         raw = torch.bmm(qv, pe.transpose(1, 2))  # (BH, T, 2T-1)
         i = torch.arange(T).unsqueeze(1)

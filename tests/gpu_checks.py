@@ -74,7 +74,7 @@ class _Task:
         assert len(self.target_dictionary) == V
 
 
-def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128):
+def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128, learned_pos=False):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
     from espresso_amd.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderModel
 
@@ -82,6 +82,7 @@ def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128):
     e = cfg.encoder
     e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = embed_dim, ffn, 2, heads
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, layer_type
+    e.learned_pos = learned_pos
     e.conv_channels = "[64, 64, 16, 16]"
     cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
     cfg.layernorm_embedding = True
@@ -104,7 +105,9 @@ def check_encoder_vs_reference(layer_type="conformer"):
 
     name = f"ref_{layer_type}_ctc_tiny"
     g, sd, grads, bn_after = load_fixture(name)
-    model = build_tiny_model(layer_type).to(DEV)
+    learned = layer_type.endswith("_learnedpos")
+    layer_type = layer_type.split("_")[0]
+    model = build_tiny_model(layer_type, learned_pos=learned).to(DEV)
     load_ref_state(model, sd)
     feats = torch.from_numpy(g["feats"]).to(DEV)
     lengths = torch.from_numpy(g["lengths"]).to(DEV)

@@ -58,7 +58,7 @@ def test_adam_clip():
     assert r["bf16_exact"], r
 
 
-@pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
+@pytest.mark.parametrize("layer_type", ["conformer", "transformer", "transformer_learnedpos"])
 def test_encoder_vs_reference_fixture(layer_type):
     r = G.check_encoder_vs_reference(layer_type)
     print(r)
@@ -190,7 +190,7 @@ def test_transducer_vs_reference_fixture():
     r = G.check_transducer_vs_reference()
     print(r)
     assert r["out_lengths_equal"], r
-    tol = 1.5e-2 * max(1.0, r["eval_logits_ref_max"])
+    tol = 2.5e-2 * max(1.0, r["eval_logits_ref_max"])  # bf16 logits (half an ulp = 0.4 %) on top of the bf16 encoder / joint
     assert r["eval_logits_abs"] < tol and r["train_logits_abs"] < tol, r
     assert r["fc_out_max"] < 1e-2, r                       # output layer: no kink upstream of it
     assert abs(r["worst_scale"][1] - 1.0) < 7e-2, r        # every gradient has the right size and direction ...

@@ -15,9 +15,10 @@ def _load(golden_dir, name):
     return g, sd
 
 
-@pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
+@pytest.mark.parametrize("layer_type", ["conformer", "transformer", "transformer_learnedpos"])
 def test_encoder_restatement_matches_reference(golden_dir, layer_type):
     g, sd = _load(golden_dir, f"ref_{layer_type}_ctc_tiny")
+    layer_type = layer_type.split("_")[0]
     feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
     lo, ol = torch_ref.encoder(feats, lengths, sd, H=4, layer_type=layer_type, training=False)
     assert ol.tolist() == g["out::out_lengths"].tolist()
