@@ -1,7 +1,8 @@
-"""`label_smoothed_cross_entropy_v2` (uniform smoothing) — interface and bookkeeping of
+"""`label_smoothed_cross_entropy_v2` — interface and bookkeeping of
 espresso/criterions/label_smoothed_cross_entropy_v2.py:158-243 on the fused HIP kernel
-(log-sum-exp + target gather + row sum + gradient in one pass per row; pad rows zeroed).
-Unigram / temporal smoothing (:49-92) are not implemented yet (recipes use `uniform`)."""
+(log-sum-exp + target gather + smoothing term + gradient in one pass per row; pad rows zeroed).
+Smoothing types (:49-119): `uniform`, `unigram` (dictionary counts + pseudo count, :152-155) and `temporal`
+(neighbouring targets 5:2, the WSJ recipe) are all evaluated inside the kernel."""
 import math
 
 import torch
@@ -12,9 +13,14 @@ from ..registry import register_criterion
 
 @register_criterion("label_smoothed_cross_entropy_v2")
 class LabelSmoothedCrossEntropyV2Criterion:
-    def __init__(self, task, sentence_avg=True, label_smoothing=0.1, smoothing_type="uniform", **unused):
-        if smoothing_type != "uniform":
-            raise NotImplementedError(f"smoothing_type={smoothing_type}")
+    def __init__(self, task, sentence_avg=True, label_smoothing=0.1, smoothing_type="uniform", unigram_pseudo_count=1.0, **unused):
+        if smoothing_type not in ("uniform", "unigram", "temporal"):
+            raise ValueError("Unsupported smoothing type: {}".format(smoothing_type))
+        self.smoothing_type = smoothing_type
+        self.unigram_tensor = None
+        if smoothing_type == "unigram":
+            u = torch.tensor(task.target_dictionary.count, dtype=torch.float32) + unigram_pseudo_count
+            self.unigram_tensor = u / u.sum()
         self.task = task
         self.sentence_avg = sentence_avg
         self.eps = label_smoothing
@@ -34,7 +40,13 @@ class LabelSmoothedCrossEntropyV2Criterion:
         if logits is None:
             logits = logits3.reshape(-1, logits3.shape[-1])
         target = sample["target"].reshape(-1).to(torch.int32).contiguous()
-        loss, nll = F.label_smoothed_ce(logits, target, self.padding_idx, self.eps)
+        prior = None
+        if self.unigram_tensor is not None:
+            if self.unigram_tensor.device != logits.device:
+                self.unigram_tensor = self.unigram_tensor.to(logits.device)
+            prior = self.unigram_tensor
+        loss, nll = F.label_smoothed_ce(logits, target, self.padding_idx, self.eps, self.smoothing_type, prior,
+                                        sample["target"].shape[1])
         sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
         logging_output = {"loss": loss.detach(), "nll_loss": nll.detach(), "ntokens": sample["ntokens"],
                           "nsentences": sample["target"].size(0), "sample_size": sample_size}

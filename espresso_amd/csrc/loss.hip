@@ -254,12 +254,16 @@ __global__ void ctc_collapse_kernel(const int* __restrict__ best, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// Label-smoothed CE (uniform).  logits [M][ld] (bf16 or fp32), target[M] int64-as-int32 pairs -> we take int32.
-// out_loss[0] += sum loss, out_loss[1] += sum nll ; optional dlogits = scale * dloss/dlogits ; optional lprobs
+// Label-smoothed CE — espresso/criterions/label_smoothed_cross_entropy_v2.py:49-119.  logits [M][ld] (bf16 or fp32), int32
+// targets.  smoothing: 0 uniform (eps_i = eps/(V-1): (1-eps-eps_i) nll + eps_i * -sum_v lprob_v), 1 unigram (prior[v] over
+// the vocabulary: (1-eps) nll + eps * -sum_v prior_v lprob_v), 2 temporal (the previous / next two targets of the same
+// sentence with weights 2:5:5:2, pad neighbours dropped, normalised: row m = b*U + u).  out_loss[0] += sum loss,
+// out_loss[1] += sum nll; optional dlogits = scale * dloss/dlogits.
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void lsce_kernel(const TIn* __restrict__ logits, long ld, const int* __restrict__ target,
                                                    float* __restrict__ out_loss, TOut* __restrict__ dlogits, long ld_out,
-                                                   int V, int pad_idx, float eps, float scale) {
+                                                   int V, int pad_idx, float eps, float scale, int smoothing,
+                                                   const float* __restrict__ prior, int U) {
   __shared__ float sm[16];
   const long row = blockIdx.x;
   const TIn* x = logits + row * ld;
@@ -269,35 +273,75 @@ __global__ __launch_bounds__(256) void lsce_kernel(const TIn* __restrict__ logit
     if (dl) for (int c = threadIdx.x; c < V; c += 256) { if constexpr (sizeof(TOut) == 2) dl[c] = 0; else dl[c] = 0.f; }
     return;
   }
+  auto ld1 = [&](int c) -> float { if constexpr (sizeof(TIn) == 2) return bf2f(x[c]); else return x[c]; };
   float mx = -INFINITY, tot = 0.f;
   for (int c = threadIdx.x; c < V; c += 256) {
-    float v; if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
+    const float v = ld1(c);
     mx = fmaxf(mx, v);
-    tot += v;
+    tot += smoothing == 1 ? prior[c] * v : v;  // sum_v w_v x_v for the dense weightings
   }
   mx = block_max(mx, sm);
   tot = block_sum(tot, sm);
   float s = 0.f;
-  for (int c = threadIdx.x; c < V; c += 256) {
-    float v; if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
-    s += expf(v - mx);
-  }
+  for (int c = threadIdx.x; c < V; c += 256) s += expf(ld1(c) - mx);
   s = block_sum(s, sm);
   const float lse = mx + logf(s);
-  float xt; if constexpr (sizeof(TIn) == 2) xt = bf2f(x[tgt]); else xt = x[tgt];
-  const float nll = lse - xt;
-  const float smooth = (float)V * lse - tot;  // -sum_c lprob_c
-  const float eps_i = eps / (float)(V - 1);
-  const float wn = 1.f - eps - eps_i;
+  const float nll = lse - ld1(tgt);
+  // temporal neighbours (at most four non-zero weights)
+  int nb[4] = {-1, -1, -1, -1};
+  float nw[4] = {0.f, 0.f, 0.f, 0.f};
+  float wsum = 1.f;
+  float smooth, wn, we;
+  if (smoothing == 2) {
+    const int u = (int)(row % U);
+    const int off[4] = {-2, -1, 1, 2};
+    const float wt[4] = {2.f, 5.f, 5.f, 2.f};
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int uu = u + off[k];
+      if (uu < 0 || uu >= U) continue;
+      const int t = target[row + off[k]];
+      if (t == pad_idx) continue;
+      nb[k] = t;
+      nw[k] = wt[k];
+      z += wt[k];
+    }
+    smooth = 0.f;
+    if (z > 0.f) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (nb[k] >= 0) { nw[k] /= z; smooth += nw[k] * (lse - ld1(nb[k])); }
+    } else {
+      wsum = 0.f;
+    }
+    wn = 1.f - eps;
+    we = eps;
+  } else if (smoothing == 1) {
+    smooth = lse - tot;  // prior sums to one
+    wn = 1.f - eps;
+    we = eps;
+  } else {
+    smooth = (float)V * lse - tot;  // -sum_c lprob_c
+    we = eps / (float)(V - 1);
+    wn = 1.f - eps - we;
+    wsum = (float)V;
+  }
   if (threadIdx.x == 0) {
-    atomicAdd(out_loss + 0, wn * nll + eps_i * smooth);
+    atomicAdd(out_loss + 0, wn * nll + we * smooth);
     atomicAdd(out_loss + 1, nll);
   }
   if (dl) {
-    const float k = wn + eps_i * (float)V;
+    // d/dz [wn (lse - z_t) + we (W lse - sum_v w_v z_v)] = (wn + we W) softmax - wn onehot_t - we w
+    const float k = wn + we * wsum;
     for (int c = threadIdx.x; c < V; c += 256) {
-      float v; if constexpr (sizeof(TIn) == 2) v = bf2f(x[c]); else v = x[c];
-      float g = expf(v - lse) * k - eps_i - (c == tgt ? wn : 0.f);
+      float g = expf(ld1(c) - lse) * k - (c == tgt ? wn : 0.f);
+      if (smoothing == 0) g -= we;
+      else if (smoothing == 1) g -= we * prior[c];
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (nb[q] == c) g -= we * nw[q];
+      }
       g *= scale;
       if constexpr (sizeof(TOut) == 2) dl[c] = f2bf(g); else dl[c] = g;
     }
@@ -374,23 +418,16 @@ extern "C" int ea_ctc_grad(const float* lprobs, const void* workspace, const flo
 
 extern "C" int ea_label_smoothed_ce(const void* logits, long ld, int logits_bf16, const int* target,
                                     float* out_loss /*[2] zeroed*/, void* dlogits, long ld_out, int dlogits_bf16, long M,
-                                    int V, int pad_idx, float eps, float grad_scale, hipStream_t stream) {
+                                    int V, int pad_idx, float eps, float grad_scale, int smoothing, const float* prior,
+                                    int tgt_len, hipStream_t stream) {
   if (M <= 0) return 0;
+  if (smoothing < 0 || smoothing > 2 || (smoothing == 1 && !prior) || (smoothing == 2 && (tgt_len <= 0 || M % tgt_len))) return -2;
   dim3 g((unsigned)M), blk(256);
-  if (logits_bf16) {
-    if (dlogits_bf16 || !dlogits)
-      hipLaunchKernelGGL((lsce_kernel<bf16_t, bf16_t>), g, blk, 0, stream, (const bf16_t*)logits, ld, target, out_loss,
-                         (bf16_t*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
-    else
-      hipLaunchKernelGGL((lsce_kernel<bf16_t, float>), g, blk, 0, stream, (const bf16_t*)logits, ld, target, out_loss,
-                         (float*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
-  } else {
-    if (dlogits_bf16 && dlogits)
-      hipLaunchKernelGGL((lsce_kernel<float, bf16_t>), g, blk, 0, stream, (const float*)logits, ld, target, out_loss,
-                         (bf16_t*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
-    else
-      hipLaunchKernelGGL((lsce_kernel<float, float>), g, blk, 0, stream, (const float*)logits, ld, target, out_loss,
-                         (float*)dlogits, ld_out, V, pad_idx, eps, grad_scale);
-  }
+#define EA_LSCE(TI, TO)                                                                                               \
+  hipLaunchKernelGGL((lsce_kernel<TI, TO>), g, blk, 0, stream, (const TI*)logits, ld, target, out_loss, (TO*)dlogits, ld_out, V, \
+                     pad_idx, eps, grad_scale, smoothing, prior, tgt_len)
+  if (logits_bf16) { if (dlogits_bf16 || !dlogits) EA_LSCE(bf16_t, bf16_t); else EA_LSCE(bf16_t, float); }
+  else { if (dlogits_bf16 && dlogits) EA_LSCE(float, bf16_t); else EA_LSCE(float, float); }
+#undef EA_LSCE
   return EA_CHECK_LAUNCH();
 }

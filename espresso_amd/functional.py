@@ -433,31 +433,33 @@ class _LabelSmoothedCE(torch.autograd.Function):
     """(sum loss, sum nll) over non-pad rows — espresso/criterions/label_smoothed_cross_entropy_v2.py:94-119."""
 
     @staticmethod
-    def forward(ctx, logits, target, pad_idx, eps):
+    def forward(ctx, logits, target, pad_idx, eps, smoothing="uniform", prior=None, tgt_len=0):
         M, V = logits.shape
         if logits.stride(1) != 1:
             logits = logits.contiguous()
-        out, _ = K.label_smoothed_ce(logits, logits.stride(0), target, M, V, pad_idx, eps, want_grad=False)
-        ctx.save_for_backward(logits, target)
-        ctx.cfg = (pad_idx, eps)
+        out, _ = K.label_smoothed_ce(logits, logits.stride(0), target, M, V, pad_idx, eps, want_grad=False, smoothing=smoothing,
+                                     prior=prior, tgt_len=tgt_len)
+        ctx.save_for_backward(logits, target, prior)
+        ctx.cfg = (pad_idx, eps, smoothing, tgt_len)
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, dloss, _dnll):
-        logits, target = ctx.saved_tensors
-        pad_idx, eps = ctx.cfg
+        logits, target, prior = ctx.saved_tensors
+        pad_idx, eps, smoothing, tgt_len = ctx.cfg
         M, V = logits.shape
         bf = logits.dtype == torch.bfloat16
         # grad scale read on the host would sync; the loss scale is 1 in fp32/bf16 training, so apply
         # it lazily with the streaming kernel only when a non-unit scale tensor is passed.
         _, dl = K.label_smoothed_ce(logits, logits.stride(0), target, M, V, pad_idx, eps, want_grad=True, grad_bf16=bf,
-                                    grad_ld=_pad8(V) if bf else V)
+                                    grad_ld=_pad8(V) if bf else V, smoothing=smoothing, prior=prior, tgt_len=tgt_len)
         g = dl if dl.shape[1] == V else dl[:, :V]
-        return g * dloss.to(g.dtype), None, None, None
+        return g * dloss.to(g.dtype), None, None, None, None, None, None
 
 
-def label_smoothed_ce(logits, target, pad_idx, eps):
-    return _LabelSmoothedCE.apply(logits, target, pad_idx, eps)
+def label_smoothed_ce(logits, target, pad_idx, eps, smoothing="uniform", prior=None, tgt_len=0):
+    """smoothing "uniform" | "unigram" (prior fp32 [V]) | "temporal" (rows are b*tgt_len + u)."""
+    return _LabelSmoothedCE.apply(logits, target, pad_idx, eps, smoothing, prior, tgt_len)
 
 
 # ------------------------------------------------------------------------------------------------

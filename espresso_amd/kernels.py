@@ -391,8 +391,11 @@ def ctc_loss_grad(lprobs, ws, nll, targets, in_len, tgt_len, B, T, V, Lmax, blan
     return dl
 
 
+SMOOTHING = {"uniform": 0, "unigram": 1, "temporal": 2}
+
+
 def label_smoothed_ce(logits, ld, target, M, V, pad_idx, eps, want_grad=True, grad_bf16=True, grad_scale=1.0,
-                      grad_ld=None):
+                      grad_ld=None, smoothing="uniform", prior=None, tgt_len=0):
     assert target.dtype == torch.int32
     dev = logits.device
     out = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -402,7 +405,8 @@ def label_smoothed_ce(logits, ld, target, M, V, pad_idx, eps, want_grad=True, gr
         dl = torch.zeros(M, grad_ld, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=dev)
     check(
         _lib.lib().ea_label_smoothed_ce(_p(logits), ld, int(logits.dtype == torch.bfloat16), _p(target), _p(out),
-                                        _p(dl), grad_ld, int(grad_bf16), M, V, pad_idx, eps, grad_scale, _stream()),
+                                        _p(dl), grad_ld, int(grad_bf16), M, V, pad_idx, eps, grad_scale, SMOOTHING[smoothing],
+                                        _p(prior), tgt_len, _stream()),
         "ea_label_smoothed_ce",
     )
     return out, dl

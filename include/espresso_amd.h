@@ -222,9 +222,12 @@ int ea_ctc_grad(const float* lprobs, const void* workspace, const float* nll, co
 int ea_ctc_greedy_decode(const void* x, long ld, int x_bf16, const int* in_len, int* best, float* bestv, int* tokens,
                          int* align, int* out_len, float* score, int B, int T, int V, int blank, int pad,
                          ea_stream_t stream);
+/* Label-smoothed CE — espresso/criterions/label_smoothed_cross_entropy_v2.py:49-119.  smoothing 0 = uniform, 1 = unigram
+ * (prior fp32 [V], sums to one), 2 = temporal (neighbouring targets of the same sentence, weights 2:5:5:2; rows are
+ * b*tgt_len + u).  out_loss[0] += sum loss, out_loss[1] += sum nll (pad rows skipped). */
 int ea_label_smoothed_ce(const void* logits, long ld, int logits_bf16, const int* target, float* out_loss,
                          void* dlogits, long ld_out, int dlogits_bf16, long M, int V, int pad_idx, float eps,
-                         float grad_scale, ea_stream_t stream);
+                         float grad_scale, int smoothing, const float* prior, int tgt_len, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Front-end: Kaldi fbank + global CMVN + SpecAugment + padding — espresso/tools/utils.py:426-454

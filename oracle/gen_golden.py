@@ -476,8 +476,23 @@ def label_smoothing_fixture():
     lg = logits.clone().requires_grad_(True)
     loss, _ = label_smoothed_nll_loss(torch.log_softmax(lg, -1), target.unsqueeze(-1), 0.1, ignore_index=1, reduce=True)
     loss.backward()
-    np.savez(os.path.join(OUT, "label_smoothing.npz"), logits=logits.numpy(), target=target.numpy(),
-             dlogits=lg.grad.numpy(), **{k: np.array(v) for k, v in res.items()})
+    # unigram / temporal smoothing (:49-119): rows are (b, u) with B = 1 sentence of M tokens
+    from espresso.criterions.label_smoothed_cross_entropy_v2 import temporal_label_smoothing_prob_mask
+    extra = {}
+    prior = torch.rand(V) + 0.1
+    prior = (prior / prior.sum()).unsqueeze(-1)
+    target_uniform = target.clone()
+    target = target.clone()
+    target[20] = target[18]  # equal neighbours: their weights must add up
+    for kind, kw in (("unigram", dict(unigram_tensor=prior)),
+                     ("temporal", dict(prob_mask=temporal_label_smoothing_prob_mask(lprobs.view(1, M, V), target.view(1, M), 1)))):
+        lg2 = logits.clone().requires_grad_(True)
+        loss2, nll2 = label_smoothed_nll_loss(torch.log_softmax(lg2, -1), target.unsqueeze(-1), 0.1, ignore_index=1, reduce=True,
+                                              smoothing_type=kind, **kw)
+        loss2.backward()
+        extra[f"{kind}_loss"], extra[f"{kind}_nll"], extra[f"{kind}_dlogits"] = np.array(loss2.item()), np.array(nll2.item()), lg2.grad.numpy()
+    np.savez(os.path.join(OUT, "label_smoothing.npz"), logits=logits.numpy(), target=target_uniform.numpy(), target2=target.numpy(),
+             prior=prior.squeeze(-1).numpy(), dlogits=lg.grad.numpy(), **{k: np.array(v) for k, v in res.items()}, **extra)
     print("label smoothing", res)
 
 

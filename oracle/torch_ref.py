@@ -205,16 +205,36 @@ def ctc_nll_numpy(lprobs_tv, target, blank=0):
     return np.inf if m == -np.inf else -(m + np.log(sum(np.exp(v - m) for v in tail)))
 
 
-def label_smoothed_nll(logits, target, eps, pad_idx):
-    """espresso/criterions/label_smoothed_cross_entropy_v2.py:94-119 (uniform)."""
+def label_smoothed_nll(logits, target, eps, pad_idx, smoothing="uniform", prior=None, tgt_len=None):
+    """espresso/criterions/label_smoothed_cross_entropy_v2.py:49-119: uniform, unigram (prior over the vocabulary) and
+    temporal smoothing (previous / next two targets of the sentence, weights 2:5:5:2, pad neighbours dropped, normalised;
+    rows are b*tgt_len + u)."""
     lp = torch.log_softmax(logits.float(), -1)
     nll = -lp.gather(-1, target.unsqueeze(-1)).squeeze(-1)
-    smooth = -lp.sum(-1)
+    if smoothing == "uniform":
+        smooth = -lp.sum(-1)
+    elif smoothing == "unigram":
+        smooth = -(lp * prior.to(lp).view(1, -1)).sum(-1)
+    else:
+        M, V = lp.shape
+        U = tgt_len
+        w = torch.zeros(M, V)
+        t = target.view(-1, U)
+        for off, wt in ((-2, 2.0), (-1, 5.0), (1, 5.0), (2, 2.0)):
+            for b in range(t.shape[0]):
+                for u in range(U):
+                    if 0 <= u + off < U and int(t[b, u + off]) != pad_idx:
+                        w[b * U + u, int(t[b, u + off])] += wt
+        z = w.sum(-1, keepdim=True)
+        w = w / torch.where(z == 0, torch.ones_like(z), z)
+        smooth = -(lp * w).sum(-1)
     m = target.eq(pad_idx)
     nll = nll.masked_fill(m, 0.0)
     smooth = smooth.masked_fill(m, 0.0)
-    eps_i = eps / (lp.size(-1) - 1)
-    return (1.0 - eps - eps_i) * nll.sum() + eps_i * smooth.sum(), nll.sum()
+    if smoothing == "uniform":
+        eps_i = eps / (lp.size(-1) - 1)
+        return (1.0 - eps - eps_i) * nll.sum() + eps_i * smooth.sum(), nll.sum()
+    return (1.0 - eps) * nll.sum() + eps * smooth.sum(), nll.sum()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -952,3 +952,21 @@ def check_lm_fusion_beam_search():
     got = torch.stack(got, 1)
     res["forced_decode_pos_score_abs"] = float((got[:, :-1] - ref_pos[:, :-1]).abs().max())  # last = forced EOS at max_len
     return res
+
+
+def check_label_smoothing_kernel():
+    """ea_label_smoothed_ce (uniform / unigram / temporal) vs the reference's label_smoothed_nll_loss outputs (fixture)."""
+    from espresso_amd import functional as F
+
+    g = np.load(os.path.join(GOLD, "label_smoothing.npz"))
+    res = {}
+    for kind in ("uniform", "unigram", "temporal"):
+        tgt = torch.from_numpy(g["target" if kind == "uniform" else "target2"]).to(DEV).to(torch.int32)
+        x = torch.from_numpy(g["logits"]).to(DEV).requires_grad_(True)
+        prior = torch.from_numpy(g["prior"]).to(DEV) if kind == "unigram" else None
+        loss, nll = F.label_smoothed_ce(x, tgt, 1, 0.1, kind, prior, tgt.numel())
+        loss.backward()
+        ref_loss = float(g["loss_0.1"] if kind == "uniform" else g[f"{kind}_loss"])
+        ref_grad = torch.from_numpy(g["dlogits" if kind == "uniform" else f"{kind}_dlogits"])
+        res[kind] = {"loss_rel": abs(float(loss) - ref_loss) / abs(ref_loss), "grad_abs": float((x.grad.cpu() - ref_grad).abs().max())}
+    return res

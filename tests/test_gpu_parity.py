@@ -230,3 +230,11 @@ def test_lm_fusion_beam_search_vs_reference():
     assert r["forced_decode_pos_score_abs"] < 0.1, r
     for tag in ("lm05", "lm10_eosf"):
         assert r[tag]["score_abs"] < 3e-2, r
+
+
+def test_label_smoothing_kernel_all_types_vs_reference():
+    """fp32 logits: loss 1e-5 relative, gradient 1e-5 absolute (north-star fp32 tolerance 1e-3)"""
+    r = G.check_label_smoothing_kernel()
+    print(r)
+    for kind, v in r.items():
+        assert v["loss_rel"] < 1e-5 and v["grad_abs"] < 1e-5, (kind, r)

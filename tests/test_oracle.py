@@ -62,6 +62,19 @@ def test_label_smoothing_matches_reference(golden_dir):
         assert float(nll) == pytest.approx(float(g[f"nll_{eps}"]), rel=1e-6)
 
 
+@pytest.mark.parametrize("kind", ["unigram", "temporal"])
+def test_label_smoothing_variants_match_reference(golden_dir, kind):
+    g = np.load(os.path.join(golden_dir, "label_smoothing.npz"))
+    logits = torch.from_numpy(g["logits"]).requires_grad_(True)
+    target = torch.from_numpy(g["target2"])
+    loss, nll = torch_ref.label_smoothed_nll(logits, target, 0.1, 1, smoothing=kind, prior=torch.from_numpy(g["prior"]),
+                                             tgt_len=target.numel())
+    assert float(loss) == pytest.approx(float(g[f"{kind}_loss"]), rel=1e-6)
+    assert float(nll) == pytest.approx(float(g[f"{kind}_nll"]), rel=1e-6)
+    loss.backward()
+    assert float((logits.grad - torch.from_numpy(g[f"{kind}_dlogits"])).abs().max()) < 1e-6
+
+
 def test_fbank_frame_count_matches_reference_formula():
     """espresso/tools/utils.py:457-486 pins only the frame count of the torchaudio fbank."""
     from espresso_amd.tools.utils import num_samples_to_num_frames
