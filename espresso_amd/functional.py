@@ -918,15 +918,18 @@ def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=0):
 # ------------------------------------------------------------------------------------------------ LSTM
 class _LSTMLayer(torch.autograd.Function):
     """One LSTM layer over a whole (teacher-forced) sequence — the time loop of
-    espresso/models/speech_lstm.py:846-893 for one `LSTMCell` (fairseq/models/lstm.py:LSTMCell = torch.nn.LSTMCell).
+    espresso/models/speech_lstm.py:846-893 for one `LSTMCell` (fairseq/models/lstm.py:LSTMCell = torch.nn.LSTMCell), and one
+    direction of the packed `nn.LSTM` of the BiLSTM encoder (:470-520).
 
     x: bf16 [U*B][I] time-major rows (t*B + b).  Returns hs bf16 [U*B][H] (and the final (h, c) fp32).
+    reverse: walk t = U-1 .. 0.  frozen: uint8 [U][B], 1 where t >= length[b] (packed-sequence semantics: the state of such a
+    row does not advance, its output is 0 and it receives no gradient; requires zero initial state).
     The input projection of ALL steps is one GEMM; each step then costs one small recurrent GEMM (fp32 output with the
-    input projection as fp32 residual) + one element-wise cell kernel.  Backward walks the steps in reverse with one
-    recurrent dgrad GEMM per step and computes every weight gradient with a single GEMM over all steps."""
+    input projection as fp32 residual) + one element-wise cell kernel.  Backward walks the steps in the opposite order with
+    one recurrent dgrad GEMM per step and computes every weight gradient with a single GEMM over all steps."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih16, w_hh16, h0, c0, B, U):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih16, w_hh16, h0, c0, B, U, reverse=False, frozen=None):
         H = w_hh.shape[1]
         I = w_ih.shape[1]
         dev = x.device
@@ -941,54 +944,194 @@ class _LSTMLayer(torch.autograd.Function):
         h_last = torch.empty(B, H, dtype=torch.float32, device=dev)
         h0_16 = K.cast_f32_to_bf16(h0.float().contiguous()) if h0 is not None else None
         c0 = c0.float().contiguous() if c0 is not None else None
-        for t in range(U):
-            if t == 0 and h0_16 is None:
-                Gt = gx[0:B]
+        assert frozen is None or (h0 is None and c0 is None), "packed sequences start from the zero state"
+        order = range(U - 1, -1, -1) if reverse else range(U)
+        prev = None
+        for n, t in enumerate(order):
+            if prev is None and h0_16 is None:
+                Gt = gx[t * B:(t + 1) * B]
             else:
-                hp = h0_16 if t == 0 else hs[(t - 1) * B: t * B]
+                hp = h0_16 if prev is None else hs[prev * B:(prev + 1) * B]
                 K.gemm(hp, w_hh16, G, B, 4 * H, H, lda=H, ldb=H, ldc=4 * H, resid=gx, ldr=4 * H, r_off=t * B * 4 * H)
                 Gt = G
-            K.lstm_cell_fwd(Gt, c0 if t == 0 else cs[t - 1], cs[t], h_last if t == U - 1 else None, hs[t * B:(t + 1) * B], H, act[t], B, H)
-        ctx.save_for_backward(x, hs, cs, act, w_ih16, w_hh16, h0_16, c0)
-        ctx.dims = (B, U, H, I, b_ih is not None, h0 is not None)
-        return hs, h_last, cs[U - 1]
+            K.lstm_cell_fwd(Gt, c0 if prev is None else cs[prev], cs[t], h_last if n == U - 1 else None, hs[t * B:(t + 1) * B], H,
+                            act[t], B, H, keep_row=frozen[t] if frozen is not None else None, frozen_out_zero=frozen is not None)
+            prev = t
+        ctx.save_for_backward(x, hs, cs, act, w_ih16, w_hh16, h0_16, c0, frozen)
+        ctx.dims = (B, U, H, I, b_ih is not None, h0 is not None, reverse)
+        return hs, h_last, cs[prev]
 
     @staticmethod
     def backward(ctx, dhs, dh_last, dc_last):
-        x, hs, cs, act, w_ih16, w_hh16, h0_16, c0 = ctx.saved_tensors
-        B, U, H, I, has_bias, has_h0 = ctx.dims
+        x, hs, cs, act, w_ih16, w_hh16, h0_16, c0, frozen = ctx.saved_tensors
+        B, U, H, I, has_bias, has_h0, reverse = ctx.dims
         dev = x.device
         dhs = dhs.contiguous() if dhs is not None else None
         dG = torch.empty(U * B, 4 * H, dtype=torch.bfloat16, device=dev)
         dh_rec = dh_last.float().contiguous().clone() if dh_last is not None else None
         dc = dc_last.float().contiguous().clone() if dc_last is not None else None
-        for t in range(U - 1, -1, -1):
+        order = list(range(U - 1, -1, -1) if reverse else range(U))  # forward processing order
+        for n in range(U - 1, -1, -1):
+            t = order[n]
+            tp = order[n - 1] if n > 0 else None  # the step whose state fed this one
             dc_new = torch.empty(B, H, dtype=torch.float32, device=dev)
             K.lstm_cell_bwd(dhs[t * B:(t + 1) * B] if dhs is not None else None, H, dh_rec, dc, act[t],
-                            c0 if t == 0 else cs[t - 1], cs[t], dG[t * B:(t + 1) * B], 4 * H, dc_new, B, H)
+                            c0 if tp is None else cs[tp], cs[t], dG[t * B:(t + 1) * B], 4 * H, dc_new, B, H,
+                            frozen=frozen[t] if frozen is not None else None)
             dc = dc_new
-            if t > 0 or has_h0:
-                # dh_{t-1} (recurrent part) = dG_t W_hh
+            if tp is not None or has_h0:
+                # gradient of the recurrent input h_{prev} = dG_t W_hh
                 dh_rec = torch.empty(B, H, dtype=torch.float32, device=dev)
                 K.gemm(dG, w_hh16, dh_rec, B, H, 4 * H, lda=4 * H, ldb=H, ldc=H, b_kstrided=True, a_off=t * B * 4 * H)
         dx = torch.empty(U * B, I, dtype=torch.bfloat16, device=dev)
         K.gemm(dG, w_ih16, dx, U * B, I, 4 * H, lda=4 * H, ldb=I, ldc=I, b_kstrided=True)
         dw_ih = _wgrad(dG, x, U * B, 4 * H, I)
-        # dW_hh = sum_t dG_t^T h_{t-1}: steps 1..U-1 pair with hs[0..U-2]; step 0 pairs with h0 (zero when absent)
+        # dW_hh = sum_t dG_t^T h_{prev(t)}: in forward order steps 1..U-1 pair with hs of steps 0..U-2 (reverse: dG rows of
+        # steps 0..U-2 pair with hs rows 1..U-1); the first processed step pairs with h0 (zero when absent)
         dw_hh = torch.zeros(4 * H, H, dtype=torch.float32, device=dev)
         if U > 1:
-            K.gemm(dG, hs, dw_hh, 4 * H, H, (U - 1) * B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, a_off=B * 4 * H)
+            if reverse:
+                K.gemm(dG, hs, dw_hh, 4 * H, H, (U - 1) * B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, b_off=B * H)
+            else:
+                K.gemm(dG, hs, dw_hh, 4 * H, H, (U - 1) * B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, a_off=B * 4 * H)
         if has_h0:
-            K.gemm(dG, h0_16, dw_hh, 4 * H, H, B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, accumulate=True)
+            K.gemm(dG, h0_16, dw_hh, 4 * H, H, B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, accumulate=True,
+                   a_off=order[0] * B * 4 * H)
         db = K.colsum(dG, torch.zeros(4 * H, dtype=torch.float32, device=dev), U * B, 4 * H, 4 * H) if has_bias else None
         return (dx, dw_ih, dw_hh, db, db.clone() if db is not None else None, None, None,
-                dh_rec if has_h0 else None, dc if c0 is not None else None, None, None)
+                dh_rec if has_h0 else None, dc if c0 is not None else None, None, None, None, None)
 
 
 def lstm_layer(x, cell, B, U, h0=None, c0=None):
     """x bf16 [U*B][I] time-major; cell: LSTMCellParams.  Returns (hs bf16 [U*B][H], h_last fp32, c_last fp32)."""
     return _LSTMLayer.apply(x, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, bf16_weight(cell.weight_ih),
                             bf16_weight(cell.weight_hh), h0, c0, B, U)
+
+def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, B, U, reverse=False, frozen=None):
+    """One direction of a packed nn.LSTM layer (weights named weight_ih_l0[_reverse] ...).  Returns hs bf16 [U*B][H]."""
+    return _LSTMLayer.apply(x, w_ih, w_hh, b_ih, b_hh, bf16_weight(w_ih), bf16_weight(w_hh), None, None, B, U, reverse, frozen)[0]
+
+
+class _GradSink(torch.autograd.Function):
+    """Identity on its tensor arguments whose backward returns gradients that later (per-step) backward passes have
+    ACCUMULATED IN PLACE into `acc[i]` (fp32 buffers created on first use).  It sits upstream of every per-step node of a
+    recurrent decoder, so autograd runs it after all of them: per-step weight / key / value gradients then cost one
+    accumulate-GEMM or one in-place kernel each instead of a fresh full-size tensor and an add per step."""
+
+    @staticmethod
+    def forward(ctx, holder, *tensors):
+        ctx.holder = holder
+        holder.shapes = [(t.shape, t.device) for t in tensors]
+        holder.acc = [None] * len(tensors)
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = []
+        for a, g, (shape, dev) in zip(ctx.holder.acc, grads, ctx.holder.shapes):
+            if a is None:
+                out.append(g)
+            else:
+                out.append(a.view(shape) if g is None else a.view(shape) + g.to(a.dtype))
+        return (None,) + tuple(out)
+
+
+class GradSink:
+    def __init__(self, *tensors):
+        self.acc, self.shapes = None, None
+        self.views = _GradSink.apply(self, *tensors)
+
+    def buf(self, i):
+        if self.acc[i] is None:
+            shape, dev = self.shapes[i]
+            self.acc[i] = torch.zeros(shape, dtype=torch.float32, device=dev)
+        return self.acc[i]
+
+
+class _LSTMCellStep(torch.autograd.Function):
+    """One LSTMCell step with autograd (attention decoders, where every step depends on the previous context).
+    x16 bf16 [B][I], h_prev16 bf16 [B][H], c_prev fp32 [B][H] -> (h16 bf16, c fp32).  Weight / bias gradients are accumulated
+    into the GradSink `sink` (views order: w_ih, w_hh, b_ih, b_hh)."""
+
+    @staticmethod
+    def forward(ctx, x16, h_prev16, c_prev, w_ih_v, w_hh_v, b_ih_v, b_hh_v, w_ih16, w_hh16, bias_sum, sink):
+        B, I = x16.shape
+        H = w_hh16.shape[1]
+        dev = x16.device
+        x16, h_prev16 = x16.contiguous(), h_prev16.contiguous()
+        G = torch.empty(B, 4 * H, dtype=torch.float32, device=dev)
+        K.gemm(x16, w_ih16, G, B, 4 * H, I, lda=I, ldb=I, ldc=4 * H, bias=bias_sum)
+        K.gemm(h_prev16, w_hh16, G, B, 4 * H, H, lda=H, ldb=H, ldc=4 * H, resid=G, ldr=4 * H)
+        h16 = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
+        c = torch.empty(B, H, dtype=torch.float32, device=dev)
+        act = torch.empty(B, 4 * H, dtype=torch.float32, device=dev)
+        c_prev = c_prev.contiguous()
+        K.lstm_cell_fwd(G, c_prev, c, None, h16, H, act, B, H)
+        ctx.save_for_backward(x16, h_prev16, c_prev, c, act, w_ih16, w_hh16)
+        ctx.sink = sink
+        return h16, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        x16, h_prev16, c_prev, c, act, w_ih16, w_hh16 = ctx.saved_tensors
+        B, I = x16.shape
+        H = w_hh16.shape[1]
+        dev = x16.device
+        dG = torch.empty(B, 4 * H, dtype=torch.bfloat16, device=dev)
+        dc_prev = torch.empty(B, H, dtype=torch.float32, device=dev)
+        K.lstm_cell_bwd(dh.contiguous() if dh is not None else None, H, None, dc.contiguous() if dc is not None else None, act, c_prev, c,
+                        dG, 4 * H, dc_prev, B, H)
+        dx = torch.empty(B, I, dtype=torch.bfloat16, device=dev)
+        K.gemm(dG, w_ih16, dx, B, I, 4 * H, lda=4 * H, ldb=I, ldc=I, b_kstrided=True)
+        dhp = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
+        K.gemm(dG, w_hh16, dhp, B, H, 4 * H, lda=4 * H, ldb=H, ldc=H, b_kstrided=True)
+        sk = ctx.sink
+        K.gemm(dG, x16, sk.buf(0), 4 * H, I, B, lda=4 * H, ldb=I, ldc=I, a_kstrided=True, b_kstrided=True, accumulate=True)
+        K.gemm(dG, h_prev16, sk.buf(1), 4 * H, H, B, lda=4 * H, ldb=H, ldc=H, a_kstrided=True, b_kstrided=True, accumulate=True)
+        K.colsum(dG, sk.buf(2), B, 4 * H, 4 * H)
+        sk.acc[3] = sk.acc[2]  # bias_hh receives the same gradient as bias_ih
+        return dx, dhp, dc_prev, None, None, None, None, None, None, None, None
+
+
+def lstm_cell_ag(x16, h_prev16, c_prev, cell, sink, bias_sum):
+    """Autograd LSTMCell step; `sink` = GradSink(cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh) shared by all steps."""
+    v = sink.views
+    return _LSTMCellStep.apply(x16, h_prev16, c_prev, v[0], v[1], v[2], v[3], bf16_weight(cell.weight_ih), bf16_weight(cell.weight_hh),
+                               bias_sum, sink)
+
+
+class _BahdanauStep(torch.autograd.Function):
+    """Additive attention of one decoder step (espresso/modules/speech_attention.py:38-87).  qp bf16 [B][A] (query_proj of
+    the layer-0 hidden), key bf16 [T*B][A] / value bf16 [T*B][Cv] time-major views coming out of a GradSink (gradients are
+    accumulated there, buffers 0 / 1), nv fp32 [A] = g v/||v||, bias fp32 [A].  Returns (context bf16 [B][Cv], p fp32 [T][B])."""
+
+    @staticmethod
+    def forward(ctx, qp, key_v, value_v, nv, bias, lens, sink, T, B):
+        qp = qp.contiguous()
+        nv32 = nv.detach().float().contiguous()
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        p, c = K.bahdanau_fwd(qp, key_v, value_v, nv32, b32, lens, T, B)
+        ctx.save_for_backward(qp, key_v, value_v, nv32, b32, lens, p)
+        ctx.sink, ctx.dims = sink, (T, B)
+        ctx.mark_non_differentiable(p)
+        return c, p
+
+    @staticmethod
+    def backward(ctx, dctx, _dp):
+        qp, key_v, value_v, nv32, b32, lens, p = ctx.saved_tensors
+        T, B = ctx.dims
+        sk = ctx.sink
+        A = qp.shape[1]
+        dnv = torch.zeros(A, dtype=torch.float32, device=qp.device)
+        dbias = torch.zeros(A, dtype=torch.float32, device=qp.device) if b32 is not None else None
+        dqp = K.bahdanau_bwd(dctx.contiguous(), qp, key_v, value_v, nv32, b32, lens, p, sk.buf(0), sk.buf(1), dnv, dbias, T, B)
+        return dqp, None, None, dnv, dbias, None, None, None, None
+
+
+def bahdanau_step(qp, sink, nv, bias, lens, T, B):
+    """sink = GradSink(key [T*B][A] bf16, value [T*B][Cv] bf16).  Returns (context bf16 [B][Cv], attention fp32 [T][B])."""
+    return _BahdanauStep.apply(qp, sink.views[0], sink.views[1], nv, bias, lens, sink, T, B)
+
 
 
 def lstm_cell_step(x16, cell, h_prev16, h_prev32, c_prev, keep_row=None):

@@ -552,14 +552,35 @@ def rnnt_loss_grad(logits, targets, logit_lengths, target_lengths, loss, ws, bla
 
 
 # ------------------------------------------------------------------------------------------------ LSTM
-def lstm_cell_fwd(gates_pre, c_prev, c_out, h_f32, h_bf16, ldh, gates_act, B, H, keep_row=None, h_prev_f32=None, ldg=None):
+def lstm_cell_fwd(gates_pre, c_prev, c_out, h_f32, h_bf16, ldh, gates_act, B, H, keep_row=None, h_prev_f32=None, ldg=None,
+                  frozen_out_zero=False):
     check(_lib.lib().ea_lstm_cell_fwd(_p(gates_pre), ldg if ldg is not None else 4 * H, _p(c_prev), _p(c_out), _p(h_f32), _p(h_bf16),
-                                      ldh, _p(gates_act), _p(keep_row), _p(h_prev_f32), B, H, _stream()), "ea_lstm_cell_fwd")
+                                      ldh, _p(gates_act), _p(keep_row), _p(h_prev_f32), int(frozen_out_zero), B, H, _stream()),
+          "ea_lstm_cell_fwd")
 
 
-def lstm_cell_bwd(dh_bf16, ld_dh, dh_f32, dc_in, gates_act, c_prev, c, dgates, lddg, dc_prev, B, H):
+def lstm_cell_bwd(dh_bf16, ld_dh, dh_f32, dc_in, gates_act, c_prev, c, dgates, lddg, dc_prev, B, H, frozen=None):
     check(_lib.lib().ea_lstm_cell_bwd(_p(dh_bf16), ld_dh, _p(dh_f32), _p(dc_in), _p(gates_act), _p(c_prev), _p(c), _p(dgates), lddg,
-                                      _p(dc_prev), B, H, _stream()), "ea_lstm_cell_bwd")
+                                      _p(dc_prev), _p(frozen), B, H, _stream()), "ea_lstm_cell_bwd")
+
+
+def bahdanau_fwd(qp, key, value, nv, bias, lens, T, B, ctx=None, ldc=None, kv_col=None, Bkv=0):
+    A, Cv = qp.shape[1], value.shape[-1]
+    p = torch.empty(T, B, dtype=torch.float32, device=qp.device)
+    if ctx is None:
+        ctx = torch.empty(B, Cv, dtype=torch.bfloat16, device=qp.device)
+        ldc = Cv
+    check(_lib.lib().ea_bahdanau_fwd(_p(qp), _p(key), _p(value), _p(nv), _p(bias), _p(lens), _p(p), _p(ctx), ldc, T, B, A, Cv,
+                                     _p(kv_col), Bkv, _stream()), "ea_bahdanau_fwd")
+    return p, ctx
+
+
+def bahdanau_bwd(dctx, qp, key, value, nv, bias, lens, p, dkey_acc, dvalue_acc, dnv_acc, dbias_acc, T, B):
+    A, Cv = qp.shape[1], value.shape[-1]
+    dqp = torch.empty(B, A, dtype=torch.bfloat16, device=qp.device)
+    check(_lib.lib().ea_bahdanau_bwd(_p(dctx), dctx.stride(0), _p(qp), _p(key), _p(value), _p(nv), _p(bias), _p(lens), _p(p), _p(dqp),
+                                     _p(dkey_acc), _p(dvalue_acc), _p(dnv_acc), _p(dbias_acc), T, B, A, Cv, _stream()), "ea_bahdanau_bwd")
+    return dqp
 
 
 def gather_rows(src, parent, out=None):

@@ -1,8 +1,10 @@
-"""LSTM decoder / predictor — espresso/models/speech_lstm.py:600-1048 (`SpeechLSTMDecoder`).
+"""`speech_lstm` — espresso/models/speech_lstm.py: `SpeechLSTMModel` (:169-357), `SpeechLSTMEncoder` (:358-598, conv front-end +
+packed BiLSTM stack) and `SpeechLSTMDecoder` (:600-1048).
 
-This round implements the attention-free mode (attn_type None): the predictor of the transducer
-(espresso/models/transformer/speech_transformer_transducer_base.py:195-212) and the decoder-only LSTM language model
-(espresso/models/lstm_lm.py:88-198).  Parameter names follow the reference's state_dict (`embed_tokens.weight`,
+The decoder serves three roles: attention-free (attn_type None) as the predictor of the transducer
+(espresso/models/transformer/speech_transformer_transducer_base.py:195-212) and as the decoder-only LSTM language model
+(espresso/models/lstm_lm.py:88-198); with Bahdanau attention + input feeding as the decoder of the `speech_lstm`
+encoder-decoder (BASELINE config 1).  Parameter names follow the reference's state_dict (`embed_tokens.weight`,
 `layers.{i}.weight_ih|weight_hh|bias_ih|bias_hh`, optional `additional_fc`, `fc_out`).  Without attention / input feeding
 the per-step loop of :846-893 factorises into stacked sequence LSTMs, so each layer runs over the whole teacher-forced
 sequence (one input-projection GEMM + per-step recurrent GEMM + cell kernel; functional._LSTMLayer); incremental decoding
@@ -13,6 +15,7 @@ import torch.nn as nn
 from .. import functional as F
 from .. import kernels as K
 from ..modules.params import LinearParams
+from ..registry import register_model
 
 
 class LSTMCellParams(nn.Module):
@@ -51,21 +54,29 @@ class SpeechLSTMDecoder(nn.Module):
                  dropout_out=0.1, encoder_output_units=0, attn_type=None, attn_dim=0, need_attn=False, residual=False,
                  pretrained_embed=None, share_input_output_embed=False, max_target_positions=1024):
         super().__init__()
-        if attn_type is not None and str(attn_type).lower() != "none":
-            raise NotImplementedError("attention LSTM decoder (speech_lstm enc-dec, config 1) is scheduled after the transducer path")
         self.dictionary = dictionary
         self.dropout_in, self.dropout_out = float(dropout_in), float(dropout_out)
         self.hidden_size, self.num_layers, self.residual = hidden_size, num_layers, residual
         self.share_input_output_embed = share_input_output_embed
         self.max_target_positions = max_target_positions
-        self.encoder_output_units = 0
-        self.attention = None
+        no_attn = attn_type is None or str(attn_type).lower() == "none"
+        if no_attn:
+            encoder_output_units = 0
+        self.encoder_output_units = encoder_output_units
+        self.need_attn = need_attn and not no_attn
         pad = dictionary.pad()
         self.embed_tokens = pretrained_embed if pretrained_embed is not None else LSTMEmbedding(len(dictionary), embed_dim, pad)
         embed_dim = self.embed_tokens.embedding_dim
-        self.layers = nn.ModuleList([LSTMCellParams(embed_dim if i == 0 else hidden_size, hidden_size) for i in range(num_layers)])
-        if hidden_size != out_embed_dim:
-            self.additional_fc = lstm_linear(hidden_size, out_embed_dim)
+        self.layers = nn.ModuleList([LSTMCellParams(encoder_output_units + (embed_dim if i == 0 else hidden_size), hidden_size)
+                                     for i in range(num_layers)])
+        if no_attn:
+            self.attention = None
+        elif str(attn_type).lower() == "bahdanau":
+            self.attention = BahdanauAttentionParams(hidden_size, encoder_output_units, attn_dim)
+        else:
+            raise NotImplementedError(f"attention type {attn_type} (the recipes use bahdanau)")
+        if hidden_size + encoder_output_units != out_embed_dim:
+            self.additional_fc = lstm_linear(hidden_size + encoder_output_units, out_embed_dim)
         if not share_input_output_embed:
             self.fc_out = lstm_linear(out_embed_dim, len(dictionary))
 
@@ -73,8 +84,10 @@ class SpeechLSTMDecoder(nn.Module):
         return self.max_target_positions
 
     # ---------------------------------------------------------------- teacher-forced path
-    def extract_features(self, prev_output_tokens, **unused):
-        """prev_output_tokens [B][U] -> (features bf16 [B][U][H_out], None).  speech_lstm.py:766-919 with encoder_out None."""
+    def extract_features(self, prev_output_tokens, encoder_out=None, **unused):
+        """prev_output_tokens [B][U] -> (features bf16 [B][U][H_out], attn or None).  speech_lstm.py:766-919."""
+        if self.attention is not None:
+            return self._extract_features_attention(prev_output_tokens, encoder_out)
         B, U = prev_output_tokens.shape
         tr = self.training
         tok = prev_output_tokens.t().contiguous().view(-1).to(torch.int32)  # time-major rows t*B + b
@@ -107,8 +120,57 @@ class SpeechLSTMDecoder(nn.Module):
         return y[:, : len(self.dictionary)].reshape(*shp[:-1], -1)
 
     def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, **kwargs):
-        x, attn = self.extract_features(prev_output_tokens)
+        x, attn = self.extract_features(prev_output_tokens, encoder_out=encoder_out)
         return self.output_layer(x), attn
+
+    def _extract_features_attention(self, prev_output_tokens, encoder_out):
+        """Attention decoder with input feeding (:846-893): per step layer-0 cell -> Bahdanau attention on its hidden state ->
+        the context is appended to every upper layer's input and fed to the next step's layer 0.  Each step is a handful of
+        autograd nodes on the HIP kernels; weight / key / value gradients are accumulated in place (functional.GradSink)."""
+        B, U = prev_output_tokens.shape
+        tr = self.training
+        enc = encoder_out["_x_tb"][0]                      # bf16 [T*B][Cv] time-major
+        lens = encoder_out["src_lengths"][0].to(torch.int32).contiguous()
+        T = enc.shape[0] // B
+        H, Cv = self.hidden_size, self.encoder_output_units
+        at = self.attention
+        key = F.linear(enc, at.value_proj.weight, None)    # [T*B][A]
+        kv = F.GradSink(key, enc)
+        nv = at.g * at.v / torch.norm(at.v)
+        sinks = [F.GradSink(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh) for c in self.layers]
+        bsum = [(c.bias_ih + c.bias_hh).detach().float().contiguous() for c in self.layers]
+        tok = prev_output_tokens.t().contiguous().view(-1).to(torch.int32)
+        x = F.embedding(self.embed_tokens.weight, tok, None, None, 1.0, self.embed_tokens.padding_idx)
+        if tr and self.dropout_in > 0:
+            x = F.dropout(x, self.dropout_in)
+        dev = x.device
+        h = [torch.zeros(B, H, dtype=torch.bfloat16, device=dev) for _ in self.layers]
+        c = [torch.zeros(B, H, dtype=torch.float32, device=dev) for _ in self.layers]
+        feed = torch.zeros(B, Cv, dtype=torch.bfloat16, device=dev)
+        outs = []
+        for j in range(U):
+            inp = torch.cat((x[j * B:(j + 1) * B], feed), dim=1)
+            ctx = None
+            for i, cell in enumerate(self.layers):
+                h[i], c[i] = F.lstm_cell_ag(inp, h[i], c[i], cell, sinks[i], bsum[i])
+                prev_in = inp[:, :H] if (self.residual and i > 0) else None
+                if i == 0:
+                    qp = F.linear(h[0], at.query_proj.weight, None)
+                    ctx, _ = F.bahdanau_step(qp, kv, nv, at.b, lens, T, B)
+                inp = torch.cat((h[i], ctx), dim=1)
+                if tr and self.dropout_out > 0:
+                    inp = F.dropout(inp, self.dropout_out)
+                if prev_in is not None:
+                    inp = torch.cat((inp[:, :H] + prev_in, inp[:, H:]), dim=1)
+            feed = ctx
+            outs.append(inp)
+        y = torch.stack(outs, 0).transpose(0, 1).contiguous()  # B x U x (H + Cv)
+        if hasattr(self, "additional_fc"):
+            y = F.linear(y.view(B * U, -1), self.additional_fc.weight, self.additional_fc.bias)
+            if tr and self.dropout_out > 0:
+                y = F.dropout(y, self.dropout_out)
+            y = y.view(B, U, -1)
+        return y, None
 
     # ---------------------------------------------------------------- incremental path (inference)
     def init_state(self, n, device):
@@ -144,3 +206,184 @@ class SpeechLSTMDecoder(nn.Module):
         """index_select of every cached tensor by the surviving beams (speech_lstm.py:981-999)."""
         idx = new_order.to(torch.int32).contiguous()
         return {k: [K.gather_rows(t.contiguous(), idx) for t in v] for k, v in state.items()}
+
+
+class BahdanauAttentionParams(nn.Module):
+    """espresso/modules/speech_attention.py:38-64 storage (normalize=True): query_proj, value_proj (no bias), v, b, g."""
+
+    def __init__(self, query_dim, value_dim, embed_dim):
+        super().__init__()
+        import math
+
+        self.query_proj = LinearParams(query_dim, embed_dim, bias=False)
+        self.value_proj = LinearParams(value_dim, embed_dim, bias=False)
+        self.query_proj.weight.data.uniform_(-0.1, 0.1)
+        self.value_proj.weight.data.uniform_(-0.1, 0.1)
+        self.v = nn.Parameter(torch.empty(embed_dim).uniform_(-0.1, 0.1))
+        self.b = nn.Parameter(torch.zeros(embed_dim))
+        self.g = nn.Parameter(torch.full((1,), math.sqrt(1.0 / embed_dim)))
+
+
+class LSTMParams(nn.Module):
+    """Single-layer torch.nn.LSTM storage (weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0 and the *_reverse set),
+    init U(-0.1, 0.1) like fairseq/models/lstm.py:LSTM."""
+
+    def __init__(self, input_size, hidden_size, bidirectional=False):
+        super().__init__()
+        self.bidirectional = bidirectional
+        for sfx in ([""] + (["_reverse"] if bidirectional else [])):
+            setattr(self, "weight_ih_l0" + sfx, nn.Parameter(torch.empty(4 * hidden_size, input_size).uniform_(-0.1, 0.1)))
+            setattr(self, "weight_hh_l0" + sfx, nn.Parameter(torch.empty(4 * hidden_size, hidden_size).uniform_(-0.1, 0.1)))
+            setattr(self, "bias_ih_l0" + sfx, nn.Parameter(torch.empty(4 * hidden_size).uniform_(-0.1, 0.1)))
+            setattr(self, "bias_hh_l0" + sfx, nn.Parameter(torch.empty(4 * hidden_size).uniform_(-0.1, 0.1)))
+
+    def direction(self, sfx):
+        return tuple(getattr(self, n + sfx) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"))
+
+
+class SpeechLSTMEncoder(nn.Module):
+    """espresso/models/speech_lstm.py:358-598: ConvBNReLU front-end, then `num_layers` single-layer (Bi)LSTMs over packed
+    sequences (state frozen and output zero beyond each utterance's length), dropout between layers, optional residuals."""
+
+    def __init__(self, pre_encoder=None, input_size=83, hidden_size=512, num_layers=1, dropout_in=0.1, dropout_out=0.1,
+                 bidirectional=False, residual=False, max_source_positions=3600):
+        super().__init__()
+        self.pre_encoder = pre_encoder
+        self.num_layers, self.hidden_size, self.bidirectional, self.residual = num_layers, hidden_size, bidirectional, residual
+        self.dropout_in, self.dropout_out = float(dropout_in), float(dropout_out)
+        self.max_source_positions = max_source_positions
+        d = 2 if bidirectional else 1
+        self.lstm = nn.ModuleList([LSTMParams(input_size if i == 0 else d * hidden_size, hidden_size, bidirectional)
+                                   for i in range(num_layers)])
+        self.output_units = d * hidden_size
+
+    def output_lengths(self, in_lengths):
+        return in_lengths if self.pre_encoder is None else self.pre_encoder.output_lengths(in_lengths)
+
+    def max_positions(self):
+        return self.max_source_positions
+
+    def _first_layer_weight(self, w):
+        """The channels-last sub-sampler emits features ordered (f, c); the reference's LSTM expects (c, f): permute the input
+        axis of layer 0's weight_ih once per call (autograd un-permutes), as the Transformer encoder does for fc0."""
+        C = self.pre_encoder.out_channels[-1]
+        Fp = w.shape[1] // C
+        return w.view(w.shape[0], C, Fp).permute(0, 2, 1).reshape(w.shape[0], Fp * C)
+
+    def forward(self, src_tokens, src_lengths, **unused):
+        tr = self.training
+        B = src_tokens.shape[0]
+        x, x_lengths, padding_mask, _ = self.pre_encoder(src_tokens, src_lengths, p_drop=self.dropout_in if tr else 0.0)
+        T = padding_mask.shape[1]
+        D = x.shape[1]
+        x = x.view(B, T, D).transpose(0, 1).contiguous().view(T * B, D)  # time-major rows t*B + b
+        frozen = padding_mask.t().contiguous().to(torch.uint8)            # [T][B], 1 where t >= length
+        for i, layer in enumerate(self.lstm):
+            prev_x = x
+            outs = []
+            for sfx, rev in ((("", False),) + ((("_reverse", True),) if self.bidirectional else ())):
+                w_ih, w_hh, b_ih, b_hh = layer.direction(sfx)
+                if i == 0 and self.pre_encoder is not None:
+                    w_ih = self._first_layer_weight(w_ih)
+                outs.append(F.lstm_direction(x, w_ih, w_hh, b_ih, b_hh, B, T, reverse=rev, frozen=frozen))
+            x = torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]
+            if i < len(self.lstm) - 1 and tr and self.dropout_out > 0:
+                x = F.dropout(x, self.dropout_out)
+            if self.residual and i > 0:
+                x = x + prev_x
+        C = x.shape[1]
+        return {
+            "encoder_out": [x.view(T, B, C)],                      # T x B x C
+            "encoder_padding_mask": [padding_mask.t()] if bool(padding_mask.any()) else [],  # T x B
+            "encoder_embedding": [], "encoder_states": [], "src_tokens": [],
+            "src_lengths": [x_lengths],
+            "_x_tb": [x],
+        }
+
+
+ARCHS = {
+    "speech_lstm": dict(dropout=0.4, encoder_conv_channels="[64, 64, 128, 128]", encoder_conv_kernel_sizes="[(3, 3), (3, 3), (3, 3), (3, 3)]",
+                        encoder_conv_strides="[(1, 1), (2, 2), (1, 1), (2, 2)]", encoder_rnn_hidden_size=320, encoder_rnn_layers=3,
+                        encoder_rnn_bidirectional=True, encoder_rnn_residual=False, decoder_embed_dim=48, decoder_hidden_size=320,
+                        decoder_layers=3, decoder_out_embed_dim=960, decoder_rnn_residual=True, attention_type="bahdanau",
+                        attention_dim=320, need_attention=False, share_decoder_input_output_embed=False),
+}
+ARCHS["speech_conv_lstm_wsj"] = dict(ARCHS["speech_lstm"])
+ARCHS["speech_conv_lstm_librispeech"] = dict(ARCHS["speech_lstm"], dropout=0.3, encoder_rnn_hidden_size=1024, encoder_rnn_layers=4,
+                                             decoder_embed_dim=512, decoder_hidden_size=1024, decoder_layers=3,
+                                             decoder_out_embed_dim=3072, attention_dim=512)
+ARCHS["speech_conv_lstm_swbd"] = dict(ARCHS["speech_lstm"], dropout=0.5, encoder_rnn_hidden_size=640, encoder_rnn_layers=4,
+                                      decoder_embed_dim=640, decoder_hidden_size=640, decoder_layers=3, decoder_out_embed_dim=1920,
+                                      attention_dim=640)
+
+
+@register_model("speech_lstm")
+class SpeechLSTMModel(nn.Module):
+    """`speech_lstm` (espresso/models/speech_lstm.py:169-357): encoder-decoder with attention; `forward` returns
+    (fp32 logits [B][U][V], attention or None) like the reference's decoder output."""
+
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder, self.decoder = encoder, decoder
+        self.num_updates = 0
+
+    @classmethod
+    def build_model(cls, args, task):
+        from ..modules.speech_convolutions import ConvBNReLU
+        from ..tools import utils as speech_utils
+
+        a = dict(ARCHS[(args.get("arch") if isinstance(args, dict) else getattr(args, "arch", None)) or "speech_lstm"])
+        a.update({k: v for k, v in (args if isinstance(args, dict) else vars(args)).items() if v is not None})
+        ev = speech_utils.eval_str_nested_list_or_tuple
+        ch = ev(a["encoder_conv_channels"], type=int)
+        conv = ConvBNReLU(ch, ev(a["encoder_conv_kernel_sizes"], type=int), ev(a["encoder_conv_strides"], type=int),
+                          in_channels=task.feat_in_channels)
+        in_size = conv.output_feat_dim(task.feat_dim // task.feat_in_channels)
+        drop = a["dropout"]
+        enc = SpeechLSTMEncoder(pre_encoder=conv, input_size=in_size, hidden_size=a["encoder_rnn_hidden_size"],
+                                num_layers=a["encoder_rnn_layers"], dropout_in=a.get("encoder_rnn_dropout_in", drop),
+                                dropout_out=a.get("encoder_rnn_dropout_out", drop), bidirectional=a["encoder_rnn_bidirectional"],
+                                residual=a["encoder_rnn_residual"], max_source_positions=a.get("max_source_positions", 3600))
+        if a["share_decoder_input_output_embed"] and a["decoder_embed_dim"] != a["decoder_out_embed_dim"]:
+            raise ValueError("--share-decoder-input-output-embed requires --decoder-embed-dim to match --decoder-out-embed-dim")
+        dec = SpeechLSTMDecoder(task.target_dictionary, embed_dim=a["decoder_embed_dim"], hidden_size=a["decoder_hidden_size"],
+                                out_embed_dim=a["decoder_out_embed_dim"], num_layers=a["decoder_layers"],
+                                dropout_in=a.get("decoder_dropout_in", drop), dropout_out=a.get("decoder_dropout_out", drop),
+                                encoder_output_units=enc.output_units, attn_type=a["attention_type"], attn_dim=a["attention_dim"],
+                                need_attn=a["need_attention"], residual=a["decoder_rnn_residual"],
+                                share_input_output_embed=a["share_decoder_input_output_embed"],
+                                max_target_positions=a.get("max_target_positions", 1024))
+        return cls(enc, dec)
+
+    def set_num_updates(self, n):
+        self.num_updates = n
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
+        enc = self.encoder(src_tokens, src_lengths)
+        return self.decoder(prev_output_tokens, encoder_out=enc)
+
+    def forward_encoder(self, src_tokens, src_lengths):
+        return self.encoder(src_tokens, src_lengths)
+
+    def max_positions(self):
+        return (self.encoder.max_positions(), self.decoder.max_positions())
+
+    def max_decoder_positions(self):
+        return self.decoder.max_positions()
+
+    def get_targets(self, sample, net_output):
+        return sample["target"]
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        """`conv_layers_before` -> `pre_encoder` (speech_lstm.py:583-597); checkpoints trained with
+        `encoder_multilayer_rnn_as_single_module` hold one nn.LSTM (`lstm.weight_ih_l{k}`): map to the per-layer modules."""
+        import re
+
+        for k in list(state_dict.keys()):
+            if "conv_layers_before" in k:
+                state_dict[k.replace("conv_layers_before", "pre_encoder")] = state_dict.pop(k)
+        for k in list(state_dict.keys()):
+            m = re.match(r"^(.*encoder\.lstm\.)(weight_ih|weight_hh|bias_ih|bias_hh)_l(\d+)(_reverse)?$", k)
+            if m:
+                state_dict[f"{m.group(1)}{m.group(3)}.{m.group(2)}_l0{m.group(4) or ''}"] = state_dict.pop(k)
+        return state_dict

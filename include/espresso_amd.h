@@ -325,11 +325,27 @@ int ea_lookahead_logprobs(const int* nodes, const int* prev_tok, const float* cu
  * ea_gather_rows: out[n] = in[parent[n]] over rows of W elements of 2 or 4 bytes (beam reorder of cached LSTM states,
  * speech_lstm.py:981-999). */
 int ea_lstm_cell_fwd(const float* gates_pre, long ldg, const float* c_prev, float* c_out, float* h_out_f32, void* h_out_bf16,
-                     long ldh, float* gates_act, const uint8_t* keep_row, const float* h_prev_f32, int B, int H,
-                     ea_stream_t stream);
+                     long ldh, float* gates_act, const uint8_t* keep_row, const float* h_prev_f32, int frozen_out_zero, int B,
+                     int H, ea_stream_t stream);
 int ea_lstm_cell_bwd(const void* dh_bf16, long ld_dh, const float* dh_f32, const float* dc_in, const float* gates_act,
-                     const float* c_prev, const float* c, void* dgates, long lddg, float* dc_prev, int B, int H,
-                     ea_stream_t stream);
+                     const float* c_prev, const float* c, void* dgates, long lddg, float* dc_prev, const uint8_t* frozen, int B,
+                     int H, ea_stream_t stream);
+/* frozen_out_zero / frozen: packed-sequence semantics of the BiLSTM encoder (speech_lstm.py:470-520, pack_padded_sequence /
+ * pad_packed_sequence with padding_value 0): rows past their length keep their state, emit zeros and get no gradient.
+ *
+ * Bahdanau attention of one decoder step — espresso/modules/speech_attention.py:38-87 (normalize=True):
+ *   score[t][b] = sum_a nv[a] tanh(qp[b][a] + key[t][b][a] + bias[a]), nv = g v/||v|| (caller), softmax over t < len[b],
+ *   ctx[b] = sum_t p[t][b] value[t][b].  qp bf16 [B][A]; key bf16 [T][B][A]; value bf16 [T][B][Cv]; p fp32 [T][B]; ctx bf16 [B][ldc].
+ * bwd (one step): dqp bf16 [B][A]; dkey_acc fp32 [T][B][A] and dvalue_acc fp32 [T][B][Cv] are accumulated in place over the
+ * decoder steps; dnv_acc / dbias_acc fp32 [A] by atomics. */
+int ea_bahdanau_fwd(const void* qp, const void* key, const void* value, const float* nv, const float* bias, const int* len,
+                    float* p_out, void* ctx, long ldc, int T, int B, int A, int Cv, const int* kv_col, int Bkv,
+                    ea_stream_t stream);
+/* kv_col (int [B], or NULL): beam search — row b attends over column kv_col[b] of key / value / len, which then have Bkv
+ * columns (one per sentence) instead of B. */
+int ea_bahdanau_bwd(const void* dctx, long ldd, const void* qp, const void* key, const void* value, const float* nv,
+                    const float* bias, const int* len, const float* p, void* dqp, float* dkey_acc, float* dvalue_acc,
+                    float* dnv_acc, float* dbias_acc, int T, int B, int A, int Cv, ea_stream_t stream);
 int ea_gather_rows(const void* in, void* out, const int* parent, int N, int W, int elem_bytes, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -318,6 +318,82 @@ def transducer_fixture(name="ref_conformer_transducer_tiny"):
     print([k for k in sd if not k.startswith("encoder")])
 
 
+def speech_lstm_fixture(name="ref_speech_lstm_tiny"):
+    """speech_lstm (BASELINE config 1): conv front-end + 2-layer packed BiLSTM encoder + 2-layer LSTM decoder with Bahdanau
+    attention, input feeding, residuals and additional_fc; label-smoothed CE (uniform 0.1).  Logits / loss / gradients and
+    a beam search, all from the reference's own modules."""
+    import argparse
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.models.speech_lstm import SpeechLSTMModel, base_architecture
+    from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
+    from fairseq.sequence_generator import SequenceGenerator
+
+    torch.manual_seed(8642)
+    V = 40
+    args = argparse.Namespace(dropout=0.0, encoder_conv_channels="[64, 64, 16, 16]", encoder_rnn_hidden_size=32, encoder_rnn_layers=2,
+                              encoder_rnn_residual=True, decoder_embed_dim=24, decoder_hidden_size=32, decoder_layers=2,
+                              decoder_out_embed_dim=48, attention_dim=40, criterion_name="label_smoothed_cross_entropy_v2",
+                              scheduled_sampling_probs=[1.0], start_scheduled_sampling_epoch=1, max_source_positions=3600,
+                              max_target_positions=200)
+    base_architecture(args)
+
+    class T:
+        feat_dim, feat_in_channels = 80, 1
+        cfg = argparse.Namespace(num_batch_buckets=0)
+    dic = AsrDictionary()
+    for i in range(V - len(dic) - 1):
+        dic.add_symbol(f"t{i}")
+    dic.add_symbol("<space>")
+    T.target_dictionary = dic
+    model = SpeechLSTMModel.build_model(args, T)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.mul_(2.5)  # U(-0.25, 0.25): LSTM gates and attention away from the linear regime
+    B, Tn = 3, 70
+    lengths = torch.tensor([70, 61, 37])
+    feats = torch.randn(B, Tn, 80)
+    for b in range(B):
+        feats[b, lengths[b]:] = 0.0
+    pad, eos = dic.pad(), dic.eos()
+    tl = [7, 5, 3]
+    target = torch.full((B, 8), pad, dtype=torch.long)
+    prev = torch.full((B, 8), pad, dtype=torch.long)
+    for b, L in enumerate(tl):
+        toks = torch.randint(dic.nspecial, V, (L,))
+        target[b, :L] = toks
+        target[b, L] = eos
+        prev[b, 0] = eos
+        prev[b, 1:L + 1] = toks
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    out, beams = {}, {}
+    model.eval()
+    with torch.no_grad():
+        lo, _ = model(feats, lengths, prev)
+    out["eval_logits"] = lo.numpy()
+    for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=10)),):
+        gen = SequenceGenerator([model], dic, **kw)
+        hyps = gen.generate([model], {"net_input": {"src_tokens": feats, "src_lengths": lengths}})
+        for bi, hl in enumerate(hyps):
+            for hi, hyp in enumerate(hl):
+                beams[f"beam::{tag}::{bi}::{hi}::tokens"] = hyp["tokens"].numpy()
+                beams[f"beam::{tag}::{bi}::{hi}::score"] = np.array(float(hyp["score"]))
+                beams[f"beam::{tag}::{bi}::{hi}::pos"] = hyp["positional_scores"].numpy()
+        print(tag, [[h["tokens"].tolist() for h in hl] for hl in hyps], [[round(float(h["score"]), 3) for h in hl] for hl in hyps])
+    model.train()
+    lo, _ = model(feats, lengths, prev)
+    lprobs = torch.log_softmax(lo.float(), -1).view(-1, V)
+    loss, nll = label_smoothed_nll_loss(lprobs, target.view(-1, 1), 0.1, ignore_index=pad, reduce=True)
+    loss.backward()
+    out["train_logits"] = lo.detach().numpy()
+    out["loss"], out["nll"] = np.array(loss.item()), np.array(nll.item())
+    grads = {n: p.grad.detach().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), feats=feats.numpy(), lengths=lengths.numpy(), prev=prev.numpy(),
+                        target=target.numpy(), **beams, **{"sd::" + k: v.numpy() for k, v in sd.items()},
+                        **{"out::" + k: v for k, v in out.items()}, **{"grad::" + k: v for k, v in grads.items()})
+    print(name, "loss", loss.item(), "params", sum(p.numel() for p in model.parameters()))
+    print(list(sd.keys()))
+
+
 def lm_fusion_fixture(name="ref_lm_fusion_tiny"):
     """Shallow fusion inside the reference's SequenceGenerator (fairseq/sequence_generator.py:385-393): the enc-dec model of
     ref_transformer_encdec_tiny.npz (weights reloaded from that fixture) + a tiny sub-word LSTM LM, beam 3, lm_weight 0.5."""
@@ -526,6 +602,9 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "encdec":
         encdec_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "speechlstm":
+        speech_lstm_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "learnedpos":
         encoder_fixture("transformer", "ref_transformer_learnedpos_ctc_tiny", learned_pos=True)

@@ -373,3 +373,99 @@ def transducer(feats, lengths, prev_tokens, sd, H, pad_idx=1, residual=False, tr
     sdd = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
     dec, _ = lstm_predictor(prev_tokens, sdd, residual=residual, pad_idx=pad_idx)
     return transducer_joint(x.transpose(0, 1), dec, sdd), out_len
+
+
+# ------------------------------------------------------------------------------------------------ speech_lstm (config 1)
+def packed_lstm_direction(x_tbd, lengths, sd, p, sfx, reverse):
+    """One direction of a single-layer nn.LSTM over a packed batch (pack_padded_sequence / pad_packed_sequence, padding 0):
+    every utterance runs over its own `length` steps from the zero state; padded steps emit zeros."""
+    T, B, _ = x_tbd.shape
+    H = sd[p + "weight_hh_l0" + sfx].shape[1]
+    out = x_tbd.new_zeros(T, B, H)
+    cell_sd = {"weight_ih": sd[p + "weight_ih_l0" + sfx], "weight_hh": sd[p + "weight_hh_l0" + sfx],
+               "bias_ih": sd[p + "bias_ih_l0" + sfx], "bias_hh": sd[p + "bias_hh_l0" + sfx]}
+    for b in range(B):
+        L = int(lengths[b])
+        h, c = x_tbd.new_zeros(1, H), x_tbd.new_zeros(1, H)
+        steps = range(L - 1, -1, -1) if reverse else range(L)
+        rows = {}
+        for t in steps:
+            h, c = lstm_cell(x_tbd[t, b:b + 1], h, c, cell_sd, "")
+            rows[t] = h
+        if L > 0:
+            out[:L, b] = torch.cat([rows[t] for t in range(L)], 0)
+    return out
+
+
+def speech_lstm_encoder(feats, lengths, sd, p="encoder.", residual=False, training=False, update=None,
+                        strides=((1, 1), (2, 2), (1, 1), (2, 2))):
+    """espresso/models/speech_lstm.py:425-530 (dropout 0).  Returns (x (T',B,C), out_lengths)."""
+    enc_sd = {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    x, out_len, pad = conv_bn_relu(feats.float(), lengths, enc_sd, "pre_encoder.", strides, training, update)
+    x = x.transpose(0, 1)
+    i = 0
+    while f"lstm.{i}.weight_ih_l0" in enc_sd:
+        q = f"lstm.{i}."
+        outs = [packed_lstm_direction(x, out_len, enc_sd, q, "", False)]
+        if (q + "weight_ih_l0_reverse") in enc_sd:
+            outs.append(packed_lstm_direction(x, out_len, enc_sd, q, "_reverse", True))
+        y = torch.cat(outs, -1)
+        x = y + x if (residual and i > 0) else y
+        i += 1
+    return x, out_len
+
+
+def bahdanau_attention(query, value, sd, p, key_padding_mask=None):
+    """espresso/modules/speech_attention.py:66-87 (normalize=True).  query (B,Hq); value (T,B,Cv); mask (T,B)."""
+    pq = F.linear(query, sd[p + "query_proj.weight"]).unsqueeze(0)
+    key = F.linear(value, sd[p + "value_proj.weight"])
+    v = sd[p + "v"]
+    nv = sd[p + "g"] * v / torch.norm(v)
+    scores = (nv * torch.tanh(pq + key + sd[p + "b"])).sum(2)
+    if key_padding_mask is not None:
+        scores = scores.masked_fill(key_padding_mask, float("-inf"))
+    a = torch.softmax(scores, 0)
+    return (a.unsqueeze(2) * value).sum(0), a
+
+
+def speech_lstm_decoder(prev_tokens, enc_tbc, enc_lengths, sd, p="decoder.", residual=True, pad_idx=1, state=None):
+    """espresso/models/speech_lstm.py:766-930 with attention + input feeding (dropout 0).  Returns (logits (B,U,V), state)."""
+    T, B, Cv = enc_tbc.shape
+    mask = torch.arange(T).unsqueeze(1) >= enc_lengths.unsqueeze(0)
+    mask = mask if bool(mask.any()) else None
+    x = F.embedding(prev_tokens, sd[p + "embed_tokens.weight"], padding_idx=pad_idx).transpose(0, 1)
+    nl = 0
+    while (p + f"layers.{nl}.weight_ih") in sd:
+        nl += 1
+    H = sd[p + "layers.0.weight_hh"].shape[1]
+    if state is None:
+        state = {"h": [x.new_zeros(B, H) for _ in range(nl)], "c": [x.new_zeros(B, H) for _ in range(nl)], "feed": x.new_zeros(B, Cv)}
+    outs = []
+    for j in range(x.shape[0]):
+        inp = torch.cat((x[j], state["feed"]), 1)
+        ctx = None
+        for i in range(nl):
+            h, c = lstm_cell(inp, state["h"][i], state["c"][i], sd, p + f"layers.{i}.")
+            prev_in = inp[:, :H] if (residual and i > 0) else None
+            if i == 0:
+                ctx, _ = bahdanau_attention(h, enc_tbc, sd, p + "attention.", mask)
+            inp = torch.cat((h, ctx), 1)
+            if prev_in is not None:
+                inp = torch.cat((inp[:, :H] + prev_in, inp[:, H:]), 1)
+            state["h"][i], state["c"][i] = h, c
+        state["feed"] = ctx
+        outs.append(inp)
+    y = torch.stack(outs, 0).transpose(0, 1)
+    if (p + "additional_fc.weight") in sd:
+        y = F.linear(y, sd[p + "additional_fc.weight"], sd[p + "additional_fc.bias"])
+    if (p + "fc_out.weight") in sd:
+        y = F.linear(y, sd[p + "fc_out.weight"], sd[p + "fc_out.bias"])
+    else:
+        y = F.linear(y, sd[p + "embed_tokens.weight"])
+    return y, state
+
+
+def speech_lstm(feats, lengths, prev_tokens, sd, enc_residual=False, dec_residual=True, pad_idx=1, training=False, update=None):
+    sdd = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() and v.dtype != torch.float32 else v) for k, v in sd.items()}
+    x, out_len = speech_lstm_encoder(feats, lengths, sdd, residual=enc_residual, training=training, update=update)
+    return speech_lstm_decoder(prev_tokens, x, out_len, sdd, residual=dec_residual, pad_idx=pad_idx)[0], x, out_len

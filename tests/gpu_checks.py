@@ -970,3 +970,59 @@ def check_label_smoothing_kernel():
         ref_grad = torch.from_numpy(g["dlogits" if kind == "uniform" else f"{kind}_dlogits"])
         res[kind] = {"loss_rel": abs(float(loss) - ref_loss) / abs(ref_loss), "grad_abs": float((x.grad.cpu() - ref_grad).abs().max())}
     return res
+
+
+# ------------------------------------------------------------------ speech_lstm (BASELINE config 1)
+def build_tiny_speech_lstm(V=40):
+    from espresso_amd.models.speech_lstm import SpeechLSTMModel
+
+    return SpeechLSTMModel.build_model(dict(arch="speech_lstm", dropout=0.0, encoder_conv_channels="[64, 64, 16, 16]",
+                                            encoder_rnn_hidden_size=32, encoder_rnn_layers=2, encoder_rnn_residual=True,
+                                            decoder_embed_dim=24, decoder_hidden_size=32, decoder_layers=2, decoder_out_embed_dim=48,
+                                            attention_dim=40), _TaskAR(V))
+
+
+def check_speech_lstm_vs_reference():
+    """Reference weights -> HIP speech_lstm: logits (eval / train), label-smoothed CE and all gradients vs what the reference's
+    SpeechLSTMModel produced (tests/golden/ref_speech_lstm_tiny.npz)."""
+    from espresso_amd import functional as F
+
+    g = np.load(os.path.join(GOLD, "ref_speech_lstm_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    grads = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad::")}
+    model = build_tiny_speech_lstm().to(DEV)
+    missing, unexpected = model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    feats, lengths = torch.from_numpy(g["feats"]).to(DEV), torch.from_numpy(g["lengths"]).to(DEV)
+    prev, target = torch.from_numpy(g["prev"]).to(DEV), torch.from_numpy(g["target"]).to(DEV)
+    valid = target.ne(0).cpu()
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        lo, _ = model(feats, lengths, prev)
+    ref = torch.from_numpy(g["out::eval_logits"])
+    res["eval_logits_abs_valid"] = float((lo.float().cpu() - ref)[valid].abs().max())
+    res["logits_ref_max"] = float(ref[valid].abs().max())
+    model.train()
+    lo, _ = model(feats, lengths, prev)
+    res["train_logits_abs_valid"] = float((lo.float().cpu() - torch.from_numpy(g["out::train_logits"]))[valid].abs().max())
+    V = lo.shape[-1]
+    loss, nll = F.label_smoothed_ce(lo.reshape(-1, V), target.reshape(-1).to(torch.int32).contiguous(), 0, 0.1)
+    loss.backward()
+    torch.cuda.synchronize()
+    res["loss"], res["ref_loss"] = float(loss), float(g["out::loss"])
+    l2, scale = {}, {}
+    for n, p in model.named_parameters():
+        if n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias"):
+            continue
+        r = grads[n]
+        a = p.grad.float().cpu()
+        l2[n] = float((a - r).norm() / (r.norm() + 1e-12))
+        scale[n] = float((a * r).sum() / ((r * r).sum() + 1e-20))
+    # the conv/BatchNorm front-end sits behind the whole recurrent stack: its bf16 gradient noise is bounded separately
+    fe = {k: v for k, v in l2.items() if k.startswith("encoder.pre_encoder")}
+    rest = {k: v for k, v in l2.items() if not k.startswith("encoder.pre_encoder")}
+    res["worst_l2"] = max(rest.items(), key=lambda kv: kv[1])
+    res["worst_l2_frontend"] = max(fe.items(), key=lambda kv: kv[1])
+    res["worst_scale"] = max(((k, v) for k, v in scale.items() if not k.startswith("encoder.pre_encoder")), key=lambda kv: abs(kv[1] - 1.0))
+    return res

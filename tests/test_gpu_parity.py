@@ -238,3 +238,16 @@ def test_label_smoothing_kernel_all_types_vs_reference():
     print(r)
     for kind, v in r.items():
         assert v["loss_rel"] < 1e-5 and v["grad_abs"] < 1e-5, (kind, r)
+
+
+def test_speech_lstm_vs_reference_fixture():
+    """BASELINE config 1 model (conv + packed BiLSTM encoder, attention LSTM decoder) on the HIP kernels vs the reference's own
+    outputs: bf16 hidden states / contexts -> logits 2.5e-2 of range, loss 1e-2 rel, gradients 10 % L2 / 5 % scale"""
+    r = G.check_speech_lstm_vs_reference()
+    print(r)
+    tol = 2.5e-2 * max(1.0, r["logits_ref_max"])
+    assert r["eval_logits_abs_valid"] < tol and r["train_logits_abs_valid"] < tol, r
+    assert abs(r["loss"] - r["ref_loss"]) <= 1e-2 * r["ref_loss"], r
+    assert r["worst_l2"][1] < 0.1, r
+    assert r["worst_l2_frontend"][1] < 0.5, r   # same bound as the Conformer/Transformer encoder tests use for the conv/BN stack
+    assert abs(r["worst_scale"][1] - 1.0) < 5e-2, r

@@ -159,3 +159,23 @@ def test_transducer_restatement_matches_reference(golden_dir):
               "fc_out.weight_v", "proj_decoder.weight", "laynorm_proj_encoder.weight", "encoder.fc0.weight"):
         ref = torch.from_numpy(g["grad::" + k])
         assert float((leaf[k].grad - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), k
+
+
+def test_speech_lstm_restatement_matches_reference(golden_dir):
+    """conv front-end + packed BiLSTM encoder + Bahdanau-attention LSTM decoder (input feeding, residuals, additional_fc)
+    restated in oracle/torch_ref.py vs the reference SpeechLSTMModel's own logits, label-smoothed loss and gradients."""
+    g, sd = _load(golden_dir, "ref_speech_lstm_tiny")
+    feats, lengths, prev = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"])
+    lo, _, _ = torch_ref.speech_lstm(feats, lengths, prev, sd, enc_residual=True, dec_residual=True, pad_idx=0, training=False)
+    assert float((lo - torch.from_numpy(g["out::eval_logits"])).abs().max()) < 5e-5
+    leaf = {k: v.clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v.clone() for k, v in sd.items()}
+    lo, _, _ = torch_ref.speech_lstm(feats, lengths, prev, leaf, enc_residual=True, dec_residual=True, pad_idx=0, training=True, update={})
+    assert float((lo - torch.from_numpy(g["out::train_logits"])).abs().max()) < 5e-5
+    target = torch.from_numpy(g["target"])
+    loss, nll = torch_ref.label_smoothed_nll(lo.reshape(-1, lo.shape[-1]), target.reshape(-1), 0.1, 0)  # pad = 0 (no <s> in this dictionary)
+    assert float(loss) == pytest.approx(float(g["out::loss"]), rel=1e-5)
+    loss.backward()
+    for k in ("encoder.lstm.0.weight_hh_l0_reverse", "encoder.lstm.1.weight_ih_l0", "decoder.attention.v", "decoder.attention.g",
+              "decoder.attention.value_proj.weight", "decoder.layers.1.weight_ih", "decoder.embed_tokens.weight"):
+        ref = torch.from_numpy(g["grad::" + k])
+        assert float((leaf[k].grad - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max())), k
