@@ -72,7 +72,7 @@ class LSTMLanguageModelEspresso(nn.Module):
         """tokens [N][step+1]; parent int [N] = surviving beams (None at step 0) -> fp32 log-probs [N][V]."""
         if parent is not None:
             state["lstm"] = self.decoder.reorder_state(state["lstm"], parent)
-        feat, state["lstm"] = self.decoder.step(tokens[:, -1], state["lstm"])
+        feat, state["lstm"] = self.decoder.advance(tokens[:, -1], state["lstm"])
         logits = self.decoder.output_layer(feat)
         N, V = logits.shape
         return K.log_softmax(logits, N, V, logits.stride(0))

@@ -180,8 +180,9 @@ class SpeechLSTMDecoder(nn.Module):
         return {"h16": [z16() for _ in self.layers], "h32": [z32() for _ in self.layers], "c": [z32() for _ in self.layers]}
 
     @torch.no_grad()
-    def step(self, tokens, state, keep_row=None):
-        """tokens int [N] (last emitted token of each hypothesis) -> (features bf16 [N][H_out], new state).
+    def advance(self, tokens, state, keep_row=None):
+        """Attention-free single step (predictor / LM).
+        tokens int [N] (last emitted token of each hypothesis) -> (features bf16 [N][H_out], new state).
         keep_row uint8 [N]: rows whose state must not advance (speech_lstm.py:1001-1040 masked_copy_cached_state)."""
         tok = tokens.view(-1).to(torch.int32).contiguous()
         x = F.embedding(self.embed_tokens.weight, tok, None, None, 1.0, self.embed_tokens.padding_idx)
@@ -200,6 +201,62 @@ class SpeechLSTMDecoder(nn.Module):
         if hasattr(self, "additional_fc"):
             x = F.linear(x, self.additional_fc.weight, self.additional_fc.bias)
         return x, new
+
+    # ---------------------------------------------------------------- SequenceGenerator hooks (attention decoder)
+    @torch.no_grad()
+    def init_incremental(self, encoder_out, bsz, beam):
+        """Encoder keys (value_proj applied once) and values stay ONE copy per sentence; hypotheses address them through
+        `kv_col` (the reference re-orders / replicates encoder_out per beam, speech_lstm.py:531-566)."""
+        assert self.attention is not None
+        enc = encoder_out["_x_tb"][0]
+        dev = enc.device
+        T = enc.shape[0] // bsz
+        N = bsz * beam
+        H, Cv = self.hidden_size, self.encoder_output_units
+        at = self.attention
+        return {
+            "T": T, "Bkv": bsz, "value": enc, "key": F.linear(enc, at.value_proj.weight, None).contiguous(),
+            "len": encoder_out["src_lengths"][0].to(torch.int32).contiguous(),
+            "nv": (at.g * at.v / torch.norm(at.v)).float().contiguous(), "bias": at.b.detach().float().contiguous(),
+            "kv_col": torch.arange(bsz, device=dev, dtype=torch.int32).repeat_interleave(beam).contiguous(),
+            "h16": [torch.zeros(N, H, dtype=torch.bfloat16, device=dev) for _ in self.layers],
+            "h32": [torch.zeros(N, H, dtype=torch.float32, device=dev) for _ in self.layers],
+            "c": [torch.zeros(N, H, dtype=torch.float32, device=dev) for _ in self.layers],
+            "feed": torch.zeros(N, Cv, dtype=torch.bfloat16, device=dev),
+        }
+
+    @torch.no_grad()
+    def step(self, st, tokens, step, parent):
+        """One beam-search step of the attention decoder: tokens [N][step+1], parent int64 [N] (rows of the previous step each
+        hypothesis continues; None at step 0) -> fp32 log-probs [N][V]."""
+        if parent is not None:
+            idx = parent.to(torch.int32).contiguous()
+            for k in ("h16", "h32", "c"):
+                st[k] = [K.gather_rows(t, idx) for t in st[k]]
+            st["feed"] = K.gather_rows(st["feed"], idx)
+            st["kv_col"] = K.gather_rows(st["kv_col"].view(-1, 1).view(torch.float32), idx).view(torch.int32).view(-1)
+        N = tokens.shape[0]
+        H = self.hidden_size
+        x = F.embedding(self.embed_tokens.weight, tokens[:, -1].to(torch.int32).contiguous(), None, None, 1.0, self.embed_tokens.padding_idx)
+        inp = torch.cat((x, st["feed"]), dim=1)
+        ctx = None
+        for i, cell in enumerate(self.layers):
+            h16, h32, c = F.lstm_cell_step(inp, cell, st["h16"][i], st["h32"][i], st["c"][i])
+            prev_in = inp[:, :H] if (self.residual and i > 0) else None
+            if i == 0:
+                qp = F.linear(h16, self.attention.query_proj.weight, None)
+                _, ctx = K.bahdanau_fwd(qp.contiguous(), st["key"], st["value"], st["nv"], st["bias"], st["len"], st["T"], N,
+                                        kv_col=st["kv_col"], Bkv=st["Bkv"])
+            inp = torch.cat((h16, ctx), dim=1)
+            if prev_in is not None:
+                inp = torch.cat((inp[:, :H] + prev_in, inp[:, H:]), dim=1)
+            st["h16"][i], st["h32"][i], st["c"][i] = h16, h32, c
+        st["feed"] = ctx
+        y = inp
+        if hasattr(self, "additional_fc"):
+            y = F.linear(y.contiguous(), self.additional_fc.weight, self.additional_fc.bias)
+        logits = self.output_layer(y)
+        return K.log_softmax(logits, N, logits.shape[1], logits.stride(0))
 
     @staticmethod
     def reorder_state(state, new_order):

@@ -51,7 +51,7 @@ class TensorizedLookaheadLanguageModel:
         p, st = K._p, K._stream()
         if state["cumsum"] is None:  # first step: the word history is <eos>, every hypothesis sits at the root
             w = torch.full((N,), self.word_eos_idx, dtype=torch.long, device=dev)
-            feat, state["lstm"] = self.lm_decoder.step(w, state["lstm"])
+            feat, state["lstm"] = self.lm_decoder.advance(w, state["lstm"])
             logits = self.lm_decoder.output_layer(feat)
             state["cumsum"] = torch.empty(N, Vw, dtype=torch.float32, device=dev)
             state["lp_eos"] = torch.empty(N, dtype=torch.float32, device=dev)
@@ -70,7 +70,7 @@ class TensorizedLookaheadLanguageModel:
             w = torch.where(w < 0, torch.full_like(w, self.word_unk_idx), w)
             space = prev == self.subword_space_idx
             frozen = (~space).to(torch.uint8).contiguous()  # the word LM only advances where a word was just closed
-            feat, state["lstm"] = self.lm_decoder.step(w, state["lstm"], keep_row=frozen)
+            feat, state["lstm"] = self.lm_decoder.advance(w, state["lstm"], keep_row=frozen)
             logits = self.lm_decoder.output_layer(feat)
             _lib.check(lib.ea_softmax_cumsum(p(logits), logits.stride(0), p(space.to(torch.uint8).contiguous()), p(state["cumsum"]),
                                              p(state["lp_eos"]), N, Vw, self.word_eos_idx, st), "ea_softmax_cumsum")

@@ -80,14 +80,14 @@ class TransducerGreedyDecoder:
             blank_mask = step >= enc_len  # B
             k = 0
             while not bool(blank_mask.all()) and k < Ex + 1:
-                dec_out, new_state = model.decoder.step(prev, state)
+                dec_out, new_state = model.decoder.advance(prev, state)
                 logits = model.joint_step(E[:, step].contiguous(), dec_out)[:, :V]
                 if self.temperature != 1.0:
                     logits = logits / self.temperature
                 lprobs = K.log_softmax(logits, bsz, V, logits.stride(0))
                 if self.lm_model is not None:
                     lm_prev = torch.where(prev > self.blank, prev - 1, prev) if self.no_blank_in_lm else prev
-                    lm_feat, new_lm_state = self.lm_model.decoder.step(lm_prev, lm_state)
+                    lm_feat, new_lm_state = self.lm_model.decoder.advance(lm_prev, lm_state)
                     lm_logits = self.lm_model.decoder.output_layer(lm_feat)
                     lm_lprobs = K.log_softmax(lm_logits, bsz, lm_logits.shape[1], lm_logits.stride(0))
                     nb = lprobs[:, nonblank]

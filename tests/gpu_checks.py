@@ -1026,3 +1026,45 @@ def check_speech_lstm_vs_reference():
     res["worst_l2_frontend"] = max(fe.items(), key=lambda kv: kv[1])
     res["worst_scale"] = max(((k, v) for k, v in scale.items() if not k.startswith("encoder.pre_encoder")), key=lambda kv: abs(kv[1] - 1.0))
     return res
+
+
+def check_speech_lstm_beam_search():
+    """Beam search with the attention LSTM decoder (incremental state: (h, c) per layer, input feed, per-sentence encoder keys /
+    values addressed through kv_col) vs the reference SequenceGenerator's beams on the same weights."""
+    from espresso_amd.sequence_generator import SequenceGenerator
+
+    g = np.load(os.path.join(GOLD, "ref_speech_lstm_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = build_tiny_speech_lstm().to(DEV)
+    model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    model.eval()
+    d = _TaskAR(40).target_dictionary
+    sample = {"net_input": {"src_tokens": torch.from_numpy(g["feats"]).to(DEV), "src_lengths": torch.from_numpy(g["lengths"]).to(DEV)}}
+    gen = SequenceGenerator([model], d, beam_size=3, max_len_a=0.0, max_len_b=10)
+    hyps = gen.generate([model], sample)
+    res = {"in_beam": [], "score_abs": 0.0}
+    for b, hl in enumerate(hyps):
+        refset, hi = {}, 0
+        while f"beam::b3::{b}::{hi}::tokens" in g.files:
+            refset[tuple(g[f"beam::b3::{b}::{hi}::tokens"].tolist())] = float(g[f"beam::b3::{b}::{hi}::score"])
+            hi += 1
+        res["in_beam"].append(sum(tuple(h["tokens"].tolist()) in refset for h in hl) / len(hl))
+        for h in hl:
+            k = tuple(h["tokens"].tolist())
+            if k in refset:
+                res["score_abs"] = max(res["score_abs"], abs(float(h["score"]) - refset[k]))
+    # force-decode the reference's best hypotheses through the incremental path
+    toks = torch.stack([torch.from_numpy(g[f"beam::b3::{b}::0::tokens"]) for b in range(3)]).to(DEV)
+    ref_pos = torch.stack([torch.from_numpy(g[f"beam::b3::{b}::0::pos"]) for b in range(3)])
+    with torch.no_grad():
+        enc_out = model.forward_encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+        st = model.decoder.init_incremental(enc_out, 3, 1)
+        cur = torch.full((3, 1), d.eos(), dtype=torch.long, device=DEV)
+        got = []
+        for step in range(toks.shape[1]):
+            lp = model.decoder.step(st, cur, step, None if step == 0 else torch.arange(3, device=DEV))
+            got.append(lp.gather(-1, toks[:, step:step + 1]).squeeze(-1).cpu())
+            cur = torch.cat([cur, toks[:, step:step + 1]], 1)
+    got = torch.stack(got, 1)
+    res["forced_decode_pos_score_abs"] = float((got[:, :-1] - ref_pos[:, :-1]).abs().max())
+    return res

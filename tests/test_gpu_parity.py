@@ -251,3 +251,10 @@ def test_speech_lstm_vs_reference_fixture():
     assert r["worst_l2"][1] < 0.1, r
     assert r["worst_l2_frontend"][1] < 0.5, r   # same bound as the Conformer/Transformer encoder tests use for the conv/BN stack
     assert abs(r["worst_scale"][1] - 1.0) < 5e-2, r
+
+
+def test_speech_lstm_beam_search_vs_reference():
+    r = G.check_speech_lstm_beam_search()
+    print(r)
+    assert r["forced_decode_pos_score_abs"] < 5e-2, r   # per-position log-probs of the reference's best hypotheses
+    assert r["score_abs"] < 3e-2, r                     # hypotheses found by both generators carry the same score
