@@ -169,6 +169,10 @@ def main():
     samples = [synthetic.make_sample(b, n_samples, VOCAB, pad, device, seed=1) for b in mine]
     task.build_frontend(device, cmvn=estimate_cmvn(task, samples[0], device))
     task.begin_epoch(1)
+    # start-up only: size the arenas for the longest utterance and the largest batch of this run (no parameter update)
+    by_T = max(samples, key=lambda s: max(s["num_samples"]))
+    by_M = max(samples, key=lambda s: s["audio_seconds"])
+    trainer.reserve([by_M] if by_M is by_T else [by_M, by_T])
     torch.cuda.synchronize()
 
     def sync():

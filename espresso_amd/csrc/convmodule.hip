@@ -13,72 +13,83 @@
 namespace {
 
 constexpr int KMAX = 31;
-constexpr int TT = 32;  // output timesteps per block
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// Depthwise-conv tiles: one workgroup = CT channels x TTILE output steps of one utterance; the input rows (plus the KW-1
+// halo) are staged once in LDS with every global load in flight at once, then each thread produces TPT consecutive outputs
+// of one channel from registers.  (The first version streamed the rows through a per-thread shift register: 62 dependent
+// row loads per wavefront and only ~800 wavefronts in flight — 51 us where the traffic is worth 5 us.)
+constexpr int CT = 64, TTILE = 64, TPT = TTILE / 4;
+
 // Y [M][2C] -> U = a*sigmoid(g) [M][C] (saved), Z = dwconv(U) [M][C] (pre-BN), stats += (sum, sumsq)
 template <int KW>
-__global__ __launch_bounds__(128) void glu_dwconv_fwd_kernel(const bf16_t* __restrict__ Y,
+__global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16_t* __restrict__ Y,
                                                              const float* __restrict__ w,  // [C][KW]
                                                              bf16_t* __restrict__ U, bf16_t* __restrict__ Z,
                                                              float* __restrict__ stats, int T, int C) {
-  constexpr int PAD = (KW - 1) / 2;
-  const int c = (blockIdx.x * 128 + threadIdx.x) * 2;
-  if (c >= C) return;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.y * TT;
-  float w0[KW], w1[KW];
-#pragma unroll
-  for (int k = 0; k < KW; ++k) {
-    w0[k] = w[(long)c * KW + k];
-    w1[k] = w[(long)(c + 1) * KW + k];
-  }
-  float x0[KW], x1[KW];
-#pragma unroll
-  for (int k = 0; k < KW; ++k) x0[k] = x1[k] = 0.f;
-  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1;
+  __shared__ float su[ROWS][CT];
+  __shared__ float sred[2][4][CT];
+  const int c0 = blockIdx.x * CT, t0 = blockIdx.y * TTILE, b = blockIdx.z;
   const long rowbase = (long)b * T;
-  // stream inputs t0-PAD .. t0+TT-1+PAD ; output t = tin - PAD once the window is full
-  for (int tin = t0 - PAD; tin < t0 + TT + PAD; ++tin) {
+  for (int i = threadIdx.x; i < ROWS * (CT / 2); i += 256) {
+    const int row = i / (CT / 2), cp = (i % (CT / 2)) * 2;
+    const int tin = t0 - PAD + row;
     float u0 = 0.f, u1 = 0.f;
-    if (tin >= 0 && tin < T) {
-      const bf16_t* yr = Y + (rowbase + tin) * (2L * C);
-      const uint32_t a = *reinterpret_cast<const uint32_t*>(yr + c);
-      const uint32_t g = *reinterpret_cast<const uint32_t*>(yr + C + c);
+    if (tin >= 0 && tin < T && c0 + cp < C) {
+      const bf16_t* yr = Y + (rowbase + tin) * (2L * C) + c0 + cp;
+      const uint32_t a = *reinterpret_cast<const uint32_t*>(yr);
+      const uint32_t g = *reinterpret_cast<const uint32_t*>(yr + C);
       u0 = __uint_as_float(a << 16) * sigmoid_f(__uint_as_float(g << 16));
       u1 = __uint_as_float(a & 0xffff0000u) * sigmoid_f(__uint_as_float(g & 0xffff0000u));
-      if (tin >= t0 && tin < t0 + TT) *reinterpret_cast<uint32_t*>(U + (rowbase + tin) * C + c) = pack_bf2(u0, u1);
-      // conv consumes the bf16-rounded U (what backward will see)
-      u0 = bf2f(f2bf(u0));
-      u1 = bf2f(f2bf(u1));
+      const uint32_t pk = pack_bf2(u0, u1);
+      if (row >= PAD && row < PAD + TTILE) *reinterpret_cast<uint32_t*>(U + (rowbase + tin) * C + c0 + cp) = pk;
+      // the conv consumes the bf16-rounded U (what backward will see)
+      u0 = __uint_as_float(pk << 16);
+      u1 = __uint_as_float(pk & 0xffff0000u);
     }
+    su[row][cp] = u0;
+    su[row][cp + 1] = u1;
+  }
+  const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  float wk[KW];
 #pragma unroll
-    for (int k = 0; k < KW - 1; ++k) {
-      x0[k] = x0[k + 1];
-      x1[k] = x1[k + 1];
-    }
-    x0[KW - 1] = u0;
-    x1[KW - 1] = u1;
-    const int tout = tin - PAD;
-    if (tout >= t0 && tout < T) {
-      float z0 = 0.f, z1 = 0.f;
+  for (int k = 0; k < KW; ++k) wk[k] = c < C ? w[(long)c * KW + k] : 0.f;
+  __syncthreads();
+  float acc[TPT];
 #pragma unroll
-      for (int k = 0; k < KW; ++k) {
-        z0 += w0[k] * x0[k];
-        z1 += w1[k] * x1[k];
-      }
-      *reinterpret_cast<uint32_t*>(Z + (rowbase + tout) * C + c) = pack_bf2(z0, z1);
-      z0 = bf2f(f2bf(z0));
-      z1 = bf2f(f2bf(z1));
-      s0 += z0; s1 += z1; q0 += z0 * z0; q1 += z1 * z1;
+  for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
+  // output j of this thread sits at tile step grp*TPT + j and reads LDS rows grp*TPT + j + k, k = 0..KW-1
+#pragma unroll
+  for (int r = 0; r < TPT + KW - 1; ++r) {
+    const float x = su[grp * TPT + r][cl];
+#pragma unroll
+    for (int j = 0; j < TPT; ++j)
+      if (r - j >= 0 && r - j < KW) acc[j] += wk[r - j] * x;
+  }
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int j = 0; j < TPT; ++j) {
+    const int tout = t0 + grp * TPT + j;
+    if (tout < T && c < C) {
+      const bf16_t zb = f2bf(acc[j]);
+      Z[(rowbase + tout) * C + c] = zb;
+      const float z = bf2f(zb);
+      s += z;
+      q += z * z;
     }
   }
   if (stats) {
-    atomicAdd(stats + c, s0);
-    atomicAdd(stats + c + 1, s1);
-    atomicAdd(stats + C + c, q0);
-    atomicAdd(stats + C + c + 1, q1);
+    sred[0][grp][cl] = s;
+    sred[1][grp][cl] = q;
+    __syncthreads();
+    if (threadIdx.x < CT && c0 + threadIdx.x < C) {
+      const int x = threadIdx.x;
+      atomicAdd(stats + c0 + x, sred[0][0][x] + sred[0][1][x] + sred[0][2][x] + sred[0][3][x]);
+      atomicAdd(stats + C + c0 + x, sred[1][0][x] + sred[1][1][x] + sred[1][2][x] + sred[1][3][x]);
+    }
   }
 }
 
@@ -224,93 +235,124 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16_t* __r
   }
 }
 
-// dU[t] = sum_k w[k] * dZ[t + PAD - k]; then GLU backward -> dY [M][2C]
+// dU[t] = sum_k w[k] * dZ[t + PAD - k]; then GLU backward -> dY [M][2C]   (same tiling as the forward kernel)
 template <int KW>
-__global__ __launch_bounds__(128) void glu_dwconv_bwd_data_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y,
+__global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y,
                                                                   const float* __restrict__ w, bf16_t* __restrict__ dY,
                                                                   int T, int C) {
-  constexpr int PAD = (KW - 1) / 2;
-  const int c = (blockIdx.x * 128 + threadIdx.x) * 2;
-  if (c >= C) return;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.y * TT;
-  float w0[KW], w1[KW];
-#pragma unroll
-  for (int k = 0; k < KW; ++k) {  // flipped taps
-    w0[k] = w[(long)c * KW + (KW - 1 - k)];
-    w1[k] = w[(long)(c + 1) * KW + (KW - 1 - k)];
-  }
-  float x0[KW], x1[KW];
-#pragma unroll
-  for (int k = 0; k < KW; ++k) x0[k] = x1[k] = 0.f;
+  constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1;
+  __shared__ float sd[ROWS][CT];
+  const int c0 = blockIdx.x * CT, t0 = blockIdx.y * TTILE, b = blockIdx.z;
   const long rowbase = (long)b * T;
-  for (int tin = t0 - PAD; tin < t0 + TT + PAD; ++tin) {
+  for (int i = threadIdx.x; i < ROWS * (CT / 2); i += 256) {
+    const int row = i / (CT / 2), cp = (i % (CT / 2)) * 2;
+    const int tin = t0 - PAD + row;
     float d0 = 0.f, d1 = 0.f;
-    if (tin >= 0 && tin < T) {
-      const uint32_t dd = *reinterpret_cast<const uint32_t*>(dZ + (rowbase + tin) * C + c);
+    if (tin >= 0 && tin < T && c0 + cp < C) {
+      const uint32_t dd = *reinterpret_cast<const uint32_t*>(dZ + (rowbase + tin) * C + c0 + cp);
       d0 = __uint_as_float(dd << 16);
       d1 = __uint_as_float(dd & 0xffff0000u);
     }
+    sd[row][cp] = d0;
+    sd[row][cp + 1] = d1;
+  }
+  const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  float wk[KW];
 #pragma unroll
-    for (int k = 0; k < KW - 1; ++k) {
-      x0[k] = x0[k + 1];
-      x1[k] = x1[k + 1];
+  for (int k = 0; k < KW; ++k) wk[k] = c < C ? w[(long)c * KW + k] : 0.f;
+  __syncthreads();
+  float acc[TPT];
+#pragma unroll
+  for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
+  // dU[tout] needs dZ[tout + PAD - k]: LDS row (grp*TPT + j) + 2*PAD - k, i.e. tap k = j + 2*PAD - r for row offset r
+#pragma unroll
+  for (int r = 0; r < TPT + KW - 1; ++r) {
+    const float x = sd[grp * TPT + r][cl];
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+      const int k = j + 2 * PAD - r;
+      if (k >= 0 && k < KW) acc[j] += wk[k] * x;
     }
-    x0[KW - 1] = d0;
-    x1[KW - 1] = d1;
-    const int tout = tin - PAD;
-    if (tout >= t0 && tout < T) {
-      // window holds dZ[tout-PAD .. tout+PAD] at x[0..KW-1];  dU[tout] = sum_j w[j]*dZ[tout+PAD-j]
-      float u0 = 0.f, u1 = 0.f;
+  }
 #pragma unroll
-      for (int k = 0; k < KW; ++k) {
-        u0 += w0[k] * x0[k];
-        u1 += w1[k] * x1[k];
-      }
+  for (int j = 0; j < TPT; ++j) {
+    const int tout = t0 + grp * TPT + j;
+    if (tout < T && c < C) {
       const bf16_t* yr = Y + (rowbase + tout) * (2L * C);
-      const uint32_t a = *reinterpret_cast<const uint32_t*>(yr + c);
-      const uint32_t g = *reinterpret_cast<const uint32_t*>(yr + C + c);
-      const float a0 = __uint_as_float(a << 16), a1 = __uint_as_float(a & 0xffff0000u);
-      const float sg0 = sigmoid_f(__uint_as_float(g << 16)), sg1 = sigmoid_f(__uint_as_float(g & 0xffff0000u));
+      const float a = bf2f(yr[c]);
+      const float sg = sigmoid_f(bf2f(yr[C + c]));
       bf16_t* dyr = dY + (rowbase + tout) * (2L * C);
-      *reinterpret_cast<uint32_t*>(dyr + c) = pack_bf2(u0 * sg0, u1 * sg1);
-      *reinterpret_cast<uint32_t*>(dyr + C + c) = pack_bf2(u0 * a0 * sg0 * (1.f - sg0), u1 * a1 * sg1 * (1.f - sg1));
+      dyr[c] = f2bf(acc[j] * sg);
+      dyr[C + c] = f2bf(acc[j] * a * sg * (1.f - sg));
     }
   }
 }
 
 // dw[c][k] += sum_{b,t} dZ[b,t,c] * U[b,t-PAD+k,c]
-// Weight gradient of the depthwise conv: one channel per thread, 32-step time tiles -> many wavefronts to hide the
-// dependent-load latency; each block writes its partial [C][KW] slab (no atomics), a second kernel sums slabs.
-constexpr int TTW = 32;
+// Weight gradient of the depthwise conv: workgroup = (CT channels, one utterance), looping over 64-step time tiles staged in
+// LDS; thread (channel, tap group of 8) keeps a sliding window of U in registers.  One partial [C][KW] slab per utterance
+// (no atomics), a second kernel sums the B slabs.
 template <int KW>
-__global__ __launch_bounds__(128) void dwconv_bwd_weight_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ U,
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ U,
                                                                 float* __restrict__ part, int T, int C) {
-  constexpr int PAD = (KW - 1) / 2;
-  const int c = blockIdx.x * 128 + threadIdx.x;
-  if (c >= C) return;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.y * TTW;
-  float a0[KW], x0[KW];
-#pragma unroll
-  for (int k = 0; k < KW; ++k) a0[k] = x0[k] = 0.f;
+  constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1, KG = 8;
+  __shared__ float sU[ROWS + KG][CT];
+  __shared__ float sD[TTILE][CT];
+  const int c0 = blockIdx.x * CT, b = blockIdx.z;
   const long rowbase = (long)b * T;
-  for (int tin = t0 - PAD; tin < t0 + TTW + PAD; ++tin) {
-    float u0 = 0.f;
-    if (tin >= 0 && tin < T) u0 = bf2f(U[(rowbase + tin) * C + c]);
+  const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;  // taps grp*8 .. grp*8+7
+  float acc[KG];
 #pragma unroll
-    for (int k = 0; k < KW - 1; ++k) x0[k] = x0[k + 1];
-    x0[KW - 1] = u0;
-    const int tout = tin - PAD;
-    if (tout >= t0 && tout < T) {
-      const float d0 = bf2f(dZ[(rowbase + tout) * C + c]);
+  for (int k = 0; k < KG; ++k) acc[k] = 0.f;
+  for (int t0 = 0; t0 < T; t0 += TTILE) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (ROWS + KG) * (CT / 2); i += 256) {
+      const int row = i / (CT / 2), cp = (i % (CT / 2)) * 2;
+      const int tin = t0 - PAD + row;
+      float u0 = 0.f, u1 = 0.f;
+      if (row < ROWS && tin >= 0 && tin < T && c0 + cp < C) {
+        const uint32_t uu = *reinterpret_cast<const uint32_t*>(U + (rowbase + tin) * C + c0 + cp);
+        u0 = __uint_as_float(uu << 16);
+        u1 = __uint_as_float(uu & 0xffff0000u);
+      }
+      sU[row][cp] = u0;
+      sU[row][cp + 1] = u1;
+    }
+    for (int i = threadIdx.x; i < TTILE * (CT / 2); i += 256) {
+      const int row = i / (CT / 2), cp = (i % (CT / 2)) * 2;
+      const int t = t0 + row;
+      float d0 = 0.f, d1 = 0.f;
+      if (t < T && c0 + cp < C) {
+        const uint32_t dd = *reinterpret_cast<const uint32_t*>(dZ + (rowbase + t) * C + c0 + cp);
+        d0 = __uint_as_float(dd << 16);
+        d1 = __uint_as_float(dd & 0xffff0000u);
+      }
+      sD[row][cp] = d0;
+      sD[row][cp + 1] = d1;
+    }
+    __syncthreads();
+    // dw[k] += dZ[t] * U[t - PAD + k]  ->  LDS row of U = (t - t0) + k ; window x[kk] = sU[tt + grp*8 + kk]
+    float x[KG];
 #pragma unroll
-      for (int k = 0; k < KW; ++k) a0[k] += d0 * x0[k];
+    for (int kk = 0; kk < KG - 1; ++kk) x[kk + 1] = sU[grp * KG + kk][cl];
+#pragma unroll
+    for (int tt = 0; tt < TTILE; ++tt) {
+#pragma unroll
+      for (int kk = 0; kk < KG - 1; ++kk) x[kk] = x[kk + 1];
+      x[KG - 1] = sU[tt + grp * KG + KG - 1][cl];
+      const float d = sD[tt][cl];
+#pragma unroll
+      for (int kk = 0; kk < KG; ++kk) acc[kk] += d * x[kk];
     }
   }
-  float* out = part + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * C + c) * KW;
+  const int c = c0 + cl;
+  if (c < C) {
+    float* out = part + ((long)b * C + c) * KW;
 #pragma unroll
-  for (int k = 0; k < KW; ++k) out[k] = a0[k];
+    for (int kk = 0; kk < KG; ++kk)
+      if (grp * KG + kk < KW) out[grp * KG + kk] = acc[kk];
+  }
 }
 __global__ __launch_bounds__(256) void dwconv_weight_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nslab,
                                                                    int n) {
@@ -348,24 +390,24 @@ static inline int egrid_ch(long n, int nch) {
 template <int KW>
 static void launch_glu_dwconv_fwd(dim3 grid, hipStream_t stream, const bf16_t* Y, const float* w, bf16_t* U, bf16_t* Z,
                                   float* stats, int T, int C) {
-  hipLaunchKernelGGL((glu_dwconv_fwd_kernel<KW>), grid, dim3(128), 0, stream, Y, w, U, Z, stats, T, C);
+  hipLaunchKernelGGL((glu_dwconv_fwd_kernel<KW>), grid, dim3(256), 0, stream, Y, w, U, Z, stats, T, C);
 }
 template <int KW>
 static void launch_glu_dwconv_bwd_data(dim3 grid, hipStream_t stream, const bf16_t* dZ, const bf16_t* Y, const float* w,
                                        bf16_t* dY, int T, int C) {
-  hipLaunchKernelGGL((glu_dwconv_bwd_data_kernel<KW>), grid, dim3(128), 0, stream, dZ, Y, w, dY, T, C);
+  hipLaunchKernelGGL((glu_dwconv_bwd_data_kernel<KW>), grid, dim3(256), 0, stream, dZ, Y, w, dY, T, C);
 }
 template <int KW>
 static void launch_dwconv_bwd_weight(dim3 grid, hipStream_t stream, const bf16_t* dZ, const bf16_t* U, float* dw, int T,
                                      int C) {
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KW>), grid, dim3(128), 0, stream, dZ, U, dw, T, C);
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KW>), grid, dim3(256), 0, stream, dZ, U, dw, T, C);
 }
 
 extern "C" int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z, float* stats, int B, int T,
                                  int C, int KW, hipStream_t stream) {
   if (B <= 0 || T <= 0) return 0;
   if (C % 2) return -2;
-  dim3 grid((C / 2 + 127) / 128, (T + TT - 1) / TT, B);
+  dim3 grid((C + CT - 1) / CT, (T + TTILE - 1) / TTILE, B);
   EA_KW_DISPATCH(KW, launch_glu_dwconv_fwd, grid, stream, (const bf16_t*)Y, w, (bf16_t*)U, (bf16_t*)Z, stats, T, C);
   return EA_CHECK_LAUNCH();
 }
@@ -424,19 +466,19 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
 }
 
 extern "C" long ea_dwconv_wgrad_workspace_bytes(int B, int T, int C, int KW) {
-  return (long)B * ((T + TTW - 1) / TTW) * C * KW * (long)sizeof(float);
+  (void)T;
+  return (long)B * C * KW * (long)sizeof(float);
 }
 
 extern "C" int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float* w, void* dY, float* dw,
                                  void* wgrad_ws, int B, int T, int C, int KW, hipStream_t stream) {
   if (B <= 0 || T <= 0) return 0;
   if (C % 2) return -2;
-  dim3 grid((C / 2 + 127) / 128, (T + TT - 1) / TT, B);
+  dim3 grid((C + CT - 1) / CT, (T + TTILE - 1) / TTILE, B);
   EA_KW_DISPATCH(KW, launch_glu_dwconv_bwd_data, grid, stream, (const bf16_t*)dZ, (const bf16_t*)Y, w, (bf16_t*)dY, T, C);
-  dim3 gridw((C + 127) / 128, (T + TTW - 1) / TTW, B);
+  dim3 gridw((C + CT - 1) / CT, 1, B);
   float* part = (float*)wgrad_ws;
   EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, gridw, stream, (const bf16_t*)dZ, (const bf16_t*)U, part, T, C);
-  hipLaunchKernelGGL(dwconv_weight_reduce_kernel, dim3((C * KW + 255) / 256), dim3(256), 0, stream, part, dw,
-                     (int)(gridw.y * gridw.z), C * KW);
+  hipLaunchKernelGGL(dwconv_weight_reduce_kernel, dim3((C * KW + 255) / 256), dim3(256), 0, stream, part, dw, B, C * KW);
   return EA_CHECK_LAUNCH();
 }

@@ -58,5 +58,24 @@ class Trainer:
         self.lr_scheduler.step_update(self.num_updates)
         return self._stats
 
+    def reserve(self, samples):
+        """Size every grow-only arena (saved activations per layer, scratch, split-K slabs, allocator pools) for the largest
+        batch shapes that will be seen: one forward + backward over each given sample with gradient reduction disabled,
+        gradients and BatchNorm statistics restored afterwards; no optimizer update.  Called once at start-up (the reference's
+        trainer does the same for the CUDA caching allocator with its dummy-batch / OOM-recovery logic, trainer.py:803-855)."""
+        bn = {n: b.clone() for n, b in self.model.named_buffers()}
+        self.model.train()
+        with self.ddp.no_sync():
+            for sample in samples:
+                sample = self.task.prepare_sample(sample, train=True)
+                loss, _, _ = self.criterion(self.ddp, sample)
+                loss.backward()
+        self.flat.zero_grad()
+        with torch.no_grad():
+            for n, b in self.model.named_buffers():
+                b.copy_(bn[n])
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
     def valid_step(self, sample):
         return self.task.valid_step(sample, self.model, self.criterion)
