@@ -153,45 +153,58 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
 }
 
 // BN backward pass 1: red[0][c] += sum dy, red[1][c] += sum dy*xhat, dy = dH * act'(y)
-// block = 256 threads = TC channel pairs x (256/TC) row lanes; rows split over blockIdx.y
+// A thread owns one 8-channel chunk (16-byte loads of Z and dH, per-channel constants hoisted) and walks rows in steps of the
+// block's row lanes; per-block partial sums meet in LDS and cost 2*C atomics per block, so blocks take >= 32 rows per lane
+// group (fp32 atomics run at ~33 G/s: the first version issued 2*C atomics per 8 rows and spent its time there).
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16_t* __restrict__ Z, const bf16_t* __restrict__ dH,
                                                                 const float* __restrict__ mean_rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ red, long M, int C, int act,
-                                                                int rows_per_block, int TC) {
-  __shared__ float sm[2][256][2];
-  const int cx = threadIdx.x % TC, ry = threadIdx.x / TC, TR = 256 / TC;
-  const int c = (blockIdx.x * TC + cx) * 2;
+                                                                int rows_per_block, int TCH) {
+  extern __shared__ float sm[];  // [lanes][TCH][16]
+  const int nch = C >> 3;
+  const int cx = threadIdx.x % TCH, ry = threadIdx.x / TCH, lanes = 256 / TCH;
+  const int ch = blockIdx.x * TCH + cx;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = min(M, r0 + rows_per_block);
-  float sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f;
-  if (c < C) {
-    const float m0 = mean_rstd[c], m1 = mean_rstd[c + 1], i0 = mean_rstd[C + c], i1 = mean_rstd[C + c + 1];
-    const float g0 = gamma[c], g1 = gamma[c + 1], b0 = beta[c], b1 = beta[c + 1];
-    for (long m = r0 + ry; m < r1; m += TR) {
-      const uint32_t zz = *reinterpret_cast<const uint32_t*>(Z + m * C + c);
-      const uint32_t dd = *reinterpret_cast<const uint32_t*>(dH + m * C + c);
-      const float xh0 = (__uint_as_float(zz << 16) - m0) * i0, xh1 = (__uint_as_float(zz & 0xffff0000u) - m1) * i1;
-      const float y0 = xh0 * g0 + b0, y1 = xh1 * g1 + b1;
-      float d0 = __uint_as_float(dd << 16), d1 = __uint_as_float(dd & 0xffff0000u);
-      d0 *= act == 2 ? dsilu_f(y0) : (act == 1 ? (y0 > 0.f ? 1.f : 0.f) : 1.f);
-      d1 *= act == 2 ? dsilu_f(y1) : (act == 1 ? (y1 > 0.f ? 1.f : 0.f) : 1.f);
-      sa0 += d0; sa1 += d1; sb0 += d0 * xh0; sb1 += d1 * xh1;
+  float sa[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sa[e] = sb[e] = 0.f;
+  if (ch < nch) {
+    float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = ch * 8 + e;
+      mu[e] = mean_rstd[c]; rs[e] = mean_rstd[C + c]; ga[e] = gamma[c]; be[e] = beta[c];
+    }
+    for (long m = r0 + ry; m < r1; m += lanes) {
+      const uint4 uz = *reinterpret_cast<const uint4*>(Z + m * C + ch * 8);
+      const uint4 ud = *reinterpret_cast<const uint4*>(dH + m * C + ch * 8);
+      const uint32_t wz[4] = {uz.x, uz.y, uz.z, uz.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = (e & 1) ? __uint_as_float(wz[e >> 1] & 0xffff0000u) : __uint_as_float(wz[e >> 1] << 16);
+        float d = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
+        const float xh = (z - mu[e]) * rs[e];
+        const float y = xh * ga[e] + be[e];
+        d *= act == 2 ? dsilu_f(y) : (act == 1 ? (y > 0.f ? 1.f : 0.f) : 1.f);
+        sa[e] += d;
+        sb[e] += d * xh;
+      }
     }
   }
-  sm[0][threadIdx.x][0] = sa0; sm[0][threadIdx.x][1] = sa1;
-  sm[1][threadIdx.x][0] = sb0; sm[1][threadIdx.x][1] = sb1;
+  float* mine = sm + ((long)ry * TCH + cx) * 16;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mine[e] = sa[e]; mine[8 + e] = sb[e]; }
   __syncthreads();
-  if (threadIdx.x < TC && c < C) {
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-    for (int r = 0; r < TR; ++r) {
-      a0 += sm[0][r * TC + cx][0]; a1 += sm[0][r * TC + cx][1];
-      b0 += sm[1][r * TC + cx][0]; b1 += sm[1][r * TC + cx][1];
-    }
-    atomicAdd(red + c, a0);
-    atomicAdd(red + c + 1, a1);
-    atomicAdd(red + C + c, b0);
-    atomicAdd(red + C + c + 1, b1);
+  // TCH*16 outputs per block: thread t sums column t over the row lanes
+  for (int o = threadIdx.x; o < TCH * 16; o += 256) {
+    const int cxo = o / 16, e = o % 16;
+    const int cho = blockIdx.x * TCH + cxo;
+    if (cho >= nch) continue;
+    float a = 0.f;
+    for (int r = 0; r < lanes; ++r) a += sm[((long)r * TCH + cxo) * 16 + e];
+    atomicAdd(red + (e < 8 ? 0 : C) + cho * 8 + (e & 7), a);
   }
 }
 
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
 // (no atomics), a second kernel sums the B slabs.
 template <int KW>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ U,
-                                                                float* __restrict__ part, int T, int C) {
+                                                                float* __restrict__ part, int T, int C, int tiles_per_block) {
   constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1, KG = 8;
   __shared__ float sU[ROWS + KG][CT];
   __shared__ float sD[TTILE][CT];
@@ -305,7 +318,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16_t* __
   float acc[KG];
 #pragma unroll
   for (int k = 0; k < KG; ++k) acc[k] = 0.f;
-  for (int t0 = 0; t0 < T; t0 += TTILE) {
+  const int tbeg = blockIdx.y * tiles_per_block * TTILE, tend = min(T, tbeg + tiles_per_block * TTILE);
+  for (int t0 = tbeg; t0 < tend; t0 += TTILE) {
     __syncthreads();
     for (int i = threadIdx.x; i < (ROWS + KG) * (CT / 2); i += 256) {
       const int row = i / (CT / 2), cp = (i % (CT / 2)) * 2;
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16_t* __
   }
   const int c = c0 + cl;
   if (c < C) {
-    float* out = part + ((long)b * C + c) * KW;
+    float* out = part + (((long)b * gridDim.y + blockIdx.y) * C + c) * KW;
 #pragma unroll
     for (int kk = 0; kk < KG; ++kk)
       if (grp * KG + kk < KW) out[grp * KG + kk] = acc[kk];
@@ -399,8 +413,8 @@ static void launch_glu_dwconv_bwd_data(dim3 grid, hipStream_t stream, const bf16
 }
 template <int KW>
 static void launch_dwconv_bwd_weight(dim3 grid, hipStream_t stream, const bf16_t* dZ, const bf16_t* U, float* dw, int T,
-                                     int C) {
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KW>), grid, dim3(256), 0, stream, dZ, U, dw, T, C);
+                                     int C, int tiles_per_block) {
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KW>), grid, dim3(256), 0, stream, dZ, U, dw, T, C, tiles_per_block);
 }
 
 extern "C" int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z, float* stats, int B, int T,
@@ -450,14 +464,15 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
                              int act, int training, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 8) return -2;
-  int TC = 1;
-  while (TC < 256 && TC * 2 < C) TC <<= 1;  // channel-pair threads per block (power of two <= 256)
-  int rpb = (int)((M + 1023) / 1024);
-  const int TR = 256 / TC;
-  if (rpb < 8 * TR) rpb = 8 * TR;
-  dim3 g1((C / 2 + TC - 1) / TC, (unsigned)((M + rpb - 1) / rpb));
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, g1, dim3(256), 0, stream, (const bf16_t*)Z, (const bf16_t*)dH,
-                     mean_rstd, gamma, beta, red, M, C, act, rpb, TC);
+  const int nch = C / 8;
+  int TCH = 1;
+  while (TCH < 256 && TCH < nch) TCH <<= 1;  // 8-channel chunks per block row (power of two <= 256)
+  const int lanes = 256 / TCH;
+  int rpb = 8 * lanes;                        // >= 8 rows per thread
+  if (rpb < 32) rpb = 32;
+  dim3 g1((nch + TCH - 1) / TCH, (unsigned)((M + rpb - 1) / rpb));
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, g1, dim3(256), (size_t)256 * 16 * sizeof(float), stream, (const bf16_t*)Z,
+                     (const bf16_t*)dH, mean_rstd, gamma, beta, red, M, C, act, rpb, TCH);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z,
                      (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, M, C, act,
                      training ? (float)M : 0.f);
@@ -465,9 +480,13 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
   return EA_CHECK_LAUNCH();
 }
 
+constexpr int DW_TILES_PER_BLOCK = 2;
+static inline int dw_time_blocks(int T) {
+  const int nt = (T + TTILE - 1) / TTILE;
+  return (nt + DW_TILES_PER_BLOCK - 1) / DW_TILES_PER_BLOCK;
+}
 extern "C" long ea_dwconv_wgrad_workspace_bytes(int B, int T, int C, int KW) {
-  (void)T;
-  return (long)B * C * KW * (long)sizeof(float);
+  return (long)B * dw_time_blocks(T) * C * KW * (long)sizeof(float);
 }
 
 extern "C" int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float* w, void* dY, float* dw,
@@ -476,9 +495,10 @@ extern "C" int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, c
   if (C % 2) return -2;
   dim3 grid((C + CT - 1) / CT, (T + TTILE - 1) / TTILE, B);
   EA_KW_DISPATCH(KW, launch_glu_dwconv_bwd_data, grid, stream, (const bf16_t*)dZ, (const bf16_t*)Y, w, (bf16_t*)dY, T, C);
-  dim3 gridw((C + CT - 1) / CT, 1, B);
+  dim3 gridw((C + CT - 1) / CT, dw_time_blocks(T), B);
   float* part = (float*)wgrad_ws;
-  EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, gridw, stream, (const bf16_t*)dZ, (const bf16_t*)U, part, T, C);
-  hipLaunchKernelGGL(dwconv_weight_reduce_kernel, dim3((C * KW + 255) / 256), dim3(256), 0, stream, part, dw, B, C * KW);
+  EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, gridw, stream, (const bf16_t*)dZ, (const bf16_t*)U, part, T, C, DW_TILES_PER_BLOCK);
+  hipLaunchKernelGGL(dwconv_weight_reduce_kernel, dim3((C * KW + 255) / 256), dim3(256), 0, stream, part, dw,
+                     (int)(gridw.y * gridw.z), C * KW);
   return EA_CHECK_LAUNCH();
 }

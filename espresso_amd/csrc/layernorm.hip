@@ -24,9 +24,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C,
     float eps, const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
   const int nch = C >> 3;  // 16-byte chunks per row
+  // affine parameters of this lane's chunks stay in registers across the rows the wavefront walks (re-reading 2*C fp32 per
+  // row is 4x the bf16 row itself)
+  float ga[MAXC8][8], be[MAXC8][8];
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ga[i][e] = ch < nch ? gamma[ch * 8 + e] : 0.f;
+      be[i][e] = ch < nch ? beta[ch * 8 + e] : 0.f;
+    }
+  }
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
   float v[MAXC8][8];
   float s = 0.f;
 #pragma unroll
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = ch * 8 + e;
-        float t = (v[i][e] - mean) * rstd * gamma[c] + beta[c];
+        float t = (v[i][e] - mean) * rstd * ga[i][e] + be[i][e];
         if (thr) t *= ea_keep(seed, (uint64_t)row * C + c, thr, inv_keep);
         o[e] = zero ? 0.f : t;
       }
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
       u.w = pack_bf2(o[6], o[7]);
       *reinterpret_cast<uint4*>(y + (long)row * C + ch * 8) = u;
     }
+  }
   }
 }
 
@@ -102,6 +114,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = 0.f;
 
+  float gam[MAXC8][8];
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gam[i][e] = ch < nch ? gamma[ch * 8 + e] : 0.f;
+  }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   for (int row = r0 + wave; row < r1; row += 4) {
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
           xh[i][e] = h;
           dg[i][e] += dv * h;
           db[i][e] += dv;
-          const float gv = dv * gamma[c];
+          const float gv = dv * gam[i][e];
           g[i][e] = gv;
           s1 += gv;
           s2 += gv * h;
@@ -218,8 +237,10 @@ extern "C" int ea_layernorm_fwd(const void* x, const float* gamma, const float* 
                                 float drop_scale, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
+  int fblocks = (M + 3) / 4;
+  if (fblocks > 1024) fblocks = (fblocks + 1) / 2 > 1024 ? (fblocks + 1) / 2 : 1024;  // >= 2 rows per wavefront on large inputs
 #define EA_LN_FWD(NC)                                                                                                  \
-  hipLaunchKernelGGL((ln_fwd_kernel<NC>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta,      \
+  hipLaunchKernelGGL((ln_fwd_kernel<NC>), dim3(fblocks), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta,          \
                      (bf16_t*)y, mean, rstd, M, C, eps, row_zero, drop_seed, drop_thr, drop_scale)
   if (C <= 512) EA_LN_FWD(1);
   else if (C <= 1024) EA_LN_FWD(2);
