@@ -303,6 +303,17 @@ def transducer_fixture(name="ref_conformer_transducer_tiny"):
         out[f"greedy_{tag}_tokens"] = toks.numpy()
         out[f"greedy_{tag}_scores"] = scores.numpy()
         print(tag, [[int(t) for t in row if int(t) != dec.blank] for row in toks], scores.tolist())
+    # modified adaptive expansion search with the reference's own decoder (espresso/tools/transducer_beam_search_decoder.py)
+    from espresso.tools.transducer_beam_search_decoder import TransducerBeamSearchDecoder
+    for tag, kw in (("b3", dict(beam_size=3, max_num_expansions_per_step=2, prefix_alpha=1)),
+                    ("b4_beta1_g2", dict(beam_size=4, max_num_expansions_per_step=2, expansion_beta=1, expansion_gamma=2.0, prefix_alpha=2)),
+                    ("b2_nonorm", dict(beam_size=2, max_num_expansions_per_step=1, normalize_scores=False))):
+        dec = TransducerBeamSearchDecoder([model], dic, **kw)
+        toks_l, scores_l, _ = dec._generate({"net_input": {"src_tokens": feats, "src_lengths": lengths}})
+        for bi, (tk, sc) in enumerate(zip(toks_l, scores_l)):
+            out[f"beam_{tag}_{bi}_tokens"] = tk.numpy()
+            out[f"beam_{tag}_{bi}_scores"] = sc.numpy()
+        print(tag, [[int(t) for t in row if int(t) != dic.pad()] for row in toks_l[0]], scores_l[0].tolist())
     model.train()
     lo, _ = model(feats, lengths, prev)
     R = torch.randn_like(lo) * 0.1

@@ -258,3 +258,14 @@ def test_speech_lstm_beam_search_vs_reference():
     print(r)
     assert r["forced_decode_pos_score_abs"] < 5e-2, r   # per-position log-probs of the reference's best hypotheses
     assert r["score_abs"] < 3e-2, r                     # hypotheses found by both generators carry the same score
+
+
+def test_transducer_beam_search_vs_reference():
+    """1-best token ids identical to the reference decoder for every utterance and option set; scores of shared n-best entries
+    within 1e-2 (bf16 model)"""
+    r = G.check_transducer_beam_search()
+    print(r)
+    for tag, v in r.items():
+        assert all(v["best_equal"]), (tag, r)
+        assert v["score_abs"] < 1e-2, (tag, r)
+        assert min(v["nbest_in_ref"]) >= 0.5, (tag, r)
