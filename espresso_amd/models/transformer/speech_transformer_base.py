@@ -220,6 +220,8 @@ class SpeechTransformerDecoderBase(nn.Module):
 
 @register_model("speech_transformer_base", dataclass=SpeechTransformerConfig)
 class SpeechTransformerModelBase(nn.Module):
+    config_class = SpeechTransformerConfig
+
     def __init__(self, cfg, encoder, decoder):
         super().__init__()
         self.cfg, self.encoder, self.decoder = cfg, encoder, decoder

@@ -169,6 +169,8 @@ class SpeechTransformerEncoderForPrediction(SpeechTransformerEncoderBase):
 
 @register_model("speech_transformer_encoder_model", dataclass=SpeechTransformerConfig)
 class SpeechTransformerEncoderModel(nn.Module):
+    config_class = SpeechTransformerConfig
+
     def __init__(self, cfg, encoder):
         super().__init__()
         self.cfg = cfg

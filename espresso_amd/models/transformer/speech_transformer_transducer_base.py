@@ -19,6 +19,7 @@ from ...registry import register_model
 from ...tools import utils as speech_utils
 from ..speech_lstm import SpeechLSTMDecoder, lstm_linear
 from .speech_transformer_base import EmbeddingParams
+from .speech_transformer_config import SpeechTransformerTransducerConfig
 from .speech_transformer_encoder_model import SpeechTransformerEncoderBase
 
 
@@ -40,6 +41,8 @@ class WeightNormLinearParams(nn.Module):
 
 @register_model("speech_transformer_transducer_base")
 class SpeechTransformerTransducerModelBase(nn.Module):
+    config_class = SpeechTransformerTransducerConfig
+
     def __init__(self, cfg, encoder, decoder):
         super().__init__()
         self.cfg, self.encoder, self.decoder = cfg, encoder, decoder

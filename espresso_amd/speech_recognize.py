@@ -1,0 +1,214 @@
+"""Batched recognition CLI — the decoding loop and output format of espresso/speech_recognize.py:60-360 on the HIP path:
+for every batch run the chosen search (beam search with optional LM / look-ahead word-LM fusion, CTC greedy, transducer
+greedy / beam), print `T-<utt>` (reference) and `H-<utt>` (hypothesis, score in base 2) lines, accumulate WER / CER with
+`tools.wer.Scorer`, and close with the "Recognized N utterances ..." summary.
+
+Checkpoint management is fairseq's and stays out of this framework (SURVEY §2 out of scope): the model is built from a
+config mapping (`--model-config`, the `model:` block of the recipe YAML as JSON/YAML) and a `state_dict` file (`--path`:
+either a plain state_dict or a fairseq checkpoint dict whose `"model"` entry is the state_dict — reference checkpoints load
+because the parameter names are identical).  Audio comes from a Kaldi-style `wav.scp` (`utt_id path.wav`, 16-bit PCM read
+with the stdlib) and optional `text` (`utt_id tokens...`) files; the front-end (fbank + CMVN) runs on the GPU."""
+import argparse
+import json
+import math
+import sys
+import time
+import wave
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+
+def read_wav(path: str) -> np.ndarray:
+    """16-bit PCM WAV -> float32 samples at int16 scale (what torchaudio's Kaldi fbank expects: espresso/tools/utils.py:426-454)."""
+    with wave.open(path, "rb") as w:
+        assert w.getsampwidth() == 2, f"{path}: 16-bit PCM expected"
+        n, ch = w.getnframes(), w.getnchannels()
+        x = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32)
+        return x.reshape(-1, ch)[:, 0].copy() if ch > 1 else x
+
+
+def read_scp(path: str) -> Dict[str, str]:
+    out = {}
+    for line in open(path, encoding="utf-8"):
+        line = line.strip()
+        if line:
+            k, v = line.split(None, 1)
+            out[k] = v
+    return out
+
+
+def make_batches(utt_ids: List[str], n_samples: List[int], max_tokens: int, max_sentences: int) -> List[List[int]]:
+    """Length-sorted batches under the frame budget (frames = samples / 160), longest first inside a batch."""
+    order = sorted(range(len(utt_ids)), key=lambda i: -n_samples[i])
+    batches, cur, mx = [], [], 0
+    for i in order:
+        fr = n_samples[i] // 160 + 1
+        if cur and (max(mx, fr) * (len(cur) + 1) > max_tokens or len(cur) + 1 > max_sentences):
+            batches.append(cur)
+            cur, mx = [], 0
+        cur.append(i)
+        mx = max(mx, fr)
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def recognize(task, model, generator, batches: Iterable[dict], dictionary, refs: Optional[Dict[str, str]] = None, out=sys.stdout,
+              nbest: int = 1, quiet: bool = False, bpe_symbol=None):
+    """The loop of espresso/speech_recognize.py:226-330.  `batches` yield dicts with `utt_ids`, `wav`, `wav_offsets`,
+    `num_samples` (device tensors / lists as produced by `collate`).  Returns (scorer, stats)."""
+    from .tools.wer import Scorer
+
+    scorer = Scorer(dictionary, wer_output_filter=None)
+    num_sent, num_tok, t_gen, audio_s = 0, 0, 0.0, 0.0
+    for sample in batches:
+        t0 = time.perf_counter()
+        s = task.prepare_sample(sample, train=False)
+        hypos = generator.generate([model], s)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t_gen += time.perf_counter() - t0
+        audio_s += sum(sample["num_samples"]) / 16000.0
+        for i, utt in enumerate(sample["utt_ids"]):
+            if refs is not None and utt in refs and not quiet:
+                print("T-{}\t{}".format(utt, refs[utt]), file=out)
+            for j, hypo in enumerate(hypos[i][:nbest]):
+                toks = hypo["tokens"].int().cpu()
+                strip = getattr(generator, "symbols_to_strip_from_output", None) or {dictionary.eos(), dictionary.pad()}
+                hypo_str = dictionary.string(torch.tensor([t for t in toks.tolist() if t not in strip]), bpe_symbol=bpe_symbol)
+                if not quiet:
+                    print("H-{}\t{}\t{}".format(utt, hypo_str, float(hypo["score"]) / math.log(2)), file=out)
+                if j == 0:
+                    scorer.add_prediction(utt, hypo_str)
+                    if refs is not None and utt in refs:
+                        scorer.add_evaluation(utt, refs[utt], hypo_str)
+                    num_tok += len(toks)
+        num_sent += len(sample["utt_ids"])
+    print("NOTE: hypothesis and token scores are output in base 2", file=out)
+    print("Recognized {:,} utterances ({} tokens) in {:.1f}s ({:.2f} sentences/s, {:.2f} tokens/s), RTF {:.4f}".format(
+        num_sent, num_tok, t_gen, num_sent / max(t_gen, 1e-9), num_tok / max(t_gen, 1e-9), t_gen / max(audio_s, 1e-9)), file=out)
+    if refs:
+        print("WER {:.2f}%, CER {:.2f}%".format(scorer.wer(), scorer.cer()), file=out)
+    return scorer, {"sentences": num_sent, "tokens": num_tok, "seconds": t_gen, "rtf": t_gen / max(audio_s, 1e-9)}
+
+
+def collate(ids: List[int], utt_ids: List[str], waves: List[np.ndarray], device):
+    lens = [len(waves[i]) for i in ids]
+    offs = np.zeros(len(ids) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    return {"utt_ids": [utt_ids[i] for i in ids], "wav": torch.from_numpy(np.concatenate([waves[i] for i in ids])).to(device),
+            "wav_offsets": torch.from_numpy(offs).to(device), "num_samples": lens, "net_input": {}}
+
+
+def build_generator(args, model, dictionary, lm=None):
+    from .sequence_generator import SequenceGenerator
+    from .tools.ctc_decoder import CTCDecoder
+    from .tools.transducer_beam_search_decoder import TransducerBeamSearchDecoder
+    from .tools.transducer_greedy_decoder import TransducerGreedyDecoder
+
+    if args.search == "ctc":
+        return CTCDecoder(dictionary)
+    if args.search == "transducer_greedy":
+        return TransducerGreedyDecoder([model], dictionary, max_num_expansions_per_step=args.max_num_expansions_per_step,
+                                       lm_model=lm, lm_weight=args.lm_weight)
+    if args.search == "transducer_beam":
+        return TransducerBeamSearchDecoder([model], dictionary, beam_size=args.beam,
+                                           max_num_expansions_per_step=args.max_num_expansions_per_step, expansion_beta=args.expansion_beta,
+                                           expansion_gamma=args.expansion_gamma, prefix_alpha=args.prefix_alpha, lm_model=lm,
+                                           lm_weight=args.lm_weight)
+    return SequenceGenerator([model], dictionary, beam_size=args.beam, max_len_a=args.max_len_a, max_len_b=args.max_len_b,
+                             min_len=args.min_len, normalize_scores=not args.unnormalized, len_penalty=args.lenpen,
+                             unk_penalty=args.unkpen, temperature=args.temperature, lm_model=lm, lm_weight=args.lm_weight,
+                             eos_factor=args.eos_factor)
+
+
+def get_parser():
+    p = argparse.ArgumentParser("espresso_amd.speech_recognize", description=__doc__.split("\n")[0])
+    p.add_argument("--path", required=True, help="state_dict (or fairseq checkpoint dict with a 'model' entry)")
+    p.add_argument("--model", default="speech_transformer_base", help="registered model name")
+    p.add_argument("--model-config", required=True, help="JSON/YAML file with the recipe's `model:` block")
+    p.add_argument("--dict", required=True)
+    p.add_argument("--wav-scp", required=True)
+    p.add_argument("--text", default=None, help="reference transcripts (utt_id tokens...)")
+    p.add_argument("--global-cmvn-stats-path", default=None)
+    p.add_argument("--search", default="beam", choices=["beam", "ctc", "transducer_greedy", "transducer_beam"])
+    p.add_argument("--beam", type=int, default=10)
+    p.add_argument("--nbest", type=int, default=1)
+    p.add_argument("--max-len-a", type=float, default=0.08)
+    p.add_argument("--max-len-b", type=int, default=0)
+    p.add_argument("--min-len", type=int, default=1)
+    p.add_argument("--unnormalized", action="store_true")
+    p.add_argument("--lenpen", type=float, default=1.0)
+    p.add_argument("--unkpen", type=float, default=0.0)
+    p.add_argument("--temperature", type=float, default=1.0)
+    p.add_argument("--eos-factor", type=float, default=None)
+    p.add_argument("--lm-path", default=None)
+    p.add_argument("--lm-arch", default="lstm_lm_librispeech")
+    p.add_argument("--lm-weight", type=float, default=0.0)
+    p.add_argument("--word-dict", default=None, help="enables look-ahead word-LM fusion (the LM at --lm-path is a word LM)")
+    p.add_argument("--oov-penalty", type=float, default=1e-4)
+    p.add_argument("--max-num-expansions-per-step", type=int, default=2)
+    p.add_argument("--expansion-beta", type=int, default=0)
+    p.add_argument("--expansion-gamma", type=float, default=None)
+    p.add_argument("--prefix-alpha", type=int, default=None)
+    p.add_argument("--max-tokens", type=int, default=15000)
+    p.add_argument("--batch-size", type=int, default=24)
+    p.add_argument("--quiet", action="store_true")
+    return p
+
+
+def _load_state(path):
+    sd = torch.load(path, map_location="cpu")
+    return sd["model"] if isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict) else sd
+
+
+def main(argv=None):
+    args = get_parser().parse_args(argv)
+    import yaml
+
+    from . import registry
+    from .data.asr_dictionary import AsrDictionary
+    from .models.lstm_lm import LSTMLanguageModelEspresso
+    from .models.tensorized_lookahead_language_model import TensorizedLookaheadLanguageModel
+    from .tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
+
+    dev = torch.device("cuda:0")
+    model_cfg = yaml.safe_load(open(args.model_config)) if not args.model_config.endswith(".json") else json.load(open(args.model_config))
+    autoregressive = args.search == "beam"
+    task = SpeechRecognitionEspressoTask.setup_task(SpeechRecognitionEspressoConfig(
+        dict=args.dict, autoregressive=autoregressive, global_cmvn_stats_path=args.global_cmvn_stats_path))
+    cls = registry.MODEL_REGISTRY[args.model]
+    cfg_cls = getattr(cls, "config_class", None)
+    cfg = cfg_cls.from_dict(model_cfg) if cfg_cls is not None else model_cfg
+    model = cls.build_model(cfg, task)
+    sd = _load_state(args.path)
+    if hasattr(model, "upgrade_state_dict_named"):
+        sd = model.upgrade_state_dict_named(dict(sd), "")
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    lm = None
+    if args.lm_path:
+        class _LMTask:
+            target_dictionary = source_dictionary = task.target_dictionary
+        if args.word_dict:
+            _LMTask.word_dictionary = AsrDictionary.load(args.word_dict, enable_bos=False)
+        lm = LSTMLanguageModelEspresso.build_model(dict(arch=args.lm_arch, is_wordlm=bool(args.word_dict)), _LMTask)
+        lm.load_state_dict(_load_state(args.lm_path), strict=True)
+        lm = lm.to(dev).eval()
+        if args.word_dict:
+            lm = TensorizedLookaheadLanguageModel(lm, task.target_dictionary, oov_penalty=args.oov_penalty)
+    gen = build_generator(args, model, task.target_dictionary, lm)
+    scp = read_scp(args.wav_scp)
+    utt_ids = list(scp.keys())
+    waves = [read_wav(scp[u]) for u in utt_ids]
+    refs = read_scp(args.text) if args.text else None
+    task.build_frontend(dev)
+    batches = make_batches(utt_ids, [len(w) for w in waves], args.max_tokens, args.batch_size)
+    recognize(task, model, gen, (collate(b, utt_ids, waves, dev) for b in batches), task.target_dictionary, refs, nbest=args.nbest,
+              quiet=args.quiet)
+
+
+if __name__ == "__main__":
+    main()

@@ -1101,3 +1101,31 @@ def check_transducer_beam_search():
                     score_abs = max(score_abs, abs(float(scores_l[b][j]) - refset[m]))
         res[tag] = {"best_equal": best_equal, "nbest_in_ref": nbest_in_ref, "score_abs": score_abs}
     return res
+
+
+def check_speech_recognize_loop():
+    """End-to-end recognition loop of the CLI on raw audio: GPU front-end -> tiny enc-dec model -> beam search -> H-/T- lines,
+    WER bookkeeping and the summary line."""
+    import io
+
+    from espresso_amd import speech_recognize as sr
+    from espresso_amd.sequence_generator import SequenceGenerator
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
+
+    torch.manual_seed(0)
+    d = _TaskAR(40).target_dictionary
+    task = SpeechRecognitionEspressoTask.setup_task(SpeechRecognitionEspressoConfig(autoregressive=True), tgt_dict=d)
+    model = build_tiny_encdec().to(DEV).eval()
+    task.build_frontend(DEV)
+    rng = np.random.default_rng(0)
+    utts = [f"utt{i}" for i in range(5)]
+    waves = [(rng.standard_normal(int(16000 * s)) * 3000).astype(np.float32) for s in (1.2, 0.7, 2.0, 0.9, 1.5)]
+    refs = {u: "t1 t2 t3" for u in utts}
+    gen = SequenceGenerator([model], d, beam_size=3, max_len_a=0.0, max_len_b=6)
+    batches = sr.make_batches(utts, [len(w) for w in waves], max_tokens=400, max_sentences=3)
+    buf = io.StringIO()
+    scorer, stats = sr.recognize(task, model, gen, (sr.collate(b, utts, waves, DEV) for b in batches), d, refs, out=buf)
+    text = buf.getvalue()
+    return {"n_batches": len(batches), "H_lines": text.count("\nH-") + text.startswith("H-"), "T_lines": text.count("T-utt"),
+            "summary": "Recognized 5 utterances" in text, "wer_reported": "WER" in text, "sentences": stats["sentences"],
+            "wer_finite": bool(np.isfinite(scorer.wer()))}

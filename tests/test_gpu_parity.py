@@ -269,3 +269,10 @@ def test_transducer_beam_search_vs_reference():
         assert all(v["best_equal"]), (tag, r)
         assert v["score_abs"] < 1e-2, (tag, r)
         assert min(v["nbest_in_ref"]) >= 0.5, (tag, r)
+
+
+def test_speech_recognize_loop():
+    r = G.check_speech_recognize_loop()
+    print(r)
+    assert r["H_lines"] == 5 and r["T_lines"] == 5 and r["summary"] and r["wer_reported"] and r["sentences"] == 5 and r["wer_finite"], r
+    assert r["n_batches"] >= 2, r

@@ -198,3 +198,31 @@ def test_tensorized_prefix_tree_matches_reference(golden_dir):
     for k in ("children", "prev_subword_idx", "word_idx", "word_set_idx"):
         assert np.array_equal(getattr(t, k).numpy(), g["tree_" + k]), k
     assert tokenize("AB C") == "A B <space> C"
+
+
+def test_speech_recognize_host_pieces(tmp_path):
+    """WAV / scp readers, frame-budget batching and the option surface of the recognition CLI (the GPU loop is covered by the
+    generator and decoder parity tests)."""
+    import wave
+
+    import numpy as np
+
+    from espresso_amd import speech_recognize as sr
+
+    x = (np.sin(np.arange(1600) / 10.0) * 1000).astype("<i2")
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(x.tobytes())
+    y = sr.read_wav(str(p))
+    assert y.dtype == np.float32 and np.array_equal(y, x.astype(np.float32))
+    scp = tmp_path / "wav.scp"
+    scp.write_text(f"utt1 {p}\nutt2 {p}\n")
+    assert sr.read_scp(str(scp)) == {"utt1": str(p), "utt2": str(p)}
+    b = sr.make_batches(["a", "b", "c", "d"], [16000 * 10, 16000 * 2, 16000 * 9, 16000 * 3], max_tokens=2100, max_sentences=3)
+    assert sorted(sum(b, [])) == [0, 1, 2, 3] and b[0] == [0, 2] and all(len(x) <= 3 for x in b)
+    a = sr.get_parser().parse_args(["--path", "m.pt", "--model-config", "m.yaml", "--dict", "d.txt", "--wav-scp", str(scp),
+                                    "--lm-weight", "0.47", "--eos-factor", "1.5", "--beam", "60"])
+    assert a.beam == 60 and a.lm_weight == 0.47 and a.eos_factor == 1.5 and a.search == "beam"
