@@ -34,7 +34,10 @@ class LabelSmoothedCrossEntropyV2Criterion:
         return self.forward(model, sample, reduce)
 
     def forward(self, model, sample, reduce=True):
-        net_output = model(**sample["net_input"])
+        try:
+            net_output = model(**sample["net_input"], epoch=self.epoch)  # scheduled sampling is epoch-driven (:173)
+        except TypeError:
+            net_output = model(**sample["net_input"])
         logits3 = net_output[0]
         logits = net_output[1].get("_logits_bu") if isinstance(net_output[1], dict) else None
         if logits is None:

@@ -119,11 +119,16 @@ class SpeechLSTMDecoder(nn.Module):
             y = F.linear(f2, self.fc_out.weight, self.fc_out.bias, out_f32=True)
         return y[:, : len(self.dictionary)].reshape(*shp[:-1], -1)
 
-    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, **kwargs):
+    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, epoch=1, **kwargs):
+        sched = getattr(self, "scheduled_sampling_rate_scheduler", None)
+        if self.training and sched is not None and self.attention is not None:
+            p = sched.step(epoch)
+            if p < 1.0:  # scheduled sampling (:735-764): feed the model's own previous prediction with probability 1 - p
+                return self._extract_features_attention(prev_output_tokens, encoder_out, sampling_prob=p)
         x, attn = self.extract_features(prev_output_tokens, encoder_out=encoder_out)
         return self.output_layer(x), attn
 
-    def _extract_features_attention(self, prev_output_tokens, encoder_out):
+    def _extract_features_attention(self, prev_output_tokens, encoder_out, sampling_prob=1.0):
         """Attention decoder with input feeding (:846-893): per step layer-0 cell -> Bahdanau attention on its hidden state ->
         the context is appended to every upper layer's input and fed to the next step's layer 0.  Each step is a handful of
         autograd nodes on the HIP kernels; weight / key / value gradients are accumulated in place (functional.GradSink)."""
@@ -139,17 +144,29 @@ class SpeechLSTMDecoder(nn.Module):
         nv = at.g * at.v / torch.norm(at.v)
         sinks = [F.GradSink(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh) for c in self.layers]
         bsum = [(c.bias_ih + c.bias_hh).detach().float().contiguous() for c in self.layers]
-        tok = prev_output_tokens.t().contiguous().view(-1).to(torch.int32)
-        x = F.embedding(self.embed_tokens.weight, tok, None, None, 1.0, self.embed_tokens.padding_idx)
-        if tr and self.dropout_in > 0:
-            x = F.dropout(x, self.dropout_in)
-        dev = x.device
+        sampling = sampling_prob < 1.0
+        dev = enc.device
+        if not sampling:
+            tok = prev_output_tokens.t().contiguous().view(-1).to(torch.int32)
+            x = F.embedding(self.embed_tokens.weight, tok, None, None, 1.0, self.embed_tokens.padding_idx)
+            if tr and self.dropout_in > 0:
+                x = F.dropout(x, self.dropout_in)
         h = [torch.zeros(B, H, dtype=torch.bfloat16, device=dev) for _ in self.layers]
         c = [torch.zeros(B, H, dtype=torch.float32, device=dev) for _ in self.layers]
         feed = torch.zeros(B, Cv, dtype=torch.bfloat16, device=dev)
-        outs = []
+        outs, step_logits, pred = [], [], None
         for j in range(U):
-            inp = torch.cat((x[j * B:(j + 1) * B], feed), dim=1)
+            if sampling:
+                gold = prev_output_tokens[:, j]
+                if j > 0:
+                    keep_gold = torch.rand(B, device=dev).lt(sampling_prob)
+                    gold = torch.where(keep_gold, gold, pred)
+                xj = F.embedding(self.embed_tokens.weight, gold.to(torch.int32).contiguous(), None, None, 1.0, self.embed_tokens.padding_idx)
+                if tr and self.dropout_in > 0:
+                    xj = F.dropout(xj, self.dropout_in)
+            else:
+                xj = x[j * B:(j + 1) * B]
+            inp = torch.cat((xj, feed), dim=1)
             ctx = None
             for i, cell in enumerate(self.layers):
                 h[i], c[i] = F.lstm_cell_ag(inp, h[i], c[i], cell, sinks[i], bsum[i])
@@ -164,6 +181,17 @@ class SpeechLSTMDecoder(nn.Module):
                     inp = torch.cat((inp[:, :H] + prev_in, inp[:, H:]), dim=1)
             feed = ctx
             outs.append(inp)
+            if sampling:
+                yj = inp
+                if hasattr(self, "additional_fc"):
+                    yj = F.linear(yj.contiguous(), self.additional_fc.weight, self.additional_fc.bias)
+                    if tr and self.dropout_out > 0:
+                        yj = F.dropout(yj, self.dropout_out)
+                lg = self.output_layer(yj)          # fp32 [B][V]
+                step_logits.append(lg)
+                pred = lg.detach().argmax(-1)
+        if sampling:
+            return torch.stack(step_logits, 1), None  # B x U x V
         y = torch.stack(outs, 0).transpose(0, 1).contiguous()  # B x U x (H + Cv)
         if hasattr(self, "additional_fc"):
             y = F.linear(y.view(B * U, -1), self.additional_fc.weight, self.additional_fc.bias)
@@ -263,6 +291,20 @@ class SpeechLSTMDecoder(nn.Module):
         """index_select of every cached tensor by the surviving beams (speech_lstm.py:981-999)."""
         idx = new_order.to(torch.int32).contiguous()
         return {k: [K.gather_rows(t.contiguous(), idx) for t in v] for k, v in state.items()}
+
+
+class ScheduledSamplingRateScheduler:
+    """espresso/tools/scheduled_sampling_rate_scheduler.py:9-41: probability of feeding the TRUE previous token, per epoch."""
+
+    def __init__(self, scheduled_sampling_probs=(1.0,), start_scheduled_sampling_epoch=1):
+        self.scheduled_sampling_probs = list(scheduled_sampling_probs)
+        self.start_scheduled_sampling_epoch = start_scheduled_sampling_epoch
+
+    def step(self, epoch: int) -> float:
+        ps = self.scheduled_sampling_probs
+        if (len(ps) > 1 or ps[0] < 1.0) and epoch >= self.start_scheduled_sampling_epoch:
+            return ps[min(epoch - self.start_scheduled_sampling_epoch, len(ps) - 1)]
+        return 1.0
 
 
 class BahdanauAttentionParams(nn.Module):
@@ -410,14 +452,17 @@ class SpeechLSTMModel(nn.Module):
                                 need_attn=a["need_attention"], residual=a["decoder_rnn_residual"],
                                 share_input_output_embed=a["share_decoder_input_output_embed"],
                                 max_target_positions=a.get("max_target_positions", 1024))
+        probs = a.get("scheduled_sampling_probs", [1.0])
+        probs = [float(x) for x in (probs.split(",") if isinstance(probs, str) else probs)]
+        dec.scheduled_sampling_rate_scheduler = ScheduledSamplingRateScheduler(probs, a.get("start_scheduled_sampling_epoch", 1))
         return cls(enc, dec)
 
     def set_num_updates(self, n):
         self.num_updates = n
 
-    def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
+    def forward(self, src_tokens, src_lengths, prev_output_tokens, epoch=1, **kwargs):
         enc = self.encoder(src_tokens, src_lengths)
-        return self.decoder(prev_output_tokens, encoder_out=enc)
+        return self.decoder(prev_output_tokens, encoder_out=enc, epoch=epoch)
 
     def forward_encoder(self, src_tokens, src_lengths):
         return self.encoder(src_tokens, src_lengths)

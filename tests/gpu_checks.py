@@ -1129,3 +1129,41 @@ def check_speech_recognize_loop():
     return {"n_batches": len(batches), "H_lines": text.count("\nH-") + text.startswith("H-"), "T_lines": text.count("T-utt"),
             "summary": "Recognized 5 utterances" in text, "wer_reported": "WER" in text, "sentences": stats["sentences"],
             "wer_finite": bool(np.isfinite(scorer.wer()))}
+
+
+def check_scheduled_sampling():
+    """speech_lstm decoder with scheduled sampling: p = 1 reproduces teacher forcing exactly (same kernels, same order); p = 0
+    feeds the model's own argmax from step 1 on (checked against an explicit greedy roll-out), and gradients flow."""
+    from espresso_amd.models.speech_lstm import ScheduledSamplingRateScheduler
+
+    g = np.load(os.path.join(GOLD, "ref_speech_lstm_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = build_tiny_speech_lstm().to(DEV)
+    model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    feats, lengths, prev = (torch.from_numpy(g[k]).to(DEV) for k in ("feats", "lengths", "prev"))
+    model.train()
+    lo_tf, _ = model(feats, lengths, prev)
+    sch = ScheduledSamplingRateScheduler([0.999999], 1)
+    model.decoder.scheduled_sampling_rate_scheduler = sch
+    torch.manual_seed(0)
+    lo_p1, _ = model(feats, lengths, prev, epoch=1)  # rand < 0.999999 always: gold tokens
+    sch.scheduled_sampling_probs = [0.0]
+    lo_p0, _ = model(feats, lengths, prev, epoch=1)
+    # greedy roll-out with the same weights: token j = argmax of step j-1
+    roll = prev.clone()
+    for j in range(1, prev.shape[1]):
+        sch.scheduled_sampling_probs = [1.0]
+        cur, _ = model(feats, lengths, roll)
+        roll[:, j] = cur[:, j - 1].argmax(-1)
+    sch.scheduled_sampling_probs = [1.0]
+    lo_roll, _ = model(feats, lengths, roll)
+    sch.scheduled_sampling_probs = [0.0]
+    for p_ in model.parameters():
+        p_.grad = None
+    lo, _ = model(feats, lengths, prev, epoch=1)
+    lo.float().square().mean().backward()
+    torch.cuda.synchronize()
+    finite = all(bool(torch.isfinite(p_.grad).all()) for p_ in model.parameters() if p_.grad is not None)
+    has_embed_grad = float(model.decoder.embed_tokens.weight.grad.abs().sum()) > 0
+    return {"p1_vs_teacher_forcing": float((lo_p1.float() - lo_tf.float()).abs().max()),
+            "p0_vs_rollout": float((lo_p0.float() - lo_roll.float()).abs().max()), "finite": finite, "embed_grad": has_embed_grad}

@@ -276,3 +276,11 @@ def test_speech_recognize_loop():
     print(r)
     assert r["H_lines"] == 5 and r["T_lines"] == 5 and r["summary"] and r["wer_reported"] and r["sentences"] == 5 and r["wer_finite"], r
     assert r["n_batches"] >= 2, r
+
+
+def test_scheduled_sampling_lstm_decoder():
+    r = G.check_scheduled_sampling()
+    print(r)
+    assert r["p1_vs_teacher_forcing"] < 2e-2, r   # per-step output layer vs one batched GEMM: bf16 rounding only
+    assert r["p0_vs_rollout"] < 2e-2, r
+    assert r["finite"] and r["embed_grad"], r
