@@ -79,6 +79,8 @@ long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk);
 int ea_set_gemm_variant(int v);
 /* live profiling of ea_gemm_bf16 for roofline reports: enable(1) clears and starts recording one HIP-event
  * pair per launch on the launch stream; read() synchronises and returns launches, summed ms and flops. */
+/* tuning hook: XCD-aware workgroup -> tile mapping (default OFF: measured slower than round-robin); returns the previous value */
+int ea_set_gemm_xcd_swizzle(int on);
 int ea_gemm_profile_enable(int on);
 long ea_gemm_profile_read(double* total_ms, double* total_flops);
 

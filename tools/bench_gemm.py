@@ -29,9 +29,10 @@ def run(name, M, N, Kd, a_ks=False, b_ks=False, batch=1, c_f32=False, splitk=1, 
 
 if __name__ == "__main__":
   from espresso_amd import _lib
-  for variant in (0,):
+  for variant, sw in ((0, 1), (0, 0)):
     _lib.lib().ea_set_gemm_variant(variant)
-    print("=== gemm variant", variant)
+    _lib.lib().ea_set_gemm_xcd_swizzle(sw)
+    print("=== gemm variant", variant, "xcd swizzle", sw)
     M = 6468
     run("ffn1 fwd", M, 2048, 512)
     run("ffn2 fwd", M, 512, 2048)
