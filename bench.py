@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-dump", default=None, help="write the per-launch GEMM records of the roofline replay to this file")
     ap.add_argument("--n-utts", type=int, default=20000)
     ap.add_argument("--max-tokens", type=int, default=26000, help="diagnostic only: shrink the batches (host-overhead probes)")
     ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B switch: keep weight-gradient GEMMs on the main stream")
@@ -214,6 +215,8 @@ def main():
         torch.cuda.synchronize()
         ms, fl = ctypes.c_double(0), ctypes.c_double(0)
         n = lib.ea_gemm_profile_read(ctypes.byref(ms), ctypes.byref(fl))
+        if args.gemm_dump:
+            lib.ea_gemm_profile_dump(args.gemm_dump.encode())
         lib.ea_gemm_profile_enable(0)
         tot_ms, tot_fl = ms.value, fl.value
         ach = tot_fl / (tot_ms * 1e-3) / 1e12

@@ -5,7 +5,8 @@ espresso/__init__.py:6-12 does by side effect): tasks, models, criterions, optim
 lr schedulers and audio feature transforms.  Compute is hand-written HIP behind a C ABI
 (include/espresso_amd.h); see DESIGN.md."""
 from . import registry  # noqa: F401
-from .criterions import ctc_loss as _ctc, label_smoothed_cross_entropy_v2 as _lsce, transducer_loss as _rnnt  # noqa: F401
+from .criterions import cross_entropy_v2 as _cev2, ctc_loss as _ctc, label_smoothed_cross_entropy_v2 as _lsce  # noqa: F401
+from .criterions import transducer_loss as _rnnt  # noqa: F401
 from .data import feature_transforms as _ft  # noqa: F401
 from .models.transformer import speech_transformer_base as _encdec, speech_transformer_encoder_model as _enc_model  # noqa: F401
 from .models.transformer import speech_transformer_transducer_base as _transducer  # noqa: F401

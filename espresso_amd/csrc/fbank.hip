@@ -157,7 +157,37 @@ __global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ feat, 
   }
 }
 
+// Per-dimension sum / sum of squares over the valid frames of a padded feature batch, accumulated in fp64 across
+// launches (global CMVN statistics).  Block = 128 threads (one per feature), 64 frames of one utterance.
+__global__ __launch_bounds__(128) void feature_stats_kernel(const float* __restrict__ feat, const int* __restrict__ lengths,
+                                                            double* __restrict__ acc, int Tmax, int nmel) {
+  const int b = blockIdx.y, f = threadIdx.x;
+  const int len = min(lengths[b], Tmax);
+  const int t0 = blockIdx.x * 64, t1 = min(len, t0 + 64);
+  if (t0 >= t1) return;
+  if (f < nmel) {
+    const float* p = feat + ((long)b * Tmax + t0) * nmel + f;
+    double s = 0.0, q = 0.0;
+    for (int t = t0; t < t1; ++t, p += nmel) {
+      const double v = (double)*p;
+      s += v;
+      q += v * v;
+    }
+    atomicAdd(acc + f, s);
+    atomicAdd(acc + nmel + f, q);
+  }
+  if (f == 0) atomicAdd(acc + 2 * nmel, (double)(t1 - t0));
+}
+
 }  // namespace
+
+extern "C" int ea_feature_stats(const float* feat, const int* lengths, double* acc, int B, int Tmax, int nmel,
+                                hipStream_t stream) {
+  if (B <= 0 || Tmax <= 0) return 0;
+  if (nmel > 128) return -2;
+  hipLaunchKernelGGL(feature_stats_kernel, dim3((Tmax + 63) / 64, B), dim3(128), 0, stream, feat, lengths, acc, Tmax, nmel);
+  return EA_CHECK_LAUNCH();
+}
 
 extern "C" int ea_fbank_batch(const float* wav, const long* offsets, int B, const float* window,
                               const float* twiddle, const int* mel_start, const int* mel_len, const int* mel_woff,

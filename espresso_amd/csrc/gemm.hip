@@ -19,6 +19,7 @@
 // in memory (element (row,k) at ptr[k*ld + row]); it is then transposed in registers while
 // being staged (4x8 block per thread -> eight ds_write_b64), which is what lets dgrad / wgrad /
 // P·V run without materialising transposed copies in HBM.
+#include <cstdio>
 #include "common.h"
 #include "espresso_amd.h"
 
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const EaGemmParams p
 // ---- optional live profiling of the dominant kernel (bench.py roofline): HIP events around every launch on
 // the launch stream; flops = 2*M*N*K*batch per launch.
 #include <vector>
-struct GemmProf { hipEvent_t e0, e1; double flops; };
+struct GemmProf { hipEvent_t e0, e1; double flops; int M, N, K, batch, a_ks, b_ks, splitk, bm64, epi; };
 static bool g_prof_on = false;
 static std::vector<GemmProf> g_prof;
 
@@ -526,6 +527,20 @@ extern "C" long ea_gemm_profile_read(double* total_ms, double* total_flops) {
   }
   *total_ms = ms;
   *total_flops = fl;
+  return (long)g_prof.size();
+}
+
+// one text line per recorded launch: M N K batch a_kstrided b_kstrided splitk bm64 epilogue-bits ms
+extern "C" long ea_gemm_profile_dump(const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return -1;
+  for (auto& r : g_prof) {
+    hipEventSynchronize(r.e1);
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.e0, r.e1);
+    fprintf(f, "%d %d %d %d %d %d %d %d %d %.6f\n", r.M, r.N, r.K, r.batch, r.a_ks, r.b_ks, r.splitk, r.bm64, r.epi, t);
+  }
+  fclose(f);
   return (long)g_prof.size();
 }
 
@@ -581,6 +596,10 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     hipEventCreate(&pr.e0);
     hipEventCreate(&pr.e1);
     pr.flops = 2.0 * q.M * q.N * (double)q.K * q.batch;
+    pr.M = q.M; pr.N = q.N; pr.K = q.K; pr.batch = q.batch; pr.a_ks = q.a_kstrided; pr.b_ks = q.b_kstrided;
+    pr.splitk = q.splitk; pr.bm64 = bm64;
+    pr.epi = (q.bias ? 1 : 0) | (q.resid ? 2 : 0) | (q.aux ? 4 : 0) | (q.C2 ? 8 : 0) | (q.act != EA_ACT_NONE ? 16 : 0) |
+             (q.drop_thr ? 32 : 0) | (q.c_f32 ? 64 : 0);
     hipEventRecord(pr.e0, stream);
   }
   if (p.a_kstrided) {

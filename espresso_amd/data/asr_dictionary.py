@@ -24,6 +24,10 @@ class AsrDictionary:
             for s in extra_special_symbols:
                 self.add_symbol(s, n=0)
         self.nspecial = len(self.symbols)
+        self.space_index = -1
+        self.non_lang_syms = None
+        self.tokenizer = None
+        self.bpe = None
 
     def __len__(self):
         return len(self.symbols)
@@ -73,11 +77,40 @@ class AsrDictionary:
                 continue
             word, *rest = line.rstrip().rsplit(" ", 1)
             d.add_symbol(word, n=int(rest[0]) if rest else 1)
-        d.space_index = d.indices.get(d.space_word, d.unk_index)
+        d.space_index = d.indices.get(d.space_word, -1)
         d.non_lang_syms = None
         if f_non_lang_syms is not None:
-            d.non_lang_syms = [x.strip() for x in open(f_non_lang_syms, encoding="utf-8") if x.strip()]
+            d.non_lang_syms = [x.rstrip() for x in open(f_non_lang_syms, encoding="utf-8") if x.strip()]
+            for sym in d.non_lang_syms:
+                assert d.index(sym) != d.unk(), "{} in {} is not in the dictionary".format(sym, f_non_lang_syms)
         return d
+
+    def build_bpe(self, name=None, sentencepiece_model=None):
+        """espresso/data/asr_dictionary.py:118-128 — `characters_asr` gets this dictionary's space / non-language symbols."""
+        from .encoders import build_bpe
+
+        self.bpe = build_bpe(name, self, sentencepiece_model)
+        return self.bpe
+
+    def wordpiece_encode(self, x: str) -> str:
+        if self.tokenizer is not None:
+            x = self.tokenizer.encode(x)
+        if self.bpe is not None:
+            x = self.bpe.encode(x)
+        return x
+
+    def wordpiece_decode(self, x: str) -> str:
+        if self.bpe is not None:
+            x = self.bpe.decode(x)
+        if self.tokenizer is not None:
+            x = self.tokenizer.decode(x)
+        return x
+
+    def save(self, f):
+        """`<symbol> <count>` lines for the non-special symbols (fairseq/data/dictionary.py:save)."""
+        with open(f, "w", encoding="utf-8") as fd:
+            for s, c in zip(self.symbols[self.nspecial:], self.count[self.nspecial:]):
+                print(f"{s} {c}", file=fd)
 
     @classmethod
     def from_symbols(cls, symbols, enable_bos=False, add_space=True):

@@ -4,10 +4,28 @@ batch_by_size: fairseq/data/data_utils.py:282-365 + the Cython kernel
 fairseq/data/data_utils_fast.pyx:20-103 (`batch_by_size_vec`): scan indices in the given order,
 close a batch when adding the next sample would exceed max_tokens (max_len_in_batch * n) or
 max_sentences, keeping batch sizes a multiple of bsz_mult.  collate_tokens: data_utils.py:37-77."""
+import contextlib
 from typing import List, Optional
 
 import numpy as np
 import torch
+
+
+@contextlib.contextmanager
+def numpy_seed(seed, *addl_seeds):
+    """Seed numpy's global RNG inside the block and restore the previous state afterwards
+    (fairseq/data/data_utils.py:126-140; CPython's hash of a tuple of ints is deterministic across runs)."""
+    if seed is None:
+        yield
+        return
+    if len(addl_seeds) > 0:
+        seed = int(hash((seed, *addl_seeds)) % 1e6)
+    state = np.random.get_state()
+    np.random.seed(seed)
+    try:
+        yield
+    finally:
+        np.random.set_state(state)
 
 
 def batch_by_size(indices, num_tokens_vec, max_tokens=None, max_sentences=None, bsz_mult=1) -> List[np.ndarray]:

@@ -428,6 +428,14 @@ def fbank_batch(wav, offsets, B, tables, cmvn_mean, cmvn_std, Tmax, nmel=80, fra
     return feat, out_len, utt_sum
 
 
+def feature_stats(feat, lengths, acc):
+    """acc fp64 [2*nmel+1] += (sum, sum of squares, frames) over the valid frames of feat fp32 [B][Tmax][nmel]."""
+    B, Tmax, nmel = feat.shape
+    assert acc.dtype == torch.float64 and acc.numel() == 2 * nmel + 1 and feat.dtype == torch.float32 and feat.is_contiguous()
+    check(_lib.lib().ea_feature_stats(_p(feat), _p(lengths), _p(acc), B, Tmax, nmel, _stream()), "ea_feature_stats")
+    return acc
+
+
 def specaugment(feat, lengths, utt_sum, fmask, tmask, use_mean=True, mask_value=0.0):
     B, Tmax, nmel = feat.shape
     nf = fmask.shape[1] if fmask is not None else 0

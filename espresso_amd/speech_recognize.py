@@ -13,20 +13,13 @@ import json
 import math
 import sys
 import time
-import wave
 from typing import Dict, Iterable, List, Optional
 
 import numpy as np
 import torch
 
 
-def read_wav(path: str) -> np.ndarray:
-    """16-bit PCM WAV -> float32 samples at int16 scale (what torchaudio's Kaldi fbank expects: espresso/tools/utils.py:426-454)."""
-    with wave.open(path, "rb") as w:
-        assert w.getsampwidth() == 2, f"{path}: 16-bit PCM expected"
-        n, ch = w.getnframes(), w.getnchannels()
-        x = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32)
-        return x.reshape(-1, ch)[:, 0].copy() if ch > 1 else x
+from .data.audio_utils import read_wav  # noqa: E402,F401
 
 
 def read_scp(path: str) -> Dict[str, str]:
@@ -109,7 +102,7 @@ def build_generator(args, model, dictionary, lm=None):
     from .tools.transducer_greedy_decoder import TransducerGreedyDecoder
 
     if args.search == "ctc":
-        return CTCDecoder(dictionary)
+        return CTCDecoder([model], dictionary)
     if args.search == "transducer_greedy":
         return TransducerGreedyDecoder([model], dictionary, max_num_expansions_per_step=args.max_num_expansions_per_step,
                                        lm_model=lm, lm_weight=args.lm_weight)

@@ -5,8 +5,9 @@ registries, train_step / valid_step, max_positions.  Datasets hand over RAW wave
 `prepare_sample` hook runs the fused GPU front-end (fbank + CMVN + SpecAugment + padding) right
 before `model(**net_input)`, so `net_input` keeps the reference's keys (src_tokens, src_lengths)."""
 from dataclasses import dataclass, field
-from typing import Optional
+from typing import List, Optional
 
+import numpy as np
 import torch
 
 from .. import registry
@@ -28,6 +29,19 @@ class SpeechRecognitionEspressoConfig:
     feat_dim: int = 80
     feat_in_channels: int = 1
     seed: int = 1
+    # the rest of espresso/tasks/speech_recognition.py:30-124 that the path consumes
+    non_lang_syms: Optional[str] = None
+    word_dict: Optional[str] = None
+    wer_output_filter: Optional[str] = None
+    criterion_name: str = "ctc_loss"
+    include_eos_in_transducer_loss: bool = False
+    prepend_bos_as_input_feeding: bool = False
+    batch_based_on_both_src_tgt: bool = False
+    required_seq_len_multiple: int = 1
+    train_subset: str = "train"
+    valid_subset: str = "valid"
+    bpe: Optional[str] = None
+    sentencepiece_model: Optional[str] = None
 
 
 @registry.register_task("speech_recognition_espresso", dataclass=SpeechRecognitionEspressoConfig)
@@ -42,12 +56,82 @@ class SpeechRecognitionEspressoTask:
         self.blank_symbol = tgt_dict.bos_word if not cfg.autoregressive else None
         self.frontend = None
         self.epoch = 1
+        self.datasets = {}
+        self.criterion = None
+        self.decoder_for_validation = None
+        # symbols never scored by WER (speech_recognition.py:332-334: blank in addition to </s> and <pad>)
+        self.extra_symbols_to_ignore = {tgt_dict.pad()}
+        if self.blank_symbol is not None:
+            self.extra_symbols_to_ignore.add(tgt_dict.index(self.blank_symbol))
 
     @classmethod
     def setup_task(cls, cfg, tgt_dict=None):
         if tgt_dict is None:
-            tgt_dict = AsrDictionary.load(cfg.dict, enable_bos=not cfg.autoregressive)
-        return cls(cfg, tgt_dict, feat_dim=cfg.feat_dim)
+            tgt_dict = cls.load_dictionary(cfg.dict, enable_bos=not cfg.autoregressive, non_lang_syms=cfg.non_lang_syms)
+        word_dict = None
+        if getattr(cfg, "word_dict", None):
+            word_dict = cls.load_dictionary(cfg.word_dict, enable_bos=False)
+        if getattr(cfg, "bpe", None):
+            tgt_dict.build_bpe(cfg.bpe, getattr(cfg, "sentencepiece_model", None))
+        return cls(cfg, tgt_dict, feat_dim=cfg.feat_dim, word_dict=word_dict)
+
+    @classmethod
+    def load_dictionary(cls, filename, enable_bos=False, non_lang_syms=None):
+        """speech_recognition.py:297-306: `<s>` is enabled (and doubles as the blank) for CTC / transducer targets."""
+        return AsrDictionary.load(filename, enable_bos=enable_bos, f_non_lang_syms=non_lang_syms)
+
+    def build_bpe(self, name=None, sentencepiece_model=None):
+        return self.tgt_dict.build_bpe(name, sentencepiece_model)
+
+    def load_dataset(self, split: str, epoch=1, combine=False, pin_memory=True):
+        """speech_recognition.py:414-469: `<data>/<split>.json`; shuffling only for the training split."""
+        from ..data.asr_dataset import get_asr_dataset_from_json
+
+        train = split == getattr(self.cfg, "train_subset", "train")
+        ds = get_asr_dataset_from_json(self.cfg.data, split, self.tgt_dict, combine=combine, shuffle=train,
+                                       pad_to_multiple=getattr(self.cfg, "required_seq_len_multiple", 1),
+                                       autoregressive=self.cfg.autoregressive,
+                                       prepend_bos_as_input_feeding=getattr(self.cfg, "prepend_bos_as_input_feeding", False),
+                                       batch_based_on_both_src_tgt=getattr(self.cfg, "batch_based_on_both_src_tgt", False),
+                                       pin_memory=pin_memory and torch.cuda.is_available())
+        self.datasets[split] = ds
+        self.feat_dim = ds.src.feat_dim
+        return ds
+
+    def dataset(self, split):
+        return self.datasets[split]
+
+    def get_batches(self, dataset, max_tokens=None, max_sentences=None, max_positions=None, seed=1, epoch=1, num_shards=1,
+                    shard_id=0, shuffle=True, bsz_mult=1) -> List[np.ndarray]:
+        """Batch plan of fairseq's `get_batch_iterator` + `EpochBatchIterator` (fairseq/tasks/fairseq_task.py:285-306,
+        fairseq/data/iterators.py: shuffle with `seed + epoch`, then rank `shard_id` takes every `num_shards`-th
+        batch; short ranks get empty batches so that every rank runs the same number of steps)."""
+        from ..data.data_utils import batch_by_size, numpy_seed
+
+        with numpy_seed(seed):
+            indices = dataset.ordered_indices()
+        if max_positions is not None:
+            indices, _ = dataset.filter_indices_by_size(indices, max_positions)
+        batches = batch_by_size(indices, dataset.num_tokens_vec(indices), max_tokens=max_tokens, max_sentences=max_sentences,
+                                bsz_mult=bsz_mult)
+        if shuffle:
+            with numpy_seed(seed + epoch):
+                np.random.shuffle(batches)
+        if num_shards > 1:
+            n = (len(batches) + num_shards - 1) // num_shards
+            mine = batches[shard_id::num_shards]
+            batches = mine + [np.zeros(0, dtype=np.int64)] * (n - len(mine))
+        return batches
+
+    def to_device(self, sample, device):
+        """Asynchronous H2D of a collated batch (the raw-audio buffer is pinned by the collater)."""
+        def mv(x):
+            if torch.is_tensor(x):
+                return x.to(device, non_blocking=True)
+            if isinstance(x, dict):
+                return {k: mv(v) for k, v in x.items()}
+            return x
+        return {k: mv(v) for k, v in sample.items()}
 
     @property
     def target_dictionary(self):
@@ -67,8 +151,70 @@ class SpeechRecognitionEspressoTask:
     def build_model(self, model_cfg, model_name="speech_transformer_encoder_model"):
         return registry.MODEL_REGISTRY[model_name].build_model(model_cfg, self)
 
-    def build_criterion(self, name="ctc_loss", **kwargs):
-        return registry.CRITERION_REGISTRY[name](self, **kwargs)
+    def build_criterion(self, name=None, **kwargs):
+        name = name or getattr(self.cfg, "criterion_name", "ctc_loss")
+        self.cfg.criterion_name = name
+        self.criterion = registry.CRITERION_REGISTRY[name](self, **kwargs)
+        return self.criterion
+
+    def build_generator(self, models, args=None, seq_gen_cls=None, extra_gen_cls_kwargs=None, lm_model=None):
+        """speech_recognition.py:526-596: transducer greedy / beam search, CTC greedy, or the attention beam search,
+        chosen from the criterion the task was configured with.  `args`: namespace with the generation options."""
+        g = lambda k, d=None: getattr(args, k, d) if args is not None else d  # noqa: E731
+        extra = dict(extra_gen_cls_kwargs or {})
+        if g("print_alignment", False):
+            extra["print_alignment"] = True
+        crit = getattr(self.cfg, "criterion_name", "ctc_loss")
+        if crit == "transducer_loss":
+            from ..tools.transducer_beam_search_decoder import TransducerBeamSearchDecoder
+            from ..tools.transducer_greedy_decoder import TransducerGreedyDecoder
+
+            if seq_gen_cls is None:
+                seq_gen_cls = TransducerGreedyDecoder if g("beam", 1) == 1 else TransducerBeamSearchDecoder
+            include_eos = getattr(self.cfg, "include_eos_in_transducer_loss", False)
+            kw = dict(temperature=g("temperature", 1.0), max_num_expansions_per_step=g("transducer_max_num_expansions_per_step", 20),
+                      bos=self.tgt_dict.bos() if include_eos else self.tgt_dict.eos(),
+                      blank=self.tgt_dict.index(self.blank_symbol), model_predicts_eos=include_eos)
+            if seq_gen_cls is not TransducerGreedyDecoder:
+                kw.update(beam_size=g("beam", 1), normalize_scores=not g("unnormalized", False),
+                          expansion_beta=g("transducer_expansion_beta", 0), expansion_gamma=g("transducer_expansion_gamma", None),
+                          prefix_alpha=g("transducer_prefix_alpha", None))
+            if lm_model is not None:
+                kw.update(lm_model=lm_model, lm_weight=g("lm_weight", 0.0))
+            kw.update(extra)
+            return seq_gen_cls(models, self.tgt_dict, **kw)
+        if crit == "ctc_loss":
+            from ..tools.ctc_decoder import CTCDecoder
+
+            return (seq_gen_cls or CTCDecoder)(models, self.tgt_dict, beam_size=g("beam", 1), **extra)
+        from ..sequence_generator import SequenceGenerator
+
+        kw = dict(beam_size=g("beam", 5), max_len_a=g("max_len_a", 0.0), max_len_b=g("max_len_b", 200), min_len=g("min_len", 1),
+                  normalize_scores=not g("unnormalized", False), len_penalty=g("lenpen", 1.0), unk_penalty=g("unkpen", 0.0),
+                  temperature=g("temperature", 1.0), lm_model=lm_model, lm_weight=g("lm_weight", 0.0), eos_factor=g("eos_factor", None))
+        kw.update(extra)
+        return (seq_gen_cls or SequenceGenerator)(models, self.tgt_dict, **kw)
+
+    def build_validation_decoder(self, model):
+        """The greedy decoder the reference attaches for WER during validation (speech_recognition.py:497-517)."""
+        crit = getattr(self.cfg, "criterion_name", "ctc_loss")
+        if crit == "ctc_loss":
+            from ..tools.ctc_decoder import CTCDecoder
+
+            self.decoder_for_validation = CTCDecoder([model], self.tgt_dict)
+        elif crit == "transducer_loss":
+            from ..tools.transducer_greedy_decoder import TransducerGreedyDecoder
+
+            include_eos = getattr(self.cfg, "include_eos_in_transducer_loss", False)
+            self.decoder_for_validation = TransducerGreedyDecoder(
+                [model], self.tgt_dict, max_num_expansions_per_step=20,
+                bos=self.tgt_dict.bos() if include_eos else self.tgt_dict.eos(), blank=self.tgt_dict.index(self.blank_symbol),
+                model_predicts_eos=include_eos)
+        else:
+            from ..tools.simple_greedy_decoder import SimpleGreedyDecoder
+
+            self.decoder_for_validation = SimpleGreedyDecoder([model], self.tgt_dict, for_validation=True)
+        return self.decoder_for_validation
 
     def build_frontend(self, device, cmvn: Optional[GlobalCMVN] = None):
         specaug = None
@@ -83,6 +229,8 @@ class SpeechRecognitionEspressoTask:
 
     def begin_epoch(self, epoch, model=None):
         self.epoch = epoch
+        if self.criterion is not None and hasattr(self.criterion, "set_epoch"):
+            self.criterion.set_epoch(epoch)  # speech_recognition.py:609-613
 
     def prepare_sample(self, sample, train=True):
         """Run the GPU front-end when the batch carries raw audio (`wav`, `wav_offsets`, `num_samples`)."""
@@ -108,4 +256,33 @@ class SpeechRecognitionEspressoTask:
         with torch.no_grad():
             sample = self.prepare_sample(sample, train=False)
             loss, sample_size, logging_output = criterion(model, sample)
+            if self.decoder_for_validation is not None:
+                (logging_output["word_error"], logging_output["word_count"], logging_output["char_error"],
+                 logging_output["char_count"]) = self._inference_with_wer(self.decoder_for_validation, sample, model)
         return loss, sample_size, logging_output
+
+    def _inference_with_wer(self, decoder, sample, model):
+        """speech_recognition.py:663-687."""
+        from ..tools.wer import Scorer
+
+        scorer = Scorer(self.tgt_dict, wer_output_filter=getattr(self.cfg, "wer_output_filter", None))
+        tokens, _, _ = decoder.decode([model], sample)
+        pred = tokens.cpu()
+        assert pred.size(0) == sample["target"].size(0)
+        for i in range(pred.size(0)):
+            utt_id = sample["utt_id"][i]
+            ref_tokens = self.tgt_dict.wordpiece_encode(sample["text"][i])
+            pred_tokens = self.tgt_dict.string(pred[i], extra_symbols_to_ignore=self.extra_symbols_to_ignore)
+            scorer.add_evaluation(utt_id, ref_tokens, pred_tokens)
+        return scorer.tot_word_error(), scorer.tot_word_count(), scorer.tot_char_error(), scorer.tot_char_count()
+
+    def reduce_metrics(self, logging_outputs, criterion=None):
+        """Sum over the data-parallel workers' logging outputs; adds wer / cer (speech_recognition.py:615-629)."""
+        crit = criterion if criterion is not None else self.criterion
+        out = dict(crit.reduce_metrics(logging_outputs)) if crit is not None and hasattr(crit, "reduce_metrics") else {}
+        tot = {k: sum(log.get(k, 0) for log in logging_outputs) for k in ("word_error", "word_count", "char_error", "char_count")}
+        if tot["word_count"] > 0:
+            out["wer"] = float(tot["word_error"]) / tot["word_count"] * 100
+        if tot["char_count"] > 0:
+            out["cer"] = float(tot["char_error"]) / tot["char_count"] * 100
+        return out

@@ -11,22 +11,7 @@ import numpy as np
 import torch
 
 
-def tokenize(sent: str, space: str = "<space>", non_lang_syms: Optional[List[str]] = None) -> str:
-    """espresso/tools/utils.py:tokenize — characters separated by blanks, blanks become `space`, non-language symbols
-    (e.g. "<noise>") stay whole."""
-    sent = " ".join(sent.strip().split())
-    syms = sorted(non_lang_syms or [], key=len, reverse=True)
-    out, i = [], 0
-    while i < len(sent):
-        for s in syms:
-            if sent.startswith(s, i):
-                out.append(s)
-                i += len(s)
-                break
-        else:
-            out.append(space if sent[i] == " " else sent[i])
-            i += 1
-    return " ".join(out)
+from ..data.encoders import tokenize  # noqa: F401  (espresso/tools/utils.py:tokenize)
 
 
 class TensorizedPrefixTree:

@@ -36,8 +36,10 @@ class Scorer(object):
         self.results = OrderedDict()
 
     def _decode(self, s):
-        f = getattr(self.dictionary, "wordpiece_decode", None)
-        return f(s) if f is not None else wordpiece_decode(s, getattr(self.dictionary, "space_word", "<space>"))
+        d = self.dictionary
+        if getattr(d, "bpe", None) is not None or getattr(d, "tokenizer", None) is not None:
+            return d.wordpiece_decode(s)
+        return wordpiece_decode(s, getattr(self.dictionary, "space_word", "<space>"))
 
     def add_prediction(self, utt_id, pred):
         assert isinstance(utt_id, str) and isinstance(pred, str)
@@ -69,6 +71,14 @@ class Scorer(object):
 
     def wer(self):
         return self._rate(self.word_counter)
+
+    def tot_word_error(self):
+        c = self.word_counter
+        return c["sub"] + c["ins"] + c["del"]
+
+    def tot_char_error(self):
+        c = self.char_counter
+        return c["sub"] + c["ins"] + c["del"]
 
     def tot_word_count(self):
         return self.word_counter["words"]

@@ -83,6 +83,8 @@ int ea_set_gemm_variant(int v);
 int ea_set_gemm_xcd_swizzle(int on);
 int ea_gemm_profile_enable(int on);
 long ea_gemm_profile_read(double* total_ms, double* total_flops);
+/* writes one line per recorded launch ("M N K batch a_ks b_ks splitk bm64 epilogue-bits ms"); returns the count or -1 */
+long ea_gemm_profile_dump(const char* path);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused
@@ -246,6 +248,11 @@ int ea_fbank_batch(const float* wav, const long* offsets, int B, const float* wi
                    ea_stream_t stream);
 int ea_specaugment(float* feat, const int* lengths, const float* utt_sum, const int* fmask, const int* tmask,
                    int nf, int nt, int B, int Tmax, int nmel, int use_mean, float mask_value, ea_stream_t stream);
+
+/* Global CMVN statistics on the device — espresso/tools/compute_global_cmvn_stats.py:55-120 (per-utterance numpy
+ * sum / variance merged on the host).  acc fp64 [2*nmel+1] = (sum[f], sum of squares[f], frame count), accumulated
+ * across calls over the valid frames (t < lengths[b]) of feat fp32 [B][Tmax][nmel]; zeroed by the caller once. */
+int ea_feature_stats(const float* feat, const int* lengths, double* acc, int B, int Tmax, int nmel, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer on flat fp32 buffers — fairseq/utils.py:347-397 (clip_grad_norm_),

@@ -1167,3 +1167,113 @@ def check_scheduled_sampling():
     has_embed_grad = float(model.decoder.embed_tokens.weight.grad.abs().sum()) > 0
     return {"p1_vs_teacher_forcing": float((lo_p1.float() - lo_tf.float()).abs().max()),
             "p0_vs_rollout": float((lo_p0.float() - lo_roll.float()).abs().max()), "finite": finite, "embed_grad": has_embed_grad}
+
+
+def check_task_pipeline(tmp_dir):
+    """The drop-in boundary end to end on raw audio: data json -> AsrDataset/collater (pinned waveforms) -> task.to_device ->
+    GPU front-end in prepare_sample -> `cross_entropy_v2` train step -> valid step with the greedy WER decoder ->
+    reduce_metrics; `build_generator` picks the decoder class from the criterion like the reference task."""
+    import json
+
+    import torch.nn.functional as TF
+
+    from espresso_amd.data import audio_utils
+    from espresso_amd.sequence_generator import SequenceGenerator
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
+    from espresso_amd.tools.ctc_decoder import CTCDecoder
+    from espresso_amd.tools.transducer_beam_search_decoder import TransducerBeamSearchDecoder
+    from espresso_amd.tools.transducer_greedy_decoder import TransducerGreedyDecoder
+
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    d = _TaskAR(40).target_dictionary
+    utts = {}
+    for i in range(7):
+        u = f"utt{i}"
+        path = os.path.join(tmp_dir, u + ".wav")
+        audio_utils.write_wav(path, rng.standard_normal(int(16000 * rng.uniform(0.6, 1.6))) * 3000)
+        utts[u] = {"wave": path, "text": " ".join(f"t{int(k)}" for k in rng.integers(0, 36, size=int(rng.integers(2, 7))))}
+    for split in ("train", "valid"):
+        with open(os.path.join(tmp_dir, split + ".json"), "w") as f:
+            json.dump(utts, f)
+    cfg = SpeechRecognitionEspressoConfig(data=tmp_dir, autoregressive=True, criterion_name="cross_entropy_v2")
+    task = SpeechRecognitionEspressoTask.setup_task(cfg, tgt_dict=d)
+    task.build_frontend(DEV)
+    model = build_tiny_encdec().to(DEV)
+    crit = task.build_criterion(sentence_avg=False)
+    ds = task.load_dataset("train")
+    batches = task.get_batches(ds, max_tokens=400, max_sentences=4, seed=1, epoch=1)
+    sample = task.to_device(ds.collater([ds[int(i)] for i in batches[0]]), DEV)
+    loss, sample_size, log = task.train_step(sample, model, crit)
+    # independent value: torch cross entropy on the model's own logits
+    model.eval()
+    with torch.no_grad():
+        s2 = task.prepare_sample(sample, train=False)
+        logits, _ = model(**s2["net_input"])
+        ref = TF.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), s2["target"].reshape(-1), ignore_index=d.pad(), reduction="sum")
+        model.train()
+        lt, _, _ = crit(model, s2)
+    grads_finite = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    task.build_validation_decoder(model)
+    vds = task.load_dataset("valid")
+    logs = []
+    for b in task.get_batches(vds, max_tokens=400, max_sentences=4, shuffle=False):
+        _, _, lg = task.valid_step(task.to_device(vds.collater([vds[int(i)] for i in b]), DEV), model, crit)
+        logs.append(lg)
+    red = task.reduce_metrics(logs)
+    n_words = sum(len(v["text"].split()) for v in utts.values())
+    gens = {}
+    for name, beam, want in (("cross_entropy_v2", 3, SequenceGenerator), ("ctc_loss", 1, CTCDecoder)):
+        task.cfg.criterion_name = name
+        gens[name] = isinstance(task.build_generator([model], type("A", (), {"beam": beam})()), want)
+    tmodel = build_tiny_transducer().to(DEV)
+    task.cfg.criterion_name, task.blank_symbol = "transducer_loss", d.bos_word
+    gens["transducer_greedy"] = isinstance(task.build_generator([tmodel], type("A", (), {"beam": 1})()), TransducerGreedyDecoder)
+    gens["transducer_beam"] = isinstance(task.build_generator([tmodel], type("A", (), {"beam": 4})()), TransducerBeamSearchDecoder)
+    return {"loss_vs_torch": abs(float(lt) - float(ref)) / max(1.0, abs(float(ref))), "sample_size": sample_size,
+            "ntokens": sample["ntokens"], "grads_finite": grads_finite, "word_count": sum(l["word_count"] for l in logs),
+            "n_words": n_words, "wer": red.get("wer"), "loss_metric": red.get("loss"), "gens": gens,
+            "pinned": bool(ds.collater([ds[0]])["wav"].is_pinned())}
+
+
+def check_global_cmvn_stats(tmp_dir):
+    """GPU CMVN statistics tool vs the reference's recipe restated on the host (oracle fbank per utterance, then the pairwise
+    sum / unnormalised-variance merge of espresso/tools/compute_global_cmvn_stats.py:96-120)."""
+    import io
+
+    from espresso_amd.data import audio_utils
+    from espresso_amd.tools import compute_global_cmvn_stats as cg, wav2num_frames as w2n
+    from oracle import fbank_ref
+
+    rng = np.random.default_rng(3)
+    lines, waves = [], []
+    for i, sec in enumerate((1.3, 0.4, 2.2, 0.02, 0.9, 1.7)):
+        x = np.round(rng.standard_normal(int(16000 * sec)) * (500 + 700 * i)).astype(np.float32)
+        path = os.path.join(tmp_dir, f"c{i}.wav")
+        audio_utils.write_wav(path, x)
+        lines.append(f"c{i} {path}")
+        waves.append(np.clip(x, -32768, 32767))
+    scp = os.path.join(tmp_dir, "wav.scp")
+    open(scp, "w").write("\n".join(lines) + "\n")
+    cg.main(cg.get_parser().parse_args([scp, tmp_dir, "--batch-seconds", "2.5", "--device", DEV]))
+    got = np.load(os.path.join(tmp_dir, "gcmvn.npz"))
+    total_sum, total_var, total_frames = np.zeros(80), np.zeros(80), 0
+    frames = []
+    for w in waves:
+        feat = fbank_ref.fbank(w).astype(np.float64)
+        frames.append(feat.shape[0])
+        if feat.shape[0] == 0:
+            continue
+        cur_sum, cur_frames, cur_var = feat.sum(0), feat.shape[0], np.var(feat, axis=0) * feat.shape[0]
+        if total_frames > 0:
+            r = total_frames / cur_frames
+            total_var = total_var + cur_var + r / (total_frames + cur_frames) * (total_sum / r - cur_sum) ** 2
+        else:
+            total_var = cur_var
+        total_sum, total_frames = total_sum + cur_sum, total_frames + cur_frames
+    mean, std = total_sum / total_frames, np.sqrt(total_var / total_frames)
+    buf = io.StringIO()
+    w2n.main(w2n.get_parser().parse_args([scp]), out=buf)
+    nf = [int(l.split()[1]) for l in buf.getvalue().strip().split("\n")]
+    return {"mean_abs": float(np.abs(got["mean"] - mean).max()), "std_abs": float(np.abs(got["std"] - std).max()),
+            "dtype64": got["mean"].dtype == np.float64, "num_frames_equal": nf == frames}

@@ -284,3 +284,16 @@ def test_scheduled_sampling_lstm_decoder():
     assert r["p1_vs_teacher_forcing"] < 2e-2, r   # per-step output layer vs one batched GEMM: bf16 rounding only
     assert r["p0_vs_rollout"] < 2e-2, r
     assert r["finite"] and r["embed_grad"], r
+
+
+def test_task_pipeline_raw_audio_to_metrics(tmp_path):
+    r = G.check_task_pipeline(str(tmp_path))
+    assert r["loss_vs_torch"] < 2e-2, r
+    assert r["sample_size"] == r["ntokens"] and r["grads_finite"], r
+    assert r["word_count"] == r["n_words"] and r["wer"] is not None and r["wer"] >= 0.0, r
+    assert r["loss_metric"] is not None and all(r["gens"].values()) and r["pinned"], r
+
+
+def test_global_cmvn_stats_tool(tmp_path):
+    r = G.check_global_cmvn_stats(str(tmp_path))
+    assert r["mean_abs"] < 2e-4 and r["std_abs"] < 2e-4 and r["dtype64"] and r["num_frames_equal"], r

@@ -226,3 +226,163 @@ def test_speech_recognize_host_pieces(tmp_path):
     a = sr.get_parser().parse_args(["--path", "m.pt", "--model-config", "m.yaml", "--dict", "d.txt", "--wav-scp", str(scp),
                                     "--lm-weight", "0.47", "--eos-factor", "1.5", "--beam", "60"])
     assert a.beam == 60 and a.lm_weight == 0.47 and a.eos_factor == 1.5 and a.search == "beam"
+
+
+# ---- datasets / collater / task hooks (reference: tests/espresso/test_asr_dataset.py:102-189) -----------------------------
+def _toy_corpus(tmp_path, n=9, seed=0, kind="wave"):
+    import json
+
+    from espresso_amd.data import audio_utils, kaldi_io
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+
+    rng = np.random.default_rng(seed)
+    letters = list("ABCDEFGHIJKLMNOPQRSTUVWXYZ")
+    d = AsrDictionary.from_symbols(letters, enable_bos=False)
+    d.build_bpe("characters_asr")
+    utts, arrays, feats = {}, {}, {}
+    for i in range(n):
+        u = f"utt{i:03d}"
+        ns = int(rng.integers(4000, 16000))
+        x = np.round(rng.standard_normal(ns) * 3000).astype(np.float32)
+        arrays[u] = x
+        text = " ".join("".join(rng.choice(letters, size=int(rng.integers(1, 5)))) for _ in range(int(rng.integers(1, 4))))
+        if kind == "wave":
+            path = str(tmp_path / f"{u}.wav")
+            audio_utils.write_wav(path, x)
+            utts[u] = {"wave": path, "text": text}
+        else:
+            feats[u] = rng.standard_normal((int(rng.integers(20, 60)), 8)).astype(np.float32)
+            utts[u] = {"text": text}
+    if kind == "feat":
+        scp = kaldi_io.write_ark(str(tmp_path / "feats.ark"), feats)
+        for u in utts:
+            utts[u]["feat"] = scp[u]
+            utts[u]["utt2num_frames"] = str(feats[u].shape[0])
+    with open(tmp_path / "train.json", "w") as f:
+        json.dump(utts, f)
+    return d, utts, arrays, feats
+
+
+@pytest.mark.parametrize("kind", ["wave", "feat"])
+def test_asr_dataset_round_trip(tmp_path, kind):
+    from espresso_amd.data.asr_dataset import get_asr_dataset_from_json, samples_to_frames
+
+    d, utts, arrays, feats = _toy_corpus(tmp_path, kind=kind)
+    ds = get_asr_dataset_from_json(str(tmp_path), "train", d, autoregressive=True)
+    assert len(ds) == len(utts)
+    idx = list(range(len(ds)))
+    for s in range(0, len(idx), 4):
+        b = ds.collater([ds[i] for i in idx[s:s + 4]])
+        bsz = b["nsentences"]
+        assert bsz == len(b["utt_id"]) == b["target"].shape[0] == b["net_input"]["src_lengths"].numel()
+        lens = b["net_input"]["src_lengths"].tolist()
+        assert lens == sorted(lens, reverse=True)
+        hyp = d.string(b["target"], extra_symbols_to_ignore={d.pad()}).split("\n")
+        for j, u in enumerate(b["utt_id"]):
+            assert d.wordpiece_decode(hyp[j]) == utts[u]["text"] == b["text"][j]
+            # shifted decoder input: </s> first, then the target without its final </s>
+            t = b["target"][j][b["target"][j] != d.pad()]
+            p = b["net_input"]["prev_output_tokens"][j][: len(t)]
+            assert p[0] == d.eos() and torch.equal(p[1:], t[:-1])
+            if kind == "wave":
+                o0, o1 = int(b["wav_offsets"][j]), int(b["wav_offsets"][j + 1])
+                assert o1 - o0 == b["num_samples"][j] == len(arrays[u])
+                assert np.array_equal(b["wav"][o0:o1].numpy(), np.clip(arrays[u], -32768, 32767))
+                assert lens[j] == samples_to_frames(len(arrays[u]))
+            else:
+                assert torch.equal(b["net_input"]["src_tokens"][j, : lens[j]], torch.from_numpy(feats[u]))
+                assert float(b["net_input"]["src_tokens"][j, lens[j]:].abs().sum()) == 0.0
+        assert b["ntokens"] == int((b["target"] != d.pad()).sum())
+        assert b["id"].tolist() == [ds.src.utt_ids.index(u) for u in b["utt_id"]]
+
+
+def test_asr_dataset_matches_src_and_tgt():
+    from espresso_amd.data.asr_dataset import AsrDataset, AsrTextDataset, AudioFeatDataset
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+
+    d = AsrDictionary.from_symbols(list("ABC"))
+    feats = [np.full((3 + i, 2), float(i + 1), dtype=np.float32) for i in range(4)]
+    src = AudioFeatDataset(["a", "b", "c", "d"], feats)
+    tgt = AsrTextDataset(["d", "b", "x"], ["A B", "C", "A"], d)
+    ds = AsrDataset(src, src.sizes, tgt, tgt.sizes, d, shuffle=False)
+    assert ds.src.utt_ids == ds.tgt.utt_ids == ["b", "d"]
+    assert ds.src_sizes.tolist() == [4, 6] and ds.tgt_sizes.tolist() == [2, 3]
+    assert ds.ordered_indices().tolist() == [0, 1]
+    kept, ignored = ds.filter_indices_by_size(np.array([0, 1]), (5, 10))
+    assert kept.tolist() == [0] and ignored == [1]
+    assert ds.num_tokens(1) == 6 and ds.size(1) == (6, 3)
+
+
+def test_kaldi_compressed_matrix_formats():
+    import io
+    import struct
+
+    from espresso_amd.data import kaldi_io
+
+    rng = np.random.default_rng(0)
+    rows, cols = 7, 3
+    mn, rg = -2.0, 5.0
+    hdr = np.sort(rng.integers(0, 65536, size=(cols, 4)), axis=1).astype("<u2")
+    data = rng.integers(0, 256, size=(cols, rows)).astype(np.uint8)
+    buf = b"\0BCM " + struct.pack("<ffii", mn, rg, rows, cols) + hdr.tobytes() + data.tobytes()
+    got = kaldi_io.read_mat_fd(io.BytesIO(buf))
+    p = mn + rg * hdr.astype(np.float64) / 65535.0
+    for c in range(cols):
+        for r in range(rows):
+            v = float(data[c, r])
+            if v <= 64:
+                e = p[c, 0] + (p[c, 1] - p[c, 0]) * v / 64.0
+            elif v <= 192:
+                e = p[c, 1] + (p[c, 2] - p[c, 1]) * (v - 64) / 128.0
+            else:
+                e = p[c, 2] + (p[c, 3] - p[c, 2]) * (v - 192) / 63.0
+            assert abs(got[r, c] - e) < 1e-4
+    v16 = rng.integers(0, 65536, size=(rows, cols)).astype("<u2")
+    got = kaldi_io.read_mat_fd(io.BytesIO(b"\0BCM2 " + struct.pack("<ffii", mn, rg, rows, cols) + v16.tobytes()))
+    assert np.allclose(got, mn + rg * v16 / 65535.0, atol=1e-5)
+    v8 = rng.integers(0, 256, size=(rows, cols)).astype(np.uint8)
+    got = kaldi_io.read_mat_fd(io.BytesIO(b"\0BCM3 " + struct.pack("<ffii", mn, rg, rows, cols) + v8.tobytes()))
+    assert np.allclose(got, mn + rg * v8 / 255.0, atol=1e-5)
+    dm = rng.standard_normal((rows, cols))
+    got = kaldi_io.read_mat_fd(io.BytesIO(b"\0BDM \4" + struct.pack("<i", rows) + b"\4" + struct.pack("<i", cols) + dm.astype("<f8").tobytes()))
+    assert np.allclose(got, dm.astype(np.float32))
+
+
+def test_task_batches_shard_like_the_epoch_iterator(tmp_path):
+    from espresso_amd.data.asr_dataset import get_asr_dataset_from_json
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
+
+    d, utts, _, _ = _toy_corpus(tmp_path, n=23, kind="wave")
+    cfg = SpeechRecognitionEspressoConfig(data=str(tmp_path), autoregressive=True, criterion_name="label_smoothed_cross_entropy_v2")
+    task = SpeechRecognitionEspressoTask(cfg, d)
+    ds = task.load_dataset("train")
+    assert task.dataset("train") is ds and task.feat_dim == 80
+    full = task.get_batches(ds, max_tokens=250, max_sentences=4, seed=3, epoch=2)
+    again = task.get_batches(ds, max_tokens=250, max_sentences=4, seed=3, epoch=2)
+    other = task.get_batches(ds, max_tokens=250, max_sentences=4, seed=3, epoch=3)
+    assert [b.tolist() for b in full] == [b.tolist() for b in again]
+    assert sorted(i for b in full for i in b.tolist()) == list(range(len(ds)))
+    assert [b.tolist() for b in full] != [b.tolist() for b in other]
+    for b in full:
+        assert len(b) <= 4 and len(b) * int(ds.src_sizes[b].max()) <= 250
+    shards = [task.get_batches(ds, max_tokens=250, max_sentences=4, seed=3, epoch=2, num_shards=2, shard_id=r) for r in range(2)]
+    assert len(shards[0]) == len(shards[1]) == (len(full) + 1) // 2
+    merged = [b.tolist() for pair in zip(*shards) for b in pair if len(b)]
+    assert merged == [b.tolist() for b in full]
+
+
+def test_characters_asr_and_tokenize_follow_reference_order():
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+    from espresso_amd.data.encoders import CharactersAsr, tokenize
+
+    assert tokenize("  HI  <noise> YOU ", non_lang_syms=["<noise>"]) == "H I <space> <noise> <space> Y O U"
+    # alternation order, not longest match (espresso/tools/utils.py:44 joins the symbols with "|")
+    assert tokenize("<a><ab>", non_lang_syms=["<a>", "<a><ab>"]) == "<a> < a b >"
+    enc = CharactersAsr()
+    assert enc.encode("AB C") == "A B <space> C <space>"
+    assert enc.decode("A B <space> C <space>") == "AB C"
+    d = AsrDictionary.from_symbols(list("ABC"))
+    assert d.wordpiece_encode("AB C") == "AB C"
+    d.build_bpe("characters_asr")
+    ids = d.encode_line(d.wordpiece_encode("AB C"))
+    assert d.wordpiece_decode(d.string(ids)) == "AB C"
