@@ -1,6 +1,8 @@
 // Shared device helpers for the espresso_amd HIP kernels (gfx950 / CDNA4 only).
 // Wavefront = 64 lanes; all reductions below are written for that width.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -92,4 +94,15 @@ __device__ __forceinline__ float log_add(float a, float b) {
   return m + log1pf(__expf(-fabsf(a - b)));
 }
 
-#define EA_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -1)
+// EA_DEBUG_SYNC=1 in the environment: print the launch site and wait for the device after every launch (a memory fault then
+// aborts right after the line that names the offending launch).
+static inline int ea_check_launch(const char* file, int line, const char* func) {
+  static const int dbg = [] { const char* e = getenv("EA_DEBUG_SYNC"); return e && e[0] == '1' ? 1 : 0; }();
+  if (dbg) {
+    fprintf(stderr, "[ea] %s:%d %s\n", file, line, func);
+    fflush(stderr);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#define EA_CHECK_LAUNCH() ea_check_launch(__FILE__, __LINE__, __func__)

@@ -192,7 +192,8 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   G gx(dz, w.w1, dxn, M, C, F, F, C, C);
   gx.bks();
   gemm(c, gx);
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, ln_ws(c, M, C), c.s));
+  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
   release(c, mark);
 }
 
@@ -314,7 +315,8 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
   G gx(dqkv, w.wqkv, dxn, M, C, 3 * C, 3 * C, C, C);
   gx.bks();
   gemm(c, gx);
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, ln_ws(c, M, C), c.s));
+  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
 }
 
 static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
@@ -445,7 +447,8 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   G gx(dY, w.pw1, dxn, M, C, 2 * C, 2 * C, C, C);
   gx.bks();
   gemm(c, gx);
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, ln_ws(c, M, C), c.s));
+  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
+  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
   release(c, mark);
 }
 
@@ -498,8 +501,9 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   uint16_t* dB = sc.get<uint16_t>((size_t)M * C);
   uint16_t* dC = sc.get<uint16_t>((size_t)M * C);
   uint16_t* dD = sc.get<uint16_t>((size_t)M * C);
+  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
   RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
-                       1.f, nullptr, ln_ws(c, M, C), c.s));
+                       1.f, nullptr, lnws, c.s));
   ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU);
   conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32);
   attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16);
@@ -533,10 +537,22 @@ int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, l
   return 0;
 }
 
+// arena capacities are checked with a dry (sizing) pass before anything is launched
+static bool arenas_fit(const EaLayerShape& sh, bool backward, bool overlap, long saved_bytes, long scratch_bytes) {
+  EaConformerLayer L;
+  memset(&L, 0, sizeof(L));
+  Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
+  Ctx c{nullptr, true, 0, &sc, nullptr, overlap};
+  if (backward) layer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+  else layer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+  return (long)sv.peak <= saved_bytes && (long)sc.peak <= scratch_bytes;
+}
+
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
-                           const int* key_len, const float* attn_mask, const void* pe, void* saved, void* scratch,
-                           hipStream_t stream) {
+                           const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
+                           void* scratch, long scratch_bytes, hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
+  if (!arenas_fit(*shape, false, false, saved_bytes, scratch_bytes)) return -5;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, nullptr, false};
   if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
@@ -550,10 +566,12 @@ int ea_set_flash_attention(int on) {
 }
 
 int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy, void* dx,
-                           const int* key_len, const void* pe, void* saved, void* scratch, hipStream_t stream) {
+                           const int* key_len, const void* pe, void* saved, long saved_bytes, void* scratch, long scratch_bytes,
+                           hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
-  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   const bool ov = g_overlap_default && side_init();
+  if (!arenas_fit(*shape, true, ov, saved_bytes, scratch_bytes)) return -5;
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
   if (ov) stream_wait(c, c.side, c.s);
   return layer_bwd(c, layer, *shape, x_in, dy, dx, key_len, pe, sv);

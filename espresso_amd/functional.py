@@ -724,7 +724,8 @@ class _ConformerLayerNative(torch.autograd.Function):
         y = torch.empty_like(x)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(lib.ea_conformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
-                                              _ptr(pe), _ptr(saved), _ptr(scratch), stream), "ea_conformer_layer_fwd")
+                                              _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
+                   "ea_conformer_layer_fwd")
         ctx.save_for_backward(x, saved, pe, key_len)
         ctx.bind, ctx.sh, ctx.nb_scratch = bind, sh, nb_scratch.value
         return y
@@ -741,7 +742,8 @@ class _ConformerLayerNative(torch.autograd.Function):
         scratch = _scratch_buffer(ctx.nb_scratch, x.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
-                                                     _ptr(pe), _ptr(saved), _ptr(scratch), stream), "ea_conformer_layer_bwd")
+                                                     _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
+                   "ea_conformer_layer_bwd")
         if ctx.owns_arena:
             ctx.bind.saved_busy = False
         ctx.bind.finish_backward()

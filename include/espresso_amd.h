@@ -273,7 +273,8 @@ int ea_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long n, c
  * [q;k;v] rows, wo, wpos, pw1, pw2) + fp32 vectors; gradients are ACCUMULATED (+=) into the fp32
  * buffers in `grads` (the flat gradient buffer).  x: bf16 [B*T][C] batch-major rows.  `pe`: bf16
  * [2T-1][C] sinusoidal table.  `saved` carries activations from fwd to bwd, `scratch` is reusable;
- * sizes from ea_conformer_layer_workspace.  Dropout masks are re-derived from `seed`. */
+ * sizes from ea_conformer_layer_workspace; fwd / bwd get the capacities of the two arenas and return -5 before
+ * launching anything when an arena is too small.  Dropout masks are re-derived from `seed`. */
 typedef struct EaFfnParams { const float *ln_g, *ln_b; const void* w1; const float* b1; const void* w2; const float* b2; } EaFfnParams;
 typedef struct EaFfnGrads { float *ln_g, *ln_b, *w1, *b1, *w2, *b2; } EaFfnGrads;
 typedef struct EaAttnParams {
@@ -297,10 +298,11 @@ typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_a
 int ea_set_backward_overlap(int on);
 int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
-                           const int* key_len, const float* attn_mask, const void* pe, void* saved, void* scratch,
-                           ea_stream_t stream);
+                           const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
+                           void* scratch, long scratch_bytes, ea_stream_t stream);
 int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
-                           void* dx, const int* key_len, const void* pe, void* saved, void* scratch, ea_stream_t stream);
+                           void* dx, const int* key_len, const void* pe, void* saved, long saved_bytes, void* scratch,
+                           long scratch_bytes, ea_stream_t stream);
 /* tuning / test hook: use the fused attention kernels inside the layer runtime when the shape allows (default on);
  * returns the previous value.  Workspace sizes depend on it. */
 int ea_set_flash_attention(int on);

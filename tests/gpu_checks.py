@@ -1205,13 +1205,11 @@ def check_task_pipeline(tmp_dir):
     batches = task.get_batches(ds, max_tokens=400, max_sentences=4, seed=1, epoch=1)
     sample = task.to_device(ds.collater([ds[int(i)] for i in batches[0]]), DEV)
     loss, sample_size, log = task.train_step(sample, model, crit)
-    # independent value: torch cross entropy on the model's own logits
-    model.eval()
+    # independent value: torch cross entropy on the model's own logits (same mode: the sub-sampler's BatchNorm uses batch statistics)
     with torch.no_grad():
         s2 = task.prepare_sample(sample, train=False)
         logits, _ = model(**s2["net_input"])
         ref = TF.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), s2["target"].reshape(-1), ignore_index=d.pad(), reduction="sum")
-        model.train()
         lt, _, _ = crit(model, s2)
     grads_finite = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
     task.build_validation_decoder(model)
@@ -1232,6 +1230,7 @@ def check_task_pipeline(tmp_dir):
     gens["transducer_beam"] = isinstance(task.build_generator([tmodel], type("A", (), {"beam": 4})()), TransducerBeamSearchDecoder)
     return {"loss_vs_torch": abs(float(lt) - float(ref)) / max(1.0, abs(float(ref))), "sample_size": sample_size,
             "ntokens": sample["ntokens"], "grads_finite": grads_finite, "word_count": sum(l["word_count"] for l in logs),
+            "char_count": sum(l["char_count"] for l in logs), "n_utts": len(utts),
             "n_words": n_words, "wer": red.get("wer"), "loss_metric": red.get("loss"), "gens": gens,
             "pinned": bool(ds.collater([ds[0]])["wav"].is_pinned())}
 

@@ -290,7 +290,8 @@ def test_task_pipeline_raw_audio_to_metrics(tmp_path):
     r = G.check_task_pipeline(str(tmp_path))
     assert r["loss_vs_torch"] < 2e-2, r
     assert r["sample_size"] == r["ntokens"] and r["grads_finite"], r
-    assert r["word_count"] == r["n_words"] and r["wer"] is not None and r["wer"] >= 0.0, r
+    # token-level ("char") counts see every target token; without a <space>/BPE symbol each utterance is one word
+    assert r["char_count"] == r["n_words"] and r["word_count"] == r["n_utts"] and r["wer"] is not None and r["wer"] >= 0.0, r
     assert r["loss_metric"] is not None and all(r["gens"].values()) and r["pinned"], r
 
 

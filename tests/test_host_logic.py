@@ -386,3 +386,28 @@ def test_characters_asr_and_tokenize_follow_reference_order():
     d.build_bpe("characters_asr")
     ids = d.encode_line(d.wordpiece_encode("AB C"))
     assert d.wordpiece_decode(d.string(ids)) == "AB C"
+
+
+def test_layer_runtime_rejects_short_arenas_before_launching():
+    """ea_conformer_layer_fwd/bwd size their arenas with the same dry pass as the workspace query and refuse (-5) a short
+    arena before any kernel is enqueued (no GPU needed to see the refusal)."""
+    import ctypes
+
+    from espresso_amd import _lib
+    from espresso_amd._lib import EaConformerLayer, EaLayerShape
+
+    lib = _lib.lib()
+    sh = EaLayerShape()
+    sh.B, sh.T, sh.C, sh.H, sh.F, sh.KW = 3, 50, 64, 4, 128, 31
+    sh.training, sh.p_drop, sh.p_act, sh.p_attn, sh.seed, sh.has_attn_mask = 1, 0.1, 0.1, 0.1, 7, 0
+    a, b = ctypes.c_long(0), ctypes.c_long(0)
+    assert lib.ea_conformer_layer_workspace(ctypes.byref(sh), ctypes.byref(a), ctypes.byref(b)) == 0
+    assert a.value > 0 and b.value > 0
+    L = EaConformerLayer()
+    null = ctypes.c_void_p(0)
+    assert lib.ea_conformer_layer_fwd(ctypes.byref(L), ctypes.byref(sh), null, null, null, null, null, null, a.value // 2, null,
+                                      b.value, null) == -5
+    assert lib.ea_conformer_layer_bwd(ctypes.byref(L), ctypes.byref(sh), null, null, null, null, null, null, a.value, null, 1024,
+                                      null) == -5
+    sh.T = 5000  # beyond the runtime's limit: shape error, not a crash
+    assert lib.ea_conformer_layer_workspace(ctypes.byref(sh), ctypes.byref(a), ctypes.byref(b)) == -2
