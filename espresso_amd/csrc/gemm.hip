@@ -234,16 +234,28 @@ __device__ __forceinline__ void store8_bf16(bf16_t* q, bool vec, int cnt, const 
   }
 }
 
+// bias of the 8 output columns a thread owns (the same columns in every pass of the epilogue): loaded once, 2 x 16 bytes
+__device__ __forceinline__ void load_bias8(const EaGemmParams& p, int n, float (&b)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = 0.f;
+  if (!p.bias || n >= p.N) return;
+  if (n + 8 <= p.N && (((uintptr_t)p.bias) & 15) == 0) {
+    const float4 x0 = *reinterpret_cast<const float4*>(p.bias + n);
+    const float4 x1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    b[0] = x0.x; b[1] = x0.y; b[2] = x0.z; b[3] = x0.w; b[4] = x1.x; b[5] = x1.y; b[6] = x1.z; b[7] = x1.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (n + e < p.N) b[e] = p.bias[n + e];
+  }
+}
+
 __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int ks_id, int zhi, int zlo, long coff, int m,
-                                               int n, float (&v)[8], bool vec_ok) {
+                                               int n, float (&v)[8], const float (&bias8)[8], bool vec_ok) {
   const int cnt = min(8, p.N - n);
   const bool vec = vec_ok && cnt == 8;
   const bool has_drop = p.drop_thr != 0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    v[e] *= p.alpha;
-    if (p.bias && e < cnt) v[e] += p.bias[n + e];
-  }
+  for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias8[e];
   const uint64_t didx = ((uint64_t)z * (uint64_t)p.M + (uint64_t)m) * (uint64_t)p.N + (uint64_t)n;
   const long co = coff + (long)m * p.ldc + n;
   if (p.splitk > 1) {  // split-K partial slab [ks][batch][M][N] fp32 (dense, ld = N); combined by splitk_reduce_kernel
@@ -290,8 +302,13 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
     const long ro = (long)zhi * p.sR_hi + (long)zlo * p.sR_lo + (long)m * p.ldr + n;
     if (p.resid_f32) {
       const float* r = reinterpret_cast<const float*>(p.resid) + ro;
+      if (cnt == 8 && ((((uintptr_t)r) & 15) == 0)) {
+        const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) if (e < cnt) v[e] += r[e];
+        for (int e = 0; e < 8; ++e) if (e < cnt) v[e] += r[e];
+      }
     } else {
       float rr[8];
       load8_bf16(reinterpret_cast<const bf16_t*>(p.resid) + ro,
@@ -302,7 +319,11 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
   }
   if (p.c_f32) {
     float* C = reinterpret_cast<float*>(p.C) + co;
-    if (vec_ok && cnt == 8 && !p.accumulate && (p.ldc & 3) == 0 && ((((uintptr_t)C) & 15) == 0)) {
+    if (cnt == 8 && ((((uintptr_t)C) & 15) == 0)) {
+      if (p.accumulate) {
+        const float4 c0 = *reinterpret_cast<const float4*>(C), c1 = *reinterpret_cast<const float4*>(C + 4);
+        v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+      }
       *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
@@ -368,7 +389,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
   const bf16_t* a_base = A_KS ? A + (long)(a_kq * 4) * p.lda + m0 + a_rc * 8 : A + (long)(m0 + (tid >> 3)) * p.lda + (tid & 7) * 8;
   const bf16_t* b_base = B_KS ? B + (long)((tid >> 4) * 4) * p.ldb + n0 + (tid & 15) * 8
                               : B + (long)(n0 + (tid >> 3)) * p.ldb + (tid & 7) * 8;
-  auto loadA = [&](int k0) {
+  auto loadA = [&](int k0, uint4 (&ra)[4]) {
     if (A_KS) {
       if (!a_ks_active) return;
       if (a_ok && k0 + BK <= kend) load_ks_fast(a_base, p.lda, k0, ra);
@@ -382,11 +403,11 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
       }
     }
   };
-  auto loadB = [&](int k0) {
+  auto loadB = [&](int k0, uint4 (&rb)[4]) {
     if (b_ok && k0 + BK <= kend) { if (B_KS) load_ks_fast(b_base, p.ldb, k0, rb); else load_kc_fast(b_base, p.ldb, k0, rb); }
     else { if (B_KS) load_ks(B, p.ldb, p.N, kend, n0, k0, tid, rb); else load_kc(B, p.ldb, p.N, kend, n0, k0, tid, rb); }
   };
-  auto storeA = [&]() {
+  auto storeA = [&](const uint4 (&ra)[4]) {
     if (A_KS) {
       if (a_ks_active) store_ks_at(sA, a_rc * 8, a_kq * 4, ra);
     } else {
@@ -395,8 +416,8 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
     }
   };
   if (nk > 0) {
-    loadA(kbeg);
-    loadB(kbeg);
+    loadA(kbeg, ra);
+    loadB(kbeg, rb);
   }
   uint32_t a_off[2][4], b_off[2][NJ];
 #pragma unroll
@@ -407,12 +428,8 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
     for (int j = 0; j < NJ; ++j) b_off[ks][j] = lds_off(wcol + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
   }
 
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    storeA();
-    if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb);
-    __syncthreads();
-    if (kt + 1 < nk) { loadA(kbeg + (kt + 1) * BK); loadB(kbeg + (kt + 1) * BK); }
+  auto storeB = [&](const uint4 (&rb)[4]) { if (B_KS) store_ks(sB, tid, rb); else store_kc(sB, tid, rb); };
+  auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t af[4], bfr[NJ];
@@ -428,12 +445,22 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]), acc[i][j], 0, 0, 0);
     }
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    storeA(ra);
+    storeB(rb);
+    __syncthreads();
+    if (kt + 1 < nk) { loadA(kbeg + (kt + 1) * BK, ra); loadB(kbeg + (kt + 1) * BK, rb); }
+    compute();
   }
 
   // ---- epilogue: accumulators -> fp32 LDS tile (64 rows at a time) -> coalesced 16/32-byte stores ----
   // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wcol + j*16 + (lane&15)]
   float* sC = reinterpret_cast<float*>(smem);  // [64][128] fp32 = 32 KiB
   const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
+  float bias8[8];
+  load_bias8(p, n0 + (tid & 15) * 8, bias8);
 #pragma unroll
   for (int half = 0; half < BM_ / 64; ++half) {
     __syncthreads();
@@ -458,7 +485,159 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, vec_ok);
+          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok);
+        }
+      }
+    }
+  }
+}
+
+// ---- direct-to-LDS variant (both operands k-contiguous) ------------------------------------------------------------
+// Same tiles, fragment layout, swizzle and epilogue as gemm_bf16_kernel, but the operand tiles go global -> LDS with
+// `global_load_lds_dwordx4` (no staging registers, no ds_write pass) into a ring of NST stages, with NST-1 k-tiles in
+// flight and ONE raw barrier per k-tile.  A wave instruction moves 64 x 16 B = 8 LDS rows: lane l lands at row l>>3,
+// 16-byte slot l&7, so the XOR swizzle is applied to the SOURCE address (lane fetches chunk slot ^ (r&7) ^ ((r>>4)&7)).
+// Rows past M / N are clamped to the last valid row (their outputs are never stored).  Requires K % 64 == 0, leading
+// dimensions % 8 == 0 and 16-byte aligned bases (checked on the host; other launches use gemm_bf16_kernel).
+template <int BM_, int NST>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p, const int xcd_swizzle) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];  // the ONLY LDS object (ring, then the fp32 C tile)
+  constexpr int NJ = BM_ == 128 ? 4 : 2;
+  constexpr int A_BYTES = BM_ * ROW_BYTES;
+  constexpr int STAGE = A_BYTES + BN * ROW_BYTES;
+  constexpr int NA = BM_ / 32, NB = BN / 32;  // glds instructions per wave and k-tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = BM_ == 128 ? (wave >> 1) : 0;
+  const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
+  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  if (xcd_swizzle) {
+    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gx + blockIdx.x;
+    const int xcd = lin & 7, q = total >> 3, r = total & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    tile_y = v / gx;
+    tile_x = v - tile_y * gx;
+  }
+  const int m0 = tile_y * BM_, n0 = tile_x * BN;
+  const int z = blockIdx.z / p.splitk;
+  const int ks_id = blockIdx.z % p.splitk;
+  const int zhi = z / p.zdiv, zlo = z % p.zdiv;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)zhi * p.sA_hi + (long)zlo * p.sA_lo;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long)zhi * p.sB_hi + (long)zlo * p.sB_lo;
+  const long coff = (long)zhi * p.sC_hi + (long)zlo * p.sC_lo;
+  const int kbeg = ks_id * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg) / BK : 0;
+
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane source pointers (advance along k only)
+  const bf16_t* ap[NA];
+  const bf16_t* bp[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = (wave + 4 * i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7) ^ ((r >> 4) & 7);
+    ap[i] = A + (long)min(m0 + r, p.M - 1) * p.lda + kbeg + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (wave + 4 * i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7) ^ ((r >> 4) & 7);
+    bp[i] = B + (long)min(n0 + r, p.N - 1) * p.ldb + kbeg + c * 8;
+  }
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue = [&](int stage, int kt) {
+    char* base = dsm + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + (long)kt * BK), (lptr_t)(base + i * 4096), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + (long)kt * BK), (lptr_t)(base + A_BYTES + i * 4096), 16, 0, 0);
+  };
+  uint32_t a_off[2][4], b_off[2][NJ];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[ks][i] = lds_off(wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b_off[ks][j] = A_BYTES + lds_off(wcol + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+  }
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue(s, s);
+  int stage = 0, fill = NST - 1;  // stage holding tile kt ; stage that tile kt+NST-1 goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most NST-2 younger tiles (NA+NB instructions each) are still outstanding
+    if (kt + NST - 2 < nk) {
+      if (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if ((NST - 2) * (NA + NB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if ((NST - 2) * (NA + NB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if ((NST - 2) * (NA + NB) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if ((NST - 2) * (NA + NB) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's part of tile kt is in LDS; everyone is done reading tile kt-1's stage
+    if (kt + NST - 1 < nk) issue(fill, kt + NST - 1);
+    const char* st = dsm + stage * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(st + a_off[ks][i]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(st + b_off[ks][j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]), acc[i][j], 0, 0, 0);
+    }
+    stage = stage + 1 == NST ? 0 : stage + 1;
+    fill = fill + 1 == NST ? 0 : fill + 1;
+  }
+
+  float* sC = reinterpret_cast<float*>(dsm);  // [64][128] fp32 = 32 KiB
+  const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
+  float bias8[8];
+  load_bias8(p, n0 + (tid & 15) * 8, bias8);
+#pragma unroll
+  for (int half = 0; half < BM_ / 64; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (m0 + half * 64 < p.M) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int rl = pass * 16 + (tid >> 4);
+        const int m = m0 + half * 64 + rl;
+        const int n = n0 + (tid & 15) * 8;
+        if (m < p.M && n < p.N) {
+          float v[8];
+          const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
+          const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok);
         }
       }
     }
@@ -544,7 +723,7 @@ extern "C" long ea_gemm_profile_dump(const char* path) {
   return (long)g_prof.size();
 }
 
-static int g_xcd_swizzle = 0;  // measured: the default round-robin tile order is faster on every hot-path shape (and 4096^3: 736 vs 531 TFLOP/s)
+static int g_xcd_swizzle = 1;  // applies to the direct-to-LDS kernel only, gated on the grid shape (see launch site)
 extern "C" int ea_set_gemm_xcd_swizzle(int on) {
   const int old = g_xcd_swizzle;
   g_xcd_swizzle = on != 0;
@@ -557,11 +736,31 @@ extern "C" int ea_set_gemm_variant(int v) {
   return old;
 }
 
+static int g_gemm_glds = 2;  // direct-to-LDS ring kernel for launches with both operands k-contiguous (0 off, N = stages); measured best: 2
+extern "C" int ea_set_gemm_glds(int stages) {
+  const int old = g_gemm_glds;
+  g_gemm_glds = stages;
+  return old;
+}
+template <int BM_, int NST>
+static bool launch_glds(dim3 grid, hipStream_t stream, const EaGemmParams& q, int sw) {
+  constexpr int bytes = NST * (BM_ + BN) * ROW_BYTES;
+  static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM_, NST>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!attr_ok) return false;
+  hipLaunchKernelGGL((gemm_glds_kernel<BM_, NST>), grid, dim3(256), bytes, stream, q, sw);
+  return true;
+}
+static bool glds_eligible(const EaGemmParams& q) {
+  return !q.a_kstrided && !q.b_kstrided && q.K % BK == 0 && q.kchunk % BK == 0 && (q.lda & 7) == 0 && (q.ldb & 7) == 0 &&
+         ((q.sA_hi | q.sA_lo | q.sB_hi | q.sB_lo) & 7) == 0 && ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) == 0;
+}
+
 template <bool A_KS, bool B_KS>
 static void launch_gemm(dim3 grid, bool bm64, hipStream_t stream, const EaGemmParams& q) {
   // the remap helps when several n-tiles share a row block and the grid spans many row blocks (not for batched / split launches,
   // whose z index already separates the operands)
-  const int sw = (g_xcd_swizzle && grid.z == 1 && grid.x > 1 && grid.y >= 16) ? 1 : 0;
+  const int sw = 0;  // register-staged kernel: the default round-robin order measured faster on every shape
   if (bm64) hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 64>), grid, dim3(256), 0, stream, q, sw);
   else hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 128>), grid, dim3(256), 0, stream, q, sw);
 }
@@ -602,7 +801,17 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
              (q.drop_thr ? 32 : 0) | (q.c_f32 ? 64 : 0);
     hipEventRecord(pr.e0, stream);
   }
-  if (p.a_kstrided) {
+  bool done = false;
+  if (g_gemm_glds && glds_eligible(q)) {
+    // XCD-aware tile order when the whole B operand fits every XCD's L2 next to the streamed A rows (few n-tiles): measured
+    // L2 hit rate 58 -> 82 % and -10..-20 % time on the N = 512 projections; slower for square problems (B no longer stationary)
+    const int sw = (g_xcd_swizzle && grid.z == 1 && grid.x > 1 && grid.x <= 16 && grid.y >= 16) ? 1 : 0;
+    if (g_gemm_glds == 2) done = bm64 ? launch_glds<64, 2>(grid, stream, q, sw) : launch_glds<128, 2>(grid, stream, q, sw);
+    else if (g_gemm_glds == 4) done = bm64 ? launch_glds<64, 4>(grid, stream, q, sw) : launch_glds<128, 4>(grid, stream, q, sw);
+    else done = bm64 ? launch_glds<64, 3>(grid, stream, q, sw) : launch_glds<128, 3>(grid, stream, q, sw);
+  }
+  if (done) {
+  } else if (p.a_kstrided) {
     if (p.b_kstrided) launch_gemm<true, true>(grid, bm64, stream, q); else launch_gemm<true, false>(grid, bm64, stream, q);
   } else {
     if (p.b_kstrided) launch_gemm<false, true>(grid, bm64, stream, q); else launch_gemm<false, false>(grid, bm64, stream, q);

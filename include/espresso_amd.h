@@ -81,6 +81,8 @@ int ea_set_gemm_variant(int v);
  * pair per launch on the launch stream; read() synchronises and returns launches, summed ms and flops. */
 /* tuning hook: XCD-aware workgroup -> tile mapping (default OFF: measured slower than round-robin); returns the previous value */
 int ea_set_gemm_xcd_swizzle(int on);
+/* tuning hook: direct-to-LDS ring kernel for launches whose operands are both k-contiguous (0 = off, else ring stages 2..4) */
+int ea_set_gemm_glds(int stages);
 int ea_gemm_profile_enable(int on);
 long ea_gemm_profile_read(double* total_ms, double* total_flops);
 /* writes one line per recorded launch ("M N K batch a_ks b_ks splitk bm64 epilogue-bits ms"); returns the count or -1 */

@@ -39,6 +39,25 @@ def test_gemm_splitk():
     assert G.check_gemm(128, 128, 640, False, False, c_f32=True, splitk=64) < 2e-3
 
 
+@pytest.mark.parametrize("stages", [0, 2, 3, 4])   # 0 = register-staged kernel for the same launches
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_direct_to_lds_ring(stages, variant):
+    """k-contiguous launches go through the global_load_lds ring kernel (K % 64 == 0, aligned rows); ragged M / N edges are
+    clamped rows, split-K and the fused epilogues share the code of the register-staged kernel."""
+    from espresso_amd import _lib
+
+    old = _lib.lib().ea_set_gemm_glds(stages)
+    try:
+        for (M, N, K) in ((200, 130, 64), (333, 257, 128), (129, 64, 1024), (1000, 96, 448), (5, 520, 192), (6128, 512, 2048)):
+            assert G.check_gemm(M, N, K, False, False, variant=variant) < 1e-2, (M, N, K)
+            assert G.check_gemm(M, N, K, False, False, bias=True, act="silu", resid=True, variant=variant) < 1e-2, (M, N, K)
+            if K >= 192:
+                assert G.check_gemm(M, N, K, False, False, c_f32=True, splitk=3, variant=variant) < 2e-3, (M, N, K)
+        assert G.check_gemm(300, 200, 128, False, False, batch=3, variant=variant) < 1e-2
+    finally:
+        _lib.lib().ea_set_gemm_glds(old)
+
+
 def test_ctc_fp32():
     r = G.check_ctc()
     assert r["lprobs_abs"] < 1e-4, r
