@@ -27,7 +27,7 @@ template <int KW>
 __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16_t* __restrict__ Y,
                                                              const float* __restrict__ w,  // [C][KW]
                                                              bf16_t* __restrict__ U, bf16_t* __restrict__ Z,
-                                                             float* __restrict__ stats, int T, int C) {
+                                                             double* __restrict__ stats, int T, int C) {
   constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1;
   __shared__ float su[ROWS][CT];
   __shared__ float sred[2][4][CT];
@@ -87,20 +87,21 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16_t* __res
     __syncthreads();
     if (threadIdx.x < CT && c0 + threadIdx.x < C) {
       const int x = threadIdx.x;
-      atomicAdd(stats + c0 + x, sred[0][0][x] + sred[0][1][x] + sred[0][2][x] + sred[0][3][x]);
-      atomicAdd(stats + C + c0 + x, sred[1][0][x] + sred[1][1][x] + sred[1][2][x] + sred[1][3][x]);
+      // fp64 accumulators: the order of the atomics no longer shows in the fp32 statistics (run-to-run reproducible)
+      atomicAdd(stats + c0 + x, (double)(sred[0][0][x] + sred[0][1][x] + sred[0][2][x] + sred[0][3][x]));
+      atomicAdd(stats + C + c0 + x, (double)(sred[1][0][x] + sred[1][1][x] + sred[1][2][x] + sred[1][3][x]));
     }
   }
 }
 
 // stats (sum,sumsq over n rows) -> mean/rstd ; running stats update (momentum, unbiased var)
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, float* __restrict__ mean_rstd,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mean_rstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    int C, float n, float eps, float momentum) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float mean = stats[c] / n;
-  float var = stats[C + c] / n - mean * mean;
+  const float mean = (float)(stats[c] / (double)n);
+  float var = (float)(stats[C + c] / (double)n - (stats[c] / (double)n) * (stats[c] / (double)n));
   var = fmaxf(var, 0.f);
   mean_rstd[c] = mean;
   mean_rstd[C + c] = rsqrtf(var + eps);
@@ -403,7 +404,7 @@ static inline int egrid_ch(long n, int nch) {
 
 template <int KW>
 static void launch_glu_dwconv_fwd(dim3 grid, hipStream_t stream, const bf16_t* Y, const float* w, bf16_t* U, bf16_t* Z,
-                                  float* stats, int T, int C) {
+                                  double* stats, int T, int C) {
   hipLaunchKernelGGL((glu_dwconv_fwd_kernel<KW>), grid, dim3(256), 0, stream, Y, w, U, Z, stats, T, C);
 }
 template <int KW>
@@ -417,7 +418,7 @@ static void launch_dwconv_bwd_weight(dim3 grid, hipStream_t stream, const bf16_t
   hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KW>), grid, dim3(256), 0, stream, dZ, U, dw, T, C, tiles_per_block);
 }
 
-extern "C" int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z, float* stats, int B, int T,
+extern "C" int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z, double* stats, int B, int T,
                                  int C, int KW, hipStream_t stream) {
   if (B <= 0 || T <= 0) return 0;
   if (C % 2) return -2;
@@ -426,7 +427,7 @@ extern "C" int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z
   return EA_CHECK_LAUNCH();
 }
 
-extern "C" int ea_bn_finalize(const float* stats, float* mean_rstd, float* running_mean, float* running_var, int C,
+extern "C" int ea_bn_finalize(const double* stats, float* mean_rstd, float* running_mean, float* running_var, int C,
                               float n, float eps, float momentum, hipStream_t stream) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, stats, mean_rstd, running_mean,
                      running_var, C, n, eps, momentum);

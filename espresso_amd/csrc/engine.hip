@@ -402,10 +402,10 @@ static void conv_fwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, s.xn, s.mean, s.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   G g1(s.xn, w.pw1, s.Y, M, 2 * C, C, C, C, 2 * C);
   gemm(c, g1);
-  float* stats = nullptr;
+  double* stats = nullptr;  // BatchNorm batch statistics: fp64 (sum, sum of squares) accumulators
   if (sh.training) {
-    stats = sc.get<float>(2 * C);
-    if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(stats, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
+    stats = sc.get<double>(2 * C);
+    if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(stats, 0, 2 * C * sizeof(double), c.s) == hipSuccess ? 0 : -1;
   }
   RUN(ea_glu_dwconv_fwd(s.Y, w.dw, s.U, s.Z, stats, B, T, C, sh.KW, c.s));
   if (sh.training) RUN(ea_bn_finalize(stats, s.mr, w.bn_rm, w.bn_rv, C, (float)M, 1e-5f, 0.1f, c.s));

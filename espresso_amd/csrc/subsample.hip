@@ -16,7 +16,7 @@ namespace {
 // block: 256 threads = 8 positions x 32 channel pairs (CO == 64)
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W /*[CO][3][3]*/,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ Z,
-                                                        float* __restrict__ stats, int T, int F, int To, int Fo, int CO,
+                                                        double* __restrict__ stats, int T, int F, int To, int Fo, int CO,
                                                         int sy, int sx, long npos, int pos_per_block) {
   __shared__ float red[8][4][64];
   const int pl = threadIdx.x >> 5, cp = threadIdx.x & 31;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < 8; ++i) a += red[i][which][c];
         const int cc = (c0 - cp * 2) + c;
-        if (cc < CO) atomicAdd(stats + which * CO + cc, a);
+        if (cc < CO) atomicAdd(stats + which * CO + cc, (double)a);
       }
       __syncthreads();
       s[0] = s[1] = q[0] = q[1] = 0.f;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const bf16_t* __restrict__ 
 }
 
 // stats[0..C) += sum_m X[m][c], stats[C..2C) += sum_m X[m][c]^2   (X bf16 [M][C])
-__global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* __restrict__ X, float* __restrict__ stats, long M, int C,
+__global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* __restrict__ X, double* __restrict__ stats, long M, int C,
                                                        int rows_per_block) {
   __shared__ float sm[8][2][64];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) a += sm[i][which][c];
     const int cc = blockIdx.x * 64 + c;
-    if (cc < C) atomicAdd(stats + which * C + cc, a);
+    if (cc < C) atomicAdd(stats + which * C + cc, (double)a);
   }
 }
 
@@ -221,7 +221,7 @@ static inline int egrid(long n) {
 
 }  // namespace
 
-extern "C" int ea_conv1_fwd(const float* X, const float* W, const float* bias, void* Z, float* stats, int B, int T, int F,
+extern "C" int ea_conv1_fwd(const float* X, const float* W, const float* bias, void* Z, double* stats, int B, int T, int F,
                             int CO, int sy, int sx, hipStream_t stream) {
   if (B <= 0 || T <= 0) return 0;
   if (CO % 64) return -2;
@@ -261,7 +261,7 @@ extern "C" int ea_col2im3x3(const void* dcol, void* dA, int B, int T, int F, int
                      To, Fo, sy, sx, total);
   return EA_CHECK_LAUNCH();
 }
-extern "C" int ea_colstats_bf16(const void* X, float* stats, long M, int C, hipStream_t stream) {
+extern "C" int ea_colstats_bf16(const void* X, double* stats, long M, int C, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 2) return -2;
   int rpb = (int)((M + 1023) / 1024);

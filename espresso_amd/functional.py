@@ -343,7 +343,7 @@ class _ConvModule(torch.autograd.Function):
         Y = _new((M, 2 * C), torch.bfloat16, x)
         K.gemm(xn, wpw1_16, Y, M, 2 * C, C, lda=C, ldb=C, ldc=2 * C)
         wdw2 = wdw.detach().reshape(C, KW).contiguous()
-        stats = _zeros_f32(2 * C, x) if training else None
+        stats = torch.zeros(2 * C, dtype=torch.float64, device=x.device) if training else None
         U, Zt = K.glu_dwconv_fwd(Y, wdw2, B, T, C, KW, stats)
         if training:
             mr = K.bn_finalize(stats, C, M, bn_eps, bn_momentum, running_mean, running_var)
@@ -485,7 +485,7 @@ class _ConvSubsample(torch.autograd.Function):
             sy, sx = strides[i]
             Co = w.shape[0]
             To, Fo = (Tc - 1) // sy + 1, (Fc - 1) // sx + 1
-            stats = _zeros_f32(2 * Co, X) if training else None
+            stats = torch.zeros(2 * Co, dtype=torch.float64, device=X.device) if training else None
             if i == 0:
                 assert w.shape[1] == 1 and tuple(w.shape[2:]) == (3, 3)
                 Zi = K.conv1_fwd(X, w.detach().reshape(Co, 9).contiguous(), b, B, Tc, Fc, Co, sy, sx, stats)

@@ -173,11 +173,12 @@ int ea_add2_strided_bf16(const void* a, long lda, const void* b, long ldb, void*
  * Conformer convolution module middle — fairseq/modules/conformer_layer.py:79-101:
  * GLU -> depthwise Conv1d (k in {3,7,15,31}, pad (k-1)/2, no bias) -> BatchNorm1d -> SiLU.
  * Y: bf16 [B*T][2C] (pointwise_conv1 output); U,Z,H: bf16 [B*T][C]; w: fp32 [C][KW];
- * stats/red: fp32 [2][C] zeroed by the caller; mean_rstd: fp32 [2][C].
+ * stats: fp64 [2][C] (sum, sum of squares) zeroed by the caller — double accumulators make the atomics' order invisible
+ * in the fp32 statistics (reproducible forward); red: fp32 [2][C] zeroed by the caller; mean_rstd: fp32 [2][C].
  * ea_bn_act_* are also used for BatchNorm2d+ReLU of the sub-sampler (act = EA_ACT_RELU). */
-int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z, float* stats, int B, int T, int C, int KW,
+int ea_glu_dwconv_fwd(const void* Y, const float* w, void* U, void* Z, double* stats, int B, int T, int C, int KW,
                       ea_stream_t stream);
-int ea_bn_finalize(const float* stats, float* mean_rstd, float* running_mean, float* running_var, int C, float n,
+int ea_bn_finalize(const double* stats, float* mean_rstd, float* running_mean, float* running_var, int C, float n,
                    float eps, float momentum, ea_stream_t stream);
 int ea_bn_from_running(const float* running_mean, const float* running_var, float* mean_rstd, int C, float eps,
                        ea_stream_t stream);
@@ -195,13 +196,13 @@ int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float*
  * Conv2d sub-sampler — espresso/modules/speech_convolutions.py:78-102.  Channels-last bf16
  * activations [B][T][F][C]; first conv (C_in=1) direct from fp32 features [B][T][F]; later convs
  * via im2col (k = (ky*3+kx)*C + c) + ea_gemm_bf16.  Output sizes: To=(T-1)/sy+1, Fo=(F-1)/sx+1. */
-int ea_conv1_fwd(const float* X, const float* W, const float* bias, void* Z, float* stats, int B, int T, int F,
+int ea_conv1_fwd(const float* X, const float* W, const float* bias, void* Z, double* stats, int B, int T, int F,
                  int CO, int sy, int sx, ea_stream_t stream);
 int ea_conv1_wgrad(const float* X, const void* dZ, float* dW, float* dbias, int B, int T, int F, int CO, int sy,
                    int sx, ea_stream_t stream);
 int ea_im2col3x3(const void* A, void* col, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
 int ea_col2im3x3(const void* dcol, void* dA, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
-int ea_colstats_bf16(const void* X, float* stats, long M, int C, ea_stream_t stream);
+int ea_colstats_bf16(const void* X, double* stats, long M, int C, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses.
