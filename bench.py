@@ -145,10 +145,15 @@ def main():
     ap.add_argument("--n-utts", type=int, default=20000)
     ap.add_argument("--max-tokens", type=int, default=26000, help="diagnostic only: shrink the batches (host-overhead probes)")
     ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B switch: keep weight-gradient GEMMs on the main stream")
+    ap.add_argument("--gemm-xcd-mask", type=int, default=None, help="A/B switch: XCD-aware tile order (bit 0 glds kernel, bit 1 register-staged)")
     args = ap.parse_args()
     if args.no_bwd_overlap:
         from espresso_amd._lib import lib as _ealib
         _ealib().ea_set_backward_overlap(0)
+
+    if args.gemm_xcd_mask is not None:
+        from espresso_amd._lib import lib as _ealib2
+        _ealib2().ea_set_gemm_xcd_swizzle(args.gemm_xcd_mask)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -220,8 +225,15 @@ def main():
         lib.ea_gemm_profile_enable(0)
         tot_ms, tot_fl = ms.value, fl.value
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+        # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
+        # command, tools/pmc_bench_traffic.sh; counters cannot be read from inside the process)
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel+gemm_glds_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_gemm_traffic.json)",
                     "launches_per_step": n / nrep, "avg_launch_us": tot_ms * 1e3 / max(n, 1),
                     "gemm_ms_per_step": tot_ms / nrep, "gemm_flop_per_step": tot_fl / nrep}
 

@@ -348,21 +348,23 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = BM_ == 128 ? (wave >> 1) : 0;
   const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;  // first column of this wave's sub-tile
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest); remap the linear id
-  // so that consecutive tiles of one XCD walk the n-tiles of the SAME row block: its A rows are filled into one L2 instead
-  // of eight (every XCD needs the whole weight matrix B anyway).
-  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  int tile_x = blockIdx.x, tile_y = blockIdx.y, tile_z = blockIdx.z;
   if (xcd_swizzle) {
-    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
-    const int lin = blockIdx.y * gx + blockIdx.x;
+    // workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest, then y, z); give every XCD one contiguous
+    // range of the (z, y, x) tile order instead: the n-tiles of a row block and the row blocks of a batch item / k-chunk
+    // then share their operand rows in ONE L2 (bijective for any grid size)
+    const int gx = gridDim.x, gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
     const int xcd = lin & 7, q = total >> 3, r = total & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-    tile_y = v / gx;
-    tile_x = v - tile_y * gx;
+    tile_z = v / gxy;
+    const int rem = v - tile_z * gxy;
+    tile_y = rem / gx;
+    tile_x = rem - tile_y * gx;
   }
   const int m0 = tile_y * BM_, n0 = tile_x * BN;
-  const int z = blockIdx.z / p.splitk;
-  const int ks_id = blockIdx.z % p.splitk;
+  const int z = tile_z / p.splitk;
+  const int ks_id = tile_z % p.splitk;
   const int zhi = z / p.zdiv, zlo = z % p.zdiv;
 
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)zhi * p.sA_hi + (long)zlo * p.sA_lo;
@@ -510,18 +512,23 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = BM_ == 128 ? (wave >> 1) : 0;
   const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
-  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  int tile_x = blockIdx.x, tile_y = blockIdx.y, tile_z = blockIdx.z;
   if (xcd_swizzle) {
-    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
-    const int lin = blockIdx.y * gx + blockIdx.x;
+    // workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest, then y, z); give every XCD one contiguous
+    // range of the (z, y, x) tile order instead: the n-tiles of a row block and the row blocks of a batch item / k-chunk
+    // then share their operand rows in ONE L2 (bijective for any grid size)
+    const int gx = gridDim.x, gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
     const int xcd = lin & 7, q = total >> 3, r = total & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-    tile_y = v / gx;
-    tile_x = v - tile_y * gx;
+    tile_z = v / gxy;
+    const int rem = v - tile_z * gxy;
+    tile_y = rem / gx;
+    tile_x = rem - tile_y * gx;
   }
   const int m0 = tile_y * BM_, n0 = tile_x * BN;
-  const int z = blockIdx.z / p.splitk;
-  const int ks_id = blockIdx.z % p.splitk;
+  const int z = tile_z / p.splitk;
+  const int ks_id = tile_z % p.splitk;
   const int zhi = z / p.zdiv, zlo = z % p.zdiv;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)zhi * p.sA_hi + (long)zlo * p.sA_lo;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long)zhi * p.sB_hi + (long)zlo * p.sB_lo;
@@ -723,10 +730,10 @@ extern "C" long ea_gemm_profile_dump(const char* path) {
   return (long)g_prof.size();
 }
 
-static int g_xcd_swizzle = 1;  // applies to the direct-to-LDS kernel only, gated on the grid shape (see launch site)
-extern "C" int ea_set_gemm_xcd_swizzle(int on) {
+static int g_xcd_swizzle = 3;  // bit 0: direct-to-LDS kernel, bit 1: register-staged kernel; gated on the grid shape at the launch sites
+extern "C" int ea_set_gemm_xcd_swizzle(int mask) {
   const int old = g_xcd_swizzle;
-  g_xcd_swizzle = on != 0;
+  g_xcd_swizzle = mask;
   return old;
 }
 static int g_gemm_variant = 0;  // 0: automatic tile height, 1: always 128-row tiles, 2: always 64-row tiles
@@ -760,7 +767,7 @@ template <bool A_KS, bool B_KS>
 static void launch_gemm(dim3 grid, bool bm64, hipStream_t stream, const EaGemmParams& q) {
   // the remap helps when several n-tiles share a row block and the grid spans many row blocks (not for batched / split launches,
   // whose z index already separates the operands)
-  const int sw = 0;  // register-staged kernel: the default round-robin order measured faster on every shape
+  const int sw = (g_xcd_swizzle & 2) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 ? 1 : 0;
   if (bm64) hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 64>), grid, dim3(256), 0, stream, q, sw);
   else hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 128>), grid, dim3(256), 0, stream, q, sw);
 }
@@ -805,7 +812,7 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   if (g_gemm_glds && glds_eligible(q)) {
     // XCD-aware tile order when the whole B operand fits every XCD's L2 next to the streamed A rows (few n-tiles): measured
     // L2 hit rate 58 -> 82 % and -10..-20 % time on the N = 512 projections; slower for square problems (B no longer stationary)
-    const int sw = (g_xcd_swizzle && grid.z == 1 && grid.x > 1 && grid.x <= 16 && grid.y >= 16) ? 1 : 0;
+    const int sw = ((g_xcd_swizzle & 1) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 && (grid.x > 1 || grid.z > 1)) ? 1 : 0;
     if (g_gemm_glds == 2) done = bm64 ? launch_glds<64, 2>(grid, stream, q, sw) : launch_glds<128, 2>(grid, stream, q, sw);
     else if (g_gemm_glds == 4) done = bm64 ? launch_glds<64, 4>(grid, stream, q, sw) : launch_glds<128, 4>(grid, stream, q, sw);
     else done = bm64 ? launch_glds<64, 3>(grid, stream, q, sw) : launch_glds<128, 3>(grid, stream, q, sw);

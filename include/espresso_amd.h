@@ -79,8 +79,9 @@ long ea_gemm_splitk_workspace_bytes(int M, int N, int batch, int splitk);
 int ea_set_gemm_variant(int v);
 /* live profiling of ea_gemm_bf16 for roofline reports: enable(1) clears and starts recording one HIP-event
  * pair per launch on the launch stream; read() synchronises and returns launches, summed ms and flops. */
-/* tuning hook: XCD-aware workgroup -> tile mapping (default OFF: measured slower than round-robin); returns the previous value */
-int ea_set_gemm_xcd_swizzle(int on);
+/* tuning hook: XCD-aware workgroup -> tile mapping; mask bit 0 = direct-to-LDS kernel, bit 1 = register-staged kernel (both
+ * additionally gated on the grid shape); returns the previous mask */
+int ea_set_gemm_xcd_swizzle(int mask);
 /* tuning hook: direct-to-LDS ring kernel for launches whose operands are both k-contiguous (0 = off, else ring stages 2..4) */
 int ea_set_gemm_glds(int stages);
 int ea_gemm_profile_enable(int on);
