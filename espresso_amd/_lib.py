@@ -87,7 +87,7 @@ class EaLayerGrads(ctypes.Structure):
 
 class EaConformerLayer(ctypes.Structure):
     _fields_ = [("ffn1", EaFfnParams), ("attn", EaAttnParams), ("conv", EaConvParams), ("ffn2", EaFfnParams),
-                ("final_ln_g", ctypes.c_void_p), ("final_ln_b", ctypes.c_void_p), ("grads", EaLayerGrads)]
+                ("final_ln_g", ctypes.c_void_p), ("final_ln_b", ctypes.c_void_p), ("grads", EaLayerGrads), ("wt", ctypes.c_void_p)]
 
 
 class EaLayerShape(ctypes.Structure):

@@ -149,6 +149,54 @@ static inline int grid_for(long n, int per_thread) {
   return (int)b;
 }
 
+// Batched 2-D transposes of bf16 matrices (dst[c][r] = src[r][c]) through a 64x64 LDS tile: up to 8 matrices per launch.
+struct TransposeBatch {
+  const bf16_t* src[8];
+  bf16_t* dst[8];
+  int rows[8], cols[8], tile0[9];  // tile0[i] = first linear tile of matrix i ; tile0[n] = total
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const TransposeBatch tb) {
+  __shared__ bf16_t tile[64][66];
+  int mi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < tb.n && (int)blockIdx.x >= tb.tile0[i]) mi = i;
+  const int R = tb.rows[mi], Cc = tb.cols[mi];
+  const int tcols = (Cc + 63) / 64;
+  const int t = blockIdx.x - tb.tile0[mi];
+  const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
+  const bf16_t* __restrict__ src = tb.src[mi];
+  bf16_t* __restrict__ dst = tb.dst[mi];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < R && c0 + tx < Cc) tile[i][tx] = src[(long)(r0 + i) * Cc + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < Cc && r0 + tx < R) dst[(long)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+extern "C" int ea_transpose_bf16_batch(const void* const* src, void* const* dst, const int* rows, const int* cols, int n,
+                                       hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n > 8) return -2;
+  TransposeBatch tb;
+  int tot = 0;
+  for (int i = 0; i < 8; ++i) {
+    tb.src[i] = i < n ? (const bf16_t*)src[i] : nullptr;
+    tb.dst[i] = i < n ? (bf16_t*)dst[i] : nullptr;
+    tb.rows[i] = i < n ? rows[i] : 0;
+    tb.cols[i] = i < n ? cols[i] : 0;
+    tb.tile0[i] = tot;
+    if (i < n) tot += ((rows[i] + 63) / 64) * ((cols[i] + 63) / 64);
+  }
+  tb.tile0[8] = tot;
+  tb.n = n;
+  if (tot == 0) return 0;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(tot), dim3(256), 0, stream, tb);
+  return EA_CHECK_LAUNCH();
+}
+
 extern "C" int ea_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 8)), dim3(256), 0, stream, src, (bf16_t*)dst, n);

@@ -140,6 +140,45 @@ inline void bias_grad(Ctx& c, const void* X, float* out, int M, int N, long ld) 
 // ---------------------------------------------------------------------------------------------------------
 extern "C" {
 
+// k-contiguous (transposed) copies of the weights whose data-gradient GEMM has a 512-wide output and a long reduction:
+// layout of EaConformerLayer::wt, refreshed by every training forward (the weights only change in the optimizer step)
+struct WT {
+  const uint16_t *f1w1, *f2w1, *wqkv, *wo, *pw1, *pw2;
+};
+static WT wt_view(const EaConformerLayer* L, const EaLayerShape& sh) {
+  WT w{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!L->wt || !sh.training) return w;
+  const size_t C = sh.C, F = sh.F;
+  const uint16_t* p = (const uint16_t*)L->wt;
+  w.f1w1 = p; p += C * F;
+  w.f2w1 = p; p += C * F;
+  w.wqkv = p; p += 3 * C * C;
+  w.wo = p; p += C * C;
+  w.pw1 = p; p += 2 * C * C;
+  w.pw2 = p;
+  return w;
+}
+static void wt_refresh(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh) {
+  const WT w = wt_view(L, sh);
+  if (!w.f1w1) return;
+  const int C = sh.C, F = sh.F;
+  const void* src[6] = {L->ffn1.w1, L->ffn2.w1, L->attn.wqkv, L->attn.wo, L->conv.pw1, L->conv.pw2};
+  void* dst[6] = {(void*)w.f1w1, (void*)w.f2w1, (void*)w.wqkv, (void*)w.wo, (void*)w.pw1, (void*)w.pw2};
+  const int rows[6] = {F, F, 3 * C, C, 2 * C, C}, cols[6] = {C, C, C, C, C, C};
+  RUN(ea_transpose_bf16_batch(src, dst, rows, cols, 6, c.s));
+}
+// data gradient dx[M][N] = dy[M][K] W[K][N]: k-contiguous copy Wt[N][K] when available, else W read k-strided
+static inline void dgrad(Ctx& c, const void* dy, const void* W, const uint16_t* Wt, void* dx, int M, int N, int K) {
+  if (Wt) {
+    G g(dy, Wt, dx, M, N, K, K, K, N);
+    gemm(c, g);
+  } else {
+    G g(dy, W, dx, M, N, K, K, N, N);
+    g.bks();
+    gemm(c, g);
+  }
+}
+
 struct FfnSaved {
   float *mean, *rstd;
   uint16_t *xn, *z, *h;
@@ -170,7 +209,7 @@ static void ffn_fwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
 }
 
 static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaFfnParams& w, const EaFfnGrads& gw, const void* x,
-                    const void* dy, void* dx, uint64_t seed, float out_scale, int act) {
+                    const void* dy, void* dx, uint64_t seed, float out_scale, int act, const uint16_t* w1t) {
   const int M = sh.B * sh.T, C = sh.C, F = sh.F;
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
@@ -189,9 +228,7 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   wgrad(c, dz, F, xn, C, gw.w1, M, F, C);
   bias_grad(c, dz, gw.b1, M, F, F);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
-  G gx(dz, w.w1, dxn, M, C, F, F, C, C);
-  gx.bks();
-  gemm(c, gx);
+  dgrad(c, dz, w.w1, w1t, dxn, M, C, F);
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
   RUN(ea_layernorm_bwd(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
   release(c, mark);
@@ -284,7 +321,7 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
 // shared tail of the attention backward: pos_proj / bias / qkv weight gradients, dq = t1 + t2, dgrad to the block input, LN
 static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw,
                           const void* x, const void* dy, void* dx, const void* pe, uint16_t* dqkv, uint16_t* t1, uint16_t* t2,
-                          uint16_t* dBD) {
+                          uint16_t* dBD, const uint16_t* wqkvt) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad8(R);
   Arena& sc = *c.scratch;
   // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames
@@ -312,15 +349,14 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
   wgrad(c, dqkv, 3 * C, a.xn, C, gw.wqkv, M, 3 * C, C);
   bias_grad(c, dqkv, gw.bqkv, M, 3 * C, 3 * C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
-  G gx(dqkv, w.wqkv, dxn, M, C, 3 * C, 3 * C, C, C);
-  gx.bks();
-  gemm(c, gx);
+  dgrad(c, dqkv, w.wqkv, wqkvt, dxn, M, C, 3 * C);
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
   RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
 }
 
 static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
-                     const void* dy, void* dx, const int* key_len, const void* pe, uint64_t seed) {
+                     const void* dy, void* dx, const int* key_len, const void* pe, uint64_t seed, const uint16_t* wqkvt,
+                     const uint16_t* wot) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
   const float scaling = 1.0f / sqrtf((float)dh);
   Arena& sc = *c.scratch;
@@ -335,9 +371,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   wgrad(c, g, C, a.o, C, gw.wo, M, C, C);
   bias_grad(c, g, gw.bo, M, C, C);
   uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
-  G gdo(g, w.wo, dO, M, C, C, C, C, C);
-  gdo.bks();
-  gemm(c, gdo);
+  dgrad(c, g, w.wo, wot, dO, M, C, C);
   if (attn_fused(sh)) {
     uint16_t* dqkv = sc.get<uint16_t>((size_t)M * 3 * C);
     uint16_t* t1 = sc.get<uint16_t>((size_t)M * C);
@@ -347,7 +381,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     RUN(ea_flash_attention_bwd(a.qu, a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
                                Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 0, scaling, seed + 3, drop_thr(sh.p_attn),
                                drop_scale(sh.p_attn), c.s));
-    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD);
+    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt);
     release(c, mark);
     return;
   }
@@ -373,7 +407,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   G gt2(dBD, a.pp, t2, T, dh, R, Rp, C, C);
   gt2.bks().alpha(scaling).batch(Z, B, (long)B * T * Rp, (long)T * Rp, dh, 0, dh, (long)T * C);
   gemm(c, gt2);
-  attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD);
+  attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt);
   release(c, mark);
 }
 
@@ -418,7 +452,7 @@ static void conv_fwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
 }
 
 static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const EaConvParams& w, const EaConvGrads& gw, const void* x,
-                     const void* dy, void* dx, uint64_t seed) {
+                     const void* dy, void* dx, uint64_t seed, const uint16_t* pw1t, const uint16_t* pw2t) {
   const int B = sh.B, T = sh.T, C = sh.C, M = B * T;
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
@@ -431,9 +465,7 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   fork(c);
   wgrad(c, g, C, s.Hh, C, gw.pw2, M, C, C);
   uint16_t* dH = sc.get<uint16_t>((size_t)M * C);
-  G gh(g, w.pw2, dH, M, C, C, C, C, C);
-  gh.bks();
-  gemm(c, gh);
+  dgrad(c, g, w.pw2, pw2t, dH, M, C, C);
   float* red = sc.get<float>(2 * C);
   if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(red, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
   uint16_t* dZ = sc.get<uint16_t>((size_t)M * C);
@@ -444,9 +476,7 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   fork(c);
   wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
-  G gx(dY, w.pw1, dxn, M, C, 2 * C, 2 * C, C, C);
-  gx.bks();
-  gemm(c, gx);
+  dgrad(c, dY, w.pw1, pw1t, dxn, M, C, 2 * C);
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
   RUN(ea_layernorm_bwd(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
   release(c, mark);
@@ -486,6 +516,7 @@ static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   conv_fwd(c, S.cv, sh, L->conv, S.x2, S.x3, seed + 32);
   ffn_fwd(c, S.f2, sh, L->ffn2, S.x3, S.x4, seed + 48, 0.5f, EA_ACT_SILU);
   RUN(ea_layernorm_fwd(S.x4, L->final_ln_g, L->final_ln_b, x_out, S.fmean, S.frstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  wt_refresh(c, L, sh);  // weights are cache-warm here; the backward of this step reads the k-contiguous copies
   return c.rc;
 }
 
@@ -504,10 +535,11 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
   RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
                        1.f, nullptr, lnws, c.s));
-  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU);
-  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32);
-  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16);
-  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU);
+  const WT wt = wt_view(L, sh);
+  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU, wt.f2w1);
+  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32, wt.pw1, wt.pw2);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16, wt.wqkv, wt.wo);
+  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU, wt.f1w1);
   if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
 }

@@ -743,7 +743,10 @@ extern "C" int ea_set_gemm_variant(int v) {
   return old;
 }
 
-static int g_gemm_glds = 2;  // direct-to-LDS ring kernel for launches with both operands k-contiguous (0 off, N = stages); measured best: 2
+// direct-to-LDS ring kernel for launches with both operands k-contiguous: 0 off, 1 automatic ring depth (3 stages when at most
+// two workgroups land on a CU — long-K, few-tile launches such as the N = 512 projections, where a deeper ring replaces the
+// latency hiding of co-resident workgroups: 41 -> 33 us in the 12-layer FFN chain — else 2), 2..4 forced depth
+static int g_gemm_glds = 1;
 extern "C" int ea_set_gemm_glds(int stages) {
   const int old = g_gemm_glds;
   g_gemm_glds = stages;
@@ -813,8 +816,17 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     // XCD-aware tile order when the whole B operand fits every XCD's L2 next to the streamed A rows (few n-tiles): measured
     // L2 hit rate 58 -> 82 % and -10..-20 % time on the N = 512 projections; slower for square problems (B no longer stationary)
     const int sw = ((g_xcd_swizzle & 1) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 && (grid.x > 1 || grid.z > 1)) ? 1 : 0;
-    if (g_gemm_glds == 2) done = bm64 ? launch_glds<64, 2>(grid, stream, q, sw) : launch_glds<128, 2>(grid, stream, q, sw);
-    else if (g_gemm_glds == 4) done = bm64 ? launch_glds<64, 4>(grid, stream, q, sw) : launch_glds<128, 4>(grid, stream, q, sw);
+    int nst = g_gemm_glds;
+    if (nst == 1) {
+      // many workgroups and a short reduction (the K = 512 projections: 8 k-tiles, 6 workgroups per CU): co-resident
+      // workgroups already hide the latency and the ring's two-tile prologue costs more than it saves -> register-staged kernel
+      const long blocks = (long)grid.x * grid.y * grid.z;
+      const int nkt = q.kchunk / BK;
+      nst = (blocks <= 512 && nkt >= 4) ? 3 : (nkt >= 16 ? 2 : 0);
+    }
+    if (nst == 0) {
+    } else if (nst == 2) done = bm64 ? launch_glds<64, 2>(grid, stream, q, sw) : launch_glds<128, 2>(grid, stream, q, sw);
+    else if (nst == 4) done = bm64 ? launch_glds<64, 4>(grid, stream, q, sw) : launch_glds<128, 4>(grid, stream, q, sw);
     else done = bm64 ? launch_glds<64, 3>(grid, stream, q, sw) : launch_glds<128, 3>(grid, stream, q, sw);
   }
   if (done) {

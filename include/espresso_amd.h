@@ -82,7 +82,7 @@ int ea_set_gemm_variant(int v);
 /* tuning hook: XCD-aware workgroup -> tile mapping; mask bit 0 = direct-to-LDS kernel, bit 1 = register-staged kernel (both
  * additionally gated on the grid shape); returns the previous mask */
 int ea_set_gemm_xcd_swizzle(int mask);
-/* tuning hook: direct-to-LDS ring kernel for launches whose operands are both k-contiguous (0 = off, else ring stages 2..4) */
+/* tuning hook: direct-to-LDS ring kernel for launches whose operands are both k-contiguous (0 = off, 1 = automatic ring depth, 2..4 = forced number of stages); returns the previous value */
 int ea_set_gemm_glds(int stages);
 int ea_gemm_profile_enable(int on);
 long ea_gemm_profile_read(double* total_ms, double* total_flops);
@@ -109,6 +109,9 @@ int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const fl
  * Streaming helpers (AMP weight cast fairseq/tasks/fairseq_task.py:516; FairseqDropout backward
  * fairseq/modules/fairseq_dropout.py:23-25; nn.Linear bias gradient). */
 int ea_cast_f32_to_bf16(const float* src, void* dst, long n, ea_stream_t stream);
+/* n <= 8 bf16 matrices in one launch: dst[i][c][r] = src[i][r][c] (rows[i] x cols[i], dense).  Used for the k-contiguous
+ * copies of the Linear weights that the backward data-gradient GEMMs read (nn.Linear backward, x_grad = y_grad @ W). */
+int ea_transpose_bf16_batch(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, ea_stream_t stream);
 int ea_cast_bf16_to_f32(const void* src, float* dst, long n, ea_stream_t stream);
 /* out = a*x*keep(idx) + b*y  (bf16; y may be NULL) */
 int ea_scale_dropout_bf16(const void* x, const void* y, void* out, long n, float a, float b, uint64_t seed,
@@ -294,6 +297,10 @@ typedef struct EaLayerGrads { EaFfnGrads ffn1; EaAttnGrads attn; EaConvGrads con
 typedef struct EaConformerLayer {
   EaFfnParams ffn1; EaAttnParams attn; EaConvParams conv; EaFfnParams ffn2; const float *final_ln_g, *final_ln_b;
   EaLayerGrads grads;
+  /* optional (may be NULL): bf16 scratch of 2*C*F + 7*C*C elements owned by the caller.  A training forward refreshes it with
+   * the transposes of ffn1.w1, ffn2.w1, wqkv, wo, pw1, pw2 (in this order); the backward's data-gradient GEMMs with 512-wide
+   * outputs then read k-contiguous weights through the direct-to-LDS kernel instead of transposing in registers. */
+  void* wt;
 } EaConformerLayer;
 typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; int has_attn_mask; } EaLayerShape;
 

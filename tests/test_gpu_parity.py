@@ -39,7 +39,7 @@ def test_gemm_splitk():
     assert G.check_gemm(128, 128, 640, False, False, c_f32=True, splitk=64) < 2e-3
 
 
-@pytest.mark.parametrize("stages", [0, 2, 3, 4])   # 0 = register-staged kernel for the same launches
+@pytest.mark.parametrize("stages", [0, 1, 2, 3, 4])   # 0 = register-staged kernel for the same launches, 1 = automatic depth
 @pytest.mark.parametrize("variant", [1, 2])
 def test_gemm_direct_to_lds_ring(stages, variant):
     """k-contiguous launches go through the global_load_lds ring kernel (K % 64 == 0, aligned rows); ragged M / N edges are
