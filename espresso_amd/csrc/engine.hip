@@ -143,10 +143,10 @@ extern "C" {
 // k-contiguous (transposed) copies of the weights whose data-gradient GEMM has a 512-wide output and a long reduction:
 // layout of EaConformerLayer::wt, refreshed by every training forward (the weights only change in the optimizer step)
 struct WT {
-  const uint16_t *f1w1, *f2w1, *wqkv, *wo, *pw1, *pw2;
+  const uint16_t *f1w1, *f2w1, *wqkv, *wo, *pw1, *pw2, *f1w2, *f2w2;
 };
 static WT wt_view(const EaConformerLayer* L, const EaLayerShape& sh) {
-  WT w{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  WT w{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (!L->wt || !sh.training) return w;
   const size_t C = sh.C, F = sh.F;
   const uint16_t* p = (const uint16_t*)L->wt;
@@ -155,17 +155,19 @@ static WT wt_view(const EaConformerLayer* L, const EaLayerShape& sh) {
   w.wqkv = p; p += 3 * C * C;
   w.wo = p; p += C * C;
   w.pw1 = p; p += 2 * C * C;
-  w.pw2 = p;
+  w.pw2 = p; p += C * C;
+  w.f1w2 = p; p += C * F;
+  w.f2w2 = p;
   return w;
 }
 static void wt_refresh(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh) {
   const WT w = wt_view(L, sh);
   if (!w.f1w1) return;
   const int C = sh.C, F = sh.F;
-  const void* src[6] = {L->ffn1.w1, L->ffn2.w1, L->attn.wqkv, L->attn.wo, L->conv.pw1, L->conv.pw2};
-  void* dst[6] = {(void*)w.f1w1, (void*)w.f2w1, (void*)w.wqkv, (void*)w.wo, (void*)w.pw1, (void*)w.pw2};
-  const int rows[6] = {F, F, 3 * C, C, 2 * C, C}, cols[6] = {C, C, C, C, C, C};
-  RUN(ea_transpose_bf16_batch(src, dst, rows, cols, 6, c.s));
+  const void* src[8] = {L->ffn1.w1, L->ffn2.w1, L->attn.wqkv, L->attn.wo, L->conv.pw1, L->conv.pw2, L->ffn1.w2, L->ffn2.w2};
+  void* dst[8] = {(void*)w.f1w1, (void*)w.f2w1, (void*)w.wqkv, (void*)w.wo, (void*)w.pw1, (void*)w.pw2, (void*)w.f1w2, (void*)w.f2w2};
+  const int rows[8] = {F, F, 3 * C, C, 2 * C, C, C, C}, cols[8] = {C, C, C, C, C, C, F, F};
+  RUN(ea_transpose_bf16_batch(src, dst, rows, cols, 8, c.s));
 }
 // data gradient dx[M][N] = dy[M][K] W[K][N]: k-contiguous copy Wt[N][K] when available, else W read k-strided
 static inline void dgrad(Ctx& c, const void* dy, const void* W, const uint16_t* Wt, void* dx, int M, int N, int K) {
@@ -209,7 +211,7 @@ static void ffn_fwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
 }
 
 static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaFfnParams& w, const EaFfnGrads& gw, const void* x,
-                    const void* dy, void* dx, uint64_t seed, float out_scale, int act, const uint16_t* w1t) {
+                    const void* dy, void* dx, uint64_t seed, float out_scale, int act, const uint16_t* w1t, const uint16_t* w2t) {
   const int M = sh.B * sh.T, C = sh.C, F = sh.F;
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
@@ -221,8 +223,9 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   wgrad(c, g2, C, h, F, gw.w2, M, C, F);
   bias_grad(c, g2, gw.b2, M, C, C);
   uint16_t* dz = sc.get<uint16_t>((size_t)M * F);
-  G gd(g2, w.w2, dz, M, F, C, C, F, F);
-  gd.bks().aux(z, F).act(act).drop(sh.p_act, seed + 1);
+  G gd(g2, w2t ? (const void*)w2t : w.w2, dz, M, F, C, C, w2t ? C : F, F);
+  if (!w2t) gd.bks();
+  gd.aux(z, F).act(act).drop(sh.p_act, seed + 1);
   gemm(c, gd);
   fork(c);
   wgrad(c, dz, F, xn, C, gw.w1, M, F, C);
@@ -536,10 +539,10 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
                        1.f, nullptr, lnws, c.s));
   const WT wt = wt_view(L, sh);
-  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU, wt.f2w1);
+  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU, wt.f2w1, wt.f2w2);
   conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32, wt.pw1, wt.pw2);
   attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16, wt.wqkv, wt.wo);
-  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU, wt.f1w1);
+  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2);
   if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
 }

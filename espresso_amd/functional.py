@@ -608,9 +608,9 @@ class _LayerBinding:
 
         ffn(L.ffn1, L.grads.ffn1, m.ffn1)
         ffn(L.ffn2, L.grads.ffn2, m.ffn2)
-        # k-contiguous copies of six weights for the backward data-gradient GEMMs (refreshed by every training forward)
+        # k-contiguous copies of eight weights for the backward data-gradient GEMMs (refreshed by every training forward)
         Cm, Fm = m.embed_dim, m.ffn1.w_1.weight.shape[0]
-        self.wt = torch.empty(2 * Cm * Fm + 7 * Cm * Cm, dtype=torch.bfloat16, device=m.ffn1.w_1.weight.device)
+        self.wt = torch.empty(4 * Cm * Fm + 7 * Cm * Cm, dtype=torch.bfloat16, device=m.ffn1.w_1.weight.device)
         L.wt = self.wt.data_ptr()
         a = m.self_attn
         qw, kw, vw = a.q_proj.weight, a.k_proj.weight, a.v_proj.weight

@@ -297,9 +297,9 @@ typedef struct EaLayerGrads { EaFfnGrads ffn1; EaAttnGrads attn; EaConvGrads con
 typedef struct EaConformerLayer {
   EaFfnParams ffn1; EaAttnParams attn; EaConvParams conv; EaFfnParams ffn2; const float *final_ln_g, *final_ln_b;
   EaLayerGrads grads;
-  /* optional (may be NULL): bf16 scratch of 2*C*F + 7*C*C elements owned by the caller.  A training forward refreshes it with
-   * the transposes of ffn1.w1, ffn2.w1, wqkv, wo, pw1, pw2 (in this order); the backward's data-gradient GEMMs with 512-wide
-   * outputs then read k-contiguous weights through the direct-to-LDS kernel instead of transposing in registers. */
+  /* optional (may be NULL): bf16 scratch of 4*C*F + 7*C*C elements owned by the caller.  A training forward refreshes it with
+   * the transposes of ffn1.w1, ffn2.w1, wqkv, wo, pw1, pw2, ffn1.w2, ffn2.w2 (in this order); the backward's data-gradient
+   * GEMMs then read k-contiguous weights (direct-to-LDS kernel where it pays) instead of transposing them in registers. */
   void* wt;
 } EaConformerLayer;
 typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; int has_attn_mask; } EaLayerShape;
