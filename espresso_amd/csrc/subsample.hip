@@ -12,112 +12,152 @@
 
 namespace {
 
-// X [B][T][F] fp32 -> Z [B][To][Fo][CO] bf16 (pre-BN, bias added); stats[0..CO) += sum, [CO..2CO) += sumsq
-// block: 256 threads = 8 positions x 32 channel pairs (CO == 64)
+// X [B][T][F] fp32 -> Z [B][To][Fo][CO] bf16 (pre-BN, bias added); stats[0..CO) += sum, [CO..2CO) += sumsq.
+// A thread owns 8 output channels (one 16-byte store per position) and walks a contiguous run of positions; the 8 lanes of
+// a position share the nine input taps (same addresses: one L1 transaction).  256 threads = 32 runs x 8 channel chunks per
+// 64-channel slab; HBM-bound on the Z store (B*To*Fo*CO*2 bytes).
+constexpr int C1_RUN = 16;  // positions per thread run
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W /*[CO][3][3]*/,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ Z,
                                                         double* __restrict__ stats, int T, int F, int To, int Fo, int CO,
-                                                        int sy, int sx, long npos, int pos_per_block) {
-  __shared__ float red[8][4][64];
-  const int pl = threadIdx.x >> 5, cp = threadIdx.x & 31;
-  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
-  for (int c0 = cp * 2; c0 < CO; c0 += 64) {
-    float w0[9], w1[9];
+                                                        int sy, int sx, long npos) {
+  __shared__ float red[4][2][64];
+  const int grp = threadIdx.x >> 3, ch = threadIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long p0 = ((long)blockIdx.x * 32 + grp) * C1_RUN;
+  for (int cs = 0; cs < CO; cs += 64) {
+    const int c0 = cs + ch * 8;
+    float w[8][9], bv[8], s[8], q[8];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      w0[k] = W[c0 * 9 + k];
-      w1[k] = W[(c0 + 1) * 9 + k];
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) w[e][k] = W[(c0 + e) * 9 + k];
+      bv[e] = bias[c0 + e];
+      s[e] = q[e] = 0.f;
     }
-    const float b0 = bias[c0], b1 = bias[c0 + 1];
-    const long p0 = (long)blockIdx.x * pos_per_block;
-    for (long p = p0 + pl; p < min(npos, p0 + pos_per_block); p += 8) {
+    for (int r = 0; r < C1_RUN; ++r) {
+      const long p = p0 + r;
+      if (p >= npos) break;
       const int fo = (int)(p % Fo);
       const int to = (int)((p / Fo) % To);
       const long b = p / ((long)Fo * To);
-      float z0 = b0, z1 = b1;
+      float x[9];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int t = to * sy + ky - 1;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int f = fo * sx + kx - 1;
-          float x = 0.f;
-          if (t >= 0 && t < T && f >= 0 && f < F) x = X[(b * T + t) * F + f];
-          z0 += w0[ky * 3 + kx] * x;
-          z1 += w1[ky * 3 + kx] * x;
+          x[ky * 3 + kx] = (t >= 0 && t < T && f >= 0 && f < F) ? X[(b * T + t) * F + f] : 0.f;
         }
       }
-      *reinterpret_cast<uint32_t*>(Z + p * CO + c0) = pack_bf2(z0, z1);
-      z0 = bf2f(f2bf(z0)); z1 = bf2f(f2bf(z1));
-      s[0] += z0; s[1] += z1; q[0] += z0 * z0; q[1] += z1 * z1;
+      float z[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = bv[e];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a += w[e][k] * x[k];
+        z[e] = a;
+      }
+      uint4 o;
+      o.x = pack_bf2(z[0], z[1]); o.y = pack_bf2(z[2], z[3]); o.z = pack_bf2(z[4], z[5]); o.w = pack_bf2(z[6], z[7]);
+      *reinterpret_cast<uint4*>(Z + p * CO + c0) = o;
+      if (stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float zr = bf2f(f2bf(z[e]));  // statistics of the rounded values the next kernel reads
+          s[e] += zr;
+          q[e] += zr * zr;
+        }
+      }
     }
     if (stats) {
-      red[pl][0][cp * 2] = s[0]; red[pl][0][cp * 2 + 1] = s[1];
-      red[pl][1][cp * 2] = q[0]; red[pl][1][cp * 2 + 1] = q[1];
+      // lanes l, l+8, ... hold the same channels: fold the 8 position groups of a wavefront, then the 4 wavefronts via LDS
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+          s[e] += __shfl_xor(s[e], off, 64);
+          q[e] += __shfl_xor(q[e], off, 64);
+        }
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[wave][0][lane * 8 + e] = s[e];
+          red[wave][1][lane * 8 + e] = q[e];
+        }
+      }
       __syncthreads();
       if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a += red[i][which][c];
-        const int cc = (c0 - cp * 2) + c;
-        if (cc < CO) atomicAdd(stats + which * CO + cc, (double)a);
+        const float a = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        atomicAdd(stats + which * CO + cs + c, (double)a);
       }
       __syncthreads();
-      s[0] = s[1] = q[0] = q[1] = 0.f;
     }
   }
 }
 
-// dW[co][ky][kx] += sum_pos dZ[pos][co] * X[...];  dbias[co] += sum_pos dZ[pos][co]
+// dW[co][ky][kx] += sum_pos dZ[pos][co] * X[...];  dbias[co] += sum_pos dZ[pos][co].  Same thread map as the forward kernel
+// (8 channels per thread, 16-byte dZ loads, the 8 lanes of a position share the taps); HBM-bound on the dZ read.
+constexpr int C1W_RUN = 64;
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ X, const bf16_t* __restrict__ dZ,
                                                           float* __restrict__ dW, float* __restrict__ dbias, int T, int F,
-                                                          int To, int Fo, int CO, int sy, int sx, long npos,
-                                                          int pos_per_block) {
-  __shared__ float red[8][10][64];
-  const int pl = threadIdx.x >> 5, cp = threadIdx.x & 31;
-  for (int c0 = cp * 2; c0 < CO; c0 += 64) {
-    float a0[10], a1[10];
+                                                          int To, int Fo, int CO, int sy, int sx, long npos) {
+  __shared__ float red[4][10][64];
+  const int grp = threadIdx.x >> 3, ch = threadIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long p0 = ((long)blockIdx.x * 32 + grp) * C1W_RUN;
+  for (int cs = 0; cs < CO; cs += 64) {
+    const int c0 = cs + ch * 8;
+    float acc[10][8];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) a0[k] = a1[k] = 0.f;
-    const long p0 = (long)blockIdx.x * pos_per_block;
-    for (long p = p0 + pl; p < min(npos, p0 + pos_per_block); p += 8) {
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    for (int r = 0; r < C1W_RUN; ++r) {
+      const long p = p0 + r;
+      if (p >= npos) break;
       const int fo = (int)(p % Fo);
       const int to = (int)((p / Fo) % To);
       const long b = p / ((long)Fo * To);
-      const uint32_t dd = *reinterpret_cast<const uint32_t*>(dZ + p * CO + c0);
-      const float d0 = __uint_as_float(dd << 16), d1 = __uint_as_float(dd & 0xffff0000u);
+      const uint4 dd = *reinterpret_cast<const uint4*>(dZ + p * CO + c0);
+      const uint32_t dw[4] = {dd.x, dd.y, dd.z, dd.w};
+      float d[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d[2 * e] = __uint_as_float(dw[e] << 16);
+        d[2 * e + 1] = __uint_as_float(dw[e] & 0xffff0000u);
+      }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int t = to * sy + ky - 1;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int f = fo * sx + kx - 1;
-          float x = 0.f;
-          if (t >= 0 && t < T && f >= 0 && f < F) x = X[(b * T + t) * F + f];
-          a0[ky * 3 + kx] += d0 * x;
-          a1[ky * 3 + kx] += d1 * x;
+          const float x = (t >= 0 && t < T && f >= 0 && f < F) ? X[(b * T + t) * F + f] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[ky * 3 + kx][e] += d[e] * x;
         }
       }
-      a0[9] += d0;
-      a1[9] += d1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[9][e] += d[e];
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      red[pl][k][cp * 2] = a0[k];
-      red[pl][k][cp * 2 + 1] = a1[k];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = acc[k][e];
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (lane < 8) red[wave][k][lane * 8 + e] = v;
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 640; i += 256) {
       const int k = i >> 6, c = i & 63;
-      float a = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a += red[j][k][c];
-      const int cc = (c0 - cp * 2) + c;
-      if (cc < CO) {
-        if (k < 9) atomicAdd(dW + cc * 9 + k, a);
-        else if (dbias) atomicAdd(dbias + cc, a);
-      }
+      const float a = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+      if (k < 9) atomicAdd(dW + (cs + c) * 9 + k, a);
+      else if (dbias) atomicAdd(dbias + cs + c, a);
     }
     __syncthreads();
   }
@@ -227,9 +267,9 @@ extern "C" int ea_conv1_fwd(const float* X, const float* W, const float* bias, v
   if (CO % 64) return -2;
   const int To = (T - 1) / sy + 1, Fo = (F - 1) / sx + 1;
   const long npos = (long)B * To * Fo;
-  const int ppb = 512;
+  const int ppb = 32 * C1_RUN;
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((npos + ppb - 1) / ppb)), dim3(256), 0, stream, X, W, bias,
-                     (bf16_t*)Z, stats, T, F, To, Fo, CO, sy, sx, npos, ppb);
+                     (bf16_t*)Z, stats, T, F, To, Fo, CO, sy, sx, npos);
   return EA_CHECK_LAUNCH();
 }
 extern "C" int ea_conv1_wgrad(const float* X, const void* dZ, float* dW, float* dbias, int B, int T, int F, int CO,
@@ -238,9 +278,9 @@ extern "C" int ea_conv1_wgrad(const float* X, const void* dZ, float* dW, float* 
   if (CO % 64) return -2;
   const int To = (T - 1) / sy + 1, Fo = (F - 1) / sx + 1;
   const long npos = (long)B * To * Fo;
-  const int ppb = 2048;
+  const int ppb = 32 * C1W_RUN;
   hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)((npos + ppb - 1) / ppb)), dim3(256), 0, stream, X,
-                     (const bf16_t*)dZ, dW, dbias, T, F, To, Fo, CO, sy, sx, npos, ppb);
+                     (const bf16_t*)dZ, dW, dbias, T, F, To, Fo, CO, sy, sx, npos);
   return EA_CHECK_LAUNCH();
 }
 extern "C" int ea_im2col3x3(const void* A, void* col, int B, int T, int F, int C, int sy, int sx, hipStream_t stream) {
