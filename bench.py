@@ -135,6 +135,13 @@ def cpu_baseline(n_threads=None, seconds_per_utt=12.0, n_utts=4, steps=3):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: native libraries that print to fd 1 (RCCL's version banner under the image's
+    # NCCL_DEBUG=VERSION, rocm tools) are redirected to stderr; the JSON goes to a private duplicate of the original stdout
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ.pop("NCCL_DEBUG")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -158,8 +165,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("EA_DDP_FORCE") == "1":  # EA_DDP_FORCE: RCCL path with a single rank (diagnostic)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
@@ -264,8 +274,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
-    if world > 1:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

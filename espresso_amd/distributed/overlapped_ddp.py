@@ -14,6 +14,7 @@ API mirrors the wrappers in fairseq/models/distributed_fairseq_model.py:35-147: 
 `forward`, `no_sync()`, `all_reduce_grads()`.
 """
 import contextlib
+import os
 from typing import List, Optional
 
 import torch
@@ -29,6 +30,9 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self.flat = flat
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # EA_DDP_FORCE=1: run the bucket hooks and collectives even with a single rank (exercises the RCCL / stream path on
+        # a one-GPU box; the reduction itself is then the identity)
+        self.active = self.world_size > 1 or (dist.is_initialized() and os.environ.get("EA_DDP_FORCE") == "1")
         self.accumulate_grads = False
         self._on_gpu = flat.g32.is_cuda
         self.comm_stream = torch.cuda.Stream() if self._on_gpu else None
@@ -47,7 +51,7 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self._works: List = []
         self._launched = [False] * len(self.buckets)
         self._hooks = {id(p): self._make_hook(p) for p in flat.params}
-        if self.world_size > 1:
+        if self.active:
             for p in flat.params:
                 p.register_post_accumulate_grad_hook(self._hooks[id(p)])
             # gradients written directly by the native layer runtime never pass through autograd's
@@ -105,7 +109,7 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
     def all_reduce_grads(self):
         """Finish the step's reduction: launch buckets whose hooks did not all fire (unused parameters,
         dummy batches — trainer.py:873-877), wait for RCCL, re-arm.  Gradients hold the SUM over ranks."""
-        if self.world_size > 1:
+        if self.active:
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)

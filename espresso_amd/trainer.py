@@ -49,7 +49,7 @@ class Trainer:
             self._stats[1] += loss.detach()
             self._stats[2] += float(log["ntokens"])
             self._stats[3] += float(log["nsentences"])
-        if self.world_size > 1:
+        if self.ddp.active:
             dist.all_reduce(self._stats)  # C3 + sample_size in one 16-byte collective
         self.ddp.all_reduce_grads()
         self.last_coef = self.optimizer.clip_and_step(pre_scale=1.0, max_norm=self.clip_norm, denom_dev=self._stats[0:1])

@@ -1276,3 +1276,58 @@ def check_global_cmvn_stats(tmp_dir):
     nf = [int(l.split()[1]) for l in buf.getvalue().strip().split("\n")]
     return {"mean_abs": float(np.abs(got["mean"] - mean).max()), "std_abs": float(np.abs(got["std"] - std).max()),
             "dtype64": got["mean"].dtype == np.float64, "num_frames_equal": nf == frames}
+
+
+def check_label_smoothing_known_answers():
+    """The reference's own known-answer tests for the CE criterions (tests/test_label_smoothing.py:46-119) through the HIP
+    criterions: fixed model probabilities, a batch with padding; nll bookkeeping, padding additivity, reduction, zero epsilon,
+    plus the closed-form values."""
+    from espresso_amd.criterions.cross_entropy_v2 import CrossEntropyV2Criterion
+    from espresso_amd.criterions.label_smoothed_cross_entropy_v2 import LabelSmoothedCrossEntropyV2Criterion
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+
+    d = AsrDictionary.from_symbols(["w1", "w2", "w3"], enable_bos=True, add_space=False)  # <s> <pad> </s> <unk> w1 w2 w3
+    assert (len(d), d.pad(), d.eos(), d.unk()) == (7, 1, 2, 3)
+    pad, eos, w1 = 1, 2, 4
+    probs = torch.tensor([[0.05, 0.05, 0.1, 0.05, 0.3, 0.4, 0.05],
+                          [0.05, 0.10, 0.2, 0.05, 0.2, 0.3, 0.10],
+                          [0.05, 0.15, 0.3, 0.05, 0.1, 0.2, 0.15]])
+    task = type("T", (), {"target_dictionary": d})()
+
+    class FixedModel:
+        training = False
+
+        def __call__(self, prev_output_tokens=None, **kw):
+            B = prev_output_tokens.shape[0]
+            return probs.log().unsqueeze(0).expand(B, 3, 7).contiguous().to(DEV), None
+
+    def sample_of(targets):
+        L = max(len(t) for t in targets)
+        tgt = torch.full((len(targets), L), pad, dtype=torch.long)
+        for i, t in enumerate(targets):
+            tgt[i, : len(t)] = torch.tensor(t)
+        # the model always emits 3 positions; shorter targets are padded to 3 like the reference's collater does
+        tgt3 = torch.full((len(targets), 3), pad, dtype=torch.long)
+        tgt3[:, :L] = tgt
+        return {"net_input": {"prev_output_tokens": tgt3.to(DEV)}, "target": tgt3.to(DEV), "ntokens": int((tgt3 != pad).sum()),
+                "id": torch.arange(len(targets))}
+
+    model = FixedModel()
+    both = sample_of([[w1, eos], [w1, w1, eos]])
+    ce = CrossEntropyV2Criterion(task, sentence_avg=False)
+    ls = LabelSmoothedCrossEntropyV2Criterion(task, sentence_avg=False, label_smoothing=0.1)
+    ls0 = LabelSmoothedCrossEntropyV2Criterion(task, sentence_avg=False, label_smoothing=0.0)
+    nll_loss, nll_ss, nll_log = ce(model, both)
+    sm_loss, sm_ss, sm_log = ls(model, both)
+    z_loss, _, _ = ls0(model, both)
+    l1, _, _ = ls(model, sample_of([[w1, eos]]))
+    l2, _, _ = ls(model, sample_of([[w1, w1, eos]]))
+    lp = probs.log().double()
+    nll_true = -(lp[0, w1] + lp[1, eos]) - (lp[0, w1] + lp[1, w1] + lp[2, eos])
+    eps_i = 0.1 / (7 - 1)
+    smooth_true = -(lp[0].sum() + lp[1].sum()) - (lp[0].sum() + lp[1].sum() + lp[2].sum())
+    sm_true = (1 - 0.1 - eps_i) * nll_true + eps_i * smooth_true
+    return {"nll_vs_logging": abs(float(nll_loss) - float(nll_log["loss"])), "nll_vs_smooth_nll": abs(float(nll_loss) - float(sm_log["nll_loss"])),
+            "padding_additivity": abs(float(sm_loss) - float(l1) - float(l2)), "zero_eps": abs(float(nll_loss) - float(z_loss)),
+            "nll_closed_form": abs(float(nll_loss) - float(nll_true)), "smooth_closed_form": abs(float(sm_loss) - float(sm_true)),
+            "sample_sizes": (nll_ss, sm_ss, both["ntokens"])}

@@ -317,3 +317,10 @@ def test_task_pipeline_raw_audio_to_metrics(tmp_path):
 def test_global_cmvn_stats_tool(tmp_path):
     r = G.check_global_cmvn_stats(str(tmp_path))
     assert r["mean_abs"] < 2e-4 and r["std_abs"] < 2e-4 and r["dtype64"] and r["num_frames_equal"], r
+
+
+def test_label_smoothing_known_answers_of_the_reference_suite():
+    r = G.check_label_smoothing_known_answers()
+    for k in ("nll_vs_logging", "nll_vs_smooth_nll", "padding_additivity", "zero_eps", "nll_closed_form", "smooth_closed_form"):
+        assert r[k] < 1e-5, (k, r)
+    assert r["sample_sizes"] == (5, 5, 5), r
