@@ -382,7 +382,8 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
     float* Dd = sc.get<float>((size_t)Z * T);
     RUN(ea_flash_attention_bwd(a.qu, a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
-                               Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 0, scaling, seed + 3, drop_thr(sh.p_attn),
+                               Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, (sh.scratch_clean && c.overlap) ? 2 : 0, scaling, seed + 3,
+                               drop_thr(sh.p_attn),
                                drop_scale(sh.p_attn), c.s));
     attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt);
     release(c, mark);

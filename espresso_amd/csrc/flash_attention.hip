@@ -316,7 +316,7 @@ struct FlashBwdArgs {
   bf16_t* t1; bf16_t* t2; long ldt;  // [B*T][ldt] gradients of (q+u), (q+v) (unscaled q space)
   bf16_t* dBD; int ld_bd;         // [H*B][T][ld_bd]
   bf16_t* dk; bf16_t* dv; long lddkv;
-  int H, B, T, S, causal, nq, nk, dbg;
+  int H, B, T, S, causal, nq, nk, dbd_prezeroed;
   float scaling;
   uint64_t seed; uint32_t thr; float inv_keep;
 };
@@ -469,7 +469,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashBwdArgs 
     if (RELPOS) {
       wave_lds_sync();
       // t2^T[d][i] += PP^T[d][c] dBD^T[c][i] over this wavefront's 80-position band
-      if (!(a.dbg & 8))
 #pragma unroll
       for (int ct = 0; ct < 5; ++ct) {
         const int cb = (ct * 16 + g4 * 4) * BDP + li;
@@ -480,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashBwdArgs 
       }
       // dBD[z][row][T-1-row + j] = dS[row][j]: one 128-byte row segment per store instruction
       const int j = j0 + lane;
-      if (j < S && !(a.dbg & 2)) {
+      if (j < S) {
         const int row_w = i0 + 16 * w, nrow = T - row_w;  // wavefront-uniform
         bf16_t* dp = a.dBD + ((long)z * T + row_w) * a.ld_bd + (T - 1 - row_w) + j;
         const float* bs = bd + (15 + lane) * BDP;
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashBwdArgs 
       }
     }
   }
-  if (RELPOS && !(a.dbg & 4)) {
+  if (RELPOS && !a.dbd_prezeroed) {
     // columns of dBD no (row, key) pair of this workgroup wrote: r < T-1-row or r >= T-1-row + jcov.  16-byte stores
     // for the 8-element chunks that are entirely outside the band, element stores for the two boundary chunks.
     for (int iw = 0; iw < 16; ++iw) {
@@ -742,14 +741,14 @@ extern "C" int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, 
   a.t1 = (bf16_t*)t1; a.t2 = (bf16_t*)t2; a.ldt = ldt;
   a.dBD = (bf16_t*)dBD; a.ld_bd = ld_bd;
   a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lddkv = lddkv;
-  a.H = H; a.B = B; a.T = T; a.S = S; a.causal = causal & 1; a.dbg = causal >> 1 << 1;
+  a.H = H; a.B = B; a.T = T; a.S = S; a.causal = causal & 1; a.dbd_prezeroed = (causal >> 1) & 1;
   a.nq = (T + TQ - 1) / TQ; a.nk = (S + TK - 1) / TK;
   a.scaling = scaling;
   a.seed = drop_seed; a.thr = drop_thr; a.inv_keep = drop_scale;
   const dim3 gq((unsigned)(a.nq * H * B)), gk((unsigned)(a.nk * H * B));
   if (relpos) {
-    if (!(a.dbg & 16)) hipLaunchKernelGGL(flash_bwd_q_kernel<true>, gq, dim3(256), 0, stream, a);
-    if (!(a.dbg & 32)) hipLaunchKernelGGL(flash_bwd_kv_kernel<true>, gk, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(flash_bwd_q_kernel<true>, gq, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(flash_bwd_kv_kernel<true>, gk, dim3(256), 0, stream, a);
   } else {
     hipLaunchKernelGGL(flash_bwd_q_kernel<false>, gq, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(flash_bwd_kv_kernel<false>, gk, dim3(256), 0, stream, a);

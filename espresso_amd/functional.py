@@ -725,6 +725,7 @@ class _ConformerLayerNative(torch.autograd.Function):
             bind.saved_busy = bool(needs_bwd)
             ctx.owns_arena = bool(needs_bwd)
         scratch = _scratch_buffer(nb_scratch.value, x.device)
+        _scratch_tag[str(x.device)] = None  # the forward overwrites what a backward pass left in the arena
         y = torch.empty_like(x)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(lib.ea_conformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
@@ -744,6 +745,10 @@ class _ConformerLayerNative(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         scratch = _scratch_buffer(ctx.nb_scratch, x.device)
+        sh = ctx.sh
+        tag = (scratch.data_ptr(), sh.B, sh.T, sh.C, sh.H, sh.F, sh.KW, sh.training, sh.has_attn_mask)
+        sh.scratch_clean = int(_scratch_tag.get(str(x.device)) == tag)  # consecutive layers of one backward pass share the layout
+        _scratch_tag[str(x.device)] = tag
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
                                                      _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
@@ -755,6 +760,7 @@ class _ConformerLayerNative(torch.autograd.Function):
 
 
 _scratch = {}
+_scratch_tag = {}
 
 
 def _scratch_buffer(nbytes, device):

@@ -149,7 +149,9 @@ int ea_flash_attention_fwd(const void* qu, const void* qv, long ldq, const void*
  *               (q + pos_bias_v) before scaling (t2 / dBD / pp unused when qv == NULL)
  *   dBD       : bf16 [H*B][T][ld_bd] gradient of the raw positional logits (un-skewed, zero outside the band), the
  *               operand of the pos_proj weight gradient dpp[r] = sum_{b,i} dBD[.,i,r] qv[b,i]
- *   dk, dv    : bf16, row (b*S + j) * lddkv, head h at column h*dh (e.g. the k / v thirds of a packed dqkv buffer) */
+ *   dk, dv    : bf16, row (b*S + j) * lddkv, head h at column h*dh (e.g. the k / v thirds of a packed dqkv buffer)  * ea_flash_attention_bwd `causal`: bit 0 = causal mask; bit 1 = the caller guarantees that the part of every dBD row outside
+ * the band [T-1-i, T-1-i+S) is already zero (e.g. the same buffer was filled by a previous call with the same H, B, T, S and not
+ * touched since), so the kernel only writes the band. */
 int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldkv,
                            const void* pp, long ldpp, const int* key_len, const void* out, const void* dout, long ldo,
                            const float* lse, float* D, void* t1, void* t2, long ldt, void* dBD, int ld_bd, void* dk,
@@ -302,7 +304,12 @@ typedef struct EaConformerLayer {
    * GEMMs then read k-contiguous weights (direct-to-LDS kernel where it pays) instead of transposing them in registers. */
   void* wt;
 } EaConformerLayer;
-typedef struct EaLayerShape { int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; int has_attn_mask; } EaLayerShape;
+typedef struct EaLayerShape {
+  int B, T, C, H, F, KW, training; float p_drop, p_act, p_attn; uint64_t seed; int has_attn_mask;
+  /* backward only: the scratch arena is untouched since the previous ea_conformer_layer_bwd call with the same shape and
+   * settings (consecutive layers of one backward pass) - lets the attention backward skip re-zeroing its band buffer */
+  int scratch_clean;
+} EaLayerShape;
 
 /* tuning hook: run weight-gradient GEMMs / bias sums of the layer backward on a side stream (default on); returns the
  * previous value.  Sizes from ea_conformer_layer_workspace depend on this setting: query them after changing it. */
