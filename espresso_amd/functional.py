@@ -746,7 +746,9 @@ class _ConformerLayerNative(torch.autograd.Function):
         dx = torch.empty_like(x)
         scratch = _scratch_buffer(ctx.nb_scratch, x.device)
         sh = ctx.sh
-        tag = (scratch.data_ptr(), sh.B, sh.T, sh.C, sh.H, sh.F, sh.KW, sh.training, sh.has_attn_mask)
+        # everything the arena layout depends on (shape, which optional buffers exist, runtime switches via the byte count)
+        tag = (scratch.data_ptr(), ctx.nb_scratch, sh.B, sh.T, sh.C, sh.H, sh.F, sh.KW, sh.training, sh.has_attn_mask,
+               sh.p_drop > 0, sh.p_act > 0, sh.p_attn > 0)
         sh.scratch_clean = int(_scratch_tag.get(str(x.device)) == tag)  # consecutive layers of one backward pass share the layout
         _scratch_tag[str(x.device)] = tag
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
