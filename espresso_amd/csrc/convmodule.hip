@@ -477,6 +477,11 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z,
                      (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, M, C, act,
                      training ? (float)M : 0.f);
+  if (dgamma || dbeta) hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, C);
+  return EA_CHECK_LAUNCH();
+}
+// the optimizer-only tail of ea_bn_act_bwd on its own (call ea_bn_act_bwd with dgamma = dbeta = NULL first)
+extern "C" int ea_bn_param_grad(const float* red, float* dgamma, float* dbeta, int C, hipStream_t stream) {
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, C);
   return EA_CHECK_LAUNCH();
 }
@@ -496,6 +501,12 @@ extern "C" int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, c
   if (C % 2) return -2;
   dim3 grid((C + CT - 1) / CT, (T + TTILE - 1) / TTILE, B);
   EA_KW_DISPATCH(KW, launch_glu_dwconv_bwd_data, grid, stream, (const bf16_t*)dZ, (const bf16_t*)Y, w, (bf16_t*)dY, T, C);
+  if (!dw) return EA_CHECK_LAUNCH();  // data gradient only: the caller runs ea_dwconv_bwd_weight (optimizer-only) itself
+  return ea_dwconv_bwd_weight(dZ, U, dw, wgrad_ws, B, T, C, KW, stream);
+}
+extern "C" int ea_dwconv_bwd_weight(const void* dZ, const void* U, float* dw, void* wgrad_ws, int B, int T, int C, int KW,
+                                    hipStream_t stream) {
+  if (B <= 0 || T <= 0) return 0;
   dim3 gridw((C + CT - 1) / CT, dw_time_blocks(T), B);
   float* part = (float*)wgrad_ws;
   EA_KW_DISPATCH(KW, launch_dwconv_bwd_weight, gridw, stream, (const bf16_t*)dZ, (const bf16_t*)U, part, T, C, DW_TILES_PER_BLOCK);

@@ -233,7 +233,9 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dz, w.w1, w1t, dxn, M, C, F);
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
+  RUN(ea_layernorm_bwd_dx(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
+  fork(c);  // the parameter-gradient reduce only feeds the optimizer
+  RUN(ea_layernorm_param_reduce(lnws, gw.ln_g, gw.ln_b, M, C, wstream(c)));
   release(c, mark);
 }
 
@@ -354,7 +356,9 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dqkv, w.wqkv, wqkvt, dxn, M, C, 3 * C);
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
+  RUN(ea_layernorm_bwd_dx(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
+  fork(c);  // the parameter-gradient reduce only feeds the optimizer
+  RUN(ea_layernorm_param_reduce(lnws, gw.ln_g, gw.ln_b, M, C, wstream(c)));
 }
 
 static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
@@ -473,16 +477,20 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   float* red = sc.get<float>(2 * C);
   if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(red, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
   uint16_t* dZ = sc.get<uint16_t>((size_t)M * C);
-  RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, gw.bn_g, gw.bn_b, M, C, EA_ACT_SILU, sh.training, c.s));
+  RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, nullptr, nullptr, M, C, EA_ACT_SILU, sh.training, c.s));
   uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
   char* wws = sc.get<char>((size_t)ea_dwconv_wgrad_workspace_bytes(B, T, C, sh.KW));
-  RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, gw.dw, wws, B, T, C, sh.KW, c.s));
-  fork(c);
+  RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, nullptr, wws, B, T, C, sh.KW, c.s));
+  fork(c);  // BatchNorm / depthwise-filter / pointwise-1 parameter gradients: optimizer-only
+  RUN(ea_bn_param_grad(red, gw.bn_g, gw.bn_b, C, wstream(c)));
+  RUN(ea_dwconv_bwd_weight(dZ, s.U, gw.dw, wws, B, T, C, sh.KW, wstream(c)));
   wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dY, w.pw1, pw1t, dxn, M, C, 2 * C);
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
+  RUN(ea_layernorm_bwd_dx(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
+  fork(c);  // the parameter-gradient reduce only feeds the optimizer
+  RUN(ea_layernorm_param_reduce(lnws, gw.ln_g, gw.ln_b, M, C, wstream(c)));
   release(c, mark);
 }
 
@@ -537,8 +545,10 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   uint16_t* dC = sc.get<uint16_t>((size_t)M * C);
   uint16_t* dD = sc.get<uint16_t>((size_t)M * C);
   void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
+  RUN(ea_layernorm_bwd_dx(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
                        1.f, nullptr, lnws, c.s));
+  fork(c);  // the parameter-gradient reduce only feeds the optimizer
+  RUN(ea_layernorm_param_reduce(lnws, L->grads.final_ln_g, L->grads.final_ln_b, M, C, wstream(c)));
   const WT wt = wt_view(L, sh);
   ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU, wt.f2w1, wt.f2w2);
   conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32, wt.pw1, wt.pw2);

@@ -262,10 +262,9 @@ extern "C" long ea_layernorm_bwd_workspace_bytes(int M, int C) {
   return (long)((M + rpb - 1) / rpb) * 2 * C * (long)sizeof(float);
 }
 
-extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean,
-                                const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C,
-                                const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
-                                float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
+static int ln_bwd_launch(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                         float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                         float drop_scale, const void* dx_add, void* workspace, hipStream_t stream, bool reduce_params) {
   if (M <= 0) return 0;
   if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
   const int rpb = ln_bwd_rows_per_block(M, workspace != nullptr);
@@ -278,12 +277,36 @@ extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamm
   else if (C <= 1024) EA_LN_BWD(2);
   else EA_LN_BWD(4);
 #undef EA_LN_BWD
-  if (workspace) {
-    int rs = nblk / 32;
-    if (rs < 1) rs = 1;
-    if (rs > 32) rs = 32;
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(2 * C / 64, rs), dim3(256), 0, stream, (const float*)workspace, dgamma,
-                       dbeta, nblk, C);
-  }
+  if (workspace && reduce_params) return ea_layernorm_param_reduce(workspace, dgamma, dbeta, M, C, stream);
   return EA_CHECK_LAUNCH();
+}
+
+// second pass of the workspace path: dgamma / dbeta += column sums of the per-workgroup partials (optimizer-only product)
+extern "C" int ea_layernorm_param_reduce(const void* workspace, float* dgamma, float* dbeta, int M, int C, hipStream_t stream) {
+  if (M <= 0) return 0;
+  const int rpb = ln_bwd_rows_per_block(M, true);
+  const int nblk = (M + rpb - 1) / rpb;
+  int rs = nblk / 32;
+  if (rs < 1) rs = 1;
+  if (rs > 32) rs = 32;
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(2 * C / 64, rs), dim3(256), 0, stream, (const float*)workspace, dgamma,
+                     dbeta, nblk, C);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean,
+                                const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C,
+                                const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                                float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
+  return ln_bwd_launch(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, M, C, row_zero, drop_seed, drop_thr, drop_scale, dx_add,
+                       workspace, stream, true);
+}
+// dx only (workspace required): the caller runs ea_layernorm_param_reduce later, possibly on another stream
+extern "C" int ea_layernorm_bwd_dx(const void* x, const void* dy, const float* gamma, const float* mean,
+                                   const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C,
+                                   const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                                   float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
+  if (!workspace) return -2;
+  return ln_bwd_launch(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, M, C, row_zero, drop_seed, drop_thr, drop_scale, dx_add,
+                       workspace, stream, false);
 }

@@ -104,6 +104,12 @@ int ea_layernorm_bwd(const void* x, const void* dy, const float* gamma, const fl
                      void* dx, float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero,
                      uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* dx_add,
                      void* workspace, ea_stream_t stream);
+/* the two passes of ea_layernorm_bwd separately (workspace required): the parameter-gradient reduce only feeds the optimizer,
+ * so a runtime can put it on another stream */
+int ea_layernorm_bwd_dx(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                        float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero, uint64_t drop_seed,
+                        uint32_t drop_thr, float drop_scale, const void* dx_add, void* workspace, ea_stream_t stream);
+int ea_layernorm_param_reduce(const void* workspace, float* dgamma, float* dbeta, int M, int C, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming helpers (AMP weight cast fairseq/tasks/fairseq_task.py:516; FairseqDropout backward
@@ -197,6 +203,10 @@ int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rstd, const f
 long ea_dwconv_wgrad_workspace_bytes(int B, int T, int C, int KW);
 int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float* w, void* dY, float* dw,
                       void* wgrad_ws, int B, int T, int C, int KW, ea_stream_t stream);
+/* ea_glu_dwconv_bwd with dw == NULL computes dY only; the depthwise weight gradient (optimizer-only) on its own: */
+int ea_dwconv_bwd_weight(const void* dZ, const void* U, float* dw, void* wgrad_ws, int B, int T, int C, int KW, ea_stream_t stream);
+/* ea_bn_act_bwd with dgamma == dbeta == NULL skips the parameter gradients; they are then taken from `red` by: */
+int ea_bn_param_grad(const float* red, float* dgamma, float* dbeta, int C, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conv2d sub-sampler — espresso/modules/speech_convolutions.py:78-102.  Channels-last bf16
