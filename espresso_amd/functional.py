@@ -54,9 +54,9 @@ def _auto_splitk(tiles, Kred):
     return max(1, min((768 + tiles - 1) // tiles, Kred // 256))
 
 
-def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None):
+def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None, out=None):
     """dW[N_out][K_in] (fp32) = dy[M][N_out]^T x[M][K_in]   (split-K over the long M reduction)"""
-    dW = torch.empty((N_out, K_in), dtype=torch.float32, device=dy.device)
+    dW = out if out is not None else torch.empty((N_out, K_in), dtype=torch.float32, device=dy.device)
     tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
     K.gemm(dy, x, dW, N_out, K_in, M, lda=ld_dy or N_out, ldb=ld_x or K_in, ldc=K_in, a_kstrided=True, b_kstrided=True,
            splitk=_auto_splitk(tiles, M))
@@ -65,6 +65,18 @@ def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None):
 
 def _zeros_f32(n, like):
     return torch.zeros(n, dtype=torch.float32, device=like.device)
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One auxiliary stream per device for optimizer-only work of the Python-composed backward passes."""
+    key = str(device)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 # ------------------------------------------------------------------------------------------------
@@ -533,20 +545,32 @@ class _ConvSubsample(torch.autograd.Function):
         grads = [None] * (4 * L)
         Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[-1]
         dA = dout.view(B * To * Fo, Co)
+        # weight / bias gradients only feed the optimizer: they run on a side stream next to the data-gradient chain
+        # (GEMM + col2im + BatchNorm backward of the next layer down).  Outputs are allocated on the main stream, every
+        # tensor a side kernel reads is kept alive until the join below.
+        cur = torch.cuda.current_stream(X.device)
+        side = _side_stream(X.device)
+        keep = []
         for i in range(L - 1, -1, -1):
             Zi, mr, col, w16, g, beta = per[i]
             Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[i]
             dg, dbeta = _zeros_f32(Co, X), _zeros_f32(Co, X)
             dZ = K.bn_act_bwd(Zi, dA, mr, g, beta, dg, dbeta, "relu", training)
+            keep.append(dZ)
             n = B * To * Fo
+            db = _zeros_f32(Co, X)
             if i == 0:
                 dW = _zeros_f32(Co * 9, X)
-                db = _zeros_f32(Co, X)
-                K.conv1_wgrad(X, dZ, dW, db, B, Tc, Fc, Co, sy, sx)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    K.conv1_wgrad(X, dZ, dW, db, B, Tc, Fc, Co, sy, sx)
                 grads[0] = dW.view(wshapes[0])
             else:
-                dWp = _wgrad(dZ, col, n, Co, 9 * Cc)
-                db = K.colsum(dZ, _zeros_f32(Co, X), n, Co, Co)
+                dWp = torch.empty((Co, 9 * Cc), dtype=torch.float32, device=X.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    _wgrad(dZ, col, n, Co, 9 * Cc, out=dWp)
+                    K.colsum(dZ, db, n, Co, Co)
                 grads[4 * i] = dWp.view(Co, 3, 3, Cc).permute(0, 3, 1, 2)
                 dcol = _new((n, 9 * Cc), torch.bfloat16, X)
                 K.gemm(dZ, w16, dcol, n, 9 * Cc, Co, lda=Co, ldb=9 * Cc, ldc=9 * Cc, b_kstrided=True)
@@ -554,6 +578,8 @@ class _ConvSubsample(torch.autograd.Function):
             grads[4 * i + 1] = db
             grads[4 * i + 2] = dg
             grads[4 * i + 3] = dbeta
+        cur.wait_stream(side)
+        del keep
         return (None,) * 8 + tuple(grads)
 
 
