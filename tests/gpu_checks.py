@@ -1331,3 +1331,129 @@ def check_label_smoothing_known_answers():
             "padding_additivity": abs(float(sm_loss) - float(l1) - float(l2)), "zero_eps": abs(float(nll_loss) - float(z_loss)),
             "nll_closed_form": abs(float(nll_loss) - float(nll_true)), "smooth_closed_form": abs(float(sm_loss) - float(sm_true)),
             "sample_sizes": (nll_ss, sm_ss, both["ntokens"])}
+
+
+# ------------------------------------------------------------------ full-size (BASELINE config 3) property checks
+def check_fullsize_ctc(B=24, T=325, V=5004, seed=0):
+    """CTC at the headline sizes through size-independent properties: the loss of a batch is the sum of the losses of its halves
+    (bit-level independence of utterances), d loss / d logits sums to zero over the vocabulary on valid frames (softmax minus
+    posterior) and is exactly zero on padded frames, losses are finite and positive."""
+    from espresso_amd import functional as F
+
+    g = torch.Generator().manual_seed(seed)
+    logits = (torch.randn(B, T, V, generator=g) * 1.5).to(DEV)
+    in_len = torch.randint(T // 2, T + 1, (B,), generator=g).to(torch.int32)
+    in_len[0] = T
+    Lmax = 60
+    tgt_len = torch.randint(5, Lmax + 1, (B,), generator=g).to(torch.int32)
+    tgt = torch.randint(1, V, (B, Lmax), generator=g).to(torch.int32)
+
+    def run(idx):
+        x = logits[idx].reshape(len(idx) * T, V).clone().requires_grad_(True)
+        nll, _ = F.ctc_loss(x, tgt[idx].to(DEV), in_len[idx].to(DEV), tgt_len[idx].to(DEV), len(idx), T, 0)
+        nll.sum().backward()
+        return nll.detach(), x.grad.view(len(idx), T, V)
+
+    allb = list(range(B))
+    nll, grad = run(allb)
+    n1, g1 = run(allb[: B // 2])
+    n2, g2 = run(allb[B // 2:])
+    torch.cuda.synchronize()
+    valid = (torch.arange(T)[None, :] < in_len[:, None]).to(DEV)
+    rowsum = grad.sum(-1)
+    return {"finite_positive": bool(torch.isfinite(nll).all() and (nll > 0).all()),
+            "halves_nll_abs": float((nll - torch.cat([n1, n2])).abs().max()), "halves_grad_abs": float((grad - torch.cat([g1, g2])).abs().max()),
+            "grad_rowsum_abs": float(rowsum[valid].abs().max()), "pad_grad_abs": float(grad[~valid].abs().max())}
+
+
+def check_fullsize_frontend(seed=0):
+    """24 utterances up to 35 s through the fused front-end: every utterance's features are identical to those of the same
+    utterance processed alone (batch independence incl. padding), frames beyond an utterance are exactly zero, and global
+    CMVN is the affine map it should be."""
+    from espresso_amd.data.feature_transforms import GlobalCMVN
+    from espresso_amd.data.gpu_frontend import GpuFbankFrontend
+
+    rng = np.random.default_rng(seed)
+    secs = np.concatenate([[35.0, 0.03, 1.0], rng.uniform(2.0, 30.0, size=21)])
+    wavs = [(rng.standard_normal(int(16000 * s)) * 2500).astype(np.float32) for s in secs]
+    ns = [len(w) for w in wavs]
+    off = np.zeros(len(ns) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(ns)
+    wav, offs = torch.from_numpy(np.concatenate(wavs)).to(DEV), torch.from_numpy(off).to(DEV)
+    fe = GpuFbankFrontend(DEV)
+    feat, lens, frames = fe(wav, offs, ns, train=False)
+    worst, pad = 0.0, 0.0
+    for b in (0, 1, 2, 7, 23):
+        one, l1, _ = fe(torch.from_numpy(wavs[b]).to(DEV), torch.tensor([0, ns[b]], device=DEV), [ns[b]], train=False)
+        n = int(l1[0])
+        assert n == frames[b]
+        if n:
+            worst = max(worst, float((feat[b, :n] - one[0, :n]).abs().max()))
+        pad = max(pad, float(feat[b, n:].abs().max()) if n < feat.shape[1] else 0.0)
+    mean, std = rng.standard_normal(80) * 3 + 5, rng.random(80) + 1.5
+    fe2 = GpuFbankFrontend(DEV, cmvn=GlobalCMVN(mean=mean, std=std))
+    feat2, _, _ = fe2(wav, offs, ns, train=False)
+    m, s_ = torch.tensor(mean, dtype=torch.float32, device=DEV), torch.tensor(std, dtype=torch.float32, device=DEV)
+    aff = 0.0
+    for b in (0, 7):
+        n = frames[b]
+        aff = max(aff, float((feat2[b, :n] - (feat[b, :n] - m) / s_).abs().max()))
+    return {"batch_independence_abs": worst, "padding_abs": pad, "cmvn_affine_abs": aff, "frames0": frames[0], "frames1": frames[1]}
+
+
+def check_fullsize_attention(B=7, H=8, T=875, seed=0):
+    """Fused rel-pos attention at the longest utterance of the headline workload: with V = 1 every valid query row returns
+    exactly 1 (probabilities sum to one whatever the scores), padded keys get no weight, and the result does not depend on
+    what the padded keys / values contain."""
+    from espresso_amd import kernels as Kk
+
+    g = torch.Generator().manual_seed(seed)
+    C = H * 64
+    klen = torch.tensor([T, T - 1, 700, 512, 333, 65, 1][:B], dtype=torch.int32, device=DEV)
+    qu = (torch.randn(B * T, C, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    qv = (torch.randn(B * T, C, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    kv = torch.randn(B * T, 2 * C, generator=g).to(torch.bfloat16).to(DEV)
+    pp = (torch.randn(2 * T - 1, C, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    ones = kv.clone()
+    ones[:, C:] = 1.0
+    out1, _ = Kk.flash_attention_fwd(qu, qv, ones[:, :C], ones[:, C:], pp, klen, H, B, T, T, C, 2 * C, C)
+    out2, _ = Kk.flash_attention_fwd(qu, qv, kv[:, :C], kv[:, C:], pp, klen, H, B, T, T, C, 2 * C, C)
+    poisoned = kv.clone().view(B, T, 2 * C)
+    for b in range(B):
+        poisoned[b, int(klen[b]):] = 77.0
+    out3, _ = Kk.flash_attention_fwd(qu, qv, poisoned.view(B * T, 2 * C)[:, :C], poisoned.view(B * T, 2 * C)[:, C:], pp, klen, H, B, T, T, C, 2 * C, C)
+    torch.cuda.synchronize()
+    return {"ones_abs": float((out1.float() - 1.0).abs().max()), "pad_independence_abs": float((out2.float() - out3.float()).abs().max()),
+            "finite": bool(torch.isfinite(out2.float()).all())}
+
+
+def check_fullsize_encoder_batch_independence(seed=0):
+    """The full Conformer-12 + CTC model (config 3, random weights, eval mode): the longest utterance's output frames are the same
+    whether it is run alone or at the head of a padded batch of 12 utterances of very different lengths (batch items never mix:
+    attention key lengths, BatchNorm running statistics, LayerNorm rows).  Shorter utterances are NOT compared: like the
+    reference (fairseq ConvolutionModule gets no padding mask, conformer_layer.py:134-146) the depthwise convolution reads the
+    padded frames behind an utterance, so their outputs legitimately depend on the padding length."""
+    import bench
+
+    torch.manual_seed(seed)
+    task, model, _, _ = bench.build(torch.device(DEV), seed=1)
+    model.eval()
+    g = torch.Generator().manual_seed(seed)
+    lens = [1500, 1333, 1200, 997, 801, 640, 512, 400, 256, 130, 64, 17]
+    B, Tm = len(lens), max(lens)
+    feats = torch.zeros(B, Tm, 80)
+    for b, n in enumerate(lens):
+        feats[b, :n] = torch.randn(n, 80, generator=g)
+    feats, ln = feats.to(DEV), torch.tensor(lens, device=DEV)
+    worst, checked = 0.0, 0
+    with torch.no_grad():
+        out = model(feats, ln)
+        lo, ol = out["encoder_out"][0], out["src_lengths"][0]  # T' x B x V
+        for b in (0,):
+            one = model(feats[b:b + 1, : lens[b]].contiguous(), ln[b:b + 1])
+            n = int(one["src_lengths"][0][0])
+            assert n == int(ol[b])
+            worst = max(worst, float((lo[:n, b].float() - one["encoder_out"][0][:n, 0].float()).abs().max()))
+            checked += n
+    scale = float(lo.float().abs().max())
+    return {"abs": worst, "scale": scale, "frames_checked": checked, "finite": bool(torch.isfinite(lo.float()).all())}

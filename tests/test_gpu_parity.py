@@ -324,3 +324,29 @@ def test_label_smoothing_known_answers_of_the_reference_suite():
     for k in ("nll_vs_logging", "nll_vs_smooth_nll", "padding_additivity", "zero_eps", "nll_closed_form", "smooth_closed_form"):
         assert r[k] < 1e-5, (k, r)
     assert r["sample_sizes"] == (5, 5, 5), r
+
+
+# ---- BASELINE config-3 sizes through size-independent properties -------------------------------------------------------------------
+def test_fullsize_ctc_properties():
+    r = G.check_fullsize_ctc()
+    assert r["finite_positive"], r
+    assert r["halves_nll_abs"] == 0.0 and r["halves_grad_abs"] == 0.0, r       # utterances are independent bit for bit
+    assert r["grad_rowsum_abs"] < 2e-4 and r["pad_grad_abs"] == 0.0, r
+
+
+def test_fullsize_frontend_batch_independence():
+    r = G.check_fullsize_frontend()
+    assert r["batch_independence_abs"] == 0.0 and r["padding_abs"] == 0.0, r
+    assert r["cmvn_affine_abs"] < 1e-4, r
+    assert r["frames0"] == 3498 and r["frames1"] == 1, r   # 1 + (N - 400) // 160
+
+
+def test_fullsize_attention_properties():
+    r = G.check_fullsize_attention()
+    assert r["finite"] and r["ones_abs"] < 1.6e-2 and r["pad_independence_abs"] == 0.0, r
+
+
+def test_fullsize_encoder_batch_independence():
+    r = G.check_fullsize_encoder_batch_independence()
+    assert r["finite"] and r["frames_checked"] == 375, r
+    assert r["abs"] <= 3e-2 * max(1.0, r["scale"]), r   # bf16 activations; sums over different tile shapes differ in rounding only
