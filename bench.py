@@ -152,12 +152,16 @@ def main():
     ap.add_argument("--n-utts", type=int, default=20000)
     ap.add_argument("--max-tokens", type=int, default=26000, help="diagnostic only: shrink the batches (host-overhead probes)")
     ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B switch: keep weight-gradient GEMMs on the main stream")
+    ap.add_argument("--no-fused-predrop", action="store_true", help="A/B switch: separate scale+dropout pass per residual block")
     ap.add_argument("--gemm-xcd-mask", type=int, default=None, help="A/B switch: XCD-aware tile order (bit 0 glds kernel, bit 1 register-staged)")
     args = ap.parse_args()
     if args.no_bwd_overlap:
         from espresso_amd._lib import lib as _ealib
         _ealib().ea_set_backward_overlap(0)
 
+    if args.no_fused_predrop:
+        from espresso_amd._lib import lib as _ealib3
+        _ealib3().ea_set_fused_predrop(0)
     if args.gemm_xcd_mask is not None:
         from espresso_amd._lib import lib as _ealib2
         _ealib2().ea_set_gemm_xcd_swizzle(args.gemm_xcd_mask)

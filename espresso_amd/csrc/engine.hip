@@ -169,6 +169,26 @@ static void wt_refresh(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh
   const int rows[8] = {F, F, 3 * C, C, 2 * C, C, C, C}, cols[8] = {C, C, C, C, C, C, F, F};
   RUN(ea_transpose_bf16_batch(src, dst, rows, cols, 8, c.s));
 }
+// what the NEXT residual block of the backward wants as its incoming gradient: a * dropout(dx) with its own mask; produced
+// by the LayerNorm backward of the current block as a second output (no separate pass over the gradient)
+struct Pre {
+  uint16_t* buf;   // nullptr: nothing to produce
+  float a;
+  uint64_t seed;
+  float p;
+};
+static inline void ln_bwd_block(Ctx& c, const void* x, const void* dxn, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, float* dg, float* db, int M, int C, const void* dx_add, const Pre& next) {
+  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
+  if (next.buf)
+    RUN(ea_layernorm_bwd_dx2(x, dxn, gamma, mean, rstd, dx, dg, db, M, C, dx_add, lnws, next.buf, next.a, next.seed, drop_thr(next.p),
+                             drop_scale(next.p), c.s));
+  else
+    RUN(ea_layernorm_bwd_dx(x, dxn, gamma, mean, rstd, dx, dg, db, M, C, nullptr, 0, 0, 1.f, dx_add, lnws, c.s));
+  fork(c);  // the parameter-gradient reduce only feeds the optimizer
+  RUN(ea_layernorm_param_reduce(lnws, dg, db, M, C, wstream(c)));
+}
+
 // data gradient dx[M][N] = dy[M][K] W[K][N]: k-contiguous copy Wt[N][K] when available, else W read k-strided
 static inline void dgrad(Ctx& c, const void* dy, const void* W, const uint16_t* Wt, void* dx, int M, int N, int K) {
   if (Wt) {
@@ -211,14 +231,19 @@ static void ffn_fwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
 }
 
 static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaFfnParams& w, const EaFfnGrads& gw, const void* x,
-                    const void* dy, void* dx, uint64_t seed, float out_scale, int act, const uint16_t* w1t, const uint16_t* w2t) {
+                    const void* dy, void* dx, uint64_t seed, float out_scale, int act, const uint16_t* w1t, const uint16_t* w2t,
+                    const uint16_t* pre, const Pre& next) {
   const int M = sh.B * sh.T, C = sh.C, F = sh.F;
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
   float *mean = f.mean, *rstd = f.rstd;
   uint16_t *xn = f.xn, *z = f.z, *h = f.h;
-  uint16_t* g2 = sc.get<uint16_t>((size_t)M * C);
-  RUN(ea_scale_dropout_bf16(dy, nullptr, g2, (long)M * C, out_scale, 0.f, seed + 2, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+  const uint16_t* g2 = pre;  // out_scale * dropout(dy), already written by the previous block's LayerNorm backward
+  if (!g2) {
+    uint16_t* gb = sc.get<uint16_t>((size_t)M * C);
+    RUN(ea_scale_dropout_bf16(dy, nullptr, gb, (long)M * C, out_scale, 0.f, seed + 2, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+    g2 = gb;
+  }
   fork(c);
   wgrad(c, g2, C, h, F, gw.w2, M, C, F);
   bias_grad(c, g2, gw.b2, M, C, C);
@@ -232,10 +257,7 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   bias_grad(c, dz, gw.b1, M, F, F);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dz, w.w1, w1t, dxn, M, C, F);
-  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd_dx(x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
-  fork(c);  // the parameter-gradient reduce only feeds the optimizer
-  RUN(ea_layernorm_param_reduce(lnws, gw.ln_g, gw.ln_b, M, C, wstream(c)));
+  ln_bwd_block(c, x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, next);
   release(c, mark);
 }
 
@@ -326,7 +348,7 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
 // shared tail of the attention backward: pos_proj / bias / qkv weight gradients, dq = t1 + t2, dgrad to the block input, LN
 static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw,
                           const void* x, const void* dy, void* dx, const void* pe, uint16_t* dqkv, uint16_t* t1, uint16_t* t2,
-                          uint16_t* dBD, const uint16_t* wqkvt) {
+                          uint16_t* dBD, const uint16_t* wqkvt, const Pre& next) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad8(R);
   Arena& sc = *c.scratch;
   // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames
@@ -355,21 +377,20 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
   bias_grad(c, dqkv, gw.bqkv, M, 3 * C, 3 * C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dqkv, w.wqkv, wqkvt, dxn, M, C, 3 * C);
-  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd_dx(x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
-  fork(c);  // the parameter-gradient reduce only feeds the optimizer
-  RUN(ea_layernorm_param_reduce(lnws, gw.ln_g, gw.ln_b, M, C, wstream(c)));
+  ln_bwd_block(c, x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, next);
 }
 
 static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
                      const void* dy, void* dx, const int* key_len, const void* pe, uint64_t seed, const uint16_t* wqkvt,
-                     const uint16_t* wot) {
+                     const uint16_t* wot, const uint16_t* pre, const Pre& next) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
   const float scaling = 1.0f / sqrtf((float)dh);
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
   const void* g = dy;
-  if (sh.p_drop > 0.f) {
+  if (pre) {
+    g = pre;  // dropout(dy), already written by the previous block's LayerNorm backward
+  } else if (sh.p_drop > 0.f) {
     uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
     RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 4, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
     g = gg;
@@ -389,7 +410,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
                                Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, (sh.scratch_clean && c.overlap) ? 2 : 0, scaling, seed + 3,
                                drop_thr(sh.p_attn),
                                drop_scale(sh.p_attn), c.s));
-    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt);
+    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next);
     release(c, mark);
     return;
   }
@@ -415,7 +436,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   G gt2(dBD, a.pp, t2, T, dh, R, Rp, C, C);
   gt2.bks().alpha(scaling).batch(Z, B, (long)B * T * Rp, (long)T * Rp, dh, 0, dh, (long)T * C);
   gemm(c, gt2);
-  attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt);
+  attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next);
   release(c, mark);
 }
 
@@ -460,12 +481,15 @@ static void conv_fwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
 }
 
 static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const EaConvParams& w, const EaConvGrads& gw, const void* x,
-                     const void* dy, void* dx, uint64_t seed, const uint16_t* pw1t, const uint16_t* pw2t) {
+                     const void* dy, void* dx, uint64_t seed, const uint16_t* pw1t, const uint16_t* pw2t, const uint16_t* pre,
+                     const Pre& next) {
   const int B = sh.B, T = sh.T, C = sh.C, M = B * T;
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
   const void* g = dy;
-  if (sh.p_drop > 0.f) {
+  if (pre) {
+    g = pre;
+  } else if (sh.p_drop > 0.f) {
     uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
     RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 5, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
     g = gg;
@@ -487,10 +511,7 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dY, w.pw1, pw1t, dxn, M, C, 2 * C);
-  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd_dx(x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, nullptr, 0, 0, 1.f, dy, lnws, c.s));
-  fork(c);  // the parameter-gradient reduce only feeds the optimizer
-  RUN(ea_layernorm_param_reduce(lnws, gw.ln_g, gw.ln_b, M, C, wstream(c)));
+  ln_bwd_block(c, x, dxn, w.ln_g, s.mean, s.rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, next);
   release(c, mark);
 }
 
@@ -532,6 +553,7 @@ static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   return c.rc;
 }
 
+static bool g_fuse_predrop = true;  // A/B switch (ea_set_fused_predrop)
 static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, const void* x_in, const void* dy, void* dx,
                      const int* key_len, const void* pe, Arena& sv) {
   const int M = sh.B * sh.T, C = sh.C;
@@ -544,16 +566,21 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   uint16_t* dB = sc.get<uint16_t>((size_t)M * C);
   uint16_t* dC = sc.get<uint16_t>((size_t)M * C);
   uint16_t* dD = sc.get<uint16_t>((size_t)M * C);
-  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  RUN(ea_layernorm_bwd_dx(S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, 0, 0,
-                       1.f, nullptr, lnws, c.s));
-  fork(c);  // the parameter-gradient reduce only feeds the optimizer
-  RUN(ea_layernorm_param_reduce(lnws, L->grads.final_ln_g, L->grads.final_ln_b, M, C, wstream(c)));
+  // each block's incoming gradient after its residual dropout (and the 0.5 FFN scale) is written by the LayerNorm backward
+  // that produces the gradient itself (second output) — no separate pass
+  const bool dp = sh.p_drop > 0.f, fz = g_fuse_predrop;
+  uint16_t* pf2 = fz ? sc.get<uint16_t>((size_t)M * C) : nullptr;
+  uint16_t* pcv = fz && dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
+  uint16_t* pat = fz && dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
+  uint16_t* pf1 = fz ? sc.get<uint16_t>((size_t)M * C) : nullptr;
+  const Pre to_ffn2{pf2, 0.5f, seed + 48 + 2, sh.p_drop}, to_conv{pcv, 1.f, seed + 32 + 5, sh.p_drop};
+  const Pre to_attn{pat, 1.f, seed + 16 + 4, sh.p_drop}, to_ffn1{pf1, 0.5f, seed + 0 + 2, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
+  ln_bwd_block(c, S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, to_ffn2);
   const WT wt = wt_view(L, sh);
-  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU, wt.f2w1, wt.f2w2);
-  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32, wt.pw1, wt.pw2);
-  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16, wt.wqkv, wt.wo);
-  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2);
+  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU, wt.f2w1, wt.f2w2, pf2, to_conv);
+  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32, wt.pw1, wt.pw2, pcv, to_attn);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16, wt.wqkv, wt.wo, pat, to_ffn1);
+  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2, pf1, none);
   if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
 }
@@ -603,6 +630,12 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
   Ctx c{stream, false, 0, &sc, nullptr, false};
   if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
   return layer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
+}
+
+int ea_set_fused_predrop(int on) {
+  const int old = g_fuse_predrop;
+  g_fuse_predrop = on != 0;
+  return old;
 }
 
 int ea_set_flash_attention(int on) {

@@ -98,13 +98,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
 
 // Each block owns ROWS_PER_BLOCK consecutive rows (4 waves round-robin), accumulates dgamma/dbeta
 // partials per lane-column, reduces across the 4 waves through LDS and writes one partial row (or issues atomics).
+// optional second output of the backward kernel: out[i] = a * dropout(dx[i]) with its own counter-based mask (the next block's
+// "gradient after the residual dropout"), written from the values that are in registers anyway
+struct LnOut2 {
+  bf16_t* out;
+  float a;
+  uint64_t seed;
+  uint32_t thr;
+  float inv_keep;
+};
 template <int MAXC8>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int rows_per_block,
     const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep,
-    const bf16_t* __restrict__ dx_add, float* __restrict__ partial) {
+    const bf16_t* __restrict__ dx_add, float* __restrict__ partial, const LnOut2 o2) {
   extern __shared__ float red[];  // [4][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
@@ -176,6 +185,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         u.z = pack_bf2(o[4], o[5]);
         u.w = pack_bf2(o[6], o[7]);
         *reinterpret_cast<uint4*>(dx + (long)row * C + ch * 8) = u;
+        if (o2.out) {
+          const uint32_t wu[4] = {u.x, u.y, u.z, u.w};
+          float p2[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dv = (e & 1) ? __uint_as_float(wu[e >> 1] & 0xffff0000u) : __uint_as_float(wu[e >> 1] << 16);  // the rounded dx
+            float kk = 1.f;
+            if (o2.thr) kk = ea_keep(o2.seed, (uint64_t)row * C + ch * 8 + e, o2.thr, o2.inv_keep);
+            p2[e] = o2.a * dv * kk;
+          }
+          uint4 u2;
+          u2.x = pack_bf2(p2[0], p2[1]);
+          u2.y = pack_bf2(p2[2], p2[3]);
+          u2.z = pack_bf2(p2[4], p2[5]);
+          u2.w = pack_bf2(p2[6], p2[7]);
+          *reinterpret_cast<uint4*>(o2.out + (long)row * C + ch * 8) = u2;
+        }
       }
     }
   }
@@ -264,7 +290,8 @@ extern "C" long ea_layernorm_bwd_workspace_bytes(int M, int C) {
 
 static int ln_bwd_launch(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
                          float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
-                         float drop_scale, const void* dx_add, void* workspace, hipStream_t stream, bool reduce_params) {
+                         float drop_scale, const void* dx_add, void* workspace, hipStream_t stream, bool reduce_params,
+                         const LnOut2& o2) {
   if (M <= 0) return 0;
   if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
   const int rpb = ln_bwd_rows_per_block(M, workspace != nullptr);
@@ -272,7 +299,7 @@ static int ln_bwd_launch(const void* x, const void* dy, const float* gamma, cons
 #define EA_LN_BWD(NC)                                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<NC>), dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,                \
                      (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, C, rpb,    \
-                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace)
+                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace, o2)
   if (C <= 512) EA_LN_BWD(1);
   else if (C <= 1024) EA_LN_BWD(2);
   else EA_LN_BWD(4);
@@ -299,7 +326,7 @@ extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamm
                                 const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
                                 float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
   return ln_bwd_launch(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, M, C, row_zero, drop_seed, drop_thr, drop_scale, dx_add,
-                       workspace, stream, true);
+                       workspace, stream, true, LnOut2{nullptr, 1.f, 0, 0, 1.f});
 }
 // dx only (workspace required): the caller runs ea_layernorm_param_reduce later, possibly on another stream
 extern "C" int ea_layernorm_bwd_dx(const void* x, const void* dy, const float* gamma, const float* mean,
@@ -308,5 +335,15 @@ extern "C" int ea_layernorm_bwd_dx(const void* x, const void* dy, const float* g
                                    float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
   if (!workspace) return -2;
   return ln_bwd_launch(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, M, C, row_zero, drop_seed, drop_thr, drop_scale, dx_add,
-                       workspace, stream, false);
+                       workspace, stream, false, LnOut2{nullptr, 1.f, 0, 0, 1.f});
+}
+// ea_layernorm_bwd_dx with a second output out2[i] = a2 * dropout(dx[i]; seed2, thr2, scale2) (same element order and mask
+// as ea_scale_dropout_bf16 applied to dx): saves the separate pass over the gradient that the next residual block starts with
+extern "C" int ea_layernorm_bwd_dx2(const void* x, const void* dy, const float* gamma, const float* mean,
+                                    const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C,
+                                    const void* dx_add, void* workspace, void* out2, float a2, uint64_t seed2, uint32_t thr2,
+                                    float scale2, hipStream_t stream) {
+  if (!workspace) return -2;
+  return ln_bwd_launch(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, M, C, nullptr, 0, 0, 1.f, dx_add, workspace, stream, false,
+                       LnOut2{(bf16_t*)out2, a2, seed2, thr2, scale2});
 }

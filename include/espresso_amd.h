@@ -110,6 +110,12 @@ int ea_layernorm_bwd_dx(const void* x, const void* dy, const float* gamma, const
                         float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero, uint64_t drop_seed,
                         uint32_t drop_thr, float drop_scale, const void* dx_add, void* workspace, ea_stream_t stream);
 int ea_layernorm_param_reduce(const void* workspace, float* dgamma, float* dbeta, int M, int C, ea_stream_t stream);
+/* ea_layernorm_bwd_dx plus a second output out2[i] = a2 * dropout(dx[i]) with its own (seed2, thr2, scale2) mask — exactly
+ * ea_scale_dropout_bf16(dx, NULL, out2, M*C, a2, 0, seed2, thr2, scale2) without the extra pass (the next residual block of
+ * the backward starts with that product: FairseqDropout backward + the 0.5 FFN scale) */
+int ea_layernorm_bwd_dx2(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                         float* dgamma, float* dbeta, int M, int C, const void* dx_add, void* workspace, void* out2, float a2,
+                         uint64_t seed2, uint32_t thr2, float scale2, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming helpers (AMP weight cast fairseq/tasks/fairseq_task.py:516; FairseqDropout backward
@@ -334,6 +340,8 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
 /* tuning / test hook: use the fused attention kernels inside the layer runtime when the shape allows (default on);
  * returns the previous value.  Workspace sizes depend on it. */
 int ea_set_flash_attention(int on);
+/* tuning / test hook: LayerNorm backward writes the next block's dropout-scaled gradient as a second output (default on) */
+int ea_set_fused_predrop(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Look-ahead word LM fusion (csrc/lookahead.hip) — espresso/models/tensorized_lookahead_language_model.py:83-269 over the
