@@ -3,8 +3,9 @@
 espresso/models/transformer/speech_transformer_decoder.py:43-516 /
 fairseq/models/transformer/transformer_decoder.py:254-398 (teacher-forced training path: token + sinusoidal
 positional embedding, optional layernorm_embedding, N pre-LN decoder layers, final LayerNorm, output projection).
-Scheduled sampling (speech_transformer_decoder.py:283-324) is a host-side loop over this forward and is not used
-by the LibriSpeech recipe (scheduled_sampling_probs 1.0)."""
+Scheduled sampling (speech_transformer_decoder.py:254-322): the fed tokens come from a no-grad roll-out on the incremental
+decoding kernels, the training pass is one teacher-forced pass over them (same logits / gradients as the reference's
+step-by-step loop, see `_scheduled_sampling_tokens`)."""
 import math
 
 import torch
@@ -85,8 +86,40 @@ class SpeechTransformerDecoderBase(nn.Module):
             self._pos_cache[key] = tab
         return pos.reshape(-1).contiguous(), tab
 
-    def forward(self, prev_output_tokens, encoder_out=None, features_only=False, **unused):
+    def forward(self, prev_output_tokens, encoder_out=None, features_only=False, **kwargs):
         """-> (logits bf16 (B, U, V) view, extra dict)."""
+        sched = getattr(self, "scheduled_sampling_rate_scheduler", None)
+        if self.training and sched is not None and not features_only:
+            p_true = sched.step(kwargs.get("epoch", 1))
+            if p_true < 1.0:  # speech_transformer_decoder.py:254-271
+                prev_output_tokens = self._scheduled_sampling_tokens(prev_output_tokens, encoder_out, p_true)
+        return self._forward_teacher_forced(prev_output_tokens, encoder_out, features_only)
+
+    @torch.no_grad()
+    def _scheduled_sampling_tokens(self, prev_output_tokens, encoder_out, p_true):
+        """The token sequence the reference's step-by-step loop feeds (speech_transformer_decoder.py:283-322): position 0 is
+        the gold token; at every later step each sentence keeps the gold token with probability `p_true`, otherwise it is fed
+        the arg-max of the previous step's output.  The reference runs that loop WITH gradients through the incremental
+        state; because the decoder is causal, its logits and parameter gradients are exactly those of ONE teacher-forced
+        pass over the fed sequence (the discrete choices carry no gradient), so the roll-out here runs without autograd on
+        the incremental-decoding kernels (no dropout noise in the roll-out) and the training pass follows on the result."""
+        B, U = prev_output_tokens.shape
+        was_training = self.training
+        self.eval()
+        try:
+            st = self.init_incremental(encoder_out, B, 1)
+            fed = prev_output_tokens.clone()
+            for step in range(U):
+                if step > 0:
+                    keep = torch.rand(B, 1, device=fed.device).lt(p_true)
+                    fed[:, step:step + 1] = torch.where(keep, prev_output_tokens[:, step:step + 1], pred)
+                lp = self.step(st, fed[:, : step + 1], step, None)
+                pred = lp.argmax(-1, keepdim=True)
+        finally:
+            self.train(was_training)
+        return fed
+
+    def _forward_teacher_forced(self, prev_output_tokens, encoder_out, features_only=False):
         cfg, tr = self.cfg, self.training
         B, U = prev_output_tokens.shape
         enc = encoder_out["_x_bt"][0] if "_x_bt" in encoder_out else None
@@ -238,6 +271,14 @@ class SpeechTransformerModelBase(nn.Module):
         in_size = conv.output_feat_dim(task.feat_dim // task.feat_in_channels)
         encoder = SpeechTransformerEncoderBase(cfg, pre_encoder=conv, input_size=in_size)
         decoder = SpeechTransformerDecoderBase(cfg, tgt_dict, embed)
+        # speech_transformer_base.py:129-143: probability of feeding the TRUE previous token, per epoch
+        from ..speech_lstm import ScheduledSamplingRateScheduler
+
+        probs = cfg.scheduled_sampling_probs
+        if isinstance(probs, str):  # "[1.0, 0.9]" or "1.0,0.9"
+            probs = [float(x) for x in probs.strip("[]() ").split(",") if x.strip()]
+        decoder.scheduled_sampling_rate_scheduler = ScheduledSamplingRateScheduler(
+            [float(x) for x in probs], getattr(cfg, "start_scheduled_sampling_epoch", 1))
         return cls(cfg, encoder, decoder)
 
     def set_num_updates(self, n):
@@ -246,7 +287,7 @@ class SpeechTransformerModelBase(nn.Module):
 
     def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
         encoder_out = self.encoder(src_tokens, src_lengths)
-        return self.decoder(prev_output_tokens, encoder_out=encoder_out)
+        return self.decoder(prev_output_tokens, encoder_out=encoder_out, epoch=kwargs.get("epoch", 1))
 
     def forward_encoder(self, src_tokens, src_lengths):
         return self.encoder(src_tokens, src_lengths)

@@ -2,7 +2,7 @@
 (espresso/models/transformer/speech_transformer_config.py:28-365, fairseq/models/transformer/transformer_config.py).
 Only fields that affect the ASR hot path are carried; YAML keys of the recipes map 1:1."""
 from dataclasses import dataclass, field
-from typing import Optional
+from typing import List, Optional
 
 DEFAULT_MAX_SOURCE_POSITIONS = 10240
 DEFAULT_MAX_TARGET_POSITIONS = 1024
@@ -68,8 +68,8 @@ class SpeechTransformerConfig:
     no_token_positional_embeddings: bool = False
     layernorm_embedding: bool = False
     no_scale_embedding: bool = False
-    scheduled_sampling_probs: str = "1.0"
-    scheduled_sampling_start_epoch: int = 1
+    scheduled_sampling_probs: List[float] = field(default_factory=lambda: [1.0])  # P(feed the true token) per epoch
+    start_scheduled_sampling_epoch: int = 1
 
     @classmethod
     def from_dict(cls, d):

@@ -1457,3 +1457,42 @@ def check_fullsize_encoder_batch_independence(seed=0):
             checked += n
     scale = float(lo.float().abs().max())
     return {"abs": worst, "scale": scale, "frames_checked": checked, "finite": bool(torch.isfinite(lo.float()).all())}
+
+
+def check_scheduled_sampling_transformer():
+    """Attention enc-dec (Transformer decoder) with scheduled sampling: p -> 1 reproduces teacher forcing; p = 0 feeds the
+    model's own arg-max from step 1 on — the fed tokens equal an explicit greedy roll-out built from full teacher-forced
+    passes, logits equal the teacher-forced logits on that sequence, gradients reach the embedding."""
+    torch.manual_seed(0)
+    g = np.load(os.path.join(GOLD, "ref_transformer_encdec_tiny.npz"))
+    model = build_tiny_encdec().to(DEV)
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    feats, lengths, prev = (torch.from_numpy(g[k]).to(DEV) for k in ("feats", "lengths", "prev"))
+    model.train()
+    sch = model.decoder.scheduled_sampling_rate_scheduler
+    lo_tf, _ = model(feats, lengths, prev)
+    sch.scheduled_sampling_probs = [0.999999]
+    lo_p1, _ = model(feats, lengths, prev, epoch=1)
+    # explicit greedy roll-out with full passes (the sub-sampler's BatchNorm is in training mode in both paths)
+    sch.scheduled_sampling_probs = [1.0]
+    roll = prev.clone()
+    with torch.no_grad():
+        for j in range(1, prev.shape[1]):
+            cur, _ = model(feats, lengths, roll)
+            roll[:, j] = cur[:, j - 1].argmax(-1)
+        lo_roll, _ = model(feats, lengths, roll)
+    sch.scheduled_sampling_probs = [0.0]
+    enc = model.encoder(feats, lengths)
+    fed = model.decoder._scheduled_sampling_tokens(prev, enc, 0.0)
+    for p_ in model.parameters():
+        p_.grad = None
+    lo_p0, _ = model(feats, lengths, prev, epoch=1)
+    lo_p0.float().square().mean().backward()
+    torch.cuda.synchronize()
+    finite = all(bool(torch.isfinite(p_.grad).all()) for p_ in model.parameters() if p_.grad is not None)
+    sch.scheduled_sampling_probs = [1.0]
+    return {"p1_vs_teacher_forcing": float((lo_p1.float() - lo_tf.float()).abs().max()),
+            "fed_tokens_equal_rollout": float((fed == roll).float().mean()),
+            "p0_vs_rollout_logits": float((lo_p0.float() - lo_roll.float()).abs().max()), "finite": finite,
+            "embed_grad": float(model.decoder.embed_tokens.weight.grad.abs().sum()) > 0, "n_sampled": int((fed != prev).sum())}

@@ -350,3 +350,11 @@ def test_fullsize_encoder_batch_independence():
     r = G.check_fullsize_encoder_batch_independence()
     assert r["finite"] and r["frames_checked"] == 375, r
     assert r["abs"] <= 3e-2 * max(1.0, r["scale"]), r   # bf16 activations; sums over different tile shapes differ in rounding only
+
+
+def test_scheduled_sampling_transformer_decoder():
+    r = G.check_scheduled_sampling_transformer()
+    assert r["p1_vs_teacher_forcing"] == 0.0, r
+    assert r["fed_tokens_equal_rollout"] >= 0.9 and r["finite"] and r["embed_grad"] and r["n_sampled"] > 0, r
+    if r["fed_tokens_equal_rollout"] == 1.0:   # same fed sequence -> same training pass
+        assert r["p0_vs_rollout_logits"] < 5e-2, r
