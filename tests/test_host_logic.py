@@ -4,6 +4,7 @@ convert_padding_direction / edit_distance; tests/test_data_utils.py:13-136 batch
 baseline) plus dictionary layout, lr schedule, SpecAugment RNG order and registry names."""
 from collections import Counter
 
+import math
 import numpy as np
 import pytest
 import torch
@@ -411,3 +412,64 @@ def test_layer_runtime_rejects_short_arenas_before_launching():
                                       null) == -5
     sh.T = 5000  # beyond the runtime's limit: shape error, not a crash
     assert lib.ea_conformer_layer_workspace(ctypes.byref(sh), ctypes.byref(a), ctypes.byref(b)) == -2
+
+
+# ---- learning-rate schedules named by the recipes (formulas of the reference classes, torch's plateau logic as the oracle) ----
+class _Opt:
+    def __init__(self):
+        self.lr = None
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+    def get_lr(self):
+        return self.lr
+
+
+def test_tri_stage_schedule_matches_reference_formulas():
+    from espresso_amd.optim.lr_schedulers import TriStageLRSchedule
+
+    o = _Opt()
+    s = TriStageLRSchedule(o, lr=1e-3, warmup_steps=2200, hold_steps=80000, decay_steps=100000)  # transformer_librispeech.yaml
+    assert o.lr == pytest.approx(1e-5)
+    assert s.step_update(1100) == pytest.approx(1e-5 + (1e-3 - 1e-5) * 1100 / 2200)
+    assert s.step_update(2200) == pytest.approx(1e-3) and s.step_update(50000) == pytest.approx(1e-3)
+    assert s.step_update(82200 + 50000) == pytest.approx(1e-3 * math.exp(math.log(0.01) * 0.5))
+    assert s.step_update(182200) == pytest.approx(1e-5) and s.step_update(10 ** 7) == pytest.approx(1e-5)
+    s2 = TriStageLRSchedule(_Opt(), lr=2.0, phase_ratio=(0.1, 0.4, 0.5), max_update=1000)
+    assert (s2.warmup_steps, s2.hold_steps, s2.decay_steps) == (100, 400, 500)
+
+
+def test_polynomial_decay_v2_schedule():
+    from espresso_amd.optim.lr_schedulers import PolynomialDecayV2LRSchedule
+
+    o = _Opt()
+    s = PolynomialDecayV2LRSchedule(o, lr=0.002, warmup_updates=1000, end_learning_rate=1e-5, power=2.0, total_num_update=10000)
+    assert o.lr == pytest.approx(0.002 / 1000)
+    assert s.step_update(500) == pytest.approx(0.001)
+    assert s.step_update(5500) == pytest.approx((0.002 - 1e-5) * 0.5 ** 2 + 1e-5)
+    assert s.step_update(10000) == pytest.approx(1e-5) and s.step_update(99999) == pytest.approx(1e-5)
+
+
+def test_reduce_lr_on_plateau_v2_follows_torch_plateau_logic():
+    from espresso_amd.optim.lr_schedulers import ReduceLROnPlateauLRScheduleV2
+
+    losses = [5.0, 4.0, 4.0, 3.99999, 4.2, 3.0, 3.1, 3.2, 3.3, 2.0, 2.0, 2.0, 2.0, 2.0]
+    o = _Opt()
+    s = ReduceLROnPlateauLRScheduleV2(o, lr=0.1, lr_shrink=0.5, lr_patience=1, start_reduce_lr_epoch=3, final_lr_scale=0.1)
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.SGD([p], lr=0.1)
+    tsch = torch.optim.lr_scheduler.ReduceLROnPlateau(topt, patience=1, factor=0.5, mode="min", threshold=1e-4, min_lr=0.01)
+    for epoch, l in enumerate(losses, start=1):
+        got = s.step(epoch, l)
+        if epoch < 3:  # the reference only records the epoch and keeps lr[0] before start_reduce_lr_epoch
+            tsch.last_epoch = epoch
+            assert got == pytest.approx(0.1)
+        else:
+            tsch.step(l)
+            assert got == pytest.approx(topt.param_groups[0]["lr"]), (epoch, got)
+    assert o.lr == pytest.approx(0.01)  # shrunk 0.1 -> 0.05 -> 0.025 -> 0.0125 -> floor final_lr_scale * lr
+    w = ReduceLROnPlateauLRScheduleV2(_Opt(), lr=0.1, warmup_updates=10)
+    assert w.optimizer.lr == 0 and w.step_update(5) == pytest.approx(0.05) and w.step_update(10) == pytest.approx(0.1)
+    w.step_update(11)
+    assert w.warmup_end
