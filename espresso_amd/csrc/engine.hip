@@ -312,11 +312,19 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   G gq(a.xn, w.wqkv, a.qkv, M, 3 * C, C, C, C, 3 * C);
   gq.bias(w.bqkv);
   gemm(c, gq);
-  RUN(ea_relpos_q_prep(a.qkv, 3 * C, w.pos_u, w.pos_v, a.qu, a.qv, M, C, scaling, c.s));
+  // positional mode 1 (learned relative table, multihead_attention.py:806-818): `pe` IS the bf16 [2T-1][C] slice of the table,
+  // plain scaled queries for both terms, no pos_proj / pos_bias_u / pos_bias_v
+  const bool learned = sh.pos_mode == 1;
+  const uint16_t* pp = learned ? (const uint16_t*)pe : a.pp;
+  const uint16_t* qvv = learned ? a.qu : a.qv;
+  if (learned) RUN(ea_relpos_q_prep(a.qkv, 3 * C, nullptr, nullptr, a.qu, nullptr, M, C, scaling, c.s));
+  else RUN(ea_relpos_q_prep(a.qkv, 3 * C, w.pos_u, w.pos_v, a.qu, a.qv, M, C, scaling, c.s));
   if (attn_fused(sh)) {
-    G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
-    gemm(c, gpp);
-    RUN(ea_flash_attention_fwd(a.qu, a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, a.pp, C, key_len, a.o, C, a.lse, H, B, T, T, dh, 0,
+    if (!learned) {
+      G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
+      gemm(c, gpp);
+    }
+    RUN(ea_flash_attention_fwd(a.qu, qvv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, pp, C, key_len, a.o, C, a.lse, H, B, T, T, dh, 0,
                                seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
     G go(a.o, w.wo, y, M, C, C, C, C, C);
     go.bias(w.bo).drop(sh.p_drop, seed + 4).resid(x, C);
@@ -329,9 +337,11 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   G gac(a.qu, a.qkv + C, ac, T, T, dh, C, 3 * C, Sp);
   gac.f32().batch(Z, B, dh, (long)T * C, dh, (long)T * 3 * C, (long)B * T * Sp, (long)T * Sp);
   gemm(c, gac);
-  G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
-  gemm(c, gpp);
-  G gbd(a.qv, a.pp, bd, T, R, dh, C, C, Rp);
+  if (!learned) {
+    G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
+    gemm(c, gpp);
+  }
+  G gbd(qvv, pp, bd, T, R, dh, C, C, Rp);
   gbd.f32().batch(Z, B, dh, (long)T * C, dh, 0, (long)B * T * Rp, (long)T * Rp);
   gemm(c, gbd);
   RUN(ea_relpos_softmax_fwd(ac, bd, key_len, attn_mask, a.P, sh.p_attn > 0.f ? a.Pd : nullptr, H, B, T, T, Sp, Rp, Sp, 0,
@@ -348,29 +358,33 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
 // shared tail of the attention backward: pos_proj / bias / qkv weight gradients, dq = t1 + t2, dgrad to the block input, LN
 static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw,
                           const void* x, const void* dy, void* dx, const void* pe, uint16_t* dqkv, uint16_t* t1, uint16_t* t2,
-                          uint16_t* dBD, const uint16_t* wqkvt, const Pre& next) {
+                          uint16_t* dBD, const uint16_t* wqkvt, const Pre& next, float* dpe) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad8(R);
   Arena& sc = *c.scratch;
+  const bool learned = sh.pos_mode == 1;
   // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames
   // -> split-K into fp32, then one cast to bf16 for the pos_proj weight gradient
-  uint16_t* dpp = sc.get<uint16_t>((size_t)R * C);
+  uint16_t* dpp = learned ? nullptr : sc.get<uint16_t>((size_t)R * C);
   {
-    float* dpp32 = sc.get<float>((size_t)R * C);
+    // learned table: the fp32 result IS the gradient of the table slice (written to the caller's buffer)
+    float* dpp32 = learned ? dpe : sc.get<float>((size_t)R * C);
     const int tiles = ((R + 127) / 128) * H;
     int sk = (768 + tiles - 1) / tiles;
     if (sk > (B * T) / 256) sk = (B * T) / 256;
     if (sk < 1) sk = 1;
-    G gpp(dBD, a.qv, dpp32, R, dh, B * T, Rp, C, C);
+    G gpp(dBD, learned ? a.qu : a.qv, dpp32, R, dh, B * T, Rp, C, C);
     gpp.aks().bks().f32().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
     gpp.p.splitk = sk;
     if (sk > 1) gpp.p.workspace = sc.get<float>((size_t)sk * H * R * dh);
     fork(c);  // dBD, qv ready: the whole pos_proj gradient chain is optimizer-only
     gemm_on(c, gpp, wstream(c));
-    RUN(ea_cast_f32_to_bf16(dpp32, dpp, (long)R * C, wstream(c)));
+    if (!learned) RUN(ea_cast_f32_to_bf16(dpp32, dpp, (long)R * C, wstream(c)));
   }
-  wgrad(c, dpp, C, pe, C, gw.wpos, R, C, C);
-  bias_grad(c, t1, gw.pos_u, M, C, C);
-  bias_grad(c, t2, gw.pos_v, M, C, C);
+  if (!learned) {
+    wgrad(c, dpp, C, pe, C, gw.wpos, R, C, C);
+    bias_grad(c, t1, gw.pos_u, M, C, C);
+    bias_grad(c, t2, gw.pos_v, M, C, C);
+  }
   RUN(ea_add2_strided_bf16(t1, C, t2, C, dqkv, 3 * C, M, C, c.s));
   fork(c);
   wgrad(c, dqkv, 3 * C, a.xn, C, gw.wqkv, M, 3 * C, C);
@@ -382,7 +396,7 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
 
 static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
                      const void* dy, void* dx, const int* key_len, const void* pe, uint64_t seed, const uint16_t* wqkvt,
-                     const uint16_t* wot, const uint16_t* pre, const Pre& next) {
+                     const uint16_t* wot, const uint16_t* pre, const Pre& next, float* dpe = nullptr) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
   const float scaling = 1.0f / sqrtf((float)dh);
   Arena& sc = *c.scratch;
@@ -406,11 +420,12 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     uint16_t* t2 = sc.get<uint16_t>((size_t)M * C);
     uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
     float* Dd = sc.get<float>((size_t)Z * T);
-    RUN(ea_flash_attention_bwd(a.qu, a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
+    RUN(ea_flash_attention_bwd(a.qu, sh.pos_mode == 1 ? a.qu : a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C,
+                               sh.pos_mode == 1 ? (const uint16_t*)pe : a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
                                Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, (sh.scratch_clean && c.overlap) ? 2 : 0, scaling, seed + 3,
                                drop_thr(sh.p_attn),
                                drop_scale(sh.p_attn), c.s));
-    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next);
+    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next, dpe);
     release(c, mark);
     return;
   }
@@ -433,10 +448,10 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   gt1.bks().alpha(scaling).batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * 3 * C, dh, (long)T * C);
   gemm(c, gt1);
   uint16_t* t2 = sc.get<uint16_t>((size_t)M * C);
-  G gt2(dBD, a.pp, t2, T, dh, R, Rp, C, C);
+  G gt2(dBD, sh.pos_mode == 1 ? (const uint16_t*)pe : a.pp, t2, T, dh, R, Rp, C, C);
   gt2.bks().alpha(scaling).batch(Z, B, (long)B * T * Rp, (long)T * Rp, dh, 0, dh, (long)T * C);
   gemm(c, gt2);
-  attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next);
+  attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next, dpe);
   release(c, mark);
 }
 
@@ -585,6 +600,68 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   return c.rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Transformer encoder layer (pre-LN) — fairseq/modules/transformer_layer.py:135-214 as used by
+// espresso/models/transformer/speech_transformer_encoder.py (layer_type "transformer"):
+//   x = x + dropout(self_attn(LN(x)));  x = x + dropout(fc2(dropout_act(act(fc1(LN(x))))))
+// = the attention block and one FFN block of the Conformer runtime (out_scale 1, activation from the shape).  Uses the
+// `attn` and `ffn1` members of EaConformerLayer.  Saved order: [x1][attn][ffn].
+struct TLayerSaved {
+  uint16_t* x1;
+  AttnSaved at;
+  FfnSaved f;
+};
+static TLayerSaved tlayer_saved(Arena& sv, const EaLayerShape& sh) {
+  TLayerSaved L;
+  L.x1 = sv.get<uint16_t>((size_t)sh.B * sh.T * sh.C);
+  L.at = attn_saved(sv, sh);
+  L.f = ffn_saved(sv, sh);
+  return L;
+}
+// k-contiguous weight copies of the transformer layer: [fc1^T (C x F)][wqkv^T (C x 3C)][wo^T (C x C)][fc2^T (F x C)]
+static WT twt_view(const EaConformerLayer* L, const EaLayerShape& sh) {
+  WT w{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!L->wt || !sh.training) return w;
+  const size_t C = sh.C, F = sh.F;
+  const uint16_t* p = (const uint16_t*)L->wt;
+  w.f1w1 = p; p += C * F;
+  w.wqkv = p; p += 3 * C * C;
+  w.wo = p; p += C * C;
+  w.f1w2 = p;
+  return w;
+}
+static int tlayer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, const void* x_in, void* x_out, const int* key_len,
+                      const float* attn_mask, const void* pe, Arena& sv) {
+  TLayerSaved S = tlayer_saved(sv, sh);
+  const uint64_t seed = sh.seed;
+  attn_fwd(c, S.at, sh, L->attn, x_in, S.x1, key_len, attn_mask, pe, seed + 16);
+  ffn_fwd(c, S.f, sh, L->ffn1, S.x1, x_out, seed + 0, 1.f, sh.act);
+  const WT w = twt_view(L, sh);
+  if (w.f1w1) {
+    const int C = sh.C, F = sh.F;
+    const void* src[4] = {L->ffn1.w1, L->attn.wqkv, L->attn.wo, L->ffn1.w2};
+    void* dst[4] = {(void*)w.f1w1, (void*)w.wqkv, (void*)w.wo, (void*)w.f1w2};
+    const int rows[4] = {F, 3 * C, C, C}, cols[4] = {C, C, C, F};
+    RUN(ea_transpose_bf16_batch(src, dst, rows, cols, 4, c.s));
+  }
+  return c.rc;
+}
+static int tlayer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, const void* x_in, const void* dy, void* dx,
+                      const int* key_len, const void* pe, float* dpe, Arena& sv) {
+  const int M = sh.B * sh.T, C = sh.C;
+  TLayerSaved S = tlayer_saved(sv, sh);
+  Arena& sc = *c.scratch;
+  const uint64_t seed = sh.seed;
+  uint16_t* dA = sc.get<uint16_t>((size_t)M * C);
+  uint16_t* pat = sh.p_drop > 0.f ? sc.get<uint16_t>((size_t)M * C) : nullptr;
+  const Pre to_attn{pat, 1.f, seed + 16 + 4, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
+  const WT wt = twt_view(L, sh);
+  ffn_bwd(c, S.f, sh, L->ffn1, L->grads.ffn1, S.x1, dy, dA, seed + 0, 1.f, sh.act, wt.f1w1, wt.f1w2, nullptr, to_attn);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, x_in, dA, dx, key_len, pe, seed + 16, wt.wqkv, wt.wo, pat, none, dpe);
+  if (c.overlap) stream_wait(c, c.s, c.side);
+  return c.rc;
+}
+
 static bool g_overlap_default = true;
 int ea_set_backward_overlap(int on) {
   const int old = g_overlap_default;
@@ -611,12 +688,15 @@ int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, l
 }
 
 // arena capacities are checked with a dry (sizing) pass before anything is launched
-static bool arenas_fit(const EaLayerShape& sh, bool backward, bool overlap, long saved_bytes, long scratch_bytes) {
+static bool arenas_fit(const EaLayerShape& sh, bool backward, bool overlap, long saved_bytes, long scratch_bytes, bool transformer = false) {
   EaConformerLayer L;
   memset(&L, 0, sizeof(L));
   Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
   Ctx c{nullptr, true, 0, &sc, nullptr, overlap};
-  if (backward) layer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+  if (transformer) {
+    if (backward) tlayer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+    else tlayer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+  } else if (backward) layer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
   else layer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
   return (long)sv.peak <= saved_bytes && (long)sc.peak <= scratch_bytes;
 }
@@ -654,6 +734,44 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
   if (ov) stream_wait(c, c.side, c.s);
   return layer_bwd(c, layer, *shape, x_in, dy, dx, key_len, pe, sv);
+}
+
+int ea_transformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes) {
+  if (!shape_ok(*shape)) return -2;
+  EaConformerLayer L;
+  memset(&L, 0, sizeof(L));
+  Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
+  Ctx c{nullptr, true, 0, &sc, nullptr, g_overlap_default};
+  tlayer_fwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+  Arena sv2{nullptr, 0, 0};
+  tlayer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sv2);
+  *saved_bytes = (long)sv.peak + 256;
+  *scratch_bytes = (long)sc.peak + 256;
+  return 0;
+}
+
+int ea_transformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
+                             const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
+                             void* scratch, long scratch_bytes, hipStream_t stream) {
+  if (!shape_ok(*shape)) return -2;
+  if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
+  if (!arenas_fit(*shape, false, false, saved_bytes, scratch_bytes, true)) return -5;
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
+  Ctx c{stream, false, 0, &sc, nullptr, false};
+  return tlayer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
+}
+
+int ea_transformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy, void* dx,
+                             const int* key_len, const void* pe, float* dpe, void* saved, long saved_bytes, void* scratch,
+                             long scratch_bytes, hipStream_t stream) {
+  if (!shape_ok(*shape)) return -2;
+  if ((shape->pos_mode == 1) != (dpe != nullptr)) return -2;
+  const bool ov = g_overlap_default && side_init();
+  if (!arenas_fit(*shape, true, ov, saved_bytes, scratch_bytes, true)) return -5;
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
+  Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
+  if (ov) stream_wait(c, c.side, c.s);
+  return tlayer_bwd(c, layer, *shape, x_in, dy, dx, key_len, pe, dpe, sv);
 }
 
 }  // extern "C"

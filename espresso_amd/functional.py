@@ -607,12 +607,13 @@ class _LayerBinding:
     """ctypes view of one ConformerWithRelativePositionalEmbeddingEncoderLayer's parameters / gradients.
     Keeps the tensors it points to alive; rebuilt when the underlying storage changes."""
 
-    def __init__(self, m):
+    def __init__(self, m, kind="conformer"):
         import ctypes
 
         from ._lib import EaConformerLayer
 
         self.keep = []
+        self.kind = kind
         L = EaConformerLayer()
 
         def w16(p, shape=None):
@@ -632,11 +633,20 @@ class _LayerBinding:
             gdst.ln_g, gdst.ln_b = grad(f.layer_norm.weight), grad(f.layer_norm.bias)
             gdst.w1, gdst.b1, gdst.w2, gdst.b2 = grad(f.w_1.weight), grad(f.w_1.bias), grad(f.w_2.weight), grad(f.w_2.bias)
 
-        ffn(L.ffn1, L.grads.ffn1, m.ffn1)
-        ffn(L.ffn2, L.grads.ffn2, m.ffn2)
-        # k-contiguous copies of eight weights for the backward data-gradient GEMMs (refreshed by every training forward)
-        Cm, Fm = m.embed_dim, m.ffn1.w_1.weight.shape[0]
-        self.wt = torch.empty(4 * Cm * Fm + 7 * Cm * Cm, dtype=torch.bfloat16, device=m.ffn1.w_1.weight.device)
+        if kind == "conformer":
+            ffn(L.ffn1, L.grads.ffn1, m.ffn1)
+            ffn(L.ffn2, L.grads.ffn2, m.ffn2)
+            # k-contiguous copies of eight weights for the backward data-gradient GEMMs (refreshed by every training forward)
+            Cm, Fm = m.embed_dim, m.ffn1.w_1.weight.shape[0]
+            self.wt = torch.empty(4 * Cm * Fm + 7 * Cm * Cm, dtype=torch.bfloat16, device=m.ffn1.w_1.weight.device)
+        else:  # Transformer layer: (final_layer_norm, fc1, fc2) is the FFN block
+            f1, gf = L.ffn1, L.grads.ffn1
+            f1.ln_g, f1.ln_b = _ptr(m.final_layer_norm.weight), _ptr(m.final_layer_norm.bias)
+            f1.w1, f1.b1, f1.w2, f1.b2 = w16(m.fc1.weight), _ptr(m.fc1.bias), w16(m.fc2.weight), _ptr(m.fc2.bias)
+            gf.ln_g, gf.ln_b = grad(m.final_layer_norm.weight), grad(m.final_layer_norm.bias)
+            gf.w1, gf.b1, gf.w2, gf.b2 = grad(m.fc1.weight), grad(m.fc1.bias), grad(m.fc2.weight), grad(m.fc2.bias)
+            Cm, Fm = m.embed_dim, m.fc1.weight.shape[0]
+            self.wt = torch.empty(2 * Cm * Fm + 4 * Cm * Cm, dtype=torch.bfloat16, device=m.fc1.weight.device)
         L.wt = self.wt.data_ptr()
         a = m.self_attn
         qw, kw, vw = a.q_proj.weight, a.k_proj.weight, a.v_proj.weight
@@ -674,12 +684,23 @@ class _LayerBinding:
         A, GA = L.attn, L.grads.attn
         A.ln_g, A.ln_b = _ptr(m.self_attn_layer_norm.weight), _ptr(m.self_attn_layer_norm.bias)
         A.wqkv, A.bqkv, A.wo, A.bo = wqkv16.data_ptr(), bq_ptr, w16(a.out_proj.weight), _ptr(a.out_proj.bias)
-        A.pos_u, A.pos_v, A.wpos = _ptr(a.pos_bias_u), _ptr(a.pos_bias_v), w16(a.pos_proj.weight)
         GA.ln_g, GA.ln_b = grad(m.self_attn_layer_norm.weight), grad(m.self_attn_layer_norm.bias)
         GA.wqkv, GA.bqkv, GA.wo, GA.bo = gw, gb_ptr, grad(a.out_proj.weight), grad(a.out_proj.bias)
-        GA.pos_u, GA.pos_v, GA.wpos = grad(a.pos_bias_u), grad(a.pos_bias_v), grad(a.pos_proj.weight)
+        if a.pos_proj is not None:  # sinusoidal table projected per layer; a learned table needs none of these
+            A.pos_u, A.pos_v, A.wpos = _ptr(a.pos_bias_u), _ptr(a.pos_bias_v), w16(a.pos_proj.weight)
+            GA.pos_u, GA.pos_v, GA.wpos = grad(a.pos_bias_u), grad(a.pos_bias_v), grad(a.pos_proj.weight)
         for p in (qw, kw, vw, qb, kb, vb):
             grad(p)
+        self.saved_buf, self.saved_busy = None, False
+        self.L = L
+        if kind != "conformer":
+            # parameters whose gradients the runtime writes itself (a learned positional table gets its gradient through
+            # autograd instead and must not be reported as ready here)
+            mods = [a.q_proj, a.k_proj, a.v_proj, a.out_proj, m.self_attn_layer_norm, m.fc1, m.fc2, m.final_layer_norm]
+            self.params = [p for mod in mods for p in mod.parameters()]
+            if a.pos_proj is not None:
+                self.params += [a.pos_bias_u, a.pos_bias_v, a.pos_proj.weight]
+            return
         cm = m.conv_module
         Cc, GC = L.conv, L.grads.conv
         Cdim = m.embed_dim
@@ -799,6 +820,87 @@ def _scratch_buffer(nbytes, device):
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf
+
+
+class _TransformerLayerNative(torch.autograd.Function):
+    """Whole pre-LN Transformer encoder layer (rel-pos MHA block + FFN block) per C-ABI call: ea_transformer_layer_fwd / _bwd.
+    `pe`: bf16 constant sinusoidal slice, or the fp32 autograd slice of a learned table (its gradient is returned)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, module, key_len, attn_mask, B, T, p_drop, p_act, p_attn, training, act):
+        import ctypes
+
+        from . import _lib
+        from ._lib import EaLayerShape
+
+        bind = getattr(module, "_ea_binding", None)
+        qw = module.self_attn.q_proj.weight
+        if bind is None or bind.key != (qw.data_ptr(), qw.grad.data_ptr() if qw.grad is not None else 0):
+            bind = _LayerBinding(module, kind="transformer")
+            module._ea_binding = bind if bind.cacheable else None
+        learned = pe.dtype == torch.float32
+        pe16 = K.cast_f32_to_bf16(pe.detach().contiguous()) if learned else pe
+        sh = EaLayerShape()
+        sh.B, sh.T, sh.C, sh.H = B, T, module.embed_dim, module.num_heads
+        sh.F, sh.KW = module.fc1.weight.shape[0], 0
+        sh.training = int(training)
+        sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
+        sh.seed = _next_seed() * 64 % (1 << 63)
+        sh.has_attn_mask = int(attn_mask is not None)
+        sh.pos_mode = 1 if learned else 0
+        sh.act = K._ACT[act] if isinstance(act, str) else int(act)
+        nb_saved, nb_scratch = ctypes.c_long(0), ctypes.c_long(0)
+        lib = _lib.lib()
+        _lib.check(lib.ea_transformer_layer_workspace(ctypes.byref(sh), ctypes.byref(nb_saved), ctypes.byref(nb_scratch)), "workspace")
+        needs_bwd = ctx.needs_input_grad[0]
+        if bind.saved_busy or not bind.cacheable:
+            saved = torch.empty(nb_saved.value, dtype=torch.uint8, device=x.device)
+            ctx.owns_arena = False
+        else:
+            if bind.saved_buf is None or bind.saved_buf.numel() < nb_saved.value or bind.saved_buf.device != x.device:
+                bind.saved_buf = torch.empty(int(nb_saved.value * 1.1) + 4096, dtype=torch.uint8, device=x.device)
+            saved = bind.saved_buf
+            bind.saved_busy = bool(needs_bwd)
+            ctx.owns_arena = bool(needs_bwd)
+        scratch = _scratch_buffer(nb_scratch.value, x.device)
+        _scratch_tag[str(x.device)] = None
+        y = torch.empty_like(x)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.ea_transformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
+                                                _ptr(pe16), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
+                   "ea_transformer_layer_fwd")
+        ctx.save_for_backward(x, saved, pe16, key_len)
+        ctx.bind, ctx.sh, ctx.nb_scratch, ctx.learned = bind, sh, nb_scratch.value, learned
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+
+        from . import _lib
+
+        x, saved, pe16, key_len = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dpe = torch.empty(pe16.shape, dtype=torch.float32, device=x.device) if ctx.learned else None
+        scratch = _scratch_buffer(ctx.nb_scratch, x.device)
+        sh = ctx.sh
+        tag = ("transformer", scratch.data_ptr(), ctx.nb_scratch, sh.B, sh.T, sh.C, sh.H, sh.F, sh.training, sh.has_attn_mask,
+               sh.pos_mode, sh.p_drop > 0, sh.p_act > 0, sh.p_attn > 0)
+        sh.scratch_clean = int(_scratch_tag.get(str(x.device)) == tag)
+        _scratch_tag[str(x.device)] = tag
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().ea_transformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
+                                                       _ptr(pe16), _ptr(dpe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(),
+                                                       stream), "ea_transformer_layer_bwd")
+        if ctx.owns_arena:
+            ctx.bind.saved_busy = False
+        ctx.bind.finish_backward()
+        return (dx, dpe) + (None,) * 10
+
+
+def transformer_layer_native(x, pe, module, key_len, attn_mask, B, T, p_drop, p_act, p_attn, training, act):
+    return _TransformerLayerNative.apply(x, pe, module, key_len, attn_mask, B, T, p_drop, p_act, p_attn, training, act)
 
 
 def conformer_layer_native(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):

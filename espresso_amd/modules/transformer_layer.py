@@ -28,6 +28,8 @@ class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         self.final_layer_norm = LayerNormParams(d)
         self.activation_fn = cfg.activation_fn
 
+    use_native_runtime = True  # whole layer per C-ABI call (csrc/engine.hip); False: per-kernel composition
+
     def forward(self, x, B, T, key_len=None, attn_mask=None):
         cfg = self.cfg
         tr = self.training
@@ -36,6 +38,9 @@ class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         p_att = cfg.attention_dropout if tr else 0.0
         a = self.self_attn
         pe = self.positional_embedding[0]
+        if self.use_native_runtime and pe is not None and x.is_cuda and self.activation_fn in ("relu", "silu", "swish"):
+            return F.transformer_layer_native(x, _pe_table(pe, T, x.device, self.num_heads, self.embed_dim), self, key_len, attn_mask,
+                                              B, T, p_drop, p_act, p_att, tr, "silu" if self.activation_fn == "swish" else self.activation_fn)
         wqkv, bqkv, wqkv16 = a.fused_qkv()
         x = F.relpos_mhsa(x, self.self_attn_layer_norm.weight, self.self_attn_layer_norm.bias, wqkv, bqkv,
                           a.out_proj.weight, a.out_proj.bias, a.pos_bias_u, a.pos_bias_v,

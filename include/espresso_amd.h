@@ -325,6 +325,11 @@ typedef struct EaLayerShape {
   /* backward only: the scratch arena is untouched since the previous ea_conformer_layer_bwd call with the same shape and
    * settings (consecutive layers of one backward pass) - lets the attention backward skip re-zeroing its band buffer */
   int scratch_clean;
+  /* relative-position mode of the attention block: 0 = sinusoidal table projected by pos_proj with pos_bias_u / pos_bias_v (the
+   * Conformer recipes), 1 = learned table (`pe` is the bf16 [2T-1][C] slice of the table, used as is; its fp32 gradient is
+   * returned through `dpe`).  `act`: FFN activation of the Transformer layer (EA_ACT_RELU / EA_ACT_SILU); the Conformer
+   * layer always uses SiLU. */
+  int pos_mode, act;
 } EaLayerShape;
 
 /* tuning hook: run weight-gradient GEMMs / bias sums of the layer backward on a side stream (default on); returns the
@@ -337,6 +342,16 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
 int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
                            void* dx, const int* key_len, const void* pe, void* saved, long saved_bytes, void* scratch,
                            long scratch_bytes, ea_stream_t stream);
+/* Transformer encoder layer (pre-LN; fairseq/modules/transformer_layer.py:135-214 with the rel-pos MHA of
+ * multihead_attention.py:650-907) in the same runtime: uses the `attn` and `ffn1` members (+ their grads) of EaConformerLayer;
+ * `wt` (optional) holds 2*C*F + 4*C*C bf16 elements.  dpe: fp32 [2T-1][C], required iff shape->pos_mode == 1. */
+int ea_transformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
+int ea_transformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
+                             const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
+                             void* scratch, long scratch_bytes, ea_stream_t stream);
+int ea_transformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
+                             void* dx, const int* key_len, const void* pe, float* dpe, void* saved, long saved_bytes,
+                             void* scratch, long scratch_bytes, ea_stream_t stream);
 /* tuning / test hook: use the fused attention kernels inside the layer runtime when the shape allows (default on);
  * returns the previous value.  Workspace sizes depend on it. */
 int ea_set_flash_attention(int on);

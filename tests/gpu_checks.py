@@ -1496,3 +1496,47 @@ def check_scheduled_sampling_transformer():
             "fed_tokens_equal_rollout": float((fed == roll).float().mean()),
             "p0_vs_rollout_logits": float((lo_p0.float() - lo_roll.float()).abs().max()), "finite": finite,
             "embed_grad": float(model.decoder.embed_tokens.weight.grad.abs().sum()) > 0, "n_sampled": int((fed != prev).sum())}
+
+
+def check_native_transformer_layer(learned=False, seed=0, C=64, heads=4, T=37):
+    """csrc/engine.hip Transformer layer (one call per layer and direction) vs the Python composition of the individual
+    kernels: outputs and every gradient (incl. the learned relative table's), same weights, same input, no dropout."""
+    from espresso_amd.modules.transformer_layer import TransformerWithRelativePositionalEmbeddingEncoderLayer as Layer
+
+    torch.manual_seed(seed)
+    model = build_tiny_model("transformer", embed_dim=C, heads=heads, ffn=2 * C, learned_pos=learned).to(DEV)
+    layer = model.encoder.layers[0]
+    if not learned:
+        with torch.no_grad():
+            layer.self_attn.pos_bias_u.normal_(0, 0.1)
+            layer.self_attn.pos_bias_v.normal_(0, 0.1)
+    B = 3
+    x0 = bf(torch.randn(B * T, C)).to(DEV)
+    key_len = torch.tensor([T, T - 7, max(1, T // 3)], dtype=torch.int32, device=DEV)
+    model.train()
+    outs, grads = [], []
+    for native in (False, True):
+        Layer.use_native_runtime = native
+        for p in model.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = layer(x, B, T, key_len=key_len)
+        (y.float() * torch.linspace(-1, 1, C, device=DEV)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append(y.detach().float().cpu())
+        g = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+        g["__x"] = x.grad.float().cpu()
+        grads.append(g)
+    Layer.use_native_runtime = True
+    res = {"out_abs": float((outs[0] - outs[1]).abs().max()), "same_params": sorted(grads[0]) == sorted(grads[1]), "n_grads": len(grads[0])}
+    worst = ("", 0.0)
+    for n in grads[0]:
+        if n.endswith("k_proj.bias"):
+            continue
+        a, b = grads[0][n], grads[1][n]
+        e = float((a - b).abs().max() / (a.abs().max() + 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    res["worst_grad"] = worst
+    res["has_table_grad"] = any("positional" in n or "relative" in n or "embed_positions" in n for n in grads[1]) if learned else True
+    return res

@@ -358,3 +358,10 @@ def test_scheduled_sampling_transformer_decoder():
     assert r["fed_tokens_equal_rollout"] >= 0.9 and r["finite"] and r["embed_grad"] and r["n_sampled"] > 0, r
     if r["fed_tokens_equal_rollout"] == 1.0:   # same fed sequence -> same training pass
         assert r["p0_vs_rollout_logits"] < 5e-2, r
+
+
+@pytest.mark.parametrize("learned", [False, True])
+def test_native_transformer_layer_matches_kernel_composition(learned):
+    r = G.check_native_transformer_layer(learned=learned)
+    assert r["same_params"] and r["n_grads"] >= 12 and r["has_table_grad"], r
+    assert r["out_abs"] < 4e-2 and r["worst_grad"][1] < 4e-2, r

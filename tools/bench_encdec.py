@@ -34,6 +34,7 @@ def main():
     e, dc = cfg.encoder, cfg.decoder
     e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, 12, 8
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "transformer"
+    e.learned_pos = True  # transformer_librispeech.yaml: learned relative tables, one per layer
     e.conv_channels = "[64, 64, 128, 128]"
     dc.embed_dim, dc.ffn_embed_dim, dc.layers, dc.attention_heads, dc.normalize_before = 512, 2048, 6, 8, True
     dc.input_dim = dc.output_dim = 512
