@@ -63,9 +63,20 @@ def main():
         samples.append(s)
     task.build_frontend(dev)
     task.begin_epoch(1)
+    # start-up only (as bench.py): size the arenas / allocator pools for the longest utterance and the largest batch
+    by_T = max(samples, key=lambda s: max(s["num_samples"]))
+    by_M = max(samples, key=lambda s: s["audio_seconds"])
+    trainer.reserve([by_M] if by_M is by_T else [by_M, by_T])
     for i in range(args.warmup):
         trainer.train_step([samples[i]])
     torch.cuda.synchronize()
+    if os.environ.get("EA_PER_STEP"):
+        for i in range(args.warmup, need):
+            t1 = time.perf_counter()
+            trainer.train_step([samples[i]])
+            torch.cuda.synchronize()
+            print(f"step {i}: {1e3 * (time.perf_counter() - t1):7.2f} ms  B={samples[i]['nsentences']} audio={samples[i]['audio_seconds']:.0f}s "
+                  f"Tmax={max(samples[i]['num_samples']) // 160}", file=sys.stderr)
     t0 = time.perf_counter()
     for i in range(args.warmup, need):
         trainer.train_step([samples[i]])
