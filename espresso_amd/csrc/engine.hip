@@ -362,26 +362,43 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad8(R);
   Arena& sc = *c.scratch;
   const bool learned = sh.pos_mode == 1;
-  // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames
-  // -> split-K into fp32, then one cast to bf16 for the pos_proj weight gradient
-  uint16_t* dpp = learned ? nullptr : sc.get<uint16_t>((size_t)R * C);
-  {
-    // learned table: the fp32 result IS the gradient of the table slice (written to the caller's buffer)
-    float* dpp32 = learned ? dpe : sc.get<float>((size_t)R * C);
-    const int tiles = ((R + 127) / 128) * H;
-    int sk = (768 + tiles - 1) / tiles;
-    if (sk > (B * T) / 256) sk = (B * T) / 256;
-    if (sk < 1) sk = 1;
-    G gpp(dBD, learned ? a.qu : a.qv, dpp32, R, dh, B * T, Rp, C, C);
+  // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames -> split-K
+  // into fp32.  Optimizer-only: runs on the side stream.
+  const int tiles = ((R + 127) / 128) * H;
+  int sk = (768 + tiles - 1) / tiles;
+  if (sk > (B * T) / 256) sk = (B * T) / 256;
+  if (sk < 1) sk = 1;
+  if (learned) {
+    // learned table: the fp32 result IS the gradient of the table slice (written to the caller's buffer, [R][C])
+    G gpp(dBD, a.qu, dpe, R, dh, B * T, Rp, C, C);
     gpp.aks().bks().f32().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
+    gpp.p.splitk = sk;
+    if (sk > 1) gpp.p.workspace = sc.get<float>((size_t)sk * H * R * dh);
+    fork(c);
+    gemm_on(c, gpp, wstream(c));
+  } else {
+    // sinusoidal table: the product is only needed for the pos_proj weight gradient, so it is formed TRANSPOSED,
+    // dppT[h*dh+d][r]: the 64-wide head dimension becomes the row tile (64x128 tiles fully used instead of half-empty
+    // 128x64 ones) and the weight-gradient GEMM below reads it k-contiguous
+    float* dppT32 = sc.get<float>((size_t)C * Rp);
+    uint16_t* dppT = sc.get<uint16_t>((size_t)C * Rp);
+    G gpp(a.qv, dBD, dppT32, dh, R, B * T, C, Rp, Rp);
+    gpp.aks().bks().f32().batch(H, 1, dh, 0, (long)B * T * Rp, 0, (long)dh * Rp, 0);
     gpp.p.splitk = sk;
     if (sk > 1) gpp.p.workspace = sc.get<float>((size_t)sk * H * R * dh);
     fork(c);  // dBD, qv ready: the whole pos_proj gradient chain is optimizer-only
     gemm_on(c, gpp, wstream(c));
-    if (!learned) RUN(ea_cast_f32_to_bf16(dpp32, dpp, (long)R * C, wstream(c)));
-  }
-  if (!learned) {
-    wgrad(c, dpp, C, pe, C, gw.wpos, R, C, C);
+    RUN(ea_cast_f32_to_bf16(dppT32, dppT, (long)C * Rp, wstream(c)));  // pad columns R..Rp-1 are never read
+    // dWpos[n][k] += sum_r dppT[n][r] pe[r][k]
+    const int wt_tiles = ((C + 63) / 64) * ((C + 127) / 128);
+    int sk2 = (512 + wt_tiles - 1) / wt_tiles;
+    if (sk2 > R / 256) sk2 = R / 256;
+    if (sk2 < 1) sk2 = 1;
+    G gw2(dppT, pe, gw.wpos, C, C, R, Rp, C, C);
+    gw2.bks().f32().acc();
+    gw2.p.splitk = sk2;
+    if (sk2 > 1) gw2.p.workspace = sc.get<float>((size_t)sk2 * C * C);
+    gemm_on(c, gw2, wstream(c));
     bias_grad(c, t1, gw.pos_u, M, C, C);
     bias_grad(c, t2, gw.pos_v, M, C, C);
   }
