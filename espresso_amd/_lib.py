@@ -94,7 +94,16 @@ class EaLayerShape(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("T", ctypes.c_int), ("C", ctypes.c_int), ("H", ctypes.c_int), ("F", ctypes.c_int),
                 ("KW", ctypes.c_int), ("training", ctypes.c_int), ("p_drop", ctypes.c_float), ("p_act", ctypes.c_float),
                 ("p_attn", ctypes.c_float), ("seed", ctypes.c_uint64), ("has_attn_mask", ctypes.c_int), ("scratch_clean", ctypes.c_int),
-                ("pos_mode", ctypes.c_int), ("act", ctypes.c_int)]
+                ("pos_mode", ctypes.c_int), ("act", ctypes.c_int), ("S", ctypes.c_int)]
+
+
+EaXAttnParams = _mk("EaXAttnParams", ["ln_g", "ln_b", "wq", "bq", "wkv", "bkv", "wo", "bo"])
+EaXAttnGrads = _mk("EaXAttnGrads", ["ln_g", "ln_b", "wq", "bq", "wkv", "bkv", "wo", "bo"])
+
+
+class EaDecoderLayer(ctypes.Structure):
+    _fields_ = [("self_attn", EaAttnParams), ("cross", EaXAttnParams), ("ffn", EaFfnParams), ("g_self", EaAttnGrads),
+                ("g_cross", EaXAttnGrads), ("g_ffn", EaFfnGrads), ("wt", ctypes.c_void_p)]
 
 
 _SCALARS = {

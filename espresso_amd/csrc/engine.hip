@@ -679,6 +679,168 @@ static int tlayer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh,
   return c.rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Transformer decoder layer (teacher-forced training): causal self-attention, encoder-decoder attention, FFN; pre-LN.
+// Both attention blocks run on the fused flash kernels without relative positions (head dim 64).
+//   saved: [x1][self: mean rstd lse xn qkv qs o][x2][cross: mean rstd lse xn q qs kv o][ffn]
+struct DSelfSaved { float *mean, *rstd, *lse; uint16_t *xn, *qkv, *qs, *o; };
+struct DCrossSaved { float *mean, *rstd, *lse; uint16_t *xn, *q, *qs, *kv, *o; };
+struct DLayerSaved { uint16_t *x1, *x2; DSelfSaved sa; DCrossSaved ca; FfnSaved f; };
+static DLayerSaved dlayer_saved(Arena& sv, const EaLayerShape& sh) {
+  const size_t M = (size_t)sh.B * sh.T, Ms = (size_t)sh.B * sh.S, C = sh.C, Z = (size_t)sh.H * sh.B;
+  DLayerSaved L;
+  L.x1 = sv.get<uint16_t>(M * C);
+  L.sa.mean = sv.get<float>(M); L.sa.rstd = sv.get<float>(M); L.sa.lse = sv.get<float>(Z * sh.T);
+  L.sa.xn = sv.get<uint16_t>(M * C); L.sa.qkv = sv.get<uint16_t>(M * 3 * C); L.sa.qs = sv.get<uint16_t>(M * C);
+  L.sa.o = sv.get<uint16_t>(M * C);
+  L.x2 = sv.get<uint16_t>(M * C);
+  L.ca.mean = sv.get<float>(M); L.ca.rstd = sv.get<float>(M); L.ca.lse = sv.get<float>(Z * sh.T);
+  L.ca.xn = sv.get<uint16_t>(M * C); L.ca.q = sv.get<uint16_t>(M * C); L.ca.qs = sv.get<uint16_t>(M * C);
+  L.ca.kv = sv.get<uint16_t>(Ms * 2 * C); L.ca.o = sv.get<uint16_t>(M * C);
+  L.f = ffn_saved(sv, sh);
+  return L;
+}
+// k-contiguous weight copies: [fc1^T C x F][fc2^T F x C][wqkv^T C x 3C][wo^T C x C][xq^T C x C][xkv^T C x 2C][xo^T C x C]
+struct DWT { const uint16_t *fc1, *fc2, *wqkv, *wo, *xq, *xkv, *xo; };
+static DWT dwt_view(const EaDecoderLayer* L, const EaLayerShape& sh) {
+  DWT w{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!L->wt || !sh.training) return w;
+  const size_t C = sh.C, F = sh.F;
+  const uint16_t* p = (const uint16_t*)L->wt;
+  w.fc1 = p; p += C * F;
+  w.fc2 = p; p += C * F;
+  w.wqkv = p; p += 3 * C * C;
+  w.wo = p; p += C * C;
+  w.xq = p; p += C * C;
+  w.xkv = p; p += 2 * C * C;
+  w.xo = p;
+  return w;
+}
+static inline bool dshape_ok(const EaLayerShape& sh) {
+  return sh.B > 0 && sh.T > 0 && sh.S > 0 && sh.C % 8 == 0 && sh.H > 0 && sh.C / sh.H == 64 && sh.C % sh.H == 0 && sh.F % 8 == 0 &&
+         !sh.has_attn_mask;
+}
+static int dlayer_fwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, const void* x_in, const void* enc, void* x_out,
+                      const int* enc_len, Arena& sv) {
+  const int B = sh.B, T = sh.T, S = sh.S, C = sh.C, H = sh.H, M = B * T, Ms = B * S, dh = C / H;
+  const float scaling = 1.0f / sqrtf((float)dh);
+  DLayerSaved D = dlayer_saved(sv, sh);
+  const uint64_t seed = sh.seed;
+  {  // causal self-attention block: x1 = x + dropout(out_proj(attn(LN(x))))
+    const EaAttnParams& w = L->self_attn;
+    RUN(ea_layernorm_fwd(x_in, w.ln_g, w.ln_b, D.sa.xn, D.sa.mean, D.sa.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+    G gq(D.sa.xn, w.wqkv, D.sa.qkv, M, 3 * C, C, C, C, 3 * C);
+    gq.bias(w.bqkv);
+    gemm(c, gq);
+    RUN(ea_relpos_q_prep(D.sa.qkv, 3 * C, nullptr, nullptr, D.sa.qs, nullptr, M, C, scaling, c.s));
+    RUN(ea_flash_attention_fwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, C, D.sa.lse, H,
+                               B, T, T, dh, 1, seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+    G go(D.sa.o, w.wo, D.x1, M, C, C, C, C, C);
+    go.bias(w.bo).drop(sh.p_drop, seed + 16 + 4).resid(x_in, C);
+    gemm(c, go);
+  }
+  {  // encoder-decoder attention block: x2 = x1 + dropout(out_proj(attn(q = LN(x1), k = v = enc)))
+    const EaXAttnParams& w = L->cross;
+    RUN(ea_layernorm_fwd(D.x1, w.ln_g, w.ln_b, D.ca.xn, D.ca.mean, D.ca.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+    G gq(D.ca.xn, w.wq, D.ca.q, M, C, C, C, C, C);
+    gq.bias(w.bq);
+    gemm(c, gq);
+    RUN(ea_relpos_q_prep(D.ca.q, C, nullptr, nullptr, D.ca.qs, nullptr, M, C, scaling, c.s));
+    G gkv(enc, w.wkv, D.ca.kv, Ms, 2 * C, C, C, C, 2 * C);
+    gkv.bias(w.bkv);
+    gemm(c, gkv);
+    RUN(ea_flash_attention_fwd(D.ca.qs, nullptr, C, D.ca.kv, D.ca.kv + C, 2 * C, nullptr, 0, enc_len, D.ca.o, C, D.ca.lse, H, B, T, S,
+                               dh, 0, seed + 32 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+    G go(D.ca.o, w.wo, D.x2, M, C, C, C, C, C);
+    go.bias(w.bo).drop(sh.p_drop, seed + 32 + 4).resid(D.x1, C);
+    gemm(c, go);
+  }
+  ffn_fwd(c, D.f, sh, L->ffn, D.x2, x_out, seed + 0, 1.f, sh.act);
+  const DWT w = dwt_view(L, sh);
+  if (w.fc1) {
+    const int F = sh.F;
+    const void* src[7] = {L->ffn.w1, L->ffn.w2, L->self_attn.wqkv, L->self_attn.wo, L->cross.wq, L->cross.wkv, L->cross.wo};
+    void* dst[7] = {(void*)w.fc1, (void*)w.fc2, (void*)w.wqkv, (void*)w.wo, (void*)w.xq, (void*)w.xkv, (void*)w.xo};
+    const int rows[7] = {F, C, 3 * C, C, C, 2 * C, C}, cols[7] = {C, F, C, C, C, C, C};
+    RUN(ea_transpose_bf16_batch(src, dst, rows, cols, 7, c.s));
+  }
+  return c.rc;
+}
+static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, const void* x_in, const void* enc, const void* dy,
+                      void* dx, void* denc, const int* enc_len, Arena& sv) {
+  const int B = sh.B, T = sh.T, S = sh.S, C = sh.C, H = sh.H, M = B * T, Ms = B * S, dh = C / H, Z = H * B;
+  const float scaling = 1.0f / sqrtf((float)dh);
+  DLayerSaved D = dlayer_saved(sv, sh);
+  Arena& sc = *c.scratch;
+  const uint64_t seed = sh.seed;
+  const DWT wt = dwt_view(L, sh);
+  const bool dp = sh.p_drop > 0.f;
+  uint16_t* dA = sc.get<uint16_t>((size_t)M * C);  // gradient at x2
+  uint16_t* dB = sc.get<uint16_t>((size_t)M * C);  // gradient at x1
+  uint16_t* pca = dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
+  uint16_t* psa = dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
+  const Pre to_cross{pca, 1.f, seed + 32 + 4, sh.p_drop}, to_self{psa, 1.f, seed + 16 + 4, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
+  ffn_bwd(c, D.f, sh, L->ffn, L->g_ffn, D.x2, dy, dA, seed + 0, 1.f, sh.act, wt.fc1, wt.fc2, nullptr, to_cross);
+  {  // encoder-decoder attention block
+    const EaXAttnParams& w = L->cross;
+    const EaXAttnGrads& gw = L->g_cross;
+    const void* g = dp ? (const void*)pca : (const void*)dA;
+    fork(c);
+    wgrad(c, g, C, D.ca.o, C, gw.wo, M, C, C);
+    bias_grad(c, g, gw.bo, M, C, C);
+    uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
+    dgrad(c, g, w.wo, wt.xo, dO, M, C, C);
+    uint16_t* dq = sc.get<uint16_t>((size_t)M * C);
+    uint16_t* dkv = sc.get<uint16_t>((size_t)Ms * 2 * C);
+    float* Dd = sc.get<float>((size_t)Z * T);
+    RUN(ea_flash_attention_bwd(D.ca.qs, nullptr, C, D.ca.kv, D.ca.kv + C, 2 * C, nullptr, 0, enc_len, D.ca.o, dO, C, D.ca.lse, Dd, dq,
+                               nullptr, C, nullptr, 0, dkv, dkv + C, 2 * C, H, B, T, S, dh, 0, scaling, seed + 32 + 3, drop_thr(sh.p_attn),
+                               drop_scale(sh.p_attn), c.s));
+    fork(c);
+    wgrad(c, dq, C, D.ca.xn, C, gw.wq, M, C, C);
+    bias_grad(c, dq, gw.bq, M, C, C);
+    wgrad(c, dkv, 2 * C, enc, C, gw.wkv, Ms, 2 * C, C);
+    bias_grad(c, dkv, gw.bkv, Ms, 2 * C, 2 * C);
+    dgrad(c, dkv, w.wkv, wt.xkv, denc, Ms, C, 2 * C);
+    uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
+    dgrad(c, dq, w.wq, wt.xq, dxn, M, C, C);
+    ln_bwd_block(c, D.x1, dxn, w.ln_g, D.ca.mean, D.ca.rstd, dB, gw.ln_g, gw.ln_b, M, C, dA, to_self);
+  }
+  {  // causal self-attention block
+    const EaAttnParams& w = L->self_attn;
+    const EaAttnGrads& gw = L->g_self;
+    const void* g = dp ? (const void*)psa : (const void*)dB;
+    fork(c);
+    wgrad(c, g, C, D.sa.o, C, gw.wo, M, C, C);
+    bias_grad(c, g, gw.bo, M, C, C);
+    uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
+    dgrad(c, g, w.wo, wt.wo, dO, M, C, C);
+    uint16_t* dqkv = sc.get<uint16_t>((size_t)M * 3 * C);
+    float* Dd = sc.get<float>((size_t)Z * T);
+    // t1 (gradient of the scaled queries, already multiplied by the scale) goes straight into the q third of dqkv
+    RUN(ea_flash_attention_bwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, dO, C, D.sa.lse,
+                               Dd, dqkv, nullptr, 3 * C, nullptr, 0, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 1, scaling,
+                               seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+    fork(c);
+    wgrad(c, dqkv, 3 * C, D.sa.xn, C, gw.wqkv, M, 3 * C, C);
+    bias_grad(c, dqkv, gw.bqkv, M, 3 * C, 3 * C);
+    uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
+    dgrad(c, dqkv, w.wqkv, wt.wqkv, dxn, M, C, 3 * C);
+    ln_bwd_block(c, x_in, dxn, w.ln_g, D.sa.mean, D.sa.rstd, dx, gw.ln_g, gw.ln_b, M, C, dB, none);
+  }
+  if (c.overlap) stream_wait(c, c.s, c.side);
+  return c.rc;
+}
+static bool darenas_fit(const EaLayerShape& sh, bool backward, bool overlap, long saved_bytes, long scratch_bytes) {
+  EaDecoderLayer L;
+  memset(&L, 0, sizeof(L));
+  Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
+  Ctx c{nullptr, true, 0, &sc, nullptr, overlap};
+  if (backward) dlayer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
+  else dlayer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, sv);
+  return (long)sv.peak <= saved_bytes && (long)sc.peak <= scratch_bytes;
+}
+
 static bool g_overlap_default = true;
 int ea_set_backward_overlap(int on) {
   const int old = g_overlap_default;
@@ -789,6 +951,41 @@ int ea_transformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* 
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
   if (ov) stream_wait(c, c.side, c.s);
   return tlayer_bwd(c, layer, *shape, x_in, dy, dx, key_len, pe, dpe, sv);
+}
+
+int ea_decoder_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes) {
+  if (!dshape_ok(*shape)) return -2;
+  EaDecoderLayer L;
+  memset(&L, 0, sizeof(L));
+  Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
+  Ctx c{nullptr, true, 0, &sc, nullptr, g_overlap_default};
+  dlayer_fwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, sv);
+  Arena sv2{nullptr, 0, 0};
+  dlayer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sv2);
+  *saved_bytes = (long)sv.peak + 256;
+  *scratch_bytes = (long)sc.peak + 256;
+  return 0;
+}
+
+int ea_decoder_layer_fwd(const EaDecoderLayer* layer, const EaLayerShape* shape, const void* x_in, const void* enc, void* x_out,
+                         const int* enc_len, void* saved, long saved_bytes, void* scratch, long scratch_bytes, hipStream_t stream) {
+  if (!dshape_ok(*shape)) return -2;
+  if (!darenas_fit(*shape, false, false, saved_bytes, scratch_bytes)) return -5;
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
+  Ctx c{stream, false, 0, &sc, nullptr, false};
+  return dlayer_fwd(c, layer, *shape, x_in, enc, x_out, enc_len, sv);
+}
+
+int ea_decoder_layer_bwd(const EaDecoderLayer* layer, const EaLayerShape* shape, const void* x_in, const void* enc, const void* dy,
+                         void* dx, void* denc, const int* enc_len, void* saved, long saved_bytes, void* scratch, long scratch_bytes,
+                         hipStream_t stream) {
+  if (!dshape_ok(*shape)) return -2;
+  const bool ov = g_overlap_default && side_init();
+  if (!darenas_fit(*shape, true, ov, saved_bytes, scratch_bytes)) return -5;
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
+  Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
+  if (ov) stream_wait(c, c.side, c.s);
+  return dlayer_bwd(c, layer, *shape, x_in, enc, dy, dx, denc, enc_len, sv);
 }
 
 }  // extern "C"

@@ -903,6 +903,144 @@ def transformer_layer_native(x, pe, module, key_len, attn_mask, B, T, p_drop, p_
     return _TransformerLayerNative.apply(x, pe, module, key_len, attn_mask, B, T, p_drop, p_act, p_attn, training, act)
 
 
+def _adjacent(ts):
+    """True when the tensors lie back to back in memory (same dtype), in the given order."""
+    for a, b in zip(ts[:-1], ts[1:]):
+        if a is None or b is None or b.data_ptr() != a.data_ptr() + a.numel() * a.element_size():
+            return False
+    return True
+
+
+class _DecoderLayerBinding:
+    """ctypes view of a TransformerDecoderLayer for ea_decoder_layer_fwd/bwd.  Needs the FlatParams layout (q, k, v weights,
+    biases, their bf16 shadows and gradients adjacent): `ok` is False otherwise and the module keeps the per-kernel path."""
+
+    def __init__(self, m):
+        from ._lib import EaDecoderLayer
+
+        self.ok = False
+        self.keep = []
+        L = EaDecoderLayer()
+        sa, ca = m.self_attn, m.encoder_attn
+        groups = {"self": [sa.q_proj, sa.k_proj, sa.v_proj], "cross": [ca.k_proj, ca.v_proj]}
+        every = [p for mod in (sa.q_proj, sa.k_proj, sa.v_proj, sa.out_proj, ca.q_proj, ca.k_proj, ca.v_proj, ca.out_proj, m.fc1, m.fc2,
+                               m.self_attn_layer_norm, m.encoder_attn_layer_norm, m.final_layer_norm) for p in mod.parameters()]
+        if any(p.grad is None or getattr(p, "_ea_bf16", None) is None for p in every if p.dim() == 2) or any(p.grad is None for p in every):
+            return
+        for g in groups.values():
+            ws, bs = [x.weight for x in g], [x.bias for x in g]
+            if not (_adjacent([w._ea_bf16 for w in ws]) and _adjacent([w.grad for w in ws]) and _adjacent(bs)
+                    and _adjacent([b.grad for b in bs])):
+                return
+        w16 = lambda p: p._ea_bf16.data_ptr()  # noqa: E731
+        gp = lambda p: p.grad.data_ptr()  # noqa: E731
+        S, GS = L.self_attn, L.g_self
+        S.ln_g, S.ln_b = _ptr(m.self_attn_layer_norm.weight), _ptr(m.self_attn_layer_norm.bias)
+        S.wqkv, S.bqkv, S.wo, S.bo = w16(sa.q_proj.weight), _ptr(sa.q_proj.bias), w16(sa.out_proj.weight), _ptr(sa.out_proj.bias)
+        GS.ln_g, GS.ln_b = gp(m.self_attn_layer_norm.weight), gp(m.self_attn_layer_norm.bias)
+        GS.wqkv, GS.bqkv, GS.wo, GS.bo = gp(sa.q_proj.weight), gp(sa.q_proj.bias), gp(sa.out_proj.weight), gp(sa.out_proj.bias)
+        X, GX = L.cross, L.g_cross
+        X.ln_g, X.ln_b = _ptr(m.encoder_attn_layer_norm.weight), _ptr(m.encoder_attn_layer_norm.bias)
+        X.wq, X.bq, X.wkv, X.bkv = w16(ca.q_proj.weight), _ptr(ca.q_proj.bias), w16(ca.k_proj.weight), _ptr(ca.k_proj.bias)
+        X.wo, X.bo = w16(ca.out_proj.weight), _ptr(ca.out_proj.bias)
+        GX.ln_g, GX.ln_b = gp(m.encoder_attn_layer_norm.weight), gp(m.encoder_attn_layer_norm.bias)
+        GX.wq, GX.bq, GX.wkv, GX.bkv = gp(ca.q_proj.weight), gp(ca.q_proj.bias), gp(ca.k_proj.weight), gp(ca.k_proj.bias)
+        GX.wo, GX.bo = gp(ca.out_proj.weight), gp(ca.out_proj.bias)
+        F_, GF = L.ffn, L.g_ffn
+        F_.ln_g, F_.ln_b = _ptr(m.final_layer_norm.weight), _ptr(m.final_layer_norm.bias)
+        F_.w1, F_.b1, F_.w2, F_.b2 = w16(m.fc1.weight), _ptr(m.fc1.bias), w16(m.fc2.weight), _ptr(m.fc2.bias)
+        GF.ln_g, GF.ln_b = gp(m.final_layer_norm.weight), gp(m.final_layer_norm.bias)
+        GF.w1, GF.b1, GF.w2, GF.b2 = gp(m.fc1.weight), gp(m.fc1.bias), gp(m.fc2.weight), gp(m.fc2.bias)
+        C, Fd = m.embed_dim, m.fc1.weight.shape[0]
+        self.wt = torch.empty(2 * C * Fd + 8 * C * C, dtype=torch.bfloat16, device=m.fc1.weight.device)
+        L.wt = self.wt.data_ptr()
+        self.L, self.params = L, every
+        self.key = (sa.q_proj.weight.data_ptr(), sa.q_proj.weight.grad.data_ptr())
+        self.saved_buf, self.saved_busy = None, False
+        self.ok = True
+
+    def finish_backward(self):
+        if _grad_ready_callback is not None:
+            _grad_ready_callback(self.params)
+
+
+def decoder_layer_binding(module):
+    """Cached binding of a decoder layer, or None when the parameters are not in the flat layout (then: per-kernel path)."""
+    bind = getattr(module, "_ea_binding", None)
+    qw = module.self_attn.q_proj.weight
+    if bind is None or bind.key != (qw.data_ptr(), qw.grad.data_ptr() if qw.grad is not None else 0):
+        bind = _DecoderLayerBinding(module)
+        if not bind.ok:
+            return None
+        module._ea_binding = bind
+    return bind
+
+
+class _DecoderLayerNative(torch.autograd.Function):
+    """Whole pre-LN Transformer decoder layer (causal self-attention, encoder-decoder attention, FFN) per C-ABI call."""
+
+    @staticmethod
+    def forward(ctx, x, enc, bind, module, enc_len, B, U, S, p_drop, p_act, p_attn, training, act):
+        import ctypes
+
+        from . import _lib
+        from ._lib import EaLayerShape
+
+        sh = EaLayerShape()
+        sh.B, sh.T, sh.S, sh.C, sh.H = B, U, S, module.embed_dim, module.num_heads
+        sh.F, sh.KW = module.fc1.weight.shape[0], 0
+        sh.training = int(training)
+        sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
+        sh.seed = _next_seed() * 64 % (1 << 63)
+        sh.act = K._ACT[act] if isinstance(act, str) else int(act)
+        nb_saved, nb_scratch = ctypes.c_long(0), ctypes.c_long(0)
+        lib = _lib.lib()
+        _lib.check(lib.ea_decoder_layer_workspace(ctypes.byref(sh), ctypes.byref(nb_saved), ctypes.byref(nb_scratch)), "workspace")
+        needs_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if bind.saved_busy:
+            saved = torch.empty(nb_saved.value, dtype=torch.uint8, device=x.device)
+            ctx.owns_arena = False
+        else:
+            if bind.saved_buf is None or bind.saved_buf.numel() < nb_saved.value or bind.saved_buf.device != x.device:
+                bind.saved_buf = torch.empty(int(nb_saved.value * 1.1) + 4096, dtype=torch.uint8, device=x.device)
+            saved = bind.saved_buf
+            bind.saved_busy = bool(needs_bwd)
+            ctx.owns_arena = bool(needs_bwd)
+        scratch = _scratch_buffer(nb_scratch.value, x.device)
+        _scratch_tag[str(x.device)] = None
+        y = torch.empty_like(x)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.ea_decoder_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(enc), _ptr(y), _ptr(enc_len), _ptr(saved),
+                                            saved.numel(), _ptr(scratch), scratch.numel(), stream), "ea_decoder_layer_fwd")
+        ctx.save_for_backward(x, enc, saved, enc_len)
+        ctx.bind, ctx.sh, ctx.nb_scratch = bind, sh, nb_scratch.value
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+
+        from . import _lib
+
+        x, enc, saved, enc_len = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, denc = torch.empty_like(x), torch.empty_like(enc)
+        scratch = _scratch_buffer(ctx.nb_scratch, x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().ea_decoder_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(enc), _ptr(dy), _ptr(dx),
+                                                   _ptr(denc), _ptr(enc_len), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(),
+                                                   stream), "ea_decoder_layer_bwd")
+        _scratch_tag[str(x.device)] = None
+        if ctx.owns_arena:
+            ctx.bind.saved_busy = False
+        ctx.bind.finish_backward()
+        return (dx, denc) + (None,) * 11
+
+
+def decoder_layer_native(x, enc, bind, module, enc_len, B, U, S, p_drop, p_act, p_attn, training, act):
+    return _DecoderLayerNative.apply(x, enc, bind, module, enc_len, B, U, S, p_drop, p_act, p_attn, training, act)
+
+
 def conformer_layer_native(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
     return _ConformerLayerNative.apply(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training)
 

@@ -30,12 +30,20 @@ class TransformerDecoderLayer(nn.Module):
         self.final_layer_norm = LayerNormParams(d)
         self.activation_fn = cfg.activation_fn
 
+    use_native_runtime = True  # whole layer per C-ABI call (csrc/engine.hip) when the parameters live in the flat buffers
+
     def forward(self, x, enc, enc_len, B, U, S):
         """x bf16 [B*U][C]; enc bf16 [B*S][C_enc]; enc_len int32 [B] (valid encoder frames)."""
         cfg, tr = self.cfg, self.training
         p_drop = cfg.dropout if tr else 0.0
         p_act = cfg.activation_dropout if tr else 0.0
         p_att = cfg.attention_dropout if tr else 0.0
+        if (self.use_native_runtime and x.is_cuda and self.embed_dim // self.num_heads == 64 and enc.shape[1] == self.embed_dim
+                and self.activation_fn in ("relu", "silu", "swish")):
+            bind = F.decoder_layer_binding(self)  # needs the flat parameter layout of the trainer (else: per-kernel path)
+            if bind is not None:
+                return F.decoder_layer_native(x, enc, bind, self, enc_len, B, U, S, p_drop, p_act, p_att, tr,
+                                              "silu" if self.activation_fn == "swish" else self.activation_fn)
         a = self.self_attn
         wqkv, bqkv, wqkv16 = a.fused_qkv()
         x = F.relpos_mhsa(x, self.self_attn_layer_norm.weight, self.self_attn_layer_norm.bias, wqkv, bqkv, a.out_proj.weight,

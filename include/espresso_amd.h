@@ -330,6 +330,7 @@ typedef struct EaLayerShape {
    * returned through `dpe`).  `act`: FFN activation of the Transformer layer (EA_ACT_RELU / EA_ACT_SILU); the Conformer
    * layer always uses SiLU. */
   int pos_mode, act;
+  int S; /* decoder layer only: padded encoder length (keys of the encoder-decoder attention); T is then the target length */
 } EaLayerShape;
 
 /* tuning hook: run weight-gradient GEMMs / bias sums of the layer backward on a side stream (default on); returns the
@@ -352,6 +353,24 @@ int ea_transformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* 
 int ea_transformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
                              void* dx, const int* key_len, const void* pe, float* dpe, void* saved, long saved_bytes,
                              void* scratch, long scratch_bytes, ea_stream_t stream);
+/* Transformer DECODER layer (pre-LN; fairseq/modules/transformer_layer.py:241-529 as built by
+ * espresso/modules/transformer_with_relative_positional_embedding_layer.py:66-116) for teacher-forced training: causal
+ * self-attention, encoder-decoder attention over `enc` (bf16 [B*S][C], valid lengths enc_len), FFN.  Head dim 64 (fused
+ * attention kernels).  x: bf16 [B*T][C].  denc: bf16 [B*S][C], this layer's gradient w.r.t. `enc` (written, not accumulated).
+ * `wt` (optional): 2*C*F + 8*C*C bf16 elements for the k-contiguous weight copies. */
+typedef struct EaXAttnParams { const float *ln_g, *ln_b; const void* wq; const float* bq; const void* wkv; const float* bkv; const void* wo; const float* bo; } EaXAttnParams;
+typedef struct EaXAttnGrads { float *ln_g, *ln_b, *wq, *bq, *wkv, *bkv, *wo, *bo; } EaXAttnGrads;
+typedef struct EaDecoderLayer {
+  EaAttnParams self_attn; EaXAttnParams cross; EaFfnParams ffn;
+  EaAttnGrads g_self; EaXAttnGrads g_cross; EaFfnGrads g_ffn;
+  void* wt;
+} EaDecoderLayer;
+int ea_decoder_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
+int ea_decoder_layer_fwd(const EaDecoderLayer* layer, const EaLayerShape* shape, const void* x_in, const void* enc, void* x_out,
+                         const int* enc_len, void* saved, long saved_bytes, void* scratch, long scratch_bytes, ea_stream_t stream);
+int ea_decoder_layer_bwd(const EaDecoderLayer* layer, const EaLayerShape* shape, const void* x_in, const void* enc, const void* dy,
+                         void* dx, void* denc, const int* enc_len, void* saved, long saved_bytes, void* scratch, long scratch_bytes,
+                         ea_stream_t stream);
 /* tuning / test hook: use the fused attention kernels inside the layer runtime when the shape allows (default on);
  * returns the previous value.  Workspace sizes depend on it. */
 int ea_set_flash_attention(int on);

@@ -1540,3 +1540,53 @@ def check_native_transformer_layer(learned=False, seed=0, C=64, heads=4, T=37):
     res["worst_grad"] = worst
     res["has_table_grad"] = any("positional" in n or "relative" in n or "embed_positions" in n for n in grads[1]) if learned else True
     return res
+
+
+def check_native_decoder_layer(seed=0, C=256, heads=4, U=23, S=61):
+    """csrc/engine.hip Transformer decoder layer (one call per layer and direction; needs the flat parameter layout) vs the Python
+    composition of the individual kernels: output, gradients w.r.t. the layer input, the encoder output and every parameter."""
+    from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
+    from espresso_amd.modules.transformer_decoder_layer import TransformerDecoderLayer as Layer
+    from espresso_amd.optim.flat import FlatParams
+
+    torch.manual_seed(seed)
+    cfg = SpeechTransformerConfig()
+    cfg.encoder.embed_dim = cfg.decoder.embed_dim = C
+    cfg.decoder.ffn_embed_dim, cfg.decoder.attention_heads, cfg.decoder.normalize_before = 2 * C, heads, True
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    layer = Layer(cfg).to(DEV)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1) if p.abs().sum() == 0 else None
+    flat = FlatParams(layer, torch.device(DEV))
+    B = 3
+    x0 = bf(torch.randn(B * U, C)).to(DEV)
+    enc0 = bf(torch.randn(B * S, C)).to(DEV)
+    enc_len = torch.tensor([S, S - 9, max(1, S // 3)], dtype=torch.int32, device=DEV)
+    layer.train()
+    res, runs = {}, []
+    for native in (False, True):
+        Layer.use_native_runtime = native
+        flat.g32.zero_()
+        x, enc = x0.clone().requires_grad_(True), enc0.clone().requires_grad_(True)
+        y = layer(x, enc, enc_len, B, U, S)
+        (y.float() * torch.linspace(-1, 1, C, device=DEV)).sum().backward()
+        torch.cuda.synchronize()
+        g = {n: p.grad.detach().float().cpu().clone() for n, p in layer.named_parameters()}
+        g["__x"], g["__enc"] = x.grad.float().cpu(), enc.grad.float().cpu()
+        runs.append((y.detach().float().cpu(), g))
+    Layer.use_native_runtime = True
+    res["native_used"] = getattr(layer, "_ea_binding", None) is not None
+    res["out_abs"] = float((runs[0][0] - runs[1][0]).abs().max())
+    worst = ("", 0.0)
+    for n in runs[0][1]:
+        if n.endswith("k_proj.bias"):
+            continue  # exactly zero in exact arithmetic (softmax shift invariance)
+        a, b = runs[0][1][n], runs[1][1][n]
+        e = float((a - b).abs().max() / (a.abs().max() + 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    res["worst_grad"] = worst
+    res["pad_enc_grad"] = float(runs[1][1]["__enc"].view(B, S, C)[1, S - 9:].abs().max())
+    return res

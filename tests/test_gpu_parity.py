@@ -365,3 +365,10 @@ def test_native_transformer_layer_matches_kernel_composition(learned):
     r = G.check_native_transformer_layer(learned=learned)
     assert r["same_params"] and r["n_grads"] >= 12 and r["has_table_grad"], r
     assert r["out_abs"] < 4e-2 and r["worst_grad"][1] < 4e-2, r
+
+
+def test_native_decoder_layer_matches_kernel_composition():
+    r = G.check_native_decoder_layer()
+    assert r["native_used"], r
+    assert r["out_abs"] < 4e-2 and r["worst_grad"][1] < 4e-2, r
+    assert r["pad_enc_grad"] == 0.0, r   # padded encoder frames get no gradient from the attention
