@@ -78,13 +78,18 @@ class SpeechTransformerDecoderBase(nn.Module):
         B, U = prev_output_tokens.shape
         mask = prev_output_tokens.ne(self.padding_idx).int()
         pos = (torch.cumsum(mask, 1) * mask + self.padding_idx).to(torch.int32)
-        n = self.padding_idx + 1 + U
-        key = (n, str(prev_output_tokens.device))
+        return pos.reshape(-1).contiguous(), self._pos_table(self.padding_idx + 1 + U, prev_output_tokens.device)
+
+    def _pos_table(self, n, device):
+        """First `n` rows of ONE device-resident sinusoidal table (built once for max_target_positions and grown by doubling):
+        a per-length host build + pageable host-to-device copy would drain the stream at every new target length."""
+        key = str(device)
         tab = self._pos_cache.get(key)
-        if tab is None:
-            tab = sinusoidal_positional_table(n, self.embed_dim, self.padding_idx).to(prev_output_tokens.device).contiguous()
+        if tab is None or tab.shape[0] < n:
+            rows = max(n, self.max_target_positions + self.padding_idx + 2, 2 * (tab.shape[0] if tab is not None else 0))
+            tab = sinusoidal_positional_table(rows, self.embed_dim, self.padding_idx).to(device).contiguous()
             self._pos_cache[key] = tab
-        return pos.reshape(-1).contiguous(), tab
+        return tab[:n]
 
     def forward(self, prev_output_tokens, encoder_out=None, features_only=False, **kwargs):
         """-> (logits bf16 (B, U, V) view, extra dict)."""
@@ -198,12 +203,7 @@ class SpeechTransformerDecoderBase(nn.Module):
             par = None
         L = st["L"]
         pos = torch.full((N,), self.padding_idx + step + 1, dtype=torch.int32, device=dev)
-        n_tab = self.padding_idx + 2 + step
-        key = (n_tab, str(dev))
-        tab = self._pos_cache.get(key)
-        if tab is None:
-            tab = sinusoidal_positional_table(n_tab, C, self.padding_idx).to(dev).contiguous()
-            self._pos_cache[key] = tab
+        tab = self._pos_table(self.padding_idx + 2 + step, dev)
         x = K.embedding_fwd(tok, pos, self.embed_tokens.weight, tab, self.embed_scale)
         if self.layernorm_embedding is not None:
             x, _, _ = K.layernorm_fwd(x, self.layernorm_embedding.weight, self.layernorm_embedding.bias, save_stats=False)

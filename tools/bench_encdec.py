@@ -70,6 +70,11 @@ def main():
     for i in range(args.warmup):
         trainer.train_step([samples[i]])
     torch.cuda.synchronize()
+    if os.environ.get("EA_NO_GC"):
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
     if os.environ.get("EA_PER_STEP"):
         for i in range(args.warmup, need):
             t1 = time.perf_counter()
