@@ -18,13 +18,23 @@ from .optim.noam_lr_scheduler import NoamSchedule
 
 class Trainer:
     def __init__(self, task, model, criterion, device, clip_norm=2.0, lr=5.0, warmup_steps=25000, adam_betas=(0.9, 0.98),
-                 adam_eps=1e-8, weight_decay=0.0, final_lr=1e-6, seed=1, bucket_mb=64.0):
+                 adam_eps=1e-8, weight_decay=0.0, final_lr=1e-6, seed=1, bucket_mb=64.0, lr_scheduler=None):
+        """`lr_scheduler`: optional `(name, kwargs)` resolved through the registry (default: the headline recipe's `noam`)."""
         self.task, self.criterion, self.device = task, criterion, device
         self.model = model.to(device)
         self.flat = FlatParams(self.model, device)
         self.optimizer = FlatAdam(self.flat, lr=lr, betas=adam_betas, eps=adam_eps, weight_decay=weight_decay)
-        self.lr_scheduler = NoamSchedule(self.optimizer, lr=lr, warmup_steps=warmup_steps,
-                                         model_size=model.cfg.encoder.embed_dim, final_lr=final_lr)
+        if lr_scheduler is None:
+            self.lr_scheduler = NoamSchedule(self.optimizer, lr=lr, warmup_steps=warmup_steps,
+                                             model_size=model.cfg.encoder.embed_dim, final_lr=final_lr)
+        else:
+            from . import registry
+            from .optim import lr_schedulers  # noqa: F401  (registers tri_stage / polynomial_decay_v2 / reduce_lr_on_plateau_v2)
+
+            name, kw = lr_scheduler
+            self.lr_scheduler = registry.LR_SCHEDULER_REGISTRY[name](self.optimizer, lr=lr, **kw)
+        self.cfg = None
+        self._optim_history = []
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.ddp = OverlappedDistributedDataParallel(self.model, self.flat, bucket_mb=bucket_mb)
         self.clip_norm = clip_norm
@@ -41,10 +51,15 @@ class Trainer:
         for i, sample in enumerate(samples):
             last = i == len(samples) - 1
             ctx = contextlib.nullcontext() if last else self.ddp.no_sync()
+            dummy = bool(sample.get("_dummy", False))  # rank ran out of batches: same collectives, no contribution (trainer.py:873-877)
             with ctx:
                 sample = self.task.prepare_sample(sample, train=True)
                 loss, sample_size, log = self.criterion(self.ddp, sample)
+                if dummy:
+                    loss = loss * 0.0
                 loss.backward()
+            if dummy:
+                continue
             self._stats[0] += float(sample_size)
             self._stats[1] += loss.detach()
             self._stats[2] += float(log["ntokens"])
@@ -79,3 +94,133 @@ class Trainer:
 
     def valid_step(self, sample):
         return self.task.valid_step(sample, self.model, self.criterion)
+
+    # ---- configuration, learning-rate bookkeeping, checkpoints (fairseq/trainer.py:387-640, checkpoint_utils.py) ----
+
+    @classmethod
+    def from_cfg(cls, cfg, task, model, criterion, device):
+        """Trainer from a recipe configuration (espresso_amd/config.py: groups optimization / optimizer / lr_scheduler / common)."""
+        from .config import as_list, literal
+
+        opt, optim = cfg["optimization"], cfg["optimizer"]
+        if optim.get("_name", "adam") != "adam":
+            raise NotImplementedError(f"optimizer {optim.get('_name')!r} (every ASR recipe of the reference uses adam)")
+        sched = dict(cfg["lr_scheduler"])
+        name = sched.pop("_name")
+        sched.pop("lr", None)
+        if name == "reduce_lr_on_plateau_v2":
+            sched.setdefault("maximize_best_checkpoint_metric", cfg["checkpoint"]["maximize_best_checkpoint_metric"])
+        if name == "tri_stage":
+            sched.setdefault("max_update", opt["max_update"])
+            if sched.get("phase_ratio") is not None:
+                sched["phase_ratio"] = literal(sched["phase_ratio"])
+        t = cls(task, model, criterion, device, clip_norm=float(opt["clip_norm"]), lr=float(as_list(opt["lr"])[0]),
+                adam_betas=tuple(literal(optim["adam_betas"])), adam_eps=float(optim["adam_eps"]),
+                weight_decay=float(optim["weight_decay"]), seed=int(cfg["common"]["seed"]), lr_scheduler=(name, sched))
+        t.cfg = cfg
+        return t
+
+    def get_lr(self):
+        return self.optimizer.get_lr()
+
+    def lr_step_begin_epoch(self, epoch):
+        if hasattr(self.lr_scheduler, "step_begin_epoch"):
+            self.lr_scheduler.step_begin_epoch(epoch)
+        return self.get_lr()
+
+    def lr_step(self, epoch, val_loss=None):
+        """End-of-epoch schedule hook (trainer.py:1134-1138)."""
+        if hasattr(self.lr_scheduler, "step"):
+            self.lr_scheduler.step(epoch, val_loss)
+        return self.get_lr()
+
+    def _optimizer_state(self):
+        """torch.optim.Adam layout over `model.parameters()` order — what fairseq's FairseqAdam writes as
+        `last_optimizer_state` (fairseq/optim/adam.py:159-240), so either side can resume the other's checkpoint."""
+        f, o = self.flat, self.optimizer
+        state, ids = {}, []
+        for i, p in enumerate(q for q in self.model.parameters() if q.requires_grad):
+            off, n = f.offsets[id(p)], p.numel()
+            state[i] = {"step": o.step_count, "exp_avg": o.exp_avg[off:off + n].view(p.shape).clone().cpu(),
+                        "exp_avg_sq": o.exp_avg_sq[off:off + n].view(p.shape).clone().cpu()}
+            ids.append(i)
+        group = {"lr": o.lr, "betas": tuple(o.betas), "eps": o.eps, "weight_decay": o.weight_decay, "amsgrad": False, "params": ids}
+        return {"state": state, "param_groups": [group]}
+
+    def _load_optimizer_state(self, sd):
+        f, o = self.flat, self.optimizer
+        params = [q for q in self.model.parameters() if q.requires_grad]
+        if len(sd["state"]) not in (0, len(params)):
+            raise ValueError(f"optimizer state holds {len(sd['state'])} parameters, the model has {len(params)}")
+        for i, p in enumerate(params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            off, n = f.offsets[id(p)], p.numel()
+            o.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            o.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            o.step_count = int(st["step"])
+        if sd.get("param_groups"):
+            o.lr = sd["param_groups"][0].get("lr", o.lr)
+
+    def state_dict(self, extra_state=None):
+        """Checkpoint dictionary with the reference's top-level keys (fairseq/trainer.py:387-431)."""
+        sched = self.lr_scheduler.state_dict() if hasattr(self.lr_scheduler, "state_dict") else {}
+        extra = {"previous_training_time": 0.0}
+        extra.update(extra_state or {})
+        return {
+            "args": None,
+            "cfg": self.cfg,
+            "model": {k: v.detach().clone().cpu() for k, v in self.model.state_dict().items()},
+            "criterion": None,
+            "optimizer_history": self._optim_history + [{
+                "criterion_name": type(self.criterion).__name__, "optimizer_name": type(self.optimizer).__name__,
+                "lr_scheduler_state": sched, "num_updates": self.num_updates}],
+            "task_state": {},
+            "extra_state": extra,
+            "last_optimizer_state": self._optimizer_state(),
+        }
+
+    def save_checkpoint(self, filename, extra_state=None):
+        """Rank 0 writes (data-parallel replicas hold identical state); atomically, like checkpoint_utils.torch_persistent_save."""
+        import os
+
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return
+        tmp = filename + ".tmp"
+        torch.save(self.state_dict(extra_state), tmp)
+        os.replace(tmp, filename)
+
+    def load_checkpoint(self, filename, reset_optimizer=False, reset_lr_scheduler=False):
+        """Restore model / optimizer / schedule / update count (trainer.py:454-640); returns `extra_state` or None when the file
+        does not exist.  The bf16 shadow copies of the weights are refreshed from the restored fp32 masters."""
+        import os
+
+        if not os.path.exists(filename):
+            return None
+        state = torch.load(filename, map_location="cpu", weights_only=False)
+        sd = state["model"]
+        if hasattr(self.model, "upgrade_state_dict_named"):
+            sd = self.model.upgrade_state_dict_named(dict(sd), "")
+        with torch.no_grad():  # parameters are views of the flat master buffer: copy in place
+            own = self.model.state_dict()
+            missing = [k for k in own if k not in sd]
+            unexpected = [k for k in sd if k not in own]
+            if missing or unexpected:
+                raise RuntimeError(f"checkpoint does not match the model: missing {missing[:5]}, unexpected {unexpected[:5]}")
+            for k, v in own.items():
+                v.copy_(sd[k])
+        self.flat.sync_bf16()
+        hist = state.get("optimizer_history") or []
+        self._optim_history = hist[:-1]
+        last = hist[-1] if hist else None
+        if last is not None and not reset_optimizer and state.get("last_optimizer_state") is not None:
+            if last["criterion_name"] != type(self.criterion).__name__:
+                raise RuntimeError("Criterion does not match; please reset the optimizer (--reset-optimizer)")
+            self._load_optimizer_state(state["last_optimizer_state"])
+            self.num_updates = int(last["num_updates"])
+            self.model.set_num_updates(self.num_updates)
+            if not reset_lr_scheduler and hasattr(self.lr_scheduler, "load_state_dict") and last.get("lr_scheduler_state"):
+                self.lr_scheduler.load_state_dict(last["lr_scheduler_state"])
+            self.lr_scheduler.step_update(self.num_updates)
+        return state.get("extra_state") or {}

@@ -1590,3 +1590,87 @@ def check_native_decoder_layer(seed=0, C=256, heads=4, U=23, S=61):
     res["worst_grad"] = worst
     res["pad_enc_grad"] = float(runs[1][1]["__enc"].view(B, S, C)[1, S - 9:].abs().max())
     return res
+
+
+def check_speech_train_cli(tmp_dir):
+    """`espresso_amd.speech_train` on a recipe YAML in the reference's hydra layout: raw-audio data json + dictionary file ->
+    Conformer + CTC updates with update_freq 2, epoch / best / last checkpoints, validation WER, and resume: a run stopped after 3
+    updates and restarted from checkpoint_last.pt (mid-epoch) must land where an uninterrupted 6-update run lands."""
+    import contextlib
+    import io
+    import json
+
+    from espresso_amd import speech_train
+    from espresso_amd.data import audio_utils
+
+    rng = np.random.default_rng(5)
+    utts = {}
+    for i in range(12):
+        u = f"utt{i:02d}"
+        path = os.path.join(tmp_dir, u + ".wav")
+        audio_utils.write_wav(path, rng.standard_normal(int(16000 * rng.uniform(0.6, 1.6))) * 3000)
+        utts[u] = {"wave": path, "text": " ".join(f"t{int(k)}" for k in rng.integers(0, 36, size=int(rng.integers(2, 7))))}
+    for split in ("train", "valid"):
+        with open(os.path.join(tmp_dir, split + ".json"), "w") as f:
+            json.dump(utts, f)
+    with open(os.path.join(tmp_dir, "dict.txt"), "w") as f:
+        f.write("".join(f"t{i} 1\n" for i in range(36)))
+    recipe = os.path.join(tmp_dir, "recipe.yaml")
+    with open(recipe, "w") as f:
+        f.write("""
+common: {seed: 1, log_interval: 1}
+checkpoint: {save_dir: checkpoints, best_checkpoint_metric: wer, keep_last_epochs: 5}
+task:
+  _name: speech_recognition_espresso
+  data: ???
+  dict: ???
+  max_source_positions: 3600
+  max_target_positions: 200
+  autoregressive: false
+dataset: {max_tokens: 400, batch_size: 4, required_batch_size_multiple: 1, train_subset: train, valid_subset: valid, curriculum: 1}
+criterion: {_name: ctc_loss, zero_infinity: true}
+optimization: {max_epoch: 100, clip_norm: 2.0, sentence_avg: true, update_freq: [2], lr: [2.0]}
+optimizer: {_name: adam, adam_betas: "(0.9,0.98)", adam_eps: 1e-08, weight_decay: 0.0}
+lr_scheduler: {_name: noam, warmup_steps: 10, model_size: "${model.encoder.embed_dim}", final_lr: 1e-6}
+model:
+  _name: speech_transformer_encoder_model
+  encoder:
+    conv_channels: "[64, 64, 16, 16]"
+    embed_dim: 128
+    ffn_embed_dim: 256
+    layers: 2
+    attention_heads: 2
+    normalize_before: true
+    relative_positional_embeddings: true
+    layer_type: conformer
+  attention_dropout: 0.1
+  activation_dropout: 0.1
+  dropout: 0.1
+  layernorm_embedding: true
+""")
+
+    def run(save_dir, max_update):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            tr = speech_train.main(["--config", recipe, f"task.data={tmp_dir}", f"task.dict={tmp_dir}/dict.txt",
+                                    f"checkpoint.save_dir={save_dir}", f"optimization.max_update={max_update}"])
+        lines = [json.loads(l) for l in buf.getvalue().splitlines() if l.startswith("{")]
+        return tr, lines
+
+    a_dir, b_dir = os.path.join(tmp_dir, "A"), os.path.join(tmp_dir, "B")
+    tr_a, log_a = run(a_dir, 6)
+    _, log_b1 = run(b_dir, 3)
+    ck_mid = torch.load(os.path.join(b_dir, "checkpoint_last.pt"), map_location="cpu", weights_only=False)
+    tr_b, log_b2 = run(b_dir, 6)
+    sa = torch.load(os.path.join(a_dir, "checkpoint_last.pt"), map_location="cpu", weights_only=False)
+    sb = torch.load(os.path.join(b_dir, "checkpoint_last.pt"), map_location="cpu", weights_only=False)
+    diff = max(float((sa["model"][k].double() - sb["model"][k].double()).abs().max()) for k in sa["model"])
+    moved = max(float((sa["model"][k].double() - ck_mid["model"][k].double()).abs().max()) for k in sa["model"])
+    la = {l["num_updates"]: l["loss"] for l in log_a if l["kind"] == "train_inner"}
+    lb = {l["num_updates"]: l["loss"] for l in log_b1 + log_b2 if l["kind"] == "train_inner"}
+    valid = [l for l in log_a if l["kind"] == "valid"]
+    return {"files_a": sorted(os.listdir(a_dir)), "files_b": sorted(os.listdir(b_dir)), "param_diff_resumed_vs_straight": diff,
+            "param_change_updates_3_to_6": moved, "loss_a": la, "loss_b": lb,
+            "resume": [l for l in log_b2 if l["kind"] == "resume"], "mid_iterator": ck_mid["extra_state"]["train_iterator"],
+            "num_updates": (tr_a.num_updates, tr_b.num_updates), "valid": valid,
+            "hist": sb["optimizer_history"][-1]["num_updates"], "opt_step": sb["last_optimizer_state"]["state"][0]["step"]}

@@ -4,6 +4,7 @@ convert_padding_direction / edit_distance; tests/test_data_utils.py:13-136 batch
 baseline) plus dictionary layout, lr schedule, SpecAugment RNG order and registry names."""
 from collections import Counter
 
+import os
 import math
 import numpy as np
 import pytest
@@ -473,3 +474,156 @@ def test_reduce_lr_on_plateau_v2_follows_torch_plateau_logic():
     assert w.optimizer.lr == 0 and w.step_update(5) == pytest.approx(0.05) and w.step_update(10) == pytest.approx(0.1)
     w.step_update(11)
     assert w.warmup_end
+
+
+# ---- training entry point: recipe configuration, checkpoint rules, trainer state (fairseq_cli/train.py, checkpoint_utils.py) ----
+
+_RECIPE = """
+common: {seed: 3, log_interval: 10}
+checkpoint: {save_dir: ckpt, save_interval_updates: 2, keep_interval_updates: 2, keep_last_epochs: 2, best_checkpoint_metric: wer}
+task:
+  _name: speech_recognition_espresso
+  data: ???
+  dict: ???
+  autoregressive: false
+dataset: {max_tokens: 26000, batch_size: 24, train_subset: train, valid_subset: valid}
+criterion: {_name: ctc_loss, zero_infinity: true}
+optimization: {max_epoch: 100, clip_norm: 2.0, sentence_avg: true, update_freq: [2, 1], lr: [5.0]}
+optimizer: {_name: adam, adam_betas: "(0.9,0.98)", adam_eps: 1e-08, weight_decay: 0.0}
+lr_scheduler: {_name: noam, warmup_steps: 25000, model_size: "${model.encoder.embed_dim}", final_lr: 1e-6}
+model:
+  _name: speech_transformer_encoder_model
+  encoder: {embed_dim: 512, layers: 12, conv_channels: "[64, 64, 128, 128]"}
+"""
+
+
+def test_recipe_config_loader(tmp_path):
+    from espresso_amd import config as C
+
+    p = tmp_path / "recipe.yaml"
+    p.write_text(_RECIPE)
+    with pytest.raises(ValueError, match="task.data"):
+        C.load_config(str(p))
+    cfg = C.load_config(str(p), ["task.data=/d", "task.dict=/d/dict.txt", "model.encoder.embed_dim=256", "+checkpoint.patience=3",
+                                 "optimization.lr=[2.5]", "dataset.valid_subset=valid,dev"])
+    assert cfg["task"]["data"] == "/d" and cfg["checkpoint"]["patience"] == 3
+    assert cfg["lr_scheduler"]["model_size"] == 256 and isinstance(cfg["lr_scheduler"]["model_size"], int)  # interpolation keeps the type
+    assert cfg["checkpoint"]["restore_file"] == "checkpoint_last.pt" and cfg["dataset"]["required_batch_size_multiple"] == 8  # defaults
+    assert C.literal(cfg["optimizer"]["adam_betas"]) == (0.9, 0.98)
+    assert C.literal(cfg["model"]["encoder"]["conv_channels"]) == [64, 64, 128, 128]
+    assert C.as_list(cfg["optimization"]["lr"]) == [2.5]
+    assert [C.per_epoch(cfg["optimization"]["update_freq"], e) for e in (1, 2, 3, 9)] == [2, 1, 1, 1]
+    assert cfg["dataset"]["valid_subset"] == "valid,dev"
+    with pytest.raises(ValueError):
+        C.load_config(str(p), ["task.data"])
+
+
+class _FakeTrainer:
+    def __init__(self):
+        self.num_updates, self.saved = 0, []
+
+    def save_checkpoint(self, filename, extra_state=None):
+        self.saved.append((os.path.basename(filename), dict(extra_state)))
+        with open(filename, "w") as f:
+            f.write("x")
+
+
+def test_checkpoint_naming_and_retention(tmp_path):
+    """The file names and pruning of fairseq/checkpoint_utils.py:34-172 for a minimising and a maximising metric."""
+    from espresso_amd.checkpoint_utils import CheckpointSaver, checkpoint_paths
+    from espresso_amd.config import DEFAULTS
+
+    cfg = dict(DEFAULTS["checkpoint"], save_dir=str(tmp_path / "c"), save_interval_updates=2, keep_interval_updates=2, keep_last_epochs=2,
+               keep_best_checkpoints=2, best_checkpoint_metric="wer")
+    saver, tr = CheckpointSaver(cfg), _FakeTrainer()
+    ls = lambda: sorted(os.listdir(cfg["save_dir"]))
+    tr.num_updates = 2
+    files = saver.save(tr, 1, False, {"epoch": 1, "iterations_in_epoch": 2}, 30.0)
+    assert [os.path.basename(f) for f in files][:2] == ["checkpoint_1_2.pt", "checkpoint_best.pt"] and "checkpoint_last.pt" in ls()
+    assert tr.saved[-1][1]["train_iterator"]["iterations_in_epoch"] == 2 and tr.saved[-1][1]["best"] == 30.0
+    tr.num_updates = 4
+    saver.save(tr, 1, False, {}, 35.0)  # worse: no new checkpoint_best
+    assert len(tr.saved) == 2 and tr.saved[-1][0] == "checkpoint_1_4.pt" and tr.saved[-1][1]["best"] == 30.0
+    tr.num_updates = 6
+    saver.save(tr, 1, False, {}, 20.0)
+    names = ls()
+    assert "checkpoint_1_2.pt" not in names and {"checkpoint_1_4.pt", "checkpoint_1_6.pt"} <= set(names)  # keep_interval_updates = 2
+    kept_best = [n for n in names if n.startswith("checkpoint.best_wer_")]
+    assert len(kept_best) == 2 and all(n.startswith(("checkpoint.best_wer_20.000", "checkpoint.best_wer_30.000")) for n in kept_best)
+    for ep in (1, 2, 3):
+        tr.num_updates += 1
+        saver.save(tr, ep, True, {"epoch": ep}, None)  # no validation: never touches checkpoint_best
+    names = ls()
+    assert "checkpoint1.pt" not in names and {"checkpoint2.pt", "checkpoint3.pt"} <= set(names)  # keep_last_epochs = 2
+    assert [os.path.basename(p) for p in checkpoint_paths(cfg["save_dir"])] == ["checkpoint3.pt", "checkpoint2.pt"]
+    assert saver.best == 20.0
+    cfg2 = dict(cfg, save_dir=str(tmp_path / "m"), maximize_best_checkpoint_metric=True, keep_best_checkpoints=-1)
+    s2, t2 = CheckpointSaver(cfg2), _FakeTrainer()
+    for n, score in ((2, 0.5), (4, 0.4), (6, 0.7)):
+        t2.num_updates = n
+        s2.save(t2, 1, False, {}, score)
+    assert [("checkpoint_best.pt" in os.listdir(cfg2["save_dir"])), s2.best] == [True, 0.7]
+    assert sum(1 for name, _ in t2.saved if name.startswith("checkpoint_1_")) == 3
+    cfg3 = dict(cfg, save_dir=str(tmp_path / "n"), no_save=True)
+    assert CheckpointSaver(cfg3).save(_FakeTrainer(), 1, True, {}, 1.0) == [] and not os.path.exists(cfg3["save_dir"])
+
+
+def test_trainer_checkpoint_round_trip(tmp_path):
+    """Trainer.state_dict has the reference's top-level keys and a torch.optim.Adam-shaped optimizer state
+    (fairseq/trainer.py:387-431); loading restores masters, moments, update count and the schedule on a fresh trainer."""
+    import torch.nn as nn
+
+    from espresso_amd.trainer import Trainer
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(8, 16), nn.Linear(16, 4)
+            self.register_buffer("running", torch.zeros(3))
+            self.n = 0
+
+        def set_num_updates(self, n):
+            self.n = n
+
+    class Crit:
+        pass
+
+    def make(seed):
+        torch.manual_seed(seed)
+        return Trainer(None, M(), Crit(), torch.device("cpu"), lr=1e-3, lr_scheduler=("tri_stage", dict(warmup_steps=10, hold_steps=10, decay_steps=10)))
+
+    t = make(0)
+    t.optimizer.exp_avg.normal_()
+    t.optimizer.exp_avg_sq.uniform_()
+    t.optimizer.step_count = t.num_updates = 7
+    t.lr_scheduler.step_update(7)
+    t.model.running.fill_(2.5)
+    sd = t.state_dict({"train_iterator": {"epoch": 2, "iterations_in_epoch": 5}})
+    assert {"args", "cfg", "model", "criterion", "optimizer_history", "task_state", "extra_state", "last_optimizer_state"} <= set(sd)
+    assert sd["optimizer_history"][-1] == {"criterion_name": "Crit", "optimizer_name": "FlatAdam", "lr_scheduler_state": {}, "num_updates": 7}
+    los = sd["last_optimizer_state"]
+    assert list(los["state"]) == [0, 1, 2, 3] and los["state"][0]["exp_avg"].shape == (16, 8) and los["state"][3]["step"] == 7
+    assert los["param_groups"][0]["params"] == [0, 1, 2, 3] and los["param_groups"][0]["betas"] == (0.9, 0.98)
+    # the same layout torch's own Adam produces for this module
+    ref = torch.optim.Adam(M().parameters())
+    assert set(ref.state_dict()["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "params"}
+    path = str(tmp_path / "ck.pt")
+    t.save_checkpoint(path, {"train_iterator": {"epoch": 2, "iterations_in_epoch": 5}})
+    t2 = make(1)
+    assert not torch.equal(t2.model.a.weight, t.model.a.weight)
+    extra = t2.load_checkpoint(path)
+    assert extra["train_iterator"] == {"epoch": 2, "iterations_in_epoch": 5}
+    a, b = t._optimizer_state()["state"], t2._optimizer_state()["state"]  # (alignment padding between parameters is not state)
+    assert torch.equal(t2.flat.p32, t.flat.p32) and torch.equal(t2.model.running, t.model.running)
+    assert all(torch.equal(a[i][k], b[i][k]) for i in a for k in ("exp_avg", "exp_avg_sq")) and float(b[2]["exp_avg"].abs().sum()) > 0
+    assert t2.model.a.weight.data_ptr() == t2.flat.p32.data_ptr() + 4 * t2.flat.offsets[id(t2.model.a.weight)]  # still views
+    assert (t2.num_updates, t2.optimizer.step_count, t2.model.n) == (7, 7, 7) and t2.get_lr() == pytest.approx(t.get_lr())
+    t3 = make(2)
+    t3.load_checkpoint(path, reset_optimizer=True)
+    assert t3.num_updates == 0 and float(t3.optimizer.exp_avg.abs().sum()) == 0.0 and torch.equal(t3.flat.p32, t.flat.p32)
+    assert make(3).load_checkpoint(str(tmp_path / "absent.pt")) is None
+    bad = dict(sd)
+    bad["model"] = {k: v for k, v in sd["model"].items() if k != "b.bias"}
+    torch.save(bad, str(tmp_path / "bad.pt"))
+    with pytest.raises(RuntimeError, match="does not match the model"):
+        make(4).load_checkpoint(str(tmp_path / "bad.pt"))
