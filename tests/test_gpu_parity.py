@@ -1,4 +1,6 @@
 """`-m gpu` parity tests: HIP path (through the C ABI) vs the oracle / reference golden fixtures."""
+import math
+
 import pytest
 import torch
 
@@ -318,18 +320,18 @@ def test_speech_train_cli_checkpoints_and_resume(tmp_path):
     r = G.check_speech_train_cli(str(tmp_path))
     print(r)
     assert r["num_updates"] == (6, 6) and r["hist"] == 6 and r["opt_step"] == 6, r
-    # 12 utterances / 4 per batch / update_freq 2 -> 2 updates per epoch: 3 epoch checkpoints, best and last
-    assert {"checkpoint1.pt", "checkpoint2.pt", "checkpoint3.pt", "checkpoint_best.pt", "checkpoint_last.pt"} <= set(r["files_a"]), r
-    assert {"checkpoint_2_3.pt", "checkpoint_last.pt"} <= set(r["files_b"]) or "checkpoint_last.pt" in r["files_b"], r
-    assert r["mid_iterator"]["epoch"] == 2 and r["mid_iterator"]["iterations_in_epoch"] == 2 and not r["mid_iterator"]["end_of_epoch"], r
-    assert r["resume"] and r["resume"][0]["num_updates"] == 3 and r["resume"][0]["iterations_in_epoch"] == 2, r
+    # 5 batches per epoch / update_freq 2 -> 3 updates per epoch: 2 epoch checkpoints, best and last
+    assert {"checkpoint1.pt", "checkpoint2.pt", "checkpoint_best.pt", "checkpoint_last.pt"} <= set(r["files_a"]), r
+    assert {"checkpoint1.pt", "checkpoint2.pt", "checkpoint_last.pt"} <= set(r["files_b"]), r
+    assert r["mid_iterator"]["epoch"] == 1 and r["mid_iterator"]["iterations_in_epoch"] == 4 and not r["mid_iterator"]["end_of_epoch"], r
+    assert r["resume"] and r["resume"][0]["num_updates"] == 2 and r["resume"][0]["iterations_in_epoch"] == 4, r
     assert sorted(r["loss_a"]) == sorted(r["loss_b"]) == [1, 2, 3, 4, 5, 6], r
-    assert all(np.isfinite(v) for v in r["loss_a"].values()), r
+    assert all(math.isfinite(v) for v in r["loss_a"].values()), r
     assert all(abs(r["loss_a"][k] - r["loss_b"][k]) <= 2e-2 * max(1.0, abs(r["loss_a"][k])) for k in r["loss_a"]), r
     # the resumed run lands where the straight run lands (fp32 atomics in split-K reductions allow rounding-level drift), and
-    # that distance is small against what updates 4..6 changed
-    assert r["param_diff_resumed_vs_straight"] < 0.05 * r["param_change_updates_3_to_6"], r
-    assert r["valid"] and all(v["wer"] >= 0.0 and np.isfinite(v["loss"]) for v in r["valid"]), r
+    # that distance is small against what updates 3..6 changed
+    assert r["param_diff_resumed_vs_straight"] < 0.05 * r["param_change_since_resume_point"], r
+    assert r["valid"] and all(v["wer"] >= 0.0 and math.isfinite(v["loss"]) for v in r["valid"]), r
 
 
 def test_global_cmvn_stats_tool(tmp_path):
