@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=15000)
     ap.add_argument("--batch-size", type=int, default=24)
     ap.add_argument("--lm", action="store_true", help="shallow fusion with an LSTM LM (lstm_lm_librispeech: 4 x 800)")
+    ap.add_argument("--wordlm", action="store_true",
+                    help="look-ahead word-LM fusion (config 5): character units, 65 000-word lexicon, lstm_wordlm_wsj (3 x 1200) through "
+                         "TensorizedLookaheadLanguageModel")
     ap.add_argument("--lm-weight", type=float, default=0.47)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -33,8 +36,13 @@ def main():
     from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
 
     torch.manual_seed(1)
-    d = AsrDictionary.from_symbols([f"u{i}" for i in range(VOCAB - 4)], enable_bos=False)
-    d.add_symbol if False else None
+    vocab = VOCAB
+    if args.wordlm:  # the look-ahead LM walks a character prefix tree: character units + <space>, like the reference's WSJ recipe
+        chars = [chr(ord("a") + i) for i in range(26)] + ["'", ".", "-"] + [f"<n{i}>" for i in range(18)]
+        d = AsrDictionary.from_symbols(chars, enable_bos=False)
+        vocab = len(d)
+    else:
+        d = AsrDictionary.from_symbols([f"u{i}" for i in range(VOCAB - 4)], enable_bos=False)
     task = SpeechRecognitionEspressoTask.setup_task(SpeechRecognitionEspressoConfig(seed=1), tgt_dict=d)
     cfg = SpeechTransformerConfig()
     e, dc = cfg.encoder, cfg.decoder
@@ -49,11 +57,24 @@ def main():
     lm = None
     if args.lm:
         lm = LSTMLanguageModelEspresso.build_model(dict(arch="lstm_lm_librispeech"), task).to(dev).eval()
+    if args.wordlm:
+        from espresso_amd.models.tensorized_lookahead_language_model import TensorizedLookaheadLanguageModel
+
+        rng = np.random.default_rng(7)
+        words = set()
+        while len(words) < 65000:  # random lexicon over the 26 letters, lengths 2..10
+            words.add("".join(chr(ord("a") + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(2, 11)))))
+        wd = AsrDictionary.from_symbols(sorted(words), enable_bos=False, add_space=False)
+
+        class _LMTask:
+            word_dictionary = target_dictionary = source_dictionary = wd
+        wlm = LSTMLanguageModelEspresso.build_model(dict(arch="lstm_wordlm_wsj", dropout=0.0), _LMTask).to(dev).eval()
+        lm = TensorizedLookaheadLanguageModel(wlm, d, oov_penalty=1e-4, open_vocab=True)
     batches, n_samples = synthetic.make_batches(2000, max_tokens=args.max_tokens, max_sentences=args.batch_size, seed=3)
-    samples = [synthetic.make_sample(b, n_samples, VOCAB, d.pad(), dev, seed=3) for b in batches[: args.batches + 1]]
+    samples = [synthetic.make_sample(b, n_samples, vocab, d.pad(), dev, seed=3) for b in batches[: args.batches + 1]]
     task.build_frontend(dev)
     gen = SequenceGenerator([model], d, beam_size=args.beam, max_len_a=0.08, max_len_b=0, lm_model=lm, lm_weight=args.lm_weight,
-                            eos_factor=1.5 if args.lm else None)
+                            eos_factor=1.5 if (args.lm or args.wordlm) else None)
 
     def run(s):
         s = task.prepare_sample(s, train=False)
@@ -70,9 +91,9 @@ def main():
     el = time.perf_counter() - t0
     audio = sum(s["audio_seconds"] for s in samples[1:])
     nsent = sum(s["nsentences"] for s in samples[1:])
-    print(json.dumps({"metric": "decode RTF", "value": el / audio, "beam": args.beam, "lm_fusion": bool(args.lm), "sentences": nsent,
+    print(json.dumps({"metric": "decode RTF", "value": el / audio, "beam": args.beam, "lm_fusion": "lookahead_wordlm_65k_3x1200" if args.wordlm else bool(args.lm), "sentences": nsent,
                       "audio_seconds": audio, "wall_seconds": el, "sentences_per_s": nsent / el, "best_hyp_tokens_per_s": ntok / el,
-                      "model": "conv4 + 12-layer rel-pos Transformer encoder + 6-layer decoder, V=5004, bf16, random init (max-length hypotheses)",
+                      "model": f"conv4 + 12-layer rel-pos Transformer encoder + 6-layer decoder, V={vocab}, bf16, random init (max-length hypotheses)",
                       "data": "synthetic 16 kHz"}))
 
 
