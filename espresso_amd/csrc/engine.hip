@@ -49,7 +49,8 @@ struct Ctx {
     if (!c.dry && c.rc == 0) c.rc = (call); \
   } while (0)
 
-// process-wide side stream + a small ring of events (created on first use)
+// process-wide side stream + a small ring of events (created on first use, on the device that owns the caller's stream: one
+// process drives one GPU, but the calling thread's current device is whatever the host framework left it at)
 struct SideRes {
   hipStream_t stream = nullptr;
   hipEvent_t ev[32];
@@ -57,13 +58,22 @@ struct SideRes {
   bool ok = false;
 };
 static SideRes g_side;
-static bool side_init() {
+static bool side_init(hipStream_t owner) {
   if (g_side.ok) return true;
-  if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return false;
+  int cur = 0, dev = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return false;
+  dev = cur;
+  if (owner != nullptr) {
+    hipDevice_t d;
+    if (hipStreamGetDevice(owner, &d) == hipSuccess) dev = (int)d;
+  }
+  if (dev != cur && hipSetDevice(dev) != hipSuccess) return false;
+  bool ok = hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) == hipSuccess;
   for (auto& e : g_side.ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-  g_side.ok = true;
-  return true;
+    ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  if (dev != cur) (void)hipSetDevice(cur);
+  g_side.ok = ok;
+  return ok;
 }
 // make `dst` wait for everything enqueued so far on `src`
 static inline void stream_wait(Ctx& c, hipStream_t dst, hipStream_t src) {
@@ -907,7 +917,7 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
                            const int* key_len, const void* pe, void* saved, long saved_bytes, void* scratch, long scratch_bytes,
                            hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
-  const bool ov = g_overlap_default && side_init();
+  const bool ov = g_overlap_default && side_init(stream);
   if (!arenas_fit(*shape, true, ov, saved_bytes, scratch_bytes)) return -5;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
@@ -945,7 +955,7 @@ int ea_transformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* 
                              long scratch_bytes, hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
   if ((shape->pos_mode == 1) != (dpe != nullptr)) return -2;
-  const bool ov = g_overlap_default && side_init();
+  const bool ov = g_overlap_default && side_init(stream);
   if (!arenas_fit(*shape, true, ov, saved_bytes, scratch_bytes, true)) return -5;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
@@ -980,7 +990,7 @@ int ea_decoder_layer_bwd(const EaDecoderLayer* layer, const EaLayerShape* shape,
                          void* dx, void* denc, const int* enc_len, void* saved, long saved_bytes, void* scratch, long scratch_bytes,
                          hipStream_t stream) {
   if (!dshape_ok(*shape)) return -2;
-  const bool ov = g_overlap_default && side_init();
+  const bool ov = g_overlap_default && side_init(stream);
   if (!darenas_fit(*shape, true, ov, saved_bytes, scratch_bytes)) return -5;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
