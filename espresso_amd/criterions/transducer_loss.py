@@ -1,5 +1,5 @@
 """`transducer_loss` criterion — interface and bookkeeping of espresso/criterions/transducer_loss.py:44-192: targets are
-`target[:, :-1]` (EOS stripped) as int32, blank = "<s>" index, per-utterance loss from the RNN-T kernel, sum reduction,
+`target[:, :-1]` (EOS stripped; the whole target with `task.include_eos_in_transducer_loss`) as int32, blank = "<s>" index, per-utterance loss from the RNN-T kernel, sum reduction,
 sentence_avg sample size.  The arithmetic is csrc/rnnt.hip (the reference calls torchaudio.functional.rnnt_loss)."""
 import math
 
@@ -17,14 +17,19 @@ class TransducerLossCriterion:
         self.blank_idx = d.index(task.blank_symbol) if getattr(task, "blank_symbol", None) else d.bos()
         self.pad_idx, self.eos_idx = d.pad(), d.eos()
         self.sentence_avg = sentence_avg
+        self.include_eos = bool(getattr(getattr(task, "cfg", None), "include_eos_in_transducer_loss", False))  # II("task.…") :40
 
     def __call__(self, model, sample, reduce=True):
         return self.forward(model, sample, reduce)
 
     def forward(self, model, sample, reduce=True):
         net_output, encoder_out_lengths = model(**sample["net_input"])  # (B, T', U+1, V), (B,)
-        target = sample["target"][:, :-1].contiguous() if sample["target"].size(1) > 1 else sample["target"]
-        target_lengths = (sample["target"].ne(self.pad_idx) & sample["target"].ne(self.eos_idx)).sum(-1)
+        if self.include_eos:
+            target = sample["target"]
+            target_lengths = sample["target"].ne(self.pad_idx).sum(-1)
+        else:
+            target = sample["target"][:, :-1].contiguous() if sample["target"].size(1) > 1 else sample["target"]
+            target_lengths = (sample["target"].ne(self.pad_idx) & sample["target"].ne(self.eos_idx)).sum(-1)
         loss = F.rnnt_loss(net_output, target.to(torch.int32).contiguous(), encoder_out_lengths.to(torch.int32).contiguous(),
                            target_lengths.to(torch.int32).contiguous(), blank=self.blank_idx).sum()
         nsentences = sample["target"].size(0)

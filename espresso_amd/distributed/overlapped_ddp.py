@@ -50,6 +50,12 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self._pending = list(self._bucket_total)
         self._works: List = []
         self._launched = [False] * len(self.buckets)
+        # per-step accounting: a parameter must report "gradient complete" at most once per update (autograd's
+        # post-accumulate hook OR the native runtime's callback, never both) — a second report would release its bucket
+        # to RCCL before the other gradients in it exist, which no single-rank run can notice
+        self._index = {id(p): i for i, p in enumerate(flat.params)}
+        self._fired = [0] * len(flat.params)
+        self.max_fired = 0
         self._hooks = {id(p): self._make_hook(p) for p in flat.params}
         if self.active:
             for p in flat.params:
@@ -62,10 +68,12 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
 
     def _make_hook(self, p):
         ids = self._param_buckets[id(p)]
+        k = self._index[id(p)]
 
         def hook(param):
             if self.accumulate_grads:
                 return
+            self._fired[k] += 1
             for i in ids:
                 self._pending[i] -= 1
                 if self._pending[i] == 0:
@@ -110,6 +118,12 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         """Finish the step's reduction: launch buckets whose hooks did not all fire (unused parameters,
         dummy batches — trainer.py:873-877), wait for RCCL, re-arm.  Gradients hold the SUM over ranks."""
         if self.active:
+            top = max(self._fired) if self._fired else 0
+            self.max_fired = max(self.max_fired, top)
+            if top > 1:
+                bad = [i for i, n in enumerate(self._fired) if n > 1]
+                raise RuntimeError(f"{len(bad)} parameter(s) reported their gradient complete more than once in one update "
+                                   f"(flat indices {bad[:8]}): buckets were reduced before they were full")
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)
@@ -120,6 +134,7 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self._works = []
         self._pending = list(self._bucket_total)
         self._launched = [False] * len(self.buckets)
+        self._fired = [0] * len(self._fired)
 
     def __getattr__(self, name):
         try:

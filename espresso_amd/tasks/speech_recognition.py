@@ -44,6 +44,15 @@ class SpeechRecognitionEspressoConfig:
     sentencepiece_model: Optional[str] = None
 
 
+def uses_blank(cfg) -> bool:
+    """`<s>` is enabled and reserved as the blank for `ctc_loss` / `transducer_loss` (speech_recognition.py:323-327, 345-352: decided
+    by the criterion's name).  The transducer recipes set `autoregressive: true` (input feeding for the predictor) together with
+    `transducer_loss`; `ctc_loss` — also this dataclass's default when no criterion was named — never comes with an
+    autoregressive target side, so that combination means "criterion unspecified": no blank."""
+    name = getattr(cfg, "criterion_name", None)
+    return name == "transducer_loss" or (name == "ctc_loss" and not cfg.autoregressive)
+
+
 @registry.register_task("speech_recognition_espresso", dataclass=SpeechRecognitionEspressoConfig)
 class SpeechRecognitionEspressoTask:
     def __init__(self, cfg, tgt_dict, feat_dim=80, word_dict=None):
@@ -52,8 +61,8 @@ class SpeechRecognitionEspressoTask:
         self.word_dict = word_dict
         self.feat_dim = feat_dim
         self.feat_in_channels = cfg.feat_in_channels
-        # CTC / transducer (non-autoregressive target side) use "<s>" as the blank symbol
-        self.blank_symbol = tgt_dict.bos_word if not cfg.autoregressive else None
+        # CTC / transducer use "<s>" as the blank symbol
+        self.blank_symbol = tgt_dict.bos_word if uses_blank(cfg) else None
         self.frontend = None
         self.epoch = 1
         self.datasets = {}
@@ -67,7 +76,7 @@ class SpeechRecognitionEspressoTask:
     @classmethod
     def setup_task(cls, cfg, tgt_dict=None):
         if tgt_dict is None:
-            tgt_dict = cls.load_dictionary(cfg.dict, enable_bos=not cfg.autoregressive, non_lang_syms=cfg.non_lang_syms)
+            tgt_dict = cls.load_dictionary(cfg.dict, enable_bos=uses_blank(cfg), non_lang_syms=cfg.non_lang_syms)
         word_dict = None
         if getattr(cfg, "word_dict", None):
             word_dict = cls.load_dictionary(cfg.word_dict, enable_bos=False)
@@ -88,14 +97,21 @@ class SpeechRecognitionEspressoTask:
         from ..data.asr_dataset import get_asr_dataset_from_json
 
         train = split == getattr(self.cfg, "train_subset", "train")
-        ds = get_asr_dataset_from_json(self.cfg.data, split, self.tgt_dict, combine=combine, shuffle=train,
-                                       pad_to_multiple=getattr(self.cfg, "required_seq_len_multiple", 1),
-                                       autoregressive=self.cfg.autoregressive,
-                                       prepend_bos_as_input_feeding=getattr(self.cfg, "prepend_bos_as_input_feeding", False),
-                                       batch_based_on_both_src_tgt=getattr(self.cfg, "batch_based_on_both_src_tgt", False),
-                                       pin_memory=pin_memory and torch.cuda.is_available())
+        transducer = getattr(self.cfg, "criterion_name", None) == "transducer_loss"
+        ds = get_asr_dataset_from_json(
+            self.cfg.data, split, self.tgt_dict, combine=combine, shuffle=train,
+            pad_to_multiple=getattr(self.cfg, "required_seq_len_multiple", 1), autoregressive=self.cfg.autoregressive,
+            # :449-454: the transducer recipes feed <s> ... when </s> is part of the loss, and batch by frames x tokens
+            prepend_bos_as_input_feeding=(getattr(self.cfg, "prepend_bos_as_input_feeding", False)
+                                          or (transducer and getattr(self.cfg, "include_eos_in_transducer_loss", False))),
+            batch_based_on_both_src_tgt=getattr(self.cfg, "batch_based_on_both_src_tgt", False) or transducer,
+            pin_memory=pin_memory and torch.cuda.is_available())
         self.datasets[split] = ds
         self.feat_dim = ds.src.feat_dim
+        if train and ds.tgt is not None:  # :462-469: counts of </s> and <unk> from the training targets (unigram label smoothing)
+            self.tgt_dict.count[self.tgt_dict.eos()] = len(ds.tgt)
+            unk = self.tgt_dict.unk()
+            self.tgt_dict.count[unk] = int(sum(int((ds.tgt[i][0] == unk).sum()) for i in range(len(ds.tgt))))
         return ds
 
     def dataset(self, split):

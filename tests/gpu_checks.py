@@ -378,17 +378,18 @@ class _TaskAR:
         assert len(self.target_dictionary) == V
 
 
-def build_tiny_encdec(V=40):
+def build_tiny_encdec(V=40, embed_dim=64, heads=4, learned_pos=False):
     from espresso_amd.models.transformer.speech_transformer_base import SpeechTransformerModelBase
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
 
     cfg = SpeechTransformerConfig()
     e, d = cfg.encoder, cfg.decoder
-    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 64, 128, 2, 4
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = embed_dim, 128, 2, heads
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "transformer"
+    e.learned_pos = learned_pos
     e.conv_channels = "[64, 64, 16, 16]"
-    d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads, d.normalize_before = 64, 128, 2, 4, True
-    d.input_dim = d.output_dim = 64
+    d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads, d.normalize_before = embed_dim, 128, 2, heads, True
+    d.input_dim = d.output_dim = embed_dim
     cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
     cfg.layernorm_embedding = True
     cfg.max_source_positions, cfg.max_target_positions = 3600, 200
@@ -730,13 +731,13 @@ def check_lstm_layer(B=5, U=9, I=48, H=64, with_state=False, seed=0):
     return res
 
 
-def build_tiny_transducer(V=40):
+def build_tiny_transducer(V=40, embed_dim=64, heads=4):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerTransducerConfig
     from espresso_amd.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase
 
     cfg = SpeechTransformerTransducerConfig()
     e, d = cfg.encoder, cfg.decoder
-    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 64, 128, 2, 4
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = embed_dim, 128, 2, heads
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "conformer"
     e.conv_channels = "[64, 64, 16, 16]"
     d.embed_dim, d.hidden_size, d.layers, d.residual, d.dropout_in, d.dropout_out = 48, 64, 2, True, 0.0, 0.0
@@ -1675,3 +1676,95 @@ model:
             "resume": [l for l in log_b2 if l["kind"] == "resume"], "mid_iterator": ck_mid["extra_state"]["train_iterator"],
             "num_updates": (tr_a.num_updates, tr_b.num_updates), "valid": valid,
             "hist": sb["optimizer_history"][-1]["num_updates"], "opt_step": sb["last_optimizer_state"]["state"][0]["step"]}
+
+
+def check_ddp_bucket_accounting(tmp_dir):
+    """Data-parallel wrapper armed on ONE rank (RCCL group of size 1, EA_DDP_FORCE=1): for every model family, one update with a
+    single micro-batch and one with two (the first under no_sync).  Every parameter must report "gradient complete" exactly
+    once per update — through autograd's hook or through the native layer runtime's callback, never both (a double report
+    would hand a half-filled bucket to RCCL, which only a multi-rank run could notice) — and every parameter that received a
+    gradient must have reported."""
+    import json
+    import socket
+
+    import torch.distributed as dist
+
+    from espresso_amd import functional as F
+    from espresso_amd.data import audio_utils
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
+    from espresso_amd.trainer import Trainer
+
+    rng = np.random.default_rng(11)
+    utts = {}
+    for i in range(9):
+        u = f"utt{i}"
+        path = os.path.join(tmp_dir, u + ".wav")
+        audio_utils.write_wav(path, rng.standard_normal(int(16000 * rng.uniform(0.6, 1.6))) * 3000)
+        utts[u] = {"wave": path, "text": " ".join(f"t{int(k)}" for k in rng.integers(0, 35, size=int(rng.integers(2, 7))))}
+    with open(os.path.join(tmp_dir, "train.json"), "w") as f:
+        json.dump(utts, f)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {"EA_DDP_FORCE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    dist.init_process_group(backend="nccl", device_id=torch.device(DEV))
+    res = {}
+    try:
+        fams = [  # (family, autoregressive target side, "<s>" = blank in the dictionary, criterion, its options, model)
+            ("conformer_ctc", False, True, "ctc_loss", {}, lambda: build_tiny_model("conformer", embed_dim=128, heads=2)),
+            ("transformer_learned_ctc", False, True, "ctc_loss", {},
+             lambda: build_tiny_model("transformer", embed_dim=128, heads=2, learned_pos=True)),
+            ("encdec_lsce", True, False, "label_smoothed_cross_entropy_v2", {"label_smoothing": 0.1},
+             lambda: build_tiny_encdec(embed_dim=128, heads=2, learned_pos=True)),
+            # the transducer recipes: `autoregressive: true` (input feeding for the predictor) with the blank enabled
+            ("transducer", True, True, "transducer_loss", {}, lambda: build_tiny_transducer(embed_dim=128, heads=2)),
+            ("speech_lstm", True, False, "label_smoothed_cross_entropy_v2", {"label_smoothing": 0.1}, build_tiny_speech_lstm),
+        ]
+        for name, ar, blank, crit_name, ckw, make in fams:
+            torch.manual_seed(0)
+            d = (_Task(40) if blank else _TaskAR(40)).target_dictionary
+            task = SpeechRecognitionEspressoTask.setup_task(
+                SpeechRecognitionEspressoConfig(data=tmp_dir, autoregressive=ar, criterion_name=crit_name), tgt_dict=d)
+            task.build_frontend(DEV)
+            ds = task.load_dataset("train")
+            # (the transducer data set batches by frames x tokens, speech_recognition.py:454)
+            batches = task.get_batches(ds, max_tokens=4000 if crit_name == "transducer_loss" else 400, max_sentences=3, seed=1, epoch=1)
+            samples = [task.to_device(ds.collater([ds[int(i)] for i in b]), DEV) for b in batches[:3]]
+            model = make()
+            crit = task.build_criterion(crit_name, sentence_avg=False, **ckw)
+            tr = Trainer(task, model, crit, DEV, lr=1e-3, lr_scheduler=("tri_stage", dict(warmup_steps=5, hold_steps=5, decay_steps=5)))
+            tr.reserve(samples[:1])
+            fired = []
+            orig = tr.ddp.all_reduce_grads
+
+            def spy(orig=orig, tr=tr, fired=fired):
+                fired.append(list(tr.ddp._fired))
+                # parameters whose gradient is non-zero at this point must have reported
+                fired.append([bool(p.grad.abs().sum() > 0) for p in tr.flat.params])
+                return orig()
+
+            tr.ddp.all_reduce_grads = spy
+            tr.train_step([samples[0]])
+            tr.train_step([samples[1], samples[2]])
+            torch.cuda.synchronize()
+            names = {id(p): n for n, p in tr.model.named_parameters()}
+            silent = set()
+            for counts, has_grad in (fired[0:2], fired[2:4]):
+                silent |= {names[id(p)] for p, c, g in zip(tr.flat.params, counts, has_grad) if g and c == 0}
+            res[name] = {"active": tr.ddp.active, "max_fired": tr.ddp.max_fired, "has_grad_but_silent": sorted(silent),
+                         "reported": [sum(1 for c in fired[0] if c), sum(1 for c in fired[2] if c)], "n_params": len(tr.flat.params),
+                         "native_layers": sum(1 for m in tr.model.modules() if getattr(m, "_ea_binding", None) is not None),
+                         "finite": bool(torch.isfinite(tr.flat.p32).all())}
+            F.set_grad_ready_callback(None)
+    finally:
+        F.set_grad_ready_callback(None)
+        dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return res

@@ -334,6 +334,15 @@ def test_speech_train_cli_checkpoints_and_resume(tmp_path):
     assert r["valid"] and all(v["wer"] >= 0.0 and math.isfinite(v["loss"]) for v in r["valid"]), r
 
 
+def test_ddp_every_parameter_reports_once_per_update(tmp_path):
+    r = G.check_ddp_bucket_accounting(str(tmp_path))
+    print(r)
+    for fam, v in r.items():
+        assert v["active"] and v["max_fired"] == 1 and not v["has_grad_but_silent"] and v["finite"], (fam, v)
+        assert v["reported"][0] == v["reported"][1] > 0.9 * v["n_params"], (fam, v)
+    assert all(r[f]["native_layers"] >= 2 for f in ("conformer_ctc", "transformer_learned_ctc", "encdec_lsce", "transducer")), r
+
+
 def test_global_cmvn_stats_tool(tmp_path):
     r = G.check_global_cmvn_stats(str(tmp_path))
     assert r["mean_abs"] < 2e-4 and r["std_abs"] < 2e-4 and r["dtype64"] and r["num_frames_equal"], r
