@@ -42,6 +42,19 @@ DEFAULTS: Dict[str, Dict[str, Any]] = {
 }
 
 _INTERP = re.compile(r"\$\{([^}]+)\}")
+# PyYAML follows YAML 1.1, where a float needs a dot: the recipes' `adam_eps: 1e-08`, `final_lr: 1e-6`, `warmup_init_lr: 1e-05`
+# arrive as strings.  omegaconf (what the reference parses them with) reads them as floats — so does this loader.
+_FLOAT = re.compile(r"[+-]?(\d+\.?\d*|\.\d+)[eE][+-]?\d+")
+
+
+def _numbers(node):
+    if isinstance(node, dict):
+        return {k: _numbers(v) for k, v in node.items()}
+    if isinstance(node, list):
+        return [_numbers(v) for v in node]
+    if isinstance(node, str) and _FLOAT.fullmatch(node.strip()):
+        return float(node)
+    return node
 
 
 def _lookup(cfg, dotted):
@@ -99,7 +112,7 @@ def load_config(path: Optional[str], overrides: Optional[List[str]] = None, base
             raise ValueError(f"override must look like group.key=value, got {ov!r}")
         k, v = ov.split("=", 1)
         _set(cfg, k.lstrip("+"), yaml.safe_load(v) if v != "" else None)
-    cfg = _resolve(cfg, cfg)
+    cfg = _numbers(_resolve(cfg, cfg))
     miss = _missing(cfg)
     if miss:
         raise ValueError("Missing mandatory value(s): " + ", ".join(miss))

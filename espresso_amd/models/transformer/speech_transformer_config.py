@@ -42,6 +42,8 @@ class SpeechDecoderConfig:
     learned_pos: bool = False
     layerdrop: float = 0.0
     relative_positional_embeddings: bool = False
+    share_learned_relative_positional_embeddings_across_layers: bool = False  # (read only with relative positions in the decoder)
+    share_learned_relative_positional_embeddings_across_heads: bool = False
     input_dim: Optional[int] = None
     output_dim: Optional[int] = None
     relaxed_attention_weight: float = 0.0

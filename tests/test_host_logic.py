@@ -510,6 +510,9 @@ def test_recipe_config_loader(tmp_path):
     assert cfg["lr_scheduler"]["model_size"] == 256 and isinstance(cfg["lr_scheduler"]["model_size"], int)  # interpolation keeps the type
     assert cfg["checkpoint"]["restore_file"] == "checkpoint_last.pt" and cfg["dataset"]["required_batch_size_multiple"] == 8  # defaults
     assert C.literal(cfg["optimizer"]["adam_betas"]) == (0.9, 0.98)
+    # YAML 1.1 reads `1e-08` / `1e-6` as strings; omegaconf (the reference's parser) and this loader read floats
+    assert cfg["optimizer"]["adam_eps"] == 1e-8 and cfg["lr_scheduler"]["final_lr"] == 1e-6
+    assert C.load_config(str(p), ["task.data=/d", "task.dict=x", "lr_scheduler.final_lr=2e-5"])["lr_scheduler"]["final_lr"] == 2e-5
     assert C.literal(cfg["model"]["encoder"]["conv_channels"]) == [64, 64, 128, 128]
     assert C.as_list(cfg["optimization"]["lr"]) == [2.5]
     assert [C.per_epoch(cfg["optimization"]["update_freq"], e) for e in (1, 2, 3, 9)] == [2, 1, 1, 1]
@@ -627,3 +630,55 @@ def test_trainer_checkpoint_round_trip(tmp_path):
     torch.save(bad, str(tmp_path / "bad.pt"))
     with pytest.raises(RuntimeError, match="does not match the model"):
         make(4).load_checkpoint(str(tmp_path / "bad.pt"))
+
+
+_REF_RECIPES = "/root/reference/examples/asr_librispeech/config"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF_RECIPES), reason="the reference's recipe YAMLs are only present in the build container")
+def test_every_asr_recipe_of_the_reference_builds(tmp_path):
+    """Each ASR recipe YAML of the reference, read as it is, yields task + model + criterion + optimizer + schedule through the
+    training entry point's builders (what `fairseq-hydra-train --config-name <recipe>` resolves through hydra)."""
+    import glob
+
+    from espresso_amd import speech_train as st
+    from espresso_amd.config import load_config
+    from espresso_amd.trainer import Trainer
+
+    (tmp_path / "dict.txt").write_text("".join(f"u{i} 1\n" for i in range(5000)))
+    want = {  # recipe -> (model, criterion, dictionary size incl. specials [+ <s> as blank], schedule)
+        "conformer_librispeech": ("speech_transformer_base", "label_smoothed_cross_entropy_v2", 5003, "TriStageLRSchedule"),
+        "conformer_transducer_librispeech": ("speech_transformer_transducer_base", "transducer_loss", 5004, "NoamSchedule"),
+        "lstm_librispeech": ("speech_lstm", "label_smoothed_cross_entropy_v2", 5003, "ReduceLROnPlateauLRScheduleV2"),
+        "lstm_librispeech_specaug": ("speech_lstm", "label_smoothed_cross_entropy_v2", 5003, "TriStageLRSchedule"),
+        "transformer_ctc_librispeech": ("speech_transformer_encoder_model", "ctc_loss", 5004, "NoamSchedule"),
+        "transformer_librispeech": ("speech_transformer_base", "label_smoothed_cross_entropy_v2", 5003, "TriStageLRSchedule"),
+        "transformer_librispeech_specaug": ("speech_transformer_base", "label_smoothed_cross_entropy_v2", 5003, "TriStageLRSchedule"),
+        "transformer_transducer_librispeech": ("speech_transformer_transducer_base", "transducer_loss", 5004, "PolynomialDecayV2LRSchedule"),
+    }
+    seen = set()
+    for y in sorted(glob.glob(os.path.join(_REF_RECIPES, "*.yaml"))):
+        name = os.path.basename(y)[:-5]
+        if name not in want:  # lstm_lm_librispeech: language-model training (task language_modeling_for_asr) is not on this path
+            continue
+        cfg = load_config(y, [f"task.data={tmp_path}", f"task.dict={tmp_path}/dict.txt", "bpe.sentencepiece_model=none"])
+        cfg["bpe"] = {}
+        task = st.build_task(cfg)
+        model, crit = st.build_model(cfg, task), st.build_criterion(cfg, task)
+        tr = Trainer.from_cfg(cfg, task, model, crit, torch.device("cpu"))
+        lrs = [tr.lr_scheduler.step_update(n) for n in (1, 1000, 100000)]
+        got = (cfg["model"]["_name"], cfg["criterion"]["_name"], len(task.target_dictionary), type(tr.lr_scheduler).__name__)
+        assert got == want[name], (name, got)
+        assert all(isinstance(v, float) and 0.0 < v < 1.0 for v in lrs), (name, lrs)
+        assert (task.blank_symbol == "<s>") == (got[1] in ("ctc_loss", "transducer_loss")), name
+        assert tr.clip_norm == float(cfg["optimization"]["clip_norm"]) and tr.optimizer.eps == 1e-8, name
+        seen.add(name)
+        del tr, model
+    assert seen == set(want)
+    # the headline recipe: 12 x 512 encoder; `model.encoder.layer_type=conformer` is the command-line override of run_torchaudio.sh
+    cfg = load_config(os.path.join(_REF_RECIPES, "transformer_ctc_librispeech.yaml"),
+                      [f"task.data={tmp_path}", f"task.dict={tmp_path}/dict.txt", "bpe.sentencepiece_model=none", "model.encoder.layer_type=conformer"])
+    cfg["bpe"] = {}
+    task = st.build_task(cfg)
+    n = sum(p.numel() for p in st.build_model(cfg, task).parameters())
+    assert 79e6 < n < 81e6, n
