@@ -40,6 +40,19 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
     sh = getattr(p, "_ea_bf16", None)
     if sh is not None:
         return sh
+    if not torch.is_grad_enabled():
+        # inference without the trainer's flat layout (decoders step thousands of times over frozen weights): one cast per
+        # parameter version instead of one per call
+        ver = (p._version, p.data_ptr())
+        hit = getattr(p, "_ea_bf16_infer", None)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        sh = K.cast_f32_to_bf16(p.detach().contiguous())
+        try:
+            p._ea_bf16_infer = (ver, sh)
+        except (AttributeError, RuntimeError):
+            pass
+        return sh
     return K.cast_f32_to_bf16(p.detach().contiguous())
 
 
@@ -774,7 +787,7 @@ class _ConformerLayerNative(torch.autograd.Function):
         scratch = _scratch_buffer(nb_scratch.value, x.device)
         _scratch_tag[str(x.device)] = None  # the forward overwrites what a backward pass left in the arena
         y = torch.empty_like(x)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = K._stream()
         _lib.check(lib.ea_conformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
                                               _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
                    "ea_conformer_layer_fwd")
@@ -798,7 +811,7 @@ class _ConformerLayerNative(torch.autograd.Function):
                sh.p_drop > 0, sh.p_act > 0, sh.p_attn > 0)
         sh.scratch_clean = int(_scratch_tag.get(str(x.device)) == tag)  # consecutive layers of one backward pass share the layout
         _scratch_tag[str(x.device)] = tag
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = K._stream()
         _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
                                                      _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
                    "ea_conformer_layer_bwd")
@@ -865,7 +878,7 @@ class _TransformerLayerNative(torch.autograd.Function):
         scratch = _scratch_buffer(nb_scratch.value, x.device)
         _scratch_tag[str(x.device)] = None
         y = torch.empty_like(x)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = K._stream()
         _lib.check(lib.ea_transformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
                                                 _ptr(pe16), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
                    "ea_transformer_layer_fwd")
@@ -889,7 +902,7 @@ class _TransformerLayerNative(torch.autograd.Function):
                sh.pos_mode, sh.p_drop > 0, sh.p_act > 0, sh.p_attn > 0)
         sh.scratch_clean = int(_scratch_tag.get(str(x.device)) == tag)
         _scratch_tag[str(x.device)] = tag
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = K._stream()
         _lib.check(_lib.lib().ea_transformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
                                                        _ptr(pe16), _ptr(dpe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(),
                                                        stream), "ea_transformer_layer_bwd")
@@ -1009,7 +1022,7 @@ class _DecoderLayerNative(torch.autograd.Function):
         scratch = _scratch_buffer(nb_scratch.value, x.device)
         _scratch_tag[str(x.device)] = None
         y = torch.empty_like(x)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = K._stream()
         _lib.check(lib.ea_decoder_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(enc), _ptr(y), _ptr(enc_len), _ptr(saved),
                                             saved.numel(), _ptr(scratch), scratch.numel(), stream), "ea_decoder_layer_fwd")
         ctx.save_for_backward(x, enc, saved, enc_len)
@@ -1026,7 +1039,7 @@ class _DecoderLayerNative(torch.autograd.Function):
         dy = dy.contiguous()
         dx, denc = torch.empty_like(x), torch.empty_like(enc)
         scratch = _scratch_buffer(ctx.nb_scratch, x.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = K._stream()
         _lib.check(_lib.lib().ea_decoder_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(enc), _ptr(dy), _ptr(dx),
                                                    _ptr(denc), _ptr(enc_len), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(),
                                                    stream), "ea_decoder_layer_bwd")

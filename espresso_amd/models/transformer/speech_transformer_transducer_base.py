@@ -36,6 +36,13 @@ class WeightNormLinearParams(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
 
     def effective_weight(self):
+        if not torch.is_grad_enabled():  # decoding: the normalised weight is a constant, keep it (and its bf16 cast) per version
+            ver = (self.weight_v._version, self.weight_g._version, self.weight_v.data_ptr())
+            hit = getattr(self, "_infer_weight", None)
+            if hit is None or hit[0] != ver:
+                hit = (ver, self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True)))
+                self._infer_weight = hit
+            return hit[1]
         return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
 
 
@@ -114,7 +121,8 @@ class SpeechTransformerTransducerModelBase(nn.Module):
                          self.laynorm_proj_decoder.bias)
         Z = K.joint_add_relu(E_rows.contiguous(), D.contiguous(), N, 1, 1)
         w, b = self.fc_out_params()
-        return F.linear(Z, w.detach(), b, out_f32=True)
+        # (without grad mode `w` is the cached constant itself: its bf16 cast is then cached on it too)
+        return F.linear(Z, w.detach() if w.requires_grad else w, b, out_f32=True)
 
     def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
         """-> (logits bf16 [B][T'][U+1][V], encoder_out_lengths [B])  (:221-243)"""

@@ -287,20 +287,45 @@ class TransducerBeamSearchDecoder:
         most `prefix_alpha` tokens shorter) is added (logaddexp) to the longer one after extending it token by token."""
         n = hyps.size()
         lens = hyps.lens
-        merge = torch.zeros(n, n, dtype=torch.bool)
+        lens_l, seqs_l = lens.tolist(), hyps.seqs.tolist()  # host bookkeeping on plain lists
+        merge = [[False] * n for _ in range(n)]
+        any_merge = False
         for j in range(n - 1):
             for i in range(j + 1, n):
-                li = int(lens[i])
-                merge[i, j] = bool(lens[i] < lens[j]) and bool((hyps.seqs[i, :li] == hyps.seqs[j, :li]).all())
-        if self.prefix_alpha is not None:
-            merge &= (lens.unsqueeze(1) + self.prefix_alpha >= lens.unsqueeze(0))
-        if not bool(merge.any()):
+                li = lens_l[i]
+                ok = li < lens_l[j] and seqs_l[i][:li] == seqs_l[j][:li]
+                if ok and self.prefix_alpha is not None:
+                    ok = li + self.prefix_alpha >= lens_l[j]
+                merge[i][j] = ok
+                any_merge |= ok
+        if not any_merge:
+            return hyps
+        if self.lm_model is None:
+            # every (predictor output, next token) pair the merges need, through the joint in ONE call; only the m requested
+            # log-probabilities come back to the host (the reference evaluates the joint once per extension step, :487-505)
+            ri, ci, toks, spans = [], [], [], []
+            for j in range(n - 1):
+                for i in range(j + 1, n):
+                    if not merge[i][j]:
+                        continue
+                    li, lj = lens_l[i], lens_l[j]
+                    a = len(toks)
+                    ri.append(i), ci.append(li - 1), toks.append(seqs_l[j][li])
+                    for k in range(li, lj - 1):
+                        ri.append(j), ci.append(k), toks.append(seqs_l[j][k + 1])
+                    spans.append((i, j, a, len(toks)))
+            vals = self._token_lprobs(E_t, hyps.dec[ri, ci], toks)
+            for i, j, a, b in spans:
+                score = float(hyps.scores[i]) + vals[a]
+                for k in range(a + 1, b):
+                    score += vals[k]
+                hyps.scores[j] = torch.logaddexp(hyps.scores[j], torch.tensor(float(score)))
             return hyps
         for j in range(n - 1):
             for i in range(j + 1, n):
-                if not bool(merge[i, j]):
+                if not merge[i][j]:
                     continue
-                li, lj = int(lens[i]), int(lens[j])
+                li, lj = lens_l[i], lens_l[j]
                 # first extension uses hypothesis i's newest predictor output, the following ones hypothesis j's own history
                 lp, lm_lp = self._row_lprobs(E_t, hyps.dec[i, li - 1], None if hyps.lm_dec is None else hyps.lm_dec[i, li - 1])
                 tok = int(hyps.seqs[j, li])
@@ -322,6 +347,16 @@ class TransducerBeamSearchDecoder:
                 if self.lm_model is not None:
                     hyps.lm_scores[j] = torch.logaddexp(hyps.lm_scores[j], torch.tensor(float(lm_score)))
         return hyps
+
+    def _token_lprobs(self, E_t, dec_rows, toks):
+        """RAW acoustic log-probability of token toks[r] given predictor output dec_rows[r], r = 0..m-1 -> host f32 [m]."""
+        V, m = self.vocab_size, dec_rows.shape[0]
+        logits = self.model.joint_step(E_t.unsqueeze(0).expand(m, -1).contiguous(), dec_rows.contiguous())[:, :V]
+        if self.temperature != 1.0:
+            logits = logits / self.temperature
+        lp = K.log_softmax(logits, m, V, logits.stride(0))
+        idx = torch.tensor(toks, dtype=torch.long).to(lp.device)
+        return lp.gather(1, idx.unsqueeze(1)).squeeze(1).cpu()
 
     def _row_lprobs(self, E_t, dec_row, lm_row):
         """RAW acoustic log-probs of one hypothesis position (the prefix search applies the LM terms itself, :487-505)."""

@@ -1,0 +1,57 @@
+"""cProfile of the transducer beam search on one short synthetic utterance (host-side hot spots of the search loop)."""
+import cProfile, io, os, pstats, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    dev = torch.device("cuda:0")
+    import espresso_amd  # noqa: F401
+    from espresso_amd.data import synthetic
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+    from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerTransducerConfig
+    from espresso_amd.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
+    from espresso_amd.tools.transducer_beam_search_decoder import TransducerBeamSearchDecoder
+
+    V = 5004
+    torch.manual_seed(1)
+    d = AsrDictionary.from_symbols([f"u{i}" for i in range(V - 5)], enable_bos=True)
+    task = SpeechRecognitionEspressoTask.setup_task(SpeechRecognitionEspressoConfig(criterion_name="transducer_loss", seed=1), tgt_dict=d)
+    cfg = SpeechTransformerTransducerConfig()
+    e, dc = cfg.encoder, cfg.decoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, 4, 8
+    e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "conformer"
+    dc.embed_dim, dc.hidden_size, dc.layers = 512, 512, 2
+    cfg.joint_dim = 512
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    model = SpeechTransformerTransducerModelBase.build_model(cfg, task).to(dev).eval()
+    blank = d.index(task.blank_symbol)
+    with torch.no_grad():
+        model.fc_out.bias[blank] += float(os.environ.get("BLANK_BIAS", "6.0"))
+    n_samples = np.array([int(16000 * 4.0)])
+    s = synthetic.make_sample(np.array([0]), n_samples, V, d.pad(), dev, seed=3)
+    task.build_frontend(dev)
+    dec = TransducerBeamSearchDecoder([model], d, beam_size=5, max_num_expansions_per_step=2, bos=d.eos(), blank=blank)
+    sp = task.prepare_sample(s, train=False)
+    dec.generate([model], sp)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    out = dec.generate([model], sp)
+    torch.cuda.synchronize()
+    pr.disable()
+    buf = io.StringIO()
+    st = pstats.Stats(pr, stream=buf).sort_stats("cumulative")
+    st.print_stats(45)
+    print(buf.getvalue())
+    buf = io.StringIO()
+    pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(25)
+    print(buf.getvalue())
+    print("tokens", len(out[0][0]["tokens"]))
+
+
+if __name__ == "__main__":
+    main()
