@@ -50,16 +50,20 @@ def main():
     blank = d.index(task.blank_symbol)
     common = dict(max_num_expansions_per_step=2, bos=d.eos(), blank=blank)
     rate = None
+
+    def n_emitted(hyps):  # the greedy decoder returns its (frame, expansion) grid with blanks in it
+        return sum(int((h[0]["tokens"] != blank).sum()) for h in hyps)
+
     if args.emit_rate > 0:  # bisection on the blank bias with the (fast, batched) greedy decoder on the warm-up batch
         g = TransducerGreedyDecoder([model], d, **common)
         s0 = task.prepare_sample(samples[0], train=False)
         lo, hi = 0.0, 40.0
-        base = float(model.fc_out.bias[blank])
+        base = float(model.fc_out.bias[blank].detach())
         for _ in range(9):
             mid = 0.5 * (lo + hi)
             with torch.no_grad():
                 model.fc_out.bias[blank] = base + mid
-            rate = sum(len(h[0]["tokens"]) for h in g.generate([model], s0)) / samples[0]["audio_seconds"]
+            rate = n_emitted(g.generate([model], s0)) / samples[0]["audio_seconds"]
             lo, hi = (mid, hi) if rate > args.emit_rate else (lo, mid)
     decoders = [("greedy", TransducerGreedyDecoder([model], d, **common), samples),
                 ("beam", TransducerBeamSearchDecoder([model], d, beam_size=args.beam, **common), None)]
@@ -80,7 +84,7 @@ def main():
         t0 = time.perf_counter()
         ntok = 0
         for s in use[1:]:
-            ntok += sum(len(h[0]["tokens"]) for h in run(s))
+            ntok += n_emitted(run(s))
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         audio = sum(s["audio_seconds"] for s in use[1:])
