@@ -18,10 +18,61 @@ import torch.nn.functional as TF
 from .. import kernels as K
 
 
+class _Pool:
+    """Append-only device store of predictor (or LM) output rows of ONE utterance's search: hypotheses refer to rows by slot
+    number, so selecting / merging / padding hypotheses moves small host index tensors instead of re-copying `[n][L][H]`
+    histories on the device at every expansion (the reference's `index_select_` / `pad` / `cat` on the full tensors)."""
+
+    def __init__(self, width, device, cap=2048):
+        self.buf = torch.zeros(cap, width, dtype=torch.bfloat16, device=device)
+        self.n, self.device = 0, device
+
+    def put(self, rows):
+        m = rows.shape[0]
+        if self.n + m > self.buf.shape[0]:
+            grown = torch.zeros(max(2 * self.buf.shape[0], self.n + m), self.buf.shape[1], dtype=self.buf.dtype, device=self.device)
+            grown[: self.n] = self.buf[: self.n]
+            self.buf = grown
+        self.buf[self.n:self.n + m] = rows
+        self.n += m
+        return self.n - m
+
+    def get(self, slots):
+        idx = slots if torch.is_tensor(slots) else torch.tensor(slots, dtype=torch.long)
+        return self.buf.index_select(0, idx.reshape(-1).to(self.device))
+
+
+class _Hist:
+    """Per-hypothesis output history: slots [n][L] (host i64) into a shared _Pool; position lens-1 is the newest."""
+
+    def __init__(self, pool, slots):
+        self.pool, self.slots, self.device = pool, slots, pool.device
+
+    def select(self, index):
+        return _Hist(self.pool, self.slots[index])
+
+    def padded(self, L):
+        return self if L == self.slots.shape[1] else _Hist(self.pool, TF.pad(self.slots, (0, L - self.slots.shape[1])))
+
+    def last(self, lens):
+        return self.pool.get(self.slots[torch.arange(self.slots.shape[0]), lens - 1])
+
+    def put(self, lens, rows):
+        n = self.slots.shape[0]
+        base = self.pool.put(rows)
+        self.slots[torch.arange(n), lens - 1] = base + torch.arange(n)
+
+    def rows(self, ri, ci):
+        return self.pool.get(self.slots[ri, ci])
+
+    def at(self, i, k):
+        return self.pool.buf[int(self.slots[i, k])]
+
+
 class _Hyps:
     """Batch of hypotheses of ONE utterance.  Host: scores [n] f32, seqs [n][L] i64 (pad-filled), lens [n], nemit [n], prev [n],
-    lm_scores [n] or None.  Device: state (predictor (h16, h32, c) lists with n rows), dec [n][L][H] bf16 predictor outputs by
-    sequence position (position lens-1 is the newest); lm_state / lm_dec likewise."""
+    lm_scores [n] or None, dec = _Hist of predictor outputs by sequence position.  Device: state (predictor (h16, h32, c) lists
+    with n rows) and the pool behind `dec`; lm_state / lm_dec likewise."""
 
     def __init__(self, scores, seqs, lens, nemit, prev, state, dec, lm_scores=None, lm_state=None, lm_dec=None):
         self.scores, self.seqs, self.lens, self.nemit, self.prev = scores, seqs, lens, nemit, prev
@@ -36,9 +87,9 @@ class _Hyps:
         di = index.to(self.dec.device)
         sel_state = lambda st: None if st is None else {k: [t.index_select(0, di) for t in v] for k, v in st.items()}
         return _Hyps(self.scores[index], self.seqs[index], self.lens[index], self.nemit[index], self.prev[index],
-                     sel_state(self.state), self.dec.index_select(0, di),
+                     sel_state(self.state), self.dec.select(index),
                      None if self.lm_scores is None else self.lm_scores[index], sel_state(self.lm_state),
-                     None if self.lm_dec is None else self.lm_dec.index_select(0, di))
+                     None if self.lm_dec is None else self.lm_dec.select(index))
 
     def sort_by_length(self, descending=True):
         return self if self.size() == 0 else self.select(self.lens.argsort(descending=descending))
@@ -62,9 +113,7 @@ class _Hyps:
 
     def last_dec(self):
         """Predictor (and LM) output at the last non-blank position of every hypothesis (transducer_utils.py:386-417)."""
-        pos = (self.lens - 1).to(self.dec.device)
-        rows = torch.arange(self.size(), device=self.dec.device)
-        return self.dec[rows, pos], (None if self.lm_dec is None else self.lm_dec[rows, pos])
+        return self.dec.last(self.lens), (None if self.lm_dec is None else self.lm_dec.last(self.lens))
 
     @staticmethod
     def combine(a, b, pad):
@@ -75,13 +124,13 @@ class _Hyps:
             return b
         L = max(a.seqs.shape[1], b.seqs.shape[1])
         pseq = lambda s: TF.pad(s, (0, L - s.shape[1]), value=pad)
-        pdec = lambda d: None if d is None else TF.pad(d, (0, 0, 0, L - d.shape[1]))
+        cat_hist = lambda x, y: None if x is None else _Hist(x.pool, torch.cat((x.padded(L).slots, y.padded(L).slots)))
         cat_state = lambda x, y: None if x is None else {k: [torch.cat((u, v), 0) for u, v in zip(x[k], y[k])] for k in x}
         return _Hyps(torch.cat((a.scores, b.scores)), torch.cat((pseq(a.seqs), pseq(b.seqs))), torch.cat((a.lens, b.lens)),
                      torch.cat((a.nemit, b.nemit)), torch.cat((a.prev, b.prev)), cat_state(a.state, b.state),
-                     torch.cat((pdec(a.dec), pdec(b.dec))),
+                     cat_hist(a.dec, b.dec),
                      None if a.lm_scores is None else torch.cat((a.lm_scores, b.lm_scores)), cat_state(a.lm_state, b.lm_state),
-                     None if a.lm_dec is None else torch.cat((pdec(a.lm_dec), pdec(b.lm_dec))))
+                     cat_hist(a.lm_dec, b.lm_dec))
 
 
 class TransducerBeamSearchDecoder:
@@ -187,12 +236,10 @@ class TransducerBeamSearchDecoder:
         dev = hyps.dec.device
         tok = hyps.prev.to(dev)
         dec_out, hyps.state = self.model.decoder.advance(tok, hyps.state)
-        rows = torch.arange(hyps.size(), device=dev)
-        pos = (hyps.lens - 1).to(dev)
-        hyps.dec[rows, pos] = dec_out
+        hyps.dec.put(hyps.lens, dec_out)
         if self.lm_model is not None:
             lm_out, hyps.lm_state = self.lm_model.decoder.advance(self._lm_tokens(tok), hyps.lm_state)
-            hyps.lm_dec[rows, pos] = lm_out
+            hyps.lm_dec.put(hyps.lens, lm_out)
 
     # ------------------------------------------------------------------ the search (one utterance)
     def _one(self, E, enc_len, bos_token):
@@ -203,12 +250,12 @@ class TransducerBeamSearchDecoder:
         Hd = dec.hidden_size if not hasattr(dec, "additional_fc") else dec.additional_fc.weight.shape[0]
         hyps = _Hyps(torch.zeros(1), torch.full((1, 1), bos, dtype=torch.long), torch.ones(1, dtype=torch.long),
                      torch.zeros(1, dtype=torch.long), torch.full((1,), bos, dtype=torch.long), dec.init_state(1, dev),
-                     torch.zeros(1, 1, Hd, dtype=torch.bfloat16, device=dev))
+                     _Hist(_Pool(Hd, dev), torch.zeros(1, 1, dtype=torch.long)))
         if self.lm_model is not None:
             lmd = self.lm_model.decoder
             Hl = lmd.hidden_size if not hasattr(lmd, "additional_fc") else lmd.additional_fc.weight.shape[0]
             hyps.lm_scores, hyps.lm_state = torch.zeros(1), lmd.init_state(1, dev)
-            hyps.lm_dec = torch.zeros(1, 1, Hl, dtype=torch.bfloat16, device=dev)
+            hyps.lm_dec = _Hist(_Pool(Hl, dev), torch.zeros(1, 1, dtype=torch.long))
         self._advance(hyps)
         nxt = hyps
         for step in range(max_len):
@@ -275,9 +322,9 @@ class TransducerBeamSearchDecoder:
         max_length = int(h.lens.max())
         if bool((tokens[h.lens == max_length] != self.blank).any()):
             h.seqs = TF.pad(h.seqs, (0, 1), value=self.pad)
-            h.dec = TF.pad(h.dec, (0, 0, 0, 1))
+            h.dec = h.dec.padded(h.dec.slots.shape[1] + 1)
             if h.lm_dec is not None:
-                h.lm_dec = TF.pad(h.lm_dec, (0, 0, 0, 1))
+                h.lm_dec = h.lm_dec.padded(h.lm_dec.slots.shape[1] + 1)
         h.seqs.scatter_(1, h.lens.unsqueeze(1), tokens.masked_fill(bmask, self.pad).unsqueeze(1))
         h.lens = h.lens + (~bmask).long()
         h.nemit = h.nemit + 1
@@ -314,7 +361,7 @@ class TransducerBeamSearchDecoder:
                     for k in range(li, lj - 1):
                         ri.append(j), ci.append(k), toks.append(seqs_l[j][k + 1])
                     spans.append((i, j, a, len(toks)))
-            vals = self._token_lprobs(E_t, hyps.dec[ri, ci], toks)
+            vals = self._token_lprobs(E_t, hyps.dec.rows(ri, ci), toks)
             for i, j, a, b in spans:
                 score = float(hyps.scores[i]) + vals[a]
                 for k in range(a + 1, b):
@@ -327,7 +374,7 @@ class TransducerBeamSearchDecoder:
                     continue
                 li, lj = lens_l[i], lens_l[j]
                 # first extension uses hypothesis i's newest predictor output, the following ones hypothesis j's own history
-                lp, lm_lp = self._row_lprobs(E_t, hyps.dec[i, li - 1], None if hyps.lm_dec is None else hyps.lm_dec[i, li - 1])
+                lp, lm_lp = self._row_lprobs(E_t, hyps.dec.at(i, li - 1), None if hyps.lm_dec is None else hyps.lm_dec.at(i, li - 1))
                 tok = int(hyps.seqs[j, li])
                 score = float(hyps.scores[i]) + lp[tok]
                 lm_score = None
@@ -336,7 +383,7 @@ class TransducerBeamSearchDecoder:
                     lm_score = float(hyps.lm_scores[i]) + loc
                     score += self.lm_weight * loc + scale
                 for k in range(li, lj - 1):
-                    lp, lm_lp = self._row_lprobs(E_t, hyps.dec[j, k], None if hyps.lm_dec is None else hyps.lm_dec[j, k])
+                    lp, lm_lp = self._row_lprobs(E_t, hyps.dec.at(j, k), None if hyps.lm_dec is None else hyps.lm_dec.at(j, k))
                     tok = int(hyps.seqs[j, k + 1])
                     score += lp[tok]
                     if self.lm_model is not None:

@@ -682,3 +682,70 @@ def test_every_asr_recipe_of_the_reference_builds(tmp_path):
     task = st.build_task(cfg)
     n = sum(p.numel() for p in st.build_model(cfg, task).parameters())
     assert 79e6 < n < 81e6, n
+
+
+def test_transducer_beam_history_pool_matches_dense_histories():
+    """The slot-pool history of the transducer beam search (`_Pool` / `_Hist`) against the dense `[n][L][H]` tensor semantics it
+    replaces (index_select / pad / cat / write-at-lens-1 / read-at-lens-1 of espresso/tools/transducer_utils.py:62-102, 386-417,
+    492-637), over a random sequence of those operations."""
+    import torch.nn.functional as TF
+
+    from espresso_amd.tools.transducer_beam_search_decoder import _Hist, _Pool
+
+    g = torch.Generator().manual_seed(0)
+    H = 8
+    pool = _Pool(H, torch.device("cpu"), cap=4)  # tiny capacity: growth is exercised
+    hist = _Hist(pool, torch.zeros(1, 1, dtype=torch.long))
+    dense = torch.zeros(1, 1, H, dtype=torch.bfloat16)
+    lens = torch.ones(1, dtype=torch.long)
+
+    def mat(h, lens):  # dense view of the positions that have been written (0 .. lens-1)
+        out = torch.zeros(h.slots.shape[0], h.slots.shape[1], H, dtype=torch.bfloat16)
+        for i in range(h.slots.shape[0]):
+            for k in range(int(lens[i])):
+                out[i, k] = h.at(i, k)
+        return out
+
+    def mask(d, lens):
+        d = d.clone()
+        for i in range(d.shape[0]):
+            d[i, int(lens[i]):] = 0
+        return d
+
+    rows = torch.randn(1, H, generator=g).to(torch.bfloat16)
+    hist.put(lens, rows)
+    dense[torch.arange(1), lens - 1] = rows
+    saved = []
+    for step in range(60):
+        op = int(torch.randint(0, 4, (1,), generator=g))
+        n = hist.slots.shape[0]
+        if op == 0:  # select (with repetition, like the k-expansion)
+            idx = torch.randint(0, n, (int(torch.randint(1, 7, (1,), generator=g)),), generator=g)
+            hist, dense, lens = hist.select(idx), dense.index_select(0, idx), lens[idx]
+        elif op == 1:  # some hypotheses grow by one token, then the predictor output is written at the new last position
+            grow = torch.rand(n, generator=g) < 0.6
+            if bool((lens[grow] == hist.slots.shape[1]).any()):
+                hist = hist.padded(hist.slots.shape[1] + 1)
+                dense = TF.pad(dense, (0, 0, 0, 1))
+            lens = lens + grow.long()
+            keep = grow.nonzero().view(-1)
+            if keep.numel():
+                sub_h, sub_d, sub_l = hist.select(keep), dense.index_select(0, keep), lens[keep]
+                rows = torch.randn(keep.numel(), H, generator=g).to(torch.bfloat16)
+                sub_h.put(sub_l, rows)
+                sub_d[torch.arange(keep.numel()), sub_l - 1] = rows
+                saved.append((sub_h, sub_d, sub_l))
+                hist, dense, lens = sub_h, sub_d, sub_l
+        elif op == 2 and saved:  # combine with an earlier batch (pad the position axis, concatenate)
+            oh, od, ol = saved[int(torch.randint(0, len(saved), (1,), generator=g))]
+            L = max(hist.slots.shape[1], oh.slots.shape[1])
+            hist = _Hist(pool, torch.cat((hist.padded(L).slots, oh.padded(L).slots)))
+            dense = torch.cat((TF.pad(dense, (0, 0, 0, L - dense.shape[1])), TF.pad(od, (0, 0, 0, L - od.shape[1]))))
+            lens = torch.cat((lens, ol))
+        else:  # read the newest outputs
+            assert torch.equal(hist.last(lens), dense[torch.arange(dense.shape[0]), lens - 1])
+        assert hist.slots.shape[:2] == dense.shape[:2]
+        assert torch.equal(mat(hist, lens), mask(dense, lens)), step
+    ri, ci = [0, hist.slots.shape[0] - 1], [0, int(lens[-1]) - 1]
+    assert torch.equal(hist.rows(ri, ci), dense[ri, ci])
+    assert pool.buf.shape[0] > 4 and pool.n <= pool.buf.shape[0]
