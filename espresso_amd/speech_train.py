@@ -215,8 +215,13 @@ def main(argv=None):
         nonlocal valid_losses
         n = trainer.num_updates
         stop = n >= max_update
-        if opt["stop_time_hours"] > 0 and (time.time() - t_start) / 3600.0 > opt["stop_time_hours"]:
-            stop = True
+        if opt["stop_time_hours"] > 0:
+            over = (time.time() - t_start) / 3600.0 > opt["stop_time_hours"]
+            if world > 1:  # clocks differ by rank; every rank must take the same branch (collectives follow)
+                flag = torch.tensor([float(over)], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                over = bool(flag.item() > 0)
+            stop = stop or over
         ck, d = cfg["checkpoint"], cfg["dataset"]
         do_save = ((end_of_epoch and epoch % ck["save_interval"] == 0) or stop
                    or (ck["save_interval_updates"] > 0 and n > 0 and n % ck["save_interval_updates"] == 0 and n >= d["validate_after_updates"]))
