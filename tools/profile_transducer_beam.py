@@ -31,7 +31,7 @@ def main():
     blank = d.index(task.blank_symbol)
     with torch.no_grad():
         model.fc_out.bias[blank] += float(os.environ.get("BLANK_BIAS", "6.0"))
-    n_samples = np.array([int(16000 * 4.0)])
+    n_samples = np.array([int(16000 * float(os.environ.get("SECONDS_AUDIO", "4.0")))])
     s = synthetic.make_sample(np.array([0]), n_samples, V, d.pad(), dev, seed=3)
     task.build_frontend(dev)
     dec = TransducerBeamSearchDecoder([model], d, beam_size=5, max_num_expansions_per_step=2, bos=d.eos(), blank=blank)
