@@ -120,8 +120,10 @@ def build_generator(args, model, dictionary, lm=None):
 def get_parser():
     p = argparse.ArgumentParser("espresso_amd.speech_recognize", description=__doc__.split("\n")[0])
     p.add_argument("--path", required=True, help="state_dict (or fairseq checkpoint dict with a 'model' entry)")
-    p.add_argument("--model", default="speech_transformer_base", help="registered model name")
-    p.add_argument("--model-config", required=True, help="JSON/YAML file with the recipe's `model:` block")
+    p.add_argument("--model", default=None, help="registered model name (default: the checkpoint's cfg.model._name, else speech_transformer_base)")
+    p.add_argument("--model-config", default=None,
+                   help="JSON/YAML file with the recipe's `model:` block (default: the `cfg.model` stored in the checkpoint, as the "
+                        "reference rebuilds the model in checkpoint_utils.load_model_ensemble)")
     p.add_argument("--dict", required=True)
     p.add_argument("--wav-scp", required=True)
     p.add_argument("--text", default=None, help="reference transcripts (utt_id tokens...)")
@@ -152,9 +154,43 @@ def get_parser():
     return p
 
 
+def _load_file(path):
+    try:
+        return torch.load(path, map_location="cpu")
+    except Exception:  # checkpoints written by the reference carry Namespace / omegaconf objects next to the tensors
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def _load_state(path):
-    sd = torch.load(path, map_location="cpu")
+    sd = _load_file(path)
     return sd["model"] if isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict) else sd
+
+
+def resolve_model_config(model_name, model_config_path, checkpoint):
+    """(registered model name, `model:` block as a dict): explicit arguments win; otherwise what the checkpoint's `cfg` holds
+    (fairseq/checkpoint_utils.py:422-470 rebuilds the model from `state["cfg"].model` the same way)."""
+    import yaml
+
+    stored = None
+    cfg = checkpoint.get("cfg") if isinstance(checkpoint, dict) else None
+    if cfg is not None:
+        stored = cfg["model"] if isinstance(cfg, dict) else getattr(cfg, "model", None)
+        if stored is not None and not isinstance(stored, dict):
+            try:
+                from omegaconf import OmegaConf  # a reference checkpoint opened where omegaconf exists
+
+                stored = OmegaConf.to_container(stored, resolve=True)
+            except ImportError:
+                stored = dict(vars(stored)) if hasattr(stored, "__dict__") else dict(stored)
+    if model_config_path:
+        block = json.load(open(model_config_path)) if model_config_path.endswith(".json") else yaml.safe_load(open(model_config_path))
+        block = block.get("model", block) if isinstance(block.get("model"), dict) else block  # a whole recipe file is fine too
+    elif stored is not None:
+        block = dict(stored)
+    else:
+        raise ValueError("--model-config is required: the checkpoint holds no cfg.model block")
+    name = model_name or block.get("_name") or (stored or {}).get("_name") or "speech_transformer_base"
+    return name, block
 
 
 def main(argv=None):
@@ -168,15 +204,16 @@ def main(argv=None):
     from .tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
 
     dev = torch.device("cuda:0")
-    model_cfg = yaml.safe_load(open(args.model_config)) if not args.model_config.endswith(".json") else json.load(open(args.model_config))
+    state = _load_file(args.path)
+    model_name, model_cfg = resolve_model_config(args.model, args.model_config, state)
     autoregressive = args.search == "beam"
     task = SpeechRecognitionEspressoTask.setup_task(SpeechRecognitionEspressoConfig(
         dict=args.dict, autoregressive=autoregressive, global_cmvn_stats_path=args.global_cmvn_stats_path))
-    cls = registry.MODEL_REGISTRY[args.model]
+    cls = registry.MODEL_REGISTRY[model_name]
     cfg_cls = getattr(cls, "config_class", None)
     cfg = cfg_cls.from_dict(model_cfg) if cfg_cls is not None else model_cfg
     model = cls.build_model(cfg, task)
-    sd = _load_state(args.path)
+    sd = state["model"] if isinstance(state, dict) and isinstance(state.get("model"), dict) else state
     if hasattr(model, "upgrade_state_dict_named"):
         sd = model.upgrade_state_dict_named(dict(sd), "")
     model.load_state_dict(sd, strict=True)
@@ -199,8 +236,8 @@ def main(argv=None):
     refs = read_scp(args.text) if args.text else None
     task.build_frontend(dev)
     batches = make_batches(utt_ids, [len(w) for w in waves], args.max_tokens, args.batch_size)
-    recognize(task, model, gen, (collate(b, utt_ids, waves, dev) for b in batches), task.target_dictionary, refs, nbest=args.nbest,
-              quiet=args.quiet)
+    recognize(task, model, gen, (collate(b, utt_ids, waves, dev) for b in batches), task.target_dictionary, refs, out=sys.stdout,
+              nbest=args.nbest, quiet=args.quiet)
 
 
 if __name__ == "__main__":

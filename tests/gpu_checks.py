@@ -1668,6 +1668,19 @@ model:
     sb = torch.load(os.path.join(b_dir, "checkpoint_last.pt"), map_location="cpu", weights_only=False)
     diff = max(float((sa["model"][k].double() - sb["model"][k].double()).abs().max()) for k in sa["model"])
     moved = max(float((sa["model"][k].double() - ck_mid["model"][k].double()).abs().max()) for k in sa["model"])
+    # train -> recognise round trip: the recognition CLI rebuilds the model from the checkpoint's own cfg (no --model-config)
+    from espresso_amd import speech_recognize
+
+    with open(os.path.join(tmp_dir, "wav.scp"), "w") as f:
+        f.write("".join(f"{u} {v['wave']}\n" for u, v in utts.items()))
+    with open(os.path.join(tmp_dir, "text"), "w") as f:
+        f.write("".join(f"{u} {v['text']}\n" for u, v in utts.items()))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        speech_recognize.main(["--path", os.path.join(a_dir, "checkpoint_best.pt"), "--dict", os.path.join(tmp_dir, "dict.txt"),
+                               "--wav-scp", os.path.join(tmp_dir, "wav.scp"), "--text", os.path.join(tmp_dir, "text"),
+                               "--search", "ctc", "--max-tokens", "400", "--batch-size", "4"])
+    rec = buf.getvalue().splitlines()
     la = {l["num_updates"]: l["loss"] for l in log_a if l["kind"] == "train_inner"}
     lb = {l["num_updates"]: l["loss"] for l in log_b1 + log_b2 if l["kind"] == "train_inner"}
     valid = [l for l in log_a if l["kind"] == "valid"]
@@ -1675,6 +1688,7 @@ model:
             "param_change_since_resume_point": moved, "loss_a": la, "loss_b": lb,
             "resume": [l for l in log_b2 if l["kind"] == "resume"], "mid_iterator": ck_mid["extra_state"]["train_iterator"],
             "num_updates": (tr_a.num_updates, tr_b.num_updates), "valid": valid,
+            "recognize_H_lines": sum(1 for l in rec if l.startswith("H-")), "recognize_summary": [l for l in rec if "WER" in l][:2],
             "hist": sb["optimizer_history"][-1]["num_updates"], "opt_step": sb["last_optimizer_state"]["state"][0]["step"]}
 
 

@@ -332,6 +332,7 @@ def test_speech_train_cli_checkpoints_and_resume(tmp_path):
     # that distance is small against what updates 3..6 changed
     assert r["param_diff_resumed_vs_straight"] < 0.05 * r["param_change_since_resume_point"], r
     assert r["valid"] and all(v["wer"] >= 0.0 and math.isfinite(v["loss"]) for v in r["valid"]), r
+    assert r["recognize_H_lines"] == 12 and r["recognize_summary"], r   # checkpoint_best.pt -> speech_recognize, model rebuilt from its cfg
 
 
 def test_ddp_every_parameter_reports_once_per_update(tmp_path):

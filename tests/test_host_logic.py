@@ -749,3 +749,27 @@ def test_transducer_beam_history_pool_matches_dense_histories():
     ri, ci = [0, hist.slots.shape[0] - 1], [0, int(lens[-1]) - 1]
     assert torch.equal(hist.rows(ri, ci), dense[ri, ci])
     assert pool.buf.shape[0] > 4 and pool.n <= pool.buf.shape[0]
+
+
+def test_recognize_cli_rebuilds_model_from_checkpoint_cfg(tmp_path):
+    """`speech_recognize --path checkpoint_best.pt` needs no --model-config: name and `model:` block come from the checkpoint's
+    cfg (what speech_train / the reference's trainer store); explicit arguments win; a bare state_dict still needs the file."""
+    import json
+
+    from espresso_amd.speech_recognize import resolve_model_config
+
+    block = {"_name": "speech_transformer_encoder_model", "encoder": {"embed_dim": 128, "layers": 2}, "dropout": 0.1}
+    ck = {"cfg": {"model": dict(block), "task": {"_name": "speech_recognition_espresso"}}, "model": {}}
+    name, got = resolve_model_config(None, None, ck)
+    assert name == "speech_transformer_encoder_model" and got == block and got is not ck["cfg"]["model"]
+    assert resolve_model_config("speech_transformer_base", None, ck)[0] == "speech_transformer_base"
+    y = tmp_path / "m.yaml"
+    y.write_text("encoder:\n  embed_dim: 256\nlayernorm_embedding: true\n")
+    name, got = resolve_model_config(None, str(y), ck)
+    assert name == "speech_transformer_encoder_model" and got == {"encoder": {"embed_dim": 256}, "layernorm_embedding": True}
+    j = tmp_path / "recipe.json"
+    j.write_text(json.dumps({"model": {"_name": "speech_transformer_transducer_base", "joint_dim": 64}, "task": {}}))
+    assert resolve_model_config(None, str(j), {})[0] == "speech_transformer_transducer_base"
+    assert resolve_model_config(None, str(y), {"w": torch.zeros(1)})[0] == "speech_transformer_base"
+    with pytest.raises(ValueError, match="model-config"):
+        resolve_model_config(None, None, {"w": torch.zeros(1)})
