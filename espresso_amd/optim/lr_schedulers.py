@@ -133,3 +133,15 @@ class ReduceLROnPlateauLRScheduleV2:
     def load_state_dict(self, sd):
         self.best = sd["best"]
         self.last_epoch = sd.get("last_epoch", self.last_epoch)
+
+
+@register_lr_scheduler("reduce_lr_on_plateau")
+class ReduceLROnPlateauLRSchedule(ReduceLROnPlateauLRScheduleV2):
+    """fairseq/optim/lr_scheduler/reduce_lr_on_plateau.py:60-143 (the language-model recipe): the v2 schedule without a start
+    epoch or a learning-rate floor."""
+
+    def __init__(self, optimizer, lr=1e-3, lr_shrink=0.1, lr_threshold=1e-4, lr_patience=0, warmup_updates=0, warmup_init_lr=-1,
+                 maximize_best_checkpoint_metric=False):
+        super().__init__(optimizer, lr=lr, lr_shrink=lr_shrink, lr_threshold=lr_threshold, lr_patience=lr_patience,
+                         warmup_updates=warmup_updates, warmup_init_lr=warmup_init_lr, start_reduce_lr_epoch=0, final_lr_scale=0.0,
+                         maximize_best_checkpoint_metric=maximize_best_checkpoint_metric)

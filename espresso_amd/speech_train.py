@@ -65,17 +65,16 @@ class Prefetcher:
 
 
 def build_task(cfg):
-    from .tasks.speech_recognition import SpeechRecognitionEspressoConfig
-
     name = cfg["task"].get("_name", "speech_recognition_espresso")
-    cls = registry.TASK_REGISTRY[name]
-    known = SpeechRecognitionEspressoConfig.__dataclass_fields__
+    cls, dc = registry.TASK_REGISTRY[name], registry.TASK_DATACLASS_REGISTRY[name]
+    known = dc.__dataclass_fields__
     kw = {k: v for k, v in cfg["task"].items() if k in known}
-    kw.update(train_subset=cfg["dataset"]["train_subset"], valid_subset=cfg["dataset"]["valid_subset"],
-              criterion_name=cfg["criterion"]["_name"], seed=cfg["common"]["seed"])
+    extra = dict(train_subset=cfg["dataset"]["train_subset"], valid_subset=cfg["dataset"]["valid_subset"],
+                 criterion_name=cfg["criterion"]["_name"], seed=cfg["common"]["seed"])
     if cfg.get("bpe"):
-        kw.update(bpe=cfg["bpe"].get("_name"), sentencepiece_model=cfg["bpe"].get("sentencepiece_model"))
-    return cls.setup_task(SpeechRecognitionEspressoConfig(**kw))
+        extra.update(bpe=cfg["bpe"].get("_name"), sentencepiece_model=cfg["bpe"].get("sentencepiece_model"))
+    kw.update({k: v for k, v in extra.items() if k in known})
+    return cls.setup_task(dc(**kw))
 
 
 def build_model(cfg, task):

@@ -69,7 +69,8 @@ class Trainer:
         self.ddp.all_reduce_grads()
         self.last_coef = self.optimizer.clip_and_step(pre_scale=1.0, max_norm=self.clip_norm, denom_dev=self._stats[0:1])
         self.num_updates += 1
-        self.model.set_num_updates(self.num_updates)
+        if hasattr(self.model, "set_num_updates"):
+            self.model.set_num_updates(self.num_updates)
         self.lr_scheduler.step_update(self.num_updates)
         return self._stats
 
@@ -108,7 +109,7 @@ class Trainer:
         sched = dict(cfg["lr_scheduler"])
         name = sched.pop("_name")
         sched.pop("lr", None)
-        if name == "reduce_lr_on_plateau_v2":
+        if name in ("reduce_lr_on_plateau_v2", "reduce_lr_on_plateau"):
             sched.setdefault("maximize_best_checkpoint_metric", cfg["checkpoint"]["maximize_best_checkpoint_metric"])
         if name == "tri_stage":
             sched.setdefault("max_update", opt["max_update"])
@@ -219,7 +220,8 @@ class Trainer:
                 raise RuntimeError("Criterion does not match; please reset the optimizer (--reset-optimizer)")
             self._load_optimizer_state(state["last_optimizer_state"])
             self.num_updates = int(last["num_updates"])
-            self.model.set_num_updates(self.num_updates)
+            if hasattr(self.model, "set_num_updates"):
+                self.model.set_num_updates(self.num_updates)
             if not reset_lr_scheduler and hasattr(self.lr_scheduler, "load_state_dict") and last.get("lr_scheduler_state"):
                 self.lr_scheduler.load_state_dict(last["lr_scheduler_state"])
             self.lr_scheduler.step_update(self.num_updates)

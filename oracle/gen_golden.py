@@ -472,6 +472,61 @@ def lm_fusion_fixture(name="ref_lm_fusion_tiny"):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **beams, **{"lm::" + k: v.numpy() for k, v in lm.state_dict().items()})
 
 
+def lm_train_fixture(name="ref_lstm_lm_train_tiny"):
+    """Language-model TRAINING step of the reference (lstm_lm_librispeech.yaml: model lstm_lm_espresso with tied embeddings,
+    criterion cross_entropy = fairseq/criterions/cross_entropy.py:44-71): logits of a right-padded sentence batch
+    (source = </s> w1 … w_{n-1}, target = w1 … w_{n-1} </s>, the `eos` sample-break mode of fairseq's MonolingualDataset),
+    summed NLL over the non-pad targets, and all parameter gradients."""
+    import argparse
+    import torch.nn.functional as TF
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.models.lstm_lm import LSTMLanguageModelEspresso, base_lm_architecture
+    from espresso.tasks.speech_recognition import SpeechRecognitionEspressoTask  # noqa: F401
+
+    torch.manual_seed(4242)
+    V = 40
+    dic = AsrDictionary()
+    for i in range(V - len(dic) - 1):
+        dic.add_symbol(f"t{i}")
+    dic.add_symbol("<space>")
+
+    class T:
+        pass
+    T.target_dictionary = T.source_dictionary = dic
+    out = {}
+    for tag, share in (("tied", True), ("untied", False)):
+        dim_out = 32
+        args = argparse.Namespace(decoder_embed_dim=32 if share else 24, decoder_hidden_size=32, decoder_layers=2,
+                                  decoder_out_embed_dim=dim_out, dropout=0.0, share_embed=share, is_wordlm=False,
+                                  criterion_name="cross_entropy", tokens_per_sample=64)
+        base_lm_architecture(args)
+        lm = LSTMLanguageModelEspresso.build_model(args, T)
+        with torch.no_grad():
+            for p_ in lm.parameters():
+                p_.mul_(2.0)
+        lm.train()
+        rng = np.random.default_rng(11)
+        lens = [7, 5, 2, 6]
+        B, U = len(lens), max(lens)
+        target = torch.full((B, U), dic.pad(), dtype=torch.long)
+        src = torch.full((B, U), dic.pad(), dtype=torch.long)
+        for b, n in enumerate(lens):
+            sent = torch.from_numpy(rng.integers(4, V, size=n - 1))
+            target[b, : n - 1], target[b, n - 1] = sent, dic.eos()
+            src[b, 0], src[b, 1:n] = dic.eos(), sent
+        logits = lm(src, src_lengths=torch.tensor(lens))[0]
+        lprobs = lm.get_normalized_probs((logits, None), log_probs=True)
+        loss = TF.nll_loss(lprobs.view(-1, lprobs.size(-1)), target.view(-1), ignore_index=dic.pad(), reduction="sum")
+        loss.backward()
+        out.update({f"{tag}::sd::{k}": v.detach().numpy().copy() for k, v in lm.state_dict().items()})
+        out.update({f"{tag}::grad::{k}": p_.grad.numpy().copy() for k, p_ in lm.named_parameters()})
+        out[f"{tag}::logits"], out[f"{tag}::loss"] = logits.detach().numpy(), np.array(float(loss))
+        out[f"{tag}::src"], out[f"{tag}::target"], out[f"{tag}::lens"] = src.numpy(), target.numpy(), np.array(lens)
+        print(tag, "loss", float(loss), "params", sum(p_.numel() for p_ in lm.parameters()), [k for k, _ in lm.named_parameters()][:4])
+    out["pad"], out["eos"], out["V"] = np.array(dic.pad()), np.array(dic.eos()), np.array(len(dic))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def lookahead_fixture(name="ref_lookahead_wordlm_tiny"):
     """Look-ahead word LM (espresso/models/tensorized_lookahead_language_model.py) over a tiny character lexicon: the
     tensorized prefix tree, the word LSTM LM weights, and the sub-word log-probs the reference emits along scripted
@@ -622,6 +677,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lmtrain":
+        lm_train_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lookahead":
         lookahead_fixture()

@@ -1782,3 +1782,115 @@ def check_ddp_bucket_accounting(tmp_dir):
             else:
                 os.environ[k] = v
     return res
+
+
+def check_lstm_lm_training_vs_reference():
+    """Language-model TRAINING step (lstm_lm_espresso + criterion `cross_entropy`): logits, summed NLL and every parameter
+    gradient vs what the reference's model + fairseq's cross_entropy arithmetic produced (tests/golden/
+    ref_lstm_lm_train_tiny.npz, oracle/gen_golden.py lmtrain), with tied and untied output embeddings."""
+    from espresso_amd import registry
+    from espresso_amd.models.lstm_lm import LSTMLanguageModelEspresso
+
+    g = np.load(os.path.join(GOLD, "ref_lstm_lm_train_tiny.npz"))
+    task = _TaskAR(40)
+    assert task.target_dictionary.pad() == int(g["pad"]) and task.target_dictionary.eos() == int(g["eos"])
+    res = {}
+    for tag, share in (("tied", True), ("untied", False)):
+        lm = LSTMLanguageModelEspresso.build_model(dict(arch="lstm_lm_wsj", decoder_embed_dim=32 if share else 24, decoder_hidden_size=32,
+                                                        decoder_layers=2, decoder_out_embed_dim=32, dropout=0.0, share_embed=share), task)
+        sd = {k[len(tag) + 6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "::sd::")}
+        missing, unexpected = lm.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (tag, missing, unexpected)
+        lm = lm.to(DEV).train()
+        src, target = torch.from_numpy(g[tag + "::src"]).to(DEV), torch.from_numpy(g[tag + "::target"]).to(DEV)
+        lens = torch.from_numpy(g[tag + "::lens"]).to(DEV)
+        sample = {"net_input": {"src_tokens": src, "src_lengths": lens}, "target": target, "ntokens": int(lens.sum()), "nsentences": src.shape[0]}
+        crit = registry.CRITERION_REGISTRY["cross_entropy"](task)
+        logits = lm(**sample["net_input"])[0]
+        valid = target.ne(task.target_dictionary.pad())
+        ref_logits = torch.from_numpy(g[tag + "::logits"]).to(DEV)
+        loss, sample_size, _ = crit(lm, sample)
+        loss.backward()
+        worst, worst_name = 0.0, None
+        for n, p in lm.named_parameters():
+            rg = torch.from_numpy(g[f"{tag}::grad::{n}"]).to(DEV)
+            err = float((p.grad.float() - rg).abs().max() / rg.abs().max().clamp_min(1e-6))
+            if err > worst:
+                worst, worst_name = err, n
+        res[tag] = {"logits_abs": float((logits.float() - ref_logits)[valid].abs().max()), "logits_scale": float(ref_logits[valid].abs().max()),
+                    "loss_rel": abs(float(loss) - float(g[tag + "::loss"])) / float(g[tag + "::loss"]), "sample_size": sample_size,
+                    "ntokens": sample["ntokens"], "grad_rel_worst": worst, "grad_worst_name": worst_name,
+                    "n_params": sum(1 for _ in lm.parameters())}
+    return res
+
+
+def check_lm_train_cli(tmp_dir):
+    """The language-model recipe layout (`task: language_modeling_for_asr`, `criterion: cross_entropy`,
+    `lr_scheduler: reduce_lr_on_plateau`, `model: lstm_lm_espresso`) through `espresso_amd.speech_train`: binarised train split
+    (fairseq mmap format), raw-text valid split, a few epochs on a tiny corpus with a learnable regularity; validation
+    perplexity must drop and checkpoints appear."""
+    import contextlib
+    import io
+    import json
+
+    from espresso_amd import speech_train
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+    from espresso_amd.data.lm_dataset import MMapTokenFile
+
+    rng = np.random.default_rng(3)
+    words = [f"w{i}" for i in range(30)]
+    with open(os.path.join(tmp_dir, "dict.txt"), "w") as f:
+        f.write("".join(f"{w} 1\n" for w in words))
+    d = AsrDictionary.load(os.path.join(tmp_dir, "dict.txt"))
+
+    def sentence():  # deterministic successor chain from a random start: learnable by a 1-step context
+        n, w = int(rng.integers(3, 9)), int(rng.integers(0, 30))
+        out = []
+        for _ in range(n):
+            out.append(words[w])
+            w = (w * 7 + 3) % 30
+        return " ".join(out)
+
+    train = [sentence() for _ in range(96)]
+    valid = [sentence() for _ in range(24)]
+    MMapTokenFile.write(os.path.join(tmp_dir, "train"), [d.encode_line(s, append_eos=True).numpy() for s in train], dtype=np.int32)
+    with open(os.path.join(tmp_dir, "valid"), "w") as f:
+        f.write("\n".join(valid) + "\n")
+    recipe = os.path.join(tmp_dir, "lm.yaml")
+    with open(recipe, "w") as f:
+        f.write("""
+common: {seed: 1, log_interval: 4}
+checkpoint: {save_dir: checkpoints, keep_last_epochs: 2}
+task:
+  _name: language_modeling_for_asr
+  data: ???
+  dict: ???
+  sample_break_mode: eos
+  tokens_per_sample: 64
+dataset: {max_tokens: 256, batch_size: 16, required_batch_size_multiple: 8, train_subset: train, valid_subset: valid, curriculum: 1}
+criterion: {_name: cross_entropy}
+optimization: {max_epoch: 12, clip_norm: 1.0, update_freq: [1], lr: [0.05]}
+optimizer: {_name: adam, adam_betas: "(0.9,0.999)", adam_eps: 1e-08, weight_decay: 0.0}
+lr_scheduler: {_name: reduce_lr_on_plateau, lr_shrink: 0.5}
+model:
+  _name: lstm_lm_espresso
+  dropout: 0.0
+  decoder_embed_dim: 64
+  decoder_hidden_size: 64
+  decoder_layers: 2
+  decoder_out_embed_dim: 64
+  decoder_rnn_residual: false
+  decoder_dropout_in: 0.0
+  decoder_dropout_out: 0.0
+  share_embed: true
+  is_wordlm: false
+""")
+    buf = io.StringIO()
+    save_dir = os.path.join(tmp_dir, "ck")
+    with contextlib.redirect_stdout(buf):
+        tr = speech_train.main(["--config", recipe, f"task.data={tmp_dir}", f"task.dict={tmp_dir}/dict.txt", f"checkpoint.save_dir={save_dir}"])
+    lines = [json.loads(l) for l in buf.getvalue().splitlines() if l.startswith("{")]
+    valid_lines = [l for l in lines if l["kind"] == "valid"]
+    return {"files": sorted(os.listdir(save_dir)), "valid_loss": [l["loss"] for l in valid_lines], "valid_ppl": [l.get("ppl") for l in valid_lines],
+            "num_updates": tr.num_updates, "lr": [l["lr"] for l in lines if l["kind"] == "epoch_end"],
+            "train_loss": [l["loss"] for l in lines if l["kind"] == "train_inner"], "setup": [l for l in lines if l["kind"] == "setup"]}

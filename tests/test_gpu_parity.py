@@ -344,6 +344,24 @@ def test_ddp_every_parameter_reports_once_per_update(tmp_path):
     assert all(r[f]["native_layers"] >= 2 for f in ("conformer_ctc", "transformer_learned_ctc", "encdec_lsce", "transducer")), r
 
 
+def test_lstm_lm_training_step_vs_reference():
+    r = G.check_lstm_lm_training_vs_reference()
+    print(r)
+    for tag, v in r.items():
+        assert v["logits_abs"] < 2e-2 * max(1.0, v["logits_scale"]), (tag, v)   # bf16 GEMMs vs the reference's fp32
+        assert v["loss_rel"] < 1e-2 and v["sample_size"] == v["ntokens"] == 20, (tag, v)
+        assert v["grad_rel_worst"] < 5e-2, (tag, v)
+
+
+def test_language_model_recipe_through_the_training_cli(tmp_path):
+    r = G.check_lm_train_cli(str(tmp_path))
+    print(r)
+    assert {"checkpoint11.pt", "checkpoint12.pt", "checkpoint_best.pt", "checkpoint_last.pt"} <= set(r["files"]) and "checkpoint1.pt" not in r["files"], r
+    assert len(r["valid_loss"]) == 12 and all(math.isfinite(v) for v in r["valid_loss"]), r
+    assert min(r["valid_loss"]) < 0.8 * r["valid_loss"][0], r   # the successor chain is learnable: perplexity falls
+    assert r["num_updates"] >= 6 and r["train_loss"], r
+
+
 def test_global_cmvn_stats_tool(tmp_path):
     r = G.check_global_cmvn_stats(str(tmp_path))
     assert r["mean_abs"] < 2e-4 and r["std_abs"] < 2e-4 and r["dtype64"] and r["num_frames_equal"], r

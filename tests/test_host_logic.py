@@ -655,11 +655,12 @@ def test_every_asr_recipe_of_the_reference_builds(tmp_path):
         "transformer_librispeech": ("speech_transformer_base", "label_smoothed_cross_entropy_v2", 5003, "TriStageLRSchedule"),
         "transformer_librispeech_specaug": ("speech_transformer_base", "label_smoothed_cross_entropy_v2", 5003, "TriStageLRSchedule"),
         "transformer_transducer_librispeech": ("speech_transformer_transducer_base", "transducer_loss", 5004, "PolynomialDecayV2LRSchedule"),
+        "lstm_lm_librispeech": ("lstm_lm_espresso", "cross_entropy", 5003, "ReduceLROnPlateauLRSchedule"),
     }
     seen = set()
     for y in sorted(glob.glob(os.path.join(_REF_RECIPES, "*.yaml"))):
         name = os.path.basename(y)[:-5]
-        if name not in want:  # lstm_lm_librispeech: language-model training (task language_modeling_for_asr) is not on this path
+        if name not in want:
             continue
         cfg = load_config(y, [f"task.data={tmp_path}", f"task.dict={tmp_path}/dict.txt", "bpe.sentencepiece_model=none"])
         cfg["bpe"] = {}
@@ -670,6 +671,7 @@ def test_every_asr_recipe_of_the_reference_builds(tmp_path):
         got = (cfg["model"]["_name"], cfg["criterion"]["_name"], len(task.target_dictionary), type(tr.lr_scheduler).__name__)
         assert got == want[name], (name, got)
         assert all(isinstance(v, float) and 0.0 < v < 1.0 for v in lrs), (name, lrs)
+        assert type(task).__name__ == ("LanguageModelingForASRTask" if name == "lstm_lm_librispeech" else "SpeechRecognitionEspressoTask")
         assert (task.blank_symbol == "<s>") == (got[1] in ("ctc_loss", "transducer_loss")), name
         assert tr.clip_norm == float(cfg["optimization"]["clip_norm"]) and tr.optimizer.eps == 1e-8, name
         seen.add(name)
@@ -773,3 +775,51 @@ def test_recognize_cli_rebuilds_model_from_checkpoint_cfg(tmp_path):
     assert resolve_model_config(None, str(y), {"w": torch.zeros(1)})[0] == "speech_transformer_base"
     with pytest.raises(ValueError, match="model-config"):
         resolve_model_config(None, None, {"w": torch.zeros(1)})
+
+
+def test_language_model_data_follows_fairseq_monolingual_dataset(tmp_path):
+    """Token files (fairseq mmap format written and read back; raw text), `eos` / `none` sample-break modes, the shifted source /
+    future target of fairseq's MonolingualDataset, right-padded collation and the task's batch plan."""
+    from espresso_amd.data.lm_dataset import MMapTokenFile, MonolingualDataset, load_token_file
+    from espresso_amd.tasks.language_modeling_for_asr import LanguageModelingForASRConfig, LanguageModelingForASRTask
+
+    d = AsrDictionary.from_symbols([f"w{i}" for i in range(20)], enable_bos=False, add_space=False)
+    (tmp_path / "dict.txt").write_text("".join(f"w{i} 1\n" for i in range(20)))
+    lines = ["w1 w2 w3", "w4", "w5 w6 w7 w8 w9", "w10 w11"]
+    (tmp_path / "valid").write_text("\n".join(lines) + "\n")
+    raw = load_token_file(str(tmp_path / "valid"), d)
+    items = [raw[i] for i in range(len(raw))]
+    assert [len(x) for x in items] == [4, 2, 6, 3] and all(int(x[-1]) == d.eos() for x in items)
+    MMapTokenFile.write(str(tmp_path / "train"), items, dtype=np.int32)
+    mm = load_token_file(str(tmp_path / "train"), d)
+    assert isinstance(mm, MMapTokenFile) and len(mm) == 4 and mm.sizes.tolist() == [4, 2, 6, 3]
+    assert all(np.array_equal(mm[i], items[i]) and mm[i].dtype == np.int64 for i in range(4))
+    idx = open(tmp_path / "train.idx", "rb").read()
+    assert idx[:9] == b"MMIDIDX\x00\x00" and idx[17] == 4 and len(idx) == 9 + 8 + 1 + 8 + 4 * 4 + 8 * 4  # dtype code 4 = int32
+    assert np.frombuffer(idx, dtype=np.int64, count=4, offset=9 + 8 + 1 + 8 + 16).tolist() == [0, 16, 24, 48]  # byte pointers
+
+    ds = MonolingualDataset(mm, d, "eos", shuffle=False)
+    assert len(ds) == 4 and ds.sizes.tolist() == [4, 2, 6, 3]
+    it = ds[2]
+    assert it["target"].tolist() == items[2].tolist() and it["source"].tolist() == [d.eos()] + items[2][:-1].tolist()
+    assert ds[0]["source"][0] == d.eos()
+    assert ds.ordered_indices().tolist() == [1, 3, 0, 2]  # stable by length
+    batch = ds.collater([ds[0], ds[2]])
+    assert batch["ntokens"] == 10 and batch["nsentences"] == 2 and batch["net_input"]["src_lengths"].tolist() == [4, 6]
+    assert batch["target"][0].tolist() == items[0].tolist() + [d.pad()] * 2 and batch["net_input"]["src_tokens"][0, 4:].tolist() == [d.pad()] * 2
+    blocks = MonolingualDataset(mm, d, "none", tokens_per_sample=4, shuffle=False)
+    flat = np.concatenate(items)
+    assert blocks.sizes.tolist() == [4, 4, 4, 3] and blocks[1]["target"].tolist() == flat[4:8].tolist()
+    assert blocks[1]["source"].tolist() == flat[3:7].tolist() and blocks[0]["source"][0] == d.eos()
+    keep, dropped = ds.filter_indices_by_size(np.arange(4), 4)
+    assert keep.tolist() == [0, 1, 3] and dropped == [2]
+
+    task = LanguageModelingForASRTask.setup_task(LanguageModelingForASRConfig(data=str(tmp_path), dict=str(tmp_path / "dict.txt"),
+                                                                              sample_break_mode="eos", tokens_per_sample=5))
+    tds = task.load_dataset("train")
+    plan = task.get_batches(tds, max_tokens=8, max_sentences=None, max_positions=task.max_positions(), seed=1, epoch=1, shuffle=False)
+    assert sorted(int(i) for b in plan for i in b) == [0, 1, 3]  # the 6-token sentence exceeds tokens_per_sample
+    assert all(len(b) * int(tds.sizes[b].max()) <= 8 for b in plan)
+    two = task.get_batches(tds, max_tokens=8, max_positions=task.max_positions(), seed=1, epoch=1, num_shards=2, shard_id=1, shuffle=False)
+    assert len(two) == (len(plan) + 1) // 2
+    assert registry.CRITERION_REGISTRY["cross_entropy"](task).sentence_avg is False
