@@ -135,6 +135,14 @@ def validate(cfg, trainer, task, subsets, device, world, rank):
     return scores, first
 
 
+def update_group_sizes(n_batches, skip, update_freq):
+    """Micro-batches per update for the rest of an epoch (fairseq's GroupedIterator over the epoch iterator, iterators.py:
+    574-620): chunks of `update_freq`, the last one possibly shorter.  `skip` batches were consumed before a restart; saves
+    happen after whole updates, so `skip` is a chunk boundary of the uninterrupted run and the chunks line up."""
+    left = max(0, n_batches - skip)
+    return [min(update_freq, left - s) for s in range(0, left, update_freq)]
+
+
 class EarlyStop:
     """fairseq_cli/train.py:205-233 (`patience` validations without improvement)."""
 
@@ -258,18 +266,16 @@ def main(argv=None):
         dummy_src = next((b for b in batches if len(b) > 0), None)
         todo = batches[skip:]
         done = skip
-        group = []
-        stream = Prefetcher(train_ds, [b if len(b) > 0 else dummy_src for b in todo], depth=cfg["dataset"].get("data_buffer_size", 4) or 4)
-        for b, sample in zip(todo, stream):
-            sample = task.to_device(sample, device)
-            if len(b) == 0:
-                sample["_dummy"] = True
-            group.append(sample)
-            done += 1
-            if len(group) < uf and done < len(batches):
-                continue
-            interval += trainer.train_step(group)
+        stream = iter(Prefetcher(train_ds, [b if len(b) > 0 else dummy_src for b in todo], depth=cfg["dataset"].get("data_buffer_size", 4) or 4))
+        for size in update_group_sizes(len(batches), skip, uf):
             group = []
+            for b in batches[done:done + size]:
+                sample = task.to_device(next(stream), device)
+                if len(b) == 0:
+                    sample["_dummy"] = True
+                group.append(sample)
+            done += size
+            interval += trainer.train_step(group)
             n_interval += 1
             n = trainer.num_updates
             if n % cfg["common"]["log_interval"] == 0:

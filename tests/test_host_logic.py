@@ -823,3 +823,26 @@ def test_language_model_data_follows_fairseq_monolingual_dataset(tmp_path):
     two = task.get_batches(tds, max_tokens=8, max_positions=task.max_positions(), seed=1, epoch=1, num_shards=2, shard_id=1, shuffle=False)
     assert len(two) == (len(plan) + 1) // 2
     assert registry.CRITERION_REGISTRY["cross_entropy"](task).sentence_avg is False
+
+
+def test_training_loop_update_groups_and_early_stop():
+    """Micro-batch grouping of the epoch loop (whole chunks of update_freq, a shorter last one, aligned after a mid-epoch restart)
+    and the `patience` rule of fairseq_cli/train.py:205-233."""
+    from espresso_amd.speech_train import EarlyStop, update_group_sizes
+
+    assert update_group_sizes(5, 0, 2) == [2, 2, 1] and update_group_sizes(5, 4, 2) == [1] and update_group_sizes(5, 5, 2) == []
+    assert update_group_sizes(6, 0, 3) == [3, 3] and update_group_sizes(6, 3, 3) == [3] and update_group_sizes(4, 0, 1) == [1, 1, 1, 1]
+    for n, uf in ((7, 3), (8, 2), (5, 4)):  # a restart at any update boundary continues with the uninterrupted run's chunks
+        full = update_group_sizes(n, 0, uf)
+        done = 0
+        for k, size in enumerate(full):
+            assert update_group_sizes(n, done, uf) == full[k:]
+            done += size
+    cfg = {"checkpoint": {"patience": 2, "maximize_best_checkpoint_metric": False}}
+    es = EarlyStop(cfg)
+    assert [es(v) for v in (5.0, 4.0, 4.5, 3.9, 4.0, 4.1)] == [False, False, False, False, False, True]
+    assert es(None) is False
+    up = EarlyStop({"checkpoint": {"patience": 1, "maximize_best_checkpoint_metric": True}})
+    assert [up(v) for v in (0.5, 0.6, 0.6)] == [False, False, True]
+    off = EarlyStop({"checkpoint": {"patience": -1, "maximize_best_checkpoint_metric": False}})
+    assert [off(v) for v in (1.0, 2.0, 3.0)] == [False, False, False]
