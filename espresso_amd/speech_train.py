@@ -74,6 +74,9 @@ def build_task(cfg):
     if cfg.get("bpe"):
         extra.update(bpe=cfg["bpe"].get("_name"), sentencepiece_model=cfg["bpe"].get("sentencepiece_model"))
     kw.update({k: v for k, v in extra.items() if k in known})
+    if "autoregressive" in known:
+        # the reference's task default (espresso/tasks/speech_recognition.py:73-79); the LSTM recipes rely on it
+        kw.setdefault("autoregressive", True)
     return cls.setup_task(dc(**kw))
 
 

@@ -673,6 +673,8 @@ def test_every_asr_recipe_of_the_reference_builds(tmp_path):
         assert all(isinstance(v, float) and 0.0 < v < 1.0 for v in lrs), (name, lrs)
         assert type(task).__name__ == ("LanguageModelingForASRTask" if name == "lstm_lm_librispeech" else "SpeechRecognitionEspressoTask")
         assert (task.blank_symbol == "<s>") == (got[1] in ("ctc_loss", "transducer_loss")), name
+        if name != "lstm_lm_librispeech":  # input feeding everywhere but CTC (the LSTM recipes leave it to the task's default: true)
+            assert task.cfg.autoregressive == (got[1] != "ctc_loss"), name
         assert tr.clip_norm == float(cfg["optimization"]["clip_norm"]) and tr.optimizer.eps == 1e-8, name
         seen.add(name)
         del tr, model
