@@ -137,3 +137,75 @@ def per_epoch(values, epoch):
     """`update_freq` / `lr` lists are indexed by epoch and hold their last value (fairseq_cli/train.py:246-250)."""
     values = as_list(values)
     return values[min(epoch, len(values)) - 1]
+
+
+# ---- legacy command lines (examples/asr_wsj/run.sh, examples/asr_swbd/run.sh: `fairseq_cli/train.py DATA --task … --arch … --flag value`) ----
+# flag (underscored) -> configuration group; what is not listed belongs to the model (its --arch presets and overrides)
+_LEGACY_GROUPS = {
+    "common": ["seed", "log_interval", "log_format", "empty_cache_freq", "fp16", "amp", "tensorboard_logdir"],
+    "dataset": ["num_workers", "data_buffer_size", "max_tokens", "batch_size", "curriculum", "valid_subset", "train_subset",
+                "batch_size_valid", "max_tokens_valid", "required_batch_size_multiple", "validate_interval",
+                "validate_interval_updates", "validate_after_updates", "disable_validation"],
+    "distributed_training": ["ddp_backend", "distributed_world_size", "bucket_cap_mb"],
+    "optimization": ["update_freq", "lr", "max_epoch", "max_update", "clip_norm", "sentence_avg", "stop_min_lr", "stop_time_hours"],
+    "checkpoint": ["save_dir", "restore_file", "save_interval", "save_interval_updates", "keep_interval_updates", "keep_last_epochs",
+                   "keep_best_checkpoints", "best_checkpoint_metric", "maximize_best_checkpoint_metric", "no_save",
+                   "no_epoch_checkpoints", "no_last_checkpoints", "no_save_optimizer_state", "patience", "reset_optimizer",
+                   "reset_lr_scheduler", "reset_dataloader", "reset_meters"],
+    "optimizer": ["adam_betas", "adam_eps", "weight_decay"],
+    "lr_scheduler": ["lr_shrink", "lr_threshold", "lr_patience", "warmup_updates", "warmup_init_lr", "start_reduce_lr_epoch",
+                     "final_lr_scale", "warmup_steps", "hold_steps", "decay_steps", "phase_ratio", "init_lr_scale", "model_size",
+                     "final_lr", "end_learning_rate", "power", "total_num_update"],
+    "criterion": ["label_smoothing", "smoothing_type", "unigram_pseudo_count", "print_training_sample_interval", "zero_infinity"],
+    "task": ["dict", "non_lang_syms", "word_dict", "wer_output_filter", "max_source_positions", "max_target_positions",
+             "specaugment_config", "global_cmvn_stats_path", "feat_in_channels", "autoregressive", "include_eos_in_transducer_loss",
+             "sample_break_mode", "tokens_per_sample", "output_dictionary_size", "is_wordlm"],
+    "bpe": ["sentencepiece_model"],
+}
+_LEGACY_FLAG_GROUP = {f: g for g, fs in _LEGACY_GROUPS.items() for f in fs}
+_LEGACY_SELECTORS = {"task": "task", "criterion": "criterion", "optimizer": "optimizer", "lr_scheduler": "lr_scheduler", "bpe": "bpe"}
+_LIST_VALUED = {"update_freq", "lr", "scheduled_sampling_probs"}
+# --arch -> registered model (fairseq/models/__init__.py ARCH_MODEL_REGISTRY of the reference's ASR architectures)
+_ARCH_MODEL = {"speech_conv_lstm_wsj": "speech_lstm", "speech_conv_lstm_librispeech": "speech_lstm", "speech_conv_lstm_swbd": "speech_lstm",
+               "speech_lstm": "speech_lstm", "lstm_lm_wsj": "lstm_lm_espresso", "lstm_lm_librispeech": "lstm_lm_espresso",
+               "lstm_lm_swbd": "lstm_lm_espresso", "lstm_wordlm_wsj": "lstm_lm_espresso"}
+
+
+def is_legacy_argv(argv) -> bool:
+    """fairseq_cli/train.py style (positional data directory and/or --task / --arch flags) rather than --config …"""
+    return bool(argv) and not any(a in ("--config", "--config-dir", "--config-name") for a in argv) and (
+        not argv[0].startswith("-") or "--task" in argv or "--arch" in argv)
+
+
+def from_legacy_argv(argv: List[str]) -> dict:
+    """The configuration a legacy command line describes, in the same grouped form `load_config` returns."""
+    user: Dict[str, Dict[str, Any]] = {g: {} for g in DEFAULTS}
+    i, positional = 0, []
+    while i < len(argv):
+        a = argv[i]
+        if not a.startswith("--"):
+            positional.append(a)
+            i += 1
+            continue
+        key = a[2:].replace("-", "_")
+        vals = []
+        i += 1
+        while i < len(argv) and not (argv[i].startswith("--") and not _FLOAT.fullmatch(argv[i])):
+            vals.append(argv[i])
+            i += 1
+        parsed = [yaml.safe_load(v) for v in vals]
+        value = True if not vals else (parsed if (len(parsed) > 1 or key in _LIST_VALUED) else parsed[0])
+        if key in _LEGACY_SELECTORS:
+            user[_LEGACY_SELECTORS[key]]["_name"] = value
+        elif key == "arch":
+            if value not in _ARCH_MODEL:
+                raise NotImplementedError(f"--arch {value}: supported legacy architectures are {sorted(_ARCH_MODEL)} "
+                                          "(the Transformer / Conformer models are configured through the recipe YAMLs)")
+            user["model"].update(_name=_ARCH_MODEL[value], arch=value)
+        else:
+            user[_LEGACY_FLAG_GROUP.get(key, "model")][key] = value
+    if positional:
+        user["task"]["data"] = positional[0]
+    if "_name" not in user["task"]:
+        user["task"]["_name"] = "speech_recognition_espresso"
+    return load_config(None, [], base={g: b for g, b in user.items() if b})

@@ -3,6 +3,7 @@
 runs) around the native update step of `espresso_amd/trainer.py`.
 
     python -m espresso_amd.speech_train --config recipe.yaml task.data=DIR task.dict=DICT [group.key=value …]
+    python -m espresso_amd.speech_train DATA --task speech_recognition_espresso --arch speech_conv_lstm_wsj --flag value …   (legacy)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m espresso_amd.speech_train …
 
 Same semantics as the reference's loop: per-epoch batch plan shuffled with `seed + epoch` and dealt round-robin to the ranks
@@ -28,7 +29,7 @@ import torch.distributed as dist
 
 from . import registry
 from .checkpoint_utils import CheckpointSaver
-from .config import load_config, per_epoch
+from .config import from_legacy_argv, is_legacy_argv, load_config, per_epoch
 from .trainer import Trainer
 
 
@@ -169,9 +170,13 @@ def main(argv=None):
     ap.add_argument("--config-dir")
     ap.add_argument("--config-name")
     ap.add_argument("overrides", nargs="*", help="group.key=value")
-    args = ap.parse_args(argv)
-    path = args.config or os.path.join(args.config_dir, args.config_name + ("" if args.config_name.endswith(".yaml") else ".yaml"))
-    cfg = load_config(path, args.overrides)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if is_legacy_argv(argv):  # `fairseq_cli/train.py DATA --task … --arch … --flag value` of the WSJ / SWBD recipes
+        cfg = from_legacy_argv(argv)
+    else:
+        args = ap.parse_args(argv)
+        path = args.config or os.path.join(args.config_dir, args.config_name + ("" if args.config_name.endswith(".yaml") else ".yaml"))
+        cfg = load_config(path, args.overrides)
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if not torch.cuda.is_available():

@@ -848,3 +848,67 @@ def test_training_loop_update_groups_and_early_stop():
     assert [up(v) for v in (0.5, 0.6, 0.6)] == [False, False, True]
     off = EarlyStop({"checkpoint": {"patience": -1, "maximize_best_checkpoint_metric": False}})
     assert [off(v) for v in (1.0, 2.0, 3.0)] == [False, False, False]
+
+
+def test_legacy_command_lines_of_the_wsj_and_swbd_recipes(tmp_path):
+    """`fairseq_cli/train.py DATA --task … --arch … --flag value` (examples/asr_wsj/run.sh:292-303, asr_swbd/run.sh:293-303,
+    asr_wsj/run.sh:197-207) through the legacy front end: same grouped configuration, task / model / criterion / schedule build."""
+    from espresso_amd import speech_train as st
+    from espresso_amd.config import from_legacy_argv, is_legacy_argv, literal
+    from espresso_amd.trainer import Trainer
+
+    (tmp_path / "dict.txt").write_text("".join(f"u{i} 1\n" for i in range(50)) + "<space> 1\n")
+    (tmp_path / "nlsyms.txt").write_text("")
+    wsj = ["data", "--task", "speech_recognition_espresso", "--seed", "1", "--log-interval", "400", "--log-format", "simple",
+           "--print-training-sample-interval", "1000", "--num-workers", "6", "--data-buffer-size", "0", "--max-tokens", "24000",
+           "--batch-size", "32", "--curriculum", "2", "--empty-cache-freq", "2", "--valid-subset", "valid", "--batch-size-valid", "64",
+           "--ddp-backend", "legacy_ddp", "--update-freq", "2", "--distributed-world-size", "1", "--required-batch-size-multiple", "8",
+           "--optimizer", "adam", "--lr", "0.001", "--weight-decay", "0.0", "--save-dir", "exp/lstm", "--restore-file", "checkpoint_last.pt",
+           "--save-interval-updates", "400", "--keep-interval-updates", "5", "--keep-last-epochs", "5", "--validate-interval", "1",
+           "--best-checkpoint-metric", "wer", "--criterion", "label_smoothed_cross_entropy_v2", "--label-smoothing", "0.05",
+           "--smoothing-type", "temporal", "--dict", str(tmp_path / "dict.txt"), "--bpe", "characters_asr", "--non-lang-syms",
+           str(tmp_path / "nlsyms.txt"), "--max-source-positions", "3000", "--max-target-positions", "300",
+           "--arch", "speech_conv_lstm_wsj", "--max-epoch", "35", "--lr-scheduler", "reduce_lr_on_plateau_v2", "--lr-shrink", "0.5",
+           "--start-reduce-lr-epoch", "11", "--scheduled-sampling-probs", "0.5", "--start-scheduled-sampling-epoch", "6"]
+    assert is_legacy_argv(wsj) and not is_legacy_argv(["--config", "r.yaml", "task.data=x"])
+    cfg = from_legacy_argv(wsj)
+    assert cfg["task"]["data"] == "data" and cfg["task"]["_name"] == "speech_recognition_espresso" and cfg["task"]["max_source_positions"] == 3000
+    assert cfg["dataset"]["max_tokens"] == 24000 and cfg["dataset"]["curriculum"] == 2 and cfg["dataset"]["required_batch_size_multiple"] == 8
+    assert cfg["optimization"]["update_freq"] == [2] and cfg["optimization"]["lr"] == [0.001] and cfg["optimization"]["clip_norm"] == 0.0
+    assert cfg["checkpoint"]["best_checkpoint_metric"] == "wer" and cfg["checkpoint"]["keep_interval_updates"] == 5
+    assert cfg["criterion"] == {"_name": "label_smoothed_cross_entropy_v2", "print_training_sample_interval": 1000,
+                                "label_smoothing": 0.05, "smoothing_type": "temporal"}
+    assert cfg["lr_scheduler"] == {"_name": "reduce_lr_on_plateau_v2", "lr_shrink": 0.5, "start_reduce_lr_epoch": 11}
+    assert cfg["model"] == {"_name": "speech_lstm", "arch": "speech_conv_lstm_wsj", "scheduled_sampling_probs": [0.5],
+                            "start_scheduled_sampling_epoch": 6}
+    assert cfg["bpe"]["_name"] == "characters_asr" and literal(cfg["optimizer"]["adam_betas"]) == (0.9, 0.999)
+    task = st.build_task(cfg)
+    assert task.cfg.autoregressive and task.blank_symbol is None and task.cfg.non_lang_syms.endswith("nlsyms.txt")
+    model, crit = st.build_model(cfg, task), st.build_criterion(cfg, task)
+    tr = Trainer.from_cfg(cfg, task, model, crit, torch.device("cpu"))
+    assert type(tr.lr_scheduler).__name__ == "ReduceLROnPlateauLRScheduleV2" and tr.clip_norm == 0.0 and tr.get_lr() == 0.001
+    assert crit.smoothing_type == "temporal" and 5e6 < sum(p.numel() for p in model.parameters()) < 4e7
+
+    swbd = ["data", "--task", "speech_recognition_espresso", "--max-tokens", "26000", "--batch-size", "48", "--optimizer", "adam", "--lr", "0.001",
+            "--clip-norm", "2.0", "--criterion", "label_smoothed_cross_entropy_v2", "--label-smoothing", "0.1", "--smoothing-type", "uniform",
+            "--dict", str(tmp_path / "dict.txt"), "--arch", "speech_conv_lstm_swbd", "--max-epoch", "100", "--lr-scheduler", "tri_stage",
+            "--warmup-steps", "1000", "--hold-steps", "180000", "--decay-steps", "360000", "--encoder-rnn-hidden-size", "1024",
+            "--encoder-rnn-layers", "5", "--decoder-embed-dim", "512", "--decoder-hidden-size", "1024", "--decoder-out-embed-dim", "3072",
+            "--attention-dim", "512", "--dropout", "0.4", "--specaugment-config",
+            "{'time_warp_W': 0, 'freq_mask_F': 18, 'time_mask_T': 70, 'freq_mask_N': 2, 'time_mask_N': 2, 'time_mask_p': 0.2}"]
+    c2 = from_legacy_argv(swbd)
+    assert c2["model"]["encoder_rnn_layers"] == 5 and c2["model"]["dropout"] == 0.4 and c2["optimization"]["clip_norm"] == 2.0
+    assert c2["task"]["specaugment_config"]["time_mask_T"] == 70 and c2["lr_scheduler"]["hold_steps"] == 180000
+    assert type(Trainer.from_cfg(c2, st.build_task(c2), torch.nn.Linear(2, 2), object(), torch.device("cpu")).lr_scheduler).__name__ == "TriStageLRSchedule"
+
+    lm = ["lmdata", "--task", "language_modeling_for_asr", "--dict", str(tmp_path / "dict.txt"), "--max-tokens", "25600", "--batch-size", "128",
+          "--max-epoch", "25", "--optimizer", "adam", "--lr", "0.001", "--weight-decay", "5e-06", "--lr-scheduler", "reduce_lr_on_plateau",
+          "--lr-shrink", "0.5", "--arch", "lstm_lm_wsj", "--criterion", "cross_entropy", "--sample-break-mode", "eos"]
+    c3 = from_legacy_argv(lm)
+    assert c3["task"] == {"_name": "language_modeling_for_asr", "dict": str(tmp_path / "dict.txt"), "sample_break_mode": "eos", "data": "lmdata"}
+    assert c3["optimizer"]["weight_decay"] == 5e-6 and c3["model"] == {"_name": "lstm_lm_espresso", "arch": "lstm_lm_wsj"}
+    t3 = st.build_task(c3)
+    m3 = st.build_model(c3, t3)
+    assert type(t3).__name__ == "LanguageModelingForASRTask" and m3.decoder.hidden_size == 650
+    with pytest.raises(NotImplementedError, match="recipe YAMLs"):
+        from_legacy_argv(["data", "--arch", "speech_transformer_wsj"])
