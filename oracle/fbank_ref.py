@@ -1,12 +1,14 @@
 """TEST INFRASTRUCTURE ONLY — numpy restatement of torchaudio.compliance.kaldi.fbank with the
 arguments the reference uses (espresso/tools/utils.py:438-440: num_mel_bins=80, sample_frequency,
 everything else default).  torchaudio (pinned only as ">= 0.10.0", README.md:16) is NOT installable
-in this environment and nothing in the reference's tests pins its output:  **parity unpinned** at this
-boundary.  The restatement follows the published Kaldi semantics (SURVEY.md Appendix
+in this environment and nothing in the reference's tests pins its output:  **parity unpinned** against torchaudio itself
+at this boundary.  The restatement follows the published Kaldi semantics (SURVEY.md Appendix
 A.1): snip_edges framing, per-frame DC removal, pre-emphasis 0.97 with replicate padding, povey
 window, 512-point rFFT power spectrum, 80 triangular mel filters 20 Hz..Nyquist (mel = 1127 ln(1+f/700)),
-log floored at float32 eps.  It is pinned only against the closed-form frame count of
-espresso/tools/utils.py:457-486 (num_samples_to_num_frames)."""
+log floored at float32 eps.  It is pinned against the closed-form frame count of espresso/tools/utils.py:457-486
+(num_samples_to_num_frames) and, as an independent third-party check, against the Kaldi-compatible numpy front-end of
+`transformers.audio_utils` (what that library's feature extractors run in place of torchaudio.compliance.kaldi.fbank):
+max abs difference 1.4e-4 on log-mel values up to 22 (tests/test_oracle.py)."""
 import math
 
 import numpy as np

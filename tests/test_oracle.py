@@ -85,6 +85,27 @@ def test_fbank_frame_count_matches_reference_formula():
         assert fbank_ref.fbank(w).shape == (num_samples_to_num_frames([n], 16000)[0], 80)
 
 
+def test_fbank_restatement_matches_an_independent_kaldi_compatible_frontend():
+    """torchaudio is absent, but `transformers.audio_utils` ships a numpy Kaldi-compatible front-end (povey window, per-frame DC
+    removal, pre-emphasis, power spectrum, Kaldi mel scale with triangles in mel space, natural log floored at float32 eps) that
+    its own feature extractors use in place of `torchaudio.compliance.kaldi.fbank` and test against it.  Same waveform through
+    both restatements: an independent third-party pin of the oracle at the fbank boundary."""
+    au = pytest.importorskip("transformers.audio_utils")
+    from espresso_amd.data import synthetic
+
+    win = au.window_function(400, "povey", periodic=False)
+    mel = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=80, min_frequency=20, max_frequency=8000, sampling_rate=16000,
+                             norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    rng = np.random.default_rng(0)
+    for n in (400, 5000, 16000 * 3 + 123):
+        w = synthetic.waveform(n, rng).astype(np.float32)  # int16-range band-limited noise, like the bench's audio
+        theirs = au.spectrogram(w.astype(np.float64), win, frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False,
+                                preemphasis=0.97, mel_filters=mel, log_mel="log", mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+        ours = fbank_ref.fbank(w)
+        assert ours.shape == theirs.shape
+        assert np.abs(ours - theirs).max() < 5e-4, (n, np.abs(ours - theirs).max())  # log-mel values reach ~22
+
+
 def test_fbank_closed_form_properties():
     """Analytic checks of the restatement: a DC signal has zero energy after DC removal (log floor),
     and a pure tone peaks in the mel bin that contains it."""
