@@ -527,6 +527,70 @@ def lm_train_fixture(name="ref_lstm_lm_train_tiny"):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def lm_data_fixture(name="ref_lm_data_tiny"):
+    """The language-model data path of the reference on token files written by THIS repo's writer: fairseq's
+    MMapIndexedDataset reads them, TokenBlockDataset (`eos` and `none` break modes) + MonolingualDataset build the samples the
+    way LanguageModelingTask.load_dataset does (fairseq/tasks/language_modeling.py:185-262), and the batch plan is the one of
+    FairseqTask.get_batch_iterator (ordered_indices under numpy_seed(seed) -> filter_indices_by_size -> batch_by_size with the
+    reference's own Cython planner, built by oracle/build_ref_cython.py)."""
+    import tempfile
+
+    sys.path.insert(2, ROOT)
+    sys.path.insert(2, HERE)
+    import build_ref_cython
+
+    build_ref_cython.attach()
+    import types
+
+    if "compat" not in np.__dict__:  # removed in numpy 2; token_block_dataset.py:125 still spells np.compat.long
+        np.compat = types.SimpleNamespace(long=int)
+    from espresso.data.asr_dictionary import AsrDictionary
+    from fairseq.data import MonolingualDataset, TokenBlockDataset, data_utils
+    from fairseq.data.indexed_dataset import MMapIndexedDataset
+
+    from espresso_amd.data.lm_dataset import MMapTokenFile
+
+    dic = AsrDictionary()
+    for i in range(30):
+        dic.add_symbol(f"w{i}")
+    rng = np.random.default_rng(21)
+    sents = [np.concatenate((rng.integers(4, len(dic), size=int(rng.integers(1, 12))), [dic.eos()])).astype(np.int64) for _ in range(41)]
+    tmp = tempfile.mkdtemp(dir=os.path.join(HERE, "_ref"))
+    prefix = os.path.join(tmp, "train")
+    MMapTokenFile.write(prefix, sents, dtype=np.int32)
+    ds = MMapIndexedDataset(prefix)
+    assert len(ds) == len(sents) and all(np.array_equal(ds[i].numpy(), sents[i]) for i in range(len(sents)))
+    out = {"n_sent": np.array(len(sents)), "flat": np.concatenate(sents), "sizes": np.array([len(x) for x in sents]),
+           "pad": np.array(dic.pad()), "eos": np.array(dic.eos()), "V": np.array(len(dic))}
+    for mode, tps in (("eos", 8), ("none", 7)):
+        blocks = TokenBlockDataset(ds, ds.sizes, tps, pad=dic.pad(), eos=dic.eos(), break_mode=mode, include_targets=True,
+                                   use_plasma_view=False)
+        add_eos = mode is not None and mode != "none"
+        mono = MonolingualDataset(dataset=blocks, sizes=blocks.sizes, src_vocab=dic, tgt_vocab=dic, add_eos_for_other_targets=add_eos,
+                                  shuffle=True, targets=["future"], add_bos_token=False)
+        items = [mono[i] for i in range(len(mono))]
+        out[f"{mode}::n"] = np.array(len(mono))
+        out[f"{mode}::sizes"] = np.asarray(mono.sizes)
+        out[f"{mode}::src"] = np.concatenate([it["source"].numpy() for it in items])
+        out[f"{mode}::tgt"] = np.concatenate([it["target"].numpy() for it in items])
+        out[f"{mode}::len"] = np.array([len(it["source"]) for it in items])
+        for seed in (1, 5):
+            with data_utils.numpy_seed(seed):
+                idx = mono.ordered_indices()
+            out[f"{mode}::order::{seed}"] = np.asarray(idx)
+            idx, _ = mono.filter_indices_by_size(idx, tps)
+            batches = mono.batch_by_size(idx, max_tokens=40, max_sentences=6, required_batch_size_multiple=4)  # fairseq_dataset.py:144-188
+            out[f"{mode}::batches::{seed}"] = np.concatenate(batches)
+            out[f"{mode}::batch_sizes::{seed}"] = np.array([len(b) for b in batches])
+        b = mono.collater([mono[i] for i in (0, 3, 2)])
+        out[f"{mode}::collate::src"], out[f"{mode}::collate::tgt"] = b["net_input"]["src_tokens"].numpy(), b["target"].numpy()
+        out[f"{mode}::collate::lens"], out[f"{mode}::collate::ntokens"] = b["net_input"]["src_lengths"].numpy(), np.array(b["ntokens"])
+        print(mode, len(mono), [len(x) for x in batches][:8])
+    import shutil
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def lookahead_fixture(name="ref_lookahead_wordlm_tiny"):
     """Look-ahead word LM (espresso/models/tensorized_lookahead_language_model.py) over a tiny character lexicon: the
     tensorized prefix tree, the word LSTM LM weights, and the sub-word log-probs the reference emits along scripted
@@ -677,6 +741,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lmdata":
+        lm_data_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmtrain":
         lm_train_fixture()

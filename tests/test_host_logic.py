@@ -912,3 +912,39 @@ def test_legacy_command_lines_of_the_wsj_and_swbd_recipes(tmp_path):
     assert type(t3).__name__ == "LanguageModelingForASRTask" and m3.decoder.hidden_size == 650
     with pytest.raises(NotImplementedError, match="recipe YAMLs"):
         from_legacy_argv(["data", "--arch", "speech_transformer_wsj"])
+
+
+def test_language_model_data_path_matches_the_reference_fixture(tmp_path, golden_dir):
+    """tests/golden/ref_lm_data_tiny.npz (oracle/gen_golden.py lmdata): fairseq's MMapIndexedDataset read token files written by
+    THIS repo's writer, its TokenBlockDataset + MonolingualDataset built the samples (`eos` / `none`), `ordered_indices` ran
+    under numpy_seed(seed) and the reference's own Cython `batch_by_size` planned the batches.  Same files through this repo's
+    reader / dataset / task: identical samples, order, batch plan and collation."""
+    from espresso_amd.data.lm_dataset import MMapTokenFile
+    from espresso_amd.tasks.language_modeling_for_asr import LanguageModelingForASRConfig, LanguageModelingForASRTask
+
+    g = np.load(os.path.join(golden_dir, "ref_lm_data_tiny.npz"))
+    d = AsrDictionary.from_symbols([f"w{i}" for i in range(30)], enable_bos=False, add_space=False)
+    assert (d.pad(), d.eos(), len(d)) == (int(g["pad"]), int(g["eos"]), int(g["V"]))
+    bounds = np.concatenate(([0], np.cumsum(g["sizes"])))
+    sents = [g["flat"][bounds[i]:bounds[i + 1]] for i in range(int(g["n_sent"]))]
+    MMapTokenFile.write(str(tmp_path / "train"), sents, dtype=np.int32)
+    for mode, tps in (("eos", 8), ("none", 7)):
+        task = LanguageModelingForASRTask.setup_task(
+            LanguageModelingForASRConfig(data=str(tmp_path), sample_break_mode=mode, tokens_per_sample=tps), dictionary=d)
+        ds = task.load_dataset("train")
+        assert len(ds) == int(g[f"{mode}::n"]) and ds.sizes.tolist() == g[f"{mode}::sizes"].tolist()
+        items = [ds[i] for i in range(len(ds))]
+        assert [len(it["source"]) for it in items] == g[f"{mode}::len"].tolist()
+        assert np.concatenate([it["source"].numpy() for it in items]).tolist() == g[f"{mode}::src"].tolist()
+        assert np.concatenate([it["target"].numpy() for it in items]).tolist() == g[f"{mode}::tgt"].tolist()
+        for seed in (1, 5):
+            with data_utils.numpy_seed(seed):
+                assert ds.ordered_indices().tolist() == g[f"{mode}::order::{seed}"].tolist()
+            plan = task.get_batches(ds, max_tokens=40, max_sentences=6, max_positions=task.max_positions(), seed=seed, epoch=1,
+                                    shuffle=False, bsz_mult=4)
+            assert [len(b) for b in plan] == g[f"{mode}::batch_sizes::{seed}"].tolist()
+            assert np.concatenate(plan).tolist() == g[f"{mode}::batches::{seed}"].tolist()
+        b = ds.collater([ds[i] for i in (0, 3, 2)])
+        assert b["net_input"]["src_tokens"].tolist() == g[f"{mode}::collate::src"].tolist()
+        assert b["target"].tolist() == g[f"{mode}::collate::tgt"].tolist()
+        assert b["net_input"]["src_lengths"].tolist() == g[f"{mode}::collate::lens"].tolist() and b["ntokens"] == int(g[f"{mode}::collate::ntokens"])
