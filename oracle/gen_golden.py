@@ -722,10 +722,37 @@ def specaug_fixture():
     print("specaug ok")
 
 
-def batch_by_size_fixture():
-    """The reference's slow python baseline (tests/test_data_utils.py:15-41 semantics) is not importable as a
-    module function; use fairseq.data.data_utils.batch_by_size with the pure-python fallback path if available."""
-    pass
+def batch_by_size_fixture(name="ref_batch_by_size"):
+    """The reference's own Cython planner (fairseq/data/data_utils_fast.pyx: batch_by_size_vec and batch_by_size_fn, reached
+    through fairseq.data.data_utils.batch_by_size :297-360; built by oracle/build_ref_cython.py) on seeded size vectors: the
+    recipe settings (26000 frames / 24 sentences / multiple 1), multiples of 8, no sentence cap, tiny budgets, samples larger
+    than max_tokens are excluded by construction (the planner asserts)."""
+    sys.path.insert(2, HERE)
+    import build_ref_cython
+
+    build_ref_cython.attach()
+    from fairseq.data import data_utils
+
+    rng = np.random.default_rng(77)
+    out, case = {}, 0
+    for n, lo, hi in ((400, 100, 3500), (257, 1, 40), (64, 5, 6), (1, 10, 11)):
+        sizes = rng.integers(lo, hi, size=n).astype(np.int64)
+        order = np.argsort(sizes, kind="mergesort")
+        for max_tokens, max_sentences, mult in ((26000, 24, 1), (26000, 24, 8), (8000, None, 8), (None, 7, 1), (4000, 3, 2), (3600, 64, 4)):
+            if max_tokens is not None and int(sizes.max()) > max_tokens:
+                continue
+            vec = data_utils.batch_by_size(order, None, num_tokens_vec=sizes[order], max_tokens=max_tokens, max_sentences=max_sentences,
+                                           required_batch_size_multiple=mult)
+            fn = data_utils.batch_by_size(order, lambda i: int(sizes[i]), num_tokens_vec=None, max_tokens=max_tokens,
+                                          max_sentences=max_sentences, required_batch_size_multiple=mult)
+            assert [b.tolist() for b in vec] == [b.tolist() for b in fn]
+            out[f"{case}::sizes"], out[f"{case}::order"] = sizes, order
+            out[f"{case}::args"] = np.array([-1 if max_tokens is None else max_tokens, -1 if max_sentences is None else max_sentences, mult])
+            out[f"{case}::flat"], out[f"{case}::lens"] = np.concatenate(vec), np.array([len(b) for b in vec])
+            case += 1
+    out["n_cases"] = np.array(case)
+    print("batch_by_size cases", case)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
 if __name__ == "__main__":
@@ -741,6 +768,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "batchbysize":
+        batch_by_size_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmdata":
         lm_data_fixture()

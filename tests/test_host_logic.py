@@ -948,3 +948,19 @@ def test_language_model_data_path_matches_the_reference_fixture(tmp_path, golden
         assert b["net_input"]["src_tokens"].tolist() == g[f"{mode}::collate::src"].tolist()
         assert b["target"].tolist() == g[f"{mode}::collate::tgt"].tolist()
         assert b["net_input"]["src_lengths"].tolist() == g[f"{mode}::collate::lens"].tolist() and b["ntokens"] == int(g[f"{mode}::collate::ntokens"])
+
+
+def test_batch_by_size_matches_the_reference_cython_planner(golden_dir):
+    """tests/golden/ref_batch_by_size.npz: 24 cases planned by the reference's own Cython `batch_by_size_vec` / `batch_by_size_fn`
+    (fairseq/data/data_utils_fast.pyx, compiled from where it lies by oracle/build_ref_cython.py) — recipe settings, batch-size
+    multiples, no sentence cap, no token cap, tiny budgets.  The host planner of this repo gives the same batches."""
+    g = np.load(os.path.join(golden_dir, "ref_batch_by_size.npz"))
+    n = int(g["n_cases"])
+    assert n >= 20
+    for c in range(n):
+        sizes, order = g[f"{c}::sizes"], g[f"{c}::order"]
+        mt, ms, mult = (int(v) for v in g[f"{c}::args"])
+        got = data_utils.batch_by_size(order, sizes[order], max_tokens=None if mt < 0 else mt, max_sentences=None if ms < 0 else ms,
+                                       bsz_mult=mult)
+        assert [len(b) for b in got] == g[f"{c}::lens"].tolist(), (c, mt, ms, mult)
+        assert np.concatenate(got).tolist() == g[f"{c}::flat"].tolist(), (c, mt, ms, mult)
