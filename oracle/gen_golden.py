@@ -755,6 +755,44 @@ def batch_by_size_fixture(name="ref_batch_by_size"):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def epoch_iterator_fixture(name="ref_epoch_batches"):
+    """Per-rank batch order of the reference's EpochBatchIterator (fairseq/data/iterators.py:262-520: frozen batches shuffled with
+    `seed + epoch`, then ShardedIterator with empty fill) for 2 epochs x 4 shards (and 1 shard), built on the reference's own
+    batch plan (ordered by length, Cython batch_by_size)."""
+    sys.path.insert(2, HERE)
+    import build_ref_cython
+
+    build_ref_cython.attach()
+    from fairseq.data import data_utils, iterators
+
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(100, 3000, size=150).astype(np.int64)
+    order = np.argsort(sizes, kind="mergesort")
+    batches = data_utils.batch_by_size(order, None, num_tokens_vec=sizes[order], max_tokens=12000, max_sentences=8, required_batch_size_multiple=1)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(sizes)
+
+        def __getitem__(self, i):
+            return int(i)
+
+        def set_epoch(self, e):
+            pass
+
+    out = {"sizes": sizes, "order": order, "args": np.array([12000, 8, 1, 3])}
+    for shards in (1, 4):
+        for shard in range(shards):
+            itr = iterators.EpochBatchIterator(DS(), collate_fn=lambda x: x, batch_sampler=batches, seed=3, num_shards=shards, shard_id=shard,
+                                               num_workers=0, epoch=1)
+            for epoch in (1, 2):
+                got = [list(b) for b in itr.next_epoch_itr(shuffle=True)]
+                out[f"{shards}::{shard}::{epoch}::flat"] = np.array([i for b in got for i in b], dtype=np.int64)
+                out[f"{shards}::{shard}::{epoch}::lens"] = np.array([len(b) for b in got])
+    print("batches", len(batches), "per shard of 4:", len(out["4::0::1::lens"]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "encdec":
@@ -768,6 +806,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "epochitr":
+        epoch_iterator_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "batchbysize":
         batch_by_size_fixture()

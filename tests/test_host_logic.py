@@ -964,3 +964,31 @@ def test_batch_by_size_matches_the_reference_cython_planner(golden_dir):
                                        bsz_mult=mult)
         assert [len(b) for b in got] == g[f"{c}::lens"].tolist(), (c, mt, ms, mult)
         assert np.concatenate(got).tolist() == g[f"{c}::flat"].tolist(), (c, mt, ms, mult)
+
+
+def test_per_rank_epoch_batches_match_the_reference_epoch_iterator(golden_dir):
+    """tests/golden/ref_epoch_batches.npz: what the reference's EpochBatchIterator hands each of 1 / 4 data-parallel ranks in
+    epochs 1 and 2 (batches shuffled with `seed + epoch`, every num_shards-th batch per rank, empty batches as fill).
+    `task.get_batches` — the plan `speech_train` iterates — gives every rank the same batches in the same order."""
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoTask
+
+    g = np.load(os.path.join(golden_dir, "ref_epoch_batches.npz"))
+    sizes = g["sizes"]
+    max_tokens, max_sentences, mult, seed = (int(v) for v in g["args"])
+
+    class DS:
+        def ordered_indices(self):
+            return np.argsort(sizes, kind="mergesort")
+
+        def num_tokens_vec(self, indices):
+            return sizes[indices]
+
+    for shards in (1, 4):
+        for shard in range(shards):
+            for epoch in (1, 2):
+                plan = SpeechRecognitionEspressoTask.get_batches(None, DS(), max_tokens=max_tokens, max_sentences=max_sentences, seed=seed,
+                                                                 epoch=epoch, num_shards=shards, shard_id=shard, shuffle=True, bsz_mult=mult)
+                assert [len(b) for b in plan] == g[f"{shards}::{shard}::{epoch}::lens"].tolist(), (shards, shard, epoch)
+                flat = [int(i) for b in plan for i in b]
+                assert flat == g[f"{shards}::{shard}::{epoch}::flat"].tolist(), (shards, shard, epoch)
+    assert 0 in g["4::3::1::lens"].tolist()  # 26 batches over 4 ranks: the short ranks end with an empty fill batch
