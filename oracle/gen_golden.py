@@ -755,6 +755,70 @@ def batch_by_size_fixture(name="ref_batch_by_size"):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def checkpoint_rules_fixture(name="ref_checkpoint_rules"):
+    """Directory listings after each call of the reference's `checkpoint_utils.save_checkpoint` (fairseq/checkpoint_utils.py:34-172)
+    over a scripted run: mid-epoch saves every 2 updates, epoch ends, validation scores that improve / worsen / tie, with
+    keep_interval_updates=2, keep_last_epochs=2, keep_best_checkpoints=2 (minimising `wer`), then a maximising metric."""
+    import json
+    import tempfile
+
+    from fairseq import checkpoint_utils
+    from fairseq.dataclass.configs import CheckpointConfig
+
+    class Itr:
+        def __init__(self):
+            self.epoch, self._end = 1, False
+
+        def end_of_epoch(self):
+            return self._end
+
+        def state_dict(self):
+            return {"epoch": self.epoch}
+
+    class Tr:
+        data_parallel_rank = 0
+        should_save_checkpoint_on_current_rank = True
+        always_call_state_dict_during_save_checkpoint = False
+        checkpoint_suffix = ""
+
+        def __init__(self):
+            self.n = 0
+
+        def get_num_updates(self):
+            return self.n
+
+        def consolidate_optimizer(self):
+            pass
+
+        def save_checkpoint(self, filename, extra_state):
+            with open(filename, "w") as f:
+                f.write("x")
+
+    script = [  # (epoch, end_of_epoch, num_updates, val_loss)
+        (1, False, 2, 30.0), (1, False, 4, 35.0), (1, True, 5, 28.0), (2, False, 6, 28.0), (2, False, 8, 27.5), (2, True, 10, None),
+        (3, False, 12, 40.0), (3, True, 15, 26.123), (4, True, 20, 26.5), (5, False, 22, 25.0), (5, True, 25, 25.0)]
+    out = {}
+    for tag, maximize in (("min", False), ("max", True)):
+        tmp = tempfile.mkdtemp(dir=os.path.join(HERE, "_ref"))
+        cfg = CheckpointConfig()
+        cfg.save_dir, cfg.save_interval_updates, cfg.keep_interval_updates, cfg.keep_last_epochs = tmp, 2, 2, 2
+        cfg.keep_best_checkpoints, cfg.best_checkpoint_metric, cfg.maximize_best_checkpoint_metric = 2, "wer", maximize
+        if hasattr(checkpoint_utils.save_checkpoint, "best"):
+            del checkpoint_utils.save_checkpoint.best
+        tr, itr, listings = Tr(), Itr(), []
+        for epoch, end, n, val in script:
+            itr.epoch, itr._end, tr.n = epoch, end, n
+            checkpoint_utils.save_checkpoint(cfg, tr, itr, val)
+            listings.append(sorted(os.listdir(tmp)))
+        out[tag] = {"listings": listings, "best": checkpoint_utils.save_checkpoint.best}
+        import shutil
+        shutil.rmtree(tmp)
+    out["script"] = script
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(out["min"]["listings"][-1], out["min"]["best"], out["max"]["best"])
+
+
 def epoch_iterator_fixture(name="ref_epoch_batches"):
     """Per-rank batch order of the reference's EpochBatchIterator (fairseq/data/iterators.py:262-520: frozen batches shuffled with
     `seed + epoch`, then ShardedIterator with empty fill) for 2 epochs x 4 shards (and 1 shard), built on the reference's own
@@ -806,6 +870,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ckptrules":
+        checkpoint_rules_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epochitr":
         epoch_iterator_fixture()

@@ -992,3 +992,25 @@ def test_per_rank_epoch_batches_match_the_reference_epoch_iterator(golden_dir):
                 flat = [int(i) for b in plan for i in b]
                 assert flat == g[f"{shards}::{shard}::{epoch}::flat"].tolist(), (shards, shard, epoch)
     assert 0 in g["4::3::1::lens"].tolist()  # 26 batches over 4 ranks: the short ranks end with an empty fill batch
+
+
+def test_checkpoint_rules_match_the_reference_listing_by_listing(tmp_path, golden_dir):
+    """tests/golden/ref_checkpoint_rules.json: directory listings after each call of the reference's own
+    `checkpoint_utils.save_checkpoint` over a scripted run (mid-epoch saves, epoch ends, improving / worsening / tied scores,
+    keep_interval_updates / keep_last_epochs / keep_best_checkpoints, minimising and maximising).  CheckpointSaver leaves the
+    same files after every call, including the tie-breaking digit of the `checkpoint.best_*` names."""
+    import json
+
+    from espresso_amd.checkpoint_utils import CheckpointSaver
+    from espresso_amd.config import DEFAULTS
+
+    g = json.load(open(os.path.join(golden_dir, "ref_checkpoint_rules.json")))
+    for tag, maximize in (("min", False), ("max", True)):
+        cfg = dict(DEFAULTS["checkpoint"], save_dir=str(tmp_path / tag), save_interval_updates=2, keep_interval_updates=2, keep_last_epochs=2,
+                   keep_best_checkpoints=2, best_checkpoint_metric="wer", maximize_best_checkpoint_metric=maximize)
+        saver, tr = CheckpointSaver(cfg), _FakeTrainer()
+        for (epoch, end, n, val), want in zip(g["script"], g[tag]["listings"]):
+            tr.num_updates = n
+            saver.save(tr, epoch, end, {"epoch": epoch}, val)
+            assert sorted(os.listdir(cfg["save_dir"])) == want, (tag, epoch, end, n, val)
+        assert saver.best == g[tag]["best"]
