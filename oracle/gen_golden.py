@@ -819,6 +819,76 @@ def checkpoint_rules_fixture(name="ref_checkpoint_rules"):
     print(out["min"]["listings"][-1], out["min"]["best"], out["max"]["best"])
 
 
+def lr_schedule_fixture(name="ref_lr_schedules"):
+    """Learning-rate trajectories of the reference's own scheduler classes with the recipes' settings: `noam`
+    (espresso/optim/lr_scheduler/noam_lr_scheduler.py), `tri_stage` (fairseq), `polynomial_decay_v2` (espresso),
+    `reduce_lr_on_plateau_v2` (espresso over fairseq + torch's ReduceLROnPlateau) and fairseq's `reduce_lr_on_plateau`, driven by
+    scripted update counts and validation scores."""
+    import json
+    from types import SimpleNamespace as NS
+
+    from espresso.optim.lr_scheduler.noam_lr_scheduler import NoamLRScheduler as NoamSchedule
+    from espresso.optim.lr_scheduler.polynomial_decay_schedule import PolynomialDecayV2LRSchedule as PolynomialDecayLRScheduleV2
+    from espresso.optim.lr_scheduler.reduce_lr_on_plateau_v2 import ReduceLROnPlateauLRScheduleV2
+    from fairseq.optim.lr_scheduler.reduce_lr_on_plateau import ReduceLROnPlateauLRSchedule
+    from fairseq.optim.lr_scheduler.tri_stage_lr_scheduler import TriStageLRSchedule
+
+    from fairseq.optim import FairseqOptimizer
+
+    class Opt(FairseqOptimizer):  # a real FairseqOptimizer over one dummy parameter (the schedulers insist on the type)
+        def __init__(self):
+            super().__init__(None)
+            self._optimizer = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+
+    updates = [0, 1, 2, 10, 100, 999, 1000, 1001, 5000, 24999, 25000, 25001, 60000, 180000, 181000, 400000, 541000, 600000]
+    out = {"updates": updates}
+    cases = {
+        "noam": (NoamSchedule, NS(lr=[5.0], warmup_steps=25000, model_size=512, final_lr=1e-6)),
+        "noam_small": (NoamSchedule, NS(lr=[2.0], warmup_steps=10, model_size=128, final_lr=5e-3)),
+        "tri_stage": (TriStageLRSchedule, NS(lr=[0.001], warmup_steps=1000, hold_steps=180000, decay_steps=360000, phase_ratio=None,
+                                             init_lr_scale=0.01, final_lr_scale=0.05, max_update=0)),
+        "tri_stage_ratio": (TriStageLRSchedule, NS(lr=[0.002], warmup_steps=0, hold_steps=0, decay_steps=0, phase_ratio=(0.1, 0.4, 0.5),
+                                                   init_lr_scale=0.01, final_lr_scale=0.01, max_update=100000)),
+        "polynomial_decay_v2": (PolynomialDecayLRScheduleV2, NS(lr=[0.003], warmup_updates=1000, force_anneal=None, end_learning_rate=1e-5,
+                                                                power=2.0, total_num_update=400000)),
+    }
+    for tag, (cls, cfg) in cases.items():
+        opt = Opt()
+        sch = cls(cfg, opt)
+        traj = []
+        for n in updates:
+            sch.step_update(n)
+            traj.append(opt.get_lr())
+        out[tag] = {"cfg": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()}, "lr": traj}
+    scores = [10.0, 9.0, 9.5, 9.4, 8.0, 8.0, 8.1, 7.0, 7.5, 7.6, 7.7, 6.0]
+    plate = {
+        "reduce_lr_on_plateau_v2": (ReduceLROnPlateauLRScheduleV2, NS(lr=[0.001], lr_shrink=0.5, lr_threshold=1e-4, lr_patience=0, warmup_updates=900,
+                                                                      warmup_init_lr=1e-5, start_reduce_lr_epoch=4, final_lr_scale=0.1,
+                                                                      maximize_best_checkpoint_metric=False)),
+        "reduce_lr_on_plateau": (ReduceLROnPlateauLRSchedule, NS(lr=[0.001], lr_shrink=0.5, lr_threshold=1e-4, lr_patience=0, warmup_updates=0,
+                                                                 warmup_init_lr=-1, maximize_best_checkpoint_metric=False)),
+        "reduce_lr_on_plateau_v2_max": (ReduceLROnPlateauLRScheduleV2, NS(lr=[0.002], lr_shrink=0.3, lr_threshold=1e-4, lr_patience=1, warmup_updates=0,
+                                                                          warmup_init_lr=-1, start_reduce_lr_epoch=0, final_lr_scale=0.01,
+                                                                          maximize_best_checkpoint_metric=True)),
+    }
+    for tag, (cls, cfg) in plate.items():
+        opt = Opt()
+        sch = cls(cfg, opt)
+        warm = []
+        for n in (0, 1, 450, 899, 900, 901, 2000):
+            sch.step_update(n)
+            warm.append(opt.get_lr())
+        epochs = []
+        for e, v in enumerate(scores, start=1):
+            sch.step(e, -v if cfg.maximize_best_checkpoint_metric else v)
+            sch.step_update(2000 + e)
+            epochs.append(opt.get_lr())
+        out[tag] = {"cfg": vars(cfg), "warm_updates": [0, 1, 450, 899, 900, 901, 2000], "warm_lr": warm, "scores": scores, "epoch_lr": epochs}
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print({k: (v["lr"][-3:] if "lr" in v else v["epoch_lr"][-3:]) for k, v in out.items() if isinstance(v, dict)})
+
+
 def epoch_iterator_fixture(name="ref_epoch_batches"):
     """Per-rank batch order of the reference's EpochBatchIterator (fairseq/data/iterators.py:262-520: frozen batches shuffled with
     `seed + epoch`, then ShardedIterator with empty fill) for 2 epochs x 4 shards (and 1 shard), built on the reference's own
@@ -870,6 +940,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lrsched":
+        lr_schedule_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ckptrules":
         checkpoint_rules_fixture()

@@ -1014,3 +1014,53 @@ def test_checkpoint_rules_match_the_reference_listing_by_listing(tmp_path, golde
             saver.save(tr, epoch, end, {"epoch": epoch}, val)
             assert sorted(os.listdir(cfg["save_dir"])) == want, (tag, epoch, end, n, val)
         assert saver.best == g[tag]["best"]
+
+
+def test_lr_schedules_match_the_reference_trajectories(golden_dir):
+    """tests/golden/ref_lr_schedules.json: learning rates the reference's own scheduler classes produced (noam, tri_stage with
+    steps and with phase ratios, polynomial_decay_v2, reduce_lr_on_plateau_v2 with warm-up / start epoch / floor, fairseq's
+    reduce_lr_on_plateau, a maximising plateau schedule) over scripted update counts and validation scores."""
+    import json
+
+    from espresso_amd.optim import lr_schedulers  # noqa: F401
+
+    class Opt:
+        lr = 1.0
+
+        def set_lr(self, lr):
+            self.lr = lr
+
+        def get_lr(self):
+            return self.lr
+
+    g = json.load(open(os.path.join(golden_dir, "ref_lr_schedules.json")))
+    for tag in ("noam", "noam_small", "tri_stage", "tri_stage_ratio", "polynomial_decay_v2"):
+        cfg = dict(g[tag]["cfg"])
+        lr0 = cfg.pop("lr")[0]
+        cfg.pop("force_anneal", None)
+        if cfg.get("phase_ratio") is None:
+            cfg.pop("phase_ratio", None)
+        name = {"noam_small": "noam", "tri_stage_ratio": "tri_stage"}.get(tag, tag)
+        opt = Opt()
+        sch = registry.LR_SCHEDULER_REGISTRY[name](opt, lr=lr0, **cfg)
+        got = []
+        for n in g["updates"]:
+            sch.step_update(n)
+            got.append(opt.get_lr())
+        assert got == pytest.approx(g[tag]["lr"], rel=1e-9, abs=1e-15), tag
+    for tag in ("reduce_lr_on_plateau_v2", "reduce_lr_on_plateau", "reduce_lr_on_plateau_v2_max"):
+        cfg = dict(g[tag]["cfg"])
+        lr0 = cfg.pop("lr")[0]
+        opt = Opt()
+        sch = registry.LR_SCHEDULER_REGISTRY["reduce_lr_on_plateau" if tag == "reduce_lr_on_plateau" else "reduce_lr_on_plateau_v2"](opt, lr=lr0, **cfg)
+        warm = []
+        for n in g[tag]["warm_updates"]:
+            sch.step_update(n)
+            warm.append(opt.get_lr())
+        assert warm == pytest.approx(g[tag]["warm_lr"], rel=1e-9), tag
+        epochs = []
+        for e, v in enumerate(g[tag]["scores"], start=1):
+            sch.step(e, -v if cfg["maximize_best_checkpoint_metric"] else v)
+            sch.step_update(2000 + e)
+            epochs.append(opt.get_lr())
+        assert epochs == pytest.approx(g[tag]["epoch_lr"], rel=1e-9), (tag, epochs, g[tag]["epoch_lr"])
