@@ -83,7 +83,8 @@ def recognize(task, model, generator, batches: Iterable[dict], dictionary, refs:
     print("Recognized {:,} utterances ({} tokens) in {:.1f}s ({:.2f} sentences/s, {:.2f} tokens/s), RTF {:.4f}".format(
         num_sent, num_tok, t_gen, num_sent / max(t_gen, 1e-9), num_tok / max(t_gen, 1e-9), t_gen / max(audio_s, 1e-9)), file=out)
     if refs:
-        print("WER {:.2f}%, CER {:.2f}%".format(scorer.wer(), scorer.cer()), file=out)
+        for line in scorer.summary_lines():
+            print(line, file=out)
     return scorer, {"sentences": num_sent, "tokens": num_tok, "seconds": t_gen, "rtf": t_gen / max(audio_s, 1e-9)}
 
 

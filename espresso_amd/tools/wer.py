@@ -62,15 +62,18 @@ class Scorer(object):
         self.word_counter += counter
 
     @staticmethod
-    def _rate(c):
+    def _rates(c):
+        """(error rate, substitution, insertion, deletion rates) in percent — the 4-tuple of espresso/tools/wer.py:117-149."""
         assert c["words"] > 0
-        return float(c["sub"] + c["ins"] + c["del"]) / c["words"] * 100
+        n = c["words"]
+        return (float(c["sub"] + c["ins"] + c["del"]) / n * 100, float(c["sub"]) / n * 100, float(c["ins"]) / n * 100,
+                float(c["del"]) / n * 100)
 
     def cer(self):
-        return self._rate(self.char_counter)
+        return self._rates(self.char_counter)
 
     def wer(self):
-        return self._rate(self.word_counter)
+        return self._rates(self.word_counter)
 
     def tot_word_error(self):
         c = self.word_counter
@@ -86,7 +89,12 @@ class Scorer(object):
     def tot_char_count(self):
         return self.char_counter["words"]
 
+    def summary_lines(self):
+        """The two result lines of espresso/speech_recognize.py:360-377."""
+        return ["WER={:.2f}%, Sub={:.2f}%, Ins={:.2f}%, Del={:.2f}%, #words={:d}".format(*self.wer(), self.tot_word_count()),
+                "CER={:.2f}%, Sub={:.2f}%, Ins={:.2f}%, Del={:.2f}%, #chars={:d}".format(*self.cer(), self.tot_char_count())]
+
     def print_stats(self):
         c, w = self.char_counter, self.word_counter
         return ("CER: {:.2f}%, WER: {:.2f}% ({} words: sub {} ins {} del {})".format(
-            self.cer(), self.wer(), w["words"], w["sub"], w["ins"], w["del"]))
+            self.cer()[0], self.wer()[0], w["words"], w["sub"], w["ins"], w["del"]))

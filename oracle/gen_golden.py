@@ -889,6 +889,49 @@ def lr_schedule_fixture(name="ref_lr_schedules"):
     print({k: (v["lr"][-3:] if "lr" in v else v["epoch_lr"][-3:]) for k, v in out.items() if isinstance(v, dict)})
 
 
+def wer_scorer_fixture(name="ref_wer_scorer"):
+    """The reference's Scorer (espresso/tools/wer.py:16-140) on scripted (reference, hypothesis) token strings in character units
+    with <space> word boundaries, non-language symbols and a WER output filter: totals, WER / CER after every utterance."""
+    import json
+    import tempfile
+
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.tools.wer import Scorer
+
+    tmp = tempfile.mkdtemp(dir=os.path.join(HERE, "_ref"))
+    with open(os.path.join(tmp, "dict.txt"), "w") as f:
+        f.write("".join(f"{c} 1\n" for c in "abcdefghijklmnopqrstuvwxyz'") + "<space> 1\n<noise> 1\n<laugh> 1\n")
+    with open(os.path.join(tmp, "nlsyms.txt"), "w") as f:
+        f.write("<noise>\n<laugh>\n")
+    with open(os.path.join(tmp, "filter"), "w") as f:
+        f.write("#!/bin/sed -f\ns/uh //g\ns: um::g\n")
+    pairs = [
+        ("u1", "t h e <space> c a t <space> s a t", "t h e <space> c a t <space> s a t"),
+        ("u2", "a <space> b i g <space> d o g", "a <space> b a g <space> d o g s"),
+        ("u3", "<noise> h e l l o <space> w o r l d", "h e l o <space> <laugh> w o r l d"),
+        ("u4", "u h <space> y e s <space> u m", "y e s"),
+        ("u5", "o n e <space> t w o <space> t h r e e", "o n e <space> t h r e e <space> f o u r <space> f i v e"),
+        ("u6", "x", ""),
+    ]
+    out = {"pairs": pairs}
+    for tag, filt in (("plain", None), ("filtered", os.path.join(tmp, "filter"))):
+        import argparse
+        dic = AsrDictionary.load(os.path.join(tmp, "dict.txt"), f_non_lang_syms=os.path.join(tmp, "nlsyms.txt"))
+        dic.build_bpe(argparse.Namespace(bpe="characters_asr"))  # character units: words are the <space>-separated groups
+        sc = Scorer(dic, wer_output_filter=filt)
+        steps = []
+        for utt, ref, hyp in pairs:
+            sc.add_evaluation(utt, ref, hyp)
+            steps.append({"wer": list(sc.wer()), "cer": list(sc.cer()), "word_error": sc.tot_word_error(), "word_count": sc.tot_word_count(),
+                          "char_error": sc.tot_char_error(), "char_count": sc.tot_char_count()})
+        out[tag] = steps
+    import shutil
+    shutil.rmtree(tmp)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(out["plain"][-1], out["filtered"][-1])
+
+
 def epoch_iterator_fixture(name="ref_epoch_batches"):
     """Per-rank batch order of the reference's EpochBatchIterator (fairseq/data/iterators.py:262-520: frozen batches shuffled with
     `seed + epoch`, then ShardedIterator with empty fill) for 2 epochs x 4 shards (and 1 shard), built on the reference's own
@@ -940,6 +983,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wer":
+        wer_scorer_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lrsched":
         lr_schedule_fixture()

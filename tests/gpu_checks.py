@@ -1129,7 +1129,7 @@ def check_speech_recognize_loop():
     text = buf.getvalue()
     return {"n_batches": len(batches), "H_lines": text.count("\nH-") + text.startswith("H-"), "T_lines": text.count("T-utt"),
             "summary": "Recognized 5 utterances" in text, "wer_reported": "WER" in text, "sentences": stats["sentences"],
-            "wer_finite": bool(np.isfinite(scorer.wer()))}
+            "wer_finite": bool(np.isfinite(scorer.wer()[0]))}
 
 
 def check_scheduled_sampling():

@@ -178,9 +178,10 @@ def test_wer_scorer_counts():
     s.add_evaluation("u1", "a b <space> c d", "a b <space> c e <space> f")
     assert s.char_counter == Counter({"words": 5, "corr": 4, "sub": 1, "ins": 2, "del": 0})
     assert s.word_counter == Counter({"words": 2, "corr": 1, "sub": 1, "ins": 1, "del": 0})
-    assert s.wer() == 100.0 and s.cer() == 60.0
+    assert s.wer() == (100.0, 50.0, 50.0, 0.0) and s.cer() == (60.0, 20.0, 40.0, 0.0)  # (rate, sub, ins, del) like the reference
     s.add_evaluation("u2", "g h", "g h")
-    assert s.tot_word_count() == 3 and s.wer() == pytest.approx(200.0 / 3)
+    assert s.tot_word_count() == 3 and s.wer()[0] == pytest.approx(200.0 / 3)
+    assert s.summary_lines()[0].startswith("WER=66.67%, Sub=33.33%, Ins=33.33%, Del=0.00%, #words=3")
 
 
 def test_tensorized_prefix_tree_matches_reference(golden_dir):
@@ -1064,3 +1065,27 @@ def test_lr_schedules_match_the_reference_trajectories(golden_dir):
             sch.step_update(2000 + e)
             epochs.append(opt.get_lr())
         assert epochs == pytest.approx(g[tag]["epoch_lr"], rel=1e-9), (tag, epochs, g[tag]["epoch_lr"])
+
+
+def test_wer_scorer_matches_the_reference_scorer(tmp_path, golden_dir):
+    """tests/golden/ref_wer_scorer.json: the reference's Scorer (espresso/tools/wer.py) on scripted character-unit utterances with
+    <space> word boundaries, non-language symbols (dropped before scoring) and a sed-style WER output filter: the 4-tuples of
+    wer() / cer() and the running totals after every utterance."""
+    import json
+
+    from espresso_amd.tools.wer import Scorer
+
+    g = json.load(open(os.path.join(golden_dir, "ref_wer_scorer.json")))
+    (tmp_path / "dict.txt").write_text("".join(f"{c} 1\n" for c in "abcdefghijklmnopqrstuvwxyz'") + "<space> 1\n<noise> 1\n<laugh> 1\n")
+    (tmp_path / "nlsyms.txt").write_text("<noise>\n<laugh>\n")
+    (tmp_path / "filter").write_text("#!/bin/sed -f\ns/uh //g\ns: um::g\n")
+    for tag, filt in (("plain", None), ("filtered", str(tmp_path / "filter"))):
+        d = AsrDictionary.load(str(tmp_path / "dict.txt"), f_non_lang_syms=str(tmp_path / "nlsyms.txt"))
+        d.build_bpe("characters_asr")
+        sc = Scorer(d, wer_output_filter=filt)
+        for (utt, ref, hyp), want in zip(g["pairs"], g[tag]):
+            sc.add_evaluation(utt, ref, hyp)
+            assert list(sc.wer()) == pytest.approx(want["wer"]) and list(sc.cer()) == pytest.approx(want["cer"]), (tag, utt)
+            assert (sc.tot_word_error(), sc.tot_word_count(), sc.tot_char_error(), sc.tot_char_count()) == (
+                want["word_error"], want["word_count"], want["char_error"], want["char_count"]), (tag, utt)
+    assert g["plain"][-1]["word_count"] != g["filtered"][-1]["word_count"]  # the filter removed words
