@@ -14,7 +14,7 @@ class AsrDictionary:
         self.count: List[int] = []
         self.indices = {}
         if enable_bos:
-            self.bos_index = self.add_symbol(bos, n=0)
+            self.bos_index = self.add_symbol(bos)  # count 1, as the reference's add_symbol default (asr_dictionary.py:43)
         self.pad_index = self.add_symbol(pad, n=0)
         self.eos_index = self.add_symbol(eos, n=0)
         self.unk_index = self.add_symbol(unk, n=0)

@@ -106,3 +106,11 @@ def edit_distance(ref, hyp):
     counter = Counter({"words": R, "corr": 0, "sub": 0, "ins": 0, "del": 0})
     counter.update(steps)
     return dist, steps, counter
+
+
+def tokenize(sent, space="<space>", non_lang_syms=None):
+    """espresso/tools/utils.py:29-56 lives here in the reference; the implementation sits next to its main user
+    (tools/tensorized_prefix_tree.py) and is re-exported under the reference's location."""
+    from .tensorized_prefix_tree import tokenize as _tokenize
+
+    return _tokenize(sent, space=space, non_lang_syms=non_lang_syms)

@@ -932,6 +932,43 @@ def wer_scorer_fixture(name="ref_wer_scorer"):
     print(out["plain"][-1], out["filtered"][-1])
 
 
+def dictionary_fixture(name="ref_asr_dictionary"):
+    """The reference's AsrDictionary (espresso/data/asr_dictionary.py) + `characters_asr` encoder + `tokenize`
+    (espresso/tools/utils.py) on scripted sentences: symbol layout with and without <s>, text -> pieces -> ids -> string ->
+    text, unknown characters, non-language symbols kept whole."""
+    import argparse
+    import json
+    import tempfile
+
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.tools.utils import tokenize
+
+    tmp = tempfile.mkdtemp(dir=os.path.join(HERE, "_ref"))
+    with open(os.path.join(tmp, "dict.txt"), "w") as f:
+        f.write("".join(f"{c} {i + 3}\n" for i, c in enumerate("abcdefghijklmnopqrstuvwxyz'")) + "<space> 9\n<noise> 2\n<laugh> 1\n")
+    with open(os.path.join(tmp, "nlsyms.txt"), "w") as f:
+        f.write("<noise>\n<laugh>\n")
+    texts = ["hello world", "it's <noise> a dog", "  two  spaces ", "caf3 ok", "<laugh>", "", "a"]
+    out = {"texts": texts}
+    for tag, bos in (("bos", True), ("nobos", False)):
+        d = AsrDictionary.load(os.path.join(tmp, "dict.txt"), enable_bos=bos, f_non_lang_syms=os.path.join(tmp, "nlsyms.txt"))
+        d.build_bpe(argparse.Namespace(bpe="characters_asr"))
+        rows = []
+        for t in texts:
+            pieces = d.wordpiece_encode(t)
+            ids = d.encode_line(pieces, add_if_not_exist=False, append_eos=True).tolist()
+            s_ = d.string(torch.tensor(ids))
+            rows.append({"pieces": pieces, "ids": ids, "string": s_, "decoded": d.wordpiece_decode(s_),
+                         "tokenize": tokenize(t, space=d.space_word, non_lang_syms=d.non_lang_syms)})
+        out[tag] = {"len": len(d), "pad": d.pad(), "eos": d.eos(), "unk": d.unk(), "bos": d.bos() if bos else None, "space": d.space(),
+                    "symbols": d.symbols, "count": list(d.count), "rows": rows}
+    import shutil
+    shutil.rmtree(tmp)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(out["bos"]["symbols"][:6], out["nobos"]["symbols"][:5], out["bos"]["rows"][1])
+
+
 def epoch_iterator_fixture(name="ref_epoch_batches"):
     """Per-rank batch order of the reference's EpochBatchIterator (fairseq/data/iterators.py:262-520: frozen batches shuffled with
     `seed + epoch`, then ShardedIterator with empty fill) for 2 epochs x 4 shards (and 1 shard), built on the reference's own
@@ -983,6 +1020,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dictionary":
+        dictionary_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wer":
         wer_scorer_fixture()

@@ -1089,3 +1089,32 @@ def test_wer_scorer_matches_the_reference_scorer(tmp_path, golden_dir):
             assert (sc.tot_word_error(), sc.tot_word_count(), sc.tot_char_error(), sc.tot_char_count()) == (
                 want["word_error"], want["word_count"], want["char_error"], want["char_count"]), (tag, utt)
     assert g["plain"][-1]["word_count"] != g["filtered"][-1]["word_count"]  # the filter removed words
+
+
+def test_asr_dictionary_matches_the_reference_dictionary(tmp_path, golden_dir):
+    """tests/golden/ref_asr_dictionary.json: the reference's AsrDictionary + `characters_asr` encoder + `tokenize` on scripted
+    sentences (apostrophes, non-language symbols, repeated / leading spaces, out-of-vocabulary characters, empty text): symbol
+    layout with and without `<s>`, counts, text -> pieces -> ids -> string -> text."""
+    import json
+
+    from espresso_amd.tools.utils import tokenize
+
+    g = json.load(open(os.path.join(golden_dir, "ref_asr_dictionary.json")))
+    (tmp_path / "dict.txt").write_text("".join(f"{c} {i + 3}\n" for i, c in enumerate("abcdefghijklmnopqrstuvwxyz'")) + "<space> 9\n<noise> 2\n<laugh> 1\n")
+    (tmp_path / "nlsyms.txt").write_text("<noise>\n<laugh>\n")
+    for tag, bos in (("bos", True), ("nobos", False)):
+        want = g[tag]
+        d = AsrDictionary.load(str(tmp_path / "dict.txt"), enable_bos=bos, f_non_lang_syms=str(tmp_path / "nlsyms.txt"))
+        d.build_bpe("characters_asr")
+        assert (len(d), d.pad(), d.eos(), d.unk(), d.space()) == (want["len"], want["pad"], want["eos"], want["unk"], want["space"])
+        assert list(d.symbols) == want["symbols"] and [int(c) for c in d.count] == want["count"]
+        if bos:
+            assert d.bos() == want["bos"]
+        for text, row in zip(g["texts"], want["rows"]):
+            pieces = d.wordpiece_encode(text)
+            assert pieces == row["pieces"], (tag, text)
+            ids = d.encode_line(pieces, append_eos=True).tolist()
+            assert ids == row["ids"], (tag, text)
+            s = d.string(torch.tensor(ids))
+            assert s == row["string"] and d.wordpiece_decode(s) == row["decoded"], (tag, text)
+            assert tokenize(text, space=d.space_word, non_lang_syms=d.non_lang_syms) == row["tokenize"], (tag, text)
