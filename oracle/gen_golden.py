@@ -969,6 +969,38 @@ def dictionary_fixture(name="ref_asr_dictionary"):
     print(out["bos"]["symbols"][:6], out["nobos"]["symbols"][:5], out["bos"]["rows"][1])
 
 
+def collate_fixture(name="ref_asr_collate"):
+    """The reference's `collate` (espresso/data/asr_dataset.py:17-136) on scripted feature samples: length sort, frame / token
+    padding, input feeding with </s> moved to the front or <s> prepended, pad_to_multiple, samples without targets."""
+    from espresso.data.asr_dataset import collate
+
+    rng = np.random.default_rng(9)
+    pad, eos, bos = 1, 2, 0
+    lens, tl = [7, 12, 5, 12, 9], [3, 5, 2, 4, 6]
+    samples = []
+    for i, (n, m) in enumerate(zip(lens, tl)):
+        tgt = np.concatenate((rng.integers(4, 30, size=m), [eos]))
+        samples.append({"id": i, "utt_id": f"utt{i}", "source": torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32)),
+                        "target": torch.from_numpy(tgt), "text": f"text {i}"})
+    out = {"n": np.array(len(samples)), "pad": np.array(pad), "eos": np.array(eos), "bos": np.array(bos)}
+    for i, smp in enumerate(samples):
+        out[f"in::{i}::source"], out[f"in::{i}::target"] = smp["source"].numpy(), smp["target"].numpy()
+    cases = {"feed_eos": dict(input_feeding=True), "feed_bos": dict(input_feeding=True, maybe_bos_idx=bos),
+             "no_feed": dict(input_feeding=False), "mult4": dict(input_feeding=True, pad_to_multiple=4)}
+    for tag, kw in cases.items():
+        b = collate(samples, pad_idx=pad, eos_idx=eos, left_pad_source=False, left_pad_target=False, **kw)
+        out[f"{tag}::id"], out[f"{tag}::src"], out[f"{tag}::src_lengths"] = b["id"].numpy(), b["net_input"]["src_tokens"].numpy(), b["net_input"]["src_lengths"].numpy()
+        out[f"{tag}::target"], out[f"{tag}::ntokens"] = b["target"].numpy(), np.array(b["ntokens"])
+        out[f"{tag}::utt_id"] = np.array(b["utt_id"])
+        if "prev_output_tokens" in b["net_input"]:
+            out[f"{tag}::prev"] = b["net_input"]["prev_output_tokens"].numpy()
+    nt = [{k: v for k, v in smp.items() if k not in ("target", "text")} for smp in samples]
+    b = collate(nt, pad_idx=pad, eos_idx=eos)
+    out["notgt::id"], out["notgt::src_lengths"], out["notgt::keys"] = b["id"].numpy(), b["net_input"]["src_lengths"].numpy(), np.array(sorted(b.keys()))
+    print({k: v.shape for k, v in out.items() if k.endswith("::src")}, out["feed_eos::id"], out["notgt::keys"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def epoch_iterator_fixture(name="ref_epoch_batches"):
     """Per-rank batch order of the reference's EpochBatchIterator (fairseq/data/iterators.py:262-520: frozen batches shuffled with
     `seed + epoch`, then ShardedIterator with empty fill) for 2 epochs x 4 shards (and 1 shard), built on the reference's own
@@ -1020,6 +1052,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lmfusion":
         lm_fusion_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+        collate_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dictionary":
         dictionary_fixture()

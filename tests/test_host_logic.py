@@ -1118,3 +1118,31 @@ def test_asr_dictionary_matches_the_reference_dictionary(tmp_path, golden_dir):
             s = d.string(torch.tensor(ids))
             assert s == row["string"] and d.wordpiece_decode(s) == row["decoded"], (tag, text)
             assert tokenize(text, space=d.space_word, non_lang_syms=d.non_lang_syms) == row["tokenize"], (tag, text)
+
+
+def test_asr_collate_matches_the_reference_collate(golden_dir):
+    """tests/golden/ref_asr_collate.npz: the reference's `collate` on scripted feature samples — descending-length sort (ties in
+    input order), zero frame padding, token padding, input feeding with </s> moved to the front or <s> prepended,
+    pad_to_multiple, and samples without targets."""
+    from espresso_amd.data.asr_dataset import collate
+
+    g = np.load(os.path.join(golden_dir, "ref_asr_collate.npz"))
+    pad, eos, bos = int(g["pad"]), int(g["eos"]), int(g["bos"])
+    samples = [{"id": i, "utt_id": f"utt{i}", "source": torch.from_numpy(g[f"in::{i}::source"]), "target": torch.from_numpy(g[f"in::{i}::target"]),
+                "text": f"text {i}"} for i in range(int(g["n"]))]
+    cases = {"feed_eos": dict(input_feeding=True), "feed_bos": dict(input_feeding=True, maybe_bos_idx=bos),
+             "no_feed": dict(input_feeding=False), "mult4": dict(input_feeding=True, pad_to_multiple=4)}
+    for tag, kw in cases.items():
+        b = collate(samples, pad_idx=pad, eos_idx=eos, left_pad_source=False, left_pad_target=False, **kw)
+        assert b["id"].tolist() == g[f"{tag}::id"].tolist() and list(b["utt_id"]) == g[f"{tag}::utt_id"].tolist(), tag
+        assert torch.equal(b["net_input"]["src_tokens"], torch.from_numpy(g[f"{tag}::src"])), tag
+        assert b["net_input"]["src_lengths"].tolist() == g[f"{tag}::src_lengths"].tolist(), tag
+        assert b["target"].tolist() == g[f"{tag}::target"].tolist() and b["ntokens"] == int(g[f"{tag}::ntokens"]), tag
+        if f"{tag}::prev" in g.files:
+            assert b["net_input"]["prev_output_tokens"].tolist() == g[f"{tag}::prev"].tolist(), tag
+        else:
+            assert "prev_output_tokens" not in b["net_input"], tag
+    nt = [{k: v for k, v in s.items() if k not in ("target", "text")} for s in samples]
+    b = collate(nt, pad_idx=pad, eos_idx=eos)
+    assert b["id"].tolist() == g["notgt::id"].tolist() and b["net_input"]["src_lengths"].tolist() == g["notgt::src_lengths"].tolist()
+    assert sorted(b.keys()) == g["notgt::keys"].tolist() and b["target"] is None
