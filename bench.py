@@ -39,7 +39,8 @@ def build(device, seed=1):
     d = AsrDictionary.from_symbols([f"u{i}" for i in range(VOCAB - 5)], enable_bos=True)
     assert len(d) == VOCAB
     tcfg = SpeechRecognitionEspressoConfig(
-        specaugment_config="{'freq_mask_N': 2, 'freq_mask_F': 27, 'time_mask_pm': 0.04, 'time_mask_ps': 0.04}", seed=seed)
+        specaugment_config="{'freq_mask_N': 2, 'freq_mask_F': 27, 'time_mask_pm': 0.04, 'time_mask_ps': 0.04}", seed=seed,
+        criterion_name="ctc_loss")
     task = SpeechRecognitionEspressoTask.setup_task(tcfg, tgt_dict=d)
     mcfg = conformer_ctc_librispeech()
     model = task.build_model(mcfg)

@@ -1,0 +1,21 @@
+
+
+def forward_accepts_epoch(model) -> bool:
+    """Does `model.forward` take the `epoch` keyword the reference's criterions pass (label_smoothed_cross_entropy_v2.py:173)?
+    Decided from the signature (named parameter or **kwargs) of the innermost module — data-parallel wrappers forward
+    everything — and cached on the model; never by catching TypeError around the forward call."""
+    import inspect
+
+    cached = getattr(model, "_ea_accepts_epoch", None)
+    if cached is not None:
+        return cached
+    inner = model
+    while hasattr(inner, "module"):
+        inner = inner.module
+    params = inspect.signature(inner.forward).parameters
+    ok = "epoch" in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+    try:
+        model._ea_accepts_epoch = ok
+    except Exception:
+        pass
+    return ok

@@ -11,6 +11,7 @@ import torch
 from .. import functional as F
 from ..data.data_utils import numpy_seed
 from ..registry import register_criterion
+from . import forward_accepts_epoch
 
 logger = logging.getLogger(__name__)
 
@@ -33,9 +34,9 @@ class CrossEntropyV2Criterion:
         return self.forward(model, sample, reduce)
 
     def forward(self, model, sample, reduce=True):
-        try:
+        if forward_accepts_epoch(model):  # scheduled sampling is epoch-driven (label_smoothed_cross_entropy_v2.py:173)
             net_output = model(**sample["net_input"], epoch=self.epoch)
-        except TypeError:
+        else:
             net_output = model(**sample["net_input"])
         logits3 = net_output[0]
         logits = net_output[1].get("_logits_bu") if isinstance(net_output[1], dict) else None

@@ -14,7 +14,12 @@ class CtcLossCriterion:
     def __init__(self, task, sentence_avg=True, zero_infinity=True, print_training_sample_interval=500):
         self.task = task
         d = task.target_dictionary
-        self.blank_idx = d.index(task.blank_symbol) if hasattr(task, "blank_symbol") else d.bos()
+        if hasattr(task, "blank_symbol"):
+            if task.blank_symbol is None:  # a task set up for another criterion: its dictionary has no "<s>" to use as blank
+                raise ValueError(f"{type(self).__name__} needs task.blank_symbol (task.criterion_name must name this criterion)")
+            self.blank_idx = d.index(task.blank_symbol)
+        else:
+            self.blank_idx = d.bos()
         self.pad_idx = d.pad()
         self.eos_idx = d.eos()
         self.sentence_avg = sentence_avg

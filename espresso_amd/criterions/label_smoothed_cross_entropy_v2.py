@@ -9,6 +9,7 @@ import torch
 
 from .. import functional as F
 from ..registry import register_criterion
+from . import forward_accepts_epoch
 
 
 @register_criterion("label_smoothed_cross_entropy_v2")
@@ -34,9 +35,9 @@ class LabelSmoothedCrossEntropyV2Criterion:
         return self.forward(model, sample, reduce)
 
     def forward(self, model, sample, reduce=True):
-        try:
-            net_output = model(**sample["net_input"], epoch=self.epoch)  # scheduled sampling is epoch-driven (:173)
-        except TypeError:
+        if forward_accepts_epoch(model):  # scheduled sampling is epoch-driven (label_smoothed_cross_entropy_v2.py:173)
+            net_output = model(**sample["net_input"], epoch=self.epoch)
+        else:
             net_output = model(**sample["net_input"])
         logits3 = net_output[0]
         logits = net_output[1].get("_logits_bu") if isinstance(net_output[1], dict) else None

@@ -14,7 +14,12 @@ class TransducerLossCriterion:
     def __init__(self, task, sentence_avg=True, print_training_sample_interval=500):
         self.task = task
         d = task.target_dictionary
-        self.blank_idx = d.index(task.blank_symbol) if getattr(task, "blank_symbol", None) else d.bos()
+        if hasattr(task, "blank_symbol"):
+            if task.blank_symbol is None:  # a task set up for another criterion: its dictionary has no "<s>" to use as blank
+                raise ValueError(f"{type(self).__name__} needs task.blank_symbol (task.criterion_name must name this criterion)")
+            self.blank_idx = d.index(task.blank_symbol)
+        else:
+            self.blank_idx = d.bos()
         self.pad_idx, self.eos_idx = d.pad(), d.eos()
         self.sentence_avg = sentence_avg
         self.include_eos = bool(getattr(getattr(task, "cfg", None), "include_eos_in_transducer_loss", False))  # II("task.…") :40

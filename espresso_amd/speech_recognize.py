@@ -208,8 +208,10 @@ def main(argv=None):
     state = _load_file(args.path)
     model_name, model_cfg = resolve_model_config(args.model, args.model_config, state)
     autoregressive = args.search == "beam"
+    # the criterion the checkpoint was trained with decides whether "<s>" is the blank (speech_recognition.py:324, 345-347)
+    crit = {"beam": "label_smoothed_cross_entropy_v2", "ctc": "ctc_loss"}.get(args.search, "transducer_loss")
     task = SpeechRecognitionEspressoTask.setup_task(SpeechRecognitionEspressoConfig(
-        dict=args.dict, autoregressive=autoregressive, global_cmvn_stats_path=args.global_cmvn_stats_path))
+        dict=args.dict, autoregressive=autoregressive, global_cmvn_stats_path=args.global_cmvn_stats_path, criterion_name=crit))
     cls = registry.MODEL_REGISTRY[model_name]
     cfg_cls = getattr(cls, "config_class", None)
     cfg = cfg_cls.from_dict(model_cfg) if cfg_cls is not None else model_cfg

@@ -223,11 +223,9 @@ def main(argv=None):
     should_stop = trainer.num_updates >= max_update
     interval = torch.zeros(4, dtype=torch.float32, device=device)  # [sample_size, loss, ntokens, nsentences] since the last log line
     n_interval, t_interval = 0, time.time()
-    valid_losses = [None]
-
     def validate_and_save(end_of_epoch, n_batches_done):
-        """fairseq_cli/train.py:363-434."""
-        nonlocal valid_losses
+        """fairseq_cli/train.py:363-434.  Returns (valid_losses, should_stop); `valid_losses` is [None] whenever validation did
+        not run in THIS call (train.py:422), so the epoch-end plateau schedule never sees a stale loss."""
         n = trainer.num_updates
         stop = n >= max_update
         if opt["stop_time_hours"] > 0:
@@ -246,17 +244,17 @@ def main(argv=None):
         losses = [None]
         if do_validate:
             losses, _ = validate(cfg, trainer, task, valid_subsets, device, world, rank)
-            valid_losses = losses
         stop |= early_stop(losses[0])
         if do_save or stop:
-            state = {"version": 2, "epoch": epoch, "iterations_in_epoch": 0 if end_of_epoch else n_batches_done,
-                     "end_of_epoch": end_of_epoch, "shuffle": True}
+            # EpochBatchIterator.state_dict (fairseq/data/iterators.py:421-436): a finished epoch is written as the START of the next
+            state = {"version": 2, "epoch": epoch + 1 if end_of_epoch else epoch,
+                     "iterations_in_epoch": 0 if end_of_epoch else n_batches_done, "shuffle": True}
             files = saver.save(trainer, epoch, end_of_epoch, state, losses[0], is_master=rank == 0)
             if files:
                 log(rank, "checkpoint", files=[os.path.basename(f) for f in files], num_updates=n, score=losses[0])
             if world > 1:
                 dist.barrier()
-        return stop
+        return losses, stop
 
     while epoch <= max_epoch and not should_stop:
         batches = _plan(task, train_ds, cfg, epoch, world, rank, train=True)
@@ -289,6 +287,10 @@ def main(argv=None):
             if n % cfg["common"]["log_interval"] == 0:
                 ss, ls, nt, ns = interval.tolist()  # the only host<-device read of the training loop
                 gnorm = float(trainer.last_coef[1]) if trainer.last_coef is not None else None
+                if gnorm is not None and not math.isfinite(gnorm):
+                    # fairseq/trainer.py:949-958 (fp32): a non-finite gradient norm is fatal.  The fused Adam kernel leaves the
+                    # parameters untouched for such a step; it is detected here, at the loop's only host<-device read.
+                    raise FloatingPointError(f"gradients are Nan/Inf (update {n}, epoch {epoch})")
                 dt = time.time() - t_interval
                 log(rank, "train_inner", epoch=epoch, num_updates=n, loss=round(ls / max(ss, 1.0) / math.log(2), 4), ntokens=nt,
                     nsentences=ns, sample_size=ss, lr=trainer.get_lr(), gnorm=gnorm, ups=round(n_interval / max(dt, 1e-9), 2))
@@ -296,11 +298,11 @@ def main(argv=None):
                 n_interval, t_interval = 0, time.time()
             end = done >= len(batches)
             if not end:
-                should_stop = validate_and_save(False, done)
+                _, should_stop = validate_and_save(False, done)
                 if should_stop:
                     break
         if not should_stop:
-            should_stop = validate_and_save(True, done)
+            valid_losses, should_stop = validate_and_save(True, done)
             lr = trainer.lr_step(epoch, valid_losses[0])
             log(rank, "epoch_end", epoch=epoch, num_updates=trainer.num_updates, lr=lr)
             if lr <= opt["stop_min_lr"]:

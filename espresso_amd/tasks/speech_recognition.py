@@ -33,7 +33,7 @@ class SpeechRecognitionEspressoConfig:
     non_lang_syms: Optional[str] = None
     word_dict: Optional[str] = None
     wer_output_filter: Optional[str] = None
-    criterion_name: str = "ctc_loss"
+    criterion_name: Optional[str] = None  # the reference interpolates criterion._name here (speech_recognition.py:121)
     include_eos_in_transducer_loss: bool = False
     prepend_bos_as_input_feeding: bool = False
     batch_based_on_both_src_tgt: bool = False
@@ -45,12 +45,9 @@ class SpeechRecognitionEspressoConfig:
 
 
 def uses_blank(cfg) -> bool:
-    """`<s>` is enabled and reserved as the blank for `ctc_loss` / `transducer_loss` (speech_recognition.py:323-327, 345-352: decided
-    by the criterion's name).  The transducer recipes set `autoregressive: true` (input feeding for the predictor) together with
-    `transducer_loss`; `ctc_loss` — also this dataclass's default when no criterion was named — never comes with an
-    autoregressive target side, so that combination means "criterion unspecified": no blank."""
-    name = getattr(cfg, "criterion_name", None)
-    return name == "transducer_loss" or (name == "ctc_loss" and not cfg.autoregressive)
+    """`<s>` is enabled and reserved as the blank for `ctc_loss` / `transducer_loss`: decided by the criterion's name alone, as
+    the reference does (espresso/tasks/speech_recognition.py:324, 345-347); `autoregressive` plays no part in it."""
+    return getattr(cfg, "criterion_name", None) in ("transducer_loss", "ctc_loss")
 
 
 @registry.register_task("speech_recognition_espresso", dataclass=SpeechRecognitionEspressoConfig)
@@ -168,7 +165,7 @@ class SpeechRecognitionEspressoTask:
         return registry.MODEL_REGISTRY[model_name].build_model(model_cfg, self)
 
     def build_criterion(self, name=None, **kwargs):
-        name = name or getattr(self.cfg, "criterion_name", "ctc_loss")
+        name = name or getattr(self.cfg, "criterion_name", None) or "ctc_loss"
         self.cfg.criterion_name = name
         self.criterion = registry.CRITERION_REGISTRY[name](self, **kwargs)
         return self.criterion

@@ -9,19 +9,20 @@ import torch
 
 
 def collate_frames(values, pad_value=0.0, left_pad=False, pad_to_length=None, pad_to_multiple=1):
-    """Convert a list of 2d tensors into a padded 3d tensor."""
-    assert values[0].dim() == 2, "expected 2, got " + str(values[0].dim)
-    length = max(v.size(0) for v in values)
-    length = length if pad_to_length is None else max(length, pad_to_length)
-    if pad_to_multiple != 1 and length % pad_to_multiple != 0:
-        length = (length + pad_to_multiple - 1) // pad_to_multiple * pad_to_multiple
-    dim = values[0].size(1)
-    res = values[0].new(len(values), length, dim).fill_(pad_value)
-    for i, v in enumerate(values):
-        dst = res[i][length - v.size(0):, :] if left_pad else res[i][: v.size(0), :]
-        assert dst.numel() == v.numel()
-        dst.copy_(v)
-    return res
+    """List of (T_i, D) feature matrices -> one (N, T, D) batch padded with `pad_value` on the right (or on the left), with
+    T = max T_i, raised to `pad_to_length` and rounded up to a multiple of `pad_to_multiple` — the contract of
+    espresso/tools/utils.py:97-113.  (The training path pads on the GPU inside `ea_fbank_batch`; this host version serves
+    pre-computed Kaldi features.)"""
+    first = values[0]
+    if first.dim() != 2:
+        raise AssertionError(f"expected 2-d feature matrices, got {first.dim()}-d")
+    lens = [int(v.shape[0]) for v in values]
+    T = max(lens + ([int(pad_to_length)] if pad_to_length is not None else []))
+    T = -(-T // pad_to_multiple) * pad_to_multiple
+    out = torch.full((len(values), T, int(first.shape[1])), pad_value, dtype=first.dtype, device=first.device)
+    for row, v, n in zip(out, values, lens):
+        row.narrow(0, T - n if left_pad else 0, n).copy_(v)
+    return out
 
 
 def sequence_mask(sequence_length, max_len=None):
@@ -38,7 +39,9 @@ def convert_padding_direction(src_frames, src_lengths, right_to_left=False, left
     assert right_to_left ^ left_to_right
     assert src_frames.size(0) == src_lengths.size(0)
     max_len = src_frames.size(1)
-    if not bool((src_lengths < max_len).any()):
+    # the reference's early return (espresso/tools/utils.py:209): taken when NO row has the full length (its collated batches
+    # always contain one), not when no row is padded
+    if not bool(src_lengths.eq(max_len).any()):
         return src_frames
     index = torch.arange(max_len, device=src_frames.device).unsqueeze(0).expand(src_frames.size(0), -1)
     num_pads = (max_len - src_lengths).unsqueeze(1)
@@ -46,7 +49,7 @@ def convert_padding_direction(src_frames, src_lengths, right_to_left=False, left
     return src_frames.gather(1, index.unsqueeze(2).expand_as(src_frames))
 
 
-def eval_str_nested_list_or_tuple(x, type=float):
+def eval_str_nested_list_or_tuple(x, type=int):
     if x is None:
         return None
     if isinstance(x, str):

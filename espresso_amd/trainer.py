@@ -169,7 +169,8 @@ class Trainer:
         sched = self.lr_scheduler.state_dict() if hasattr(self.lr_scheduler, "state_dict") else {}
         extra = {"previous_training_time": 0.0}
         extra.update(extra_state or {})
-        return {
+        no_optim = bool(((self.cfg or {}).get("checkpoint") or {}).get("no_save_optimizer_state", False))  # trainer.py:422
+        sd = {
             "args": None,
             "cfg": self.cfg,
             "model": {k: v.detach().clone().cpu() for k, v in self.model.state_dict().items()},
@@ -179,8 +180,10 @@ class Trainer:
                 "lr_scheduler_state": sched, "num_updates": self.num_updates}],
             "task_state": {},
             "extra_state": extra,
-            "last_optimizer_state": self._optimizer_state(),
         }
+        if not no_optim:
+            sd["last_optimizer_state"] = self._optimizer_state()
+        return sd
 
     def save_checkpoint(self, filename, extra_state=None):
         """Rank 0 writes (data-parallel replicas hold identical state); atomically, like checkpoint_utils.torch_persistent_save."""

@@ -31,7 +31,8 @@ def main():
     torch.manual_seed(1)
     d = AsrDictionary.from_symbols([f"u{i}" for i in range(VOCAB - 5)], enable_bos=True)
     tcfg = SpeechRecognitionEspressoConfig(
-        specaugment_config="{'freq_mask_N': 2, 'freq_mask_F': 27, 'time_mask_pm': 0.04, 'time_mask_ps': 0.04}", seed=1)
+        specaugment_config="{'freq_mask_N': 2, 'freq_mask_F': 27, 'time_mask_pm': 0.04, 'time_mask_ps': 0.04}", seed=1,
+        criterion_name="transducer_loss")
     task = SpeechRecognitionEspressoTask.setup_task(tcfg, tgt_dict=d)
     cfg = SpeechTransformerTransducerConfig()
     e, dc = cfg.encoder, cfg.decoder
