@@ -246,7 +246,7 @@ def main():
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel+gemm_glds_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel+gemm_glds_kernel+wgrad_group_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_gemm_traffic.json)",
                     "launches_per_step": n / nrep, "avg_launch_us": tot_ms * 1e3 / max(n, 1),

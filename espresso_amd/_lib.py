@@ -94,7 +94,17 @@ class EaLayerShape(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("T", ctypes.c_int), ("C", ctypes.c_int), ("H", ctypes.c_int), ("F", ctypes.c_int),
                 ("KW", ctypes.c_int), ("training", ctypes.c_int), ("p_drop", ctypes.c_float), ("p_act", ctypes.c_float),
                 ("p_attn", ctypes.c_float), ("seed", ctypes.c_uint64), ("has_attn_mask", ctypes.c_int), ("scratch_clean", ctypes.c_int),
-                ("pos_mode", ctypes.c_int), ("act", ctypes.c_int), ("S", ctypes.c_int)]
+                ("pos_mode", ctypes.c_int), ("act", ctypes.c_int), ("S", ctypes.c_int), ("defer", ctypes.c_int)]
+
+
+class EaWgradProblem(ctypes.Structure):
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("ld_dy", ctypes.c_long), ("ld_x", ctypes.c_long),
+                ("ldw", ctypes.c_long)]
+
+
+class EaWgradGroup(ctypes.Structure):
+    _fields_ = [("count", ctypes.c_int), ("p", EaWgradProblem * 16)]
 
 
 EaXAttnParams = _mk("EaXAttnParams", ["ln_g", "ln_b", "wq", "bq", "wkv", "bkv", "wo", "bo"])

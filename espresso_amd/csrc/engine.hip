@@ -12,6 +12,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <functional>
+#include <vector>
+
 #include "espresso_amd.h"
 
 namespace {
@@ -32,6 +35,20 @@ struct Arena {
 
 inline int pad8(int n) { return (n + 7) / 8 * 8; }
 
+// Deferred side work of ONE layer backward (round 2): everything that only feeds the optimizer — weight / bias gradients,
+// LayerNorm / BatchNorm / depthwise-filter parameter gradients, the pos_proj chain — is collected while the data-gradient chain
+// is enqueued on the main stream and launched afterwards on the side stream behind a single fork: all Linear weight and bias
+// gradients of the layer as ONE grouped GEMM launch (ea_wgrad_group), all LayerNorm parameter reduces as one launch.  The
+// side work of layer k then runs next to the main chain of layer k-1, whose call joins it at its end; the two calls use
+// different halves of the scratch arena.  Per layer: ~36 launches and 3 stream-event operations instead of ~85 + ~28.
+struct Deferred {
+  EaWgradGroup grp;
+  EaLnReduceGroup ln;
+  std::vector<std::function<int(hipStream_t)>> ops;
+  Deferred() { clear(); }
+  void clear() { grp.count = 0; ln.count = 0; ops.clear(); }
+};
+
 struct Ctx {
   hipStream_t s;
   bool dry;  // size computation only: walk the arenas, launch nothing
@@ -42,6 +59,7 @@ struct Ctx {
   // scratch arena is not recycled inside a layer (a side kernel may still be reading a temporary).
   hipStream_t side;
   bool overlap;
+  Deferred* df = nullptr;  // non-null: deferred mode (also in the sizing pass, so that both walk the arena alike)
 };
 
 #define RUN(call)                         \
@@ -56,6 +74,8 @@ struct SideRes {
   hipEvent_t ev[32];
   int next = 0;
   bool ok = false;
+  hipEvent_t done[2];                // deferred mode: side work that reads scratch half h has been enqueued up to here
+  bool pending[2] = {false, false};  // ... and the main stream has not joined it yet
 };
 static SideRes g_side;
 static bool side_init(hipStream_t owner) {
@@ -70,6 +90,8 @@ static bool side_init(hipStream_t owner) {
   if (dev != cur && hipSetDevice(dev) != hipSuccess) return false;
   bool ok = hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) == hipSuccess;
   for (auto& e : g_side.ev)
+    ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  for (auto& e : g_side.done)
     ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   if (dev != cur) (void)hipSetDevice(cur);
   g_side.ok = ok;
@@ -87,7 +109,17 @@ static inline void* ln_ws(Ctx& c, int M, int C) {
 }
 // stream for optimizer-only products (wgrad / bias sums)
 static inline hipStream_t wstream(Ctx& c) { return c.overlap ? c.side : c.s; }
-static inline void fork(Ctx& c) { if (c.overlap) stream_wait(c, c.side, c.s); }
+static inline void fork(Ctx& c) { if (c.overlap && !c.df) stream_wait(c, c.side, c.s); }
+// main stream joins the deferred side work that used scratch half h (no-op when nothing is pending)
+static inline int join_half(hipStream_t main, int h) {
+  if (!g_side.ok || !g_side.pending[h]) return 0;
+  g_side.pending[h] = false;
+  return hipStreamWaitEvent(main, g_side.done[h], 0) == hipSuccess ? 0 : -1;
+}
+static inline int join_all(hipStream_t main) {
+  const int a = join_half(main, 0), b = join_half(main, 1);
+  return a ? a : b;
+}
 static inline void release(Ctx& c, size_t mark) { if (!c.overlap) c.scratch->off = mark; }
 
 inline uint32_t drop_thr(float p) {
@@ -126,8 +158,23 @@ struct G {
 inline void gemm(Ctx& c, G& g) { RUN(ea_gemm_bf16(&g.p, c.s)); }
 inline void gemm_on(Ctx& c, G& g, hipStream_t st) { RUN(ea_gemm_bf16(&g.p, st)); }
 
-// dW[N_out][K_in] += dy^T x with two-pass split-K; workspace from the scratch arena
-inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, float* dW, int M, int N_out, int K_in) {
+// dW[N_out][K_in] += dy^T x (and dbias[N_out] += column sums of dy).  Deferred mode: one more problem of the layer's grouped
+// launch.  Immediate mode: two-pass split-K GEMM (workspace from the scratch arena) + a column-sum launch.
+inline void bias_grad(Ctx& c, const void* X, float* out, int M, int N, long ld) {
+  if (c.df) {
+    if (!c.dry) c.df->ops.push_back([=](hipStream_t st) { return ea_colsum_bf16(X, out, M, N, ld, st); });
+    return;
+  }
+  RUN(ea_colsum_bf16(X, out, M, N, ld, wstream(c)));
+}
+inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, float* dW, int M, int N_out, int K_in,
+                  float* dbias = nullptr) {
+  if (c.df && c.df->grp.count < EA_WGRAD_MAX) {  // (the sizing pass counts too: both passes take the same branch)
+    EaWgradProblem& q = c.df->grp.p[c.df->grp.count++];
+    if (c.dry) return;
+    q.dy = dy; q.x = x; q.dW = dW; q.dbias = dbias; q.M = M; q.N = N_out; q.K = K_in; q.ld_dy = ld_dy; q.ld_x = ld_x; q.ldw = K_in;
+    return;
+  }
   // 64x128 output tiles; aim at ~512 resident workgroups (2 per CU): deeper splits only add slab traffic for the
   // reduce pass (measured on the 2048x512 / 512x512 weight gradients at M = 6468)
   const int tiles = ((N_out + 63) / 64) * ((K_in + 127) / 128);
@@ -141,9 +188,30 @@ inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, 
   g.aks().bks().f32().acc();
   g.p.splitk = sk;
   if (sk > 1) g.p.workspace = c.scratch->get<float>((size_t)sk * N_out * K_in);
-  gemm_on(c, g, wstream(c));
+  if (c.df) {  // group full (never with the layers of this runtime): run it with the other deferred side work
+    const EaGemmParams gp = g.p;
+    if (!c.dry) c.df->ops.push_back([=](hipStream_t st) { return ea_gemm_bf16(&gp, st); });
+  } else {
+    gemm_on(c, g, wstream(c));
+  }
+  if (dbias) bias_grad(c, dy, dbias, M, N_out, ld_dy);
 }
-inline void bias_grad(Ctx& c, const void* X, float* out, int M, int N, long ld) { RUN(ea_colsum_bf16(X, out, M, N, ld, wstream(c))); }
+// side-stream work after the main chain of a layer backward: ONE fork, the grouped launches, the remaining small kernels; then
+// the main stream joins the side work of the PREVIOUS backward call (other scratch half), which ran next to this call's chain
+static void run_deferred(Ctx& c, int half) {
+  if (c.dry || !c.df) return;
+  Deferred& d = *c.df;
+  stream_wait(c, c.side, c.s);
+  RUN(ea_wgrad_group(&d.grp, c.side));
+  RUN(ea_layernorm_param_reduce_group(&d.ln, c.side));
+  for (auto& op : d.ops) RUN(op(c.side));
+  d.clear();
+  if (c.rc == 0) {
+    if (hipEventRecord(g_side.done[half], c.side) != hipSuccess) c.rc = -1;
+    g_side.pending[half] = true;
+  }
+  if (c.rc == 0) c.rc = join_half(c.s, half ^ 1);
+}
 
 }  // namespace
 
@@ -195,6 +263,16 @@ static inline void ln_bwd_block(Ctx& c, const void* x, const void* dxn, const fl
                              drop_scale(next.p), c.s));
   else
     RUN(ea_layernorm_bwd_dx(x, dxn, gamma, mean, rstd, dx, dg, db, M, C, nullptr, 0, 0, 1.f, dx_add, lnws, c.s));
+  if (c.df) {
+    if (c.dry) return;
+    if (c.df->ln.count < EA_LNRED_MAX) {
+      EaLnReduceItem& it = c.df->ln.item[c.df->ln.count++];
+      it.workspace = lnws; it.dgamma = dg; it.dbeta = db; it.M = M; it.C = C;
+    } else {
+      c.df->ops.push_back([=](hipStream_t st) { return ea_layernorm_param_reduce(lnws, dg, db, M, C, st); });
+    }
+    return;
+  }
   fork(c);  // the parameter-gradient reduce only feeds the optimizer
   RUN(ea_layernorm_param_reduce(lnws, dg, db, M, C, wstream(c)));
 }
@@ -255,16 +333,14 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
     g2 = gb;
   }
   fork(c);
-  wgrad(c, g2, C, h, F, gw.w2, M, C, F);
-  bias_grad(c, g2, gw.b2, M, C, C);
+  wgrad(c, g2, C, h, F, gw.w2, M, C, F, gw.b2);
   uint16_t* dz = sc.get<uint16_t>((size_t)M * F);
   G gd(g2, w2t ? (const void*)w2t : w.w2, dz, M, F, C, C, w2t ? C : F, F);
   if (!w2t) gd.bks();
   gd.aux(z, F).act(act).drop(sh.p_act, seed + 1);
   gemm(c, gd);
   fork(c);
-  wgrad(c, dz, F, xn, C, gw.w1, M, F, C);
-  bias_grad(c, dz, gw.b1, M, F, F);
+  wgrad(c, dz, F, xn, C, gw.w1, M, F, C, gw.b1);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dz, w.w1, w1t, dxn, M, C, F);
   ln_bwd_block(c, x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, next);
@@ -379,7 +455,8 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
   if (sk > (B * T) / 256) sk = (B * T) / 256;
   if (sk < 1) sk = 1;
   if (learned) {
-    // learned table: the fp32 result IS the gradient of the table slice (written to the caller's buffer, [R][C])
+    // learned table: the fp32 result IS the gradient of the table slice (written to the caller's buffer, [R][C]) — the caller
+    // reads it right after this call returns, so this mode never runs deferred (checked at the entry points)
     G gpp(dBD, a.qu, dpe, R, dh, B * T, Rp, C, C);
     gpp.aks().bks().f32().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
     gpp.p.splitk = sk;
@@ -396,9 +473,6 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
     gpp.aks().bks().f32().batch(H, 1, dh, 0, (long)B * T * Rp, 0, (long)dh * Rp, 0);
     gpp.p.splitk = sk;
     if (sk > 1) gpp.p.workspace = sc.get<float>((size_t)sk * H * R * dh);
-    fork(c);  // dBD, qv ready: the whole pos_proj gradient chain is optimizer-only
-    gemm_on(c, gpp, wstream(c));
-    RUN(ea_cast_f32_to_bf16(dppT32, dppT, (long)C * Rp, wstream(c)));  // pad columns R..Rp-1 are never read
     // dWpos[n][k] += sum_r dppT[n][r] pe[r][k]
     const int wt_tiles = ((C + 63) / 64) * ((C + 127) / 128);
     int sk2 = (512 + wt_tiles - 1) / wt_tiles;
@@ -408,14 +482,29 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
     gw2.bks().f32().acc();
     gw2.p.splitk = sk2;
     if (sk2 > 1) gw2.p.workspace = sc.get<float>((size_t)sk2 * C * C);
-    gemm_on(c, gw2, wstream(c));
+    if (c.df) {
+      if (!c.dry) {
+        const EaGemmParams p1 = gpp.p, p2 = gw2.p;
+        const long ncast = (long)C * Rp;
+        c.df->ops.push_back([=](hipStream_t st) {
+          int rc = ea_gemm_bf16(&p1, st);
+          if (rc == 0) rc = ea_cast_f32_to_bf16(dppT32, dppT, ncast, st);  // pad columns R..Rp-1 are never read
+          if (rc == 0) rc = ea_gemm_bf16(&p2, st);
+          return rc;
+        });
+      }
+    } else {
+      fork(c);  // dBD, qv ready: the whole pos_proj gradient chain is optimizer-only
+      gemm_on(c, gpp, wstream(c));
+      RUN(ea_cast_f32_to_bf16(dppT32, dppT, (long)C * Rp, wstream(c)));  // pad columns R..Rp-1 are never read
+      gemm_on(c, gw2, wstream(c));
+    }
     bias_grad(c, t1, gw.pos_u, M, C, C);
     bias_grad(c, t2, gw.pos_v, M, C, C);
   }
   RUN(ea_add2_strided_bf16(t1, C, t2, C, dqkv, 3 * C, M, C, c.s));
   fork(c);
-  wgrad(c, dqkv, 3 * C, a.xn, C, gw.wqkv, M, 3 * C, C);
-  bias_grad(c, dqkv, gw.bqkv, M, 3 * C, 3 * C);
+  wgrad(c, dqkv, 3 * C, a.xn, C, gw.wqkv, M, 3 * C, C, gw.bqkv);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dqkv, w.wqkv, wqkvt, dxn, M, C, 3 * C);
   ln_bwd_block(c, x, dxn, w.ln_g, a.mean, a.rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, next);
@@ -437,8 +526,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     g = gg;
   }
   fork(c);
-  wgrad(c, g, C, a.o, C, gw.wo, M, C, C);
-  bias_grad(c, g, gw.bo, M, C, C);
+  wgrad(c, g, C, a.o, C, gw.wo, M, C, C, gw.bo);
   uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, g, w.wo, wot, dO, M, C, C);
   if (attn_fused(sh)) {
@@ -547,9 +635,22 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
   char* wws = sc.get<char>((size_t)ea_dwconv_wgrad_workspace_bytes(B, T, C, sh.KW));
   RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, nullptr, wws, B, T, C, sh.KW, c.s));
-  fork(c);  // BatchNorm / depthwise-filter / pointwise-1 parameter gradients: optimizer-only
-  RUN(ea_bn_param_grad(red, gw.bn_g, gw.bn_b, C, wstream(c)));
-  RUN(ea_dwconv_bwd_weight(dZ, s.U, gw.dw, wws, B, T, C, sh.KW, wstream(c)));
+  if (c.df) {
+    if (!c.dry) {
+      const EaConvGrads gwv = gw;
+      const uint16_t* U = s.U;
+      const int KW = sh.KW;
+      c.df->ops.push_back([=](hipStream_t st) {
+        int rc = ea_bn_param_grad(red, gwv.bn_g, gwv.bn_b, C, st);
+        if (rc == 0) rc = ea_dwconv_bwd_weight(dZ, U, gwv.dw, wws, B, T, C, KW, st);
+        return rc;
+      });
+    }
+  } else {
+    fork(c);  // BatchNorm / depthwise-filter / pointwise-1 parameter gradients: optimizer-only
+    RUN(ea_bn_param_grad(red, gw.bn_g, gw.bn_b, C, wstream(c)));
+    RUN(ea_dwconv_bwd_weight(dZ, s.U, gw.dw, wws, B, T, C, sh.KW, wstream(c)));
+  }
   wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dY, w.pw1, pw1t, dxn, M, C, 2 * C);
@@ -623,7 +724,8 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32, wt.pw1, wt.pw2, pcv, to_attn);
   attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16, wt.wqkv, wt.wo, pat, to_ffn1);
   ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2, pf1, none);
-  if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
+  if (c.df) run_deferred(c, sh.defer - 1);
+  else if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
 }
 
@@ -685,7 +787,8 @@ static int tlayer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh,
   const WT wt = twt_view(L, sh);
   ffn_bwd(c, S.f, sh, L->ffn1, L->grads.ffn1, S.x1, dy, dA, seed + 0, 1.f, sh.act, wt.f1w1, wt.f1w2, nullptr, to_attn);
   attn_bwd(c, S.at, sh, L->attn, L->grads.attn, x_in, dA, dx, key_len, pe, seed + 16, wt.wqkv, wt.wo, pat, none, dpe);
-  if (c.overlap) stream_wait(c, c.s, c.side);
+  if (c.df) run_deferred(c, sh.defer - 1);
+  else if (c.overlap) stream_wait(c, c.s, c.side);
   return c.rc;
 }
 
@@ -796,8 +899,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     const EaXAttnGrads& gw = L->g_cross;
     const void* g = dp ? (const void*)pca : (const void*)dA;
     fork(c);
-    wgrad(c, g, C, D.ca.o, C, gw.wo, M, C, C);
-    bias_grad(c, g, gw.bo, M, C, C);
+    wgrad(c, g, C, D.ca.o, C, gw.wo, M, C, C, gw.bo);
     uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
     dgrad(c, g, w.wo, wt.xo, dO, M, C, C);
     uint16_t* dq = sc.get<uint16_t>((size_t)M * C);
@@ -807,10 +909,8 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
                                nullptr, C, nullptr, 0, dkv, dkv + C, 2 * C, H, B, T, S, dh, 0, scaling, seed + 32 + 3, drop_thr(sh.p_attn),
                                drop_scale(sh.p_attn), c.s));
     fork(c);
-    wgrad(c, dq, C, D.ca.xn, C, gw.wq, M, C, C);
-    bias_grad(c, dq, gw.bq, M, C, C);
-    wgrad(c, dkv, 2 * C, enc, C, gw.wkv, Ms, 2 * C, C);
-    bias_grad(c, dkv, gw.bkv, Ms, 2 * C, 2 * C);
+    wgrad(c, dq, C, D.ca.xn, C, gw.wq, M, C, C, gw.bq);
+    wgrad(c, dkv, 2 * C, enc, C, gw.wkv, Ms, 2 * C, C, gw.bkv);
     dgrad(c, dkv, w.wkv, wt.xkv, denc, Ms, C, 2 * C);
     uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
     dgrad(c, dq, w.wq, wt.xq, dxn, M, C, C);
@@ -821,8 +921,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     const EaAttnGrads& gw = L->g_self;
     const void* g = dp ? (const void*)psa : (const void*)dB;
     fork(c);
-    wgrad(c, g, C, D.sa.o, C, gw.wo, M, C, C);
-    bias_grad(c, g, gw.bo, M, C, C);
+    wgrad(c, g, C, D.sa.o, C, gw.wo, M, C, C, gw.bo);
     uint16_t* dO = sc.get<uint16_t>((size_t)M * C);
     dgrad(c, g, w.wo, wt.wo, dO, M, C, C);
     uint16_t* dqkv = sc.get<uint16_t>((size_t)M * 3 * C);
@@ -832,8 +931,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
                                Dd, dqkv, nullptr, 3 * C, nullptr, 0, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 1, scaling,
                                seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
     fork(c);
-    wgrad(c, dqkv, 3 * C, D.sa.xn, C, gw.wqkv, M, 3 * C, C);
-    bias_grad(c, dqkv, gw.bqkv, M, 3 * C, 3 * C);
+    wgrad(c, dqkv, 3 * C, D.sa.xn, C, gw.wqkv, M, 3 * C, C, gw.bqkv);
     uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
     dgrad(c, dqkv, w.wqkv, wt.wqkv, dxn, M, C, 3 * C);
     ln_bwd_block(c, x_in, dxn, w.ln_g, D.sa.mean, D.sa.rstd, dx, gw.ln_g, gw.ln_b, M, C, dB, none);
@@ -857,6 +955,37 @@ int ea_set_backward_overlap(int on) {
   g_overlap_default = on != 0;
   return old;
 }
+static bool g_defer_default = true;
+int ea_set_backward_deferred(int on) {
+  const int old = g_defer_default;
+  g_defer_default = on != 0;
+  return old;
+}
+int ea_backward_flush(hipStream_t stream) { return join_all(stream); }
+
+// deferred mode of one backward call: requested by the caller (shape.defer = 1 + scratch half), side stream available, not
+// disabled; the learned-table attention returns `dpe` to the caller and therefore always runs its side work before returning
+static inline bool want_deferred(const EaLayerShape& sh, bool overlap) {
+  return overlap && g_defer_default && (sh.defer == 1 || sh.defer == 2) && sh.pos_mode != 1;
+}
+// scratch sizing shared by the conformer / transformer workspace queries: the arena must hold either one immediate-mode
+// backward or two deferred-mode halves
+static long scratch_need(const std::function<void(Ctx&)>& walk) {
+  Arena sc{nullptr, 0, 0};
+  Ctx c{nullptr, true, 0, &sc, nullptr, g_overlap_default};
+  walk(c);
+  long need = (long)sc.peak + 256;
+  if (g_overlap_default && g_defer_default) {
+    Arena sd{nullptr, 0, 0};
+    Deferred dummy;
+    Ctx d{nullptr, true, 0, &sd, nullptr, true};
+    d.df = &dummy;
+    walk(d);
+    const long two = 2 * (((long)sd.peak + 511) & ~255L);
+    if (two > need) need = two;
+  }
+  return need;
+}
 
 static bool shape_ok(const EaLayerShape& sh) {
   return sh.B > 0 && sh.T > 0 && sh.C % 8 == 0 && sh.H > 0 && sh.C % sh.H == 0 && sh.F % 8 == 0 && sh.T <= 1024;
@@ -866,28 +995,51 @@ int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, l
   if (!shape_ok(*shape)) return -2;
   EaConformerLayer L;
   memset(&L, 0, sizeof(L));
-  Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
-  Ctx c{nullptr, true, 0, &sc, nullptr, g_overlap_default};
-  layer_fwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
-  Arena sv2{nullptr, 0, 0};
-  layer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv2);
+  Arena sv{nullptr, 0, 0};
+  EaLayerShape sh = *shape;
+  sh.defer = 1;
+  *scratch_bytes = scratch_need([&](Ctx& c) {
+    Arena a{nullptr, 0, 0}, b{nullptr, 0, 0};
+    layer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, a);
+    layer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, b);
+    if (a.peak > sv.peak) sv.peak = a.peak;
+  });
   *saved_bytes = (long)sv.peak + 256;
-  *scratch_bytes = (long)sc.peak + 256;
   return 0;
 }
 
 // arena capacities are checked with a dry (sizing) pass before anything is launched
-static bool arenas_fit(const EaLayerShape& sh, bool backward, bool overlap, long saved_bytes, long scratch_bytes, bool transformer = false) {
+static bool arenas_fit(const EaLayerShape& sh, bool backward, bool overlap, long saved_bytes, long scratch_bytes, bool transformer = false,
+                       bool deferred = false) {
   EaConformerLayer L;
   memset(&L, 0, sizeof(L));
   Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
   Ctx c{nullptr, true, 0, &sc, nullptr, overlap};
+  Deferred dummy;
+  if (deferred) c.df = &dummy;
   if (transformer) {
     if (backward) tlayer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
     else tlayer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
   } else if (backward) layer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
   else layer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
   return (long)sv.peak <= saved_bytes && (long)sc.peak <= scratch_bytes;
+}
+
+// One backward call in deferred mode: the main chain runs out of scratch half (defer - 1); its side work is launched behind one
+// fork at the end and joined by the NEXT backward call (or ea_backward_flush / any forward call).
+static int bwd_deferred(const EaConformerLayer* layer, const EaLayerShape& sh, const void* x_in, const void* dy, void* dx,
+                        const int* key_len, const void* pe, float* dpe, void* saved, long saved_bytes, void* scratch,
+                        long scratch_bytes, hipStream_t stream, bool transformer) {
+  static Deferred df;  // one process drives one GPU from one thread (the autograd engine's device thread)
+  const int half = sh.defer - 1;
+  const long half_bytes = (scratch_bytes / 2) & ~255L;
+  if (!arenas_fit(sh, true, true, saved_bytes, half_bytes, transformer, true)) return -5;
+  if (join_half(stream, half) != 0) return -1;  // only if the caller did not alternate the halves
+  Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch + (size_t)half * half_bytes, 0, 0};
+  Ctx c{stream, false, 0, &sc, g_side.stream, true};
+  df.clear();
+  c.df = &df;
+  return transformer ? tlayer_bwd(c, layer, sh, x_in, dy, dx, key_len, pe, dpe, sv) : layer_bwd(c, layer, sh, x_in, dy, dx, key_len, pe, sv);
 }
 
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
@@ -898,6 +1050,7 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, nullptr, false};
   if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
+  if (join_all(stream) != 0) return -1;  // a forward reuses the scratch arena: no deferred side work may still be reading it
   return layer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
 }
 
@@ -918,7 +1071,9 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
                            hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
   const bool ov = g_overlap_default && side_init(stream);
+  if (want_deferred(*shape, ov)) return bwd_deferred(layer, *shape, x_in, dy, dx, key_len, pe, nullptr, saved, saved_bytes, scratch, scratch_bytes, stream, false);
   if (!arenas_fit(*shape, true, ov, saved_bytes, scratch_bytes)) return -5;
+  if (join_all(stream) != 0) return -1;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
   if (ov) stream_wait(c, c.side, c.s);
@@ -929,13 +1084,23 @@ int ea_transformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes,
   if (!shape_ok(*shape)) return -2;
   EaConformerLayer L;
   memset(&L, 0, sizeof(L));
-  Arena sv{nullptr, 0, 0}, sc{nullptr, 0, 0};
-  Ctx c{nullptr, true, 0, &sc, nullptr, g_overlap_default};
-  tlayer_fwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, sv);
-  Arena sv2{nullptr, 0, 0};
-  tlayer_bwd(c, &L, *shape, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sv2);
+  Arena sv{nullptr, 0, 0};
+  EaLayerShape sh = *shape;
+  sh.defer = 1;
+  *scratch_bytes = scratch_need([&](Ctx& c) {
+    Arena a{nullptr, 0, 0}, b{nullptr, 0, 0};
+    tlayer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, a);
+    if (sh.pos_mode == 1 && c.df) return;  // the learned-table layer never runs deferred
+    tlayer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, b);
+    if (a.peak > sv.peak) sv.peak = a.peak;
+  });
+  if (sv.peak == 0) {  // (walk order above: the first, immediate-mode walk always sets it)
+    Arena a{nullptr, 0, 0}, sc{nullptr, 0, 0};
+    Ctx c{nullptr, true, 0, &sc, nullptr, false};
+    tlayer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, a);
+    sv.peak = a.peak;
+  }
   *saved_bytes = (long)sv.peak + 256;
-  *scratch_bytes = (long)sc.peak + 256;
   return 0;
 }
 
@@ -945,6 +1110,7 @@ int ea_transformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* 
   if (!shape_ok(*shape)) return -2;
   if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
   if (!arenas_fit(*shape, false, false, saved_bytes, scratch_bytes, true)) return -5;
+  if (join_all(stream) != 0) return -1;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, nullptr, false};
   return tlayer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
@@ -956,7 +1122,9 @@ int ea_transformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* 
   if (!shape_ok(*shape)) return -2;
   if ((shape->pos_mode == 1) != (dpe != nullptr)) return -2;
   const bool ov = g_overlap_default && side_init(stream);
+  if (want_deferred(*shape, ov)) return bwd_deferred(layer, *shape, x_in, dy, dx, key_len, pe, dpe, saved, saved_bytes, scratch, scratch_bytes, stream, true);
   if (!arenas_fit(*shape, true, ov, saved_bytes, scratch_bytes, true)) return -5;
+  if (join_all(stream) != 0) return -1;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
   if (ov) stream_wait(c, c.side, c.s);
@@ -981,6 +1149,7 @@ int ea_decoder_layer_fwd(const EaDecoderLayer* layer, const EaLayerShape* shape,
                          const int* enc_len, void* saved, long saved_bytes, void* scratch, long scratch_bytes, hipStream_t stream) {
   if (!dshape_ok(*shape)) return -2;
   if (!darenas_fit(*shape, false, false, saved_bytes, scratch_bytes)) return -5;
+  if (join_all(stream) != 0) return -1;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, nullptr, false};
   return dlayer_fwd(c, layer, *shape, x_in, enc, x_out, enc_len, sv);
@@ -992,6 +1161,7 @@ int ea_decoder_layer_bwd(const EaDecoderLayer* layer, const EaLayerShape* shape,
   if (!dshape_ok(*shape)) return -2;
   const bool ov = g_overlap_default && side_init(stream);
   if (!darenas_fit(*shape, true, ov, saved_bytes, scratch_bytes)) return -5;
+  if (join_all(stream) != 0) return -1;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
   if (ov) stream_wait(c, c.side, c.s);

@@ -684,6 +684,173 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const EaGemmParams p
   }
 }
 
+
+// ---- grouped weight-gradient GEMM ----------------------------------------------------------------------------------------
+// One launch computes, for every problem i of a group,   dW_i[n][k] += sum_m dy_i[m][n] * x_i[m][k]   and
+// db_i[n] += sum_m dy_i[m][n]: all weight (and bias) gradients of one encoder layer's backward in a single grid.
+// Why grouped: each of these products has a tiny output (512x512 ... 2048x512 = 16..64 tiles of 128x128) and a long
+// reduction (M = all frames of the batch, ~6000), so launched one by one they need split-K + a reduce pass + a column-sum
+// launch each (round 1: ~30 launches and ~9 ms of side-stream kernel time per step).  Together the ~10 problems of a layer
+// are 370 (128-row) / 740 (64-row) tiles: the grid fills the chip with NO split, every workgroup owns its output tile (plain
+// fp32 read-modify-write, no atomics, no workspace) and walks the whole reduction.  Both operands are "k-strided" (the
+// reduction index m is the slow axis of dy / x): staged global -> registers -> LDS with the 4(k) x 8(row) register transpose of
+// gemm_bf16_kernel.  The bias gradient rides along: the workgroups of tile column 0 add up the dy values that pass through
+// their staging registers.
+struct WgradTable {
+  int start[EA_WGRAD_MAX + 1];  // first workgroup of problem i ; start[count] = grid size
+  int tiles_x[EA_WGRAD_MAX];    // column tiles (over K) of problem i
+};
+
+template <int BM_>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const EaWgradGroup g, const WgradTable tb) {
+  constexpr int NJ = BM_ == 128 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BM * ROW_BYTES];
+  char* sA = smem;
+  char* sB = smem + BM * ROW_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = BM_ == 128 ? (wave >> 1) : 0;
+  const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
+
+  int pi = 0;
+  const int bid = blockIdx.x;
+  while (pi + 1 < g.count && bid >= tb.start[pi + 1]) ++pi;
+  const EaWgradProblem P = g.p[pi];
+  const int local = bid - tb.start[pi];
+  const int tx = tb.tiles_x[pi];
+  const int tile_y = local / tx, tile_x = local - tile_y * tx;
+  const int R = P.N, Cn = P.K, Kr = P.M;  // output rows (dy columns), output columns (x columns), reduction length
+  const int m0 = tile_y * BM_, n0 = tile_x * BN;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(P.dy);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(P.x);
+  const long lda = P.ld_dy, ldb = P.ld_x;
+
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  const int nk = (Kr + BK - 1) / BK;
+  const bool a_ok = (m0 + BM_ <= R) && (lda & 7) == 0 && ((uintptr_t)A & 15) == 0;
+  const bool b_ok = (n0 + BN <= Cn) && (ldb & 7) == 0 && ((uintptr_t)B & 15) == 0;
+  const int a_kq = BM_ == 128 ? (tid >> 4) : (tid >> 3);
+  const int a_rc = BM_ == 128 ? (tid & 15) : (tid & 7);
+  const bool a_active = BM_ == 128 || tid < 128;
+  const bf16_t* a_base = A + (long)(a_kq * 4) * lda + m0 + a_rc * 8;
+  const bf16_t* b_base = B + (long)((tid >> 4) * 4) * ldb + n0 + (tid & 15) * 8;
+  const bool do_bias = P.dbias != nullptr && tile_x == 0;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  auto loadA = [&](int k0) {
+    if (!a_active) return;
+    if (a_ok && k0 + BK <= Kr) load_ks_fast(a_base, lda, k0, ra);
+    else load_ks_at(A, lda, R, Kr, m0 + a_rc * 8, k0 + a_kq * 4, ra);
+  };
+  auto loadB = [&](int k0) {
+    if (b_ok && k0 + BK <= Kr) load_ks_fast(b_base, ldb, k0, rb);
+    else load_ks(B, ldb, Cn, Kr, n0, k0, tid, rb);
+  };
+  if (nk > 0) { loadA(0); loadB(0); }
+  uint32_t a_off[2][4], b_off[2][NJ];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[ks][i] = lds_off(wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b_off[ks][j] = lds_off(wcol + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (a_active) {
+      if (do_bias) {  // column sums of dy: the 4 (k) x 8 (row) block this thread is about to stage
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bsum[2 * e] += __uint_as_float(w[e] << 16);
+            bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+          }
+        }
+      }
+      store_ks_at(sA, a_rc * 8, a_kq * 4, ra);
+    }
+    store_ks(sB, tid, rb);
+    __syncthreads();
+    if (kt + 1 < nk) { loadA((kt + 1) * BK); loadB((kt + 1) * BK); }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[ks][i]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + b_off[ks][j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float* sC = reinterpret_cast<float*>(smem);
+  if (do_bias) {  // fold the 16 k-quads that share a row: partial[kq][row] in LDS, one thread per row finishes
+    __syncthreads();
+    if (a_active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sC[a_kq * BM_ + a_rc * 8 + e] = bsum[e];
+    }
+    __syncthreads();
+    if (tid < BM_ && m0 + tid < R) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += sC[q * BM_ + tid];
+      P.dbias[m0 + tid] += s;
+    }
+  }
+  // accumulators -> fp32 LDS tile (64 rows at a time) -> dW += tile (each output element belongs to exactly one workgroup)
+  const bool vec_ok = (P.ldw & 3) == 0 && (((uintptr_t)P.dW) & 15) == 0;
+#pragma unroll
+  for (int half = 0; half < BM_ / 64; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int rl = pass * 8 + (tid >> 5);
+      const int m = m0 + half * 64 + rl;
+      const int n = n0 + (tid & 31) * 4;
+      if (m < R && n < Cn) {
+        const float4 x = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 31) * 4);
+        float* C = P.dW + (long)m * P.ldw + n;
+        if (vec_ok && n + 4 <= Cn) {
+          float4 c = *reinterpret_cast<const float4*>(C);
+          c.x += x.x; c.y += x.y; c.z += x.z; c.w += x.w;
+          *reinterpret_cast<float4*>(C) = c;
+        } else {
+          const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < Cn) C[e] += v[e];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- optional live profiling of the dominant kernel (bench.py roofline): HIP events around every launch on
@@ -848,6 +1015,48 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     if (blocks < 1) blocks = 1;
     if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+  }
+  return EA_CHECK_LAUNCH();
+}
+
+// All weight / bias gradients of one layer in one launch (see wgrad_group_kernel).
+extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
+  const EaWgradGroup& g = *gp;
+  if (g.count <= 0) return 0;
+  if (g.count > EA_WGRAD_MAX) return -2;
+  long tiles128 = 0;
+  for (int i = 0; i < g.count; ++i) {
+    const EaWgradProblem& p = g.p[i];
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.dy || !p.x || !p.dW) return -2;
+    tiles128 += (long)((p.N + 127) / 128) * ((p.K + BN - 1) / BN);
+  }
+  // 64-row tiles when 128-row tiles would leave CUs idle or badly balanced (each tile walks the whole reduction)
+  const bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < 1024));
+  const int bm = bm64 ? 64 : 128;
+  WgradTable tb;
+  int total = 0;
+  for (int i = 0; i < g.count; ++i) {
+    const EaWgradProblem& p = g.p[i];
+    tb.start[i] = total;
+    tb.tiles_x[i] = (p.K + BN - 1) / BN;
+    total += ((p.N + bm - 1) / bm) * tb.tiles_x[i];
+  }
+  for (int i = g.count; i <= EA_WGRAD_MAX; ++i) tb.start[i] = total;
+  for (int i = g.count; i < EA_WGRAD_MAX; ++i) tb.tiles_x[i] = 1;
+  GemmProf pr;
+  if (g_prof_on) {  // roofline accounting: one record per grouped launch (M = workgroups, N = problems, K = reduction length)
+    hipEventCreate(&pr.e0);
+    hipEventCreate(&pr.e1);
+    pr.flops = 0.0;
+    for (int i = 0; i < g.count; ++i) pr.flops += 2.0 * g.p[i].M * (double)g.p[i].N * g.p[i].K;
+    pr.M = total; pr.N = g.count; pr.K = g.p[0].M; pr.batch = 1; pr.a_ks = 1; pr.b_ks = 1; pr.splitk = 1; pr.bm64 = bm64; pr.epi = 128;
+    hipEventRecord(pr.e0, stream);
+  }
+  if (bm64) hipLaunchKernelGGL((wgrad_group_kernel<64>), dim3(total), dim3(256), 0, stream, g, tb);
+  else hipLaunchKernelGGL((wgrad_group_kernel<128>), dim3(total), dim3(256), 0, stream, g, tb);
+  if (g_prof_on) {
+    hipEventRecord(pr.e1, stream);
+    g_prof.push_back(pr);
   }
   return EA_CHECK_LAUNCH();
 }

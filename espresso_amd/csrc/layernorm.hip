@@ -255,6 +255,29 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
   }
 }
 
+// the same over several LayerNorms at once: blockIdx.z picks the item (all LayerNorms of one encoder layer's backward)
+struct LnRedDev { const float* partial; float* dgamma; float* dbeta; int nrows, C; };
+struct LnRedTable { LnRedDev it[EA_LNRED_MAX]; };
+__global__ __launch_bounds__(256) void ln_param_reduce_group_kernel(const LnRedTable tb) {
+  __shared__ float sm[4][64];
+  const LnRedDev d = tb.it[blockIdx.z];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;  // [0, 2C)
+  if (blockIdx.x * 64 >= 2 * d.C) return;
+  const int per = (d.nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(d.nrows, r0 + per);
+  float a = 0.f;
+  if (col < 2 * d.C)
+    for (int r = r0 + ry; r < r1; r += 4) a += d.partial[(long)r * 2 * d.C + col];
+  sm[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && col < 2 * d.C) {
+    a = sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx];
+    if (col < d.C) atomicAdd(d.dgamma + col, a);
+    else atomicAdd(d.dbeta + col - d.C, a);
+  }
+}
+
 }  // namespace
 
 extern "C" int ea_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
@@ -318,6 +341,28 @@ extern "C" int ea_layernorm_param_reduce(const void* workspace, float* dgamma, f
   if (rs > 32) rs = 32;
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(2 * C / 64, rs), dim3(256), 0, stream, (const float*)workspace, dgamma,
                      dbeta, nblk, C);
+  return EA_CHECK_LAUNCH();
+}
+
+extern "C" int ea_layernorm_param_reduce_group(const EaLnReduceGroup* g, hipStream_t stream) {
+  if (g->count <= 0) return 0;
+  if (g->count > EA_LNRED_MAX) return -2;
+  LnRedTable tb;
+  int maxc2 = 0, maxblk = 0, n = 0;
+  for (int i = 0; i < g->count; ++i) {
+    const EaLnReduceItem& it = g->item[i];
+    if (it.M <= 0) continue;
+    const int rpb = ln_bwd_rows_per_block(it.M, true);
+    const int nblk = (it.M + rpb - 1) / rpb;
+    tb.it[n++] = LnRedDev{(const float*)it.workspace, it.dgamma, it.dbeta, nblk, it.C};
+    if (2 * it.C > maxc2) maxc2 = 2 * it.C;
+    if (nblk > maxblk) maxblk = nblk;
+  }
+  if (n == 0) return 0;
+  int rs = maxblk / 32;
+  if (rs < 1) rs = 1;
+  if (rs > 32) rs = 32;
+  hipLaunchKernelGGL(ln_param_reduce_group_kernel, dim3((maxc2 + 63) / 64, rs, n), dim3(256), 0, stream, tb);
   return EA_CHECK_LAUNCH();
 }
 

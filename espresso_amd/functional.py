@@ -785,7 +785,7 @@ class _ConformerLayerNative(torch.autograd.Function):
             bind.saved_busy = bool(needs_bwd)
             ctx.owns_arena = bool(needs_bwd)
         scratch = _scratch_buffer(nb_scratch.value, x.device)
-        _scratch_tag[str(x.device)] = None  # the forward overwrites what a backward pass left in the arena
+        _scratch_forward_touch(str(x.device))  # the forward overwrites what a backward pass left in the arena
         y = torch.empty_like(x)
         stream = K._stream()
         _lib.check(lib.ea_conformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
@@ -809,20 +809,90 @@ class _ConformerLayerNative(torch.autograd.Function):
         # everything the arena layout depends on (shape, which optional buffers exist, runtime switches via the byte count)
         tag = (scratch.data_ptr(), ctx.nb_scratch, sh.B, sh.T, sh.C, sh.H, sh.F, sh.KW, sh.training, sh.has_attn_mask,
                sh.p_drop > 0, sh.p_act > 0, sh.p_attn > 0)
-        sh.scratch_clean = int(_scratch_tag.get(str(x.device)) == tag)  # consecutive layers of one backward pass share the layout
-        _scratch_tag[str(x.device)] = tag
+        dev = str(x.device)
+        half = _native_bwd_begin(sh, dev, tag, deferrable=ctx.owns_arena)
         stream = K._stream()
         _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
                                                      _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
                    "ea_conformer_layer_bwd")
         if ctx.owns_arena:
             ctx.bind.saved_busy = False
-        ctx.bind.finish_backward()
+        _native_bwd_end(ctx.bind, dev, half, stream)
         return (dx,) + (None,) * 10
 
 
 _scratch = {}
 _scratch_tag = {}
+
+# ---- deferred side work of the native layer backward (csrc/engine.hip "Deferred") ------------------------------------------
+# A backward call in deferred mode returns with its optimizer-only work (all weight / bias / norm-parameter gradients of the
+# layer, one grouped GEMM launch) still queued on the side stream; the NEXT backward call joins it.  So the binding whose
+# gradients became complete — and may be reported to the data-parallel wrapper — is the one of the PREVIOUS call, and the last
+# layer of a backward pass is finished by a callback the autograd engine runs at the end of that pass.
+_pending = {}        # device -> (binding awaiting the join, raw stream handle)
+_bwd_half = {}       # device -> scratch half the next deferred call uses
+_defer_enabled = True
+
+
+def _scratch_forward_touch(dev):
+    _scratch_tag[dev] = None
+    _scratch_tag.pop((dev, 0), None)
+    _scratch_tag.pop((dev, 1), None)
+
+
+def set_backward_deferred(on: bool):
+    """A/B switch (also tells the library): False = every layer backward forks and joins its side work inside the call."""
+    global _defer_enabled
+    from . import _lib
+
+    _defer_enabled = bool(on)
+    _lib.lib().ea_set_backward_deferred(int(on))
+
+
+def _native_bwd_begin(sh, dev, tag, deferrable):
+    """Fills sh.defer / sh.scratch_clean for the backward call that follows; returns the scratch half or None (immediate mode).
+    Deferred mode needs the saved-activation arena to outlive the call (the binding's grow-only arena, not a private buffer)
+    and a layer without a learned positional table (its `dpe` is consumed by autograd right after the call)."""
+    deferred = _defer_enabled and deferrable and sh.pos_mode != 1
+    if not deferred:
+        sh.defer = 0
+        sh.scratch_clean = int(_scratch_tag.get(dev) == tag)  # consecutive layers of one backward pass share the layout
+        _scratch_tag[dev] = tag
+        _scratch_tag.pop((dev, 0), None)
+        _scratch_tag.pop((dev, 1), None)
+        return None
+    half = _bwd_half.get(dev, 0)
+    _bwd_half[dev] = half ^ 1
+    sh.defer = 1 + half
+    sh.scratch_clean = int(_scratch_tag.get((dev, half)) == tag)
+    _scratch_tag[(dev, half)] = tag
+    _scratch_tag[dev] = None
+    return half
+
+
+def _flush_native_backward():
+    """End of a backward pass (autograd engine callback), or explicit: join the last layer's side work and report it."""
+    from . import _lib
+
+    for dev in list(_pending):
+        bind, stream = _pending.pop(dev)
+        _lib.check(_lib.lib().ea_backward_flush(stream), "ea_backward_flush")
+        bind.finish_backward()
+
+
+def _native_bwd_end(bind, dev, half, stream):
+    prev = _pending.pop(dev, None)
+    if half is None:  # immediate mode: the library joined everything before running this call
+        if prev is not None:
+            prev[0].finish_backward()
+        bind.finish_backward()
+        return
+    if prev is not None:
+        prev[0].finish_backward()  # this call ended with the main stream joining the previous call's side work
+    _pending[dev] = (bind, stream)
+    # runs when the engine has finished this backward pass (queued by every deferred call: a pass that died half-way must not
+    # leave the next one without its flush; all but the first invocation find nothing pending)
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_native_backward)
 
 
 def _scratch_buffer(nbytes, device):
@@ -876,7 +946,7 @@ class _TransformerLayerNative(torch.autograd.Function):
             bind.saved_busy = bool(needs_bwd)
             ctx.owns_arena = bool(needs_bwd)
         scratch = _scratch_buffer(nb_scratch.value, x.device)
-        _scratch_tag[str(x.device)] = None
+        _scratch_forward_touch(str(x.device))
         y = torch.empty_like(x)
         stream = K._stream()
         _lib.check(lib.ea_transformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
@@ -900,15 +970,15 @@ class _TransformerLayerNative(torch.autograd.Function):
         sh = ctx.sh
         tag = ("transformer", scratch.data_ptr(), ctx.nb_scratch, sh.B, sh.T, sh.C, sh.H, sh.F, sh.training, sh.has_attn_mask,
                sh.pos_mode, sh.p_drop > 0, sh.p_act > 0, sh.p_attn > 0)
-        sh.scratch_clean = int(_scratch_tag.get(str(x.device)) == tag)
-        _scratch_tag[str(x.device)] = tag
+        dev = str(x.device)
+        half = _native_bwd_begin(sh, dev, tag, deferrable=ctx.owns_arena)
         stream = K._stream()
         _lib.check(_lib.lib().ea_transformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
                                                        _ptr(pe16), _ptr(dpe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(),
                                                        stream), "ea_transformer_layer_bwd")
         if ctx.owns_arena:
             ctx.bind.saved_busy = False
-        ctx.bind.finish_backward()
+        _native_bwd_end(ctx.bind, dev, half, stream)
         return (dx, dpe) + (None,) * 10
 
 
@@ -1020,7 +1090,7 @@ class _DecoderLayerNative(torch.autograd.Function):
             bind.saved_busy = bool(needs_bwd)
             ctx.owns_arena = bool(needs_bwd)
         scratch = _scratch_buffer(nb_scratch.value, x.device)
-        _scratch_tag[str(x.device)] = None
+        _scratch_forward_touch(str(x.device))
         y = torch.empty_like(x)
         stream = K._stream()
         _lib.check(lib.ea_decoder_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(enc), _ptr(y), _ptr(enc_len), _ptr(saved),
@@ -1043,7 +1113,7 @@ class _DecoderLayerNative(torch.autograd.Function):
         _lib.check(_lib.lib().ea_decoder_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(enc), _ptr(dy), _ptr(dx),
                                                    _ptr(denc), _ptr(enc_len), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(),
                                                    stream), "ea_decoder_layer_bwd")
-        _scratch_tag[str(x.device)] = None
+        _scratch_forward_touch(str(x.device))
         if ctx.owns_arena:
             ctx.bind.saved_busy = False
         ctx.bind.finish_backward()

@@ -89,6 +89,27 @@ long ea_gemm_profile_read(double* total_ms, double* total_flops);
 /* writes one line per recorded launch ("M N K batch a_ks b_ks splitk bm64 epilogue-bits ms"); returns the count or -1 */
 long ea_gemm_profile_dump(const char* path);
 
+/* Grouped weight-gradient GEMM: ONE launch computes, for every problem i,
+ *   dW_i[n][k] += sum_m dy_i[m][n] * x_i[m][k]      (fp32, leading dim ldw)
+ *   db_i[n]    += sum_m dy_i[m][n]                  (when dbias != NULL)
+ * i.e. torch.nn.Linear's weight / bias gradients (torch autograd of F.linear as called by
+ * fairseq/modules/conformer_layer.py:134-146, multihead_attention.py:650-688, the pointwise convolutions :79-101) for all the
+ * Linear layers of one encoder layer at once: no split-K slabs, no reduce pass, no separate column-sum launches. */
+#define EA_WGRAD_MAX 16
+typedef struct EaWgradProblem {
+  const void* dy; /* bf16 [M][ld_dy], columns 0..N-1 */
+  const void* x;  /* bf16 [M][ld_x], columns 0..K-1 */
+  float* dW;      /* fp32 [N][ldw] */
+  float* dbias;   /* fp32 [N] or NULL */
+  int M, N, K;
+  long ld_dy, ld_x, ldw;
+} EaWgradProblem;
+typedef struct EaWgradGroup {
+  int count;
+  EaWgradProblem p[EA_WGRAD_MAX];
+} EaWgradGroup;
+int ea_wgrad_group(const EaWgradGroup* group, ea_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused
  * "dropout then zero padded rows" of espresso/models/transformer/speech_transformer_encoder.py:348-357.
@@ -110,6 +131,11 @@ int ea_layernorm_bwd_dx(const void* x, const void* dy, const float* gamma, const
                         float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero, uint64_t drop_seed,
                         uint32_t drop_thr, float drop_scale, const void* dx_add, void* workspace, ea_stream_t stream);
 int ea_layernorm_param_reduce(const void* workspace, float* dgamma, float* dbeta, int M, int C, ea_stream_t stream);
+/* the same for up to EA_LNRED_MAX LayerNorms in one launch (all LayerNorms of one encoder layer's backward) */
+#define EA_LNRED_MAX 8
+typedef struct EaLnReduceItem { const void* workspace; float* dgamma; float* dbeta; int M, C; } EaLnReduceItem;
+typedef struct EaLnReduceGroup { int count; EaLnReduceItem item[EA_LNRED_MAX]; } EaLnReduceGroup;
+int ea_layernorm_param_reduce_group(const EaLnReduceGroup* group, ea_stream_t stream);
 /* ea_layernorm_bwd_dx plus a second output out2[i] = a2 * dropout(dx[i]) with its own (seed2, thr2, scale2) mask — exactly
  * ea_scale_dropout_bf16(dx, NULL, out2, M*C, a2, 0, seed2, thr2, scale2) without the extra pass (the next residual block of
  * the backward starts with that product: FairseqDropout backward + the 0.5 FFN scale) */
@@ -331,11 +357,22 @@ typedef struct EaLayerShape {
    * layer always uses SiLU. */
   int pos_mode, act;
   int S; /* decoder layer only: padded encoder length (keys of the encoder-decoder attention); T is then the target length */
+  /* backward only (conformer / transformer encoder layers): 0 = the call returns with every gradient ordered on `stream`
+   * (side work forked and joined inside the call); 1 or 2 = DEFERRED mode using scratch half (defer - 1): the optimizer-only
+   * work (all weight / bias / LayerNorm / BatchNorm parameter gradients) is launched on the side stream at the end of the call
+   * and joined by the next backward call, which must use the other half — so it overlaps that call's data-gradient chain.
+   * The gradients of a deferred call are ordered on `stream` once the NEXT backward call, ea_backward_flush or any layer
+   * forward call has been issued; `saved` must stay alive until then. */
+  int defer;
 } EaLayerShape;
 
 /* tuning hook: run weight-gradient GEMMs / bias sums of the layer backward on a side stream (default on); returns the
  * previous value.  Sizes from ea_conformer_layer_workspace depend on this setting: query them after changing it. */
 int ea_set_backward_overlap(int on);
+/* tuning hook: honour EaLayerShape.defer (default on); returns the previous value.  Workspace sizes depend on it. */
+int ea_set_backward_deferred(int on);
+/* make `stream` wait for all deferred side work issued so far (call after the last layer backward of a pass) */
+int ea_backward_flush(ea_stream_t stream);
 int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
                            const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,

@@ -54,6 +54,81 @@ def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, 
     return rel_err(C, ref)
 
 
+def check_wgrad_group(seed=0, variant=0):
+    """ea_wgrad_group (all weight / bias gradients of a layer in one launch) vs fp32 torch on the same bf16 operands:
+    ragged N / K / M, padded leading dimensions, accumulation into non-zero dW / db, problems with and without bias."""
+    import ctypes
+
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+
+    lib = _lib.lib()
+    lib.ea_set_gemm_variant(variant)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    # (M, N, K, pad_dy, pad_x, bias)
+    probs = [(1000, 512, 128, 0, 0, True), (1000, 128, 512, 0, 8, True), (777, 200, 72, 8, 16, True), (333, 64, 136, 0, 0, False),
+             (64, 136, 40, 8, 0, True), (4100, 256, 256, 0, 0, True), (1000, 96, 128, 32, 0, False)]
+    grp = _lib.EaWgradGroup()
+    grp.count = len(probs)
+    keep, refs = [], []
+    for i, (M, N, K, pdy, px, bias) in enumerate(probs):
+        dy = bf(torch.randn(M, N + pdy, generator=g)).to(DEV)
+        x = bf(torch.randn(M, K + px, generator=g)).to(DEV)
+        dW = torch.randn(N, K, generator=g).to(DEV)
+        db = torch.randn(N, generator=g).to(DEV) if bias else None
+        refW = dW.double() + dy[:, :N].double().t() @ x[:, :K].double()
+        refb = db.double() + dy[:, :N].double().sum(0) if bias else None
+        q = grp.p[i]
+        q.dy, q.x, q.dW, q.dbias = dy.data_ptr(), x.data_ptr(), dW.data_ptr(), (db.data_ptr() if bias else None)
+        q.M, q.N, q.K, q.ld_dy, q.ld_x, q.ldw = M, N, K, N + pdy, K + px, K
+        keep.append((dy, x, dW, db))
+        refs.append((refW, refb))
+    _lib.check(lib.ea_wgrad_group(ctypes.byref(grp), Kk._stream()), "ea_wgrad_group")
+    torch.cuda.synchronize()
+    lib.ea_set_gemm_variant(0)
+    worst_w = worst_b = 0.0
+    for (dy, x, dW, db), (refW, refb) in zip(keep, refs):
+        worst_w = max(worst_w, float((dW.double() - refW).abs().max() / refW.abs().max()))
+        if db is not None:
+            worst_b = max(worst_b, float((db.double() - refb).abs().max() / refb.abs().max()))
+    return {"dW_rel": worst_w, "db_rel": worst_b}
+
+
+def check_deferred_backward_matches_immediate(layer_type="conformer", p_drop=0.0):
+    """The same update step with the layer backward's side work deferred (grouped weight-gradient launch, joined by the next
+    layer's call / the end-of-backward flush) and immediate (split-K launches joined inside every call): same loss, same
+    gradients up to the fp32 summation order."""
+    from espresso_amd import functional as F
+
+    g, sd, _, _ = load_fixture(f"ref_{layer_type}_ctc_tiny")
+    feats = torch.from_numpy(g["feats"]).to(DEV)
+    lengths = torch.from_numpy(g["lengths"]).to(DEV)
+    out = []
+    for deferred in (True, False):
+        F.set_backward_deferred(deferred)
+        try:
+            model = build_tiny_model(layer_type).to(DEV)
+            load_ref_state(model, sd)
+            model.train()
+            for rep in range(2):  # second pass: halves / scratch tags in their steady state
+                for p in model.parameters():
+                    p.grad = None
+                o = model(feats, lengths)
+                lo = o["encoder_out"][0].float()
+                (lo * torch.linspace(-1, 1, lo.shape[-1], device=DEV)).sum().backward()
+            torch.cuda.synchronize()
+            out.append({n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            F.set_backward_deferred(True)
+    worst = ("", 0.0)
+    for n in out[0]:
+        a, b = out[0][n], out[1][n]
+        e = float((a - b).abs().max() / (b.abs().max() + 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    return {"worst_grad": worst, "n": len(out[0])}
+
+
 # ------------------------------------------------------------------ model-level parity vs the reference fixture
 def load_fixture(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
