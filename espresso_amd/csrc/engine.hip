@@ -198,9 +198,17 @@ inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, 
 }
 // side-stream work after the main chain of a layer backward: ONE fork, the grouped launches, the remaining small kernels; then
 // the main stream joins the side work of the PREVIOUS backward call (other scratch half), which ran next to this call's chain
+static bool g_defer_inline = false;  // A/B switch: run the deferred work on the MAIN stream at the end of the layer (no overlap)
 static void run_deferred(Ctx& c, int half) {
   if (c.dry || !c.df) return;
   Deferred& d = *c.df;
+  if (g_defer_inline) {
+    RUN(ea_wgrad_group(&d.grp, c.s));
+    RUN(ea_layernorm_param_reduce_group(&d.ln, c.s));
+    for (auto& op : d.ops) RUN(op(c.s));
+    d.clear();
+    return;
+  }
   stream_wait(c, c.side, c.s);
   RUN(ea_wgrad_group(&d.grp, c.side));
   RUN(ea_layernorm_param_reduce_group(&d.ln, c.side));
@@ -962,6 +970,11 @@ int ea_set_backward_deferred(int on) {
   return old;
 }
 int ea_backward_flush(hipStream_t stream) { return join_all(stream); }
+int ea_set_backward_deferred_inline(int on) {
+  const int old = g_defer_inline;
+  g_defer_inline = on != 0;
+  return old;
+}
 
 // deferred mode of one backward call: requested by the caller (shape.defer = 1 + scratch half), side stream available, not
 // disabled; the learned-table attention returns `dpe` to the caller and therefore always runs its side work before returning

@@ -22,19 +22,11 @@
 #include <cstdio>
 #include "common.h"
 #include "espresso_amd.h"
+#include "gemm_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
-
-// 16-byte chunk c of LDS row r lives at chunk (c ^ (r&7) ^ ((r>>4)&7)).  The (r&7) term makes the ds_read_b128
-// fragment reads (16 consecutive rows, fixed c) conflict-free; the (r>>4) term is constant inside such a
-// 16-row group (reads unaffected) and spreads the transposing ds_write_b64 of the k-strided staging path,
-// whose 16 lanes hit rows 8 apart (same r&7), over 8 different bank slots instead of one.
-__device__ __forceinline__ uint32_t lds_off(int row, int chunk) {
-  return (uint32_t)(row * ROW_BYTES + ((chunk ^ (row & 7) ^ ((row >> 4) & 7)) << 4));
-}
+constexpr int BM = 128, BN = 128;
 
 // ---- global -> register staging -------------------------------------------------------------
 // K-contiguous operand: element (row,k) at p[row*ld + k]. Thread owns 4 chunks of 8 k.
@@ -195,17 +187,6 @@ __device__ __forceinline__ void load_kc_fast(const bf16_t* __restrict__ base, lo
 __device__ __forceinline__ void load_ks_fast(const bf16_t* __restrict__ base, long ld, int k0, uint4 (&r)[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const uint4*>(base + (long)(k0 + j) * ld);
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == EA_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == EA_ACT_SILU) return silu_f(v);
-  return v;
-}
-__device__ __forceinline__ float apply_dact(float z, int act) {
-  if (act == EA_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-  if (act == EA_ACT_SILU) return dsilu_f(z);
-  return 1.f;
 }
 
 // ---- epilogue on 8 consecutive output columns of one row --------------------------------------
@@ -933,6 +914,8 @@ static bool glds_eligible(const EaGemmParams& q) {
          ((q.sA_hi | q.sA_lo | q.sB_hi | q.sB_lo) & 7) == 0 && ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) == 0;
 }
 
+int gemm_pk_try(const EaGemmParams& q, hipStream_t stream, int* cfg_used);  // gemm_pk.hip: persistent 8-wave kernel
+
 template <bool A_KS, bool B_KS>
 static void launch_gemm(dim3 grid, bool bm64, hipStream_t stream, const EaGemmParams& q) {
   // the remap helps when several n-tiles share a row block and the grid spans many row blocks (not for batched / split launches,
@@ -979,7 +962,15 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     hipEventRecord(pr.e0, stream);
   }
   bool done = false;
-  if (g_gemm_glds && glds_eligible(q)) {
+  const bool kc_ok = glds_eligible(q);
+  if (kc_ok) {
+    int cfg = -1;
+    if (gemm_pk_try(q, stream, &cfg)) {
+      done = true;
+      pr.bm64 = 100 + cfg;
+    }
+  }
+  if (!done && g_gemm_glds && kc_ok) {
     // XCD-aware tile order when the whole B operand fits every XCD's L2 next to the streamed A rows (few n-tiles): measured
     // L2 hit rate 58 -> 82 % and -10..-20 % time on the N = 512 projections; slower for square problems (B no longer stationary)
     const int sw = ((g_xcd_swizzle & 1) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 && (grid.x > 1 || grid.z > 1)) ? 1 : 0;

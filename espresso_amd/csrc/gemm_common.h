@@ -1,0 +1,31 @@
+// Pieces shared by the GEMM kernels (gemm.hip: register-staged / direct-to-LDS / grouped weight-gradient kernels;
+// gemm_pk.hip: persistent 8-wave kernel): the LDS tile image and the activation functions of the fused epilogues.
+#pragma once
+#include "common.h"
+#include "espresso_amd.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
+
+// 16-byte chunk c of LDS row r lives at chunk (c ^ (r&7) ^ ((r>>4)&7)).  The (r&7) term makes the ds_read_b128
+// fragment reads (16 consecutive rows, fixed c) conflict-free; the (r>>4) term is constant inside such a
+// 16-row group (reads unaffected) and spreads the transposing ds_write_b64 of the k-strided staging path,
+// whose 16 lanes hit rows 8 apart (same r&7), over 8 different bank slots instead of one.
+__device__ __forceinline__ uint32_t lds_off(int row, int chunk) {
+  return (uint32_t)(row * ROW_BYTES + ((chunk ^ (row & 7) ^ ((row >> 4) & 7)) << 4));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == EA_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == EA_ACT_SILU) return silu_f(v);
+  return v;
+}
+__device__ __forceinline__ float apply_dact(float z, int act) {
+  if (act == EA_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == EA_ACT_SILU) return dsilu_f(z);
+  return 1.f;
+}
+
+}  // namespace

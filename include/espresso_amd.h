@@ -84,6 +84,10 @@ int ea_set_gemm_variant(int v);
 int ea_set_gemm_xcd_swizzle(int mask);
 /* tuning hook: direct-to-LDS ring kernel for launches whose operands are both k-contiguous (0 = off, 1 = automatic ring depth, 2..4 = forced number of stages); returns the previous value */
 int ea_set_gemm_glds(int stages);
+/* tuning hook: persistent 8-wave kernel (csrc/gemm_pk.hip) for launches whose operands are both k-contiguous: 0 = off,
+ * 1 = automatic tile configuration, 2 + c = configuration c forced (0: 256x128, 1: 192x128, 2: 128x128 tiles);
+ * returns the previous value */
+int ea_set_gemm_persistent(int mode);
 int ea_gemm_profile_enable(int on);
 long ea_gemm_profile_read(double* total_ms, double* total_flops);
 /* writes one line per recorded launch ("M N K batch a_ks b_ks splitk bm64 epilogue-bits ms"); returns the count or -1 */
@@ -371,6 +375,8 @@ typedef struct EaLayerShape {
 int ea_set_backward_overlap(int on);
 /* tuning hook: honour EaLayerShape.defer (default on); returns the previous value.  Workspace sizes depend on it. */
 int ea_set_backward_deferred(int on);
+/* tuning hook (A/B): run the deferred work on the caller's stream at the end of each layer backward instead of the side stream */
+int ea_set_backward_deferred_inline(int on);
 /* make `stream` wait for all deferred side work issued so far (call after the last layer backward of a pass) */
 int ea_backward_flush(ea_stream_t stream);
 int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
