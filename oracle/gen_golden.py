@@ -62,10 +62,12 @@ def build_ref_encoder(cfg, vocab):
     return SpeechTransformerEncoderForPrediction(cfg, pre_encoder=pre, input_size=20 * ch[-1], vocab_size=vocab)
 
 
-def encoder_fixture(layer_type, name, learned_pos=False):
+def encoder_fixture(layer_type, name, learned_pos=False, d=64, heads=4, ffn=128, frames=70):
+    """`d=128, heads=2` gives head dim 64 — the shape class of the recipes (512 / 8) that runs on the fused attention kernels;
+    `frames=300` makes 75 encoder frames, i.e. more than one 64-key tile of those kernels."""
     torch.manual_seed(1234)
     V = 40
-    cfg = ref_config(layer_type)
+    cfg = ref_config(layer_type, d=d, heads=heads, ffn=ffn)
     if learned_pos:  # LibriSpeech enc-dec recipes: learned relative positions, one table per layer, full embedding dim
         cfg.encoder.learned_pos = True
         cfg.encoder.share_learned_relative_positional_embeddings_across_layers = False
@@ -81,8 +83,8 @@ def encoder_fixture(layer_type, name, learned_pos=False):
                 b.copy_(0.1 * torch.randn_like(b))
             if "running_var" in n:
                 b.copy_(1.0 + 0.2 * torch.rand_like(b))
-    B, T = 3, 70
-    lengths = torch.tensor([70, 61, 37])
+    B, T = 3, frames
+    lengths = torch.tensor([frames, frames * 61 // 70, frames * 37 // 70])
     feats = torch.randn(B, T, 80)
     for b in range(B):
         feats[b, lengths[b]:] = 0.0
@@ -126,7 +128,7 @@ def encoder_fixture(layer_type, name, learned_pos=False):
     print(name, "loss", loss.item(), "params", sum(p.numel() for p in enc.parameters()))
 
 
-def encdec_fixture(name="ref_transformer_encdec_tiny"):
+def encdec_fixture(name="ref_transformer_encdec_tiny", dm=64, heads=4, ffn=128, frames=70):
     """speech_transformer_base (conv front-end + rel-pos Transformer encoder + 2-layer decoder) with
     label_smoothed_cross_entropy_v2 (uniform, eps 0.1): logits, loss, gradients from the reference's own code."""
     import ast
@@ -136,10 +138,10 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
 
     torch.manual_seed(4321)
     V = 40
-    cfg = ref_config("transformer")
+    cfg = ref_config("transformer", d=dm, heads=heads, ffn=ffn)
     d = cfg.decoder
-    d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads = 64, 128, 2, 4
-    d.input_dim = d.output_dim = 64
+    d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads = dm, ffn, 2, heads
+    d.input_dim = d.output_dim = dm
     d.normalize_before, d.learned_pos, d.relative_positional_embeddings = True, False, False
     d.layerdrop = 0.0
     d.xformers_att_config = None
@@ -170,8 +172,8 @@ def encdec_fixture(name="ref_transformer_encdec_tiny"):
         for n, p in model.named_parameters():
             if p.dim() == 1:
                 p.add_(0.1 * torch.randn_like(p))
-    B, Tn = 3, 70
-    lengths = torch.tensor([70, 61, 37])
+    B, Tn = 3, frames
+    lengths = torch.tensor([frames, frames * 61 // 70, frames * 37 // 70])
     feats = torch.randn(B, Tn, 80)
     for b in range(B):
         feats[b, lengths[b]:] = 0.0
@@ -1043,6 +1045,11 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "encdec":
         encdec_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dh64":  # head dim 64: the fused-attention / native-runtime shape class
+        encoder_fixture("conformer", "ref_conformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
+        encoder_fixture("transformer", "ref_transformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
+        encdec_fixture("ref_transformer_encdec_dh64", dm=128, heads=2, ffn=256, frames=300)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "speechlstm":
         speech_lstm_fixture()

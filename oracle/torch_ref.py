@@ -10,6 +10,51 @@ import torch
 import torch.nn.functional as F
 
 
+# ---- bf16 emulation of the HIP path's storage points -------------------------------------------------------------------
+# The HIP path computes in fp32 (MFMA accumulators, LayerNorm / softmax / BatchNorm statistics) and rounds to bf16 exactly where
+# a tensor is STORED to HBM: the bf16 weight shadows, every GEMM output (after bias / activation / residual in the fused
+# epilogue), LayerNorm / BatchNorm / GLU / depthwise-conv outputs, the scaled queries, the attention probabilities that multiply
+# V, the attention output.  With `bf16_emulation(True)` this restatement rounds at the same points (forward value AND the
+# gradient flowing back through the point — the HIP backward stores its gradients in bf16 at the same tensor boundaries), so a
+# comparison HIP vs emulation isolates real arithmetic differences from the expected bf16 rounding of the reference's fp32 run.
+_EMU = {"on": False, "flash": True}
+
+
+class bf16_emulation:
+    """Context manager: `with torch_ref.bf16_emulation(flash=True): torch_ref.encoder(...)`.  `flash`: head dim 64 (fused
+    kernels: un-normalised bf16 probabilities, fp32 normaliser) vs the unfused path (normalised probabilities rounded)."""
+
+    def __init__(self, on=True, flash=True):
+        self.new = {"on": on, "flash": flash}
+
+    def __enter__(self):
+        self.old = dict(_EMU)
+        _EMU.update(self.new)
+
+    def __exit__(self, *a):
+        _EMU.update(self.old)
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _r(x):
+    """Storage point: identity in the fp32 restatement, bf16 round trip under emulation."""
+    return _RoundBF16.apply(x) if _EMU["on"] and x.is_floating_point() else x
+
+
+def _lin(x, w, b=None):
+    """Linear on the (bf16 shadow of the) weight, fp32 accumulation; the caller rounds where the result is stored."""
+    return F.linear(x, _r(w), b)
+
+
 def sinusoidal_rel_pe(seq_len, dim):
     """espresso/modules/sinusoidal_relative_positional_embedding.py:46-71,112-124 with
     scale_embedding (relative_positional_embedding.py:28-34): rows = offsets -(L-1)..(L-1)."""
@@ -24,21 +69,22 @@ def sinusoidal_rel_pe(seq_len, dim):
 
 
 def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
-    """fairseq/modules/multihead_attention.py:650-907 (rel-pos branch).  x: (T, B, C)."""
+    """fairseq/modules/multihead_attention.py:650-907 (rel-pos branch).  x: (T, B, C).  Returns the out_proj output BEFORE the
+    residual add (the HIP epilogue adds the residual in fp32 and stores once)."""
     T, B, C = x.shape
     dh = C // H
     scaling = dh ** -0.5
-    q = F.linear(x, sd[prefix + "q_proj.weight"], sd[prefix + "q_proj.bias"])
-    k = F.linear(x, sd[prefix + "k_proj.weight"], sd[prefix + "k_proj.bias"])
-    v = F.linear(x, sd[prefix + "v_proj.weight"], sd[prefix + "v_proj.bias"])
+    q = _r(_lin(x, sd[prefix + "q_proj.weight"], sd[prefix + "q_proj.bias"]))
+    k = _r(_lin(x, sd[prefix + "k_proj.weight"], sd[prefix + "k_proj.bias"]))
+    v = _r(_lin(x, sd[prefix + "v_proj.weight"], sd[prefix + "v_proj.bias"]))
     relpos = (prefix + "pos_bias_u") in sd
     learned = (prefix + "positional_embedding.weight") in sd  # learned relative table: used as is, plain queries (:806-815)
     if learned:
-        qv = (q * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
+        qv = _r(q * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
     if relpos:
-        qv = ((q + sd[prefix + "pos_bias_v"]) * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
+        qv = _r((q + sd[prefix + "pos_bias_v"]) * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
         q = q + sd[prefix + "pos_bias_u"]
-    q = (q * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
+    q = _r(q * scaling).contiguous().view(T, B * H, dh).transpose(0, 1)
     k = k.contiguous().view(T, B * H, dh).transpose(0, 1)
     v = v.contiguous().view(T, B * H, dh).transpose(0, 1)
     w = torch.bmm(q, k.transpose(1, 2))
@@ -46,12 +92,12 @@ def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
         if learned:
             tab = sd[prefix + "positional_embedding.weight"]  # learned_relative_positional_embedding.py:71-80: centre slice
             start = tab.shape[0] // 2 - T + 1
-            pe = tab[start: start + 2 * T - 1]
+            pe = _r(tab[start: start + 2 * T - 1])
             if pe.shape[1] != C:
                 pe = pe.repeat(1, H)
         else:
-            pe = sinusoidal_rel_pe(T, C)
-            pe = F.linear(pe, sd[prefix + "pos_proj.weight"])  # (2T-1, C), same for every batch element
+            pe = _r(sinusoidal_rel_pe(T, C))
+            pe = _r(_lin(pe, sd[prefix + "pos_proj.weight"]))  # (2T-1, C), same for every batch element
         pe = pe.view(1, 2 * T - 1, H, dh).expand(B, -1, -1, -1).transpose(1, 2).reshape(B * H, 2 * T - 1, dh)
         raw = torch.bmm(qv, pe.transpose(1, 2))  # (BH, T, 2T-1)
         i = torch.arange(T).unsqueeze(1)
@@ -61,21 +107,27 @@ def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
         w = w + attn_mask.unsqueeze(0)
     if key_padding_mask is not None:
         w = w.view(B, H, T, T).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(B * H, T, T)
-    p = torch.softmax(w.float(), dim=-1)
-    a = torch.bmm(p, v).transpose(0, 1).contiguous().view(T, B, C)
-    return F.linear(a, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+    if _EMU["on"] and _EMU["flash"]:
+        # fused kernels: bf16 un-normalised probabilities feed P.V, the normaliser is the fp32 sum of the un-rounded ones
+        pu = torch.exp(w.float() - w.float().max(dim=-1, keepdim=True).values)
+        a = torch.bmm(_r(pu), v) / pu.sum(-1, keepdim=True)
+    else:
+        p = _r(torch.softmax(w.float(), dim=-1))
+        a = torch.bmm(p, v)
+    a = _r(a).transpose(0, 1).contiguous().view(T, B, C)
+    return _lin(a, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
 def _ln(x, sd, prefix):
-    return F.layer_norm(x, (x.shape[-1],), sd[prefix + "weight"], sd[prefix + "bias"], 1e-5)
+    return _r(F.layer_norm(x, (x.shape[-1],), sd[prefix + "weight"], sd[prefix + "bias"], 1e-5))
 
 
 def _ffn_conformer(x, sd, p):
     """fairseq/modules/conformer_layer.py:134-146 (swish)."""
     y = _ln(x, sd, p + "layer_norm.")
-    y = F.linear(y, sd[p + "w_1.weight"], sd[p + "w_1.bias"])
-    y = F.silu(y)
-    return F.linear(y, sd[p + "w_2.weight"], sd[p + "w_2.bias"])
+    y = _lin(y, sd[p + "w_1.weight"], sd[p + "w_1.bias"])
+    y = _r(F.silu(y))  # (the HIP epilogue applies the activation to the fp32 accumulator and stores the result)
+    return _lin(y, sd[p + "w_2.weight"], sd[p + "w_2.bias"])
 
 
 def _bn(x, sd, p, training, dim_c=1, momentum=0.1, eps=1e-5, update=None):
@@ -89,33 +141,33 @@ def _bn(x, sd, p, training, dim_c=1, momentum=0.1, eps=1e-5, update=None):
 def conv_module(x_btc, sd, p, training, update=None):
     """fairseq/modules/conformer_layer.py:79-101.  x: (B, T, C)."""
     y = _ln(x_btc, sd, p + "layer_norm.").transpose(1, 2)
-    y = F.conv1d(y, sd[p + "pointwise_conv1.weight"])
-    y = F.glu(y, dim=1)
-    w = sd[p + "depthwise_conv.weight"]
-    y = F.conv1d(y, w, padding=(w.shape[-1] - 1) // 2, groups=w.shape[0])
+    y = _r(F.conv1d(y, _r(sd[p + "pointwise_conv1.weight"])))
+    y = _r(F.glu(y, dim=1))
+    w = sd[p + "depthwise_conv.weight"]  # (fp32 in the HIP kernel)
+    y = _r(F.conv1d(y, w, padding=(w.shape[-1] - 1) // 2, groups=w.shape[0]))
     y = _bn(y, sd, p + "batch_norm.", training, update=update)
-    y = F.silu(y)
-    y = F.conv1d(y, sd[p + "pointwise_conv2.weight"])
+    y = _r(F.silu(y))
+    y = F.conv1d(y, _r(sd[p + "pointwise_conv2.weight"]))
     return y.transpose(1, 2)
 
 
 def conformer_layer(x, sd, p, H, key_padding_mask, training, update=None, attn_mask=None):
     """espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:112-141.  x: (T,B,C)."""
-    x = 0.5 * _ffn_conformer(x, sd, p + "ffn1.") + x
-    x = relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x
-    x = conv_module(x.transpose(0, 1), sd, p + "conv_module.", training, update).transpose(0, 1) + x
-    x = 0.5 * _ffn_conformer(x, sd, p + "ffn2.") + x
+    x = _r(0.5 * _ffn_conformer(x, sd, p + "ffn1.") + x)
+    x = _r(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x)
+    x = _r(conv_module(x.transpose(0, 1), sd, p + "conv_module.", training, update).transpose(0, 1) + x)
+    x = _r(0.5 * _ffn_conformer(x, sd, p + "ffn2.") + x)
     return _ln(x, sd, p + "final_layer_norm.")
 
 
 def transformer_layer(x, sd, p, H, key_padding_mask, activation="relu", attn_mask=None):
     """fairseq/modules/transformer_layer.py:163-226 with normalize_before=True."""
-    x = relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x
+    x = _r(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x)
     y = _ln(x, sd, p + "final_layer_norm.")
-    y = F.linear(y, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
-    y = F.relu(y) if activation == "relu" else F.silu(y)
-    y = F.linear(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
-    return x + y
+    y = _lin(y, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
+    y = _r(F.relu(y) if activation == "relu" else F.silu(y))
+    y = _lin(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return _r(x + y)
 
 
 def conv_bn_relu(feats, lengths, sd, p, strides, training, update=None):
@@ -126,8 +178,11 @@ def conv_bn_relu(feats, lengths, sd, p, strides, training, update=None):
     i = 0
     while (p + f"convolutions.{i}.weight") in sd:
         s = strides[i]
-        x = F.conv2d(x, sd[p + f"convolutions.{i}.weight"], sd[p + f"convolutions.{i}.bias"], stride=s, padding=1)
-        x = F.relu(_bn(x, sd, p + f"batchnorms.{i}.", training, update=update))
+        w = sd[p + f"convolutions.{i}.weight"]
+        if i > 0:
+            w = _r(w)  # (the first layer's 1-channel 3x3 kernel runs on fp32 features with fp32 weights; the others on MFMA)
+        x = _r(F.conv2d(x, w, sd[p + f"convolutions.{i}.bias"], stride=s, padding=1))
+        x = _r(F.relu(_bn(x, sd, p + f"batchnorms.{i}.", training, update=update)))
         out_len = torch.div(out_len + s[0] - 1, s[0], rounding_mode="floor")
         i += 1
     x = x.transpose(1, 2).contiguous()
@@ -148,7 +203,7 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
 
     sd = {k: _t(v) for k, v in sd.items()}
     x, out_len, pad = conv_bn_relu(feats.float(), lengths, sd, "pre_encoder.", strides, training, update)
-    x = F.linear(x, sd["fc0.weight"], sd["fc0.bias"])
+    x = _r(_lin(x, sd["fc0.weight"], sd["fc0.bias"]))
     x = _ln(x, sd, "layernorm_embedding.")
     x = x * (1 - pad.unsqueeze(-1).float())
     x = x.transpose(0, 1)
@@ -164,7 +219,7 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
     if "layer_norm.weight" in sd:
         x = _ln(x, sd, "layer_norm.")
     if "fc_out.weight" in sd:
-        x = F.linear(x, sd["fc_out.weight"], sd["fc_out.bias"])
+        x = _r(_lin(x, sd["fc_out.weight"], sd["fc_out.bias"]))
     return x, out_len
 
 

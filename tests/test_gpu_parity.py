@@ -115,18 +115,33 @@ def test_adam_clip():
     assert r["bf16_exact"], r
 
 
-@pytest.mark.parametrize("layer_type", ["conformer", "transformer", "transformer_learnedpos"])
-def test_encoder_vs_reference_fixture(layer_type):
-    r = G.check_encoder_vs_reference(layer_type)
+ENC_FIXTURES = [("conformer", "ref_conformer_ctc_tiny"), ("transformer", "ref_transformer_ctc_tiny"),
+                ("transformer", "ref_transformer_learnedpos_ctc_tiny"),
+                # head dim 64 = the recipes' shape class: fused attention kernels, 75 encoder frames (two key tiles)
+                ("conformer", "ref_conformer_ctc_dh64"), ("transformer", "ref_transformer_ctc_dh64")]
+
+
+@pytest.mark.parametrize("layer_type,fixture", ENC_FIXTURES)
+def test_encoder_vs_reference_fixture(layer_type, fixture):
+    r = G.check_encoder_vs_reference(layer_type, fixture=fixture)
     print(r)
     assert r["eval_lengths_equal"]
-    # bf16 compute vs the reference's fp32 run: north_star tolerance 1e-2 on log-probs/losses (relative for the loss)
+    # (a) bf16 compute vs the reference's own fp32 outputs: north_star tolerance 1e-2 on losses / log-probs.  Logits here have
+    #     magnitude up to 4, where ONE bf16 step is 0.0156-0.031: 1e-2 relative to the logit scale = 4e-2 absolute.
     assert abs(r["train_loss"] - r["ref_loss"]) / r["ref_loss"] < 1e-2, r
-    assert r["eval_logits_abs"] < 6e-2, r
-    assert r["train_logits_abs"] < 6e-2, r
+    assert r["eval_logits_abs"] < 4e-2 and r["train_logits_abs"] < 5e-2, r
+    # greedy ids identical to the reference's wherever its own top-2 margin exceeds the bf16 noise floor
+    assert r["clear_margin_frames"] >= 30 and r["eval_greedy_agree_clear_margin"] == 1.0, r
     assert r["eval_greedy_agree"] > 0.9, r
-    assert r["worst_grad"][1] < 0.2, r
-    assert r["bn_running_abs"] < 2e-2, r
+    assert r["bn_running_abs"] < 1e-3, r
+    # (b) vs the bf16-emulating oracle (rounds where the HIP path stores): what is left is accumulation order and single-step
+    #     rounding flips — logits within 2 bf16 steps of the largest logit, gradients within 8 % of each tensor's scale in the
+    #     worst tensor and 1.2 % in the median one (vs 13-67 % against the fp32 run: the bound that would have hidden a real bug)
+    assert abs(r["train_loss"] - r["emu_loss"]) / r["emu_loss"] < 2e-3, r
+    assert r["eval_logits_vs_emulation"] < 3.2e-2 and r["train_logits_vs_emulation"] < 4e-2, r
+    assert r["eval_logits_identical_frac"] > 0.3, r
+    assert r["worst_grad_vs_emulation"][1] < 8e-2 and r["median_grad_vs_emulation"] < 1.2e-2, r
+    assert r["worst_grad"][1] < 0.75, r  # against the fp32 run: informational (expected bf16 cancellation in BatchNorm sums)
 
 
 def test_native_layer_runtime_matches_kernel_composition():
@@ -152,24 +167,30 @@ def test_ctc_greedy_decoder_bit_exact():
     assert all(r["utts_equal_to_reference_fp32_decode"]), r  # greedy ids identical to the reference's fp32 run
 
 
-def test_encdec_label_smoothed_ce_vs_reference_fixture():
-    r = G.check_encdec_vs_reference()
+@pytest.mark.parametrize("fixture", ["ref_transformer_encdec_tiny", "ref_transformer_encdec_dh64"])
+def test_encdec_label_smoothed_ce_vs_reference_fixture(fixture):
+    r = G.check_encdec_vs_reference(fixture)
     print(r)
     assert abs(r["loss"] - r["ref_loss"]) / r["ref_loss"] < 1e-2, r
     assert abs(r["nll"] - r["ref_nll"]) / r["ref_nll"] < 1e-2, r
-    assert r["eval_logits_abs_valid"] < 6e-2, r
-    assert r["eval_greedy_agree"] > 0.9, r
+    assert r["eval_logits_abs_valid"] < 4e-2, r
+    assert r["eval_greedy_agree"] > 0.9 and r["eval_greedy_agree_clear_margin"] == 1.0, r
     # bf16 activations: gradients of the conv front-end (behind 2+2 attention stacks and four BatchNorms) are sums with
     # heavy cancellation, so their error relative to the tensor maximum is the loosest; everything else is within 20 %.
     for n, e in r["worst5"]:
         assert e < (0.5 if "pre_encoder" in n else 0.2), (n, e, r)
 
 
-def test_beam_search_vs_reference_generator():
-    r = G.check_beam_search_vs_reference()
+@pytest.mark.parametrize("fixture", ["ref_transformer_encdec_tiny", "ref_transformer_encdec_dh64"])
+def test_beam_search_vs_reference_generator(fixture):
+    r = G.check_beam_search_vs_reference(fixture)
     print(r)
     assert r["incremental_vs_full_forward_abs"] < 5e-2, r   # KV-cache path == teacher-forced path (bf16)
-    assert r["forced_decode_pos_score_abs"] < 0.1, r         # the reference generator's own positional scores reproduced
+    assert r["forced_decode_pos_score_abs"] < 3e-2, r        # the reference generator's own positional scores reproduced
+    # greedy token identity along the reference's beam-1 hypotheses at every step with a defined arg-max
+    assert r["greedy_clear_margin_steps"] >= 5 and r["greedy_clear_margin_agree"] == 1.0, r
+    if fixture.endswith("dh64"):  # no near-ties on this fixture's greedy paths: the decoded sequences themselves are identical
+        assert all(r["b1"]["top1_tokens_equal"]), r
     # The random-weight fixture has competing hypotheses 0.02 apart in normalised score (see oracle/gen_golden.py output), so
     # token-level agreement of the beams is reported, not asserted; beam-search SEMANTICS are pinned by the scripted
     # known-answer tests (tests/test_sequence_generator.py).
@@ -429,6 +450,19 @@ def test_fullsize_frontend_batch_independence():
 def test_fullsize_attention_properties():
     r = G.check_fullsize_attention()
     assert r["finite"] and r["ones_abs"] < 1.6e-2 and r["pad_independence_abs"] == 0.0, r
+
+
+@pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
+def test_fullsize_layer_vs_oracle(layer_type):
+    """embed 512 / 8 heads / FFN 2048 (config 3's layer) against the pinned oracle on the same random weights."""
+    r = G.check_fullsize_layer_vs_oracle(layer_type)
+    print(r)
+    assert r["n_grads"] > 30
+    assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r          # north_star: 1e-2 (bf16) on losses
+    assert r["eval_logits_vs_fp32"] < 1e-2 * max(4.0, r["logit_scale"]), r           # ... and log-probs, relative to their scale
+    assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 2e-3, r
+    assert r["eval_logits_vs_emu"] < 8e-3 * max(4.0, r["logit_scale"]), r
+    assert r["worst_grad_vs_emu"][1] < 8e-2 and r["median_grad_vs_emu"] < 1.2e-2, r
 
 
 def test_fullsize_encoder_batch_independence():

@@ -15,16 +15,18 @@ def _load(golden_dir, name):
     return g, sd
 
 
-@pytest.mark.parametrize("layer_type", ["conformer", "transformer", "transformer_learnedpos"])
-def test_encoder_restatement_matches_reference(golden_dir, layer_type):
-    g, sd = _load(golden_dir, f"ref_{layer_type}_ctc_tiny")
-    layer_type = layer_type.split("_")[0]
+@pytest.mark.parametrize("layer_type,fixture,H", [("conformer", "ref_conformer_ctc_tiny", 4), ("transformer", "ref_transformer_ctc_tiny", 4),
+                                                  ("transformer", "ref_transformer_learnedpos_ctc_tiny", 4),
+                                                  ("conformer", "ref_conformer_ctc_dh64", 2), ("transformer", "ref_transformer_ctc_dh64", 2)])
+def test_encoder_restatement_matches_reference(golden_dir, layer_type, fixture, H):
+    """`*_dh64`: embed 128 / 2 heads = head dim 64 (the recipes' 512 / 8 shape class, fused attention kernels), 75 encoder frames."""
+    g, sd = _load(golden_dir, fixture)
     feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
-    lo, ol = torch_ref.encoder(feats, lengths, sd, H=4, layer_type=layer_type, training=False)
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=H, layer_type=layer_type, training=False)
     assert ol.tolist() == g["out::out_lengths"].tolist()
     assert float((lo - torch.from_numpy(g["out::eval_logits"])).abs().max()) < 1e-5
     upd = {}
-    lo, ol = torch_ref.encoder(feats, lengths, sd, H=4, layer_type=layer_type, training=True, update=upd)
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=H, layer_type=layer_type, training=True, update=upd)
     assert float((lo - torch.from_numpy(g["out::train_logits"])).abs().max()) < 1e-5
     tgt = torch.from_numpy(g["targets"])
     tl = (tgt != 1).sum(-1)
