@@ -135,7 +135,122 @@ def cpu_baseline(n_threads=None, seconds_per_utt=12.0, n_utts=4, steps=3):
                       f"oracle/torch_ref.py + oracle/fbank_ref.py + torch Adam; {t:.2f} s/step"}
 
 
-def main():
+def decode_bench(device, n_utts=200, beam=10, seed=3):
+    """BASELINE config 5 (SURVEY §8d decode workload): espresso/speech_recognize.py's batched beam search at beam 10 with
+    look-ahead word-LM fusion — conv4 + 12-layer rel-pos Transformer encoder + 6-layer attention decoder, character units,
+    65 000-word lexicon prefix tree + 3 x 1200 word LSTM LM (random init: every hypothesis runs to max_len = 0.08 * frames, the
+    worst case), dev-other-like synthetic utterances (mean 6.4 s), batches of <= 15 000 frames / 24 utterances, front-end and
+    encoder inside the timed region.  Returns the `decode` block of the bench line."""
+    from espresso_amd.data import synthetic
+    from espresso_amd.data.asr_dictionary import AsrDictionary
+    from espresso_amd.models.lstm_lm import LSTMLanguageModelEspresso
+    from espresso_amd.models.tensorized_lookahead_language_model import TensorizedLookaheadLanguageModel
+    from espresso_amd.models.transformer.speech_transformer_base import SpeechTransformerModelBase
+    from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
+    from espresso_amd.sequence_generator import SequenceGenerator
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
+
+    torch.manual_seed(1)
+    chars = [chr(ord("a") + i) for i in range(26)] + ["'", ".", "-"] + [f"<n{i}>" for i in range(18)]
+    d = AsrDictionary.from_symbols(chars, enable_bos=False)
+    task = SpeechRecognitionEspressoTask.setup_task(
+        SpeechRecognitionEspressoConfig(seed=1, autoregressive=True, criterion_name="label_smoothed_cross_entropy_v2"), tgt_dict=d)
+    cfg = SpeechTransformerConfig()
+    e, dc = cfg.encoder, cfg.decoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, 12, 8
+    e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "transformer"
+    e.conv_channels = "[64, 64, 128, 128]"
+    dc.embed_dim, dc.ffn_embed_dim, dc.layers, dc.attention_heads, dc.normalize_before = 512, 2048, 6, 8, True
+    dc.input_dim = dc.output_dim = 512
+    cfg.layernorm_embedding = True
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 1024
+    model = SpeechTransformerModelBase.build_model(cfg, task).to(device).eval()
+    rng = np.random.default_rng(7)
+    words = set()
+    while len(words) < 65000:  # random lexicon over the 26 letters, lengths 2..10
+        words.add("".join(chr(ord("a") + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(2, 11)))))
+    wd = AsrDictionary.from_symbols(sorted(words), enable_bos=False, add_space=False)
+
+    class _LMTask:
+        word_dictionary = target_dictionary = source_dictionary = wd
+    wlm = LSTMLanguageModelEspresso.build_model(dict(arch="lstm_wordlm_wsj", dropout=0.0), _LMTask).to(device).eval()
+    lm = TensorizedLookaheadLanguageModel(wlm, d, oov_penalty=1e-4, open_vocab=True)
+    batches, n_samples = synthetic.make_batches(2864, max_tokens=15000, max_sentences=24, seed=seed, median_s=5.35, sigma=0.6)
+    picked, n = [], 0
+    for b in batches:  # the first batches of the shuffled plan until n_utts utterances
+        picked.append(b)
+        n += len(b)
+        if n >= n_utts:
+            break
+    samples = [synthetic.make_sample(b, n_samples, len(d), d.pad(), device, seed=seed) for b in [batches[-1]] + picked]
+    task.build_frontend(device)
+    gen = SequenceGenerator([model], d, beam_size=beam, max_len_a=0.08, max_len_b=0, lm_model=lm, lm_weight=0.47, eos_factor=1.5)
+
+    def run(smp):
+        return gen.generate([model], task.prepare_sample(smp, train=False))
+
+    run(samples[0])  # warm-up (allocator, positional tables)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ntok = nhyp_tok = 0
+    for smp in samples[1:]:
+        hyps = run(smp)
+        ntok += sum(len(h[0]["tokens"]) for h in hyps)
+        nhyp_tok += sum(len(h[0]["tokens"]) for h in hyps) * beam
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    audio = sum(smp["audio_seconds"] for smp in samples[1:])
+    nsent = sum(smp["nsentences"] for smp in samples[1:])
+    block = {"metric": "decode RTF @ beam 10 (lower is better)", "rtf": el / audio, "beam": beam,
+             "lm_fusion": "look-ahead word LM (65k-word prefix tree, 3x1200 LSTM), lm_weight 0.47, eos_factor 1.5",
+             "sentences": nsent, "audio_seconds": audio, "wall_seconds": el, "sentences_per_s": nsent / el,
+             "best_hyp_tokens_per_s": ntok / el, "hypothesis_tokens_per_s": nhyp_tok / el,
+             "workload": f"{nsent} of the 2864 synthetic dev-other-like utterances of SURVEY 8(d) (mean {audio / nsent:.1f} s), "
+                         "<=15000 frames & <=24 utts per batch, max_len 0.08*frames, conv4 + Transformer-12 encoder + 6-layer decoder, "
+                         "bf16, random init (every hypothesis runs to max_len: worst case)",
+             "target_rtf": 0.05}
+    return block, model, d
+
+
+def decode_cpu_baseline(model, d, n_utts=6, seconds=6.4, beam=10):
+    """CPU leg of the decode block: oracle/decode_ref.py (fp32 restatement of incremental beam-search decoding) with the SAME
+    encoder-decoder weights on a bounded sample, host cores of this box; no LM fusion (the CPU side has no look-ahead-LM
+    restatement — the baseline is therefore the cheaper task)."""
+    from oracle import decode_ref, fbank_ref
+    from espresso_amd.data import synthetic
+
+    sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(5)
+    n = int(seconds * 16000)
+    feats = torch.from_numpy(np.stack([fbank_ref.fbank(synthetic.waveform(n, rng)) for _ in range(n_utts)]))
+    lengths = torch.full((n_utts,), feats.shape[1])
+    t0 = time.perf_counter()
+    decode_ref.beam_search(feats, lengths, sd, H=8, pad=d.pad(), eos=d.eos(), unk=d.unk(), beam=beam, max_len_a=0.08)
+    el = time.perf_counter() - t0
+    return {"rtf": el / (n_utts * seconds), "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_utts} x {seconds:.0f} s utterances, beam {beam}, fp32, oracle/decode_ref.py (fbank excluded), no LM fusion; {el:.1f} s"}
+
+
+def spawn_ranks(n, fn, args=()):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this node (one per GPU) with the rendezvous environment the
+    driver's torch.distributed.run launch would provide, wait for them, propagate failures."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_entry, args=(n, port, fn, args), nprocs=n, join=True)
+
+
+def _rank_entry(local_rank, world, port, fn, args):
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    fn(*args)
+
+
+def main(argv=None):
     # stdout carries exactly ONE JSON line: native libraries that print to fd 1 (RCCL's version banner under the image's
     # NCCL_DEBUG=VERSION, rocm tools) are redirected to stderr; the JSON goes to a private duplicate of the original stdout
     sys.stdout.flush()
@@ -148,6 +263,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the config-5 decode block (beam-10 RTF)")
+    ap.add_argument("--decode-utts", type=int, default=1000, help="utterances of the 2864-utterance decode workload to time")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-dump", default=None, help="write the per-launch GEMM records of the roofline replay to this file")
     ap.add_argument("--n-utts", type=int, default=20000)
@@ -158,7 +275,12 @@ def main():
     ap.add_argument("--gemm-pk", type=int, default=None, help="A/B switch: persistent GEMM kernel (0 off, 1 automatic, 2+c configuration c)")
     ap.add_argument("--deferred-inline", action="store_true", help="A/B switch: deferred side work on the main stream (no overlap)")
     ap.add_argument("--no-deferred", action="store_true", help="A/B switch: layer backward joins its side work inside every call")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under torch.distributed.run: spawn one rank per GPU ourselves (rank 0 prints the line on the inherited stdout)
+        os.dup2(json_fd, 1)
+        spawn_ranks(args.gpus, main, (sys.argv[1:] if argv is None else argv,))
+        return
     if args.no_bwd_overlap:
         from espresso_amd._lib import lib as _ealib
         _ealib().ea_set_backward_overlap(0)
@@ -188,6 +310,9 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if world != args.gpus or (dist.is_initialized() and dist.get_world_size() != args.gpus and world > 1):
+        raise RuntimeError(f"--gpus {args.gpus} but the communicator has {world} rank(s): launch with "
+                           f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}` or plain `python bench.py --gpus {args.gpus}`")
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
 
@@ -225,11 +350,15 @@ def main():
     elapsed = time.perf_counter() - t0
     audio = sum(s["audio_seconds"] for s in samples[args.warmup:])
     tens = torch.tensor([elapsed, audio], dtype=torch.float64, device=device)
+    per_rank_ms = [elapsed * 1e3 / args.steps]
     if world > 1:
         mx = tens.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tens.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        each = [torch.zeros_like(tens) for _ in range(world)]
+        dist.all_gather(each, tens)
+        per_rank_ms = [float(t[0]) * 1e3 / args.steps for t in each]
         elapsed, audio = float(mx[0]), float(sm[1])
     loss_stats = trainer._stats.clone()
 
@@ -267,6 +396,13 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    decode = None
+    if rank == 0 and world == 1 and not args.no_decode:
+        del trainer, model, criterion, samples  # the decode model gets the GPU to itself
+        torch.cuda.empty_cache()
+        decode, dmodel, ddict = decode_bench(device, n_utts=args.decode_utts)
+        if not args.no_cpu_baseline:
+            decode["cpu_baseline"] = decode_cpu_baseline(dmodel, ddict)
 
     if rank == 0:
         value = audio / 3600.0 / elapsed
@@ -287,9 +423,11 @@ def main():
                                    "V=5004, on-GPU fbank+CMVN+SpecAugment, dropout 0.1, clip 2.0, Adam",
                        "parallelism": f"dp{world}", "audio_seconds_per_step_per_gpu": audio / args.steps / world,
                        "last_loss_per_sentence": float(loss_stats[1] / max(1.0, float(loss_stats[0]))),
-                       "host_enqueue_ms_per_step": host_enqueue * 1e3 / args.steps},
+                       "host_enqueue_ms_per_step": host_enqueue * 1e3 / args.steps,
+                       "per_rank_ms_per_step": per_rank_ms},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "decode": decode,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

@@ -13,18 +13,19 @@ from .data_utils import batch_by_size, collate_tokens
 SAMPLE_RATE = 16000
 
 
-def durations(n_utts: int, seed: int = 1) -> np.ndarray:
+def durations(n_utts: int, seed: int = 1, median_s: float = 12.3, sigma: float = 0.45) -> np.ndarray:
     rng = np.random.default_rng(seed)
-    return np.clip(rng.lognormal(mean=np.log(12.3), sigma=0.45, size=n_utts), 1.0, 35.0)
+    return np.clip(rng.lognormal(mean=np.log(median_s), sigma=sigma, size=n_utts), 1.0, 35.0)
 
 
 def num_frames(n_samples: np.ndarray) -> np.ndarray:
     return np.where(n_samples < 400, 0, 1 + (n_samples - 400) // 160)
 
 
-def make_batches(n_utts=20000, max_tokens=26000, max_sentences=24, seed=1, shuffle=True) -> List[np.ndarray]:
-    """Batches of utterance indices; also returns per-utterance sample counts."""
-    dur = durations(n_utts, seed)
+def make_batches(n_utts=20000, max_tokens=26000, max_sentences=24, seed=1, shuffle=True, median_s=12.3, sigma=0.45) -> List[np.ndarray]:
+    """Batches of utterance indices; also returns per-utterance sample counts.  (Decode workload of SURVEY §8d: dev-other-like
+    durations, mean 6.4 s: median_s=5.35, sigma=0.6.)"""
+    dur = durations(n_utts, seed, median_s, sigma)
     n_samples = (dur * SAMPLE_RATE).astype(np.int64)
     frames = num_frames(n_samples)
     # reference ordering: shuffle, then stable sort by target length, then by source length (descending batches

@@ -94,3 +94,28 @@ def test_bucket_slices_cover_buffer():
     sl = flat.slices_in_backward_order(100)
     assert sl[0][1] == flat.numel and sl[-1][0] == 0
     assert all(a[0] == b[1] for a, b in zip(sl, sl[1:]))
+
+
+def _bench_rank(tmp):
+    """What a rank started by bench.spawn_ranks sees: the torch.distributed.run environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*); a world-2 gloo group forms from it and reduces."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    with open(os.path.join(tmp, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{dist.get_world_size()} {float(t)}")
+    dist.destroy_process_group()
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` outside torchrun starts N ranks itself (VERDICT r1 #12): the launcher used for that."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    bench.spawn_ranks(2, _bench_rank, (str(tmp_path),))
+    for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "2 3.0"

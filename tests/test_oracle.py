@@ -202,3 +202,27 @@ def test_speech_lstm_restatement_matches_reference(golden_dir):
               "decoder.attention.value_proj.weight", "decoder.layers.1.weight_ih", "decoder.embed_tokens.weight"):
         ref = torch.from_numpy(g["grad::" + k])
         assert float((leaf[k].grad - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max())), k
+
+
+def test_incremental_decode_restatement_matches_full_forward(golden_dir):
+    """oracle/decode_ref.py (K/V-cached one-token-per-step decoder used by bench.py's CPU decode baseline) reproduces the
+    teacher-forced log-probs of the full-forward decoder restatement, which is itself pinned to the reference's outputs."""
+    from oracle import decode_ref
+
+    g, sd = _load(golden_dir, "ref_transformer_encdec_tiny")
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+    feats, lengths, prev = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"])
+    full = torch_ref.encdec(feats, lengths, prev, sd, H=4, pad_idx=0)
+    valid = torch.from_numpy(g["target"]).ne(0)
+    assert float((full - torch.from_numpy(g["out::eval_logits"]))[valid].abs().max()) < 1e-5  # the pin (non-pad positions)
+    want = torch.log_softmax(full.float(), -1)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    x, out_len = torch_ref.encoder(feats, lengths, enc_sd, 4, layer_type="transformer", training=False)
+    pad = torch.arange(x.shape[0]).unsqueeze(0) >= out_len.unsqueeze(1)
+    dec = decode_ref.IncrementalDecoder(sd, 4, pad_idx=0)
+    dec.init(x, pad, beam=1)
+    for step in range(int((prev != 0).sum(1).min())):
+        lp = dec.step(prev[:, step], step)
+        assert float((lp - want[:, step]).abs().max()) < 1e-4, step
+    toks, scores = decode_ref.beam_search(feats, lengths, sd, 4, pad=0, eos=1, unk=2, beam=3, min_steps=5)
+    assert toks.shape == (3, 5) and bool((toks[:, -1] == 1).all()) and bool(torch.isfinite(scores).all())
