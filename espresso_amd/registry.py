@@ -68,15 +68,10 @@ def register_model_architecture(model_name, arch_name):
     return deco
 
 
-def mirror_into_fairseq():  # pragma: no cover - needs fairseq on the path
-    """Insert every espresso_amd component into fairseq's own registries (drop-in under fairseq's CLIs)."""
-    import fairseq.criterions as fc
-    import fairseq.models as fm
-    import fairseq.tasks as ft
+def mirror_into_fairseq():
+    """Insert every espresso_amd component into fairseq's own registries behind fairseq's call contracts (needs fairseq and
+    espresso importable): see espresso_amd/fairseq_plugin.py; pinned by tests/test_fairseq_binding.py."""
+    from . import criterions, models, tasks  # noqa: F401  (make sure every component is registered here first)
+    from .fairseq_plugin import install
 
-    for n, c in TASK_REGISTRY.items():
-        ft.TASK_REGISTRY[n] = c
-    for n, c in MODEL_REGISTRY.items():
-        fm.MODEL_REGISTRY[n] = c
-    for n, c in CRITERION_REGISTRY.items():
-        fc.CRITERION_REGISTRY[n] = c
+    return install()

@@ -9,6 +9,10 @@ def II(s):
 
 
 class DictConfig(dict):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.__dict__["_parent"] = None  # fairseq/dataclass/utils.py:501 copies this slot
+
     def __getattr__(self, k):
         try:
             return self[k]
@@ -65,9 +69,24 @@ class OmegaConf:
 
     @staticmethod
     def merge(*cfgs):
+        """Shallow-recursive merge; a dataclass instance contributes its fields (fairseq merges a user's config INTO the
+        registered dataclass's defaults: fairseq/dataclass/utils.py:487-503)."""
+        import dataclasses
+
+        def plain(c):
+            if dataclasses.is_dataclass(c) and not isinstance(c, type):
+                return DictConfig({f.name: plain(getattr(c, f.name)) for f in dataclasses.fields(c)})
+            if isinstance(c, dict) and not isinstance(c, DictConfig):
+                return DictConfig({k: plain(v) for k, v in c.items()})
+            return c
+
         out = DictConfig()
         for c in cfgs:
-            out.update(c)
+            for k, v in plain(c).items():
+                if isinstance(v, dict) and isinstance(out.get(k), dict):
+                    out[k] = OmegaConf.merge(out[k], v)
+                else:
+                    out[k] = plain(v)
         return out
 
     @staticmethod

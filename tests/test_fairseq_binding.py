@@ -1,0 +1,115 @@
+"""Drop-in boundary from the REFERENCE's side: with fairseq + espresso importable (here: /root/reference through
+the stub packages of oracle/ref_stubs — the build container only; skipped on the GPU box, which has neither),
+`registry.mirror_into_fairseq()` makes fairseq's own entry points resolve to espresso_amd classes with the reference's call
+contracts: fairseq/tasks/__init__.py:26 setup_task, fairseq_task.py:327 build_model -> fairseq/models/__init__.py:55,
+fairseq_task.py:344 build_criterion -> fairseq/criterions (registry build_x), and the FairseqTask method signatures the
+trainer / speech_recognize.py call (fairseq_task.py:132,359,490,524,530,538)."""
+import inspect
+import os
+import sys
+
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (build container only)")
+
+
+@pytest.fixture(scope="module")
+def fairseq_env(tmp_path_factory):
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "oracle", "ref_stubs"))
+    sys.path.insert(1, REF)
+    import fairseq  # noqa: F401
+    import espresso  # noqa: F401  (registers the REFERENCE's classes under the names below)
+    from fairseq import criterions, models, tasks
+
+    ref_task_cls = tasks.TASK_REGISTRY["speech_recognition_espresso"]
+    ref_model_cls = models.MODEL_REGISTRY["speech_transformer_encoder_model"]
+    ref_crit_cls = criterions.CRITERION_REGISTRY["ctc_loss"]
+    import espresso_amd  # noqa: F401
+    from espresso_amd import registry
+
+    adapter = registry.mirror_into_fairseq()
+    tmp = tmp_path_factory.mktemp("data")
+    with open(tmp / "dict.txt", "w") as f:
+        f.write("".join(f"t{i} 1\n" for i in range(30)))
+    return dict(tasks=tasks, models=models, criterions=criterions, adapter=adapter, tmp=str(tmp), ref=(ref_task_cls, ref_model_cls, ref_crit_cls))
+
+
+def _cfg(d):
+    from omegaconf import DictConfig
+
+    return DictConfig({k: (_cfg(v) if isinstance(v, dict) else v) for k, v in d.items()})
+
+
+def test_setup_task_build_model_build_criterion_resolve_to_espresso_amd(fairseq_env):
+    e = fairseq_env
+    import torch
+
+    from espresso_amd.criterions.ctc_loss import CtcLossCriterion
+    from espresso_amd.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderModel
+    from espresso_amd.tasks.speech_recognition import SpeechRecognitionEspressoTask
+    from fairseq.tasks import FairseqTask
+
+    # the registries no longer hand out the reference's classes
+    assert e["tasks"].TASK_REGISTRY["speech_recognition_espresso"] is e["adapter"] is not e["ref"][0]
+    assert issubclass(e["models"].ARCH_MODEL_REGISTRY["speech_transformer_encoder_model"], SpeechTransformerEncoderModel)
+    assert e["criterions"].CRITERION_REGISTRY["ctc_loss"] is CtcLossCriterion is not e["ref"][2]
+
+    # fairseq.tasks.setup_task: the user's config is merged into the REFERENCE's dataclass, then our task is set up from it
+    task = e["tasks"].setup_task(_cfg({"_name": "speech_recognition_espresso", "data": e["tmp"], "dict": os.path.join(e["tmp"], "dict.txt"),
+                                       "criterion_name": "ctc_loss", "max_source_positions": 3000}))
+    assert isinstance(task, FairseqTask) and isinstance(task.inner, SpeechRecognitionEspressoTask)
+    assert task.blank_symbol == "<s>" and len(task.target_dictionary) == 30 + 4 and task.max_positions()[0] == 3000
+    assert task.feat_dim == 80 and task.source_dictionary is None
+
+    # task.build_model(cfg.model) -> fairseq.models.build_model -> our class, built from the reference-style nested config
+    model = task.build_model(_cfg({"_name": "speech_transformer_encoder_model",
+                                   "encoder": {"embed_dim": 128, "ffn_embed_dim": 256, "layers": 2, "attention_heads": 2, "layer_type": "conformer",
+                                               "normalize_before": True, "relative_positional_embeddings": True,
+                                               "conv_channels": "[64, 64, 16, 16]"},
+                                   "layernorm_embedding": True, "dropout": 0.1}))
+    assert isinstance(model, SpeechTransformerEncoderModel) and isinstance(model, torch.nn.Module)
+    assert model.cfg.encoder.embed_dim == 128 and model.cfg.encoder.layer_type == "conformer" and model.cfg.dropout == 0.1
+    keys = set(model.state_dict())
+    assert {"encoder.fc0.weight", "encoder.layers.1.self_attn.pos_bias_u", "encoder.layers.0.conv_module.depthwise_conv.weight",
+            "encoder.fc_out.weight"} <= keys  # the reference's parameter names (checkpoints move both ways)
+
+    # a configuration value the HIP path does not implement is refused, not dropped
+    with pytest.raises(NotImplementedError):
+        task.build_model(_cfg({"_name": "speech_transformer_encoder_model", "encoder": {"layerdrop": 0.3}}))
+
+    # task.build_criterion(cfg.criterion) -> fairseq.criterions.build_criterion -> our class with the config's values
+    crit = task.build_criterion(_cfg({"_name": "ctc_loss", "sentence_avg": False, "zero_infinity": True, "print_training_sample_interval": 77}))
+    assert type(crit) is CtcLossCriterion and crit.sentence_avg is False and crit.print_interval == 77
+    assert crit.blank_idx == task.target_dictionary.index("<s>")
+
+
+def test_task_adapter_keeps_the_fairseq_task_signatures(fairseq_env):
+    """Positional parameter names of every method fairseq's trainer / CLIs call on a task."""
+    from fairseq.tasks import FairseqTask
+
+    A = fairseq_env["adapter"]
+    ref_task = fairseq_env["ref"][0]
+    # load_dataset: the espresso task's own signature (speech_recognition.py:398: split, epoch, combine) plus FairseqTask's task_cfg
+    assert list(inspect.signature(ref_task.load_dataset).parameters)[:4] == list(inspect.signature(A.load_dataset).parameters)[:4]
+    for name in ("build_model", "build_criterion", "build_generator", "train_step", "valid_step", "optimizer_step",
+                 "inference_step", "begin_epoch", "reduce_metrics", "max_positions", "get_batch_iterator", "dataset",
+                 "filter_indices_by_size", "state_dict", "load_state_dict"):
+        want = [p for p in inspect.signature(getattr(FairseqTask, name)).parameters]
+        got = [p for p in inspect.signature(getattr(A, name)).parameters]
+        assert got[: len(want)] == want or set(want) <= set(got), (name, want, got)
+    want = list(inspect.signature(FairseqTask.train_step).parameters)
+    assert list(inspect.signature(A.train_step).parameters) == want == ["self", "sample", "model", "criterion", "optimizer", "update_num", "ignore_grad"]
+
+
+def test_other_registered_names_resolve(fairseq_env):
+    e = fairseq_env
+    from espresso_amd import registry
+
+    for name, cls in registry.MODEL_REGISTRY.items():
+        assert issubclass(e["models"].MODEL_REGISTRY[name], cls), name
+    for name, cls in registry.CRITERION_REGISTRY.items():
+        assert e["criterions"].CRITERION_REGISTRY[name] is cls and hasattr(cls, "build_criterion"), name
+    for arch in registry.ARCH_MODEL_REGISTRY:
+        assert arch in e["models"].ARCH_MODEL_REGISTRY and arch in e["models"].ARCH_CONFIG_REGISTRY, arch
