@@ -1,0 +1,299 @@
+// Implicit-GEMM 3x3 convolutions of the sub-sampling front-end for gfx950 — no im2col / col2im buffers.
+//
+// Reference: espresso/modules/speech_convolutions.py:78-102 (Conv2d 3x3, padding 1, stride 1 or 2, then BatchNorm2d + ReLU)
+// and its autograd.  Layout: channels-last [B][T][F][C] bf16, so the C channels of one (t, f) position are one contiguous
+// 128 / 256-byte row — exactly one (or two) 64-deep k-steps of a GEMM whose reduction index is (tap, channel).
+//
+// Round 1 lowered convs 2-4 to im2col + GEMM: a 516 000 x 576 bf16 matrix (595 MB) written and read back per layer in the
+// forward pass, the same again (GEMM -> col2im) in the backward pass; profiles/r02_*: the front-end cost 4.3 of the 20.2 ms
+// step.  Here the A-operand tile of every k-step is GATHERED straight from the activation tensor by global_load_lds: lane ->
+// (tile row, 16-byte slot); the row's source position for the step's tap is computed from the row's (b, t, f) coordinates,
+// padding taps read a 128-byte zero line.  One kernel serves
+//   forward        Z[b][to][fo][:]  = bias + sum_{ky,kx} X[b][to*s+ky-1][fo*s+kx-1][:] W[:, ky, kx, :]      (+ BatchNorm sums)
+//   data gradient  dX[b][ti][fi][:] = sum_{taps valid for (ti, fi)} dZ[b][(ti+1-ky)/s][(fi+1-kx)/s][:] Wd[:, ky, kx, :]
+// through a generic description (row grid, source-coordinate multipliers, per-tap offsets, output row mapping).  With stride 2
+// the data gradient is launched once per parity class of (ti, fi): each class has its own tap list (1, 2, 2 or 4 taps — no
+// multiplications by structural zeros).
+//
+// Tile: 128 rows (positions) x N (64 or 128 output channels = the whole channel dimension) per 256-thread workgroup, BK = 64,
+// 2-stage direct-to-LDS ring (one raw barrier per k-step), MFMA 16x16x32 bf16, the LDS image / swizzle / fragment reads of
+// gemm.hip.  Epilogue: fp32 LDS bounce, 16-byte stores, optional bias, optional per-channel (sum, sum of squares) of the
+// bf16-rounded outputs accumulated in fp64 (BatchNorm batch statistics: replaces the separate colstats pass).
+#include <hip/hip_runtime.h>
+
+#include "gemm_common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct ConvGatherArgs {
+  const bf16_t* src;   // gathered tensor [RB][ST][SF][SC]
+  const bf16_t* W;     // [N][ldw] k-contiguous: k = koff[tap] + channel
+  bf16_t* out;         // rows of N channels, row index from (b, rt, rf) via the o* fields
+  const float* bias;   // [N] or null
+  double* stats;       // [2N] (sum, sumsq) or null
+  const bf16_t* zero;  // >= 128 bytes of zeros
+  int RB, RT, RF;      // row grid: M = RB * RT * RF
+  int ST, SF, SC;
+  int at, af;          // source coordinate = r * a + b[tap]
+  int ntaps;
+  int bt[9], bf[9], koff[9];
+  int N;
+  long ldw;
+  int OT, OF, ot_mul, ot_add, of_mul, of_add;  // output row = (b * OT + rt * ot_mul + ot_add) * OF + rf * of_mul + of_add
+};
+
+template <int BN_>
+__global__ __launch_bounds__(256, 2) void conv_gather_kernel(const ConvGatherArgs a) {
+  constexpr int BM_ = 128, NST = 2;
+  constexpr int NJ = BN_ / 32;  // 2 x 2 wavefronts, each 64 x (BN_/2): NJ n-tiles of 16
+  constexpr int A_BYTES = BM_ * ROW_BYTES, STAGE = A_BYTES + BN_ * ROW_BYTES;
+  constexpr int NA = BM_ / 32, NB = BN_ / 32;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wcol = (wave & 1) * (BN_ / 2);
+  const long M = (long)a.RB * a.RT * a.RF;
+  const long m0 = (long)blockIdx.x * BM_;
+  const int cpt = a.SC / BK;  // 64-channel chunks per tap
+  const int nk = a.ntaps * cpt;
+
+  // ---- per-lane description of the NA tile rows this lane feeds (row = (wave + 4 i) * 8 + lane / 8) ----
+  int rowb[NA], rowt[NA], rowf[NA];  // b * ST (or -1 for rows past M), rt * at, rf * af
+  int cs[NA];                         // source 16-byte slot of this lane in that row (bank swizzle applied to the source)
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = (wave + 4 * i) * 8 + (lane >> 3);
+    cs[i] = (lane & 7) ^ (r & 7) ^ ((r >> 4) & 7);
+    const long p = m0 + r;
+    if (p < M) {
+      const int rf = (int)(p % a.RF);
+      const long q = p / a.RF;
+      const int rt = (int)(q % a.RT);
+      rowb[i] = (int)(q / a.RT) * a.ST;
+      rowt[i] = rt * a.at;
+      rowf[i] = rf * a.af;
+    } else {
+      rowb[i] = -1;
+      rowt[i] = rowf[i] = 0;
+    }
+  }
+  const bf16_t* bp[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (wave + 4 * i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7) ^ ((r >> 4) & 7);
+    bp[i] = a.W + (long)min(r, a.N - 1) * a.ldw + c * 8;
+  }
+  auto issue = [&](int stage, int kt) {
+    const int tap = kt / cpt, chunk = kt - tap * cpt;
+    const int dt = a.bt[tap], df = a.bf[tap];
+    const long ko = a.koff[tap] + chunk * BK;
+    char* base = dsm + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int st = rowt[i] + dt, sf = rowf[i] + df;
+      const bool ok = rowb[i] >= 0 && (unsigned)st < (unsigned)a.ST && (unsigned)sf < (unsigned)a.SF;
+      const bf16_t* s = ok ? a.src + (((long)(rowb[i] + st)) * a.SF + sf) * a.SC + chunk * BK + cs[i] * 8 : a.zero + cs[i] * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(base + i * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + ko), (lptr_t)(base + A_BYTES + i * 4096), 16, 0, 0);
+  };
+
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  uint32_t a_off[2][4], b_off[2][NJ];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[ks][i] = lds_off(wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b_off[ks][j] = A_BYTES + lds_off(wcol + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+  }
+
+  if (nk > 0) issue(0, 0);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // step kt complete in LDS; everyone is done reading the other stage
+    if (kt + 1 < nk) issue(stage ^ 1, kt + 1);
+    const char* st = dsm + stage * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(st + a_off[ks][i]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(st + b_off[ks][j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af[i]),
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[j]), acc[i][j], 0, 0, 0);
+    }
+    stage ^= 1;
+  }
+
+  // ---- epilogue: 64 rows at a time through an fp32 LDS tile; thread -> (row lane, 8 consecutive channels) ----
+  constexpr int CG = BN_ / 8;        // channel groups of 8
+  constexpr int RL = 256 / CG;       // row lanes (16 for N = 128, 32 for N = 64)
+  float* sC = reinterpret_cast<float*>(dsm);  // [64][BN_] fp32 (<= 32 KiB; the ring is 48-64 KiB)
+  const int cg = tid % CG, rlane = tid / CG;
+  float bias8[8], s8[8], q8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias8[e] = a.bias ? a.bias[cg * 8 + e] : 0.f;
+    s8[e] = q8[e] = 0.f;
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * BN_ + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 64 / RL; ++pass) {
+      const int rl = pass * RL + rlane;
+      const long p = m0 + half * 64 + rl;
+      if (p < M) {
+        const int rf = (int)(p % a.RF);
+        const long q = p / a.RF;
+        const int rt = (int)(q % a.RT);
+        const long b = q / a.RT;
+        const long orow = (b * a.OT + (long)rt * a.ot_mul + a.ot_add) * a.OF + (long)rf * a.of_mul + a.of_add;
+        const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN_ + cg * 8);
+        const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN_ + cg * 8 + 4);
+        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+        uint4 u;
+        u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(a.out + orow * a.N + cg * 8) = u;
+        if (a.stats) {  // statistics of what BatchNorm will read: the bf16-rounded values
+          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+            s8[2 * e] += lo; q8[2 * e] += lo * lo;
+            s8[2 * e + 1] += hi; q8[2 * e + 1] += hi * hi;
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {  // fold the row lanes that share a channel group, then one fp64 atomic pair per channel and workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(dsm);  // [RL][2][BN_]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(rlane * 2 + 0) * BN_ + cg * 8 + e] = s8[e];
+      red[(rlane * 2 + 1) * BN_ + cg * 8 + e] = q8[e];
+    }
+    __syncthreads();
+    if (tid < 2 * BN_) {
+      const int which = tid / BN_, c = tid - which * BN_;
+      float t = 0.f;
+      for (int r = 0; r < RL; ++r) t += red[(r * 2 + which) * BN_ + c];
+      atomicAdd(a.stats + which * a.N + c, (double)t);
+    }
+  }
+}
+
+const bf16_t* zero_line(hipStream_t stream) {
+  static bf16_t* z = nullptr;
+  if (!z) {
+    if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(z, 0, 256, stream) != hipSuccess) return nullptr;
+    hipStreamSynchronize(stream);  // once per process
+  }
+  return z;
+}
+
+template <int BN_>
+int launch_gather(const ConvGatherArgs& a, hipStream_t stream) {
+  constexpr int bytes = 2 * (128 + BN_) * ROW_BYTES;
+  static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_kernel<BN_>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!attr_ok) return -1;
+  const long M = (long)a.RB * a.RT * a.RF;
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL((conv_gather_kernel<BN_>), dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, stream, a);
+  return EA_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// Forward: X bf16 [B][T][F][Cin] -> Z bf16 [B][To][Fo][Cout] = conv3x3(X; W, stride (sy, sx), padding 1) + bias; W bf16
+// [Cout][3][3][Cin]; stats (optional, fp64 [2 Cout], accumulated): per-channel sum / sum of squares of Z.
+extern "C" int ea_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Z, double* stats, int B, int T, int F,
+                              int Cin, int Cout, int sy, int sx, hipStream_t stream) {
+  if (B <= 0 || T <= 0 || F <= 0) return 0;
+  if (Cin % 64 || (Cout != 64 && Cout != 128) || sy < 1 || sx < 1) return -2;
+  ConvGatherArgs a;
+  a.src = (const bf16_t*)X; a.W = (const bf16_t*)W; a.out = (bf16_t*)Z; a.bias = bias; a.stats = stats;
+  a.zero = zero_line(stream);
+  if (!a.zero) return -1;
+  const int To = (T - 1) / sy + 1, Fo = (F - 1) / sx + 1;
+  a.RB = B; a.RT = To; a.RF = Fo;
+  a.ST = T; a.SF = F; a.SC = Cin;
+  a.at = sy; a.af = sx;
+  a.ntaps = 9;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      const int t = ky * 3 + kx;
+      a.bt[t] = ky - 1; a.bf[t] = kx - 1; a.koff[t] = t * Cin;
+    }
+  a.N = Cout; a.ldw = 9L * Cin;
+  a.OT = To; a.OF = Fo; a.ot_mul = 1; a.ot_add = 0; a.of_mul = 1; a.of_add = 0;
+  return Cout == 128 ? launch_gather<128>(a, stream) : launch_gather<64>(a, stream);
+}
+
+// Data gradient: dZ bf16 [B][To][Fo][Cout] -> dX bf16 [B][T][F][Cin]; Wd bf16 [Cin][3][3][Cout] (the forward weight with its
+// channel axes swapped).  One launch per parity class of the input position (one class for stride 1).
+extern "C" int ea_conv3x3_dgrad(const void* dZ, const void* Wd, void* dX, int B, int T, int F, int Cin, int Cout, int sy, int sx,
+                                hipStream_t stream) {
+  if (B <= 0 || T <= 0 || F <= 0) return 0;
+  if (Cout % 64 || (Cin != 64 && Cin != 128) || sy < 1 || sx < 1 || sy > 2 || sx > 2) return -2;
+  const int To = (T - 1) / sy + 1, Fo = (F - 1) / sx + 1;
+  const bf16_t* zero = zero_line(stream);
+  if (!zero) return -1;
+  for (int pt = 0; pt < sy; ++pt)
+    for (int pf = 0; pf < sx; ++pf) {
+      ConvGatherArgs a;
+      a.src = (const bf16_t*)dZ; a.W = (const bf16_t*)Wd; a.out = (bf16_t*)dX; a.bias = nullptr; a.stats = nullptr; a.zero = zero;
+      a.RB = B; a.RT = (T - pt + sy - 1) / sy; a.RF = (F - pf + sx - 1) / sx;  // positions ti = rt*sy + pt < T
+      a.ST = To; a.SF = Fo; a.SC = Cout;
+      a.at = 1; a.af = 1;
+      a.ntaps = 0;
+      for (int ky = 0; ky < 3; ++ky) {
+        if ((pt + 1 - ky) % sy) continue;  // (ti + 1 - ky) must be a multiple of the stride
+        for (int kx = 0; kx < 3; ++kx) {
+          if ((pf + 1 - kx) % sx) continue;
+          const int t = a.ntaps++;
+          // to = (rt*sy + pt + 1 - ky) / sy = rt + (pt + 1 - ky) / sy   (exact; C division of a negative multiple is exact too)
+          a.bt[t] = (pt + 1 - ky) / sy; a.bf[t] = (pf + 1 - kx) / sx; a.koff[t] = (ky * 3 + kx) * Cout;
+        }
+      }
+      a.N = Cin; a.ldw = 9L * Cout;
+      a.OT = T; a.OF = F; a.ot_mul = sy; a.ot_add = pt; a.of_mul = sx; a.of_add = pf;
+      if (a.RT <= 0 || a.RF <= 0) continue;
+      if (a.ntaps == 0) return -2;
+      const int rc = Cin == 128 ? launch_gather<128>(a, stream) : launch_gather<64>(a, stream);
+      if (rc) return rc;
+    }
+  return 0;
+}

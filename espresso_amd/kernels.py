@@ -337,6 +337,21 @@ def conv1_wgrad(X, dZ, dW, dbias, B, T, F, CO, sy, sx):
     check(_lib.lib().ea_conv1_wgrad(_p(X), _p(dZ), _p(dW), _p(dbias), B, T, F, CO, sy, sx, _stream()), "ea_conv1_wgrad")
 
 
+def conv3x3_fwd(X, W16, bias, B, T, F, Cin, Cout, sy, sx, stats=None):
+    """Implicit-GEMM conv: X bf16 [B*T*F][Cin] (channels-last) -> Z bf16 [B*To*Fo][Cout]; W16 bf16 [Cout][9*Cin] (tap-major)."""
+    To, Fo = (T - 1) // sy + 1, (F - 1) // sx + 1
+    Z = torch.empty((B * To * Fo, Cout), dtype=torch.bfloat16, device=X.device)
+    check(_lib.lib().ea_conv3x3_fwd(_p(X), _p(W16), _p(bias), _p(Z), _p(stats), B, T, F, Cin, Cout, sy, sx, _stream()), "ea_conv3x3_fwd")
+    return Z
+
+
+def conv3x3_dgrad(dZ, Wd16, B, T, F, Cin, Cout, sy, sx):
+    """dX bf16 [B*T*F][Cin] from dZ bf16 [B*To*Fo][Cout]; Wd16 bf16 [Cin][9*Cout]."""
+    dX = torch.empty((B * T * F, Cin), dtype=torch.bfloat16, device=dZ.device)
+    check(_lib.lib().ea_conv3x3_dgrad(_p(dZ), _p(Wd16), _p(dX), B, T, F, Cin, Cout, sy, sx, _stream()), "ea_conv3x3_dgrad")
+    return dX
+
+
 def im2col3x3(A, B, T, F, C, sy, sx):
     To, Fo = (T - 1) // sy + 1, (F - 1) // sx + 1
     col = torch.empty(B * To * Fo, 9 * C, dtype=torch.bfloat16, device=A.device)

@@ -252,6 +252,17 @@ int ea_conv1_fwd(const float* X, const float* W, const float* bias, void* Z, dou
                  int CO, int sy, int sx, ea_stream_t stream);
 int ea_conv1_wgrad(const float* X, const void* dZ, float* dW, float* dbias, int B, int T, int F, int CO, int sy,
                    int sx, ea_stream_t stream);
+/* Implicit-GEMM 3x3 convolutions (csrc/conv_igemm.hip; espresso/modules/speech_convolutions.py:78-102 and its autograd), channels-last
+ * bf16 [B][T][F][C], padding 1, strides 1 or 2, Cin a multiple of 64, Cout 64 or 128 — no im2col / col2im buffers.
+ *   fwd:   Z[B][To][Fo][Cout] = conv(X; W[Cout][3][3][Cin]) + bias ; stats (optional, fp64 [2*Cout], accumulated) receives the
+ *          per-channel sum / sum of squares of the bf16 outputs (BatchNorm batch statistics)
+ *   dgrad: dX[B][T][F][Cin] from dZ[B][To][Fo][Cout] and Wd[Cin][3][3][Cout] (the forward weight with its channel axes swapped)
+ *   wgrad: dW[Cout][3][3][Cin] (fp32, +=) and dbias[Cout] (fp32, += ; may be NULL) from X and dZ; workspace from
+ *          ea_conv3x3_wgrad_workspace_bytes */
+int ea_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Z, double* stats, int B, int T, int F, int Cin,
+                   int Cout, int sy, int sx, ea_stream_t stream);
+int ea_conv3x3_dgrad(const void* dZ, const void* Wd, void* dX, int B, int T, int F, int Cin, int Cout, int sy, int sx,
+                     ea_stream_t stream);
 int ea_im2col3x3(const void* A, void* col, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
 int ea_col2im3x3(const void* dcol, void* dA, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
 int ea_colstats_bf16(const void* X, double* stats, long M, int C, ea_stream_t stream);

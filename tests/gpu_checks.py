@@ -92,6 +92,37 @@ def check_gemm_epilogue_pairs(M=777, N=264, K=192, seed=0):
     return {"c2_vs_general": max(d[0], d[1]), "aux_vs_general": d[2], "drop_vs_general": d[3]}
 
 
+def check_conv3x3(Cin=64, Cout=128, sy=2, sx=2, B=2, T=37, F=21, seed=0):
+    """Implicit-GEMM 3x3 convolution (forward + BatchNorm sums, data gradient) vs torch conv2d / its autograd on the same bf16
+    operands (fp32 CPU): odd T / F (ragged parity classes, padding taps on every border), strides 1 and 2."""
+    from espresso_amd import kernels as Kk
+
+    g = torch.Generator().manual_seed(seed)
+    X = bf(torch.randn(B, T, F, Cin, generator=g))
+    W = bf(torch.randn(Cout, 3, 3, Cin, generator=g) * (9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, generator=g)
+    xr = X.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = W.float().permute(0, 3, 1, 2)
+    zr = torch.nn.functional.conv2d(xr, wr, bias, stride=(sy, sx), padding=1)
+    To, Fo = zr.shape[2], zr.shape[3]
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    Z = Kk.conv3x3_fwd(X.to(DEV).reshape(-1, Cin), W.to(DEV).reshape(Cout, 9 * Cin), bias.to(DEV), B, T, F, Cin, Cout, sy, sx, stats=stats)
+    torch.cuda.synchronize()
+    zh = Z.float().cpu().view(B, To, Fo, Cout)
+    zref = zr.detach().permute(0, 2, 3, 1)
+    res = {"fwd_rel": float((zh - zref).abs().max() / zref.abs().max())}
+    s_ref = torch.cat([zh.double().sum((0, 1, 2)), (zh.double() ** 2).sum((0, 1, 2))])
+    res["stats_rel"] = float((stats.cpu() - s_ref).abs().max() / s_ref.abs().max())
+    dZ = bf(torch.randn(B, To, Fo, Cout, generator=g))
+    (dxr,) = torch.autograd.grad(zr, xr, dZ.float().permute(0, 3, 1, 2))
+    Wd = W.permute(3, 1, 2, 0).contiguous()  # [Cin][3][3][Cout]
+    dX = Kk.conv3x3_dgrad(dZ.to(DEV).reshape(-1, Cout), Wd.to(DEV).reshape(Cin, 9 * Cout), B, T, F, Cin, Cout, sy, sx)
+    torch.cuda.synchronize()
+    dref = dxr.permute(0, 2, 3, 1)
+    res["dgrad_rel"] = float((dX.float().cpu().view(B, T, F, Cin) - dref).abs().max() / dref.abs().max())
+    return res
+
+
 def check_wgrad_group(seed=0, variant=0):
     """ea_wgrad_group (all weight / bias gradients of a layer in one launch) vs fp32 torch on the same bf16 operands:
     ragged N / K / M, padded leading dimensions, accumulation into non-zero dW / db, problems with and without bias."""

@@ -41,6 +41,15 @@ def test_gemm_splitk():
     assert G.check_gemm(128, 128, 640, False, False, c_f32=True, splitk=64) < 2e-3
 
 
+@pytest.mark.parametrize("cin,cout,sy,sx", [(64, 64, 2, 2), (64, 128, 1, 1), (128, 128, 2, 2), (128, 64, 1, 2)])
+def test_conv3x3_implicit_gemm(cin, cout, sy, sx):
+    r = G.check_conv3x3(Cin=cin, Cout=cout, sy=sy, sx=sx)
+    print(r)
+    assert r["fwd_rel"] < 8e-3 and r["dgrad_rel"] < 8e-3 and r["stats_rel"] < 1e-5, r   # bf16 outputs: one rounding step
+    r = G.check_conv3x3(Cin=cin, Cout=cout, sy=sy, sx=sx, B=3, T=130, F=40, seed=1)     # several 128-position tiles per class
+    assert r["fwd_rel"] < 8e-3 and r["dgrad_rel"] < 8e-3 and r["stats_rel"] < 1e-5, r
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_wgrad_group(variant):
     r = G.check_wgrad_group(variant=variant)
