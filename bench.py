@@ -274,6 +274,7 @@ def main(argv=None):
     ap.add_argument("--gemm-xcd-mask", type=int, default=None, help="A/B switch: XCD-aware tile order (bit 0 glds kernel, bit 1 register-staged)")
     ap.add_argument("--gemm-pk", type=int, default=None, help="A/B switch: persistent GEMM kernel (0 off, 1 automatic, 2+c configuration c)")
     ap.add_argument("--deferred-inline", action="store_true", help="A/B switch: deferred side work on the main stream (no overlap)")
+    ap.add_argument("--no-conv-igemm", action="store_true", help="A/B switch: im2col + GEMM + col2im sub-sampler (round 1) instead of the implicit GEMM")
     ap.add_argument("--no-deferred", action="store_true", help="A/B switch: layer backward joins its side work inside every call")
     args = ap.parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -294,6 +295,9 @@ def main(argv=None):
     if args.deferred_inline:
         from espresso_amd._lib import lib as _ealib5
         _ealib5().ea_set_backward_deferred_inline(1)
+    if args.no_conv_igemm:
+        from espresso_amd import functional as _F2
+        _F2.set_conv_implicit_gemm(False)
     if args.no_deferred:
         from espresso_amd import functional as _F
         _F.set_backward_deferred(False)

@@ -235,6 +235,217 @@ int launch_gather(const ConvGatherArgs& a, hipStream_t stream) {
   return EA_CHECK_LAUNCH();
 }
 
+
+// ---- weight gradient: dW[cout][tap][cin] += sum_p dZ[p][cout] X[src(p, tap)][cin] ----------------------------------------
+// A "TN" product: the reduction index (position p) is the slow axis of BOTH operands.  gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: within a 16-lane group lane i receives column i of the 4 x 16 block whose rows are the 8-byte pieces
+// supplied by lanes 4j .. 4j+3 — probed on hardware, tools/probes/tr_read_probe.hip) delivers MFMA fragments with k running
+// down the rows of a row-major [k][64 channels] image, so both operand tiles go global -> LDS with global_load_lds exactly as
+// they lie in HBM (position rows of 128 bytes; the tap's source rows gathered like in the forward kernel) — no register
+// transposes, no im2col matrix.  Bank swizzle for the transposing reads: 32-byte chunk c of row r is stored at chunk
+// c ^ (r & 3) ^ ((r >> 3) & 1), which makes the 8 rows x 32 bytes one 32-lane read cycle touches hit 64 distinct banks.
+// Workgroup = 64 cout x 64 cin x all taps over a slice of the positions (split-K): the dZ tile of a 64-position chunk is
+// loaded once and its fragments are kept in registers for the nine tap tiles.  Partial sums go to fp32 slabs, a small second
+// kernel folds them into dW (fp32 atomics: 19 M of them per layer would cost more than the whole product).
+struct ConvWgradArgs {
+  const bf16_t* X;     // [RB][ST][SF][Cin]
+  const bf16_t* dZ;    // [RB][RT][RF][Cout]
+  float* slab;         // [nsplit][Cout][ntaps][Cin]
+  const bf16_t* zero;
+  int RB, RT, RF, ST, SF, Cin, Cout;
+  int at, af, ntaps;
+  int bt[9], bf[9];
+  int chunks_per_wg;   // 64-position chunks per workgroup
+};
+
+__device__ __forceinline__ int tr_sw(int r) { return (r & 3) ^ ((r >> 3) & 1); }
+// Eight transposing reads + their wait in ONE asm statement: hipcc does not track the completion of loads issued from inline
+// asm, so the destinations must not be visible to it (copied, spilled) before the data has landed
+// (/opt/skills/guides/cdna_hip_programming.md 5.7 item 1, form (i)).
+__device__ __forceinline__ void ds_read_tr16_x8(const uint32_t (&ad)[8], uint2 (&o)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+      : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs a) {
+  constexpr int TILE = 64 * ROW_BYTES;  // 8 KiB: 64 position rows x 64 channels
+  __shared__ __attribute__((aligned(16))) char lds[3 * TILE];  // [A][B0][B1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // wave tile: cout rows wr*32.., cin cols wc*32..
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+  const long M = (long)a.RB * a.RT * a.RF;
+  const long chunk0 = (long)blockIdx.z * a.chunks_per_wg;
+  long nch = (M + 63) / 64 - chunk0;
+  if (nch > a.chunks_per_wg) nch = a.chunks_per_wg;
+  if (nch < 0) nch = 0;
+
+  f32x4_t acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // lane -> two rows of a tile: row = (wave + 4 i) * 8 + lane / 8, 16-byte slot lane & 7 (32-byte chunk swizzled at the source)
+  int rr[2], cs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    rr[i] = (wave + 4 * i) * 8 + (lane >> 3);
+    cs[i] = (lane & 7) ^ (tr_sw(rr[i]) << 1);
+  }
+  int rowb[2], rowt[2], rowf[2];  // this chunk's two rows: b * ST (or -1), rt * at, rf * af
+  long rowp[2];
+  auto decode = [&](long ch) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long p = (chunk0 + ch) * 64 + rr[i];
+      rowp[i] = p;
+      if (p < M) {
+        const int rf = (int)(p % a.RF);
+        const long q = p / a.RF;
+        rowb[i] = (int)(q / a.RT) * a.ST;
+        rowt[i] = (int)(q % a.RT) * a.at;
+        rowf[i] = rf * a.af;
+      } else {
+        rowb[i] = -1;
+        rowt[i] = rowf[i] = 0;
+      }
+    }
+  };
+  auto issue_A = [&]() {  // dZ rows of the decoded chunk
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16_t* s = rowb[i] >= 0 ? a.dZ + rowp[i] * a.Cout + co0 + cs[i] * 8 : a.zero + cs[i] * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_B = [&](int buf, int tap) {  // X rows the decoded chunk's positions read through `tap`
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int st = rowt[i] + a.bt[tap], sf = rowf[i] + a.bf[tap];
+      const bool ok = rowb[i] >= 0 && (unsigned)st < (unsigned)a.ST && (unsigned)sf < (unsigned)a.SF;
+      const bf16_t* s = ok ? a.X + (((long)(rowb[i] + st)) * a.SF + sf) * a.Cin + ci0 + cs[i] * 8 : a.zero + cs[i] * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + (1 + buf) * TILE + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  };
+  // transposing fragment reads: tile at byte offset tile_off, the wave's 32 channels [c0, c0 + 32) (two 16-channel tiles) x 64
+  // positions (two 32-deep halves) -> fr[ks][tile] = 8 bf16 per lane (k = ks*32 + 8*(lane>>4) + e, channel c0 + 16*tile + (lane&15))
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+  auto read_frags = [&](int tile_off, int c0, uint4 (&fr)[2][2]) {
+    const int g = lane >> 4, i = lane & 15;
+    uint32_t ad[8];
+    uint2 o[8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = ks * 32 + 8 * g + (i >> 2) + 4 * h;
+          const int chunk = (c0 >> 4) + t;
+          ad[(ks * 2 + t) * 2 + h] = lds0 + tile_off + r * ROW_BYTES + ((chunk ^ tr_sw(r)) << 5) + (i & 3) * 8;
+        }
+    ds_read_tr16_x8(ad, o);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fr[ks][t] = make_uint4(o[(ks * 2 + t) * 2].x, o[(ks * 2 + t) * 2].y, o[(ks * 2 + t) * 2 + 1].x, o[(ks * 2 + t) * 2 + 1].y);
+  };
+
+  const int nsteps = (int)nch * a.ntaps;
+  if (nsteps > 0) {
+    decode(0);
+    issue_A();
+    issue_B(0, 0);
+  }
+  uint4 fa[2][2];  // dZ fragments of the current chunk: [ksub][cout tile]
+  int buf = 0;
+  long ch = 0;
+  int tap = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // this step's tiles are complete; everyone is done with the other B buffer (and with A when tap == 0 was read)
+    if (tap == 0) read_frags(0, wr * 32, fa);
+    uint4 fb[2][2];
+    read_frags((1 + buf) * TILE, wc * 32, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    // next step's loads (A of the next chunk goes out one step early: its fragments were copied to registers at tap 0, but other
+    // waves may still be reading the A tile during step (ch, 0) — so never before the barrier of step (ch, 1))
+    const int ntap = tap + 1 == a.ntaps ? 0 : tap + 1;
+    if (s + 1 < nsteps) {
+      if (ntap == 0) {
+        decode(ch + 1);
+        issue_A();
+      }
+      issue_B(buf ^ 1, ntap);
+    }
+    // acc[tap] += dZ_tile^T X_tile   (static tap index: the accumulators are registers)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t == tap) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[ks][i]),
+                  __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[ks][j]), acc[t][i][j], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+    tap = ntap;
+    if (ntap == 0) ++ch;
+  }
+
+  // partial sums -> slab[z][cout][tap][cin]: lane holds acc[t][i][j][r] = (cout wr*32 + i*16 + (lane>>4)*4 + r, cin wc*32 + j*16 + (lane&15))
+  float* out = a.slab + (long)blockIdx.z * a.Cout * a.ntaps * a.Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (t < a.ntaps) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r, ci = ci0 + wc * 32 + j * 16 + (lane & 15);
+            out[((long)co * a.ntaps + t) * a.Cin + ci] = acc[t][i][j][r];
+          }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, long n, int nsplit) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    float4 s = *reinterpret_cast<const float4*>(slab + i);
+    for (int z = 1; z < nsplit; ++z) {
+      const float4 x = *reinterpret_cast<const float4*>(slab + (long)z * n + i);
+      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    }
+    float4 d = *reinterpret_cast<const float4*>(dW + i);
+    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+    *reinterpret_cast<float4*>(dW + i) = d;
+  }
+}
+
+static int wgrad_split(long M, int Cin, int Cout) {
+  const long chunks = (M + 63) / 64;
+  const int blocks = (Cin / 64) * (Cout / 64);
+  long nsplit = (768 + blocks - 1) / blocks;         // ~3 workgroups per CU in total
+  if (nsplit > chunks / 8) nsplit = chunks / 8;      // at least 8 chunks (72 tap steps) per workgroup
+  if (nsplit < 1) nsplit = 1;
+  return (int)nsplit;
+}
+
 }  // namespace
 
 // Forward: X bf16 [B][T][F][Cin] -> Z bf16 [B][To][Fo][Cout] = conv3x3(X; W, stride (sy, sx), padding 1) + bias; W bf16
@@ -296,4 +507,36 @@ extern "C" int ea_conv3x3_dgrad(const void* dZ, const void* Wd, void* dX, int B,
       if (rc) return rc;
     }
   return 0;
+}
+
+extern "C" long ea_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout, int sy, int sx) {
+  const int To = (T - 1) / sy + 1, Fo = (F - 1) / sx + 1;
+  return (long)wgrad_split((long)B * To * Fo, Cin, Cout) * Cout * 9 * Cin * (long)sizeof(float);
+}
+
+// Weight gradient: dW fp32 [Cout][3][3][Cin] += sum over positions of dZ (x) X-taps.  (The bias gradient of a convolution that
+// feeds BatchNorm is available from BatchNorm's own sums — exactly zero in training mode — and is not computed here.)
+extern "C" int ea_conv3x3_wgrad(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin, int Cout,
+                                int sy, int sx, hipStream_t stream) {
+  if (B <= 0 || T <= 0 || F <= 0) return 0;
+  if (Cin % 64 || Cout % 64 || sy < 1 || sx < 1 || !workspace) return -2;
+  ConvWgradArgs a;
+  a.X = (const bf16_t*)X; a.dZ = (const bf16_t*)dZ; a.slab = (float*)workspace;
+  a.zero = zero_line(stream);
+  if (!a.zero) return -1;
+  const int To = (T - 1) / sy + 1, Fo = (F - 1) / sx + 1;
+  a.RB = B; a.RT = To; a.RF = Fo; a.ST = T; a.SF = F; a.Cin = Cin; a.Cout = Cout;
+  a.at = sy; a.af = sx; a.ntaps = 9;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) { a.bt[ky * 3 + kx] = ky - 1; a.bf[ky * 3 + kx] = kx - 1; }
+  const long M = (long)B * To * Fo;
+  const int nsplit = wgrad_split(M, Cin, Cout);
+  const long chunks = (M + 63) / 64;
+  a.chunks_per_wg = (int)((chunks + nsplit - 1) / nsplit);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
+  const long n = (long)Cout * 9 * Cin;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dW, n, nsplit);
+  return EA_CHECK_LAUNCH();
 }

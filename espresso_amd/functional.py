@@ -487,6 +487,14 @@ def label_smoothed_ce(logits, target, pad_idx, eps, smoothing="uniform", prior=N
     return _LabelSmoothedCE.apply(logits, target, pad_idx, eps, smoothing, prior, tgt_len)
 
 
+_CONV_IGEMM = True  # A/B switch: implicit-GEMM 3x3 convolutions (False: the round-1 im2col + GEMM + col2im lowering)
+
+
+def set_conv_implicit_gemm(on: bool):
+    global _CONV_IGEMM
+    _CONV_IGEMM = bool(on)
+
+
 # ------------------------------------------------------------------------------------------------
 class _ConvSubsample(torch.autograd.Function):
     """ConvBNReLU stack of espresso/modules/speech_convolutions.py:78-102 in channels-last form.
@@ -515,6 +523,12 @@ class _ConvSubsample(torch.autograd.Function):
                 assert w.shape[1] == 1 and tuple(w.shape[2:]) == (3, 3)
                 Zi = K.conv1_fwd(X, w.detach().reshape(Co, 9).contiguous(), b, B, Tc, Fc, Co, sy, sx, stats)
                 col, w16 = None, None
+            elif _CONV_IGEMM and Cc % 64 == 0 and Co in (64, 128):
+                # implicit GEMM (csrc/conv_igemm.hip): the tap tiles are gathered straight from the channels-last activation,
+                # BatchNorm sums come out of the epilogue; what backward needs is the layer's INPUT, not a 9x larger im2col matrix
+                w16 = K.cast_f32_to_bf16(w.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Cc).contiguous())
+                Zi = K.conv3x3_fwd(A, w16, b, B, Tc, Fc, Cc, Co, sy, sx, stats=stats)
+                col = A
             else:
                 col = K.im2col3x3(A, B, Tc, Fc, Cc, sy, sx)
                 w16 = K.cast_f32_to_bf16(w.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Cc).contiguous())
@@ -537,6 +551,8 @@ class _ConvSubsample(torch.autograd.Function):
         ctx.save_for_backward(X, row_zero, *[t for t in saved if t is not None])
         ctx.layout = [[t is not None for t in saved[6 * i: 6 * i + 6]] for i in range(L)]
         ctx.cfg = (B, cfgs, p_drop, seed, training, [tuple(p.shape) for p in params[0::4]])
+        ctx.igemm = [i > 0 and _CONV_IGEMM and cfgs[i][2] % 64 == 0 and cfgs[i][5] in (64, 128) for i in range(L)]
+        ctx.weights = [params[4 * i] for i in range(L)]
         return out
 
     @staticmethod
@@ -578,6 +594,20 @@ class _ConvSubsample(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     K.conv1_wgrad(X, dZ, dW, db, B, Tc, Fc, Co, sy, sx)
                 grads[0] = dW.view(wshapes[0])
+            elif ctx.igemm[i]:
+                # `col` is the layer's input activation here.  Weight gradient (side stream): transposing-LDS-read kernel over
+                # the input and dZ; data gradient: gather GEMM per parity class of the input position.  The bias gradient of a
+                # convolution feeding BatchNorm comes from BatchNorm's own sums: sum_p dZ = gamma * rstd * (dbeta - dbeta) = 0 with
+                # batch statistics (the batch mean removes the bias), gamma * rstd * dbeta with running statistics.
+                dWp = _zeros_f32(Co * 9 * Cc, X).view(Co, 9 * Cc)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    K.conv3x3_wgrad(col, dZ, dWp, B, Tc, Fc, Cc, Co, sy, sx)
+                grads[4 * i] = dWp.view(Co, 3, 3, Cc).permute(0, 3, 1, 2)
+                if not training:
+                    db = g.detach() * mr[1] * dbeta
+                wd16 = K.cast_f32_to_bf16(ctx.weights[i].detach().permute(1, 2, 3, 0).reshape(Cc, 9 * Co).contiguous())
+                dA = K.conv3x3_dgrad(dZ, wd16, B, Tc, Fc, Cc, Co, sy, sx)
             else:
                 dWp = torch.empty((Co, 9 * Cc), dtype=torch.float32, device=X.device)
                 side.wait_stream(cur)

@@ -352,6 +352,15 @@ def conv3x3_dgrad(dZ, Wd16, B, T, F, Cin, Cout, sy, sx):
     return dX
 
 
+def conv3x3_wgrad(X, dZ, dW, B, T, F, Cin, Cout, sy, sx):
+    """dW fp32 [Cout][9*Cin] += weight gradient of the 3x3 conv from X bf16 [B*T*F][Cin] and dZ bf16 [B*To*Fo][Cout]."""
+    lib = _lib.lib()
+    nb = lib.ea_conv3x3_wgrad_workspace_bytes(B, T, F, Cin, Cout, sy, sx)
+    ws = torch.empty(nb, dtype=torch.uint8, device=X.device)
+    check(lib.ea_conv3x3_wgrad(_p(X), _p(dZ), _p(dW), _p(ws), B, T, F, Cin, Cout, sy, sx, _stream()), "ea_conv3x3_wgrad")
+    return dW
+
+
 def im2col3x3(A, B, T, F, C, sy, sx):
     To, Fo = (T - 1) // sy + 1, (F - 1) // sx + 1
     col = torch.empty(B * To * Fo, 9 * C, dtype=torch.bfloat16, device=A.device)

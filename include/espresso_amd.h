@@ -263,6 +263,9 @@ int ea_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Z, dou
                    int Cout, int sy, int sx, ea_stream_t stream);
 int ea_conv3x3_dgrad(const void* dZ, const void* Wd, void* dX, int B, int T, int F, int Cin, int Cout, int sy, int sx,
                      ea_stream_t stream);
+long ea_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout, int sy, int sx);
+int ea_conv3x3_wgrad(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin, int Cout, int sy,
+                     int sx, ea_stream_t stream);
 int ea_im2col3x3(const void* A, void* col, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
 int ea_col2im3x3(const void* dcol, void* dA, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
 int ea_colstats_bf16(const void* X, double* stats, long M, int C, ea_stream_t stream);

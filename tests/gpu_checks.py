@@ -120,6 +120,15 @@ def check_conv3x3(Cin=64, Cout=128, sy=2, sx=2, B=2, T=37, F=21, seed=0):
     torch.cuda.synchronize()
     dref = dxr.permute(0, 2, 3, 1)
     res["dgrad_rel"] = float((dX.float().cpu().view(B, T, F, Cin) - dref).abs().max() / dref.abs().max())
+    # weight gradient (transposing-LDS-read kernel), accumulated into a non-zero buffer
+    wleaf = wr.clone().requires_grad_(True)
+    zr2 = torch.nn.functional.conv2d(X.float().permute(0, 3, 1, 2), wleaf, None, stride=(sy, sx), padding=1)
+    (dwr,) = torch.autograd.grad(zr2, wleaf, dZ.float().permute(0, 3, 1, 2))
+    dW0 = torch.randn(Cout, 9 * Cin, generator=g)
+    dW = Kk.conv3x3_wgrad(X.to(DEV).reshape(-1, Cin), dZ.to(DEV).reshape(-1, Cout), dW0.clone().to(DEV), B, T, F, Cin, Cout, sy, sx)
+    torch.cuda.synchronize()
+    wref = dW0 + dwr.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    res["wgrad_rel"] = float((dW.cpu() - wref).abs().max() / wref.abs().max())
     return res
 
 
@@ -191,6 +200,8 @@ def check_deferred_backward_matches_immediate(layer_type="conformer", p_drop=0.0
             F.set_backward_deferred(True)
     worst = ("", 0.0)
     for n in out[0]:
+        if (".pre_encoder.convolutions." in n and n.endswith(".bias")) or n.endswith("self_attn.k_proj.bias"):
+            continue  # true gradient exactly zero: both runs hold round-off noise there
         a, b = out[0][n], out[1][n]
         e = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         if e > worst[1]:

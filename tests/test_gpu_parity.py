@@ -45,9 +45,9 @@ def test_gemm_splitk():
 def test_conv3x3_implicit_gemm(cin, cout, sy, sx):
     r = G.check_conv3x3(Cin=cin, Cout=cout, sy=sy, sx=sx)
     print(r)
-    assert r["fwd_rel"] < 8e-3 and r["dgrad_rel"] < 8e-3 and r["stats_rel"] < 1e-5, r   # bf16 outputs: one rounding step
+    assert r["fwd_rel"] < 8e-3 and r["dgrad_rel"] < 8e-3 and r["stats_rel"] < 1e-5 and r["wgrad_rel"] < 2e-3, r   # bf16 outputs: one rounding step
     r = G.check_conv3x3(Cin=cin, Cout=cout, sy=sy, sx=sx, B=3, T=130, F=40, seed=1)     # several 128-position tiles per class
-    assert r["fwd_rel"] < 8e-3 and r["dgrad_rel"] < 8e-3 and r["stats_rel"] < 1e-5, r
+    assert r["fwd_rel"] < 8e-3 and r["dgrad_rel"] < 8e-3 and r["stats_rel"] < 1e-5 and r["wgrad_rel"] < 2e-3, r
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
