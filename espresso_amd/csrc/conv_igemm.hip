@@ -424,23 +424,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, long n, int nsplit) {
-  const long stride = (long)gridDim.x * 256 * 4;
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-    float4 s = *reinterpret_cast<const float4*>(slab + i);
-    for (int z = 1; z < nsplit; ++z) {
-      const float4 x = *reinterpret_cast<const float4*>(slab + (long)z * n + i);
-      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
-    }
+  // grid (column blocks, slab groups): a workgroup adds up its group of slabs for 1024 outputs; groups meet in dW with fp32
+  // atomics (a 64 x 64 x 9 gradient split 512 ways is 75 MB of slabs over 36 column blocks: one block per column chunk walked
+  // all of them serially and took longer than the MFMA kernel itself)
+  const int zper = (nsplit + gridDim.y - 1) / gridDim.y;
+  const int z0 = blockIdx.y * zper, z1 = min(nsplit, z0 + zper);
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n || z0 >= z1) return;
+  float4 s = *reinterpret_cast<const float4*>(slab + (long)z0 * n + i);
+  for (int z = z0 + 1; z < z1; ++z) {
+    const float4 x = *reinterpret_cast<const float4*>(slab + (long)z * n + i);
+    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+  }
+  if (gridDim.y == 1) {
     float4 d = *reinterpret_cast<const float4*>(dW + i);
     d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
     *reinterpret_cast<float4*>(dW + i) = d;
+  } else {
+    atomicAdd(dW + i, s.x); atomicAdd(dW + i + 1, s.y); atomicAdd(dW + i + 2, s.z); atomicAdd(dW + i + 3, s.w);
   }
 }
 
 static int wgrad_split(long M, int Cin, int Cout) {
   const long chunks = (M + 63) / 64;
   const int blocks = (Cin / 64) * (Cout / 64);
-  long nsplit = (768 + blocks - 1) / blocks;         // ~3 workgroups per CU in total
+  long nsplit = (512 + blocks - 1) / blocks;         // 2 workgroups per CU in total
   if (nsplit > chunks / 8) nsplit = chunks / 8;      // at least 8 chunks (72 tap steps) per workgroup
   if (nsplit < 1) nsplit = 1;
   return (int)nsplit;
@@ -535,8 +543,10 @@ extern "C" int ea_conv3x3_wgrad(const void* X, const void* dZ, float* dW, void* 
   a.chunks_per_wg = (int)((chunks + nsplit - 1) / nsplit);
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
   const long n = (long)Cout * 9 * Cin;
-  long blocks = (n / 4 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dW, n, nsplit);
+  const long blocks = (n / 4 + 255) / 256;
+  int zg = (int)(1024 / blocks);  // ~1024 workgroups in all
+  if (zg > nsplit / 4) zg = nsplit / 4;
+  if (zg < 1) zg = 1;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks, zg), dim3(256), 0, stream, (const float*)workspace, dW, n, nsplit);
   return EA_CHECK_LAUNCH();
 }

@@ -471,7 +471,12 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
   const int lanes = 256 / TCH;
   int rpb = 8 * lanes;                        // >= 8 rows per thread
   if (rpb < 32) rpb = 32;
-  dim3 g1((nch + TCH - 1) / TCH, (unsigned)((M + rpb - 1) / rpb));
+  // every block ends with 2*8*TCH atomics onto the same 2*C sums: cap the grid at ~2048 blocks (the sub-sampler's 2 M-row,
+  // 64-channel maps launched 7 660 blocks = 1 M atomics on 128 addresses and ran at 1.5 TB/s)
+  const long gx = (nch + TCH - 1) / TCH;
+  const long want = (M + (2048 / gx) - 1) / (2048 / gx > 0 ? 2048 / gx : 1);
+  if (want > rpb) rpb = (int)((want + lanes - 1) / lanes * lanes);
+  dim3 g1((unsigned)gx, (unsigned)((M + rpb - 1) / rpb));
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, g1, dim3(256), (size_t)256 * 16 * sizeof(float), stream, (const bf16_t*)Z,
                      (const bf16_t*)dH, mean_rstd, gamma, beta, red, M, C, act, rpb, TCH);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z,

@@ -18,6 +18,8 @@ a per-call 64-bit seed is saved and the kernels re-derive the mask from (seed, e
 import math
 from typing import Optional
 
+import collections
+
 import torch
 
 from . import kernels as K
@@ -1309,6 +1311,24 @@ def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=0):
 
 
 # ------------------------------------------------------------------------------------------------ LSTM
+_LSTM_PERSISTENT = True
+_lstm_counters = collections.deque(maxlen=64)  # barrier scratch (most recent launches) of the persistent launches ([1] != 0: a wait timed out); checked by lstm_barrier_timeouts()
+
+
+def set_lstm_persistent(on: bool) -> bool:
+    """Persistent whole-sequence LSTM kernels (default) vs one recurrent GEMM + cell kernel per step.  Returns the old setting."""
+    global _LSTM_PERSISTENT
+    old, _LSTM_PERSISTENT = _LSTM_PERSISTENT, bool(on)
+    return old
+
+
+def lstm_barrier_timeouts() -> int:
+    """Number of persistent LSTM launches since the last call whose grid barrier gave up (synchronises; diagnostics / tests)."""
+    n = sum(int(c[1].item() != 0) for c in _lstm_counters)
+    _lstm_counters.clear()
+    return n
+
+
 class _LSTMLayer(torch.autograd.Function):
     """One LSTM layer over a whole (teacher-forced) sequence — the time loop of
     espresso/models/speech_lstm.py:846-893 for one `LSTMCell` (fairseq/models/lstm.py:LSTMCell = torch.nn.LSTMCell), and one
@@ -1340,6 +1360,14 @@ class _LSTMLayer(torch.autograd.Function):
         assert frozen is None or (h0 is None and c0 is None), "packed sequences start from the zero state"
         order = range(U - 1, -1, -1) if reverse else range(U)
         prev = None
+        persistent = _LSTM_PERSISTENT and K.lstm_seq_supported(B, H)
+        if persistent:  # the whole time loop in one launch (csrc/lstm_seq.hip)
+            counter = torch.empty(2, dtype=torch.int32, device=dev)
+            K.lstm_seq_fwd(gx, w_hh16, h0_16, c0, frozen, hs, cs, act, h_last, counter, B, U, H, reverse=reverse,
+                           frozen_out_zero=frozen is not None)
+            prev = 0 if reverse else U - 1
+            order = ()
+            _lstm_counters.append(counter)
         for n, t in enumerate(order):
             if prev is None and h0_16 is None:
                 Gt = gx[t * B:(t + 1) * B]
@@ -1352,6 +1380,7 @@ class _LSTMLayer(torch.autograd.Function):
             prev = t
         ctx.save_for_backward(x, hs, cs, act, w_ih16, w_hh16, h0_16, c0, frozen)
         ctx.dims = (B, U, H, I, b_ih is not None, h0 is not None, reverse)
+        ctx.persistent = persistent
         return hs, h_last, cs[prev]
 
     @staticmethod
@@ -1365,7 +1394,17 @@ class _LSTMLayer(torch.autograd.Function):
         dc = dc_last.float().contiguous().clone() if dc_last is not None else None
         order = list(range(U - 1, -1, -1) if reverse else range(U))  # forward processing order
         sk_rec = max(1, min(16, (4 * H) // 512)) if B <= 64 else 1
-        for n in range(U - 1, -1, -1):
+        steps = range(U - 1, -1, -1)
+        if ctx.persistent:
+            counter = torch.empty(2, dtype=torch.int32, device=dev)
+            dh0 = torch.empty(B, H, dtype=torch.float32, device=dev) if has_h0 else None
+            dc0 = torch.empty(B, H, dtype=torch.float32, device=dev) if c0 is not None else None
+            K.lstm_seq_bwd(dhs, dh_rec, dc, act, cs, c0, frozen, w_hh16.t().contiguous(), dG, dh0, dc0, counter, B, U, H,
+                           reverse=reverse)
+            dh_rec, dc = dh0, dc0
+            steps = ()
+            _lstm_counters.append(counter)
+        for n in steps:
             t = order[n]
             tp = order[n - 1] if n > 0 else None  # the step whose state fed this one
             dc_new = torch.empty(B, H, dtype=torch.float32, device=dev)

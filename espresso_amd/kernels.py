@@ -599,6 +599,20 @@ def lstm_cell_bwd(dh_bf16, ld_dh, dh_f32, dc_in, gates_act, c_prev, c, dgates, l
                                       _p(dc_prev), _p(frozen), B, H, _stream()), "ea_lstm_cell_bwd")
 
 
+def lstm_seq_supported(B, H):
+    return bool(_lib.lib().ea_lstm_seq_supported(int(B), int(H)))
+
+
+def lstm_seq_fwd(gx, w_hh16, h0_16, c0, frozen, hs, cs, act, h_last, counter, B, U, H, reverse=False, frozen_out_zero=False):
+    check(_lib.lib().ea_lstm_seq_fwd(_p(gx), _p(w_hh16), _p(h0_16), _p(c0), _p(frozen), _p(hs), _p(cs), _p(act), _p(h_last),
+                                     _p(counter), B, U, H, int(reverse), int(frozen_out_zero), _stream()), "ea_lstm_seq_fwd")
+
+
+def lstm_seq_bwd(dhs, dh_last, dc_last, act, cs, c0, frozen, w_hhT16, dG, dh0, dc0, counter, B, U, H, reverse=False):
+    check(_lib.lib().ea_lstm_seq_bwd(_p(dhs), _p(dh_last), _p(dc_last), _p(act), _p(cs), _p(c0), _p(frozen), _p(w_hhT16), _p(dG),
+                                     _p(dh0), _p(dc0), _p(counter), B, U, H, int(reverse), _stream()), "ea_lstm_seq_bwd")
+
+
 def bahdanau_fwd(qp, key, value, nv, bias, lens, T, B, ctx=None, ldc=None, kv_col=None, Bkv=0):
     A, Cv = qp.shape[1], value.shape[-1]
     p = torch.empty(T, B, dtype=torch.float32, device=qp.device)

@@ -468,6 +468,24 @@ int ea_lstm_cell_fwd(const float* gates_pre, long ldg, const float* c_prev, floa
 int ea_lstm_cell_bwd(const void* dh_bf16, long ld_dh, const float* dh_f32, const float* dc_in, const float* gates_act,
                      const float* c_prev, const float* c, void* dgates, long lddg, float* dc_prev, const uint8_t* frozen, int B,
                      int H, ea_stream_t stream);
+/* Whole time loop of one LSTM layer in one persistent launch (csrc/lstm_seq.hip) — the LSTMCell loop of
+ * espresso/models/speech_lstm.py:846-893 and one direction of the packed nn.LSTM of :470-520.  Recurrent weights stay in
+ * registers, workgroups exchange h_t (fwd) / dgates_t (bwd) through global memory behind a grid barrier per step.
+ *   gx fp32 [U*B][4H] = x W_ih^T + b_ih + b_hh (rows t*B + b); w_hh bf16 [4H][H]; w_hhT bf16 [H][4H]; h0 bf16 [B][H] / c0 fp32
+ *   [B][H] (NULL = zero state); frozen uint8 [U][B] (NULL = none); reverse: walk t = U-1 .. 0.
+ *   fwd out: hs bf16 [U*B][H], cs fp32 [U][B][H], act fp32 [U][B][4H] (activated gates i,f,g,o), h_last fp32 [B][H] (may be NULL).
+ *   bwd in : dhs bf16 [U*B][H] (may be NULL), dh_last / dc_last fp32 [B][H] (may be NULL);
+ *   bwd out: dG bf16 [U*B][4H] (gradient of the gate pre-activations), dh0 / dc0 fp32 [B][H] (may be NULL).
+ *   counter: 2 x uint32 of device scratch (zeroed by the call); counter[1] != 0 afterwards = a barrier wait timed out.
+ * ea_lstm_seq_supported: 1 <= B <= 64 and H in {256, 320, 512, 640, 768, 800, 1024}; other shapes return -2 (callers use
+ * the per-step ea_gemm_bf16 + ea_lstm_cell_* path). */
+int ea_lstm_seq_supported(int B, int H);
+int ea_lstm_seq_fwd(const float* gx, const void* w_hh, const void* h0, const float* c0, const uint8_t* frozen, void* hs, float* cs,
+                    float* act, float* h_last, unsigned* counter, int B, int U, int H, int reverse, int frozen_out_zero,
+                    ea_stream_t stream);
+int ea_lstm_seq_bwd(const void* dhs, const float* dh_last, const float* dc_last, const float* act, const float* cs, const float* c0,
+                    const uint8_t* frozen, const void* w_hhT, void* dG, float* dh0, float* dc0, unsigned* counter, int B, int U,
+                    int H, int reverse, ea_stream_t stream);
 /* frozen_out_zero / frozen: packed-sequence semantics of the BiLSTM encoder (speech_lstm.py:470-520, pack_padded_sequence /
  * pad_packed_sequence with padding_value 0): rows past their length keep their state, emit zeros and get no gradient.
  *

@@ -970,6 +970,63 @@ def check_lstm_layer(B=5, U=9, I=48, H=64, with_state=False, seed=0):
     return res
 
 
+def check_lstm_persistent_vs_stepwise(B=5, U=11, I=96, H=256, with_state=False, reverse=False, ragged=False, seed=0):
+    """The persistent whole-sequence kernels (csrc/lstm_seq.hip) against the per-step GEMM + cell-kernel path (itself pinned to
+    torch.nn.LSTMCell above): same op, same bf16 storage points, only the fp32 summation order of the recurrent product
+    differs.  ragged: packed-sequence semantics (frozen rows), as the BiLSTM encoder uses them."""
+    from espresso_amd import functional as F
+    from espresso_amd import kernels as K
+    from espresso_amd.models.speech_lstm import LSTMCellParams
+
+    assert K.lstm_seq_supported(B, H)
+    torch.manual_seed(seed)
+    cell = LSTMCellParams(I, H).to(DEV)
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.mul_(3.0 * (64.0 / H) ** 0.5 if H > 64 else 3.0)
+    x0 = bf(torch.randn(U * B, I)).to(DEV)
+    h0 = torch.randn(B, H, device=DEV) * 0.5 if with_state else None
+    c0 = torch.randn(B, H, device=DEV) * 0.5 if with_state else None
+    R = torch.randn(U * B, H, device=DEV)
+    frozen = None
+    if ragged:
+        lens = torch.randint(1, U + 1, (B,), device=DEV)
+        lens[0] = U
+        frozen = (torch.arange(U, device=DEV).unsqueeze(1) >= lens.unsqueeze(0)).to(torch.uint8).contiguous()
+    out = {}
+    for mode in (True, False):
+        old = F.set_lstm_persistent(mode)
+        try:
+            for p in cell.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            h0g = h0.clone().requires_grad_(True) if with_state else None
+            c0g = c0.clone().requires_grad_(True) if with_state else None
+            if ragged or reverse:
+                hs = F.lstm_direction(x, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, B, U, reverse=reverse, frozen=frozen)
+                (hs.float() * R).sum().backward()
+                vals = {"hs": hs.detach().float()}
+            else:
+                hs, hl, cl = F.lstm_layer(x, cell, B, U, h0g, c0g)
+                ((hs.float() * R).sum() + (hl * 0.3).sum() + (cl * 0.2).sum()).backward()
+                vals = {"hs": hs.detach().float(), "h_last": hl.detach(), "c_last": cl.detach()}
+            for n, p in cell.named_parameters():
+                vals["grad_" + n] = p.grad.detach().float().clone()
+            vals["grad_x"] = x.grad.float()
+            if with_state:
+                vals["grad_h0"], vals["grad_c0"] = h0g.grad.clone(), c0g.grad.clone()
+            out[mode] = vals
+        finally:
+            F.set_lstm_persistent(old)
+    torch.cuda.synchronize()
+    res = {"barrier_timeouts": F.lstm_barrier_timeouts()}
+    for k in out[True]:
+        a_, b_ = out[True][k], out[False][k]
+        res[k] = float((a_ - b_).abs().max() / (b_.abs().max() + 1e-9))
+    res["finite"] = all(bool(torch.isfinite(v).all()) for v in out[True].values())
+    return res
+
+
 def build_tiny_transducer(V=40, embed_dim=64, heads=4):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerTransducerConfig
     from espresso_amd.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase

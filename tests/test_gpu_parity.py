@@ -271,6 +271,23 @@ def test_lstm_layer_vs_torch_lstmcell(with_state):
             assert v < 2e-2, (k, r)
 
 
+@pytest.mark.parametrize("shape", [
+    dict(B=5, U=11, I=96, H=256), dict(B=16, U=7, I=64, H=512, with_state=True), dict(B=20, U=9, I=80, H=320, with_state=True),
+    dict(B=37, U=6, I=64, H=1024), dict(B=3, U=1, I=64, H=512, with_state=True), dict(B=9, U=13, I=64, H=320, ragged=True),
+    dict(B=18, U=10, I=64, H=256, ragged=True, reverse=True), dict(B=4, U=8, I=64, H=800, reverse=True)],
+    ids=lambda d: "-".join(f"{k}{v}" for k, v in d.items()))
+def test_lstm_persistent_kernels_vs_stepwise_path(shape):
+    """csrc/lstm_seq.hip (one launch per layer and direction, weights in registers, grid barrier per step) vs the per-step
+    path: identical bf16 storage points, so everything agrees to fp32-summation-order noise amplified by bf16 re-rounding of h /
+    dgates (1e-2 of range over ~10 recurrent steps); no barrier timeout"""
+    r = G.check_lstm_persistent_vs_stepwise(**shape)
+    print(r)
+    assert r.pop("finite"), r
+    assert r.pop("barrier_timeouts") == 0, r
+    for k, v in r.items():
+        assert v < 1e-2, (k, r)
+
+
 def test_transducer_vs_reference_fixture():
     """speech_transformer_transducer_base on the HIP kernels vs the reference model's own outputs (fixture generated by
     oracle/gen_golden.py transducer): bf16 logits within 1e-2 * range (north-star tolerance), gradients 3e-2 of range"""
