@@ -266,6 +266,7 @@ def main(argv=None):
     ap.add_argument("--no-decode", action="store_true", help="skip the config-5 decode block (beam-10 RTF)")
     ap.add_argument("--decode-utts", type=int, default=1000, help="utterances of the 2864-utterance decode workload to time")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-nt-bytes", type=int, default=None, help="diagnostic: non-temporal store threshold of the GEMM epilogue (0 = off)")
     ap.add_argument("--gemm-dump", default=None, help="write the per-launch GEMM records of the roofline replay to this file")
     ap.add_argument("--n-utts", type=int, default=20000)
     ap.add_argument("--max-tokens", type=int, default=26000, help="diagnostic only: shrink the batches (host-overhead probes)")
@@ -301,6 +302,9 @@ def main(argv=None):
     if args.no_deferred:
         from espresso_amd import functional as _F
         _F.set_backward_deferred(False)
+    if args.gemm_nt_bytes is not None:
+        from espresso_amd._lib import lib as _ealib3
+        _ealib3().ea_set_gemm_nt_store_min_bytes(args.gemm_nt_bytes)
     if args.gemm_xcd_mask is not None:
         from espresso_amd._lib import lib as _ealib2
         _ealib2().ea_set_gemm_xcd_swizzle(args.gemm_xcd_mask)
@@ -380,6 +384,8 @@ def main(argv=None):
         torch.cuda.synchronize()
         ms, fl = ctypes.c_double(0), ctypes.c_double(0)
         n = lib.ea_gemm_profile_read(ctypes.byref(ms), ctypes.byref(fl))
+        alg = ctypes.c_double(0)
+        lib.ea_gemm_profile_bytes(ctypes.byref(alg))
         if args.gemm_dump:
             lib.ea_gemm_profile_dump(args.gemm_dump.encode())
         lib.ea_gemm_profile_enable(0)
@@ -388,12 +394,15 @@ def main(argv=None):
         # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
         # command, tools/pmc_bench_traffic.sh; counters cannot be read from inside the process)
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        tname = next((n for n in ("r02_gemm_traffic.json", "r01_gemm_traffic.json")
+                      if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n))), None)
+        if tname:
+            traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname))).get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel+gemm_glds_kernel+wgrad_group_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_gemm_traffic.json)",
+                    "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tname})",
+                    "algorithmic_bytes_per_launch": alg.value / max(n, 1),
+                    "traffic_over_algorithmic": (traffic / (alg.value / max(n, 1))) if traffic else None,
                     "launches_per_step": n / nrep, "avg_launch_us": tot_ms * 1e3 / max(n, 1),
                     "gemm_ms_per_step": tot_ms / nrep, "gemm_flop_per_step": tot_fl / nrep}
 

@@ -204,11 +204,15 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* q, bool vec, int cnt, f
     for (int e = 0; e < 8; ++e) o[e] = e < cnt ? bf2f(q[e]) : 0.f;
   }
 }
-__device__ __forceinline__ void store8_bf16(bf16_t* q, bool vec, int cnt, const float (&v)[8]) {
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store8_bf16(bf16_t* q, bool vec, int cnt, const float (&v)[8], bool nt = false) {
   if (vec) {
-    uint4 u;
+    u32x4_t u;
     u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
-    *reinterpret_cast<uint4*>(q) = u;
+    // large outputs are streamed past the L2 (the consumer is another kernel, mostly on another XCD): their write-allocate
+    // otherwise evicts the stationary operand the co-resident tiles share
+    if (nt) __builtin_nontemporal_store(u, reinterpret_cast<u32x4_t*>(q));
+    else *reinterpret_cast<u32x4_t*>(q) = u;
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (e < cnt) q[e] = f2bf(v[e]);
@@ -231,7 +235,7 @@ __device__ __forceinline__ void load_bias8(const EaGemmParams& p, int n, float (
 }
 
 __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int ks_id, int zhi, int zlo, long coff, int m,
-                                               int n, float (&v)[8], const float (&bias8)[8], bool vec_ok) {
+                                               int n, float (&v)[8], const float (&bias8)[8], bool vec_ok, bool nt = false) {
   const int cnt = min(8, p.N - n);
   const bool vec = vec_ok && cnt == 8;
   const bool has_drop = p.drop_thr != 0;
@@ -261,14 +265,14 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
     }
   } else {
     if (p.C2) {
-      store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v);
+      store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v, nt);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[e] = apply_act(v[e], p.act);
         if (has_drop) v[e] *= ea_keep(p.drop_seed, didx + e, p.drop_thr, p.drop_scale);
       }
       store8_bf16(reinterpret_cast<bf16_t*>(p.C2) + coff + (long)m * p.ldc2 + n,
-                  vec && (p.ldc2 & 7) == 0 && ((((uintptr_t)p.C2) & 15) == 0), cnt, v);
+                  vec && (p.ldc2 & 7) == 0 && ((((uintptr_t)p.C2) & 15) == 0), cnt, v, nt);
       return;
     }
 #pragma unroll
@@ -312,7 +316,7 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
       for (int e = 0; e < 8; ++e) if (e < cnt) C[e] = p.accumulate ? C[e] + v[e] : v[e];
     }
   } else {
-    store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v);
+    store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v, nt);
   }
 }
 
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
   const int wm = BM_ == 128 ? (wave >> 1) : 0;
   const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;  // first column of this wave's sub-tile
   int tile_x = blockIdx.x, tile_y = blockIdx.y, tile_z = blockIdx.z;
-  if (xcd_swizzle) {
+  if (xcd_swizzle & 1) {
     // workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest, then y, z); give every XCD one contiguous
     // range of the (z, y, x) tile order instead: the n-tiles of a row block and the row blocks of a batch item / k-chunk
     // then share their operand rows in ONE L2 (bijective for any grid size)
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok);
+          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok, (xcd_swizzle & 2) != 0);
         }
       }
     }
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
   const int wm = BM_ == 128 ? (wave >> 1) : 0;
   const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
   int tile_x = blockIdx.x, tile_y = blockIdx.y, tile_z = blockIdx.z;
-  if (xcd_swizzle) {
+  if (xcd_swizzle & 1) {
     // workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest, then y, z); give every XCD one contiguous
     // range of the (z, y, x) tile order instead: the n-tiles of a row block and the row blocks of a batch item / k-chunk
     // then share their operand rows in ONE L2 (bijective for any grid size)
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok);
+          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok, (xcd_swizzle & 2) != 0);
         }
       }
     }
@@ -694,7 +698,11 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const EaWgradGroup g, 
   const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
 
   int pi = 0;
-  const int bid = blockIdx.x;
+  // workgroups are dealt round-robin to the 8 XCDs: hand every XCD one contiguous range of the (problem, row block, column
+  // block) tile list instead, so that the tiles that walk the same dy / x columns share ONE L2 (PMC: 601 MB of L2 fills per
+  // launch against 207 MB of operands when neighbouring tiles sat on 8 different XCDs)
+  const int total = gridDim.x, xcd = blockIdx.x & 7, xq = total >> 3, xr = total & 7;
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
   while (pi + 1 < g.count && bid >= tb.start[pi + 1]) ++pi;
   const EaWgradProblem P = g.p[pi];
   const int local = bid - tb.start[pi];
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const EaWgradGroup g, 
 // ---- optional live profiling of the dominant kernel (bench.py roofline): HIP events around every launch on
 // the launch stream; flops = 2*M*N*K*batch per launch.
 #include <vector>
-struct GemmProf { hipEvent_t e0, e1; double flops; int M, N, K, batch, a_ks, b_ks, splitk, bm64, epi; };
+struct GemmProf { hipEvent_t e0, e1; double flops, bytes; int M, N, K, batch, a_ks, b_ks, splitk, bm64, epi; };
 static bool g_prof_on = false;
 static std::vector<GemmProf> g_prof;
 
@@ -864,6 +872,16 @@ extern "C" long ea_gemm_profile_read(double* total_ms, double* total_flops) {
   return (long)g_prof.size();
 }
 
+// algorithmic bytes of the recorded launches: every operand read once, every output written once (A + B + C, plus the
+// residual / auxiliary / second-output tensors of the fused epilogues; a split-K launch writes its fp32 slabs; a grouped
+// weight-gradient launch reads dy and x once and read-modify-writes dW) — the denominator of bench.py's traffic ratio
+extern "C" int ea_gemm_profile_bytes(double* total_bytes) {
+  double b = 0.0;
+  for (auto& r : g_prof) b += r.bytes;
+  *total_bytes = b;
+  return 0;
+}
+
 // one text line per recorded launch: M N K batch a_kstrided b_kstrided splitk bm64 epilogue-bits ms
 extern "C" long ea_gemm_profile_dump(const char* path) {
   FILE* f = fopen(path, "w");
@@ -878,6 +896,15 @@ extern "C" long ea_gemm_profile_dump(const char* path) {
   return (long)g_prof.size();
 }
 
+static long g_nt_store_min_bytes = 0;  // > 0: bf16 outputs of at least this size are written with non-temporal stores (measured neutral on the bench step: off)
+extern "C" long ea_set_gemm_nt_store_min_bytes(long bytes) {
+  const long old = g_nt_store_min_bytes;
+  g_nt_store_min_bytes = bytes;
+  return old;
+}
+static inline int nt_flag(const EaGemmParams& q) {
+  return (g_nt_store_min_bytes > 0 && !q.c_f32 && q.splitk <= 1 && 2L * q.M * q.N * q.batch >= g_nt_store_min_bytes) ? 2 : 0;
+}
 static int g_xcd_swizzle = 3;  // bit 0: direct-to-LDS kernel, bit 1: register-staged kernel; gated on the grid shape at the launch sites
 extern "C" int ea_set_gemm_xcd_swizzle(int mask) {
   const int old = g_xcd_swizzle;
@@ -920,7 +947,7 @@ template <bool A_KS, bool B_KS>
 static void launch_gemm(dim3 grid, bool bm64, hipStream_t stream, const EaGemmParams& q) {
   // the remap helps when several n-tiles share a row block and the grid spans many row blocks (not for batched / split launches,
   // whose z index already separates the operands)
-  const int sw = (g_xcd_swizzle & 2) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 ? 1 : 0;
+  const int sw = ((g_xcd_swizzle & 2) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 ? 1 : 0) | nt_flag(q);
   if (bm64) hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 64>), grid, dim3(256), 0, stream, q, sw);
   else hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 128>), grid, dim3(256), 0, stream, q, sw);
 }
@@ -959,6 +986,9 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
     pr.splitk = q.splitk; pr.bm64 = bm64;
     pr.epi = (q.bias ? 1 : 0) | (q.resid ? 2 : 0) | (q.aux ? 4 : 0) | (q.C2 ? 8 : 0) | (q.act != EA_ACT_NONE ? 16 : 0) |
              (q.drop_thr ? 32 : 0) | (q.c_f32 ? 64 : 0);
+    const double mn = (double)q.M * q.N * q.batch;
+    pr.bytes = 2.0 * q.batch * ((double)q.M * q.K + (double)q.N * q.K) + mn * (q.splitk > 1 ? 4.0 * q.splitk : (q.c_f32 ? 4.0 : 2.0)) +
+               (q.resid ? 2.0 * mn : 0.0) + (q.aux ? 2.0 * mn : 0.0) + (q.C2 ? 2.0 * mn : 0.0);
     hipEventRecord(pr.e0, stream);
   }
   bool done = false;
@@ -973,7 +1003,7 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   if (!done && g_gemm_glds && kc_ok) {
     // XCD-aware tile order when the whole B operand fits every XCD's L2 next to the streamed A rows (few n-tiles): measured
     // L2 hit rate 58 -> 82 % and -10..-20 % time on the N = 512 projections; slower for square problems (B no longer stationary)
-    const int sw = ((g_xcd_swizzle & 1) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 && (grid.x > 1 || grid.z > 1)) ? 1 : 0;
+    const int sw = (((g_xcd_swizzle & 1) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 && (grid.x > 1 || grid.z > 1)) ? 1 : 0) | nt_flag(q);
     int nst = g_gemm_glds;
     if (nst == 1) {
       // many workgroups and a short reduction (the K = 512 projections: 8 k-tiles, 6 workgroups per CU): co-resident
@@ -1039,7 +1069,11 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
     hipEventCreate(&pr.e0);
     hipEventCreate(&pr.e1);
     pr.flops = 0.0;
-    for (int i = 0; i < g.count; ++i) pr.flops += 2.0 * g.p[i].M * (double)g.p[i].N * g.p[i].K;
+    pr.bytes = 0.0;
+    for (int i = 0; i < g.count; ++i) {
+      pr.flops += 2.0 * g.p[i].M * (double)g.p[i].N * g.p[i].K;
+      pr.bytes += 2.0 * g.p[i].M * ((double)g.p[i].N + g.p[i].K) + 8.0 * g.p[i].N * (double)g.p[i].K;
+    }
     pr.M = total; pr.N = g.count; pr.K = g.p[0].M; pr.batch = 1; pr.a_ks = 1; pr.b_ks = 1; pr.splitk = 1; pr.bm64 = bm64; pr.epi = 128;
     hipEventRecord(pr.e0, stream);
   }

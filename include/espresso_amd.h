@@ -88,8 +88,12 @@ int ea_set_gemm_glds(int stages);
  * 1 = automatic tile configuration, 2 + c = configuration c forced (0: 256x128, 1: 192x128, 2: 128x128 tiles);
  * returns the previous value */
 int ea_set_gemm_persistent(int mode);
+/* bf16 GEMM outputs of at least `bytes` are written with non-temporal stores (default 0 = never: measured neutral on the training step); returns the old value */
+long ea_set_gemm_nt_store_min_bytes(long bytes);
 int ea_gemm_profile_enable(int on);
 long ea_gemm_profile_read(double* total_ms, double* total_flops);
+/* algorithmic HBM bytes of the recorded launches (operands read once, outputs written once) */
+int ea_gemm_profile_bytes(double* total_bytes);
 /* writes one line per recorded launch ("M N K batch a_ks b_ks splitk bm64 epilogue-bits ms"); returns the count or -1 */
 long ea_gemm_profile_dump(const char* path);
 
