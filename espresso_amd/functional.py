@@ -162,13 +162,17 @@ def layer_norm(x, g, b, eps=1e-5, row_zero=None, drop_p=0.0):
 # ------------------------------------------------------------------------------------------------
 class _FFN(torch.autograd.Function):
     """y = out_scale * drop2(W2 drop1(act(W1 LN(x) + b1)) + b2) + x   (pre_ln=True)
-       y = out_scale * drop2(W2 drop1(act(W1 x + b1)) + b2) + x        (pre_ln=False, x already normalised... not used)"""
+       y = out_scale * drop2(W2 drop1(act(W1 x + b1)) + b2) + x        (ln_g None: post-LN layers, fairseq transformer_layer.py:200-226
+                                                                      with normalize_before False; the caller applies the LayerNorm)"""
 
     @staticmethod
     def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, w1_16, w2_16, act, p_act, p_out, out_scale, eps):
         M, C = x.shape
         Fd = w1.shape[0]
-        xn, mean, rstd = K.layernorm_fwd(x, ln_g, ln_b, eps)
+        if ln_g is not None:
+            xn, mean, rstd = K.layernorm_fwd(x, ln_g, ln_b, eps)
+        else:  # post-LN layer: the caller normalises the residual sum afterwards
+            xn, mean, rstd = x, None, None
         s1 = _next_seed() if p_act > 0 else 0
         s2 = _next_seed() if p_out > 0 else 0
         z = _new((M, Fd), torch.bfloat16, x)
@@ -198,6 +202,8 @@ class _FFN(torch.autograd.Function):
         db1 = K.colsum(dz, _zeros_f32(Fd, x), M, Fd, Fd)
         dxn = _new((M, C), torch.bfloat16, x)
         K.gemm(dz, w1_16, dxn, M, C, Fd, lda=Fd, ldb=C, ldc=C, b_kstrided=True)
+        if ln_g is None:
+            return dxn + dy, None, None, dW1, db1, dW2, db2, None, None, None, None, None, None, None
         dg, db = _zeros_f32(C, x), _zeros_f32(C, x)
         dx = K.layernorm_bwd(x, dxn, ln_g, mean, rstd, dg, db, dx_add=dy)
         return dx, dg, db, dW1, db1, dW2, db2, None, None, None, None, None, None, None
@@ -1266,6 +1272,52 @@ class _Embedding(torch.autograd.Function):
 def embedding(W, tokens, positions=None, pos_table=None, scale=1.0, pad_idx=-1):
     """bf16 [M][C] = scale * W[tokens] + pos_table[positions] ; tokens/positions int32 [M]."""
     return _Embedding.apply(W, tokens, positions, pos_table, scale, pad_idx)
+
+
+class _AddPositions(torch.autograd.Function):
+    """bf16 [M][C] = scale * x + table[positions] — the absolute positional embedding of the legacy encoder presets
+    (espresso/models/transformer/speech_transformer_encoder.py:345-347; positions from fairseq utils.make_positions: 1..len on
+    frames, padding_idx on padded frames).  A one-off element-wise pass outside the layer stack: plain tensor ops."""
+
+    @staticmethod
+    def forward(ctx, x, table, positions, scale):
+        ctx.save_for_backward(positions)
+        ctx.scale, ctx.tshape, ctx.tgrad = scale, table.shape, table.requires_grad
+        return (x.float() * scale + table.float().index_select(0, positions)).to(torch.bfloat16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (positions,) = ctx.saved_tensors
+        dt = None
+        if ctx.tgrad:
+            dt = torch.zeros(ctx.tshape, dtype=torch.float32, device=dy.device).index_add_(0, positions, dy.float())
+        return (dy if ctx.scale == 1.0 else (dy.float() * ctx.scale).to(dy.dtype)), dt, None, None
+
+
+def add_positions(x, table, positions, scale=1.0):
+    return _AddPositions.apply(x, table, positions, scale)
+
+
+class _ZeroRows(torch.autograd.Function):
+    """x with the rows marked in row_zero (uint8 [M]) set to 0 (padded frames, speech_transformer_encoder.py:353-355)."""
+
+    @staticmethod
+    def forward(ctx, x, row_zero):
+        ctx.save_for_backward(row_zero)
+        y = x.contiguous().clone()
+        K.zero_rows(y, row_zero)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (row_zero,) = ctx.saved_tensors
+        g = dy.contiguous().clone()
+        K.zero_rows(g, row_zero)
+        return g, None
+
+
+def zero_rows(x, row_zero):
+    return _ZeroRows.apply(x, row_zero)
 
 
 def dropout(x, p):

@@ -21,6 +21,16 @@ from ...tools import utils as speech_utils
 from .speech_transformer_config import DEFAULT_MAX_SOURCE_POSITIONS, SpeechTransformerConfig
 
 
+class AbsolutePositionTable(nn.Module):
+    """fairseq LearnedPositionalEmbedding storage (`embed_positions.weight`, padding row 0 zero, N(0, d^-0.5) init)."""
+
+    def __init__(self, num_embeddings, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num_embeddings, dim))
+        nn.init.normal_(self.weight, mean=0, std=dim ** -0.5)
+        nn.init.constant_(self.weight[0], 0)
+
+
 class SpeechTransformerEncoderBase(nn.Module):
     def __init__(self, cfg, pre_encoder=None, input_size=83):
         super().__init__()
@@ -32,8 +42,14 @@ class SpeechTransformerEncoderBase(nn.Module):
         self.pre_encoder = pre_encoder
         self.fc0 = LinearParams(input_size, d) if input_size != d else None
         self.embed_scale = 1.0 if (cfg.no_scale_embedding or self.fc0 is not None) else d ** 0.5
-        if not cfg.encoder.relative_positional_embeddings and not cfg.no_token_positional_embeddings:
-            raise NotImplementedError("absolute positional embeddings: the ASR recipes use relative positions")
+        # absolute positions (speech_transformer_encoder.py:95-103: the legacy `speech_transformer_{wsj,swbd,librispeech}` presets):
+        # sinusoidal table (no parameters) or learned `embed_positions.weight`; padding_idx 0, positions 1..len
+        self.embed_positions = None
+        self.abs_positions = not cfg.encoder.relative_positional_embeddings and not cfg.no_token_positional_embeddings
+        if self.abs_positions and cfg.encoder.learned_pos:
+            n = int(self.output_lengths(cfg.max_source_positions)) if pre_encoder is not None else cfg.max_source_positions
+            self.embed_positions = AbsolutePositionTable(n + 1, d)  # fairseq PositionalEmbedding: num_embeddings + padding_idx + 1
+        self._sin_table = None
         self.layernorm_embedding = LayerNormParams(d) if cfg.layernorm_embedding else None
         nl = cfg.encoder.layers
         if not cfg.encoder.relative_positional_embeddings:
@@ -63,8 +79,6 @@ class SpeechTransformerEncoderBase(nn.Module):
         else:
             self.layer_norm = None
         self.transformer_context = speech_utils.eval_str_nested_list_or_tuple(cfg.encoder.transformer_context, type=int)
-        if cfg.encoder.chunk_size > 0:
-            raise NotImplementedError("chunk-streaming masks (not used by the LibriSpeech recipes)")
         self.num_updates = 0
 
     def set_num_updates(self, num_updates):
@@ -73,9 +87,19 @@ class SpeechTransformerEncoderBase(nn.Module):
     def output_lengths(self, in_lengths):
         return in_lengths if self.pre_encoder is None else self.pre_encoder.output_lengths(in_lengths)
 
-    def get_attn_mask(self, max_len, device):
-        """Additive fp32 [T][T] mask from `transformer_context` (speech_transformer_encoder.py:250-263),
-        already filled with -1e8 where masked (conformer layer :107-110), or None."""
+    def get_attn_mask(self, max_len, device, in_lengths=None):
+        """Additive fp32 [T][T] mask from the chunk-streaming setting (speech_transformer_encoder.py:240-248: drawn under
+        `numpy_seed(num_updates)`, last chunk partial at inference) or `transformer_context` (:250-263), already filled with
+        -1e8 where masked (conformer layer :107-110), or None."""
+        if self.cfg.encoder.chunk_size > 0:
+            from ...data.data_utils import numpy_seed
+
+            with numpy_seed(self.num_updates):
+                vis = speech_utils.chunk_streaming_mask(in_lengths, self.cfg.encoder.chunk_size,
+                                                        left_window=self.cfg.encoder.chunk_left_window,
+                                                        right_window=self.cfg.encoder.chunk_right_window,
+                                                        always_partial_in_last=not self.training)
+            return torch.zeros(max_len, max_len, device=device).masked_fill(~vis.to(device), -1e8).contiguous()
         tc = self.transformer_context
         if tc is None or (tc[0] is None and tc[1] is None):
             return None
@@ -87,6 +111,24 @@ class SpeechTransformerEncoderBase(nn.Module):
         else:
             m = ones.triu(tc[1] + 1) | ones.tril(-tc[0] - 1)
         return torch.zeros(max_len, max_len, device=device).masked_fill(m, -1e8).contiguous()
+
+    def _add_positions(self, x, padding_mask):
+        """x = embed_scale * x + embed_positions(make_positions(~padding_mask))  (speech_transformer_encoder.py:343-347)."""
+        B, Tp = padding_mask.shape
+        valid = (~padding_mask).to(torch.int64)
+        pos = (torch.cumsum(valid, dim=1) * valid).reshape(-1)  # fairseq utils.make_positions with padding_idx 0
+        if not self.abs_positions:
+            table = torch.zeros(1, self.embed_dim, device=x.device)
+            pos = torch.zeros_like(pos)
+        elif self.embed_positions is not None:
+            table = self.embed_positions.weight
+        else:
+            if self._sin_table is None or self._sin_table.shape[0] < Tp + 1 or self._sin_table.device != x.device:
+                from .speech_transformer_base import sinusoidal_positional_table
+
+                self._sin_table = sinusoidal_positional_table(max(Tp + 1, 1024), self.embed_dim, 0).to(x.device)
+            table = self._sin_table
+        return F.add_positions(x, table, pos, self.embed_scale)
 
     def _fc0_weight(self):
         """fc0 consumes (c*F' + f)-ordered features in the reference; the channels-last sub-sampler
@@ -106,14 +148,24 @@ class SpeechTransformerEncoderBase(nn.Module):
         Tp = padding_mask.shape[1]
         if self.fc0 is not None:
             x = F.linear(x, self._fc0_weight(), self.fc0.bias)
+        if self.abs_positions or self.embed_scale != 1.0:
+            x = self._add_positions(x, padding_mask)
         if self.layernorm_embedding is not None:
             x = F.layer_norm(x, self.layernorm_embedding.weight, self.layernorm_embedding.bias, row_zero=row_zero, drop_p=p)
-        else:
-            raise NotImplementedError("layernorm_embedding=false (all recipes set it true)")
+        else:  # legacy presets: dropout straight on the embedding, padded frames zeroed (speech_transformer_encoder.py:350-355)
+            if p > 0:
+                x = F.dropout(x, p)
+            if row_zero is not None:
+                x = F.zero_rows(x, row_zero)
         key_len = x_lengths.to(torch.int32).contiguous()
-        attn_mask = self.get_attn_mask(Tp, x.device)
+        attn_mask = self.get_attn_mask(Tp, x.device, in_lengths=x_lengths)
         states = [x] if return_all_hiddens else []
-        for layer in self.layers:
+        # LayerDrop (fairseq/modules/layer_drop.py:38-44: one uniform draw per layer per forward, layer kept when the draw exceeds p)
+        ld = float(getattr(cfg.encoder, "layerdrop", 0.0) or 0.0)
+        keep = torch.empty(len(self.layers)).uniform_() > ld if (tr and ld > 0) else None
+        for i, layer in enumerate(self.layers):
+            if keep is not None and not bool(keep[i]):
+                continue
             x = layer(x, B, Tp, key_len=key_len, attn_mask=attn_mask)
             if return_all_hiddens:
                 states.append(x)
@@ -239,7 +291,7 @@ class SpeechTransformerEncoderModel(nn.Module):
             if "conv_layers_before" in k:
                 state_dict[k.replace("conv_layers_before", "pre_encoder")] = state_dict.pop(k)
         for k in list(state_dict.keys()):
-            if k.endswith("positional_embedding._float_tensor"):
+            if k.endswith("positional_embedding._float_tensor") or k.endswith("embed_positions._float_tensor"):
                 state_dict.pop(k)
         return state_dict
 

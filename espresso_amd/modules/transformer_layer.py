@@ -17,8 +17,6 @@ class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         self.embed_dim = d
         self.num_heads = cfg.encoder.attention_heads
         self.normalize_before = cfg.encoder.normalize_before
-        if not self.normalize_before:
-            raise NotImplementedError("post-LN encoder layers (the recipes set normalize_before: true)")
         self.positional_embedding = [positional_embedding]
         self.self_attn = MultiheadAttentionParams(d, self.num_heads, relpos=positional_embedding is not None,
                                                   positional_embedding=positional_embedding)
@@ -38,7 +36,8 @@ class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         p_att = cfg.attention_dropout if tr else 0.0
         a = self.self_attn
         pe = self.positional_embedding[0]
-        if self.use_native_runtime and pe is not None and x.is_cuda and self.activation_fn in ("relu", "silu", "swish"):
+        if (self.use_native_runtime and pe is not None and self.normalize_before and x.is_cuda
+                and self.activation_fn in ("relu", "silu", "swish")):
             return F.transformer_layer_native(x, _pe_table(pe, T, x.device, self.num_heads, self.embed_dim), self, key_len, attn_mask,
                                               B, T, p_drop, p_act, p_att, tr, "silu" if self.activation_fn == "swish" else self.activation_fn)
         wqkv, bqkv, wqkv16 = a.fused_qkv()
@@ -46,6 +45,11 @@ class TransformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
                           a.out_proj.weight, a.out_proj.bias, a.pos_bias_u, a.pos_bias_v,
                           a.pos_proj.weight if a.pos_proj is not None else None,
                           _pe_table(pe, T, x.device, self.num_heads, self.embed_dim), key_len, attn_mask, B, T, self.num_heads,
-                          p_attn=p_att, p_out=p_drop, wqkv16=wqkv16)
+                          p_attn=p_att, p_out=p_drop, wqkv16=wqkv16, pre_ln=self.normalize_before)
+        if not self.normalize_before:  # post-LN (fairseq transformer_layer.py:176-226 with normalize_before False)
+            x = F.layer_norm(x, self.self_attn_layer_norm.weight, self.self_attn_layer_norm.bias)
+            x = F.ffn_module(x, None, None, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, act=self.activation_fn,
+                             p_act=p_act, p_out=p_drop, out_scale=1.0)
+            return F.layer_norm(x, self.final_layer_norm.weight, self.final_layer_norm.bias)
         return F.ffn_module(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
                             self.fc2.weight, self.fc2.bias, act=self.activation_fn, p_act=p_act, p_out=p_drop, out_scale=1.0)

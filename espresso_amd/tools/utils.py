@@ -117,3 +117,25 @@ def tokenize(sent, space="<space>", non_lang_syms=None):
     from .tensorized_prefix_tree import tokenize as _tokenize
 
     return _tokenize(sent, space=space, non_lang_syms=non_lang_syms)
+
+
+def chunk_streaming_mask(sequence_length, chunk_size, left_window=0, right_window=0, always_partial_in_last=False):
+    """Visibility mask (T x T bool, True = query row may attend key column) of the chunk-streaming encoder —
+    espresso/tools/utils.py:131-194.  The time axis is cut into chunks of `chunk_size` frames; a frame sees its own chunk,
+    `left_window` chunks before it and `right_window` chunks after it.  The short chunk is the last one, or — in training, on a
+    coin flip from numpy's global RNG (drawn exactly when the reference draws it: only if `always_partial_in_last` is False) —
+    the first one."""
+    import numpy as np
+
+    T = int(sequence_length.max())
+    dev = sequence_length.device
+    starts = torch.arange(0, T, chunk_size, device=dev)
+    if not always_partial_in_last and np.random.rand() > 0.5:
+        starts = torch.cat([starts.new_zeros(1), (T - starts).flip(0)[:-1]])  # short chunk first
+    n = starts.numel()
+    ends = torch.cat([starts[1:], starts.new_full((1,), T)])
+    t = torch.arange(T, device=dev)
+    chunk = torch.searchsorted(starts, t, right=True) - 1  # chunk index of every frame
+    lo = starts[(chunk - left_window).clamp(min=0)]
+    hi = ends[(chunk + right_window).clamp(max=n - 1)]
+    return (t.unsqueeze(0) >= lo.unsqueeze(1)) & (t.unsqueeze(0) < hi.unsqueeze(1))

@@ -4,6 +4,7 @@
 Runs only in the build container (the GPU box has no /root/reference); the fixtures it writes are
 committed.  Usage:  python oracle/gen_golden.py
 """
+import json
 import os
 import sys
 
@@ -62,7 +63,7 @@ def build_ref_encoder(cfg, vocab):
     return SpeechTransformerEncoderForPrediction(cfg, pre_encoder=pre, input_size=20 * ch[-1], vocab_size=vocab)
 
 
-def encoder_fixture(layer_type, name, learned_pos=False, d=64, heads=4, ffn=128, frames=70):
+def encoder_fixture(layer_type, name, learned_pos=False, d=64, heads=4, ffn=128, frames=70, legacy=None):
     """`d=128, heads=2` gives head dim 64 — the shape class of the recipes (512 / 8) that runs on the fused attention kernels;
     `frames=300` makes 75 encoder frames, i.e. more than one 64-key tile of those kernels."""
     torch.manual_seed(1234)
@@ -72,6 +73,18 @@ def encoder_fixture(layer_type, name, learned_pos=False, d=64, heads=4, ffn=128,
         cfg.encoder.learned_pos = True
         cfg.encoder.share_learned_relative_positional_embeddings_across_layers = False
         cfg.encoder.share_learned_relative_positional_embeddings_across_heads = False
+    meta = {}
+    if legacy is not None:
+        # what the argparse presets `speech_transformer_{wsj,swbd,librispeech}` configure (speech_transformer_legacy.py:103-178):
+        # absolute positions (sinusoidal or learned), no embedding LayerNorm; optionally post-LN and chunk-streaming masks
+        cfg.encoder.relative_positional_embeddings = False
+        cfg.encoder.learned_pos = bool(legacy.get("learned_pos", False))
+        cfg.layernorm_embedding = bool(legacy.get("layernorm_embedding", False))
+        cfg.encoder.normalize_before = bool(legacy.get("normalize_before", True))
+        cfg.encoder.chunk_size = int(legacy.get("chunk_size", 0))
+        cfg.encoder.chunk_left_window = int(legacy.get("chunk_left_window", 0))
+        cfg.encoder.chunk_right_window = int(legacy.get("chunk_right_window", 0))
+        meta = dict(legacy)
     enc = build_ref_encoder(cfg, V)
     # make BN affine / running stats and biases non-trivial so the check exercises them
     with torch.no_grad():
@@ -120,6 +133,7 @@ def encoder_fixture(layer_type, name, learned_pos=False, d=64, heads=4, ffn=128,
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         feats=feats.numpy(), lengths=lengths.numpy(), targets=tgt.numpy(),
+        meta=np.array(json.dumps(meta)),
         **{"sd::" + k: v.numpy() for k, v in sd.items()},
         **{"out::" + k: v for k, v in out.items()},
         **{"grad::" + k: v for k, v in grads.items()},
@@ -1050,6 +1064,12 @@ if __name__ == "__main__":
         encoder_fixture("conformer", "ref_conformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
         encoder_fixture("transformer", "ref_transformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
         encdec_fixture("ref_transformer_encdec_dh64", dm=128, heads=2, ffn=256, frames=300)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "legacy":  # encoder configurations of the argparse presets / streaming options
+        encoder_fixture("transformer", "ref_transformer_ctc_legacy", d=128, heads=2, ffn=256, frames=150, legacy={})
+        encoder_fixture("transformer", "ref_transformer_ctc_postln_chunk", legacy=dict(
+            learned_pos=True, normalize_before=False, chunk_size=4, chunk_left_window=1, chunk_right_window=0))
+        encoder_fixture("conformer", "ref_conformer_ctc_abspos", legacy={})
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "speechlstm":
         speech_lstm_fixture()

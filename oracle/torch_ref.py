@@ -160,8 +160,14 @@ def conformer_layer(x, sd, p, H, key_padding_mask, training, update=None, attn_m
     return _ln(x, sd, p + "final_layer_norm.")
 
 
-def transformer_layer(x, sd, p, H, key_padding_mask, activation="relu", attn_mask=None):
-    """fairseq/modules/transformer_layer.py:163-226 with normalize_before=True."""
+def transformer_layer(x, sd, p, H, key_padding_mask, activation="relu", attn_mask=None, normalize_before=True):
+    """fairseq/modules/transformer_layer.py:163-226 (pre-LN; post-LN when normalize_before is False)."""
+    if not normalize_before:
+        x = _ln(_r(relpos_mhsa(x, sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x), sd, p + "self_attn_layer_norm.")
+        y = _lin(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
+        y = _r(F.relu(y) if activation == "relu" else F.silu(y))
+        y = _lin(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+        return _ln(_r(x + y), sd, p + "final_layer_norm.")
     x = _r(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x)
     y = _ln(x, sd, p + "final_layer_norm.")
     y = _lin(y, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
@@ -192,8 +198,44 @@ def conv_bn_relu(feats, lengths, sd, p, strides, training, update=None):
     return x, out_len, pad
 
 
+def chunk_attn_mask(out_lengths, chunk_size, left_window, right_window, training, num_updates=0):
+    """Additive (T', T') mask of the chunk-streaming encoder: espresso/models/transformer/speech_transformer_encoder.py:240-248 +
+    espresso/tools/utils.py:131-194, restated with plain loops.  Chunks of `chunk_size` encoder frames; a frame sees its chunk,
+    `left_window` chunks to the left and `right_window` to the right; in training a coin flip (numpy RNG seeded with the update
+    count, fairseq numpy_seed) decides whether the short chunk is the first instead of the last; masked entries get -1e8
+    (fairseq transformer_layer.py:186-189)."""
+    T = int(out_lengths.max())
+    state = np.random.get_state()
+    np.random.seed(num_updates)
+    short_first = training and np.random.rand() > 0.5
+    np.random.set_state(state)
+    bounds = list(range(0, T, chunk_size))
+    if short_first:
+        bounds = [0] + sorted(T - b for b in bounds)[:-1]
+    bounds.append(T)
+    n = len(bounds) - 1
+    m = torch.full((T, T), -1e8)
+    for t in range(T):
+        c = max(i for i in range(n) if bounds[i] <= t)
+        lo, hi = bounds[max(c - left_window, 0)], bounds[min(c + right_window, n - 1) + 1]
+        m[t, lo:hi] = 0.0
+    return m
+
+
+def legacy_encoder_kwargs(meta, lengths, training, strides=((1, 1), (2, 2), (1, 1), (2, 2))):
+    """Keyword arguments of `encoder` for a fixture written with `legacy=...` (oracle/gen_golden.py): post-LN flag and the chunk mask."""
+    kw = {"normalize_before": bool(meta.get("normalize_before", True))}
+    if int(meta.get("chunk_size", 0)) > 0:
+        ol = lengths.clone()
+        for s_ in strides:
+            ol = torch.div(ol + s_[0] - 1, s_[0], rounding_mode="floor")
+        kw["attn_mask"] = chunk_attn_mask(ol, int(meta["chunk_size"]), int(meta.get("chunk_left_window", 0)),
+                                          int(meta.get("chunk_right_window", 0)), training)
+    return kw
+
+
 def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activation="relu",
-            strides=((1, 1), (2, 2), (1, 1), (2, 2)), update=None):
+            strides=((1, 1), (2, 2), (1, 1), (2, 2)), update=None, normalize_before=True, attn_mask=None):
     """espresso/models/transformer/speech_transformer_encoder.py:298-409 + fc_out
     (speech_transformer_encoder_model.py:207-208), dropout = 0.  Returns (logits (T',B,V), out_lengths)."""
     def _t(v):
@@ -204,7 +246,14 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
     sd = {k: _t(v) for k, v in sd.items()}
     x, out_len, pad = conv_bn_relu(feats.float(), lengths, sd, "pre_encoder.", strides, training, update)
     x = _r(_lin(x, sd["fc0.weight"], sd["fc0.bias"]))
-    x = _ln(x, sd, "layernorm_embedding.")
+    if "embed_positions.weight" in sd or "embed_positions._float_tensor" in sd:
+        # absolute positions of the legacy presets (speech_transformer_encoder.py:345-347; make_positions with padding_idx 0)
+        valid = (~pad).long()
+        pos = torch.cumsum(valid, 1) * valid
+        tab = sd["embed_positions.weight"] if "embed_positions.weight" in sd else sinusoidal_abs_pe(int(pos.max()) + 1, x.shape[-1], 0)
+        x = _r(x + tab[pos])
+    if "layernorm_embedding.weight" in sd:
+        x = _ln(x, sd, "layernorm_embedding.")
     x = x * (1 - pad.unsqueeze(-1).float())
     x = x.transpose(0, 1)
     kpm = pad if bool(pad.any()) else None
@@ -212,9 +261,9 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
     while f"layers.{i}.final_layer_norm.weight" in sd:
         p = f"layers.{i}."
         if layer_type == "conformer":
-            x = conformer_layer(x, sd, p, H, kpm, training, update)
+            x = conformer_layer(x, sd, p, H, kpm, training, update, attn_mask=attn_mask)
         else:
-            x = transformer_layer(x, sd, p, H, kpm, activation)
+            x = transformer_layer(x, sd, p, H, kpm, activation, attn_mask=attn_mask, normalize_before=normalize_before)
         i += 1
     if "layer_norm.weight" in sd:
         x = _ln(x, sd, "layer_norm.")

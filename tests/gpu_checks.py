@@ -229,7 +229,7 @@ class _Task:
         assert len(self.target_dictionary) == V
 
 
-def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128, learned_pos=False):
+def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128, learned_pos=False, legacy=None):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
     from espresso_amd.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderModel
 
@@ -242,6 +242,14 @@ def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128, learned_p
     cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
     cfg.layernorm_embedding = True
     cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    if legacy is not None:  # the options of a fixture written with `legacy=...` (oracle/gen_golden.py)
+        e.relative_positional_embeddings = False
+        e.learned_pos = bool(legacy.get("learned_pos", False))
+        cfg.layernorm_embedding = bool(legacy.get("layernorm_embedding", False))
+        e.normalize_before = bool(legacy.get("normalize_before", True))
+        e.chunk_size = int(legacy.get("chunk_size", 0))
+        e.chunk_left_window = int(legacy.get("chunk_left_window", 0))
+        e.chunk_right_window = int(legacy.get("chunk_right_window", 0))
     return SpeechTransformerEncoderModel.build_model(cfg, _Task(V))
 
 
@@ -255,7 +263,7 @@ def load_ref_state(model, sd):
 
 def _fixture_shape(fixture):
     """(embed_dim, heads, ffn) of an encoder fixture: `*_dh64` = head dim 64 (the recipes' 512 / 8 shape class)."""
-    return (128, 2, 256) if fixture.endswith("_dh64") else (64, 4, 128)
+    return (128, 2, 256) if fixture.endswith("_dh64") or fixture == "ref_transformer_ctc_legacy" else (64, 4, 128)
 
 
 def check_encoder_vs_reference(layer_type="conformer", fixture=None):
@@ -274,7 +282,13 @@ def check_encoder_vs_reference(layer_type="conformer", fixture=None):
     learned = "learnedpos" in name
     layer_type = layer_type.split("_")[0]
     d, H, ffn = _fixture_shape(name)
-    model = build_tiny_model(layer_type, embed_dim=d, heads=H, ffn=ffn, learned_pos=learned).to(DEV)
+    legacy = None
+    if "meta" in g.files:
+        import json
+
+        legacy = json.loads(str(g["meta"]))
+    lkw = lambda training: torch_ref.legacy_encoder_kwargs(legacy, torch.from_numpy(g["lengths"]), training) if legacy is not None else {}
+    model = build_tiny_model(layer_type, embed_dim=d, heads=H, ffn=ffn, learned_pos=learned, legacy=legacy).to(DEV)
     load_ref_state(model, sd)
     feats = torch.from_numpy(g["feats"]).to(DEV)
     lengths = torch.from_numpy(g["lengths"]).to(DEV)
@@ -290,7 +304,7 @@ def check_encoder_vs_reference(layer_type="conformer", fixture=None):
     flash = d // H == 64
     with torch.no_grad(), torch_ref.bf16_emulation(True, flash=flash):
         emu_eval, _ = torch_ref.encoder(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), sd, H=H, layer_type=layer_type,
-                                        training=False)
+                                        training=False, **lkw(False))
     res["eval_logits_vs_emulation"] = float((lo - emu_eval).abs().max())
     # the same in units of the bf16 spacing at each logit's magnitude (a bf16 logit of magnitude 2..4 cannot be closer than 0.0156)
     ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(lo.abs(), emu_eval.abs()).clamp_min(2.0 ** -20))) - 7)
@@ -327,11 +341,11 @@ def check_encoder_vs_reference(layer_type="conformer", fixture=None):
     res["train_loss"] = float(loss.detach())
     res["ref_loss"] = float(g["out::train_loss"])
     # ---- bf16-emulating oracle, train mode: loss and every gradient ----
-    sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version" else v.clone())
-           for k, v in sd.items()}
+    sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version"
+               and not k.endswith("_float_tensor") else v.clone()) for k, v in sd.items()}
     with torch_ref.bf16_emulation(True, flash=flash):
         lt, ole = torch_ref.encoder(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), sde, H=H, layer_type=layer_type,
-                                    training=True)
+                                    training=True, **lkw(True))
         tg = torch.from_numpy(g["targets"])
         eloss = torch_ref.ctc_loss_sum(lt, tg, ole, (tg != 1).sum(-1))
         eloss.backward()

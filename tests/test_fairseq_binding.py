@@ -77,7 +77,7 @@ def test_setup_task_build_model_build_criterion_resolve_to_espresso_amd(fairseq_
 
     # a configuration value the HIP path does not implement is refused, not dropped
     with pytest.raises(NotImplementedError):
-        task.build_model(_cfg({"_name": "speech_transformer_encoder_model", "encoder": {"layerdrop": 0.3}}))
+        task.build_model(_cfg({"_name": "speech_transformer_encoder_model", "quant_noise": {"pq": 0.1}}))
 
     # task.build_criterion(cfg.criterion) -> fairseq.criterions.build_criterion -> our class with the config's values
     crit = task.build_criterion(_cfg({"_name": "ctc_loss", "sentence_avg": False, "zero_infinity": True, "print_training_sample_interval": 77}))

@@ -127,7 +127,12 @@ def test_adam_clip():
 ENC_FIXTURES = [("conformer", "ref_conformer_ctc_tiny"), ("transformer", "ref_transformer_ctc_tiny"),
                 ("transformer", "ref_transformer_learnedpos_ctc_tiny"),
                 # head dim 64 = the recipes' shape class: fused attention kernels, 75 encoder frames (two key tiles)
-                ("conformer", "ref_conformer_ctc_dh64"), ("transformer", "ref_transformer_ctc_dh64")]
+                ("conformer", "ref_conformer_ctc_dh64"), ("transformer", "ref_transformer_ctc_dh64"),
+                # encoder options of the argparse presets (absolute sinusoidal positions, no embedding LayerNorm; head dim 64: plain
+                # fused attention) and the non-default ones the reference accepts (learned absolute positions + post-LN +
+                # chunk-streaming mask; Conformer layers with absolute positions)
+                ("transformer", "ref_transformer_ctc_legacy"), ("transformer", "ref_transformer_ctc_postln_chunk"),
+                ("conformer", "ref_conformer_ctc_abspos")]
 
 
 @pytest.mark.parametrize("layer_type,fixture", ENC_FIXTURES)
@@ -149,7 +154,13 @@ def test_encoder_vs_reference_fixture(layer_type, fixture):
     assert abs(r["train_loss"] - r["emu_loss"]) / r["emu_loss"] < 2e-3, r
     assert r["eval_logits_vs_emulation"] < 3.2e-2 and r["train_logits_vs_emulation"] < 4e-2, r
     assert r["eval_logits_identical_frac"] > 0.3, r
-    assert r["worst_grad_vs_emulation"][1] < 8e-2 and r["median_grad_vs_emulation"] < 1.2e-2, r
+    # (Conformer with absolute positions and NO embedding LayerNorm: the gradient that reaches the sub-sampler keeps a large
+    #  common-mode part that BatchNorm's backward subtracts again, so bf16 rounding of it shows up amplified in the sub-sampler
+    #  weights — 12 % vs the emulation where the fp32 run is 22 % off; every encoder-layer tensor stays under 8 %.)
+    worst_bound, median_bound = (0.15, 1.5e-2) if fixture == "ref_conformer_ctc_abspos" else (8e-2, 1.2e-2)
+    assert r["worst_grad_vs_emulation"][1] < worst_bound and r["median_grad_vs_emulation"] < median_bound, r
+    if fixture == "ref_conformer_ctc_abspos":
+        assert r["worst_grad_vs_emulation"][0].startswith("pre_encoder."), r
     assert r["worst_grad"][1] < 0.75, r  # against the fp32 run: informational (expected bf16 cancellation in BatchNorm sums)
 
 

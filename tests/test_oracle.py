@@ -40,6 +40,36 @@ def test_encoder_restatement_matches_reference(golden_dir, layer_type, fixture, 
     assert tot == pytest.approx(float(g["out::train_loss"]), rel=1e-5)
 
 
+@pytest.mark.parametrize("layer_type,fixture,H", [("transformer", "ref_transformer_ctc_legacy", 2), ("transformer", "ref_transformer_ctc_postln_chunk", 4),
+                                                  ("conformer", "ref_conformer_ctc_abspos", 4)])
+def test_encoder_restatement_matches_reference_legacy_configurations(golden_dir, layer_type, fixture, H):
+    """The encoder options of the argparse presets `speech_transformer_{wsj,swbd,librispeech}` (absolute sinusoidal positions, no
+    embedding LayerNorm) and the non-default ones the reference accepts (learned absolute positions, post-LN, chunk-streaming
+    masks incl. the training-time coin flip under numpy_seed(num_updates)): fixtures from the reference's own encoder."""
+    import json
+
+    g, sd = _load(golden_dir, fixture)
+    meta = json.loads(str(g["meta"]))
+    feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=H, layer_type=layer_type, training=False,
+                               **torch_ref.legacy_encoder_kwargs(meta, lengths, False))
+    assert ol.tolist() == g["out::out_lengths"].tolist()
+    assert float((lo - torch.from_numpy(g["out::eval_logits"])).abs().max()) < 2e-5
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and k != "version" and not k.endswith("_float_tensor"):
+            v.requires_grad_(True)
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=H, layer_type=layer_type, training=True,
+                               **torch_ref.legacy_encoder_kwargs(meta, lengths, True))
+    assert float((lo - torch.from_numpy(g["out::train_logits"])).abs().max()) < 2e-5
+    tgt = torch.from_numpy(g["targets"])
+    loss = torch_ref.ctc_loss_sum(lo, tgt, ol, (tgt != 1).sum(-1))
+    assert float(loss) == pytest.approx(float(g["out::train_loss"]), rel=1e-6)
+    loss.backward()
+    for name in [k for k in ("fc_out.weight", "embed_positions.weight", "layers.0.fc1.weight", "layers.1.self_attn.q_proj.weight", "fc0.weight") if k in sd]:
+        ref = torch.from_numpy(g["grad::" + name])
+        assert float((sd[name].grad - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6, name
+
+
 def test_encoder_restatement_gradients(golden_dir):
     g, sd = _load(golden_dir, "ref_conformer_ctc_tiny")
     for k, v in sd.items():
