@@ -9,7 +9,7 @@ from .criterions import cross_entropy_v2 as _cev2, ctc_loss as _ctc, label_smoot
 from .criterions import cross_entropy as _ce, transducer_loss as _rnnt  # noqa: F401
 from .data import feature_transforms as _ft  # noqa: F401
 from .models.transformer import speech_transformer_base as _encdec, speech_transformer_encoder_model as _enc_model  # noqa: F401
-from .models.transformer import speech_transformer_transducer_base as _transducer  # noqa: F401
+from .models.transformer import speech_transformer_legacy as _legacy, speech_transformer_transducer_base as _transducer  # noqa: F401
 from .models import lstm_lm as _lstm_lm, speech_lstm as _speech_lstm  # noqa: F401
 from .optim import adam as _adam, lr_schedulers as _lrs, noam_lr_scheduler as _noam  # noqa: F401
 from .tasks import language_modeling_for_asr as _lm_task, speech_recognition as _task  # noqa: F401

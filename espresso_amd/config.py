@@ -168,7 +168,9 @@ _LIST_VALUED = {"update_freq", "lr", "scheduled_sampling_probs"}
 # --arch -> registered model (fairseq/models/__init__.py ARCH_MODEL_REGISTRY of the reference's ASR architectures)
 _ARCH_MODEL = {"speech_conv_lstm_wsj": "speech_lstm", "speech_conv_lstm_librispeech": "speech_lstm", "speech_conv_lstm_swbd": "speech_lstm",
                "speech_lstm": "speech_lstm", "lstm_lm_wsj": "lstm_lm_espresso", "lstm_lm_librispeech": "lstm_lm_espresso",
-               "lstm_lm_swbd": "lstm_lm_espresso", "lstm_wordlm_wsj": "lstm_lm_espresso"}
+               "lstm_lm_swbd": "lstm_lm_espresso", "lstm_wordlm_wsj": "lstm_lm_espresso",
+               "speech_transformer": "speech_transformer", "speech_transformer_wsj": "speech_transformer",
+               "speech_transformer_librispeech": "speech_transformer", "speech_transformer_swbd": "speech_transformer"}
 
 
 def is_legacy_argv(argv) -> bool:
@@ -200,7 +202,7 @@ def from_legacy_argv(argv: List[str]) -> dict:
         elif key == "arch":
             if value not in _ARCH_MODEL:
                 raise NotImplementedError(f"--arch {value}: supported legacy architectures are {sorted(_ARCH_MODEL)} "
-                                          "(the Transformer / Conformer models are configured through the recipe YAMLs)")
+                                          "(the other Transformer / Conformer models are configured through the recipe YAMLs)")
             user["model"].update(_name=_ARCH_MODEL[value], arch=value)
         else:
             user[_LEGACY_FLAG_GROUP.get(key, "model")][key] = value

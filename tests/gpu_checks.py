@@ -614,6 +614,58 @@ def build_tiny_encdec(V=40, embed_dim=64, heads=4, learned_pos=False, ffn=128):
     return SpeechTransformerModelBase.build_model(cfg, _TaskAR(V))
 
 
+def check_legacy_speech_transformer_step(arch="speech_transformer_wsj"):
+    """One teacher-forced training step of the argparse preset (absolute encoder positions, no embedding LayerNorm) on the HIP
+    path, against the fp32 oracle driven by the same weights (encoder restatement with absolute positions + decoder restatement):
+    logits within the bf16 bound, finite non-zero gradients for every parameter."""
+    from espresso_amd import functional as F
+    from espresso_amd.models.transformer.speech_transformer_legacy import SpeechTransformerModel
+    from oracle import torch_ref
+
+    torch.manual_seed(3)
+    V = 40
+    task = _Task(V)
+    model = SpeechTransformerModel.build_model(dict(arch=arch, encoder_layers=2, decoder_layers=1, encoder_embed_dim=128,
+                                                    encoder_ffn_embed_dim=256, encoder_attention_heads=2, decoder_attention_heads=2,
+                                                    encoder_conv_channels="[64, 64, 16, 16]", dropout=0.0, attention_dropout=0.0,
+                                                    activation_dropout=0.0), task).to(DEV)
+    B, T, U = 3, 120, 9
+    lengths = torch.tensor([120, 100, 64], device=DEV)
+    feats = torch.randn(B, T, 80, device=DEV)
+    for b in range(B):
+        feats[b, lengths[b]:] = 0
+    tl = [9, 7, 4]
+    target = torch.zeros(B, U, dtype=torch.long, device=DEV)  # pad = 0? use the dictionary's pad
+    pad, eos = task.target_dictionary.pad(), task.target_dictionary.eos()
+    target.fill_(pad)
+    prev = torch.full((B, U), pad, dtype=torch.long, device=DEV)
+    for b, n in enumerate(tl):
+        toks = torch.randint(4, V, (n - 1,), device=DEV)
+        target[b, : n - 1], target[b, n - 1] = toks, eos
+        prev[b, 0], prev[b, 1:n] = eos, toks
+    model.eval()
+    with torch.no_grad():
+        lo, _ = model(feats, lengths, prev)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    enc_sd["embed_positions._float_tensor"] = torch.zeros(1)  # marks sinusoidal absolute positions for the restatement
+    x, ol = torch_ref.encoder(feats.cpu(), lengths.cpu(), enc_sd, H=2, layer_type="transformer", training=False)
+    pad_mask = torch.arange(x.shape[0]).unsqueeze(0) >= ol.unsqueeze(1)
+    ref = torch_ref.decoder(prev.cpu(), x, pad_mask if bool(pad_mask.any()) else None, sd, H=2, pad_idx=pad)
+    valid = target.ne(pad).cpu()
+    res = {"eval_logits_abs_valid": float((lo.float().cpu() - ref)[valid].abs().max()), "ref_logit_scale": float(ref[valid].abs().max())}
+    model.train()
+    lo, extra = model(feats, lengths, prev)
+    loss, nll = F.label_smoothed_ce(extra["_logits_bu"], target.reshape(-1).to(torch.int32).contiguous(), pad, 0.1)
+    loss.backward()
+    torch.cuda.synchronize()
+    res["loss_finite"] = bool(torch.isfinite(loss))
+    bad = [n for n, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all()) or float(p.grad.abs().max()) == 0.0]
+    # exactly-zero gradients by construction: key biases (softmax shift invariance), conv biases in front of BatchNorm
+    res["params_without_gradient"] = [n for n in bad if not (n.endswith("k_proj.bias") or (".convolutions." in n and n.endswith(".bias")))]
+    return res
+
+
 def _encdec_for(fixture):
     d, H, ffn = _fixture_shape(fixture)
     return build_tiny_encdec(embed_dim=d, heads=H, ffn=ffn)
