@@ -54,6 +54,8 @@ def config_from_flat(args) -> SpeechTransformerConfig:
 
 @register_model("speech_transformer")
 class SpeechTransformerModel(SpeechTransformerModelBase):
+    config_class = None  # configured by flat argparse-style arguments (folded into SpeechTransformerConfig by build_model)
+
     @classmethod
     def build_model(cls, args, task):
         cfg = args if isinstance(args, SpeechTransformerConfig) else config_from_flat(args)

@@ -911,8 +911,16 @@ def test_legacy_command_lines_of_the_wsj_and_swbd_recipes(tmp_path):
     t3 = st.build_task(c3)
     m3 = st.build_model(c3, t3)
     assert type(t3).__name__ == "LanguageModelingForASRTask" and m3.decoder.hidden_size == 650
+    # the argparse Transformer presets resolve to the legacy model (absolute encoder positions, no embedding LayerNorm) ...
+    c4 = from_legacy_argv(["data", "--arch", "speech_transformer_wsj", "--dict", str(tmp_path / "dict.txt"), "--encoder-layers", "2",
+                           "--decoder-layers", "1", "--criterion", "label_smoothed_cross_entropy_v2"])
+    assert c4["model"] == {"_name": "speech_transformer", "arch": "speech_transformer_wsj", "encoder_layers": 2, "decoder_layers": 1}
+    m4 = st.build_model(c4, st.build_task(c4))
+    assert type(m4).__name__ == "SpeechTransformerModel" and m4.encoder.abs_positions and m4.encoder.layernorm_embedding is None
+    assert m4.cfg.encoder.embed_dim == 256 and m4.cfg.dropout == 0.2 and len(m4.encoder.layers) == 2
+    # ... and an architecture nobody registered is refused by name
     with pytest.raises(NotImplementedError, match="recipe YAMLs"):
-        from_legacy_argv(["data", "--arch", "speech_transformer_wsj"])
+        from_legacy_argv(["data", "--arch", "speech_tdnn_wsj"])
 
 
 def test_language_model_data_path_matches_the_reference_fixture(tmp_path, golden_dir):
