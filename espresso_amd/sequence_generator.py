@@ -41,16 +41,17 @@ class SequenceGenerator:
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, max_len=0, min_len=1, normalize_scores=True,
                  len_penalty=1.0, unk_penalty=0.0, temperature=1.0, match_source_len=False, lm_model=None, lm_weight=1.0,
                  eos_factor=None, eos=None, search=None, **unused):
-        self.model = models[0] if isinstance(models, (list, tuple)) else models
-        if isinstance(models, (list, tuple)) and len(models) > 1:
-            raise NotImplementedError("ensembles (the ASR recipes decode a single averaged checkpoint)")
+        # an ensemble (`--path a:b`) decodes with the log of the MEAN probability of its members
+        # (fairseq/sequence_generator.py:837-939 EnsembleModel.forward_decoder: logsumexp of the log-probabilities - log n)
+        self.models = list(models) if isinstance(models, (list, tuple)) else [models]
+        self.model = self.models[0]
         self.tgt_dict = tgt_dict
         self.pad, self.unk = tgt_dict.pad(), tgt_dict.unk()
         self.eos = tgt_dict.eos() if eos is None else eos
         self.vocab_size = len(tgt_dict)
         self.beam_size = min(beam_size, self.vocab_size - 1)
         self.max_len_a, self.max_len_b, self.min_len = max_len_a, max_len_b, min_len
-        mp = self.model.max_decoder_positions() if hasattr(self.model, "max_decoder_positions") else 1024
+        mp = min((m.max_decoder_positions() if hasattr(m, "max_decoder_positions") else 1024) for m in self.models)
         self.max_len = max_len or mp
         self.normalize_scores, self.len_penalty, self.unk_penalty = normalize_scores, len_penalty, unk_penalty
         self.temperature = temperature
@@ -84,8 +85,8 @@ class SequenceGenerator:
             max_len = min(int(self.max_len_a * src_len + self.max_len_b), self.max_len - 1)
         assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
 
-        encoder_out = self.model.forward_encoder(net_input["src_tokens"], net_input.get("src_lengths"))
-        state = self.model.decoder.init_incremental(encoder_out, bsz, beam)
+        states = [m.decoder.init_incremental(m.forward_encoder(net_input["src_tokens"], net_input.get("src_lengths")), bsz, beam)
+                  for m in self.models]
         lm_state = self.lm_model.init_incremental(bsz, beam) if self.lm_model is not None else None
 
         scores = torch.zeros(bsz * beam, max_len + 1, dtype=torch.float32, device=dev)
@@ -101,7 +102,10 @@ class SequenceGenerator:
         parent: Optional[torch.Tensor] = None
 
         for step in range(max_len + 1):
-            lprobs = self.model.decoder.step(state, tokens[:, : step + 1], step, parent)  # fp32 [N][V]
+            lprobs = self.models[0].decoder.step(states[0], tokens[:, : step + 1], step, parent)  # fp32 [N][V]
+            if len(self.models) > 1:
+                every = [lprobs] + [m.decoder.step(st, tokens[:, : step + 1], step, parent) for m, st in zip(self.models[1:], states[1:])]
+                lprobs = torch.logsumexp(torch.stack(every, 0), dim=0) - math.log(len(every))
             if self.lm_model is not None:
                 lm_lprobs = self.lm_model.step(lm_state, tokens[:, : step + 1], step, parent)
                 lprobs = lprobs + self.lm_weight * lm_lprobs

@@ -9,6 +9,7 @@ either a plain state_dict or a fairseq checkpoint dict whose `"model"` entry is 
 because the parameter names are identical).  Audio comes from a Kaldi-style `wav.scp` (`utt_id path.wav`, 16-bit PCM read
 with the stdlib) and optional `text` (`utt_id tokens...`) files; the front-end (fbank + CMVN) runs on the GPU."""
 import argparse
+import os
 import json
 import math
 import sys
@@ -112,7 +113,7 @@ def build_generator(args, model, dictionary, lm=None):
                                            max_num_expansions_per_step=args.max_num_expansions_per_step, expansion_beta=args.expansion_beta,
                                            expansion_gamma=args.expansion_gamma, prefix_alpha=args.prefix_alpha, lm_model=lm,
                                            lm_weight=args.lm_weight)
-    return SequenceGenerator([model], dictionary, beam_size=args.beam, max_len_a=args.max_len_a, max_len_b=args.max_len_b,
+    return SequenceGenerator(model if isinstance(model, (list, tuple)) else [model], dictionary, beam_size=args.beam, max_len_a=args.max_len_a, max_len_b=args.max_len_b,
                              min_len=args.min_len, normalize_scores=not args.unnormalized, len_penalty=args.lenpen,
                              unk_penalty=args.unkpen, temperature=args.temperature, lm_model=lm, lm_weight=args.lm_weight,
                              eos_factor=args.eos_factor)
@@ -205,22 +206,32 @@ def main(argv=None):
     from .tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
 
     dev = torch.device("cuda:0")
-    state = _load_file(args.path)
+    paths = args.path.split(os.pathsep)  # `--path a.pt:b.pt` = an ensemble (fairseq utils.split_paths in speech_recognize.py:107)
+    state = _load_file(paths[0])
     model_name, model_cfg = resolve_model_config(args.model, args.model_config, state)
     autoregressive = args.search == "beam"
     # the criterion the checkpoint was trained with decides whether "<s>" is the blank (speech_recognition.py:324, 345-347)
     crit = {"beam": "label_smoothed_cross_entropy_v2", "ctc": "ctc_loss"}.get(args.search, "transducer_loss")
     task = SpeechRecognitionEspressoTask.setup_task(SpeechRecognitionEspressoConfig(
         dict=args.dict, autoregressive=autoregressive, global_cmvn_stats_path=args.global_cmvn_stats_path, criterion_name=crit))
-    cls = registry.MODEL_REGISTRY[model_name]
-    cfg_cls = getattr(cls, "config_class", None)
-    cfg = cfg_cls.from_dict(model_cfg) if cfg_cls is not None else model_cfg
-    model = cls.build_model(cfg, task)
-    sd = state["model"] if isinstance(state, dict) and isinstance(state.get("model"), dict) else state
-    if hasattr(model, "upgrade_state_dict_named"):
-        sd = model.upgrade_state_dict_named(dict(sd), "")
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev).eval()
+    def load_member(state, name, block):
+        cls = registry.MODEL_REGISTRY[name]
+        cfg_cls = getattr(cls, "config_class", None)
+        cfg = cfg_cls.from_dict(block) if cfg_cls is not None else block
+        m = cls.build_model(cfg, task)
+        sd = state["model"] if isinstance(state, dict) and isinstance(state.get("model"), dict) else state
+        if hasattr(m, "upgrade_state_dict_named"):
+            sd = m.upgrade_state_dict_named(dict(sd), "")
+        m.load_state_dict(sd, strict=True)
+        return m.to(dev).eval()
+
+    model = load_member(state, model_name, model_cfg)
+    members = [model]
+    for extra in paths[1:]:  # every member is rebuilt from ITS OWN checkpoint's configuration (checkpoint_utils.load_model_ensemble)
+        st = _load_file(extra)
+        members.append(load_member(st, *resolve_model_config(args.model, args.model_config, st)))
+    if len(members) > 1 and args.search != "beam":
+        raise NotImplementedError("ensembles are implemented for the attention decoder's beam search (--search beam)")
     lm = None
     if args.lm_path:
         class _LMTask:
@@ -232,7 +243,7 @@ def main(argv=None):
         lm = lm.to(dev).eval()
         if args.word_dict:
             lm = TensorizedLookaheadLanguageModel(lm, task.target_dictionary, oov_penalty=args.oov_penalty)
-    gen = build_generator(args, model, task.target_dictionary, lm)
+    gen = build_generator(args, members if len(members) > 1 else model, task.target_dictionary, lm)
     scp = read_scp(args.wav_scp)
     utt_ids = list(scp.keys())
     waves = [read_wav(scp[u]) for u in utt_ids]

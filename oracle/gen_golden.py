@@ -142,16 +142,11 @@ def encoder_fixture(layer_type, name, learned_pos=False, d=64, heads=4, ffn=128,
     print(name, "loss", loss.item(), "params", sum(p.numel() for p in enc.parameters()))
 
 
-def encdec_fixture(name="ref_transformer_encdec_tiny", dm=64, heads=4, ffn=128, frames=70):
-    """speech_transformer_base (conv front-end + rel-pos Transformer encoder + 2-layer decoder) with
-    label_smoothed_cross_entropy_v2 (uniform, eps 0.1): logits, loss, gradients from the reference's own code."""
-    import ast
+def _build_ref_encdec(dm, heads, ffn, V=40):
+    """The reference's speech_transformer_base at test size; returns (model, dictionary)."""
     from espresso.data.asr_dictionary import AsrDictionary
     from espresso.models.transformer.speech_transformer_base import SpeechTransformerModelBase
-    from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
 
-    torch.manual_seed(4321)
-    V = 40
     cfg = ref_config("transformer", d=dm, heads=heads, ffn=ffn)
     d = cfg.decoder
     d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads = dm, ffn, 2, heads
@@ -186,6 +181,47 @@ def encdec_fixture(name="ref_transformer_encdec_tiny", dm=64, heads=4, ffn=128, 
         for n, p in model.named_parameters():
             if p.dim() == 1:
                 p.add_(0.1 * torch.randn_like(p))
+    return model, dic
+
+
+def ensemble_fixture(name="ref_transformer_encdec_ensemble", dm=64, heads=4, ffn=128, frames=70):
+    """Beam search over an ENSEMBLE of two independently initialised models with the reference's own SequenceGenerator
+    (fairseq/sequence_generator.py:837-939 EnsembleModel: log of the mean probability)."""
+    from fairseq.sequence_generator import SequenceGenerator
+
+    torch.manual_seed(777)
+    m1, dic = _build_ref_encdec(dm, heads, ffn)
+    m2, _ = _build_ref_encdec(dm, heads, ffn)
+    m1.eval()
+    m2.eval()
+    B = 3
+    lengths = torch.tensor([frames, frames * 61 // 70, frames * 37 // 70])
+    feats = torch.randn(B, frames, 80)
+    for b in range(B):
+        feats[b, lengths[b]:] = 0.0
+    beams = {}
+    for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)), ("b1", dict(beam_size=1, max_len_a=0.0, max_len_b=12))):
+        gen = SequenceGenerator([m1, m2], dic, **kw)
+        hyps = gen.generate([m1, m2], {"net_input": {"src_tokens": feats, "src_lengths": lengths}})
+        for bi, hl in enumerate(hyps):
+            for hi, hyp in enumerate(hl):
+                beams[f"beam::{tag}::{bi}::{hi}::tokens"] = hyp["tokens"].numpy()
+                beams[f"beam::{tag}::{bi}::{hi}::score"] = np.array(float(hyp["score"]))
+                beams[f"beam::{tag}::{bi}::{hi}::pos"] = hyp["positional_scores"].numpy()
+        print(tag, [[h["tokens"].tolist() for h in hl] for hl in hyps], [[round(float(h["score"]), 3) for h in hl] for hl in hyps])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), feats=feats.numpy(), lengths=lengths.numpy(), **beams,
+                        **{"sd::" + k: v.numpy() for k, v in m1.state_dict().items()},
+                        **{"sd2::" + k: v.numpy() for k, v in m2.state_dict().items()})
+
+
+def encdec_fixture(name="ref_transformer_encdec_tiny", dm=64, heads=4, ffn=128, frames=70):
+    """speech_transformer_base (conv front-end + rel-pos Transformer encoder + 2-layer decoder) with
+    label_smoothed_cross_entropy_v2 (uniform, eps 0.1): logits, loss, gradients from the reference's own code."""
+    from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
+
+    torch.manual_seed(4321)
+    V = 40
+    model, dic = _build_ref_encdec(dm, heads, ffn, V)
     B, Tn = 3, frames
     lengths = torch.tensor([frames, frames * 61 // 70, frames * 37 // 70])
     feats = torch.randn(B, Tn, 80)
@@ -1064,6 +1100,9 @@ if __name__ == "__main__":
         encoder_fixture("conformer", "ref_conformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
         encoder_fixture("transformer", "ref_transformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
         encdec_fixture("ref_transformer_encdec_dh64", dm=128, heads=2, ffn=256, frames=300)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ensemble":
+        ensemble_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "legacy":  # encoder configurations of the argparse presets / streaming options
         encoder_fixture("transformer", "ref_transformer_ctc_legacy", d=128, heads=2, ffn=256, frames=150, legacy={})

@@ -717,6 +717,57 @@ def check_encdec_vs_reference(fixture="ref_transformer_encdec_tiny"):
 
 
 # ------------------------------------------------------------------ beam search with incremental decoding
+def check_ensemble_beam_search_vs_reference(fixture="ref_transformer_encdec_ensemble"):
+    """Two independently initialised reference models decoded as an ensemble by the reference's own SequenceGenerator
+    (fairseq/sequence_generator.py:837-939) vs the HIP path with the same two state dicts: the reference's per-position scores
+    reproduced by force-decoding its best hypotheses through both incremental decoders, scores of the hypotheses both beams hold,
+    greedy identity at clear-margin steps."""
+    from espresso_amd.sequence_generator import SequenceGenerator
+
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    members = []
+    for pre in ("sd::", "sd2::"):
+        sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+        m = _encdec_for(fixture).to(DEV)
+        missing, unexpected = m.load_state_dict(m.upgrade_state_dict_named(dict(sd), ""), strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        members.append(m.eval())
+    d = _TaskAR(40).target_dictionary
+    sample = {"net_input": {"src_tokens": torch.from_numpy(g["feats"]).to(DEV), "src_lengths": torch.from_numpy(g["lengths"]).to(DEV)}}
+    res = {}
+    for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)), ("b1", dict(beam_size=1, max_len_a=0.0, max_len_b=12))):
+        hyps = SequenceGenerator(members, d, **kw).generate(members, sample)
+        top_equal, score_err, shared = [], 0.0, 0
+        for b, hl in enumerate(hyps):
+            ref, hi = {}, 0
+            while f"beam::{tag}::{b}::{hi}::tokens" in g.files:
+                ref[tuple(g[f"beam::{tag}::{b}::{hi}::tokens"].tolist())] = float(g[f"beam::{tag}::{b}::{hi}::score"])
+                hi += 1
+            top_equal.append(tuple(hl[0]["tokens"].tolist()) == tuple(g[f"beam::{tag}::{b}::0::tokens"].tolist()))
+            for h in hl:
+                k = tuple(h["tokens"].tolist())
+                if k in ref:
+                    shared += 1
+                    score_err = max(score_err, abs(float(h["score"]) - ref[k]))
+        res[tag] = {"top1_tokens_equal": top_equal, "shared_hypotheses": shared, "score_abs": score_err}
+    ref_best = torch.stack([torch.from_numpy(g[f"beam::b3::{b}::0::tokens"]) for b in range(3)]).to(DEV)
+    ref_pos = torch.stack([torch.from_numpy(g[f"beam::b3::{b}::0::pos"]) for b in range(3)])
+    L = ref_best.shape[1]
+    n_clear = n_match = 0
+    with torch.no_grad():
+        sts = [m.decoder.init_incremental(m.forward_encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"]), 3, 1)
+               for m in members]
+        cur = torch.full((3, 1), d.eos(), dtype=torch.long, device=DEV)
+        got = []
+        for step in range(L):
+            par = None if step == 0 else torch.arange(3, device=DEV)
+            lp = torch.logsumexp(torch.stack([m.decoder.step(st, cur, step, par).float() for m, st in zip(members, sts)], 0), 0) - math.log(2.0)
+            got.append(lp.gather(-1, ref_best[:, step:step + 1]).squeeze(-1).cpu())
+            cur = torch.cat([cur, ref_best[:, step:step + 1]], 1)
+    res["forced_decode_pos_score_abs"] = float((torch.stack(got, 1) - ref_pos).abs().max())
+    return res
+
+
 def check_beam_search_vs_reference(fixture="ref_transformer_encdec_tiny"):
     """HIP incremental decoder + beam kernels vs what the reference's SequenceGenerator produced with the same weights
     (tests/golden/ref_transformer_encdec_{tiny,dh64}.npz: beam 3, beam 3 + eos_factor 1.5, beam 1)."""

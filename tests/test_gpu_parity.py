@@ -227,6 +227,15 @@ def test_beam_search_vs_reference_generator(fixture):
         assert r[tag]["score_abs"] < 3e-2, r
 
 
+def test_ensemble_beam_search_vs_reference_generator():
+    """`--path a:b`: the reference's SequenceGenerator over two models vs the HIP generator over the same two state dicts"""
+    r = G.check_ensemble_beam_search_vs_reference()
+    print(r)
+    assert r["forced_decode_pos_score_abs"] < 3e-2, r   # log of the mean member probability, per position, as the reference scored it
+    for tag in ("b3", "b1"):
+        assert r[tag]["shared_hypotheses"] >= 3 and r[tag]["score_abs"] < 3e-2, r
+
+
 def test_rnnt_loss_fp32():
     r = G.check_rnnt()
     print(r)

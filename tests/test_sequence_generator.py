@@ -57,6 +57,20 @@ def test_known_answers_host_logic_cpu():
     _assert_scenarios(TorchRefSearch(), "cpu")
 
 
+def test_ensemble_of_identical_members_reproduces_the_single_model_answers():
+    """fairseq/sequence_generator.py:837-939 EnsembleModel: log of the mean member probability — two copies of the scripted
+    model must give the known answers again (logsumexp(x, x) - log 2 = x), through separate incremental states per member."""
+    d, w1, w2, sample, m1 = scripted_setup()
+    _, _, _, _, m2 = scripted_setup()
+    gen = SequenceGenerator([m1, m2], d, beam_size=2, search=TorchRefSearch())
+    hypos = gen.generate([m1, m2], sample)
+    eos = d.eos()
+    _check(hypos[0][0], [w1, eos], [0.9, 1.0])
+    _check(hypos[0][1], [w2, w1, w2, eos], [0.1, 0.9, 0.9, 1.0])
+    _check(hypos[1][0], [w1, w2, w1, eos], [0.7, 0.4, 0.4, 1.0])
+    _check(hypos[1][1], [w1, w2, eos], [0.7, 0.4, 0.6])
+
+
 @pytest.mark.gpu
 def test_known_answers_hip_beam_kernels():
     if not torch.cuda.is_available():
