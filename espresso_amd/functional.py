@@ -78,8 +78,45 @@ def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None, out=None):
     return dW
 
 
+# Small zero-initialised accumulators (bias / LayerNorm / BatchNorm parameter-gradient sums, BatchNorm statistics) are carved out
+# of ONE pool that is cleared with a single fill per update step (Trainer.train_step -> begin_step) instead of one torch.zeros
+# launch each (~30 per step).  A buffer handed out is only valid until the next begin_step(); everything that takes one consumes
+# it within the step (autograd adds it into the flat gradient, BatchNorm finalises its statistics).  Outside a step (tests,
+# inference) or when the pool is exhausted the call falls back to torch.zeros.
+_zero_pool = {"buf": None, "off": 0, "live": False}
+_ZERO_POOL_BYTES = 1 << 20
+
+
+def begin_step(device):
+    """Clear the zero pool for a new update step (one fill)."""
+    zp = _zero_pool
+    if zp["buf"] is None or zp["buf"].device != torch.device(device):
+        zp["buf"] = torch.zeros(_ZERO_POOL_BYTES, dtype=torch.uint8, device=device)
+    else:
+        zp["buf"].zero_()
+    zp["off"], zp["live"] = 0, True
+
+
+def end_step():
+    _zero_pool["live"] = False
+
+
+def _pool_zeros(shape, dtype, device):
+    zp = _zero_pool
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    if zp["live"] and zp["buf"].device == torch.device(device):
+        off = (zp["off"] + 255) // 256 * 256
+        if off + nbytes <= _ZERO_POOL_BYTES:
+            zp["off"] = off + nbytes
+            return zp["buf"][off: off + nbytes].view(dtype).view(shape)
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
 def _zeros_f32(n, like):
-    return torch.zeros(n, dtype=torch.float32, device=like.device)
+    return _pool_zeros((n,), torch.float32, like.device)
 
 
 _side_streams = {}
@@ -526,7 +563,7 @@ class _ConvSubsample(torch.autograd.Function):
             sy, sx = strides[i]
             Co = w.shape[0]
             To, Fo = (Tc - 1) // sy + 1, (Fc - 1) // sx + 1
-            stats = torch.zeros(2 * Co, dtype=torch.float64, device=X.device) if training else None
+            stats = _pool_zeros((2 * Co,), torch.float64, X.device) if training else None
             if i == 0:
                 assert w.shape[1] == 1 and tuple(w.shape[2:]) == (3, 3)
                 Zi = K.conv1_fwd(X, w.detach().reshape(Co, 9).contiguous(), b, B, Tc, Fc, Co, sy, sx, stats)

@@ -307,7 +307,9 @@ def bn_act_fwd(Z, mean_rstd, gamma, beta, act):
 
 def bn_act_bwd(Z, dH, mean_rstd, gamma, beta, dgamma, dbeta, act, training=True):
     M, C = Z.shape
-    red = torch.zeros(2, C, dtype=torch.float32, device=Z.device)
+    from . import functional as _F  # (zero pool: one fill per update step instead of one per call)
+
+    red = _F._pool_zeros((2, C), torch.float32, Z.device)
     dZ = torch.empty_like(Z)
     check(
         _lib.lib().ea_bn_act_bwd(_p(Z), _p(dH), _p(mean_rstd), _p(gamma), _p(beta), _p(red), _p(dZ), _p(dgamma),

@@ -112,6 +112,28 @@ class SpeechTransformerEncoderBase(nn.Module):
             m = ones.triu(tc[1] + 1) | ones.tril(-tc[0] - 1)
         return torch.zeros(max_len, max_len, device=device).masked_fill(m, -1e8).contiguous()
 
+    def _count_batchnorm_forward(self, device):
+        """`num_batches_tracked += 1` of every BatchNorm of the encoder (4 in the sub-sampler + one per Conformer layer) as ONE
+        launch: the counters are re-seated once as views of one int64 buffer (state_dict keys and values unchanged)."""
+        flat = getattr(self, "_bn_counters", None)
+        mods = getattr(self, "_bn_counter_mods", None)
+        ok = (flat is not None and flat.device == device and len(mods) > 0
+              and mods[0].num_batches_tracked.data_ptr() == flat.data_ptr())
+        if not ok:
+            owners = ([self.pre_encoder] if self.pre_encoder is not None else []) + [l for l in self.layers if hasattr(l, "conv_module")]
+            mods = list(self.pre_encoder.batchnorms) if self.pre_encoder is not None else []
+            mods += [l.conv_module.batch_norm for l in self.layers if hasattr(l, "conv_module")]
+            if not mods:
+                self._bn_counters, self._bn_counter_mods = None, []
+                return
+            flat = torch.stack([m.num_batches_tracked.detach().to(device).long().reshape(()) for m in mods])
+            for i, m in enumerate(mods):
+                m._buffers["num_batches_tracked"] = flat[i]
+            for o in owners:
+                o._counters_managed = True
+            self._bn_counters, self._bn_counter_mods = flat, mods
+        flat.add_(1)
+
     def _add_positions(self, x, padding_mask):
         """x = embed_scale * x + embed_positions(make_positions(~padding_mask))  (speech_transformer_encoder.py:343-347)."""
         B, Tp = padding_mask.shape
@@ -144,6 +166,8 @@ class SpeechTransformerEncoderBase(nn.Module):
         tr = self.training
         B = src_tokens.shape[0]
         p = cfg.dropout if tr else 0.0
+        if tr and float(getattr(cfg.encoder, "layerdrop", 0.0) or 0.0) == 0.0 and src_tokens.is_cuda:
+            self._count_batchnorm_forward(src_tokens.device)
         x, x_lengths, padding_mask, row_zero = self.pre_encoder(src_tokens, src_lengths, p_drop=p if self.fc0 is not None else 0.0)
         Tp = padding_mask.shape[1]
         if self.fc0 is not None:

@@ -128,7 +128,7 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
                 and not getattr(self.positional_embedding[0], "learnable", False)):
             y = F.conformer_layer_native(x, self, key_len, attn_mask, self.positional_embedding[0].table(T, x.device), B, T,
                                          p_drop, p_act, p_att, tr)
-            if tr:
+            if tr and not getattr(self, "_counters_managed", False):
                 self.conv_module.batch_norm.num_batches_tracked += 1
             return y
         f = self.ffn1
@@ -147,7 +147,7 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
                           c.batch_norm.weight, c.batch_norm.bias, c.pointwise_conv2.weight, c.batch_norm.running_mean,
                           c.batch_norm.running_var, B, T, p_out=p_drop, bn_eps=c.batch_norm.eps,
                           bn_momentum=c.batch_norm.momentum, training=tr)
-        if tr:
+        if tr and not getattr(self, "_counters_managed", False):
             c.batch_norm.num_batches_tracked += 1
         f = self.ffn2
         x = F.ffn_module(x, f.layer_norm.weight, f.layer_norm.bias, f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias,

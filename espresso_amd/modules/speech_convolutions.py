@@ -29,6 +29,13 @@ class ConvBNReLU(nn.Module):
 
     def output_lengths(self, in_lengths):
         out = in_lengths
+        if isinstance(out, torch.Tensor):
+            # ceil(ceil(x / a) / b) == ceil(x / (a b)): one add + one floor-divide on the device instead of three tiny launches
+            # per convolution (speech_convolutions.py:60-67 computes the same numbers layer by layer)
+            total = 1
+            for stride in self.strides:
+                total *= self._stride2(stride)[0]
+            return out if total == 1 else torch.div(out + (total - 1), total, rounding_mode="floor")
         for stride in self.strides:
             s = self._stride2(stride)[0]
             if isinstance(out, torch.Tensor):
@@ -61,7 +68,7 @@ class ConvBNReLU(nn.Module):
         x = F.conv_subsample(src.contiguous().float(), row_zero, [self._stride2(s) for s in self.strides], params, bufs,
                              p_drop=p_drop, training=self.training, bn_eps=self.batchnorms[0].eps,
                              bn_momentum=self.batchnorms[0].momentum)
-        if self.training:
+        if self.training and not getattr(self, "_counters_managed", False):
             for bn in self.batchnorms:
                 bn.num_batches_tracked += 1
         return x, x_lengths, padding_mask, row_zero

@@ -53,6 +53,7 @@ class Trainer:
             self.model.train()
             self._train_mode_checked = True
         self._stats.zero_()
+        F.begin_step(self._stats.device)  # one fill for all the small zero-initialised accumulators of this update
         for i, sample in enumerate(samples):
             last = i == len(samples) - 1
             ctx = contextlib.nullcontext() if last else self.ddp.no_sync()
@@ -65,13 +66,15 @@ class Trainer:
                 loss.backward()
             if dummy:
                 continue
-            self._stats[0] += float(sample_size)
-            self._stats[1] += loss.detach()
-            self._stats[2] += float(log["ntokens"])
-            self._stats[3] += float(log["nsentences"])
+            # (in-place adds on one-element views: `stats[i] += x` would be view + add + copy-back, two launches each)
+            self._stats[0:1].add_(float(sample_size))
+            self._stats[1:2].add_(loss.detach().reshape(1))
+            self._stats[2:3].add_(float(log["ntokens"]))
+            self._stats[3:4].add_(float(log["nsentences"]))
         if self.ddp.active:
             dist.all_reduce(self._stats)  # C3 + sample_size in one 16-byte collective
         self.ddp.all_reduce_grads()
+        F.end_step()
         self.last_coef = self.optimizer.clip_and_step(pre_scale=1.0, max_norm=self.clip_norm, denom_dev=self._stats[0:1])
         self.num_updates += 1
         if hasattr(self.model, "set_num_updates"):

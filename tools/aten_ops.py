@@ -1,16 +1,18 @@
 """Which lines of espresso_amd issue ATen device ops inside one update step (the "micro-op" launches between the HIP kernels).
     python tools/aten_ops.py [steps]  -> gpurun_out/aten_ops.txt
-torch.profiler (CPU + CUDA activities, with_stack) over a few bench steps; every ATen op that launched a device kernel / copy is
-attributed to the innermost espresso_amd (or bench.py) frame of its Python stack."""
-import collections, os, sys
+A TorchDispatchMode records every ATen call that touches a device tensor (views excluded) together with the innermost
+espresso_amd / bench.py frame of its Python stack; autograd runs single-threaded for the measurement so that the ops issued
+from inside custom backward functions are seen (and attributed) too."""
+import collections, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from torch.profiler import ProfilerActivity, profile
+from torch.utils._python_dispatch import TorchDispatchMode
+from torch.utils._pytree import tree_flatten
 import bench
 from espresso_amd.data import synthetic
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 device = torch.device("cuda:0")
 task, model, criterion, trainer = bench.build(device)
 batches, n_samples = synthetic.make_batches(20000, max_tokens=26000, max_sentences=24, seed=1)
@@ -22,33 +24,41 @@ trainer.reserve([max(samples, key=lambda s: s["audio_seconds"]), max(samples, ke
 for i in range(3):
     trainer.train_step([samples[i]])
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+
+VIEWS = ("view", "as_strided", "slice", "select", "transpose", "t.", "expand", "alias", "detach", "unsqueeze", "squeeze", "permute",
+         "_unsafe_view", "reshape", "unbind", "split", "narrow", "_reshape_alias", "lift_fresh", "is_pinned", "empty", "_local_scalar",
+         "record_stream", "set_", "resize_", "sym_")
+counts = collections.Counter()
+
+
+class Tracer(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = str(func).replace("aten.", "")
+        if any(name.startswith(v) for v in VIEWS):
+            return out
+        flat, _ = tree_flatten((args, kwargs, out))
+        if not any(isinstance(a, torch.Tensor) and a.is_cuda for a in flat):
+            return out
+        site = "?"
+        for fr in reversed(traceback.extract_stack()[:-1]):
+            if ("espresso_amd/" in fr.filename or fr.filename.endswith("bench.py")) and "aten_ops.py" not in fr.filename:
+                site = f"{fr.filename.split('repo/')[-1].split('espresso_amd/')[-1]}:{fr.lineno} {fr.name}"
+                break
+        counts[(site, name)] += 1
+        return out
+
+
+torch.autograd.set_multithreading_enabled(False)
+with Tracer():
     for i in range(3, 3 + steps):
         trainer.train_step([samples[i]])
-    torch.cuda.synchronize()
-
-by_site = collections.Counter()
-by_op = collections.Counter()
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or not ev.kernels:  # only ops that put something on the device queue themselves
-        continue
-    if any(ch.kernels for ch in ev.cpu_children if ch.name.startswith("aten::")):
-        continue  # a composite: its child is counted
-    site = "?"
-    for fr in ev.stack or []:
-        if "espresso_amd/" in fr or "bench.py" in fr:
-            site = fr.split("repo/")[-1]
-            break
-    by_site[(site, ev.name)] += len(ev.kernels)
-    by_op[ev.name] += len(ev.kernels)
-out = [f"device launches issued by ATen ops, per step (over {steps} steps)"]
-for (site, op), n in sorted(by_site.items(), key=lambda kv: -kv[1]):
-    out.append(f"{n / steps:8.1f}  {op:28s} {site}")
-out.append("")
-for op, n in by_op.most_common():
-    out.append(f"{n / steps:8.1f}  {op}")
-out.append(f"total {sum(by_op.values()) / steps:.1f} per step")
+torch.cuda.synchronize()
+out = [f"ATen device ops per update step (views excluded), {steps} steps, by issuing line"]
+for (site, op), n in sorted(counts.items(), key=lambda kv: -kv[1]):
+    out.append(f"{n / steps:8.1f}  {op:34s} {site}")
+out.append(f"total {sum(counts.values()) / steps:.1f} per step")
 txt = "\n".join(out)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", "aten_ops.txt"), "w").write(txt)
-print(txt[:8000])
+print(txt[:12000])
