@@ -6,10 +6,14 @@ top-(beam + beta) expansions with optional prune-by-value (gamma), blank hypothe
 through the predictor and, after the last round, closed with their blank probability; final scores normalised by length.
 
 Layout of the work: everything that is per-hypothesis *bookkeeping* (scores, token sequences, lengths, emission counts) is a
-handful of tiny host tensors — selection uses the same torch.topk / argsort calls as the reference, so ties break the
-same way; everything that is *model compute* (predictor LSTM step for all surviving hypotheses at once, joint step,
-log-softmax, optional LM step) runs on the HIP kernels with the predictor / LM state and the per-position predictor outputs
-kept on the device and re-indexed by the surviving-hypothesis index lists."""
+handful of tiny host tensors per utterance — selection uses the same torch.topk / argsort calls as the reference, so ties break
+the same way.  Everything that is *model compute* (predictor LSTM step, joint step, log-softmax, optional LM step) runs on the
+HIP kernels and is BATCHED ACROSS THE UTTERANCES of the sample: each utterance's search is a coroutine that yields its next
+compute request (joint over these hypotheses at this frame / advance these hypotheses / raw token log-probabilities for the prefix
+merge); the driver serves all pending requests of one kind with ONE launch sequence and ONE device-to-host transfer and resumes
+the coroutines.  Predictor / LM outputs AND their (h, c) states live in append-only device pools shared by the whole batch;
+hypotheses carry slot numbers, so select / merge / pad / top-k move small host index tensors and launch nothing."""
+from collections import defaultdict
 from typing import List, Optional
 
 import torch
@@ -19,12 +23,11 @@ from .. import kernels as K
 
 
 class _Pool:
-    """Append-only device store of predictor (or LM) output rows of ONE utterance's search: hypotheses refer to rows by slot
-    number, so selecting / merging / padding hypotheses moves small host index tensors instead of re-copying `[n][L][H]`
-    histories on the device at every expansion (the reference's `index_select_` / `pad` / `cat` on the full tensors)."""
+    """Append-only device store of rows ([cap][width], any dtype) shared by every utterance of a batch: hypotheses refer to rows by
+    slot number (the reference `index_select_`s / pads / concatenates `[n][L][H]` histories and `[L][n][H]` states instead)."""
 
-    def __init__(self, width, device, cap=2048):
-        self.buf = torch.zeros(cap, width, dtype=torch.bfloat16, device=device)
+    def __init__(self, width, device, dtype=torch.bfloat16, cap=4096):
+        self.buf = torch.zeros(cap, width, dtype=dtype, device=device)
         self.n, self.device = 0, device
 
     def put(self, rows):
@@ -42,6 +45,28 @@ class _Pool:
         return self.buf.index_select(0, idx.reshape(-1).to(self.device))
 
 
+class _StatePools:
+    """(h16, h32, c) of every layer of an LSTM predictor / LM in row pools; slot 0 is the zero state."""
+
+    def __init__(self, dec, device):
+        z = dec.init_state(1, device)
+        self.pools = {k: [_Pool(t.shape[1], device, t.dtype) for t in v] for k, v in z.items()}
+        for k, v in z.items():
+            for pool, t in zip(self.pools[k], v):
+                pool.put(t)
+
+    def get(self, slots):
+        idx = slots.to(self.pools["c"][0].device)
+        return {k: [p.buf.index_select(0, idx) for p in v] for k, v in self.pools.items()}
+
+    def put(self, state):
+        base = None
+        for k, v in state.items():
+            for pool, t in zip(self.pools[k], v):
+                base = pool.put(t)
+        return base
+
+
 class _Hist:
     """Per-hypothesis output history: slots [n][L] (host i64) into a shared _Pool; position lens-1 is the newest."""
 
@@ -54,41 +79,49 @@ class _Hist:
     def padded(self, L):
         return self if L == self.slots.shape[1] else _Hist(self.pool, TF.pad(self.slots, (0, L - self.slots.shape[1])))
 
-    def last(self, lens):
-        return self.pool.get(self.slots[torch.arange(self.slots.shape[0]), lens - 1])
+    def last_slots(self, lens):
+        return self.slots[torch.arange(self.slots.shape[0]), lens - 1]
 
-    def put(self, lens, rows):
+    def set_last(self, lens, base):
         n = self.slots.shape[0]
-        base = self.pool.put(rows)
         self.slots[torch.arange(n), lens - 1] = base + torch.arange(n)
 
+    def slots_at(self, ri, ci):
+        return self.slots[ri, ci]
+
+    # row-valued forms of the three accessors above (single-batch use and the dense-semantics test)
+    def last(self, lens):
+        return self.pool.get(self.last_slots(lens))
+
+    def put(self, lens, rows):
+        self.set_last(lens, self.pool.put(rows))
+
     def rows(self, ri, ci):
-        return self.pool.get(self.slots[ri, ci])
+        return self.pool.get(self.slots_at(ri, ci))
 
     def at(self, i, k):
         return self.pool.buf[int(self.slots[i, k])]
 
 
 class _Hyps:
-    """Batch of hypotheses of ONE utterance.  Host: scores [n] f32, seqs [n][L] i64 (pad-filled), lens [n], nemit [n], prev [n],
-    lm_scores [n] or None, dec = _Hist of predictor outputs by sequence position.  Device: state (predictor (h16, h32, c) lists
-    with n rows) and the pool behind `dec`; lm_state / lm_dec likewise."""
+    """Batch of hypotheses of ONE utterance, host tensors only: scores [n] f32, seqs [n][L] i64 (pad-filled), lens [n], nemit [n],
+    prev [n], sslot [n] (row of the predictor state in the shared state pools), dec = _Hist of predictor-output slots by sequence
+    position; lm_scores / lm_sslot / lm_dec likewise when an LM is fused."""
 
-    def __init__(self, scores, seqs, lens, nemit, prev, state, dec, lm_scores=None, lm_state=None, lm_dec=None):
+    def __init__(self, scores, seqs, lens, nemit, prev, sslot, dec, lm_scores=None, lm_sslot=None, lm_dec=None):
         self.scores, self.seqs, self.lens, self.nemit, self.prev = scores, seqs, lens, nemit, prev
-        self.state, self.dec = state, dec
-        self.lm_scores, self.lm_state, self.lm_dec = lm_scores, lm_state, lm_dec
+        self.sslot, self.dec = sslot, dec
+        self.lm_scores, self.lm_sslot, self.lm_dec = lm_scores, lm_sslot, lm_dec
 
     def size(self):
         return int(self.scores.numel())
 
     def select(self, index):
         """transducer_utils.py:62-102 index_select_ (returns a new batch)."""
-        di = index.to(self.dec.device)
-        sel_state = lambda st: None if st is None else {k: [t.index_select(0, di) for t in v] for k, v in st.items()}
         return _Hyps(self.scores[index], self.seqs[index], self.lens[index], self.nemit[index], self.prev[index],
-                     sel_state(self.state), self.dec.select(index),
-                     None if self.lm_scores is None else self.lm_scores[index], sel_state(self.lm_state),
+                     self.sslot[index], self.dec.select(index),
+                     None if self.lm_scores is None else self.lm_scores[index],
+                     None if self.lm_sslot is None else self.lm_sslot[index],
                      None if self.lm_dec is None else self.lm_dec.select(index))
 
     def sort_by_length(self, descending=True):
@@ -111,9 +144,9 @@ class _Hyps:
     def masked(self, mask):
         return self.select(mask.nonzero(as_tuple=False).view(-1))
 
-    def last_dec(self):
-        """Predictor (and LM) output at the last non-blank position of every hypothesis (transducer_utils.py:386-417)."""
-        return self.dec.last(self.lens), (None if self.lm_dec is None else self.lm_dec.last(self.lens))
+    def last_slots(self):
+        """Slots of the predictor (and LM) output at the last non-blank position of every hypothesis (transducer_utils.py:386-417)."""
+        return self.dec.last_slots(self.lens), (None if self.lm_dec is None else self.lm_dec.last_slots(self.lens))
 
     @staticmethod
     def combine(a, b, pad):
@@ -125,12 +158,10 @@ class _Hyps:
         L = max(a.seqs.shape[1], b.seqs.shape[1])
         pseq = lambda s: TF.pad(s, (0, L - s.shape[1]), value=pad)
         cat_hist = lambda x, y: None if x is None else _Hist(x.pool, torch.cat((x.padded(L).slots, y.padded(L).slots)))
-        cat_state = lambda x, y: None if x is None else {k: [torch.cat((u, v), 0) for u, v in zip(x[k], y[k])] for k in x}
+        cat = lambda x, y: None if x is None else torch.cat((x, y))
         return _Hyps(torch.cat((a.scores, b.scores)), torch.cat((pseq(a.seqs), pseq(b.seqs))), torch.cat((a.lens, b.lens)),
-                     torch.cat((a.nemit, b.nemit)), torch.cat((a.prev, b.prev)), cat_state(a.state, b.state),
-                     cat_hist(a.dec, b.dec),
-                     None if a.lm_scores is None else torch.cat((a.lm_scores, b.lm_scores)), cat_state(a.lm_state, b.lm_state),
-                     cat_hist(a.lm_dec, b.lm_dec))
+                     torch.cat((a.nemit, b.nemit)), torch.cat((a.prev, b.prev)), torch.cat((a.sslot, b.sslot)),
+                     cat_hist(a.dec, b.dec), cat(a.lm_scores, b.lm_scores), cat(a.lm_sslot, b.lm_sslot), cat_hist(a.lm_dec, b.lm_dec))
 
 
 class TransducerBeamSearchDecoder:
@@ -185,94 +216,151 @@ class TransducerBeamSearchDecoder:
         return out
 
     @torch.no_grad()
-    def _generate(self, sample, bos_token: Optional[int] = None):
+    def _generate(self, sample, bos_token: Optional[int] = None, only: Optional[List[int]] = None):
+        """only: search just these utterances of the batch (same encoder pass; the others return None) — lets a test compare a
+        search that shared its launches with the other utterances against the same search running alone."""
         net_input = sample["net_input"]
         enc = self.model.encoder(net_input["src_tokens"], net_input["src_lengths"])
         x = enc["_x_bt"][0]
         enc_len = enc["src_lengths"][0].tolist()
         bsz = len(enc_len)
         Tp = x.shape[0] // bsz
-        E = self.model.joint_encoder_branch(x).view(bsz, Tp, -1)
-        toks, scs = [], []
+        dev = x.device
+        self._E = self.model.joint_encoder_branch(x).contiguous()  # [bsz * T'][J], row = utterance * T' + frame
+        self._Tp = Tp
+        dec = self.model.decoder
+        Hd = dec.hidden_size if not hasattr(dec, "additional_fc") else dec.additional_fc.weight.shape[0]
+        self._dec_pool, self._dec_state = _Pool(Hd, dev), _StatePools(dec, dev)
+        self._lm_pool = self._lm_state = None
+        if self.lm_model is not None:
+            lmd = self.lm_model.decoder
+            Hl = lmd.hidden_size if not hasattr(lmd, "additional_fc") else lmd.additional_fc.weight.shape[0]
+            self._lm_pool, self._lm_state = _Pool(Hl, dev), _StatePools(lmd, dev)
         # the search's bookkeeping is many small host-tensor operations: run them on one thread (with the intra-op pool of a
         # 128-core host every `seqs[index]` / pad / topk above the parallel grain fans out and synchronises: 0.75 ms per select)
         threads = torch.get_num_threads()
         torch.set_num_threads(1)
         try:
-            for i in range(bsz):
-                t, s = self._one(E[i], int(enc_len[i]), bos_token)
-                toks.append(t)
-                scs.append(s)
+            searches = [self._one(i, int(enc_len[i]), bos_token) if (only is None or i in only) else None for i in range(bsz)]
+            done = [(None, None)] * bsz
+            pending = {}
+            for i, g in enumerate(searches):
+                if g is None:
+                    continue
+                try:
+                    pending[i] = next(g)
+                except StopIteration as e:  # (an utterance without frames)
+                    done[i] = e.value
+            while pending:
+                kinds = defaultdict(list)
+                for i, req in pending.items():
+                    kinds[req[0]].append((i, req))
+                answers = {}
+                for kind, items in kinds.items():
+                    answers.update(self._serve(kind, items))
+                nxt = {}
+                for i, ans in answers.items():
+                    try:
+                        nxt[i] = searches[i].send(ans)
+                    except StopIteration as e:
+                        done[i] = e.value
+                pending = nxt
         finally:
             torch.set_num_threads(threads)
-        return toks, scs, None
+            self._E = self._dec_pool = self._dec_state = self._lm_pool = self._lm_state = None
+        return [d[0] for d in done], [d[1] for d in done], None
 
-    # ------------------------------------------------------------------ model compute on the device
-    def _lprobs(self, E_t, dec_rows, lm_rows):
-        """Joint + log-softmax (+ LM shallow fusion that keeps the non-blank mass, :289-321).  Returns (lprobs [n][V] f32 on
-        the HOST, lm_lprobs padded to V on the host or None)."""
-        n = dec_rows.shape[0]
+    # ------------------------------------------------------------------ model compute on the device, batched over utterances
+    def _joint_lprobs(self, frame_rows, dec_slots):
+        """log-softmax(joint(E[frame_rows[r]], predictor output dec_slots[r]) / temperature), r = 0..N-1 -> device f32 [N][V]."""
         V = self.vocab_size
-        logits = self.model.joint_step(E_t.unsqueeze(0).expand(n, -1).contiguous(), dec_rows.contiguous())[:, :V]
+        dev = self._E.device
+        E_rows = self._E.index_select(0, frame_rows.to(dev))
+        logits = self.model.joint_step(E_rows, self._dec_pool.get(dec_slots))[:, :V]
         if self.temperature != 1.0:
             logits = logits / self.temperature
-        lprobs = K.log_softmax(logits, n, V, logits.stride(0))
+        return K.log_softmax(logits, logits.shape[0], V, logits.stride(0))
+
+    def _serve(self, kind, items):
+        """items: [(utterance, request)] of one kind -> {utterance: answer}; one launch sequence and one device-to-host copy."""
+        if kind == "advance":
+            self._advance_many([req[1] for _, req in items])
+            return {i: None for i, _ in items}
+        sizes = [int(req[2].numel()) for _, req in items]
+        rows = torch.cat([torch.full((n,), int(req[1]), dtype=torch.long) for n, (_, req) in zip(sizes, items)])
+        lp = self._joint_lprobs(rows, torch.cat([req[2] for _, req in items]))
+        if kind == "token":  # RAW acoustic log-probability of one given token per row (prefix merge)
+            tok = torch.cat([req[3] for _, req in items]).to(lp.device)
+            vals = lp.gather(1, tok.unsqueeze(1)).squeeze(1).cpu().split(sizes)
+            return {i: v for (i, _), v in zip(items, vals)}
+        if kind == "blank":  # blank log-probability that closes the non-blank hypotheses of the last expansion round
+            vals = lp[:, self.blank].cpu().split(sizes)
+            return {i: v for (i, _), v in zip(items, vals)}
+        assert kind == "lprobs"
         lm_pad = None
-        if self.lm_model is not None:
+        if self.lm_model is not None:  # shallow fusion that keeps the non-blank mass (:289-321)
+            n, V = lp.shape
+            lm_rows = self._lm_pool.get(torch.cat([req[3] for _, req in items]))
             lm_logits = self.lm_model.decoder.output_layer(lm_rows.contiguous())
             lm_lp = K.log_softmax(lm_logits, n, lm_logits.shape[1], lm_logits.stride(0))
-            nb = torch.ones(V, dtype=torch.bool, device=lprobs.device)
+            nb = torch.ones(V, dtype=torch.bool, device=lp.device)
             nb[self.blank] = False
-            lp_nb = lprobs[:, nb]
+            lp_nb = lp[:, nb]
             if not self.no_blank_in_lm:
                 lm_lp = lm_lp[:, nb]
             fused = lp_nb + self.lm_weight * lm_lp
             fused = fused + (lp_nb.exp().sum(1).log() - fused.exp().sum(1).log()).unsqueeze(1)
-            lprobs[:, nb] = fused
-            lm_pad = torch.cat((lm_lp[:, : self.blank], lm_lp.new_zeros(n, 1), lm_lp[:, self.blank:]), 1).cpu()
+            lp[:, nb] = fused
+            lm_pad = torch.cat((lm_lp[:, : self.blank], lm_lp.new_zeros(n, 1), lm_lp[:, self.blank:]), 1).cpu().split(sizes)
         if self.model_predicts_eos:
-            lprobs[:, self.blank] = torch.logaddexp(lprobs[:, self.blank], lprobs[:, self.eos])
-            lprobs[:, self.eos] = float("-inf")
-        return lprobs.cpu(), lm_pad
+            lp[:, self.blank] = torch.logaddexp(lp[:, self.blank], lp[:, self.eos])
+            lp[:, self.eos] = float("-inf")
+        host = lp.cpu().split(sizes)
+        return {i: (host[k], None if lm_pad is None else lm_pad[k]) for k, (i, _) in enumerate(items)}
 
     def _lm_tokens(self, tokens):
         return torch.where(tokens > self.blank, tokens - 1, tokens) if self.no_blank_in_lm else tokens
 
-    def _advance(self, hyps):
-        """Push the newest token of every hypothesis through the predictor (and LM); store the outputs at position lens-1."""
-        dev = hyps.dec.device
-        tok = hyps.prev.to(dev)
-        dec_out, hyps.state = self.model.decoder.advance(tok, hyps.state)
-        hyps.dec.put(hyps.lens, dec_out)
+    def _advance_many(self, batches):
+        """Push the newest token of every hypothesis of every given batch through the predictor (and LM) in one call; the outputs
+        go to position lens-1 of the histories, the new states to fresh slots."""
+        dev = self._dec_pool.device
+        tok = torch.cat([h.prev for h in batches]).to(dev)
+        dec_out, new = self.model.decoder.advance(tok, self._dec_state.get(torch.cat([h.sslot for h in batches])))
+        base, sbase = self._dec_pool.put(dec_out), self._dec_state.put(new)
         if self.lm_model is not None:
-            lm_out, hyps.lm_state = self.lm_model.decoder.advance(self._lm_tokens(tok), hyps.lm_state)
-            hyps.lm_dec.put(hyps.lens, lm_out)
+            lm_out, lm_new = self.lm_model.decoder.advance(self._lm_tokens(tok), self._lm_state.get(torch.cat([h.lm_sslot for h in batches])))
+            lbase, lsbase = self._lm_pool.put(lm_out), self._lm_state.put(lm_new)
+        off = 0
+        for h in batches:
+            n = h.size()
+            h.dec.set_last(h.lens, base + off)
+            h.sslot = sbase + off + torch.arange(n)
+            if self.lm_model is not None:
+                h.lm_dec.set_last(h.lens, lbase + off)
+                h.lm_sslot = lsbase + off + torch.arange(n)
+            off += n
 
-    # ------------------------------------------------------------------ the search (one utterance)
-    def _one(self, E, enc_len, bos_token):
-        dev = E.device
+    # ------------------------------------------------------------------ the search of one utterance (a coroutine: see _generate)
+    def _one(self, utt, enc_len, bos_token):
         max_len = min(enc_len, self.max_len) if self.max_len > 0 else enc_len
         bos = self.bos if bos_token is None else bos_token
-        dec = self.model.decoder
-        Hd = dec.hidden_size if not hasattr(dec, "additional_fc") else dec.additional_fc.weight.shape[0]
         hyps = _Hyps(torch.zeros(1), torch.full((1, 1), bos, dtype=torch.long), torch.ones(1, dtype=torch.long),
-                     torch.zeros(1, dtype=torch.long), torch.full((1,), bos, dtype=torch.long), dec.init_state(1, dev),
-                     _Hist(_Pool(Hd, dev), torch.zeros(1, 1, dtype=torch.long)))
+                     torch.zeros(1, dtype=torch.long), torch.full((1,), bos, dtype=torch.long), torch.zeros(1, dtype=torch.long),
+                     _Hist(self._dec_pool, torch.zeros(1, 1, dtype=torch.long)))
         if self.lm_model is not None:
-            lmd = self.lm_model.decoder
-            Hl = lmd.hidden_size if not hasattr(lmd, "additional_fc") else lmd.additional_fc.weight.shape[0]
-            hyps.lm_scores, hyps.lm_state = torch.zeros(1), lmd.init_state(1, dev)
-            hyps.lm_dec = _Hist(_Pool(Hl, dev), torch.zeros(1, 1, dtype=torch.long))
-        self._advance(hyps)
+            hyps.lm_scores, hyps.lm_sslot = torch.zeros(1), torch.zeros(1, dtype=torch.long)
+            hyps.lm_dec = _Hist(self._lm_pool, torch.zeros(1, 1, dtype=torch.long))
+        yield ("advance", hyps)
         nxt = hyps
         for step in range(max_len):
             nxt = nxt.sort_by_length(descending=True)
-            E_t = E[step]
-            hyps = self._prefix_search_and_merge(nxt, E_t)
+            frame = utt * self._Tp + step  # row of this utterance's frame in the joint's encoder branch
+            hyps = yield from self._prefix_search_and_merge(nxt, frame)
             blanks = None
             for exp_idx in range(self.max_num_expansions_per_step):
-                d_last, lm_last = hyps.last_dec()
-                lprobs, lm_pad = self._lprobs(E_t, d_last, lm_last)
+                d_last, lm_last = hyps.last_slots()
+                lprobs, lm_pad = yield ("lprobs", frame, d_last, lm_last)
                 kexp = self._select_k_expansions(hyps, lprobs, lm_pad)
                 bmask = kexp.prev == self.blank
                 kb = kexp.masked(bmask)
@@ -281,18 +369,13 @@ class TransducerBeamSearchDecoder:
                 if knb.size() == 0:  # every candidate emitted blank: early exit of the expansions
                     nxt = blanks.keep_top_k(self.beam_size, self.normalize_scores)
                     break
-                self._advance(knb)
+                yield ("advance", knb)
                 if exp_idx < self.max_num_expansions_per_step - 1:
                     hyps = knb
                 else:
                     # last round: close the non-blank hypotheses with their blank probability, merge, prune
-                    d_last, _ = knb.last_dec()
-                    n = knb.size()
-                    logits = self.model.joint_step(E_t.unsqueeze(0).expand(n, -1).contiguous(), d_last.contiguous())[:, : self.vocab_size]
-                    if self.temperature != 1.0:
-                        logits = logits / self.temperature
-                    lp = K.log_softmax(logits, n, self.vocab_size, logits.stride(0))
-                    knb.scores = knb.scores + lp[:, self.blank].cpu()
+                    lp_blank = yield ("blank", frame, knb.last_slots()[0])
+                    knb.scores = knb.scores + lp_blank
                     knb.prev = torch.full_like(knb.prev, self.blank)
                     knb.nemit = knb.nemit + 1
                     nxt = _Hyps.combine(blanks, knb, self.pad).keep_top_k(self.beam_size, self.normalize_scores)
@@ -336,9 +419,10 @@ class TransducerBeamSearchDecoder:
         h.lens = h.lens + (~bmask).long()
         h.nemit = h.nemit + 1
 
-    def _prefix_search_and_merge(self, hyps, E_t):
+    def _prefix_search_and_merge(self, hyps, frame):
         """:417-601 — `hyps` sorted by non-increasing length; the score of a hypothesis that is a prefix of a longer one (at
-        most `prefix_alpha` tokens shorter) is added (logaddexp) to the longer one after extending it token by token."""
+        most `prefix_alpha` tokens shorter) is added (logaddexp) to the longer one after extending it token by token.
+        (A generator like `_one`: the joint evaluations it needs are requests served together with the other utterances'.)"""
         n = hyps.size()
         lens = hyps.lens
         lens_l, seqs_l = lens.tolist(), hyps.seqs.tolist()  # host bookkeeping on plain lists
@@ -368,13 +452,14 @@ class TransducerBeamSearchDecoder:
                     for k in range(li, lj - 1):
                         ri.append(j), ci.append(k), toks.append(seqs_l[j][k + 1])
                     spans.append((i, j, a, len(toks)))
-            vals = self._token_lprobs(E_t, hyps.dec.rows(ri, ci), toks)
+            vals = yield ("token", frame, hyps.dec.slots_at(ri, ci), torch.tensor(toks, dtype=torch.long))
             for i, j, a, b in spans:
                 score = float(hyps.scores[i]) + vals[a]
                 for k in range(a + 1, b):
                     score += vals[k]
                 hyps.scores[j] = torch.logaddexp(hyps.scores[j], torch.tensor(float(score)))
             return hyps
+        E_t = self._E[frame]
         for j in range(n - 1):
             for i in range(j + 1, n):
                 if not merge[i][j]:
@@ -401,16 +486,7 @@ class TransducerBeamSearchDecoder:
                 if self.lm_model is not None:
                     hyps.lm_scores[j] = torch.logaddexp(hyps.lm_scores[j], torch.tensor(float(lm_score)))
         return hyps
-
-    def _token_lprobs(self, E_t, dec_rows, toks):
-        """RAW acoustic log-probability of token toks[r] given predictor output dec_rows[r], r = 0..m-1 -> host f32 [m]."""
-        V, m = self.vocab_size, dec_rows.shape[0]
-        logits = self.model.joint_step(E_t.unsqueeze(0).expand(m, -1).contiguous(), dec_rows.contiguous())[:, :V]
-        if self.temperature != 1.0:
-            logits = logits / self.temperature
-        lp = K.log_softmax(logits, m, V, logits.stride(0))
-        idx = torch.tensor(toks, dtype=torch.long).to(lp.device)
-        return lp.gather(1, idx.unsqueeze(1)).squeeze(1).cpu()
+        yield  # (makes this function a generator also on the paths that request nothing)
 
     def _row_lprobs(self, E_t, dec_row, lm_row):
         """RAW acoustic log-probs of one hypothesis position (the prefix search applies the LM terms itself, :487-505)."""

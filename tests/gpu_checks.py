@@ -1514,6 +1514,16 @@ def check_transducer_beam_search():
                 if m in refset:
                     score_abs = max(score_abs, abs(float(scores_l[b][j]) - refset[m]))
         res[tag] = {"best_equal": best_equal, "nbest_in_ref": nbest_in_ref, "score_abs": score_abs}
+        if tag == "b3":
+            # the searches of a batch run as coroutines whose joint / predictor requests are served together: the answers must be
+            # what each utterance's search gets when it runs alone (on the same encoder output: the reference's model itself is
+            # not invariant to batch padding — the sub-sampler's padded frames feed the next convolution's receptive field)
+            same_tokens, sdiff = [], 0.0
+            for b in range(len(toks_l)):
+                t1, s1, _ = dec._generate(sample, only=[b])  # same encoder pass, this utterance's search alone on the device
+                same_tokens.append(torch.equal(t1[b], toks_l[b]))
+                sdiff = max(sdiff, float((s1[b] - scores_l[b]).abs().max()))
+            res["batched_equals_single"] = {"tokens": same_tokens, "score_abs": sdiff}
     return res
 
 

@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--batches", type=int, default=2)
-    ap.add_argument("--beam-utts", type=int, default=6, help="utterances decoded by the beam search (it runs one utterance at a time)")
+    ap.add_argument("--beam-utts", type=int, default=6, help="utterances of the batch decoded by the beam search (searches batched across utterances)")
     ap.add_argument("--max-tokens", type=int, default=15000)
     ap.add_argument("--batch-size", type=int, default=24)
     ap.add_argument("--emit-rate", type=float, default=0.0, help="calibrate the blank bias to this many emitted tokens per audio second")
