@@ -974,7 +974,8 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   }
   // tile-height choice: 64-row tiles when 128-row tiles would leave the 256 CUs (x3 resident workgroups) under-filled
   const long tiles128 = (long)((q.N + BN - 1) / BN) * ((q.M + BM - 1) / BM) * q.batch * q.splitk;
-  const bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < 1536));
+  static const long bm_thr = [] { const char* e = getenv("EA_GEMM_BM_THR"); return e ? atol(e) : 1536L; }();  // (diagnostic override)
+  const bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < bm_thr));
   const int bm = bm64 ? 64 : BM;
   dim3 grid((q.N + BN - 1) / BN, (q.M + bm - 1) / bm, q.batch * q.splitk), block(256);
   GemmProf pr;
