@@ -27,7 +27,7 @@ template <typename TIn>
 __global__ __launch_bounds__(256) void rnnt_lse_kernel(const TIn* __restrict__ logits, const int* __restrict__ targets,
                                                        const int* __restrict__ T_len, const int* __restrict__ U_len,
                                                        float* __restrict__ lse, float* __restrict__ lpb, float* __restrict__ lpy,
-                                                       int T, int U1, int V, int Umax, int blank, long nnodes) {
+                                                       int T, int U1, int V, long ld, int Umax, int blank, long nnodes) {
   const int lane = threadIdx.x & 63;
   const long node = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= nnodes) return;
@@ -35,11 +35,43 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(const TIn* __restrict__ l
   const int t = (int)((node / U1) % T);
   const int b = (int)(node / ((long)U1 * T));
   if (t >= T_len[b] || u > U_len[b]) return;
-  const TIn* z = logits + node * V;
-  float mx = -INFINITY;
+  const TIn* z = logits + node * ld;
+  float mx = -INFINITY, s = 0.f;
+  if constexpr (sizeof(TIn) == 2) {
+    if ((ld & 7) == 0 && (((uintptr_t)logits) & 15) == 0) {
+      // rows padded to a multiple of 8 elements: 16-byte loads (8 logits per lane and step; the second pass hits L1 / L2)
+      const int nch = (V + 7) >> 3;
+      for (int c = lane; c < nch; c += 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+          if (c * 8 + e < V) mx = fmaxf(mx, x);
+        }
+      }
+      mx = wave_max(mx);
+      for (int c = lane; c < nch; c += 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+          if (c * 8 + e < V) s += expf(x - mx);
+        }
+      }
+      s = wave_sum(s);
+      const float l = mx + logf(s);
+      if (lane == 0) {
+        lse[node] = l;
+        lpb[node] = ldz(z, blank) - l;
+        lpy[node] = (u < U_len[b]) ? ldz(z, targets[(long)b * Umax + u]) - l : -INFINITY;
+      }
+      return;
+    }
+  }
   for (int v = lane; v < V; v += 64) mx = fmaxf(mx, ldz(z, v));
   mx = wave_max(mx);
-  float s = 0.f;
   for (int v = lane; v < V; v += 64) s += expf(ldz(z, v) - mx);
   s = wave_sum(s);
   const float l = mx + logf(s);
@@ -111,7 +143,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const TIn* __restrict__ 
                                                         const float* __restrict__ lse, const float* __restrict__ lpb,
                                                         const float* __restrict__ lpy, const float* __restrict__ alpha,
                                                         const float* __restrict__ beta, const float* __restrict__ loss,
-                                                        TOut* __restrict__ grad, int T, int U1, int V, int Umax, int blank,
+                                                        TOut* __restrict__ grad, int T, int U1, int V, long ld, int Umax, int blank,
                                                         float scale, const float* __restrict__ scale_dev, long nnodes) {
   const int lane = threadIdx.x & 63;
   const long node = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -119,15 +151,15 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const TIn* __restrict__ 
   const int u = (int)(node % U1);
   const int t = (int)((node / U1) % T);
   const int b = (int)(node / ((long)U1 * T));
-  TOut* g = grad + node * V;
+  TOut* g = grad + node * ld;  // (the gradient has the logits' row pitch; its pad columns are written as zeros)
   const int Tb = T_len[b], Ub = U_len[b];
   const float L = loss[b];
   if (t >= Tb || u > Ub || !(L < INFINITY)) {
-    for (int v = lane; v < V; v += 64) { if constexpr (sizeof(TOut) == 2) g[v] = 0; else g[v] = 0.f; }
+    for (int v = lane; v < (int)ld; v += 64) { if constexpr (sizeof(TOut) == 2) g[v] = 0; else g[v] = 0.f; }
     return;
   }
   if (scale_dev) scale *= scale_dev[0];
-  const TIn* z = logits + node * V;
+  const TIn* z = logits + node * ld;
   const float a = alpha[node];
   const float occ = a + beta[node] + L;  // log occupancy of (t,u)
   const float l = lse[node];
@@ -139,11 +171,37 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const TIn* __restrict__ 
     y = targets[(long)b * Umax + u];
     cy = expf(a + lpy[node] + beta[node + 1] + L);
   }
-  for (int v = lane; v < V; v += 64) {
-    float gv = expf(ldz(z, v) - l + occ);
-    if (v == blank) gv -= cb;
-    if (v == y) gv -= cy;
-    gv *= scale;
+  if constexpr (sizeof(TIn) == 2 && sizeof(TOut) == 2) {
+    if ((ld & 7) == 0 && ((((uintptr_t)logits) | ((uintptr_t)grad)) & 15) == 0) {
+      const int nch = (int)(ld >> 3);
+      for (int c = lane; c < nch; c += 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int v = c * 8 + e;
+          const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+          float gv = expf(x - l + occ);
+          if (v == blank) gv -= cb;
+          if (v == y) gv -= cy;
+          o[e] = v < V ? gv * scale : 0.f;
+        }
+        uint4 r;
+        r.x = pack_bf2(o[0], o[1]); r.y = pack_bf2(o[2], o[3]); r.z = pack_bf2(o[4], o[5]); r.w = pack_bf2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(g + c * 8) = r;
+      }
+      return;
+    }
+  }
+  for (int v = lane; v < (int)ld; v += 64) {
+    float gv = 0.f;
+    if (v < V) {
+      gv = expf(ldz(z, v) - l + occ);
+      if (v == blank) gv -= cb;
+      if (v == y) gv -= cy;
+      gv *= scale;
+    }
     if constexpr (sizeof(TOut) == 2) g[v] = f2bf(gv); else g[v] = gv;
   }
 }
@@ -227,10 +285,10 @@ extern "C" int ea_joint_reduce(const void* dZ, void* dE, void* dD, int B, int T,
 extern "C" long ea_rnnt_workspace_bytes(int B, int T, int U1) { return 5L * B * T * U1 * (long)sizeof(float); }
 
 extern "C" int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths,
-                            const int* target_lengths, float* loss /*[B]*/, void* workspace, int B, int T, int U1, int V, int Umax,
-                            int blank, hipStream_t stream) {
+                            const int* target_lengths, float* loss /*[B]*/, void* workspace, int B, int T, int U1, int V, long ld,
+                            int Umax, int blank, hipStream_t stream) {
   if (B <= 0) return 0;
-  if (T <= 0 || U1 <= 0 || U1 > 512) return -2;
+  if (T <= 0 || U1 <= 0 || U1 > 512 || ld < V) return -2;
   const long n = (long)B * T * U1;
   float* lse = (float*)workspace;
   float* lpb = lse + n;
@@ -239,10 +297,10 @@ extern "C" int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targ
   float* beta = alpha + n;
   if (logits_bf16)
     hipLaunchKernelGGL(rnnt_lse_kernel<bf16_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)logits, targets,
-                       logit_lengths, target_lengths, lse, lpb, lpy, T, U1, V, Umax, blank, n);
+                       logit_lengths, target_lengths, lse, lpb, lpy, T, U1, V, ld, Umax, blank, n);
   else
     hipLaunchKernelGGL(rnnt_lse_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const float*)logits, targets,
-                       logit_lengths, target_lengths, lse, lpb, lpy, T, U1, V, Umax, blank, n);
+                       logit_lengths, target_lengths, lse, lpb, lpy, T, U1, V, ld, Umax, blank, n);
   const int UP = (U1 + 63) / 64 * 64;
   hipLaunchKernelGGL(rnnt_scan_kernel, dim3(B), dim3(2 * UP), (size_t)4 * (UP + 2) * sizeof(float), stream, lpb, lpy,
                      logit_lengths, target_lengths, alpha, beta, loss, T, U1, UP);
@@ -251,9 +309,10 @@ extern "C" int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targ
 
 extern "C" int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths,
                             const int* target_lengths, const float* loss, const void* workspace, void* grad, int grad_bf16, int B,
-                            int T, int U1, int V, int Umax, int blank, float grad_scale, const float* grad_scale_dev,
+                            int T, int U1, int V, long ld, int Umax, int blank, float grad_scale, const float* grad_scale_dev,
                             hipStream_t stream) {
   if (B <= 0) return 0;
+  if (ld < V) return -2;
   const long n = (long)B * T * U1;
   const float* lse = (const float*)workspace;
   const float* lpb = lse + n;
@@ -262,7 +321,7 @@ extern "C" int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targ
   const float* beta = alpha + n;
 #define EA_RNNT_GRAD(TI, TO)                                                                                              \
   hipLaunchKernelGGL((rnnt_grad_kernel<TI, TO>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const TI*)logits, targets, \
-                     logit_lengths, target_lengths, lse, lpb, lpy, alpha, beta, loss, (TO*)grad, T, U1, V, Umax, blank,     \
+                     logit_lengths, target_lengths, lse, lpb, lpy, alpha, beta, loss, (TO*)grad, T, U1, V, ld, Umax, blank, \
                      grad_scale, grad_scale_dev, n)
   if (logits_bf16) { if (grad_bf16) EA_RNNT_GRAD(bf16_t, bf16_t); else EA_RNNT_GRAD(bf16_t, float); }
   else { if (grad_bf16) EA_RNNT_GRAD(float, bf16_t); else EA_RNNT_GRAD(float, float); }

@@ -1380,7 +1380,11 @@ class _RNNTLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, targets, logit_lengths, target_lengths, blank):
-        logits = logits.contiguous() if logits.dtype == torch.bfloat16 else logits.float().contiguous()
+        if logits.dtype != torch.bfloat16:
+            logits = logits.float()
+        st = logits.stride()
+        if not (st[3] == 1 and st[2] >= logits.shape[3] and st[1] == logits.shape[2] * st[2] and st[0] == logits.shape[1] * st[1]):
+            logits = logits.contiguous()  # (a [..., :V] view of rows with a padded pitch is used as it is: no copy of B*T*U*V)
         loss, ws = K.rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank)
         ctx.save_for_backward(logits, targets, logit_lengths, target_lengths, loss, ws)
         ctx.blank = blank
@@ -1690,24 +1694,39 @@ class _TransducerJoint(torch.autograd.Function):
         V, J = w.shape
         Z = K.joint_add_relu(E.contiguous(), D.contiguous(), B, T, U1)
         n = B * T * U1
-        logits = torch.empty(n, V, dtype=torch.bfloat16, device=E.device)
-        K.gemm(Z, w16, logits, n, V, J, lda=J, ldb=J, ldc=V, bias=b)
+        # rows padded to a multiple of 64 columns (5004 -> 5056): 16-byte aligned rows for the epilogue stores and the loss kernels,
+        # and a reduction length the direct-to-LDS GEMM takes when the logits' gradient is the A operand of the data gradient
+        Vp = (V + 63) // 64 * 64
+        buf = torch.empty(n, Vp, dtype=torch.bfloat16, device=E.device)
+        K.gemm(Z, w16, buf, n, V, J, lda=J, ldb=J, ldc=Vp, bias=b)
         ctx.save_for_backward(Z, w16)
-        ctx.dims = (B, T, U1, V, J, b is not None)
-        return logits.view(B, T, U1, V)
+        ctx.dims = (B, T, U1, V, J, b is not None, Vp)
+        return buf.view(B, T, U1, Vp)[..., :V]
 
     @staticmethod
     def backward(ctx, dlogits):
         Z, w16 = ctx.saved_tensors
-        B, T, U1, V, J, has_bias = ctx.dims
+        B, T, U1, V, J, has_bias, Vp = ctx.dims
         n = B * T * U1
-        dl = dlogits.contiguous().view(n, V)
+        st = dlogits.stride()
+        if dlogits.dtype == torch.bfloat16 and st[3] == 1 and st[2] == Vp and st[1] == U1 * Vp and st[0] == T * U1 * Vp:
+            dl = dlogits.as_strided((n, Vp), (Vp, 1))  # the loss kernel's padded gradient (pad columns are zeros)
+        else:
+            dl = torch.zeros(n, Vp, dtype=torch.bfloat16, device=dlogits.device)
+            dl[:, :V] = dlogits.reshape(n, V)
+        # data gradient: dZ = dl W through the k-contiguous form (the weight's transposed, zero-padded bf16 copy [J][Vp]):
+        # both operands k-contiguous and K = Vp a multiple of 64 -> direct-to-LDS ring kernel
+        wt = torch.zeros(J, Vp, dtype=torch.bfloat16, device=dl.device)
+        wt[:, :V] = w16.t()
         dZ = torch.empty(n, J, dtype=torch.bfloat16, device=dl.device)
         # relu'(pre) == (Z > 0): the post-activation tensor doubles as the derivative mask
-        K.gemm(dl, w16, dZ, n, J, V, lda=V, ldb=J, ldc=J, b_kstrided=True, aux=Z, ldaux=J, act="relu")
+        K.gemm(dl, wt, dZ, n, J, Vp, lda=Vp, ldb=Vp, ldc=J, aux=Z, ldaux=J, act="relu")
         dE, dD = K.joint_reduce(dZ, B, T, U1)
-        dw = _wgrad(dl, Z, n, V, J)
-        db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, V) if has_bias else None
+        # dW [V][J] = dl^T Z over all B*T*U1 lattice nodes: split-K GEMM on the aligned (padded-pitch) gradient.  (The grouped
+        # weight-gradient kernel was tried here: 632 tiles each walking 45 000 rows of a 10 KB-pitch operand ran at 115 TFLOP/s,
+        # slower than the split-K launch.)
+        dw = _wgrad(dl, Z, n, V, J, ld_dy=Vp)
+        db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp) if has_bias else None
         return dE, dD, dw, db, None, None, None, None
 
 

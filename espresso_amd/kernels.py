@@ -566,26 +566,35 @@ def beam_topk(lprobs, prev_scores, bsz, beam, nbeam_used, k):
     return cs, ct, cb
 
 
-def rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank):
-    """logits fp32 or bf16 [B][T][U1][V]; returns (loss [B], workspace)."""
+def _rnnt_pitch(logits):
+    """(B, T, U1, V, ld) of a [B][T][U1][V] logits tensor that is contiguous or a column-slice view of rows with pitch ld."""
     B, T, U1, V = logits.shape
-    assert logits.dtype in (torch.float32, torch.bfloat16) and logits.is_contiguous()
+    assert logits.dtype in (torch.float32, torch.bfloat16) and logits.stride(3) == 1
+    ld = logits.stride(2)
+    assert ld >= V and logits.stride(1) == U1 * ld and logits.stride(0) == T * U1 * ld, "logits rows must be equally spaced"
+    return B, T, U1, V, ld
+
+
+def rnnt_loss_fwd(logits, targets, logit_lengths, target_lengths, blank):
+    """logits fp32 or bf16 [B][T][U1][V] (rows may be padded: a [..., :V] view of a wider buffer); returns (loss [B], workspace)."""
+    B, T, U1, V, ld = _rnnt_pitch(logits)
     Umax = targets.shape[1]
     assert U1 == Umax + 1
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     ws = torch.empty(int(_lib.lib().ea_rnnt_workspace_bytes(B, T, U1)), dtype=torch.uint8, device=logits.device)
     check(_lib.lib().ea_rnnt_loss(_p(logits), int(logits.dtype == torch.bfloat16), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), B, T, U1, V,
-                                  Umax, blank, _stream()), "ea_rnnt_loss")
+                                  ld, Umax, blank, _stream()), "ea_rnnt_loss")
     return loss, ws
 
 
 def rnnt_loss_grad(logits, targets, logit_lengths, target_lengths, loss, ws, blank, grad_scale_dev=None, grad_bf16=False):
-    B, T, U1, V = logits.shape
-    grad = torch.empty(logits.shape, dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=logits.device)
+    """Gradient with the logits' own row pitch (pad columns zero); returned as the [..., :V] view when the rows are padded."""
+    B, T, U1, V, ld = _rnnt_pitch(logits)
+    grad = torch.empty((B, T, U1, ld), dtype=torch.bfloat16 if grad_bf16 else torch.float32, device=logits.device)
     check(_lib.lib().ea_rnnt_grad(_p(logits), int(logits.dtype == torch.bfloat16), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws), _p(grad),
-                                  int(grad_bf16), B, T, U1, V, targets.shape[1], blank, 1.0, _p(grad_scale_dev), _stream()),
+                                  int(grad_bf16), B, T, U1, V, ld, targets.shape[1], blank, 1.0, _p(grad_scale_dev), _stream()),
           "ea_rnnt_grad")
-    return grad
+    return grad if ld == V else grad[..., :V]
 
 
 # ------------------------------------------------------------------------------------------------ LSTM
@@ -599,6 +608,21 @@ def lstm_cell_fwd(gates_pre, c_prev, c_out, h_f32, h_bf16, ldh, gates_act, B, H,
 def lstm_cell_bwd(dh_bf16, ld_dh, dh_f32, dc_in, gates_act, c_prev, c, dgates, lddg, dc_prev, B, H, frozen=None):
     check(_lib.lib().ea_lstm_cell_bwd(_p(dh_bf16), ld_dh, _p(dh_f32), _p(dc_in), _p(gates_act), _p(c_prev), _p(c), _p(dgates), lddg,
                                       _p(dc_prev), _p(frozen), B, H, _stream()), "ea_lstm_cell_bwd")
+
+
+def wgrad_group(problems):
+    """ea_wgrad_group: for every problem (dy bf16 [M][ld_dy], x bf16 [M][ld_x], dW fp32 [N][ldw] accumulated in place, dbias fp32 [N]
+    or None accumulated in place, M, N, K, ld_dy, ld_x, ldw) one grid computes dW += dy^T x and dbias += colsum(dy)."""
+    import ctypes
+
+    assert 0 < len(problems) <= 16
+    grp = _lib.EaWgradGroup()
+    grp.count = len(problems)
+    for i, (dy, x, dW, db, M, N, Kk, ld_dy, ld_x, ldw) in enumerate(problems):
+        q = grp.p[i]
+        q.dy, q.x, q.dW, q.dbias = dy.data_ptr(), x.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else None)
+        q.M, q.N, q.K, q.ld_dy, q.ld_x, q.ldw = M, N, Kk, ld_dy, ld_x, ldw
+    check(_lib.lib().ea_wgrad_group(ctypes.byref(grp), _stream()), "ea_wgrad_group")
 
 
 def lstm_seq_supported(B, H):

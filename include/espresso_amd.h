@@ -529,14 +529,17 @@ int ea_beam_topk(const float* lprobs, const float* prev_scores, int bsz, int bea
  * RNN-T loss — torchaudio.functional.rnnt_loss as called at espresso/criterions/transducer_loss.py:130-140
  * (blank = "<s>", clamp = -1, fused log-softmax).  logits fp32 or bf16 (logits_bf16) [B][T][U1][V] (U1 = Umax + 1; bf16 is
  * what the reference's fc_out produces under bf16 autocast), targets int32 [B][Umax], loss fp32 [B] = -log p(y|x);
- * grad = grad_scale * d(sum loss)/d(logits), fp32 or bf16, same shape as logits.
+ * grad = grad_scale * d(sum loss)/d(logits), fp32 or bf16, same layout as logits.
+ * ld: row pitch of logits AND grad in elements (>= V).  The joint of this library writes rows padded to a multiple of 64
+ * (V = 5004 -> 5056): 16-byte accesses here, aligned fast paths / direct-to-LDS GEMMs for the three joint products; the grad
+ * kernel writes the pad columns as zeros so that they can be part of a GEMM reduction.
  * workspace: ea_rnnt_workspace_bytes(B,T,U1) bytes, kept between the two calls. */
 long ea_rnnt_workspace_bytes(int B, int T, int U1);
 int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths, const int* target_lengths,
-                 float* loss, void* workspace, int B, int T, int U1, int V, int Umax, int blank, ea_stream_t stream);
+                 float* loss, void* workspace, int B, int T, int U1, int V, long ld, int Umax, int blank, ea_stream_t stream);
 int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths, const int* target_lengths,
-                 const float* loss, const void* workspace, void* grad, int grad_bf16, int B, int T, int U1, int V, int Umax,
-                 int blank, float grad_scale, const float* grad_scale_dev, ea_stream_t stream);
+                 const float* loss, const void* workspace, void* grad, int grad_bf16, int B, int T, int U1, int V, long ld,
+                 int Umax, int blank, float grad_scale, const float* grad_scale_dev, ea_stream_t stream);
 /* Joint network element-wise stages (espresso/models/transformer/speech_transformer_transducer_base.py:276-299):
  * Z[b][t][u] = relu(E[b][t] + D[b][u]) (bf16, E [B*T][J], D [B*U1][J], Z [B*T*U1][J], J % 8 == 0) and its backward
  * reductions dE[b][t] = sum_u dZ[b][t][u], dD[b][u] = sum_t dZ[b][t][u] (either output may be NULL). */
