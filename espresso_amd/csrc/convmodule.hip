@@ -452,6 +452,146 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
                              long M, int C, int act, int training, hipStream_t stream);
 
 namespace {
+// BatchNorm (+ activation) backward of the FIRST sub-sampler layer fused with that convolution's weight gradient
+// (espresso/modules/speech_convolutions.py:78-102, layer 0: 1 input channel, 3x3): dZ = BN'(dH) is formed in registers from Z and
+// dH, rounded to bf16 like the stored tensor it replaces, and is consumed on the spot by
+//   dW[co][ky][kx] += sum_pos dZ[pos][co] * X[b][to*sy+ky-1][fo*sx+kx-1],   dbias[co] += sum_pos dZ[pos][co].
+// The first layer needs no data gradient, so dZ (251 MB at the recipe's batch) is neither written nor read back, and the weight
+// gradient is no longer the last, un-overlapped kernel of the backward pass.
+// The products run on MFMA as a [64 co] x [16: 9 taps, a column of ones for the bias, 6 x zero] x [32 positions] tile per wave
+// step (the scalar version spent ~300 VALU operations per position and lane group: 380 us; this one is bound by reading Z and
+// dH once): a wave stages its 32 x 64 dZ block in LDS as it lies in memory ([position][channel]) and reads the A fragments with
+// ds_read_b64_tr_b16 (k = position runs down the rows); the B operand is the tap value of X for (position, tap), split into
+// bf16 hi + lo parts (two MFMAs into one accumulator) so that the fp32 features lose nothing.
+__device__ __forceinline__ int c1_sw(int r) { return (r & 3) ^ ((r >> 3) & 1); }
+__device__ __forceinline__ void c1_tr_read8(const uint32_t (&ad)[8], uint2 (&o)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+      : "memory");
+}
+__global__ __launch_bounds__(256) void conv1_bn_bwd_wgrad_kernel(const float* __restrict__ X, const bf16_t* __restrict__ Z,
+                                                                 const bf16_t* __restrict__ dH, const float* __restrict__ mean_rstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ red, float* __restrict__ dW,
+                                                                 float* __restrict__ dbias, int T, int F, int To, int Fo, int CO,
+                                                                 int sy, int sx, long npos, int act, float n) {
+  __shared__ __attribute__((aligned(16))) char tile[4][32 * 128];  // per wave: [32 positions][64 channels] bf16
+  __shared__ float sred[4][64][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g4 = lane >> 4;
+  const float invn = n > 0.f ? 1.f / n : 0.f;
+  const long nblk = (npos + 31) / 32;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(&tile[wave][0]);
+  for (int cs = 0; cs < CO; cs += 64) {
+    // staging role: lane owns channels cs + 8 * (lane & 7) .. + 7 of positions (lane >> 3) + 8 * it
+    const int c8 = lane & 7, prow = lane >> 3;
+    float mu[8], rs[8], ga[8], be[8], r0[8], r1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cs + c8 * 8 + e;
+      mu[e] = mean_rstd[c]; rs[e] = mean_rstd[CO + c]; ga[e] = gamma[c]; be[e] = beta[c];
+      r0[e] = red[c] * invn; r1[e] = red[CO + c] * invn;
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+      const long pb = blk * 32;
+      // ---- dZ of 32 positions x 64 channels -> LDS (bf16, as stored before) ----
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = prow + 8 * it;
+        const long p = pb + r;
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (p < npos) {
+          const uint4 uz = *reinterpret_cast<const uint4*>(Z + p * CO + cs + c8 * 8);
+          const uint4 ud = *reinterpret_cast<const uint4*>(dH + p * CO + cs + c8 * 8);
+          const uint32_t wz[4] = {uz.x, uz.y, uz.z, uz.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+          float d[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float z = (e & 1) ? __uint_as_float(wz[e >> 1] & 0xffff0000u) : __uint_as_float(wz[e >> 1] << 16);
+            float g = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
+            const float xh = (z - mu[e]) * rs[e];
+            const float y = xh * ga[e] + be[e];
+            g *= act == 2 ? dsilu_f(y) : (act == 1 ? (y > 0.f ? 1.f : 0.f) : 1.f);
+            d[e] = rs[e] * ga[e] * (g - r0[e] - xh * r1[e]);
+          }
+          o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);
+        }
+        *reinterpret_cast<uint4*>(&tile[wave][r * 128 + (((c8 >> 1) ^ c1_sw(r)) << 5) + (c8 & 1) * 16]) = o;
+      }
+      // ---- B operand: X tap values of (position 8 g4 + j, column li) as bf16 hi / lo ----
+      int fo = (int)(pb % Fo), to = (int)((pb / Fo) % To);  // wave-uniform
+      long b = pb / ((long)Fo * To);
+      uint32_t bh[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g4 + j;
+        int f = fo + k, t = to;
+        long bb = b;
+        while (f >= Fo) { f -= Fo; ++t; }
+        while (t >= To) { t -= To; ++bb; }
+        float x = 0.f;
+        if (pb + k < npos) {
+          if (li < 9) {
+            const int ti = t * sy + li / 3 - 1, fi = f * sx + li % 3 - 1;
+            if (ti >= 0 && ti < T && fi >= 0 && fi < F) x = X[(bb * T + ti) * F + fi];
+          } else if (li == 9) {
+            x = 1.f;
+          }
+        }
+        const uint32_t hi = (uint32_t)f2bf(x);
+        const uint32_t lo = (uint32_t)f2bf(x - __uint_as_float(hi << 16));
+        if (j & 1) { bh[j >> 1] |= hi << 16; bl[j >> 1] |= lo << 16; }
+        else { bh[j >> 1] = hi; bl[j >> 1] = lo; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- A fragments: channels 16 mt + li, positions 8 g4 .. + 7 (two transposing reads of 4 positions each) ----
+      uint32_t ad[8];
+      uint2 o8[8];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = 8 * g4 + 4 * h + (li >> 2);
+          ad[mt * 2 + h] = lds0 + r * 128 + ((mt ^ c1_sw(r)) << 5) + (li & 3) * 8;
+        }
+      c1_tr_read8(ad, o8);
+      const bf16x8_t vbh = __builtin_bit_cast(bf16x8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+      const bf16x8_t vbl = __builtin_bit_cast(bf16x8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, make_uint4(o8[mt * 2].x, o8[mt * 2].y, o8[mt * 2 + 1].x, o8[mt * 2 + 1].y));
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a8),
+                                                          __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, vbh), acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a8),
+                                                          __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, vbl), acc[mt], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();  // the tile is rewritten in the next iteration
+    }
+    // ---- fold the four waves, then one atomic per output and workgroup ----
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sred[wave][mt * 16 + g4 * 4 + r][li] = acc[mt][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 10; i += 256) {
+      const int c = i / 10, k = i % 10;
+      const float a = sred[0][c][k] + sred[1][c][k] + sred[2][c][k] + sred[3][c][k];
+      if (k < 9) atomicAdd(dW + (cs + c) * 9 + k, a);
+      else if (dbias) atomicAdd(dbias + cs + c, a);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void bn_param_grad_kernel(const float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -460,11 +600,43 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ red, float* __res
 }
 }  // namespace
 
+static void launch_bn_bwd_reduce(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
+                                 float* red, long M, int C, int act, hipStream_t stream);
+
 extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rstd, const float* gamma,
                              const float* beta, float* red, void* dZ, float* dgamma, float* dbeta, long M, int C,
                              int act, int training, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 8) return -2;
+  launch_bn_bwd_reduce(Z, dH, mean_rstd, gamma, beta, red, M, C, act, stream);
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z,
+                     (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, M, C, act,
+                     training ? (float)M : 0.f);
+  if (dgamma || dbeta) hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, C);
+  return EA_CHECK_LAUNCH();
+}
+
+// First sub-sampler layer: BatchNorm (+ activation) backward and the 3x3 / 1-channel convolution's weight (and bias) gradient in
+// one pass over Z and dH (conv1_bn_bwd_wgrad_kernel); `red` (fp32 [2 C], zeroed by the caller) receives BatchNorm's two sums.
+extern "C" int ea_conv1_bn_bwd(const float* X, const void* Z, const void* dH, const float* mean_rstd, const float* gamma,
+                               const float* beta, float* red, float* dgamma, float* dbeta, float* dW, float* dbias, int B, int T,
+                               int F, int CO, int sy, int sx, int act, int training, hipStream_t stream) {
+  if (B <= 0 || T <= 0) return 0;
+  if (CO % 64) return -2;
+  const int To = (T - 1) / sy + 1, Fo = (F - 1) / sx + 1;
+  const long npos = (long)B * To * Fo;
+  launch_bn_bwd_reduce(Z, dH, mean_rstd, gamma, beta, red, npos, CO, act, stream);
+  long nb = (npos + 127) / 128;  // one 32-position block per wave and step; ~4 workgroups per CU walk the rest with a grid stride
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(conv1_bn_bwd_wgrad_kernel, dim3((unsigned)nb), dim3(256), 0, stream, X, (const bf16_t*)Z,
+                     (const bf16_t*)dH, mean_rstd, gamma, beta, red, dW, dbias, T, F, To, Fo, CO, sy, sx, npos, act,
+                     training ? (float)npos : 0.f);
+  if (dgamma || dbeta) hipLaunchKernelGGL(bn_param_grad_kernel, dim3((CO + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, CO);
+  return EA_CHECK_LAUNCH();
+}
+
+static void launch_bn_bwd_reduce(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
+                                 float* red, long M, int C, int act, hipStream_t stream) {
   const int nch = C / 8;
   int TCH = 1;
   while (TCH < 256 && TCH < nch) TCH <<= 1;  // 8-channel chunks per block row (power of two <= 256)
@@ -479,11 +651,6 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
   dim3 g1((unsigned)gx, (unsigned)((M + rpb - 1) / rpb));
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, g1, dim3(256), (size_t)256 * 16 * sizeof(float), stream, (const bf16_t*)Z,
                      (const bf16_t*)dH, mean_rstd, gamma, beta, red, M, C, act, rpb, TCH);
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z,
-                     (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, M, C, act,
-                     training ? (float)M : 0.f);
-  if (dgamma || dbeta) hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, C);
-  return EA_CHECK_LAUNCH();
 }
 // the optimizer-only tail of ea_bn_act_bwd on its own (call ea_bn_act_bwd with dgamma = dbeta = NULL first)
 extern "C" int ea_bn_param_grad(const float* red, float* dgamma, float* dbeta, int C, hipStream_t stream) {

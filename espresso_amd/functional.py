@@ -535,6 +535,16 @@ def label_smoothed_ce(logits, target, pad_idx, eps, smoothing="uniform", prior=N
 _CONV_IGEMM = True  # A/B switch: implicit-GEMM 3x3 convolutions (False: the round-1 im2col + GEMM + col2im lowering)
 
 
+_CONV1_FUSED_BWD = True
+
+
+def set_conv1_fused_backward(on: bool) -> bool:
+    """First sub-sampler layer: fused BatchNorm-backward + weight-gradient kernel (default) vs separate kernels.  Returns the old setting."""
+    global _CONV1_FUSED_BWD
+    old, _CONV1_FUSED_BWD = _CONV1_FUSED_BWD, bool(on)
+    return old
+
+
 def set_conv_implicit_gemm(on: bool):
     global _CONV_IGEMM
     _CONV_IGEMM = bool(on)
@@ -629,6 +639,13 @@ class _ConvSubsample(torch.autograd.Function):
             Zi, mr, col, w16, g, beta = per[i]
             Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[i]
             dg, dbeta = _zeros_f32(Co, X), _zeros_f32(Co, X)
+            if i == 0 and Co % 64 == 0 and _CONV1_FUSED_BWD:
+                # first layer: BatchNorm backward + conv1 weight gradient in one pass (csrc/convmodule.hip conv1_bn_bwd_wgrad_kernel):
+                # no dZ tensor, and the weight gradient is no longer the last, un-overlapped kernel of the backward pass
+                db, dW = _zeros_f32(Co, X), _zeros_f32(Co * 9, X)
+                K.conv1_bn_bwd(X, Zi, dA, mr, g, beta, dg, dbeta, dW, db, B, Tc, Fc, Co, sy, sx, "relu", training)
+                grads[0], grads[1], grads[2], grads[3] = dW.view(wshapes[0]), db, dg, dbeta
+                continue
             dZ = K.bn_act_bwd(Zi, dA, mr, g, beta, dg, dbeta, "relu", training)
             keep.append(dZ)
             n = B * To * Fo

@@ -305,6 +305,15 @@ def bn_act_fwd(Z, mean_rstd, gamma, beta, act):
     return H
 
 
+def conv1_bn_bwd(X, Z, dH, mean_rstd, gamma, beta, dgamma, dbeta, dW, dbias, B, T, F, CO, sy, sx, act, training=True):
+    """BatchNorm(+act) backward of the first sub-sampler layer fused with conv1's weight / bias gradient (no dZ tensor)."""
+    from . import functional as _F
+
+    red = _F._pool_zeros((2, CO), torch.float32, Z.device)
+    check(_lib.lib().ea_conv1_bn_bwd(_p(X), _p(Z), _p(dH), _p(mean_rstd), _p(gamma), _p(beta), _p(red), _p(dgamma), _p(dbeta), _p(dW),
+                                     _p(dbias), B, T, F, CO, sy, sx, _ACT[act], int(training), _stream()), "ea_conv1_bn_bwd")
+
+
 def bn_act_bwd(Z, dH, mean_rstd, gamma, beta, dgamma, dbeta, act, training=True):
     M, C = Z.shape
     from . import functional as _F  # (zero pool: one fill per update step instead of one per call)

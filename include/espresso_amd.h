@@ -247,6 +247,14 @@ int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float*
 int ea_dwconv_bwd_weight(const void* dZ, const void* U, float* dw, void* wgrad_ws, int B, int T, int C, int KW, ea_stream_t stream);
 /* ea_bn_act_bwd with dgamma == dbeta == NULL skips the parameter gradients; they are then taken from `red` by: */
 int ea_bn_param_grad(const float* red, float* dgamma, float* dbeta, int C, ea_stream_t stream);
+/* First sub-sampler layer (espresso/modules/speech_convolutions.py:78-102, layer 0): BatchNorm (+ activation) backward and the
+ * 3x3 / 1-input-channel convolution's weight + bias gradient in one pass over Z and dH — dZ is formed in registers, never stored
+ * (the first layer needs no data gradient).  X fp32 [B][T][F] (the feature matrix), Z / dH bf16 [B][To][Fo][CO], CO % 64 == 0;
+ * red fp32 [2 CO] zeroed by the caller (receives BatchNorm's sums); dW fp32 [CO][3][3] and dbias fp32 [CO] (may be NULL)
+ * accumulated; dgamma / dbeta accumulated when non-NULL. */
+int ea_conv1_bn_bwd(const float* X, const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
+                    float* red, float* dgamma, float* dbeta, float* dW, float* dbias, int B, int T, int F, int CO, int sy, int sx,
+                    int act, int training, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conv2d sub-sampler — espresso/modules/speech_convolutions.py:78-102.  Channels-last bf16

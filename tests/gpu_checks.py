@@ -1144,6 +1144,42 @@ def check_lstm_persistent_vs_stepwise(B=5, U=11, I=96, H=256, with_state=False, 
     return res
 
 
+def check_conv1_fused_backward(B=3, T=53, Fd=80, seed=0):
+    """First sub-sampler layer: fused BatchNorm-backward + weight-gradient kernel (no dZ tensor) vs the separate kernels, same
+    module, same inputs: identical bf16 dZ values by construction, so the gradients agree to fp32 summation order."""
+    from espresso_amd import functional as F
+    from espresso_amd.modules.speech_convolutions import ConvBNReLU
+
+    torch.manual_seed(seed)
+    conv = ConvBNReLU([64, 64, 128, 128], [(3, 3)] * 4, [(1, 1), (2, 2), (1, 1), (2, 2)], in_channels=1).to(DEV)
+    with torch.no_grad():
+        for bn in conv.batchnorms:
+            bn.weight.add_(0.2 * torch.randn_like(bn.weight))
+            bn.bias.add_(0.2 * torch.randn_like(bn.bias))
+    x = torch.randn(B, T, Fd, device=DEV)
+    lens = torch.tensor([T, T - 9, T // 2], device=DEV)[:B]
+    out = {}
+    for training in (True, False):
+        conv.train(training)
+        for mode in (True, False):
+            old = F.set_conv1_fused_backward(mode)
+            try:
+                conv.zero_grad()
+                y, _, _, _ = conv(x, lens)
+                R = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+                (y.float() * R).sum().backward()
+                out[(training, mode)] = {n: p.grad.detach().clone() for n, p in conv.named_parameters() if n.split(".")[1] == "0"}
+            finally:
+                F.set_conv1_fused_backward(old)
+    torch.cuda.synchronize()
+    res = {}
+    for training in (True, False):
+        a_, b_ = out[(training, True)], out[(training, False)]
+        for n in a_:
+            res[("train" if training else "eval") + ":" + n] = float((a_[n] - b_[n]).abs().max() / (b_[n].abs().max() + 1e-12))
+    return res
+
+
 def build_tiny_transducer(V=40, embed_dim=64, heads=4):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerTransducerConfig
     from espresso_amd.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase

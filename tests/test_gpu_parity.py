@@ -164,6 +164,18 @@ def test_encoder_vs_reference_fixture(layer_type, fixture):
     assert r["worst_grad"][1] < 0.75, r  # against the fp32 run: informational (expected bf16 cancellation in BatchNorm sums)
 
 
+def test_conv1_fused_batchnorm_backward_and_weight_gradient():
+    """csrc/convmodule.hip conv1_bn_bwd_wgrad_kernel vs bn_act_bwd + conv1_wgrad (training and eval statistics): same bf16 dZ
+    values -> gradients equal to fp32 atomics / summation order (1e-3 of each tensor's scale; the conv bias gradient is exactly
+    cancelled by BatchNorm in training mode and is compared in eval mode only)"""
+    r = G.check_conv1_fused_backward()
+    print(r)
+    for k, v in r.items():
+        if k == "train:convolutions.0.bias":
+            continue
+        assert v < 1e-3, (k, r)
+
+
 def test_legacy_speech_transformer_preset_training_step():
     """`speech_transformer_wsj` (absolute sinusoidal encoder positions, no embedding LayerNorm, Transformer decoder): eval logits vs
     the fp32 oracle with the same weights within the bf16 bound (4e-2 at |logit| <= 4), every parameter gets a finite gradient"""
