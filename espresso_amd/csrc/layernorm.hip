@@ -96,6 +96,78 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   }
 }
 
+// C <= 512: a wavefront takes RW rows AT ONCE (one 16-byte chunk per lane and row): the RW loads are in flight together and
+// the 2*RW butterfly reductions interleave, instead of one dependent load -> reduce -> reduce -> store chain per row (the
+// one-row kernel is latency-bound: every wave of the grid is resident, each walks 1-2 rows, 11 us for 6 MB in and 6 MB out).
+template <int RW>
+__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C,
+    float eps, const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep) {
+  const int lane = threadIdx.x & 63;
+  const int nch = C >> 3;
+  const bool on = lane < nch;
+  float ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ga[e] = on ? gamma[lane * 8 + e] : 0.f;
+    be[e] = on ? beta[lane * 8 + e] : 0.f;
+  }
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
+  float v[RW][8], s[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = min(row0 + r, M - 1);
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (on) u = *reinterpret_cast<const uint4*>(x + (long)row * C + lane * 8);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    s[r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[r][2 * e] = __uint_as_float(w[e] << 16);
+      v[r][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+      s[r] += v[r][2 * e] + v[r][2 * e + 1];
+    }
+  }
+  float mean[RW], q[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) mean[r] = wave_sum(s[r]) / (float)C;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    q[r] = 0.f;
+    if (on) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[r][e] - mean[r];
+        q[r] += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    const float rstd = rsqrtf(wave_sum(q[r]) / (float)C + eps);
+    if (row >= M) continue;
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean[r];
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    if (!on) continue;
+    const bool zero = row_zero && row_zero[row];
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (v[r][e] - mean[r]) * rstd * ga[e] + be[e];
+      if (thr) t *= ea_keep(seed, (uint64_t)row * C + lane * 8 + e, thr, inv_keep);
+      o[e] = zero ? 0.f : t;
+    }
+    uint4 u;
+    u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(y + (long)row * C + lane * 8) = u;
+  }
+}
+
 // Each block owns ROWS_PER_BLOCK consecutive rows (4 waves round-robin), accumulates dgamma/dbeta
 // partials per lane-column, reduces across the 4 waves through LDS and writes one partial row (or issues atomics).
 // optional second output of the backward kernel: out[i] = a * dropout(dx[i]) with its own counter-based mask (the next block's
@@ -286,6 +358,16 @@ extern "C" int ea_layernorm_fwd(const void* x, const float* gamma, const float* 
                                 float drop_scale, hipStream_t stream) {
   if (M <= 0) return 0;
   if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
+  static const int rw_mode = [] { const char* e = getenv("EA_LN_ROWS"); return e ? atoi(e) : 4; }();  // (diagnostic: 0 = one row per wave)
+  if (C <= 512 && M >= 2048 && rw_mode > 0) {
+    if (rw_mode >= 4)
+      hipLaunchKernelGGL((ln_fwd_rows_kernel<4>), dim3((M + 15) / 16), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean,
+                         rstd, M, C, eps, row_zero, drop_seed, drop_thr, drop_scale);
+    else
+      hipLaunchKernelGGL((ln_fwd_rows_kernel<2>), dim3((M + 7) / 8), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean,
+                         rstd, M, C, eps, row_zero, drop_seed, drop_thr, drop_scale);
+    return EA_CHECK_LAUNCH();
+  }
   int fblocks = (M + 3) / 4;
   if (fblocks > 1024) fblocks = (fblocks + 1) / 2 > 1024 ? (fblocks + 1) / 2 : 1024;  // >= 2 rows per wavefront on large inputs
 #define EA_LN_FWD(NC)                                                                                                  \
