@@ -264,7 +264,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the config-5 decode block (beam-10 RTF)")
-    ap.add_argument("--decode-utts", type=int, default=1000, help="utterances of the 2864-utterance decode workload to time")
+    ap.add_argument("--decode-utts", type=int, default=2864, help="utterances of the 2864-utterance decode workload (SURVEY 8d) to time; default: all of it")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-nt-bytes", type=int, default=None, help="diagnostic: non-temporal store threshold of the GEMM epilogue (0 = off)")
     ap.add_argument("--gemm-dump", default=None, help="write the per-launch GEMM records of the roofline replay to this file")
