@@ -365,6 +365,7 @@ static inline bool attn_fused(const EaLayerShape& sh) {
 struct AttnSaved {
   float *mean, *rstd, *lse;
   uint16_t *xn, *qkv, *qu, *qv, *pp, *P, *Pd, *o;
+  uint16_t* bits;  // attention-dropout keep bits of the fused rel-pos kernels (NULL without dropout)
 };
 static AttnSaved attn_saved(Arena& sv, const EaLayerShape& sh) {
   const int M = sh.B * sh.T, C = sh.C, T = sh.T, Z = sh.H * sh.B, Sp = pad8(T), R = 2 * T - 1;
@@ -380,9 +381,11 @@ static AttnSaved attn_saved(Arena& sv, const EaLayerShape& sh) {
     a.pp = sv.get<uint16_t>((size_t)R * C);
     a.P = a.Pd = nullptr;
     a.o = sv.get<uint16_t>((size_t)M * C);
+    a.bits = sh.p_attn > 0.f ? sv.get<uint16_t>((size_t)ea_flash_keep_bits_bytes(sh.H, sh.B, T) / 2) : nullptr;
     return a;
   }
   a.lse = nullptr;
+  a.bits = nullptr;
   a.mean = sv.get<float>(M);
   a.rstd = sv.get<float>(M);
   a.xn = sv.get<uint16_t>((size_t)M * C);
@@ -419,7 +422,7 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
       gemm(c, gpp);
     }
     RUN(ea_flash_attention_fwd(a.qu, qvv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, pp, C, key_len, a.o, C, a.lse, H, B, T, T, dh, 0,
-                               seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+                               seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), a.bits, c.s));
     G go(a.o, w.wo, y, M, C, C, C, C, C);
     go.bias(w.bo).drop(sh.p_drop, seed + 4).resid(x, C);
     gemm(c, go);
@@ -547,7 +550,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
                                sh.pos_mode == 1 ? (const uint16_t*)pe : a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
                                Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, (sh.scratch_clean && c.overlap) ? 2 : 0, scaling, seed + 3,
                                drop_thr(sh.p_attn),
-                               drop_scale(sh.p_attn), c.s));
+                               drop_scale(sh.p_attn), a.bits, c.s));
     attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next, dpe);
     release(c, mark);
     return;
@@ -855,7 +858,7 @@ static int dlayer_fwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     gemm(c, gq);
     RUN(ea_relpos_q_prep(D.sa.qkv, 3 * C, nullptr, nullptr, D.sa.qs, nullptr, M, C, scaling, c.s));
     RUN(ea_flash_attention_fwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, C, D.sa.lse, H,
-                               B, T, T, dh, 1, seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+                               B, T, T, dh, 1, seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
     G go(D.sa.o, w.wo, D.x1, M, C, C, C, C, C);
     go.bias(w.bo).drop(sh.p_drop, seed + 16 + 4).resid(x_in, C);
     gemm(c, go);
@@ -871,7 +874,7 @@ static int dlayer_fwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     gkv.bias(w.bkv);
     gemm(c, gkv);
     RUN(ea_flash_attention_fwd(D.ca.qs, nullptr, C, D.ca.kv, D.ca.kv + C, 2 * C, nullptr, 0, enc_len, D.ca.o, C, D.ca.lse, H, B, T, S,
-                               dh, 0, seed + 32 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+                               dh, 0, seed + 32 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
     G go(D.ca.o, w.wo, D.x2, M, C, C, C, C, C);
     go.bias(w.bo).drop(sh.p_drop, seed + 32 + 4).resid(D.x1, C);
     gemm(c, go);
@@ -915,7 +918,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     float* Dd = sc.get<float>((size_t)Z * T);
     RUN(ea_flash_attention_bwd(D.ca.qs, nullptr, C, D.ca.kv, D.ca.kv + C, 2 * C, nullptr, 0, enc_len, D.ca.o, dO, C, D.ca.lse, Dd, dq,
                                nullptr, C, nullptr, 0, dkv, dkv + C, 2 * C, H, B, T, S, dh, 0, scaling, seed + 32 + 3, drop_thr(sh.p_attn),
-                               drop_scale(sh.p_attn), c.s));
+                               drop_scale(sh.p_attn), nullptr, c.s));
     fork(c);
     wgrad(c, dq, C, D.ca.xn, C, gw.wq, M, C, C, gw.bq);
     wgrad(c, dkv, 2 * C, enc, C, gw.wkv, Ms, 2 * C, C, gw.bkv);
@@ -937,7 +940,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     // t1 (gradient of the scaled queries, already multiplied by the scale) goes straight into the q third of dqkv
     RUN(ea_flash_attention_bwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, dO, C, D.sa.lse,
                                Dd, dqkv, nullptr, 3 * C, nullptr, 0, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 1, scaling,
-                               seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+                               seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
     fork(c);
     wgrad(c, dqkv, 3 * C, D.sa.xn, C, gw.wqkv, M, 3 * C, C, gw.bqkv);
     uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);

@@ -24,6 +24,7 @@
 // XCD and share its L2 copy of K / V / PP.
 #include "common.h"
 #include "espresso_amd.h"
+#include "flash_internal.h"
 
 namespace {
 
@@ -39,16 +40,6 @@ __device__ __forceinline__ uint32_t off16(int row, int chunk) { return (uint32_t
 
 
 
-struct FlashFwdArgs {
-  const bf16_t* qu; const bf16_t* qv; long ldq;
-  const bf16_t* k; const bf16_t* v; long ldkv;
-  const bf16_t* pp; long ldpp;
-  const int* klen;
-  bf16_t* out; long ldo;
-  float* lse;
-  int H, B, T, S, causal, nq;
-  uint64_t seed; uint32_t thr; float inv_keep;
-};
 
 // bijective XCD-aware remap of a 1-D grid (8 XCDs, round-robin dispatch): consecutive virtual ids stay on one XCD
 __device__ __forceinline__ int xcd_remap(int id, int total) {
@@ -305,21 +296,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct FlashBwdArgs {
-  const bf16_t* qu; const bf16_t* qv; long ldq;
-  const bf16_t* k; const bf16_t* v; long ldkv;
-  const bf16_t* pp; long ldpp;
-  const int* klen;
-  const bf16_t* out; const bf16_t* dout; long ldo;
-  const float* lse;
-  float* D;                       // [H*B][T]   (written by the Q kernel, read by the KV kernel)
-  bf16_t* t1; bf16_t* t2; long ldt;  // [B*T][ldt] gradients of (q+u), (q+v) (unscaled q space)
-  bf16_t* dBD; int ld_bd;         // [H*B][T][ld_bd]
-  bf16_t* dk; bf16_t* dv; long lddkv;
-  int H, B, T, S, causal, nq, nk, dbd_prezeroed;
-  float scaling;
-  uint64_t seed; uint32_t thr; float inv_keep;
-};
 
 template <bool RELPOS>
 __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashBwdArgs a) {
@@ -695,10 +671,20 @@ extern "C" int ea_flash_attention_supported(int dh, int T, int S, int relpos) {
   return dh == DH && T > 0 && S > 0 && (!relpos || T == S);
 }
 
+extern "C" long ea_flash_keep_bits_bytes(int H, int B, int T) {
+  const long nkt = (T + TK - 1) / TK;
+  return (long)H * B * nkt * (nkt * 64) * 4 * (long)sizeof(uint16_t);
+}
+
+extern "C" int ea_flash_keep_bits(void* keep_bits, int H, int B, int T, uint64_t drop_seed, uint32_t drop_thr, hipStream_t stream) {
+  if (H <= 0 || B <= 0 || T <= 0 || !keep_bits) return keep_bits ? 0 : -2;
+  return ea_rp_keep_bits((uint16_t*)keep_bits, H, B, T, drop_seed, drop_thr, stream);
+}
+
 extern "C" int ea_flash_attention_fwd(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldkv,
                                       const void* pp, long ldpp, const int* key_len, void* out, long ldo, float* lse, int H,
                                       int B, int T, int S, int dh, int causal, uint64_t drop_seed, uint32_t drop_thr,
-                                      float drop_scale, hipStream_t stream) {
+                                      float drop_scale, void* keep_bits, hipStream_t stream) {
   if (H <= 0 || B <= 0 || T <= 0) return 0;
   const bool relpos = qv != nullptr;
   if (!ea_flash_attention_supported(dh, T, S, relpos) || (relpos && !pp)) return -2;
@@ -711,8 +697,17 @@ extern "C" int ea_flash_attention_fwd(const void* qu, const void* qv, long ldq, 
   a.klen = key_len;
   a.out = (bf16_t*)out; a.ldo = ldo;
   a.lse = lse;
-  a.H = H; a.B = B; a.T = T; a.S = S; a.causal = causal; a.nq = (T + TQ - 1) / TQ;
+  a.H = H; a.B = B; a.T = T; a.S = S; a.causal = causal & 1; a.nq = (T + TQ - 1) / TQ;
   a.seed = drop_seed; a.thr = drop_thr; a.inv_keep = drop_scale;
+  a.bits = (const uint16_t*)keep_bits;
+  if (ea_rp_eligible(relpos, T, S, causal, drop_thr, keep_bits)) {
+    // encoder hot path (flash_relpos.hip); the keep decisions are evaluated once, here, unless the caller already did
+    if (drop_thr && !(causal & 4)) {
+      const int rc = ea_rp_keep_bits((uint16_t*)keep_bits, H, B, T, drop_seed, drop_thr, stream);
+      if (rc) return rc;
+    }
+    return ea_rp_fwd(a, stream);
+  }
   const dim3 grid((unsigned)(a.nq * H * B));
   if (relpos) hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(256), 0, stream, a);
@@ -723,7 +718,8 @@ extern "C" int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, 
                                       const void* pp, long ldpp, const int* key_len, const void* out, const void* dout, long ldo,
                                       const float* lse, float* D, void* t1, void* t2, long ldt, void* dBD, int ld_bd, void* dk,
                                       void* dv, long lddkv, int H, int B, int T, int S, int dh, int causal, float scaling,
-                                      uint64_t drop_seed, uint32_t drop_thr, float drop_scale, hipStream_t stream) {
+                                      uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* keep_bits,
+                                      hipStream_t stream) {
   if (H <= 0 || B <= 0 || T <= 0) return 0;
   const bool relpos = qv != nullptr;
   if (!ea_flash_attention_supported(dh, T, S, relpos)) return -2;
@@ -745,6 +741,8 @@ extern "C" int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, 
   a.nq = (T + TQ - 1) / TQ; a.nk = (S + TK - 1) / TK;
   a.scaling = scaling;
   a.seed = drop_seed; a.thr = drop_thr; a.inv_keep = drop_scale;
+  a.bits = (const uint16_t*)keep_bits;
+  if (ea_rp_eligible(relpos, T, S, causal, drop_thr, keep_bits)) return ea_rp_bwd(a, stream);
   const dim3 gq((unsigned)(a.nq * H * B)), gk((unsigned)(a.nk * H * B));
   if (relpos) {
     hipLaunchKernelGGL(flash_bwd_q_kernel<true>, gq, dim3(256), 0, stream, a);

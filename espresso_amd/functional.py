@@ -297,10 +297,10 @@ class _RelPosMHSA(torch.autograd.Function):
                 K.gemm(pe, wpos16, pp, R, C, C, lda=C, ldb=C, ldc=C)
         sa = _next_seed() if p_attn > 0 else 0
         fused = attn_mask is None and K.flash_attention_supported(dh, T, T, relpos)
-        P = Pd = lse = None
+        P = Pd = lse = bits = None
         if fused:
-            o, lse = K.flash_attention_fwd(qu, qv if relpos else None, qkv[:, C:], qkv[:, 2 * C:], pp, key_len, H, B, T, T, C, 3 * C,
-                                           C, causal=causal, drop_p=p_attn, drop_seed=sa)
+            o, lse, bits = K.flash_attention_fwd(qu, qv if relpos else None, qkv[:, C:], qkv[:, 2 * C:], pp, key_len, H, B, T, T, C,
+                                                 3 * C, C, causal=causal, drop_p=p_attn, drop_seed=sa, want_bits=True)
         else:
             ac = _new((Z * T, Sp), torch.float32, x)
             K.gemm(qu, qkv, ac, T, T, dh, lda=C, ldb=3 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, T * C), sB=(dh, T * 3 * C),
@@ -318,13 +318,13 @@ class _RelPosMHSA(torch.autograd.Function):
         so = _next_seed() if p_out > 0 else 0
         y = _new((M, C), torch.bfloat16, x)
         K.gemm(o, wo16, y, M, C, C, lda=C, ldb=C, ldc=C, bias=bo, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
-        ctx.save_for_backward(x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe, lse, key_len)
+        ctx.save_for_backward(x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe, lse, key_len, bits)
         ctx.cfg = (B, T, H, p_attn, p_out, sa, so, pre_ln, relpos, learned, fused, causal)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe, lse, key_len) = ctx.saved_tensors
+        (x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe, lse, key_len, bits) = ctx.saved_tensors
         B, T, H, p_attn, p_out, sa, so, pre_ln, relpos, learned, fused, causal = ctx.cfg
         M, C = x.shape
         dh = C // H
@@ -343,7 +343,7 @@ class _RelPosMHSA(torch.autograd.Function):
         if fused:
             t1, t2, dBD = K.flash_attention_bwd(qu, qv if relpos else None, qkv[:, C:], qkv[:, 2 * C:], pp, key_len, o, do, lse,
                                                 dqkv[:, C:], dqkv[:, 2 * C:], H, B, T, T, C, 3 * C, 3 * C, ldpp=C, causal=causal,
-                                                scaling=scaling, drop_p=p_attn, drop_seed=sa)
+                                                scaling=scaling, drop_p=p_attn, drop_seed=sa, keep_bits=bits)
         else:
             # dPd[z][i][j] = sum_d do[(b,i),h,d] v[(b,j),h,d]
             dPd = _new((Z * T, Sp), torch.float32, x)

@@ -216,25 +216,35 @@ def flash_attention_supported(dh, T, S, relpos):
     return bool(_lib.lib().ea_flash_attention_supported(dh, T, S, int(relpos)))
 
 
+def flash_keep_bits_buffer(H, B, T, device):
+    """Device buffer for the attention-dropout keep bits of the rel-pos encoder kernels (csrc/flash_relpos.hip)."""
+    return torch.empty(int(_lib.lib().ea_flash_keep_bits_bytes(H, B, T)) // 2, dtype=torch.int16, device=device)
+
+
 def flash_attention_fwd(qu, qv, k, v, pp, key_len, H, B, T, S, ldq, ldkv, ldpp=0, causal=False, drop_p=0.0, drop_seed=0,
-                        want_lse=True):
+                        want_lse=True, want_bits=False):
     """Fused attention forward.  qu/qv: [B*T][ldq] bf16; k, v: tensors (views allowed) whose data_ptr is head 0 of row 0,
-    rows ldkv apart.  Returns (out [B*T][H*64] bf16, lse [H*B][T] fp32 or None)."""
+    rows ldkv apart.  Returns (out [B*T][H*64] bf16, lse [H*B][T] fp32 or None); with want_bits also the keep-bit buffer
+    the rel-pos encoder kernels filled (None when dropout is off or the general kernels ran): hand it to flash_attention_bwd."""
     dh = 64
     out = torch.empty(B * T, H * dh, dtype=torch.bfloat16, device=qu.device)
     lse = torch.empty(H * B, T, dtype=torch.float32, device=qu.device) if want_lse else None
     thr, scale = drop_params(drop_p)
+    bits = None
+    if want_bits and thr and qv is not None and T == S and not causal:
+        bits = flash_keep_bits_buffer(H, B, T, qu.device)
     check(
         _lib.lib().ea_flash_attention_fwd(_p(qu), _p(qv), ldq, _p(k), _p(v), ldkv, _p(pp), ldpp, _p(key_len), _p(out),
-                                          H * dh, _p(lse), H, B, T, S, dh, int(causal), drop_seed, thr, scale, _stream()),
+                                          H * dh, _p(lse), H, B, T, S, dh, int(causal), drop_seed, thr, scale, _p(bits), _stream()),
         "ea_flash_attention_fwd",
     )
-    return out, lse
+    return (out, lse, bits) if want_bits else (out, lse)
 
 
 def flash_attention_bwd(qu, qv, k, v, pp, key_len, out, dout, lse, dk, dv, H, B, T, S, ldq, ldkv, lddkv, ldpp=0, causal=False,
-                        scaling=1.0, drop_p=0.0, drop_seed=0):
-    """Fused attention backward.  dk / dv: destination views (row stride lddkv).  Returns (t1, t2, dBD)."""
+                        scaling=1.0, drop_p=0.0, drop_seed=0, keep_bits=None):
+    """Fused attention backward.  dk / dv: destination views (row stride lddkv).  keep_bits: the buffer flash_attention_fwd
+    returned with want_bits (None: the general kernels re-evaluate the dropout hash).  Returns (t1, t2, dBD)."""
     dh = 64
     C = H * dh
     relpos = qv is not None
@@ -247,7 +257,7 @@ def flash_attention_bwd(qu, qv, k, v, pp, key_len, out, dout, lse, dk, dv, H, B,
     check(
         _lib.lib().ea_flash_attention_bwd(_p(qu), _p(qv), ldq, _p(k), _p(v), ldkv, _p(pp), ldpp, _p(key_len), _p(out), _p(dout),
                                           C, _p(lse), _p(D), _p(t1), _p(t2), C, _p(dBD), Rp, _p(dk), _p(dv), lddkv, H, B, T, S,
-                                          dh, int(causal), scaling, drop_seed, thr, scale, _stream()),
+                                          dh, int(causal), scaling, drop_seed, thr, scale, _p(keep_bits), _stream()),
         "ea_flash_attention_bwd",
     )
     return t1, t2, dBD

@@ -188,7 +188,16 @@ int ea_flash_attention_supported(int dh, int T, int S, int relpos);
 int ea_flash_attention_fwd(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldkv,
                            const void* pp, long ldpp, const int* key_len, void* out, long ldo, float* lse, int H, int B,
                            int T, int S, int dh, int causal, uint64_t drop_seed, uint32_t drop_thr, float drop_scale,
-                           ea_stream_t stream);
+                           void* keep_bits, ea_stream_t stream);
+/* Attention-dropout keep decisions as bits (flash_relpos.hip): the rel-pos encoder kernels (qv != NULL, T == S, no causal
+ * mask) read 16 keep bits per lane and key tile instead of hashing every element in each of the three kernels.  The
+ * decisions are the same ea_keep(seed, (z*T + i)*S + j) as everywhere else.  keep_bits: ea_flash_keep_bits_bytes(H, B, T)
+ * bytes of device memory; ea_flash_attention_fwd fills it (or expects it filled by ea_flash_keep_bits when bit 2 of
+ * `causal` is set) and ea_flash_attention_bwd reads it.  keep_bits == NULL with dropout on selects the general kernels. */
+long ea_flash_keep_bits_bytes(int H, int B, int T);
+/* 0: the general kernels also serve the rel-pos encoder attention (A/B measurements, tests); returns the previous value */
+int ea_set_flash_relpos(int on);
+int ea_flash_keep_bits(void* keep_bits, int H, int B, int T, uint64_t drop_seed, uint32_t drop_thr, ea_stream_t stream);
 /* Backward of ea_flash_attention_fwd (probabilities recomputed from lse; same dropout stream).
  *   out, dout : bf16 [B*T][ldo] forward output and its gradient;  D: fp32 [H*B][T] scratch (row dot dO.O)
  *   t1, t2    : bf16 [B*T][ldt], scaling * dL/dqu and scaling * dL/dqv, i.e. the gradients w.r.t. (q + pos_bias_u) and
@@ -202,7 +211,8 @@ int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, const void*
                            const void* pp, long ldpp, const int* key_len, const void* out, const void* dout, long ldo,
                            const float* lse, float* D, void* t1, void* t2, long ldt, void* dBD, int ld_bd, void* dk,
                            void* dv, long lddkv, int H, int B, int T, int S, int dh, int causal, float scaling,
-                           uint64_t drop_seed, uint32_t drop_thr, float drop_scale, ea_stream_t stream);
+                           uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* keep_bits,
+                           ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Relative-position attention glue — fairseq/modules/multihead_attention.py:679-688 (q+u, q+v,

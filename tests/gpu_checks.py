@@ -939,9 +939,23 @@ def _attn_reference(qu, qv, k, v, pp, klen, H, B, T, S, causal):
     return s, p, f(v, S)
 
 
-def check_flash_attention(B=3, H=4, T=150, S=None, relpos=True, causal=False, padded=True, drop_p=0.0, seed=0):
+def _flash_impl(general):
+    """select the general kernels (flash_attention.hip) or the rel-pos encoder kernels (flash_relpos.hip); returns the previous setting"""
+    from espresso_amd import _lib
+    return _lib.lib().ea_set_flash_relpos(0 if general else 1)
+
+
+def check_flash_attention(B=3, H=4, T=150, S=None, relpos=True, causal=False, padded=True, drop_p=0.0, seed=0, general=False):
     """Fused attention forward vs the fp32 restatement (and, with dropout, vs the unfused softmax kernel's mask)."""
     from espresso_amd import kernels as K
+    prev = _flash_impl(general)
+    try:
+        return _check_flash_attention(K, B, H, T, S, relpos, causal, padded, drop_p, seed)
+    finally:
+        _flash_impl(not prev)
+
+
+def _check_flash_attention(K, B, H, T, S, relpos, causal, padded, drop_p, seed):
     dev = "cuda:0"
     S = S or T
     dh, C = 64, H * 64
@@ -956,7 +970,8 @@ def check_flash_attention(B=3, H=4, T=150, S=None, relpos=True, causal=False, pa
     if padded:
         klen = torch.randint(max(1, S // 3), S + 1, (B,), device=dev, generator=g).int()
         klen[0] = S
-    out, lse = K.flash_attention_fwd(qu, qv, k, v, pp, klen, H, B, T, S, C, 2 * C, C, causal=causal, drop_p=drop_p, drop_seed=1234)
+    out, lse, _ = K.flash_attention_fwd(qu, qv, k, v, pp, klen, H, B, T, S, C, 2 * C, C, causal=causal, drop_p=drop_p, drop_seed=1234,
+                                        want_bits=True)
     s, p, vf = _attn_reference(qu, qv, k.contiguous(), v.contiguous(), pp, klen, H, B, T, S, causal)
     lse_ref = torch.logsumexp(s, dim=-1)  # [B][H][T]
     if drop_p > 0:
@@ -979,9 +994,17 @@ def check_flash_attention(B=3, H=4, T=150, S=None, relpos=True, causal=False, pa
     }
 
 
-def check_flash_attention_bwd(B=3, H=4, T=150, S=None, relpos=True, causal=False, padded=True, drop_p=0.0, seed=0):
+def check_flash_attention_bwd(B=3, H=4, T=150, S=None, relpos=True, causal=False, padded=True, drop_p=0.0, seed=0, general=False):
     """Fused attention backward vs torch autograd through the fp32 restatement."""
     from espresso_amd import kernels as K
+    prev = _flash_impl(general)
+    try:
+        return _check_flash_attention_bwd(K, B, H, T, S, relpos, causal, padded, drop_p, seed)
+    finally:
+        _flash_impl(not prev)
+
+
+def _check_flash_attention_bwd(K, B, H, T, S, relpos, causal, padded, drop_p, seed):
     dev = "cuda:0"
     S = S or T
     dh, C = 64, H * 64
@@ -998,10 +1021,11 @@ def check_flash_attention_bwd(B=3, H=4, T=150, S=None, relpos=True, causal=False
         klen = torch.randint(max(1, S // 3), S + 1, (B,), device=dev, generator=g).int()
         klen[0] = S
     scaling = 0.125
-    out, lse = K.flash_attention_fwd(qu, qv, k, v, pp, klen, H, B, T, S, C, 2 * C, C, causal=causal, drop_p=drop_p, drop_seed=77)
+    out, lse, bits = K.flash_attention_fwd(qu, qv, k, v, pp, klen, H, B, T, S, C, 2 * C, C, causal=causal, drop_p=drop_p, drop_seed=77,
+                                           want_bits=True)
     dkv = torch.full((B * S, 2 * C), float("nan"), dtype=torch.bfloat16, device=dev)
     t1, t2, dBD = K.flash_attention_bwd(qu, qv, k, v, pp, klen, out, dout, lse, dkv[:, :C], dkv[:, C:], H, B, T, S, C, 2 * C, 2 * C,
-                                        ldpp=C, causal=causal, scaling=scaling, drop_p=drop_p, drop_seed=77)
+                                        ldpp=C, causal=causal, scaling=scaling, drop_p=drop_p, drop_seed=77, keep_bits=bits)
     # reference
     leaf = lambda x: x.float().clone().requires_grad_(True) if x is not None else None
     qu_r, qv_r, k_r, v_r, pp_r = leaf(qu), leaf(qv), leaf(k.contiguous()), leaf(v.contiguous()), leaf(pp)

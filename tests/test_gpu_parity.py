@@ -271,6 +271,12 @@ def test_simple_greedy_decoder():
     dict(T=100, relpos=False, causal=True, padded=False),
     dict(T=50, S=170, relpos=False, padded=True),
     dict(T=150, relpos=True, padded=True, drop_p=0.1),
+    dict(T=308, B=2, H=8, relpos=True, padded=True, drop_p=0.1),
+    dict(T=129, B=5, H=2, relpos=True, padded=True, drop_p=0.1, seed=3),
+    dict(T=700, B=1, H=2, relpos=True, padded=False),
+    # the general kernels on the encoder shapes (what flash_relpos.hip replaced; they still serve EA_FLASH_V1=1)
+    dict(T=150, relpos=True, padded=True, general=True),
+    dict(T=150, relpos=True, padded=True, drop_p=0.1, general=True),
 ])
 def test_flash_attention_forward(kw):
     """fused scores+skew+softmax+dropout+PV vs fp32 restatement of multihead_attention.py:788-907 (bf16 probabilities:
@@ -288,6 +294,12 @@ def test_flash_attention_forward(kw):
     dict(T=100, relpos=False, causal=True, padded=False),
     dict(T=50, S=170, relpos=False, padded=True),
     dict(T=150, relpos=True, padded=True, drop_p=0.1),
+    dict(T=64, relpos=True, padded=True),
+    dict(T=308, B=2, H=8, relpos=True, padded=True, drop_p=0.1),
+    dict(T=129, B=5, H=2, relpos=True, padded=True, drop_p=0.1, seed=3),
+    dict(T=700, B=1, H=2, relpos=True, padded=False),
+    dict(T=150, relpos=True, padded=True, general=True),
+    dict(T=150, relpos=True, padded=True, drop_p=0.1, general=True),
 ])
 def test_flash_attention_backward(kw):
     """fused attention backward (dS recomputed from the saved logsumexp) vs autograd of the fp32 restatement; bf16

@@ -4,8 +4,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_flash
 rm -rf $OUT; mkdir -p $OUT
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o fl -- python $R/tools/bench_flash.py ${1:-24} ${2:-255} > $OUT.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o fl -- python $R/tools/bench_flash.py ${1:-21} ${2:-308} > $OUT.log 2>&1
 DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
 python $R/tools/rocpd_summary.py $DB $R/gpurun_out/prof_flash_summary.txt > /dev/null
-grep -E "flash" $R/gpurun_out/prof_flash_summary.txt | cut -c1-150
+grep -E "flash|rp_|keep_bits" $R/gpurun_out/prof_flash_summary.txt | cut -c1-150
 rm -rf $OUT
