@@ -62,9 +62,84 @@ __device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
   pk.y = pack_bf2(c, d);
   return __builtin_bit_cast(bf16x4_t, pk);
 }
-// transposing read: lane (g = lane>>4, i = lane&15) passes the address of element [k0(g) + (i>>2)][m0 + 4*(i&3)] of a row-major
-// image and receives the four elements [k0(g) + e][m0 + i], e = 0..3
-__device__ __forceinline__ bf16x4_t trr(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4_t)p); }
+// transposing read (ds_read_b64_tr_b16): lane (g = lane>>4, i = lane&15) passes the address of element
+// [k0(g) + (i>>2)][m0 + 4*(i&3)] of a row-major image and receives the four elements [k0(g) + e][m0 + i], e = 0..3.
+// Issued from inline asm in batches with their own wait: through the builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of
+// the first transposing read of every tile (it cannot tell them from the global_load_lds writes in flight), which drains
+// the operand prefetch in the middle of the tile it should overlap with.  The compiler does not track loads issued from
+// asm, so the results must not be visible to it before the wait inside the same statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
+// 4 addresses x 4 immediate offsets -> o[a*4 + q] = image at ad[a] + OFFq
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void trr16(const uint32_t (&ad)[4], uint2 (&o)[16]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%20\n\tds_read_b64_tr_b16 %1, %16 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %2, %16 offset:%22\n\tds_read_b64_tr_b16 %3, %16 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %4, %17 offset:%20\n\tds_read_b64_tr_b16 %5, %17 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %6, %17 offset:%22\n\tds_read_b64_tr_b16 %7, %17 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %8, %18 offset:%20\n\tds_read_b64_tr_b16 %9, %18 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %10, %18 offset:%22\n\tds_read_b64_tr_b16 %11, %18 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %12, %19 offset:%20\n\tds_read_b64_tr_b16 %13, %19 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %14, %19 offset:%22\n\tds_read_b64_tr_b16 %15, %19 offset:%23\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]),
+        "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
+      : "memory");
+}
+// 2 addresses x 4 immediate offsets
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void trr8(const uint32_t (&ad)[2], uint2 (&o)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %6, %9 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(ad[0]), "v"(ad[1]), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
+      : "memory");
+}
+// 20 addresses, no offsets (the five 16-row blocks of a wave's positional window x four 16-column tiles)
+__device__ __forceinline__ void trr20(const uint32_t (&ad)[20], uint2 (&o)[20]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %20\n\tds_read_b64_tr_b16 %1, %21\n\tds_read_b64_tr_b16 %2, %22\n\tds_read_b64_tr_b16 %3, %23\n\t"
+      "ds_read_b64_tr_b16 %4, %24\n\tds_read_b64_tr_b16 %5, %25\n\tds_read_b64_tr_b16 %6, %26\n\tds_read_b64_tr_b16 %7, %27\n\t"
+      "ds_read_b64_tr_b16 %8, %28\n\tds_read_b64_tr_b16 %9, %29\n\tds_read_b64_tr_b16 %10, %30\n\tds_read_b64_tr_b16 %11, %31\n\t"
+      "ds_read_b64_tr_b16 %12, %32\n\tds_read_b64_tr_b16 %13, %33\n\tds_read_b64_tr_b16 %14, %34\n\tds_read_b64_tr_b16 %15, %35\n\t"
+      "ds_read_b64_tr_b16 %16, %36\n\tds_read_b64_tr_b16 %17, %37\n\tds_read_b64_tr_b16 %18, %38\n\tds_read_b64_tr_b16 %19, %39\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]),
+        "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]),
+        "=&v"(o[17]), "=&v"(o[18]), "=&v"(o[19])
+      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]), "v"(ad[8]), "v"(ad[9]),
+        "v"(ad[10]), "v"(ad[11]), "v"(ad[12]), "v"(ad[13]), "v"(ad[14]), "v"(ad[15]), "v"(ad[16]), "v"(ad[17]), "v"(ad[18]),
+        "v"(ad[19])
+      : "memory");
+}
+// 8 bytes of the un-skew buffer as two SCALAR float loads (merged into one ds_read_b64 / ds_read2 by the compiler): hipcc
+// puts `s_waitcnt vmcnt(0)` in front of vector-typed LDS loads that follow a global_load_lds (type-based alias analysis
+// cannot separate them from the in-flight LDS writes), which would drain the next tile's prefetch in mid-tile
+__device__ __forceinline__ uint2 lds_u2(const char* p) {
+  const float* f = reinterpret_cast<const float*>(p);
+  return make_uint2(__float_as_uint(f[0]), __float_as_uint(f[1]));
+}
+__device__ __forceinline__ bf16x8_t cat2(uint2 lo, uint2 hi) {
+  return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+// the [64 d] x [64 keys / rows] transposed operand of an image as eight 16x32 fragments: f[dt*2 + kb], keys kb*32 .. +31 in the
+// permuted order (rows 4g..4g+3 of the block's first 16, then of its second 16)
+__device__ __forceinline__ void tr_image(const char* img, const uint32_t (&tro)[4], bf16x8_t (&f)[8]) {
+  const uint32_t b = lds_addr(img);
+  const uint32_t ad[4] = {b + tro[0], b + tro[1], b + tro[2], b + tro[3]};
+  uint2 o[16];
+  trr16<0, 2048, 4096, 6144>(ad, o);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f[dt * 2 + 0] = cat2(o[dt * 4 + 0], o[dt * 4 + 1]);
+    f[dt * 2 + 1] = cat2(o[dt * 4 + 2], o[dt * 4 + 3]);
+  }
+}
 __device__ __forceinline__ bf16x8_t ldf(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -275,14 +350,15 @@ __global__ __launch_bounds__(256, 2) void rp_fwd_kernel(const FlashFwdArgs a) {
       for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha;
 
     // O^T[d][i] += sum_j V^T[d][j] Pd^T[j][i], 32 keys per MFMA
+    {
+      bf16x8_t vf[8];
+      tr_image(sV, L.tro, vf);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const bf16x8_t pb = cat(pack4(acc_s[2 * kb][0], acc_s[2 * kb][1], acc_s[2 * kb][2], acc_s[2 * kb][3]),
-                              pack4(acc_s[2 * kb + 1][0], acc_s[2 * kb + 1][1], acc_s[2 * kb + 1][2], acc_s[2 * kb + 1][3]));
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8_t pb = cat(pack4(acc_s[2 * kb][0], acc_s[2 * kb][1], acc_s[2 * kb][2], acc_s[2 * kb][3]),
+                                pack4(acc_s[2 * kb + 1][0], acc_s[2 * kb + 1][1], acc_s[2 * kb + 1][2], acc_s[2 * kb + 1][3]));
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t vf = cat(trr(sV + kb * 4096 + L.tro[dt]), trr(sV + kb * 4096 + 2048 + L.tro[dt]));
-        acc_o[dt] = mfma32(vf, pb, acc_o[dt]);
+        for (int dt = 0; dt < 4; ++dt) acc_o[dt] = mfma32(vf[dt * 2 + kb], pb, acc_o[dt]);
       }
     }
     slot_lo = slot_hi;
@@ -454,13 +530,14 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
     softmax_bwd_tile<DROP, false>(acc_s, acc_dp, dsb, pdb, lse2, Di, a.inv_keep, piece, kl - j0, g4);
 
     // t1^T[d][i] += sum_j K^T[d][j] dS^T[j][i]
+    if (!(a.dbg & 4)) {
+      bf16x8_t kf[8];
+      tr_image(sK, L.tro, kf);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const bf16x8_t db = cat(dsb[2 * kb], dsb[2 * kb + 1]);
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8_t db = cat(dsb[2 * kb], dsb[2 * kb + 1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t kf = cat(trr(sK + kb * 4096 + L.tro[dt]), trr(sK + kb * 4096 + 2048 + L.tro[dt]));
-        acc_t1[dt] = mfma32(kf, db, acc_t1[dt]);
+        for (int dt = 0; dt < 4; ++dt) acc_t1[dt] = mfma32(kf[dt * 2 + kb], db, acc_t1[dt]);
       }
     }
     // un-skew: dBD^T[15 - i_w + j][i_w] = dS^T[j][i_w], kept as bf16 [row i_w][position c']
@@ -475,40 +552,54 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
     }
     wave_lds_sync();
     // t2^T[d][i] += sum_c' PP^T[d][c0w + c'] dBD^T[c'][i] over the wave's 80 positions: 2 x 32 (permuted) + 16
+    if (!(a.dbg & 2)) {
+      uint32_t ad[20];
+      uint2 pf[20];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      uint2 blo = *reinterpret_cast<const uint2*>(ob_rd + cb * 64);
-      const uint2 bhi = *reinterpret_cast<const uint2*>(ob_rd + cb * 64 + 32);
-      if (cb == 0) {
-        blo.x &= mlo.x;
-        blo.y &= mlo.y;
+      for (int q16 = 0; q16 < 5; ++q16) {
+        const int qq = q16 - w + 3;  // 16-row block of the window
+        const uint32_t pbk = lds_addr(((qq >> 2) ? blk_hi : blk_lo) + (qq & 3) * 2048);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ad[q16 * 4 + dt] = pbk + L.tro[dt];
       }
-      const bf16x8_t db = cat(__builtin_bit_cast(bf16x4_t, blo), __builtin_bit_cast(bf16x4_t, bhi));
-      const int qa = 2 * cb - w + 3, qb = qa + 1;  // 16-row blocks of the window
-      const char* pa = ((qa >> 2) ? blk_hi : blk_lo) + (qa & 3) * 2048;
-      const char* pb = ((qb >> 2) ? blk_hi : blk_lo) + (qb & 3) * 2048;
+      trr20(ad, pf);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc_t2[dt] = mfma32(cat(trr(pa + L.tro[dt]), trr(pb + L.tro[dt])), db, acc_t2[dt]);
-    }
-    {
-      uint2 bl = *reinterpret_cast<const uint2*>(ob_rd + 128);
+      for (int cb = 0; cb < 2; ++cb) {
+        uint2 blo = lds_u2(ob_rd + cb * 64);
+        const uint2 bhi = lds_u2(ob_rd + cb * 64 + 32);
+        if (cb == 0) {
+          blo.x &= mlo.x;
+          blo.y &= mlo.y;
+        }
+        const bf16x8_t db = cat2(blo, bhi);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc_t2[dt] = mfma32(cat2(pf[(2 * cb) * 4 + dt], pf[(2 * cb + 1) * 4 + dt]), db, acc_t2[dt]);
+      }
+      uint2 bl = lds_u2(ob_rd + 128);
       bl.x &= mhi.x;
       bl.y &= mhi.y;
-      const int qa = 4 - w + 3;
-      const char* pa = ((qa >> 2) ? blk_hi : blk_lo) + (qa & 3) * 2048;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc_t2[dt] = mfma16(trr(pa + L.tro[dt]), __builtin_bit_cast(bf16x4_t, bl), acc_t2[dt]);
+      for (int dt = 0; dt < 4; ++dt)
+        acc_t2[dt] = mfma16(__builtin_bit_cast(bf16x4_t, pf[16 + dt]), __builtin_bit_cast(bf16x4_t, bl), acc_t2[dt]);
     }
     // dBD[z][row][T-1-row + j] = dS[row][j]: one 128-byte row segment per store instruction
-    {
+    if (!(a.dbg & 1)) {
       const int j = j0 + lane;
       if (j < T) {
         const int row_w = i0 + 16 * w, nrow = T - row_w;  // wavefront-uniform
         bf16_t* dp = a.dBD + ((long)z * T + row_w) * a.ld_bd + (T - 1 - row_w) + j;
         const bf16_t* bs = ob + 15 + lane;
+        bf16_t val[16];  // all 16 LDS reads first: a predicated read-store chain waits for LDS once per row
 #pragma unroll
-        for (int iw = 0; iw < 16; ++iw)
-          if (iw < nrow) dp[(long)iw * (a.ld_bd - 1)] = bs[iw * (OBP - 1)];
+        for (int iw = 0; iw < 16; ++iw) val[iw] = bs[iw * (OBP - 1)];
+        if (nrow >= 16) {
+#pragma unroll
+          for (int iw = 0; iw < 16; ++iw) dp[(long)iw * (a.ld_bd - 1)] = val[iw];
+        } else {
+#pragma unroll
+          for (int iw = 0; iw < 16; ++iw)
+            if (iw < nrow) dp[(long)iw * (a.ld_bd - 1)] = val[iw];
+        }
       }
     }
     wave_lds_sync();  // un-skew buffer reads done before the next tile's skew writes
@@ -613,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
     const long o = (long)ic * a.ldq + g4 * 8;
     qv_next[0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Qvb + o));
     qv_next[1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Qvb + o + 32));
-    lse_next = (i < T) ? a.lse[(long)z * T + ic] * LOG2E : INFINITY;
+    lse_next = a.lse[(long)z * T + ic];  // raw: any arithmetic on it here would wait for the load (and the prefetch behind it)
     D_next = a.D[(long)z * T + ic];
     if (DROP) piece_next = bitp[(long)i0 * 4];
   };
@@ -633,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
     const int slot_nx = slot_lo == 2 ? 0 : slot_lo + 1;
     qv[0] = qv_next[0];
     qv[1] = qv_next[1];
-    const float lse2 = lse_next, Di = D_next;
+    const float lse2 = (i0 + 16 * w + li < T) ? lse_next * LOG2E : INFINITY, Di = D_next;
     const uint32_t piece = piece_next;
     if (it + 1 < nq) {
       char* st = lds + ((it + 1) & 1) * 2 * IMG;
@@ -673,19 +764,31 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
       *reinterpret_cast<bf16x4_t*>(exw + (exo ^ (jt << 5))) = dsb[jt];
       *reinterpret_cast<bf16x4_t*>(exw + 2048 + (exo ^ (jt << 5))) = pdb[jt];
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // not __syncthreads(): that also waits for the prefetch (vmcnt)
+    __builtin_amdgcn_s_barrier();
     // phase 2: this wave's 16 keys, all 64 rows:  dK^T[d][j] += sum_i Qu^T[d][i] dS[i][j],  dV^T[d][j] += sum_i dO^T[d][i] Pd[i][j]
+    {
+      const uint32_t eb = lds_addr(exbase);
+      const uint32_t ead[2] = {eb + exr[0], eb + exr[1]};
+      uint2 bx[8];  // bx[hh*4 + q]: q = 0 dS rows 0..31, 1 Pd rows 0..31, 2 dS rows 32..63, 3 Pd rows 32..63
+      trr8<0, 2048, 2 * BNC, 2 * BNC + 2048>(ead, bx);
+      const uint32_t qb = lds_addr(sQ);
 #pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-      const char* ex = exbase + 2 * ks2 * BNC;
-      const bf16x8_t bs = cat(trr(ex + exr[0]), trr(ex + exr[1]));
-      const bf16x8_t bp = cat(trr(ex + 2048 + exr[0]), trr(ex + 2048 + exr[1]));
+      for (int half = 0; half < 2; ++half) {  // two 16-column tiles of d per batch of reads
+        const int d0 = half * 2;
+        const uint32_t aad[4] = {qb + (trk[0] ^ (uint32_t)(d0 << 5)), qb + (trk[1] ^ (uint32_t)(d0 << 5)),
+                                 qb + (trk[0] ^ (uint32_t)((d0 + 1) << 5)), qb + (trk[1] ^ (uint32_t)((d0 + 1) << 5))};
+        uint2 ax[16];  // ax[(dd*2 + hh)*4 + q]: q = 0 Qu rows 0..31, 1 Qu rows 32..63, 2 dO rows 0..31, 3 dO rows 32..63
+        trr16<0, 4096, IMG, IMG + 4096>(aad, ax);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t aq = cat(trr(sQ + ks2 * 4096 + (trk[0] ^ (dt << 5))), trr(sQ + ks2 * 4096 + (trk[1] ^ (dt << 5))));
-        acc_dk[dt] = mfma32(aq, bs, acc_dk[dt]);
-        const bf16x8_t ag = cat(trr(sG + ks2 * 4096 + (trk[0] ^ (dt << 5))), trr(sG + ks2 * 4096 + (trk[1] ^ (dt << 5))));
-        acc_dv[dt] = mfma32(ag, bp, acc_dv[dt]);
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+          for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const bf16x8_t aq = cat2(ax[(dd * 2 + 0) * 4 + ks2], ax[(dd * 2 + 1) * 4 + ks2]);
+            const bf16x8_t ag = cat2(ax[(dd * 2 + 0) * 4 + 2 + ks2], ax[(dd * 2 + 1) * 4 + 2 + ks2]);
+            acc_dk[d0 + dd] = mfma32(aq, cat2(bx[0 * 4 + 2 * ks2], bx[1 * 4 + 2 * ks2]), acc_dk[d0 + dd]);
+            acc_dv[d0 + dd] = mfma32(ag, cat2(bx[0 * 4 + 2 * ks2 + 1], bx[1 * 4 + 2 * ks2 + 1]), acc_dv[d0 + dd]);
+          }
       }
     }
     slot_lo = slot_nx;
@@ -734,7 +837,10 @@ int ea_rp_fwd(const FlashFwdArgs& a, hipStream_t stream) {
   return EA_CHECK_LAUNCH();
 }
 
-int ea_rp_bwd(const FlashBwdArgs& a, hipStream_t stream) {
+int ea_rp_bwd(const FlashBwdArgs& a_in, hipStream_t stream) {
+  static const int dbg = [] { const char* e = getenv("EA_RP_DBG"); return e ? atoi(e) : 0; }();
+  FlashBwdArgs a = a_in;
+  a.dbg = dbg;
   const dim3 gq((unsigned)(a.nq * a.H * a.B)), gk((unsigned)(a.nk * a.H * a.B));
   if (a.thr) {
     hipLaunchKernelGGL(rp_bwd_q_kernel<true>, gq, dim3(256), 0, stream, a);
