@@ -10,6 +10,7 @@
 // the Python composition in espresso_amd/functional.py (which remains as the reference for tests).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -357,6 +358,7 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
 
 // saved layout of the attention block is produced by the same get<> sequence in fwd and bwd
 static bool g_flash = true;
+static bool g_flash_bits_side = [] { const char* e = getenv("EA_FLASH_BITS_INLINE"); return !(e && e[0] == '1'); }();
 // fused (flash) attention: head dim 64 and no additive attention mask; decided from the shape alone so that the saved
 // layout of forward and backward agree
 static inline bool attn_fused(const EaLayerShape& sh) {
@@ -405,6 +407,16 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   const float scaling = 1.0f / sqrtf((float)dh);
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
+  // attention-dropout keep bits: data independent, so the bit kernel runs on the side stream under the LayerNorm / QKV GEMM
+  // of this block (the side stream first waits for the main stream: an earlier backward may still be reading the buffer)
+  bool bits_on_side = false;
+  if (a.bits && attn_fused(sh) && !c.dry && c.rc == 0 && g_flash_bits_side && side_init(c.s)) {
+    hipEvent_t e0 = g_side.ev[g_side.next];
+    g_side.next = (g_side.next + 1) % 32;
+    if (hipEventRecord(e0, c.s) != hipSuccess || hipStreamWaitEvent(g_side.stream, e0, 0) != hipSuccess) c.rc = -1;
+    RUN(ea_flash_keep_bits(a.bits, H, B, T, seed + 3, drop_thr(sh.p_attn), g_side.stream));
+    bits_on_side = true;
+  }
   RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, a.xn, a.mean, a.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   G gq(a.xn, w.wqkv, a.qkv, M, 3 * C, C, C, C, 3 * C);
   gq.bias(w.bqkv);
@@ -421,8 +433,13 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
       G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
       gemm(c, gpp);
     }
-    RUN(ea_flash_attention_fwd(a.qu, qvv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, pp, C, key_len, a.o, C, a.lse, H, B, T, T, dh, 0,
-                               seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), a.bits, c.s));
+    if (bits_on_side) {
+      hipEvent_t e1 = g_side.ev[g_side.next];
+      g_side.next = (g_side.next + 1) % 32;
+      if (c.rc == 0 && (hipEventRecord(e1, g_side.stream) != hipSuccess || hipStreamWaitEvent(c.s, e1, 0) != hipSuccess)) c.rc = -1;
+    }
+    RUN(ea_flash_attention_fwd(a.qu, qvv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, pp, C, key_len, a.o, C, a.lse, H, B, T, T, dh,
+                               bits_on_side ? 4 : 0, seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), a.bits, c.s));
     G go(a.o, w.wo, y, M, C, C, C, C, C);
     go.bias(w.bo).drop(sh.p_drop, seed + 4).resid(x, C);
     gemm(c, go);

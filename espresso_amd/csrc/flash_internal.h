@@ -30,6 +30,7 @@ struct FlashBwdArgs {
   float scaling;
   uint64_t seed; uint32_t thr; float inv_keep;
   const uint16_t* bits;
+  unsigned long long* prof;  // RP_PROF builds: per-wave phase cycle sums
   int dbg;  // diagnostic builds of the rel-pos kernels: EA_RP_DBG bit mask of phases to skip (results are then wrong)
 };
 

@@ -38,6 +38,8 @@ constexpr int BNC = 80 * BDP * 4;        // bytes of one wave's skew buffer (als
 constexpr int OBP = 88;                  // pitch (bf16) of the un-skew buffer [16 rows][80 positions]
 constexpr int PP_OFF = 4 * IMG, BNC_OFF = 7 * IMG;
 constexpr int LDS_BYTES = 7 * IMG + 4 * BNC;  // 2 stages x 2 images + 3 positional blocks + 4 skew buffers = 80 384
+constexpr int AUX_OFF = LDS_BYTES;            // KV kernel: 2 stages x {lse[64], D[64]} fp32 behind the skew buffers
+constexpr int LDS_BYTES_KV = LDS_BYTES + 1024;  // 81 408 <= 81 920 = half of a CU's LDS
 constexpr float LOG2E = 1.4426950408889634f;
 
 // 16-byte slot s of image row r lives at slot s ^ swz(r): conflict free for ds_read_b128 operand fragments AND for both
@@ -148,6 +150,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// -DRP_PROF: s_memtime stamps at the phase boundaries of the backward kernels, per-wave sums written to a.prof and averaged on
+// the host by ea_rp_bwd (EA_RP_PROF=1).  Diagnostic only: the stamps wait for lgkmcnt and so add sync points of their own.
+#ifdef RP_PROF
+#define PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(); unsigned prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_MARK(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[k] += (unsigned)(n_ - prof_t); prof_t = n_; }
+#define PROF_DUMP(kern) if (a.prof && (threadIdx.x & 63) == 0) { unsigned long long* o_ = a.prof + ((long)(kern) * 8192 + (long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10; for (int k_ = 0; k_ < 10; ++k_) o_[k_] = prof_acc[k_]; }
+#else
+#define PROF_DECL
+#define PROF_MARK(k)
+#define PROF_DUMP(kern)
+#endif
+
 struct LaneK {
   int lane, w, li, g4;
   uint32_t offk[2];  // k-contiguous fragment: row li (+16 rows = +2048 bytes), slot ks*4 + g4
@@ -173,16 +187,38 @@ __device__ __forceinline__ LaneK lane_consts() {
   return L;
 }
 
-// one [64][64] bf16 image: rows row0 .. row0+63 of `base` (clamped to [0, rmax]) -> LDS at dst.  A wave instruction moves
+// one [64][64] bf16 image: rows row0 .. row0+63 of a matrix (clamped to [0, rmax]) -> LDS at dst.  A wave instruction moves
 // 8 rows (lane -> row lane>>3, slot lane&7); wave w carries row groups w and w+4; the swizzle is applied to the source chunk.
-__device__ __forceinline__ void issue_img(char* dst, const bf16_t* base, long ld, int row0, int rmax, int w, int lane) {
+// The per-lane source pointers for row0 = 0 are formed once; a tile whose rows are all in range adds one wave-uniform offset.
+struct ImgSrc {
+  const bf16_t* p[2];
+  long ld;
+  int rmax;
+};
+__device__ __forceinline__ ImgSrc img_src(const bf16_t* base, long ld, int rmax, int w, int lane) {
+  ImgSrc s;
+  s.ld = ld;
+  s.rmax = rmax;
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int grp = w + 4 * n;
-    const int r = grp * 8 + (lane >> 3);
-    const int ch = (lane & 7) ^ swz(r);
-    const int g = min(max(row0 + r, 0), rmax);
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + (long)g * ld + ch * 8), (lptr_t)(dst + grp * 1024), 16, 0, 0);
+    const int r = (w + 4 * n) * 8 + (lane >> 3);
+    s.p[n] = base + (long)r * ld + (((lane & 7) ^ swz(r)) << 3);
+  }
+  return s;
+}
+__device__ __forceinline__ void issue_img(char* dst, const ImgSrc& s, int row0, int w, int lane) {
+  if (row0 >= 0 && row0 + 63 <= s.rmax) {  // wave-uniform
+    const long off = (long)row0 * s.ld;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      __builtin_amdgcn_global_load_lds((gptr_t)(s.p[n] + off), (lptr_t)(dst + (w + 4 * n) * 1024), 16, 0, 0);
+  } else {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int r = (w + 4 * n) * 8 + (lane >> 3);
+      const int g = min(max(row0 + r, 0), s.rmax);
+      __builtin_amdgcn_global_load_lds((gptr_t)(s.p[n] + (long)(g - r) * s.ld), (lptr_t)(dst + (w + 4 * n) * 1024), 16, 0, 0);
+    }
   }
 }
 
@@ -191,21 +227,32 @@ __device__ __forceinline__ void issue_img(char* dst, const bf16_t* base, long ld
 // S^T[j][i] += BD^T[15 - i_w + j][i_w] through the wave's LDS buffer.
 __device__ __forceinline__ void add_band(f32x4_t (&acc_s)[4], const bf16x8_t (&qv)[2], const char* blk_lo, const char* blk_hi,
                                          float* bd, const LaneK& L) {
-#pragma unroll
-  for (int ct = 0; ct < 5; ++ct) {
+  // software pipeline over the five band tiles: the table fragments of tile ct+1 are read while tile ct is on the MFMA pipe,
+  // and the skew reads of key tile jt = ct-1 (they need band tiles ct-1 and ct) follow the stores of tile ct directly.  LDS
+  // serves a wavefront's instructions in order, so the cross-lane store -> load hand-off needs no wait; the compiler keeps
+  // the order because stores and loads go to the same array through index expressions it cannot tell apart.
+  bf16x8_t pf[2][2];
+  auto frag = [&](int ct, bf16x8_t (&f)[2]) {
     const int q = ct - L.w + 3;  // wave-uniform, 0..7
     const char* p = ((q >> 2) ? blk_hi : blk_lo) + (q & 3) * 2048;
-    f32x4_t t = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f[0] = ldf(p + L.offk[0]);
+    f[1] = ldf(p + L.offk[1]);
+  };
+  frag(0, pf[0]);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) t = mfma32(ldf(p + L.offk[ks]), qv[ks], t);
+  for (int ct = 0; ct < 5; ++ct) {
+    if (ct + 1 < 5) frag(ct + 1, pf[(ct + 1) & 1]);
+    f32x4_t t = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    t = mfma32(pf[ct & 1][0], qv[0], t);
+    t = mfma32(pf[ct & 1][1], qv[1], t);
 #pragma unroll
     for (int r = 0; r < 4; ++r) bd[L.bd_w + (ct * 16 + r) * BDP] = t[r];
+    if (ct >= 1) {
+      const int jt = ct - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_s[jt][r] += bd[L.bd_r + (jt * 16 + r) * BDP];
+    }
   }
-  wave_lds_sync();
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc_s[jt][r] += bd[L.bd_r + (jt * 16 + r) * BDP];
 }
 
 // keep decision of element (jt, r) from the lane's 16-bit piece: all-ones / zero mask
@@ -271,10 +318,15 @@ __global__ __launch_bounds__(256, 2) void rp_fwd_kernel(const FlashFwdArgs a) {
   const bf16_t* Vb = a.v + (long)b * T * a.ldkv + h * DH;
   const bf16_t* PPb = a.pp + h * DH;
   const int R = 2 * T - 1;
+  const ImgSrc srcK = img_src(Kb, a.ldkv, T - 1, w, lane), srcV = img_src(Vb, a.ldkv, T - 1, w, lane);
+  const ImgSrc srcP = img_src(PPb, a.ldpp, R - 1, w, lane);
   const int pbase = (T - 1) - (i0 + TQ - 1);  // first table row of positional block 0
   float* bd = reinterpret_cast<float*>(lds + BNC_OFF + w * BNC);
-  const uint16_t* bitp = DROP ? a.bits + (((long)z * nkt) * (nkt * 64) + i) * 4 + g4 : nullptr;
-  const long bit_step = (long)nkt * 64 * 4;
+  // the lane's 16-bit piece is read inside its aligned 32-bit word (pieces g4 and g4^1): a 16-bit load is widened with an AND
+  // that hipcc places right behind the prefetch, together with a wait for everything in flight
+  const uint32_t* bitp = DROP ? reinterpret_cast<const uint32_t*>(a.bits) + (((long)z * nkt) * (nkt * 64) + i) * 2 + (g4 >> 1) : nullptr;
+  const long bit_step = (long)nkt * 64 * 2;
+  const int ksh = (g4 & 1) * 16;
 
   f32x4_t acc_o[4];
 #pragma unroll
@@ -283,10 +335,10 @@ __global__ __launch_bounds__(256, 2) void rp_fwd_kernel(const FlashFwdArgs a) {
   uint32_t piece = 0, piece_next = 0;
 
   if (nt > 0) {
-    issue_img(lds, Kb, a.ldkv, 0, T - 1, w, lane);
-    issue_img(lds + IMG, Vb, a.ldkv, 0, T - 1, w, lane);
-    issue_img(lds + PP_OFF, PPb, a.ldpp, pbase, R - 1, w, lane);
-    issue_img(lds + PP_OFF + IMG, PPb, a.ldpp, pbase + 64, R - 1, w, lane);
+    issue_img(lds, srcK, 0, w, lane);
+    issue_img(lds + IMG, srcV, 0, w, lane);
+    issue_img(lds + PP_OFF, srcP, pbase, w, lane);
+    issue_img(lds + PP_OFF + IMG, srcP, pbase + 64, w, lane);
     if (DROP) piece_next = bitp[0];
   }
   int slot_lo = 0;  // ring slot of positional block t
@@ -296,13 +348,17 @@ __global__ __launch_bounds__(256, 2) void rp_fwd_kernel(const FlashFwdArgs a) {
     __builtin_amdgcn_s_barrier();  // tile t is in LDS (every wave's part); everyone is done with tile t-1
     const int slot_hi = slot_lo == 2 ? 0 : slot_lo + 1;
     const int slot_nx = slot_hi == 2 ? 0 : slot_hi + 1;
-    if (DROP) piece = piece_next;
+    if (DROP) {
+      piece = piece_next;
+      asm volatile("" : "+v"(piece));  // pin the copy (and the compiler's wait for the load) HERE, ahead of the next tile's prefetch
+    }
     if (t + 1 < nt) {
-      char* st = lds + ((t + 1) & 1) * 2 * IMG;
-      issue_img(st, Kb, a.ldkv, j0 + TK, T - 1, w, lane);
-      issue_img(st + IMG, Vb, a.ldkv, j0 + TK, T - 1, w, lane);
-      issue_img(lds + PP_OFF + slot_nx * IMG, PPb, a.ldpp, pbase + 64 * (t + 2), R - 1, w, lane);
+      // register-destination loads first: a later wait for one of them is then `vmcnt(6)`, not a wait for the prefetch
       if (DROP) piece_next = bitp[(long)(t + 1) * bit_step];
+      char* st = lds + ((t + 1) & 1) * 2 * IMG;
+      issue_img(st, srcK, j0 + TK, w, lane);
+      issue_img(st + IMG, srcV, j0 + TK, w, lane);
+      issue_img(lds + PP_OFF + slot_nx * IMG, srcP, pbase + 64 * (t + 2), w, lane);
     }
     const char* sK = lds + (t & 1) * 2 * IMG;
     const char* sV = sK + IMG;
@@ -311,10 +367,20 @@ __global__ __launch_bounds__(256, 2) void rp_fwd_kernel(const FlashFwdArgs a) {
     f32x4_t acc_s[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc_s[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    {  // fragments of key tile jt+1 are read while tile jt is on the MFMA pipe
+      bf16x8_t fr[2][2];
+      fr[0][0] = ldf(sK + L.offk[0]);
+      fr[0][1] = ldf(sK + L.offk[1]);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) acc_s[jt] = mfma32(ldf(sK + jt * 2048 + L.offk[ks]), qu[ks], acc_s[jt]);
+      for (int jt = 0; jt < 4; ++jt) {
+        if (jt + 1 < 4) {
+          fr[(jt + 1) & 1][0] = ldf(sK + (jt + 1) * 2048 + L.offk[0]);
+          fr[(jt + 1) & 1][1] = ldf(sK + (jt + 1) * 2048 + L.offk[1]);
+        }
+        acc_s[jt] = mfma32(fr[jt & 1][0], qu[0], acc_s[jt]);
+        acc_s[jt] = mfma32(fr[jt & 1][1], qu[1], acc_s[jt]);
+      }
+    }
     add_band(acc_s, qv, lds + PP_OFF + slot_lo * IMG, lds + PP_OFF + slot_hi * IMG, bd, L);
 
     if (j0 + TK > kl) {  // the tile that contains the sentence end
@@ -340,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void rp_fwd_kernel(const FlashFwdArgs a) {
       for (int r = 0; r < 4; ++r) {
         const float p = fexp2(fmaf(acc_s[jt][r], LOG2E, -msc));
         psum += p;
-        acc_s[jt][r] = DROP ? fand(p, keep_mask(piece, jt * 4 + r)) : p;  // 1/(1-p) is applied once at the end
+        acc_s[jt][r] = DROP ? fand(p, keep_mask(piece, ksh + jt * 4 + r)) : p;  // 1/(1-p) is applied once at the end
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -386,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void rp_fwd_kernel(const FlashFwdArgs a) {
 // Inputs: acc_s = content logits (S^T), acc_dp = dO . V^T (dPd^T), both already on MFMA; the positional band is added here.
 template <bool DROP, bool WANT_PD>
 __device__ __forceinline__ void softmax_bwd_tile(f32x4_t (&acc_s)[4], const f32x4_t (&acc_dp)[4], bf16x4_t (&dsb)[4], bf16x4_t (&pdb)[4],
-                                                 float lse2, float Di, float inv_keep, uint32_t piece, int jrel_end, int g4) {
+                                                 float lse2, float Di, float inv_keep, uint32_t piece, int ksh, int jrel_end, int g4) {
   // jrel_end = kl - j0: keys at or past it are padding (>= 64: nothing to mask)
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
@@ -397,7 +463,7 @@ __device__ __forceinline__ void softmax_bwd_tile(f32x4_t (&acc_s)[4], const f32x
       if (jrel_end < 64 && jt * 16 + g4 * 4 + r >= jrel_end) p = 0.f;
       float dp = acc_dp[jt][r];
       if (DROP) {
-        const uint32_t m = keep_mask(piece, jt * 4 + r);
+        const uint32_t m = keep_mask(piece, ksh + jt * 4 + r);
         dp = fand(dp * inv_keep, m);
         if (WANT_PD) pd[r] = fand(p * inv_keep, m);
       } else if (WANT_PD) {
@@ -462,11 +528,16 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
   const bf16_t* Vb = a.v + (long)b * T * a.ldkv + h * DH;
   const bf16_t* PPb = a.pp + h * DH;
   const int R = 2 * T - 1;
+  const ImgSrc srcK = img_src(Kb, a.ldkv, T - 1, w, lane), srcV = img_src(Vb, a.ldkv, T - 1, w, lane);
+  const ImgSrc srcP = img_src(PPb, a.ldpp, R - 1, w, lane);
   const int pbase = (T - 1) - (i0 + TQ - 1);
   float* bd = reinterpret_cast<float*>(lds + BNC_OFF + w * BNC);
   bf16_t* ob = reinterpret_cast<bf16_t*>(bd);  // un-skew buffer [16 rows][OBP], aliases the skew buffer (dead by then)
-  const uint16_t* bitp = DROP ? a.bits + (((long)z * nkt) * (nkt * 64) + i) * 4 + g4 : nullptr;
-  const long bit_step = (long)nkt * 64 * 4;
+  // the lane's 16-bit piece is read inside its aligned 32-bit word (pieces g4 and g4^1): a 16-bit load is widened with an AND
+  // that hipcc places right behind the prefetch, together with a wait for everything in flight
+  const uint32_t* bitp = DROP ? reinterpret_cast<const uint32_t*>(a.bits) + (((long)z * nkt) * (nkt * 64) + i) * 2 + (g4 >> 1) : nullptr;
+  const long bit_step = (long)nkt * 64 * 2;
+  const int ksh = (g4 & 1) * 16;
   // un-skewed band of row li covers positions c' in [15-li, 78-li] of the wave's 80; what else the buffer holds is stale
   uint2 mlo, mhi;  // AND masks for the B-operand pieces c' = 4*g4 + e and c' = 64 + 4*g4 + e
   {
@@ -484,29 +555,55 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
 
   uint32_t piece = 0, piece_next = 0;
   int jcov = 0;
+  uint32_t dbd_pk[8];
+  int dbd_j0 = -1;  // key tile whose dBD rows wait in dbd_pk
+  auto store_dbd = [&]() {
+    const int j = dbd_j0 + lane;
+    if (dbd_j0 >= 0 && j < T) {
+      const int row_w = i0 + 16 * w, nrow = T - row_w;  // wavefront-uniform
+      bf16_t* dp = a.dBD + ((long)z * T + row_w) * a.ld_bd + (T - 1 - row_w) + j;
+      if (nrow >= 16) {
+#pragma unroll
+        for (int iw = 0; iw < 16; ++iw) dp[(long)iw * (a.ld_bd - 1)] = (bf16_t)(dbd_pk[iw >> 1] >> (16 * (iw & 1)));
+      } else {
+#pragma unroll
+        for (int iw = 0; iw < 16; ++iw)
+          if (iw < nrow) dp[(long)iw * (a.ld_bd - 1)] = (bf16_t)(dbd_pk[iw >> 1] >> (16 * (iw & 1)));
+      }
+    }
+  };
   if (nt > 0) {
-    issue_img(lds, Kb, a.ldkv, 0, T - 1, w, lane);
-    issue_img(lds + IMG, Vb, a.ldkv, 0, T - 1, w, lane);
-    issue_img(lds + PP_OFF, PPb, a.ldpp, pbase, R - 1, w, lane);
-    issue_img(lds + PP_OFF + IMG, PPb, a.ldpp, pbase + 64, R - 1, w, lane);
+    issue_img(lds, srcK, 0, w, lane);
+    issue_img(lds + IMG, srcV, 0, w, lane);
+    issue_img(lds + PP_OFF, srcP, pbase, w, lane);
+    issue_img(lds + PP_OFF + IMG, srcP, pbase + 64, w, lane);
     if (DROP) piece_next = bitp[0];
   }
   int slot_lo = 0;
+  PROF_DECL
   for (int t = 0; t < nt; ++t) {
     const int j0 = t * TK;
     jcov = min(T, j0 + TK);
+    PROF_MARK(9)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    PROF_MARK(0)
+    store_dbd();  // previous tile's rows
     const int slot_hi = slot_lo == 2 ? 0 : slot_lo + 1;
     const int slot_nx = slot_hi == 2 ? 0 : slot_hi + 1;
-    if (DROP) piece = piece_next;
-    if (t + 1 < nt) {
-      char* st = lds + ((t + 1) & 1) * 2 * IMG;
-      issue_img(st, Kb, a.ldkv, j0 + TK, T - 1, w, lane);
-      issue_img(st + IMG, Vb, a.ldkv, j0 + TK, T - 1, w, lane);
-      issue_img(lds + PP_OFF + slot_nx * IMG, PPb, a.ldpp, pbase + 64 * (t + 2), R - 1, w, lane);
-      if (DROP) piece_next = bitp[(long)(t + 1) * bit_step];
+    if (DROP) {
+      piece = piece_next;
+      asm volatile("" : "+v"(piece));  // pin the copy (and the compiler's wait for the load) HERE, ahead of the next tile's prefetch
     }
+    if (t + 1 < nt) {
+      // register-destination loads first: a later wait for one of them is then `vmcnt(6)`, not a wait for the prefetch
+      if (DROP) piece_next = bitp[(long)(t + 1) * bit_step];
+      char* st = lds + ((t + 1) & 1) * 2 * IMG;
+      issue_img(st, srcK, j0 + TK, w, lane);
+      issue_img(st + IMG, srcV, j0 + TK, w, lane);
+      issue_img(lds + PP_OFF + slot_nx * IMG, srcP, pbase + 64 * (t + 2), w, lane);
+    }
+    PROF_MARK(1)
     const char* sK = lds + (t & 1) * 2 * IMG;
     const char* sV = sK + IMG;
     const char* blk_lo = lds + PP_OFF + slot_lo * IMG;
@@ -518,16 +615,30 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
       acc_s[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       acc_dp[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    {  // fragments of key tile jt+1 are read while tile jt is on the MFMA pipe
+      bf16x8_t fr[2][4];
+      auto frag = [&](int jt, bf16x8_t (&f)[4]) {
+        f[0] = ldf(sK + jt * 2048 + L.offk[0]);
+        f[1] = ldf(sK + jt * 2048 + L.offk[1]);
+        f[2] = ldf(sV + jt * 2048 + L.offk[0]);
+        f[3] = ldf(sV + jt * 2048 + L.offk[1]);
+      };
+      frag(0, fr[0]);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        acc_s[jt] = mfma32(ldf(sK + jt * 2048 + L.offk[ks]), qu[ks], acc_s[jt]);
-        acc_dp[jt] = mfma32(ldf(sV + jt * 2048 + L.offk[ks]), dO[ks], acc_dp[jt]);
+        if (jt + 1 < 4) frag(jt + 1, fr[(jt + 1) & 1]);
+        acc_s[jt] = mfma32(fr[jt & 1][0], qu[0], acc_s[jt]);
+        acc_dp[jt] = mfma32(fr[jt & 1][2], dO[0], acc_dp[jt]);
+        acc_s[jt] = mfma32(fr[jt & 1][1], qu[1], acc_s[jt]);
+        acc_dp[jt] = mfma32(fr[jt & 1][3], dO[1], acc_dp[jt]);
       }
+    }
+    PROF_MARK(2)
     add_band(acc_s, qv, blk_lo, blk_hi, bd, L);
+    PROF_MARK(3)
     bf16x4_t dsb[4], pdb[4];
-    softmax_bwd_tile<DROP, false>(acc_s, acc_dp, dsb, pdb, lse2, Di, a.inv_keep, piece, kl - j0, g4);
+    softmax_bwd_tile<DROP, false>(acc_s, acc_dp, dsb, pdb, lse2, Di, a.inv_keep, piece, ksh, kl - j0, g4);
+    PROF_MARK(4)
 
     // t1^T[d][i] += sum_j K^T[d][j] dS^T[j][i]
     if (!(a.dbg & 4)) {
@@ -540,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
         for (int dt = 0; dt < 4; ++dt) acc_t1[dt] = mfma32(kf[dt * 2 + kb], db, acc_t1[dt]);
       }
     }
+    PROF_MARK(5)
     // un-skew: dBD^T[15 - i_w + j][i_w] = dS^T[j][i_w], kept as bf16 [row i_w][position c']
     wave_lds_sync();  // the skew reads above are done before the same bytes are rewritten
 #pragma unroll
@@ -582,29 +694,23 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
       for (int dt = 0; dt < 4; ++dt)
         acc_t2[dt] = mfma16(__builtin_bit_cast(bf16x4_t, pf[16 + dt]), __builtin_bit_cast(bf16x4_t, bl), acc_t2[dt]);
     }
-    // dBD[z][row][T-1-row + j] = dS[row][j]: one 128-byte row segment per store instruction
+    PROF_MARK(6)
+    // dBD[z][row][T-1-row + j] = dS[row][j]: lane = key, one 128-byte row segment per store instruction.  The values are only
+    // READ here (two rows per register); the stores go out at the top of the next tile, ahead of its prefetch: vmcnt counts
+    // loads and stores in one queue, so stores issued behind the prefetch would make the next `s_waitcnt vmcnt(0)` wait for
+    // their write acknowledgements (11 % of the kernel in the s_memtime profile)
     if (!(a.dbg & 1)) {
-      const int j = j0 + lane;
-      if (j < T) {
-        const int row_w = i0 + 16 * w, nrow = T - row_w;  // wavefront-uniform
-        bf16_t* dp = a.dBD + ((long)z * T + row_w) * a.ld_bd + (T - 1 - row_w) + j;
-        const bf16_t* bs = ob + 15 + lane;
-        bf16_t val[16];  // all 16 LDS reads first: a predicated read-store chain waits for LDS once per row
+      const bf16_t* bs = ob + 15 + lane;
 #pragma unroll
-        for (int iw = 0; iw < 16; ++iw) val[iw] = bs[iw * (OBP - 1)];
-        if (nrow >= 16) {
-#pragma unroll
-          for (int iw = 0; iw < 16; ++iw) dp[(long)iw * (a.ld_bd - 1)] = val[iw];
-        } else {
-#pragma unroll
-          for (int iw = 0; iw < 16; ++iw)
-            if (iw < nrow) dp[(long)iw * (a.ld_bd - 1)] = val[iw];
-        }
-      }
+      for (int k = 0; k < 8; ++k)
+        dbd_pk[k] = (uint32_t)bs[(2 * k) * (OBP - 1)] | ((uint32_t)bs[(2 * k + 1) * (OBP - 1)] << 16);
+      dbd_j0 = j0;
     }
     wave_lds_sync();  // un-skew buffer reads done before the next tile's skew writes
     slot_lo = slot_hi;
+    PROF_MARK(7)
   }
+  store_dbd();  // last tile
 
   if (i < T) {
     bf16_t* o1 = a.t1 + ((long)b * T + i) * a.ldt + h * DH;
@@ -620,6 +726,7 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
       *reinterpret_cast<uint2*>(o2 + dt * 16 + g4 * 4) = pk;
     }
   }
+  PROF_MARK(9)
   if (!a.dbd_prezeroed) {
     // columns of dBD no (row, key) pair of this workgroup wrote: r < T-1-row or r >= T-1-row + jcov
     for (int iw = 0; iw < 16; ++iw) {
@@ -639,12 +746,14 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
       }
     }
   }
+  PROF_MARK(8)
+  PROF_DUMP(0)
 }
 
 // ---- KV kernel: workgroup = (z, 64 keys), loop over query tiles -> dK, dV
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES_KV];
   const LaneK L = lane_consts();
   const int lane = L.lane, w = L.w, li = L.li, g4 = L.g4;
   const int vid = xcd_remap(blockIdx.x, gridDim.x);
@@ -679,6 +788,8 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
   const bf16_t* dOb = a.dout + (long)b * T * a.ldo + h * DH;
   const bf16_t* PPb = a.pp + h * DH;
   const int R = 2 * T - 1;
+  const ImgSrc srcQ = img_src(Qub, a.ldq, T - 1, w, lane), srcG = img_src(dOb, a.ldo, T - 1, w, lane);
+  const ImgSrc srcP = img_src(PPb, a.ldpp, R - 1, w, lane);
   const int pb0 = (T - 1) - (TQ - 1) + j0;  // first table row of positional block 0 (query tile 0); block u starts 64 u lower
   float* bd = reinterpret_cast<float*>(lds + BNC_OFF + w * BNC);
   char* exw = lds + BNC_OFF + w * BNC;  // this wave's rows of the exchange tiles: dS at +0, Pd at +2048 ([16][64] bf16 each)
@@ -693,46 +804,63 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
     trk[hh] = rr * 128 + ((((li & 3) >> 1) ^ swz(rr)) << 4) + (li & 1) * 8;
   }
   const char* exbase = lds + BNC_OFF;
-  const uint16_t* bitp = DROP ? a.bits + (((long)z * nkt + kt) * (nkt * 64) + 16 * w + li) * 4 + g4 : nullptr;
+  const uint32_t* bitp = DROP ? reinterpret_cast<const uint32_t*>(a.bits) + (((long)z * nkt + kt) * (nkt * 64) + 16 * w + li) * 2 + (g4 >> 1) : nullptr;
+  const int ksh = (g4 & 1) * 16;
 
   bf16x8_t qv[2], qv_next[2];
-  float lse_next = 0.f, D_next = 0.f;
   uint32_t piece_next = 0;
-  auto row_loads = [&](int i0) {  // per-lane operands of query tile i0: row i = i0 + 16 w + li
+  // per-lane operands of query tile i0 (row i = i0 + 16 w + li): Qv fragments and the keep piece into registers; lse and D of
+  // the tile's 64 rows into LDS (4-byte global_load_lds by waves 0 / 1): as register loads their destinations got paired
+  // with live values in packed-math operands and the compiler waited for everything in flight in mid-tile
+  auto row_loads = [&](int i0, int stage) {
     const int i = i0 + 16 * w + li;
     const int ic = min(i, T - 1);
     const long o = (long)ic * a.ldq + g4 * 8;
     qv_next[0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Qvb + o));
     qv_next[1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Qvb + o + 32));
-    lse_next = a.lse[(long)z * T + ic];  // raw: any arithmetic on it here would wait for the load (and the prefetch behind it)
-    D_next = a.D[(long)z * T + ic];
-    if (DROP) piece_next = bitp[(long)i0 * 4];
+    if (DROP) piece_next = bitp[(long)i0 * 2];
+    if (w < 2) {
+      const float* src = (w == 0 ? a.lse : a.D) + (long)z * T + min(i0 + lane, T - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + AUX_OFF + stage * 512 + w * 256), 4, 0, 0);
+    }
   };
   if (nq > 0) {
-    issue_img(lds, Qub, a.ldq, 0, T - 1, w, lane);
-    issue_img(lds + IMG, dOb, a.ldo, 0, T - 1, w, lane);
-    issue_img(lds + PP_OFF, PPb, a.ldpp, pb0, R - 1, w, lane);               // block 0 -> slot 0
-    issue_img(lds + PP_OFF + 2 * IMG, PPb, a.ldpp, pb0 + 64, R - 1, w, lane);  // block -1 -> slot 2
-    row_loads(0);
+    issue_img(lds, srcQ, 0, w, lane);
+    issue_img(lds + IMG, srcG, 0, w, lane);
+    issue_img(lds + PP_OFF, srcP, pb0, w, lane);               // block 0 -> slot 0
+    issue_img(lds + PP_OFF + 2 * IMG, srcP, pb0 + 64, w, lane);  // block -1 -> slot 2
+    row_loads(0, 0);
   }
   int slot_lo = 0;  // ring slot of block `it` (window rows 0..63); block it-1 (rows 64..127) sits one slot below
+  PROF_DECL
   for (int it = 0; it < nq; ++it) {
     const int i0 = it * TQ;
+    PROF_MARK(9)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile `it` landed; everyone is done with the exchange tiles of tile it-1
+    PROF_MARK(0)
     const int slot_hi = slot_lo == 0 ? 2 : slot_lo - 1;
     const int slot_nx = slot_lo == 2 ? 0 : slot_lo + 1;
     qv[0] = qv_next[0];
     qv[1] = qv_next[1];
-    const float lse2 = (i0 + 16 * w + li < T) ? lse_next * LOG2E : INFINITY, Di = D_next;
-    const uint32_t piece = piece_next;
-    if (it + 1 < nq) {
-      char* st = lds + ((it + 1) & 1) * 2 * IMG;
-      issue_img(st, Qub, a.ldq, i0 + TQ, T - 1, w, lane);
-      issue_img(st + IMG, dOb, a.ldo, i0 + TQ, T - 1, w, lane);
-      issue_img(lds + PP_OFF + slot_nx * IMG, PPb, a.ldpp, pb0 - 64 * (it + 1), R - 1, w, lane);
-      row_loads(i0 + TQ);
+    const float* aux = reinterpret_cast<const float*>(lds + AUX_OFF + (it & 1) * 512) + 16 * w + li;
+    const float lse_raw = aux[0], Di = aux[64];
+    uint32_t piece = piece_next;
+    {  // pin the copies (and the compiler's waits for these loads) HERE, ahead of the next tile's prefetch
+      uint4 q0 = __builtin_bit_cast(uint4, qv[0]), q1 = __builtin_bit_cast(uint4, qv[1]);
+      asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(piece));
+      qv[0] = __builtin_bit_cast(bf16x8_t, q0);
+      qv[1] = __builtin_bit_cast(bf16x8_t, q1);
     }
+    const float lse2 = (i0 + 16 * w + li < T) ? lse_raw * LOG2E : INFINITY;
+    if (it + 1 < nq) {
+      row_loads(i0 + TQ, (it + 1) & 1);  // register-destination loads first: a later wait for one of them is `vmcnt(6)`, not a wait for the prefetch
+      char* st = lds + ((it + 1) & 1) * 2 * IMG;
+      issue_img(st, srcQ, i0 + TQ, w, lane);
+      issue_img(st + IMG, srcG, i0 + TQ, w, lane);
+      issue_img(lds + PP_OFF + slot_nx * IMG, srcP, pb0 - 64 * (it + 1), w, lane);
+    }
+    PROF_MARK(1)
     const char* sQ = lds + (it & 1) * 2 * IMG;
     const char* sG = sQ + IMG;
     // phase 1: this wave's 16 rows x 64 keys
@@ -755,17 +883,22 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
         acc_s[jt] = mfma32(kf[jt][ks], qu[ks], acc_s[jt]);
         acc_dp[jt] = mfma32(vf[jt][ks], dO[ks], acc_dp[jt]);
       }
+    PROF_MARK(2)
     add_band(acc_s, qv, lds + PP_OFF + slot_lo * IMG, lds + PP_OFF + slot_hi * IMG, bd, L);
+    PROF_MARK(3)
     bf16x4_t dsb[4], pdb[4];
-    softmax_bwd_tile<DROP, true>(acc_s, acc_dp, dsb, pdb, lse2, Di, a.inv_keep, piece, kl - j0, g4);
+    softmax_bwd_tile<DROP, true>(acc_s, acc_dp, dsb, pdb, lse2, Di, a.inv_keep, piece, ksh, kl - j0, g4);
+    PROF_MARK(4)
     wave_lds_sync();  // skew reads done before the exchange tiles overwrite the buffer
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       *reinterpret_cast<bf16x4_t*>(exw + (exo ^ (jt << 5))) = dsb[jt];
       *reinterpret_cast<bf16x4_t*>(exw + 2048 + (exo ^ (jt << 5))) = pdb[jt];
     }
+    PROF_MARK(5)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // not __syncthreads(): that also waits for the prefetch (vmcnt)
     __builtin_amdgcn_s_barrier();
+    PROF_MARK(6)
     // phase 2: this wave's 16 keys, all 64 rows:  dK^T[d][j] += sum_i Qu^T[d][i] dS[i][j],  dV^T[d][j] += sum_i dO^T[d][i] Pd[i][j]
     {
       const uint32_t eb = lds_addr(exbase);
@@ -792,6 +925,7 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
       }
     }
     slot_lo = slot_nx;
+    PROF_MARK(7)
   }
   const int j = j0 + 16 * w + li;
   if (j < T) {
@@ -808,6 +942,8 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_kv_kernel(const FlashBwdArgs a)
       *reinterpret_cast<uint2*>(ov + dt * 16 + g4 * 4) = pk;
     }
   }
+  PROF_MARK(8)
+  PROF_DUMP(1)
 }
 
 }  // namespace
@@ -841,6 +977,16 @@ int ea_rp_bwd(const FlashBwdArgs& a_in, hipStream_t stream) {
   static const int dbg = [] { const char* e = getenv("EA_RP_DBG"); return e ? atoi(e) : 0; }();
   FlashBwdArgs a = a_in;
   a.dbg = dbg;
+  a.prof = nullptr;
+#ifdef RP_PROF
+  static unsigned long long* prof_buf = nullptr;
+  static const int prof_on = [] { const char* e = getenv("EA_RP_PROF"); return e && e[0] == '1' ? 1 : 0; }();
+  if (prof_on) {
+    if (!prof_buf) hipMalloc(&prof_buf, 2 * 8192 * 10 * sizeof(unsigned long long));
+    hipMemsetAsync(prof_buf, 0, 2 * 8192 * 10 * sizeof(unsigned long long), stream);
+    a.prof = prof_buf;
+  }
+#endif
   const dim3 gq((unsigned)(a.nq * a.H * a.B)), gk((unsigned)(a.nk * a.H * a.B));
   if (a.thr) {
     hipLaunchKernelGGL(rp_bwd_q_kernel<true>, gq, dim3(256), 0, stream, a);
@@ -849,5 +995,32 @@ int ea_rp_bwd(const FlashBwdArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL(rp_bwd_q_kernel<false>, gq, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(rp_bwd_kv_kernel<false>, gk, dim3(256), 0, stream, a);
   }
+#ifdef RP_PROF
+  if (a.prof) {
+    static int calls = 0;
+    if (++calls == 20) {  // one report, from a warm call
+      hipStreamSynchronize(stream);
+      static unsigned long long h[2 * 8192 * 10];
+      hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost);
+      const char* names[2] = {"Q ", "KV"};
+      const int nw[2] = {(int)gq.x * 4, (int)gk.x * 4};
+      for (int k = 0; k < 2; ++k) {
+        double sum[10] = {0};
+        int cnt = 0;
+        for (int wv = 0; wv < nw[k] && wv < 8192; ++wv) {
+          const unsigned long long* o = h + ((long)k * 8192 + wv) * 10;
+          unsigned long long tot = 0;
+          for (int p = 0; p < 10; ++p) tot += o[p];
+          if (!tot) continue;
+          ++cnt;
+          for (int p = 0; p < 10; ++p) sum[p] += (double)o[p];
+        }
+        fprintf(stderr, "[rp prof] %s waves %d, mean s_memtime ticks per wave by phase:", names[k], cnt);
+        for (int p = 0; p < 10; ++p) fprintf(stderr, " p%d=%.0f", p, cnt ? sum[p] / cnt : 0.0);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+#endif
   return EA_CHECK_LAUNCH();
 }

@@ -13,6 +13,7 @@ H = 8
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 308
 ragged = len(sys.argv) > 3
+PREZERO = 2 if os.environ.get("FLASH_PREZERO") == "1" else 0  # bit 1 of `causal`: dBD outside the band is already zero
 C = H * 64
 g = torch.Generator(device=DEV).manual_seed(0)
 qu = torch.randn(B * T, C, device=DEV, generator=g).to(torch.bfloat16) * 0.3
@@ -42,7 +43,7 @@ def run(p, relpos, n=30):
         e[1].record()
         res = K.flash_attention_bwd(qu, qv if relpos else None, qkv[:, C:], qkv[:, 2 * C:], pp if relpos else None, klen, out, dout, lse,
                                     dqkv[:, C:], dqkv[:, 2 * C:], H, B, T, T, C, 3 * C, 3 * C, ldpp=C, scaling=0.125, drop_p=p, drop_seed=1,
-                                    keep_bits=bits)
+                                    keep_bits=bits, causal=PREZERO)
         e[2].record()
         torch.cuda.synchronize()
         if it >= 5:
