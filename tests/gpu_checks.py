@@ -2457,3 +2457,56 @@ model:
     return {"files": sorted(os.listdir(save_dir)), "valid_loss": [l["loss"] for l in valid_lines], "valid_ppl": [l.get("ppl") for l in valid_lines],
             "num_updates": tr.num_updates, "lr": [l["lr"] for l in lines if l["kind"] == "epoch_end"],
             "train_loss": [l["loss"] for l in lines if l["kind"] == "train_inner"], "setup": [l for l in lines if l["kind"] == "setup"]}
+
+
+# ------------------------------------------------------------------ training-trajectory parity (+n2)
+def check_training_trajectory(steps=None):
+    """tests/trajectory.py: `steps` Adam updates of the dh-64 Conformer-CTC on the learnable synthetic task, HIP path vs the
+    oracle (fp32 and bf16-emulating), same initial weights, batches and order; held-out greedy token error rate at the end."""
+    from espresso_amd import functional as F
+    from espresso_amd.optim.adam import FlatAdam
+    from espresso_amd.optim.flat import FlatParams
+    from tests import trajectory as TR
+
+    g, sd, _, _ = load_fixture(TR.FIXTURE)
+    d, H, ffn = _fixture_shape(TR.FIXTURE)
+    steps = steps or TR.STEPS
+    train, heldout = TR.make_batches(TR.TRAIN_BATCHES, seed=0), TR.make_batches(TR.HELDOUT_BATCHES, seed=1)
+    model = build_tiny_model("conformer", embed_dim=d, heads=H, ffn=ffn).to(DEV)
+    load_ref_state(model, sd)
+    flat = FlatParams(model, DEV)
+    opt = FlatAdam(flat, lr=TR.LR, betas=TR.BETAS, eps=TR.EPS)
+    model.train()
+    losses = []
+    for step in range(steps):
+        feats, lens, tg = (t.to(DEV) for t in train[step % len(train)])
+        F.begin_step(feats.device)
+        out = model(feats, lens)
+        B, Tp = out["encoder_padding_mask"][0].shape
+        nll, _ = F.ctc_loss(out["_logits_bt"][0], tg.to(torch.int32).contiguous(), out["src_lengths"][0].to(torch.int32),
+                            (tg != 1).sum(-1).to(torch.int32), B, Tp, blank=0)
+        loss = nll.sum()
+        loss.backward()
+        F.end_step()
+        opt.clip_and_step(pre_scale=1.0, max_norm=TR.CLIP, denom_dev=torch.full((1,), float(B), device=DEV))
+        losses.append(float(loss.detach()) / B)
+    model.eval()
+    err = tot = 0
+    with torch.no_grad():
+        for feats, lens, tg in heldout:
+            out = model(feats.to(DEV), lens.to(DEV))
+            e, t_ = TR.greedy_errors(out["encoder_out"][0].float().cpu(), out["src_lengths"][0].cpu(), tg)
+            err += e
+            tot += t_
+    torch.cuda.synchronize()
+    res = {"hip_losses": losses, "hip_ter": err / tot, "tokens": tot}
+    for tag, emu in (("fp32", False), ("emu", True)):
+        ol, oe, ot = TR.train_oracle(sd, train, heldout, steps, emu)
+        rel = [abs(a - b) / max(b, 1e-3) for a, b in zip(losses, ol)]
+        half = lambda ls: next((i for i, x in enumerate(ls) if x < 0.5 * ls[5]), len(ls))
+        res[tag] = {"losses": ol, "ter": oe / ot, "max_rel_first24": max(rel[:24]), "max_rel_all": max(rel),
+                    "auc_rel": abs(sum(losses) - sum(ol)) / sum(ol),
+                    "half_plateau_step": half(ol), "hip_half_plateau_step": half(losses),
+                    "final_loss": sum(ol[-10:]) / 10}
+    res["hip_final_loss"] = sum(losses[-10:]) / 10
+    return res

@@ -1,0 +1,112 @@
+"""Training-trajectory parity on a learnable synthetic task (stand-in for the north-star's "WER within 0.1 abs": there is no
+corpus and no trained checkpoint in this environment).
+
+Task: every target token owns a random 80-dimensional template; an utterance is its token sequence with each template held
+for 8 frames plus Gaussian noise (sigma 2.5: neighbouring tokens are confusable), ragged lengths, no repeated neighbours.  A 2-layer
+Conformer-CTC (the weights of tests/golden/ref_conformer_ctc_dh64.npz: head dim 64, i.e. the fused rel-pos attention kernels)
+is trained from the same initial weights on the same batches in the same order, dropout 0, by
+  * the HIP path: model forward / CTC / backward through the C ABI, FlatAdam (csrc/optim.hip), and
+  * the oracle: oracle/torch_ref.py (fp32, or rounding to bf16 at the HIP storage points) + a restatement of
+    fairseq/utils.py:347-397 (clip) and fairseq/optim/adam.py:215-240 (Adam).
+Compared: the loss of every update and the greedy-CTC token error rate on held-out batches at the end.
+TEST INFRASTRUCTURE ONLY."""
+import math
+
+import numpy as np
+import torch
+
+FIXTURE = "ref_conformer_ctc_dh64"
+HEADS = 2
+LR, BETAS, EPS, CLIP = 2e-3, (0.9, 0.98), 1e-8, 2.0
+STEPS, TRAIN_BATCHES, HELDOUT_BATCHES = 80, 30, 12  # 30 x 8 utterances, each batch seen 2-3 times; 675 held-out tokens
+
+
+def make_batches(nbatch, seed, B=8, ntok=36, hold=8, noise=2.5, tmpl_seed=1234):
+    tmpl = np.random.default_rng(tmpl_seed).standard_normal((40, 80)).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(nbatch):
+        U = rng.integers(5, 10, size=B)
+        feats = np.zeros((B, int(U.max()) * hold, 80), np.float32)
+        tg = np.ones((B, int(U.max())), np.int64)  # pad = 1
+        lens = np.zeros(B, np.int64)
+        for b in range(B):
+            toks, prev = [], -1
+            for _u in range(U[b]):
+                t = int(rng.integers(4, 4 + ntok))
+                while t == prev:
+                    t = int(rng.integers(4, 4 + ntok))
+                toks.append(t)
+                prev = t
+            tg[b, : U[b]] = toks
+            lens[b] = U[b] * hold
+            feats[b, : lens[b]] = np.repeat(tmpl[toks], hold, axis=0) + noise * rng.standard_normal((U[b] * hold, 80)).astype(np.float32)
+        order = np.argsort(-lens, kind="stable")
+        out.append((torch.from_numpy(feats[order]), torch.from_numpy(lens[order]), torch.from_numpy(tg[order])))
+    return out
+
+
+def greedy_errors(logits_tbv, out_len, targets):
+    """(edit-distance errors, reference tokens) of the greedy CTC hypotheses (collapse repeats, drop blank 0)"""
+    err = tot = 0
+    for b in range(targets.shape[0]):
+        ids = logits_tbv[: int(out_len[b]), b].argmax(-1).tolist()
+        hyp, prev = [], -1
+        for i in ids:
+            if i != prev and i != 0:
+                hyp.append(i)
+            prev = i
+        ref = [int(t) for t in targets[b] if t != 1]
+        d = list(range(len(ref) + 1))
+        for i, h in enumerate(hyp, 1):
+            nd = [i]
+            for j, r in enumerate(ref, 1):
+                nd.append(min(d[j] + 1, nd[j - 1] + 1, d[j - 1] + (h != r)))
+            d = nd
+        err += d[-1]
+        tot += len(ref)
+    return err, tot
+
+
+def train_oracle(sd, train, heldout, steps, emulate):
+    from oracle import torch_ref
+
+    P = {k: (v.clone().float().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("_float_tensor")
+             and k != "version" else v.clone()) for k, v in sd.items()}
+    names = [k for k, v in P.items() if v.requires_grad]
+    m = {k: torch.zeros_like(P[k]) for k in names}
+    v2 = {k: torch.zeros_like(P[k]) for k in names}
+    losses = []
+    for step in range(steps):
+        feats, lens, tg = train[step % len(train)]
+        upd = {}
+        with torch_ref.bf16_emulation(emulate, flash=True):
+            lt, ol = torch_ref.encoder(feats, lens, P, H=HEADS, layer_type="conformer", training=True, update=upd)
+            loss = torch_ref.ctc_loss_sum(lt, tg, ol, (tg != 1).sum(-1))
+        for k in names:
+            P[k].grad = None
+        loss.backward()
+        B = feats.shape[0]
+        with torch.no_grad():
+            gn = math.sqrt(sum(float((P[k].grad / B).pow(2).sum()) for k in names if P[k].grad is not None))
+            coef = min(1.0, CLIP / (gn + 1e-6)) / B
+            t = step + 1
+            ss = LR * math.sqrt(1 - BETAS[1] ** t) / (1 - BETAS[0] ** t)
+            for k in names:
+                if P[k].grad is None:
+                    continue
+                gk = P[k].grad * coef
+                m[k].mul_(BETAS[0]).add_(gk, alpha=1 - BETAS[0])
+                v2[k].mul_(BETAS[1]).addcmul_(gk, gk, value=1 - BETAS[1])
+                P[k].addcdiv_(m[k], v2[k].sqrt().add_(EPS), value=-ss)
+            for k, val in upd.items():
+                P[k] = val
+        losses.append(float(loss.detach()) / B)
+    err = tot = 0
+    with torch.no_grad(), torch_ref.bf16_emulation(emulate, flash=True):
+        for feats, lens, tg in heldout:
+            lt, ol = torch_ref.encoder(feats, lens, P, H=HEADS, layer_type="conformer", training=False)
+            e, t_ = greedy_errors(lt, ol, tg)
+            err += e
+            tot += t_
+    return losses, err, tot
