@@ -20,6 +20,8 @@ from typing import Optional
 
 import collections
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -550,6 +552,13 @@ def set_conv_implicit_gemm(on: bool):
     _CONV_IGEMM = bool(on)
 
 
+def _conv_igemm_ok(cin, cout, sy, sx):
+    """A layer takes the implicit-GEMM kernels only if ALL THREE of them accept it (forward: Cin % 64, Cout in {64, 128}; data
+    gradient: Cin in {64, 128}, Cout % 64, strides <= 2; weight gradient: both % 64): forward and backward must agree on the
+    lowering, and anything else (the reference accepts arbitrary channel lists) takes im2col + GEMM + col2im."""
+    return _CONV_IGEMM and cin in (64, 128) and cout in (64, 128) and sy in (1, 2) and sx in (1, 2)
+
+
 # ------------------------------------------------------------------------------------------------
 class _ConvSubsample(torch.autograd.Function):
     """ConvBNReLU stack of espresso/modules/speech_convolutions.py:78-102 in channels-last form.
@@ -578,7 +587,7 @@ class _ConvSubsample(torch.autograd.Function):
                 assert w.shape[1] == 1 and tuple(w.shape[2:]) == (3, 3)
                 Zi = K.conv1_fwd(X, w.detach().reshape(Co, 9).contiguous(), b, B, Tc, Fc, Co, sy, sx, stats)
                 col, w16 = None, None
-            elif _CONV_IGEMM and Cc % 64 == 0 and Co in (64, 128):
+            elif _conv_igemm_ok(Cc, Co, sy, sx):
                 # implicit GEMM (csrc/conv_igemm.hip): the tap tiles are gathered straight from the channels-last activation,
                 # BatchNorm sums come out of the epilogue; what backward needs is the layer's INPUT, not a 9x larger im2col matrix
                 w16 = K.cast_f32_to_bf16(w.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Cc).contiguous())
@@ -606,7 +615,7 @@ class _ConvSubsample(torch.autograd.Function):
         ctx.save_for_backward(X, row_zero, *[t for t in saved if t is not None])
         ctx.layout = [[t is not None for t in saved[6 * i: 6 * i + 6]] for i in range(L)]
         ctx.cfg = (B, cfgs, p_drop, seed, training, [tuple(p.shape) for p in params[0::4]])
-        ctx.igemm = [i > 0 and _CONV_IGEMM and cfgs[i][2] % 64 == 0 and cfgs[i][5] in (64, 128) for i in range(L)]
+        ctx.igemm = [i > 0 and _conv_igemm_ok(cfgs[i][2], cfgs[i][5], cfgs[i][6], cfgs[i][7]) for i in range(L)]
         ctx.weights = [params[4 * i] for i in range(L)]
         return out
 

@@ -2510,3 +2510,38 @@ def check_training_trajectory(steps=None):
                     "final_loss": sum(ol[-10:]) / 10}
     res["hip_final_loss"] = sum(losses[-10:]) / 10
     return res
+
+
+def check_conv_subsample_nondefault_channels(channels=(64, 192, 128), strides=(1, 2, 2)):
+    """A sub-sampler whose middle layers the implicit-GEMM kernels accept only partly (192 input channels: forward yes, data
+    gradient no): forward and backward must pick the same lowering per layer.  Compared with the same stack on the im2col
+    lowering (implicit GEMM switched off) — same bf16 operands, so outputs agree to one bf16 step and gradients to 2e-2."""
+    from espresso_amd import functional as F
+    from espresso_amd.modules.speech_convolutions import ConvBNReLU
+
+    torch.manual_seed(0)
+    m = ConvBNReLU(list(channels), [3] * len(channels), list(strides)).to(DEV)
+    m.train()
+    x = torch.randn(3, 41, 20, device=DEV)
+    lens = torch.tensor([41, 33, 17], device=DEV)
+    R = None
+    out = {}
+    for tag, on in (("igemm", True), ("im2col", False)):
+        F.set_conv_implicit_gemm(on)
+        try:
+            for p in m.parameters():
+                p.grad = None
+            y, _, _, _ = m(x, lens)
+            if R is None:
+                R = torch.randn_like(y.float())
+            (y.float() * R).sum().backward()
+            torch.cuda.synchronize()
+            out[tag] = (y.float().cpu(), {n: p.grad.float().cpu().clone() for n, p in m.named_parameters()})
+        finally:
+            F.set_conv_implicit_gemm(True)
+    ya, ga = out["igemm"]
+    yb, gb = out["im2col"]
+    worst = max(((float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-6)), n) for n in ga
+                 if not (n.startswith("convolutions.") and n.endswith(".bias"))), key=lambda t: t[0])
+    return {"out_rel": float((ya - yb).abs().max() / yb.abs().max()), "worst_grad": (worst[1], worst[0]),
+            "finite": bool(all(torch.isfinite(g).all() for g in ga.values()))}

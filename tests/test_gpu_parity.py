@@ -594,3 +594,11 @@ def test_training_trajectory_vs_oracle():
         assert abs(r["hip_final_loss"] - r[tag]["final_loss"]) < 0.3, r
         assert abs(r["hip_ter"] - r[tag]["ter"]) <= 0.01, r
     assert r["hip_final_loss"] < 1.5 and r["hip_ter"] < 0.05, r
+
+
+def test_conv_subsample_nondefault_channel_list():
+    """a channel list the implicit-GEMM data-gradient kernel refuses (Cin = 192) used to pass the forward gate and
+    fail with -2 in backward; the gate is now the intersection of the three kernels' constraints"""
+    r = G.check_conv_subsample_nondefault_channels()
+    print(r)
+    assert r["finite"] and r["out_rel"] < 2e-2 and r["worst_grad"][1] < 3e-2, r
