@@ -36,9 +36,12 @@ __device__ __forceinline__ void grid_wait(unsigned* counter, unsigned target) {
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 26)) {  // seconds: something is badly wrong; do not hang the device
+      if (++spins > (1u << 26)) {  // seconds: a workgroup of this grid never became resident; do not hang the device
         counter[1] = 1;
-        break;
+        __threadfence_system();
+        // and do not carry on with stale h / dgates either (the results would be silently wrong): abort the launch, the
+        // host sees hipErrorLaunchFailure at its next synchronisation
+        __builtin_trap();
       }
     }
   }
@@ -286,9 +289,19 @@ int launch_bwd(const LstmSeqBwdArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// 1 when the persistent kernels cover this shape (H a multiple of 32 among the instantiated sizes, at most 64 batch rows)
+// 1 when the persistent kernels cover this shape (H a multiple of 32 among the instantiated sizes, at most 64 batch rows) AND the
+// device can hold the whole grid at once: the grid barrier needs every workgroup resident (up to H / 16 = 64 workgroups of 256
+// threads; one per CU is always placeable on an otherwise idle device, so the CU count of the current device is the gate —
+// small or partitioned devices fall back to the per-step path)
 extern "C" int ea_lstm_seq_supported(int B, int H) {
   if (B < 1 || B > 64) return 0;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  if (cus < H / 16) return 0;
   switch (H) {
     case 256: case 320: case 512: case 640: case 768: case 800: case 1024: return 1;
     default: return 0;

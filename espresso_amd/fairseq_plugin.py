@@ -55,8 +55,8 @@ def adapt_cfg(cfg, target_cls, ref_defaults=None, where=""):
                 kw[k] = adapt_cfg(v, sub, ref_defaults.get(k) if isinstance(ref_defaults.get(k), dict) else None, f"{where}{k}.")
             else:
                 kw[k] = v
-        elif v is not None and not (isinstance(v, str) and v.startswith("${")) and k in ref_defaults and ref_defaults[k] != v:
-            bad[k] = v
+        elif v is not None and not (isinstance(v, str) and v.startswith("${")) and (k not in ref_defaults or ref_defaults[k] != v):
+            bad[k] = v  # (also a key the reference's own dataclass does not have: nothing says it is safe to ignore)
     if bad:
         raise NotImplementedError(f"espresso_amd does not implement {where}{sorted(bad)} (non-default values {bad})")
     return target_cls(**kw)
@@ -165,7 +165,29 @@ def install():
             return self.inner.build_generator(models, args, seq_gen_cls=seq_gen_cls, extra_gen_cls_kwargs=extra_gen_cls_kwargs)
 
         # -- fairseq_task.py:490 --
+        def _check_ddp(self, model):
+            """The native layer runtime accumulates weight gradients straight into p.grad (its autograd backward returns None for
+            parameters), so torch's DistributedDataParallel reducer (`--ddp-backend pytorch_ddp`, fairseq's default) never sees
+            them as ready: replicas would diverge silently.  fairseq's legacy_ddp / no_c10d wrappers all-reduce the .grad
+            buffers after backward (fairseq/distributed/legacy_distributed_data_parallel.py:76-165) and are fine."""
+            import torch.distributed as dist
+
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+                return
+            from torch.nn.parallel import DistributedDataParallel as TorchDDP
+
+            m, depth = model, 0
+            while m is not None and depth < 8:
+                if isinstance(m, TorchDDP):
+                    raise NotImplementedError(
+                        "espresso_amd under fairseq's trainer needs --ddp-backend legacy_ddp (or no_c10d): the pytorch_ddp reducer "
+                        "does not see the gradients the HIP layer runtime writes into p.grad")
+                m, depth = getattr(m, "module", None), depth + 1
+
         def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
+            if not getattr(self, "_ddp_checked", False):
+                self._check_ddp(model)
+                self._ddp_checked = True
             model.train()
             if hasattr(model, "set_num_updates"):
                 model.set_num_updates(update_num)

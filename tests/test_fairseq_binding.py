@@ -113,3 +113,44 @@ def test_other_registered_names_resolve(fairseq_env):
         assert e["criterions"].CRITERION_REGISTRY[name] is cls and hasattr(cls, "build_criterion"), name
     for arch in registry.ARCH_MODEL_REGISTRY:
         assert arch in e["models"].ARCH_MODEL_REGISTRY and arch in e["models"].ARCH_CONFIG_REGISTRY, arch
+
+
+def test_adapt_cfg_refuses_what_it_would_drop(fairseq_env):
+    """a non-default value of a field the HIP path does not implement raises — including a key the reference's own
+    dataclass does not have (nothing says it is safe to ignore); None / `${...}` interpolations / reference defaults pass"""
+    import dataclasses
+
+    from espresso_amd.fairseq_plugin import adapt_cfg
+
+    @dataclasses.dataclass
+    class Ours:
+        a: int = 1
+
+    ref = {"a": 1, "b": 2.0, "c": None}
+    assert adapt_cfg({"a": 5, "b": 2.0, "c": None, "d": None, "e": "${task.x}"}, Ours, ref).a == 5
+    with pytest.raises(NotImplementedError):
+        adapt_cfg({"a": 5, "b": 3.0}, Ours, ref)          # non-default value of an unimplemented reference field
+    with pytest.raises(NotImplementedError):
+        adapt_cfg({"a": 5, "zzz": 1}, Ours, ref)          # a key nobody knows
+
+
+def test_task_adapter_refuses_pytorch_ddp(fairseq_env, monkeypatch):
+    """the native layer runtime writes weight gradients into p.grad behind autograd's back; torch's DDP reducer never
+    sees them, so the adapter refuses a model wrapped in it when world_size > 1 (legacy_ddp / no_c10d all-reduce .grad buffers)"""
+    import torch
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as TorchDDP
+
+    adapter = fairseq_env["adapter"]
+    task = adapter.__new__(adapter)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
+    wrapped = TorchDDP.__new__(TorchDDP)   # no process group needed: only the type is inspected
+
+    class Proxy:  # fairseq's ModuleProxyWrapper keeps the wrapped module in `.module`
+        def __init__(self, m):
+            self.module = m
+
+    with pytest.raises(NotImplementedError, match="legacy_ddp"):
+        task._check_ddp(Proxy(wrapped))
+    task._check_ddp(Proxy(torch.nn.Linear(2, 2)))  # anything else passes
