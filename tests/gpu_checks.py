@@ -1943,7 +1943,7 @@ def check_fullsize_encoder_batch_independence(seed=0):
     return {"abs": worst, "scale": scale, "frames_checked": checked, "finite": bool(torch.isfinite(lo.float()).all())}
 
 
-def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0):
+def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0, layers=1, lens=(400, 333, 250, 120), tl=(9, 7, 5, 3)):
     """Config-3 LAYER dimensions (embed 512, 8 heads of 64, FFN 2048, depthwise kernel 31, conv front-end 64-64-128-128) in a
     one-layer model with random weights, HIP vs the pinned oracle (oracle/torch_ref.py) on the same weights and inputs: eval
     logits, train-mode CTC loss and every gradient, against the fp32 restatement (north_star's bf16 tolerance) and against its
@@ -1958,7 +1958,7 @@ def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0):
     V, H = 200, 8
     cfg = SpeechTransformerConfig()
     e = cfg.encoder
-    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, 1, H
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, layers, H
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, layer_type
     e.conv_channels = "[64, 64, 128, 128]"
     cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
@@ -1972,12 +1972,11 @@ def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0):
     sd = {k[len("encoder."):]: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("encoder.")}
     model = model.to(DEV)
     g = torch.Generator().manual_seed(seed + 1)
-    lens = [400, 333, 250, 120]
+    lens, tl = list(lens), list(tl)
     feats = torch.zeros(len(lens), max(lens), 80)
     for b, n in enumerate(lens):
         feats[b, :n] = torch.randn(n, 80, generator=g)
     lengths = torch.tensor(lens)
-    tl = [9, 7, 5, 3]
     tgt = torch.full((len(lens), max(tl)), 1, dtype=torch.long)
     for b, n in enumerate(tl):
         tgt[b, :n] = torch.randint(4, V, (n,), generator=g)
@@ -2512,9 +2511,9 @@ def check_training_trajectory(steps=None):
     return res
 
 
-def check_conv_subsample_nondefault_channels(channels=(64, 192, 128), strides=(1, 2, 2)):
+def check_conv_subsample_nondefault_channels(channels=(64, 192, 128, 64), strides=(1, 2, 1, 2)):
     """A sub-sampler whose middle layers the implicit-GEMM kernels accept only partly (192 input channels: forward yes, data
-    gradient no): forward and backward must pick the same lowering per layer.  Compared with the same stack on the im2col
+    gradient no; the last layer, 128 -> 64, takes them): forward and backward must pick the same lowering per layer.  Compared with the same stack on the im2col
     lowering (implicit GEMM switched off) — same bf16 operands, so outputs agree to one bf16 step and gradients to 2e-2."""
     from espresso_amd import functional as F
     from espresso_amd.modules.speech_convolutions import ConvBNReLU
