@@ -358,13 +358,15 @@ def sinusoidal_abs_pe(num_embeddings, dim, padding_idx):
 
 
 def mha(q_in, kv_in, sd, p, H, key_padding_mask=None, causal=False):
-    """fairseq/modules/multihead_attention.py (no positional embedding): q_in (U,B,C), kv_in (S,B,C)."""
+    """fairseq/modules/multihead_attention.py (no positional embedding): q_in (U,B,C), kv_in (S,B,C).  Returns the out_proj
+    output BEFORE the residual add (the HIP epilogue adds the residual in fp32 and stores once)."""
     U, B, C = q_in.shape
     S = kv_in.shape[0]
     dh = C // H
-    q = F.linear(q_in, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * dh ** -0.5
-    k = F.linear(kv_in, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
-    v = F.linear(kv_in, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    q = _r(_lin(q_in, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]))
+    q = _r(q * dh ** -0.5)
+    k = _r(_lin(kv_in, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"]))
+    v = _r(_lin(kv_in, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"]))
     q = q.contiguous().view(U, B * H, dh).transpose(0, 1)
     k = k.contiguous().view(S, B * H, dh).transpose(0, 1)
     v = v.contiguous().view(S, B * H, dh).transpose(0, 1)
@@ -373,39 +375,45 @@ def mha(q_in, kv_in, sd, p, H, key_padding_mask=None, causal=False):
         w = w + torch.triu(torch.full((U, S), float("-inf")), 1).unsqueeze(0)
     if key_padding_mask is not None:
         w = w.view(B, H, U, S).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(B * H, U, S)
-    a = torch.bmm(torch.softmax(w.float(), -1), v).transpose(0, 1).contiguous().view(U, B, C)
-    return F.linear(a, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+    if _EMU["on"] and _EMU["flash"]:
+        pu = torch.exp(w.float() - w.float().max(dim=-1, keepdim=True).values)
+        a = torch.bmm(_r(pu), v) / pu.sum(-1, keepdim=True)
+    else:
+        a = torch.bmm(_r(torch.softmax(w.float(), -1)), v)
+    a = _r(a).transpose(0, 1).contiguous().view(U, B, C)
+    return _lin(a, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
 
 
 def decoder(prev_tokens, enc_out, enc_pad, sd, H, pad_idx, p="decoder.", activation="relu"):
     """espresso/models/transformer/speech_transformer_decoder.py + fairseq transformer_decoder.py:254-370 and
-    transformer_layer.py:384-529 (pre-LN, cross attention, no layerdrop, dropout 0).  Returns logits (B,U,V)."""
+    transformer_layer.py:384-529 (pre-LN, cross attention, no layerdrop, dropout 0).  Returns logits (B,U,V).
+    `_r` marks the tensors the HIP decoder stores in bf16 (csrc/engine.hip ea_decoder_layer_*): identity outside bf16_emulation."""
     B, U = prev_tokens.shape
     W = sd[p + "embed_tokens.weight"]
     C = W.shape[1]
     x = math.sqrt(C) * F.embedding(prev_tokens, W)
     mask = prev_tokens.ne(pad_idx).int()
     positions = (torch.cumsum(mask, 1) * mask).long() + pad_idx
-    x = x + sinusoidal_abs_pe(pad_idx + 1 + U, C, pad_idx)[positions]
+    x = _r(x + sinusoidal_abs_pe(pad_idx + 1 + U, C, pad_idx)[positions])
     if (p + "layernorm_embedding.weight") in sd:
         x = _ln(x, sd, p + "layernorm_embedding.")
     x = x.transpose(0, 1)
     i = 0
     while (p + f"layers.{i}.fc1.weight") in sd:
         lp = p + f"layers.{i}."
-        x = mha(_ln(x, sd, lp + "self_attn_layer_norm."), _ln(x, sd, lp + "self_attn_layer_norm."), sd, lp + "self_attn.", H,
-                causal=True) + x
+        y = _ln(x, sd, lp + "self_attn_layer_norm.")
+        x = _r(mha(y, y, sd, lp + "self_attn.", H, causal=True) + x)
         y = _ln(x, sd, lp + "encoder_attn_layer_norm.")
-        x = mha(y, enc_out, sd, lp + "encoder_attn.", H, key_padding_mask=enc_pad) + x
+        x = _r(mha(y, enc_out, sd, lp + "encoder_attn.", H, key_padding_mask=enc_pad) + x)
         y = _ln(x, sd, lp + "final_layer_norm.")
-        y = F.linear(y, sd[lp + "fc1.weight"], sd[lp + "fc1.bias"])
-        y = F.relu(y) if activation == "relu" else F.silu(y)
-        x = F.linear(y, sd[lp + "fc2.weight"], sd[lp + "fc2.bias"]) + x
+        y = _lin(y, sd[lp + "fc1.weight"], sd[lp + "fc1.bias"])
+        y = _r(F.relu(y) if activation == "relu" else F.silu(y))
+        x = _r(_lin(y, sd[lp + "fc2.weight"], sd[lp + "fc2.bias"]) + x)
         i += 1
     if (p + "layer_norm.weight") in sd:
         x = _ln(x, sd, p + "layer_norm.")
     x = x.transpose(0, 1)
-    return F.linear(x, sd[p + "output_projection.weight"])
+    return _r(_lin(x, sd[p + "output_projection.weight"]))
 
 
 def encdec(feats, lengths, prev_tokens, sd, H, pad_idx, training=False):

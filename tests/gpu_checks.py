@@ -713,6 +713,33 @@ def check_encdec_vs_reference(fixture="ref_transformer_encdec_tiny"):
         errs.append((float((p.grad.float().cpu() - r).abs().max() / (float(r.abs().max()) + 1e-12)), n))
     errs.sort(reverse=True)
     res["worst5"] = [(n, round(e, 4)) for e, n in errs[:5]]
+    # ---- the same training pass on the bf16-emulating oracle (rounds where the HIP path stores): tight gradient bounds ----
+    from oracle import torch_ref
+
+    d, H, _ = _fixture_shape(fixture)
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version"
+               and not k.endswith("_float_tensor") else v.clone()) for k, v in sd0.items()}
+    with torch_ref.bf16_emulation(True, flash=(d // H == 64)):
+        el = torch_ref.encdec(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"]), sde, H, 0, training=True)
+        eloss, enll = torch_ref.label_smoothed_nll(el.reshape(-1, el.shape[-1]), torch.from_numpy(g["target"]).reshape(-1), 0.1, 0)
+        eloss.backward()
+    res["emu_loss"] = float(eloss.detach())
+    res["train_logits_vs_emulation"] = float((lo.detach().float().cpu() - el.detach())[valid].abs().max())
+    errs_emu, l2_emu = [], []
+    for n, p in model.named_parameters():
+        if (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias")) or n.endswith("attn.k_proj.bias"):
+            continue
+        ge = sde[n].grad
+        errs_emu.append((float((p.grad.float().cpu() - ge).abs().max() / (float(ge.abs().max()) + 1e-12)), n))
+        l2_emu.append((float((p.grad.float().cpu() - ge).norm() / (float(ge.norm()) + 1e-12)), n))
+    errs_emu.sort(reverse=True)
+    l2_emu.sort(reverse=True)
+    res["worst_grad_vs_emulation"] = (errs_emu[0][1], errs_emu[0][0])
+    res["worst5_vs_emulation"] = [(n, round(e, 4)) for e, n in errs_emu[:5]]
+    res["median_grad_vs_emulation"] = errs_emu[len(errs_emu) // 2][0]
+    res["worst_l2_vs_emulation"] = (l2_emu[0][1], l2_emu[0][0])
+    res["median_l2_vs_emulation"] = l2_emu[len(l2_emu) // 2][0]
     return res
 
 

@@ -216,10 +216,22 @@ def test_encdec_label_smoothed_ce_vs_reference_fixture(fixture):
     assert abs(r["nll"] - r["ref_nll"]) / r["ref_nll"] < 1e-2, r
     assert r["eval_logits_abs_valid"] < 4e-2, r
     assert r["eval_greedy_agree"] > 0.9 and r["eval_greedy_agree_clear_margin"] == 1.0, r
-    # bf16 activations: gradients of the conv front-end (behind 2+2 attention stacks and four BatchNorms) are sums with
-    # heavy cancellation, so their error relative to the tensor maximum is the loosest; everything else is within 20 %.
+    # vs the reference's fp32 run (informational bound): gradients of the conv front-end (behind 2+2 attention stacks and four
+    # BatchNorms) are sums with heavy cancellation, so their error relative to the tensor maximum is the loosest
     for n, e in r["worst5"]:
         assert e < (0.5 if "pre_encoder" in n else 0.2), (n, e, r)
+    # vs the bf16-emulating oracle (rounds where the HIP path stores): loss 1e-3, logits two bf16 steps,
+    # every gradient within 8 % of its tensor's scale and 1.5 % in the median — except the ReLU FFN of the decoder's top
+    # layers (fc1 weight / bias and the LayerNorm in front): with 21 target positions a handful of pre-activations that sit
+    # within one bf16 step of zero decide a fifth of that gradient, and two bf16 realisations (HIP, emulation — and the
+    # emulation against the fp32 run: 18 %) each land differently.  Those tensors are held to 25 % element-wise and, like
+    # every other tensor, to 10 % in L2.
+    assert abs(r["loss"] - r["emu_loss"]) / r["emu_loss"] < 1e-3, r
+    assert r["train_logits_vs_emulation"] < 4e-2, r
+    kink = ("fc1.weight", "fc1.bias", "final_layer_norm.weight", "final_layer_norm.bias")
+    for n, e in r["worst5_vs_emulation"]:
+        assert e < (0.25 if n.startswith("decoder.") and n.endswith(kink) else 8e-2), (n, e, r)
+    assert r["median_grad_vs_emulation"] < 1.5e-2 and r["worst_l2_vs_emulation"][1] < 0.10 and r["median_l2_vs_emulation"] < 1.5e-2, r
 
 
 @pytest.mark.parametrize("fixture", ["ref_transformer_encdec_tiny", "ref_transformer_encdec_dh64"])

@@ -1,6 +1,7 @@
 """CPU tests that PIN the oracle: the restatements in oracle/ must reproduce what the reference's own
 modules produced (golden fixtures written by oracle/gen_golden.py from /root/reference)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -274,3 +275,50 @@ def test_trajectory_task_is_learnable_by_the_oracle():
     assert e32 / tot < 0.05, (e32, tot)
     assert max(abs(a - b) / b for a, b in zip(l32[:24], lem[:24])) < 1.5e-2
     assert abs(e32 - eem) / tot <= 0.01, (e32, eem, tot)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
+def test_encoder_restatement_matches_reference_at_8_heads(layer_type):
+    """The recipes' attention geometry — embed 512, EIGHT heads of 64 — against the reference's own encoder, live (the state
+    dict would make a 20 MB fixture, so nothing is stored: the reference is imported through oracle/ref_stubs exactly as
+    oracle/gen_golden.py does and run on seeded inputs here).  Closes the chain for H = 8: reference == oracle (this test, 1e-5)
+    and oracle == HIP path (the full-size -m gpu tests, same oracle functions).  The committed dh-64 fixtures have 2 heads."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gen_golden as GG
+
+    torch.manual_seed(7)
+    V, H = 40, 8
+    cfg = GG.ref_config(layer_type, d=512, heads=H, ffn=256, layers=2)
+    enc = GG.build_ref_encoder(cfg, V)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    feats = torch.randn(2, 150, 80)
+    lengths = torch.tensor([150, 97])
+    feats[1, 97:] = 0
+    tgt = torch.tensor([[5, 9, 11, 4, 30], [7, 8, 1, 1, 1]])
+    tl = (tgt != 1).sum(-1)
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    enc.eval()
+    with torch.no_grad():
+        ref_eval = enc(feats, lengths)["encoder_out"][0]
+    enc.train()
+    o = enc(feats, lengths)
+    lp = torch.log_softmax(o["encoder_out"][0].float(), -1)
+    flat = torch.cat([tgt[b, : int(tl[b])] for b in range(2)])
+    ref_loss = torch.nn.functional.ctc_loss(lp, flat, o["src_lengths"][0], tl, blank=0, reduction="sum", zero_infinity=True)
+    ref_loss.backward()
+    ref_grads = {n: p.grad.clone() for n, p in enc.named_parameters()}
+
+    lo, ol = torch_ref.encoder(feats, lengths, sd, H=H, layer_type=layer_type, training=False)
+    assert float((lo - ref_eval).abs().max()) < 1e-5
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version" else v.clone()) for k, v in sd.items()}
+    lt, ol = torch_ref.encoder(feats, lengths, sdo, H=H, layer_type=layer_type, training=True)
+    loss = torch_ref.ctc_loss_sum(lt, tgt, ol, tl)
+    assert float(loss) == pytest.approx(float(ref_loss), rel=1e-6)
+    loss.backward()
+    worst = max(float((sdo[n].grad - g).abs().max() / (g.abs().max() + 1e-12)) for n, g in ref_grads.items() if sdo[n].grad is not None)
+    assert worst < 2e-4, worst
+    assert sum(sdo[n].grad is not None for n in ref_grads) == len(ref_grads)
