@@ -428,17 +428,19 @@ def encdec(feats, lengths, prev_tokens, sd, H, pad_idx, training=False):
 # ------------------------------------------------------------------------------------------------ transducer
 def lstm_cell(x, h, c, sd, p):
     """torch.nn.LSTMCell (gate order i, f, g, o) as wrapped by fairseq/models/lstm.py:LSTMCell."""
-    g = F.linear(x, sd[p + "weight_ih"], sd[p + "bias_ih"]) + F.linear(h, sd[p + "weight_hh"], sd[p + "bias_hh"])
+    # HIP (csrc/lstm.hip, lstm_seq.hip): bf16 weights and bf16 x / h feed the MFMA products, gates and the cell state stay
+    # fp32, the hidden state is stored in bf16 (`_r`: identity outside bf16_emulation)
+    g = _lin(x, sd[p + "weight_ih"], sd[p + "bias_ih"]) + _lin(h, sd[p + "weight_hh"], sd[p + "bias_hh"])
     i, f, gg, o = g.chunk(4, dim=1)
     c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
-    return torch.sigmoid(o) * torch.tanh(c2), c2
+    return _r(torch.sigmoid(o) * torch.tanh(c2)), c2
 
 
 def lstm_predictor(prev_tokens, sd, p="decoder.", residual=False, pad_idx=1, state=None):
     """espresso/models/speech_lstm.py:766-919 with encoder_out None (no attention, no input feeding), dropout 0:
     the per-step loop over the LSTMCell stack.  Returns (features (B,U,H), final state [(h, c)] per layer)."""
     emb = sd[p + "embed_tokens.weight"]
-    x = F.embedding(prev_tokens, emb, padding_idx=pad_idx).transpose(0, 1)  # U x B x E
+    x = _r(F.embedding(prev_tokens, emb, padding_idx=pad_idx)).transpose(0, 1)  # U x B x E
     nl = 0
     while (p + f"layers.{nl}.weight_ih") in sd:
         nl += 1
@@ -454,28 +456,29 @@ def lstm_predictor(prev_tokens, sd, p="decoder.", residual=False, pad_idx=1, sta
             prev_in = inp
             inp = h
             if residual and i > 0:
-                inp = inp + prev_in
+                inp = _r(inp + prev_in)
             state[i] = (h, c)
         outs.append(inp)
     y = torch.stack(outs, 0).transpose(0, 1)
     if (p + "additional_fc.weight") in sd:
-        y = F.linear(y, sd[p + "additional_fc.weight"], sd[p + "additional_fc.bias"])
+        y = _r(_lin(y, sd[p + "additional_fc.weight"], sd[p + "additional_fc.bias"]))
     return y, state
 
 
 def transducer_joint(enc_btc, dec_buh, sd):
     """speech_transformer_transducer_base.py:276-299 with the weight-normed fc_out (weight = g * v / ||v||_row)."""
-    e = F.layer_norm(F.linear(enc_btc, sd["proj_encoder.weight"], sd["proj_encoder.bias"]), (sd["proj_encoder.weight"].shape[0],),
-                     sd["laynorm_proj_encoder.weight"], sd["laynorm_proj_encoder.bias"])
-    d = F.layer_norm(F.linear(dec_buh, sd["proj_decoder.weight"], sd["proj_decoder.bias"]), (sd["proj_decoder.weight"].shape[0],),
-                     sd["laynorm_proj_decoder.weight"], sd["laynorm_proj_decoder.bias"])
-    z = F.relu(e.unsqueeze(2) + d.unsqueeze(1))
+    # HIP: both projections, their LayerNorms, relu(E + D), the effective (weight-normed) matrix and the logits are stored in bf16
+    e = _r(F.layer_norm(_r(_lin(enc_btc, sd["proj_encoder.weight"], sd["proj_encoder.bias"])), (sd["proj_encoder.weight"].shape[0],),
+                        sd["laynorm_proj_encoder.weight"], sd["laynorm_proj_encoder.bias"]))
+    d = _r(F.layer_norm(_r(_lin(dec_buh, sd["proj_decoder.weight"], sd["proj_decoder.bias"])), (sd["proj_decoder.weight"].shape[0],),
+                        sd["laynorm_proj_decoder.weight"], sd["laynorm_proj_decoder.bias"]))
+    z = _r(F.relu(e.unsqueeze(2) + d.unsqueeze(1)))
     if "fc_out.weight_v" in sd:
         v = sd["fc_out.weight_v"]
         w = v * (sd["fc_out.weight_g"] / v.norm(dim=1, keepdim=True))
     else:
         w = sd["decoder.embed_tokens.weight"]
-    return F.linear(z, w, sd["fc_out.bias"])
+    return _r(_lin(z, w, sd["fc_out.bias"]))
 
 
 def transducer(feats, lengths, prev_tokens, sd, H, pad_idx=1, residual=False, training=False, update=None):

@@ -1295,6 +1295,32 @@ def check_transducer_vs_reference():
     res["worst_l2"] = max(l2.items(), key=lambda kv: kv[1])
     res["worst_scale"] = max(scale.items(), key=lambda kv: abs(kv[1] - 1.0))
     res["fc_out_max"] = max(mx[k] for k in mx if k.startswith("fc_out"))
+    # ---- the same pass on the bf16-emulating oracle (rounds where the HIP path stores) ----
+    from oracle import torch_ref
+
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version" else v.clone())
+           for k, v in sd0.items()}
+    with torch_ref.bf16_emulation(True, flash=False):
+        el, _ = torch_ref.transducer(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"]), sde, H=4, residual=True,
+                                     training=True)
+        (el * torch.from_numpy(g["R"])).sum().backward()
+    res["train_logits_vs_emulation"] = float((lo.detach().float().cpu() - el.detach())[valid].abs().max())
+    l2e, mxe = {}, {}
+    for n, p in model.named_parameters():
+        if (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias")) or n.endswith("attn.k_proj.bias"):
+            continue
+        ge = sde[n].grad
+        if ge is None:
+            continue
+        a = p.grad.float().cpu()
+        l2e[n] = float((a - ge).norm() / (ge.norm() + 1e-12))
+        mxe[n] = float((a - ge).abs().max() / (float(ge.abs().max()) + 1e-12))
+    res["n_vs_emulation"] = len(l2e)
+    res["worst_l2_vs_emulation"] = max(l2e.items(), key=lambda kv: kv[1])
+    res["median_l2_vs_emulation"] = sorted(l2e.values())[len(l2e) // 2]
+    res["worst_max_vs_emulation"] = max(mxe.items(), key=lambda kv: kv[1])
+    res["median_max_vs_emulation"] = sorted(mxe.values())[len(mxe) // 2]
     return res
 
 

@@ -364,6 +364,13 @@ def test_transducer_vs_reference_fixture():
     assert r["fc_out_max"] < 1e-2, r                       # output layer: no kink upstream of it
     assert abs(r["worst_scale"][1] - 1.0) < 7e-2, r        # every gradient has the right size and direction ...
     assert r["worst_l2"][1] < 0.22, r                      # ... up to the ReLU-kink noise of bf16 activations (see check)
+    # vs the bf16-emulating oracle (encoder, LSTM predictor and joint round where the HIP path stores): the logits agree to
+    # three bf16 steps; the gradients do NOT get tighter than against the fp32 run, because the noise is not rounding of the
+    # operands but derivative flips of relu(E + D) wherever E + D sits within one bf16 step of zero (~0.5 % of the lattice
+    # nodes, a different set in every bf16 realisation) — zero-mean, it reaches every upstream tensor alike (median 6.6 % in
+    # L2).  Bound: 13 % worst / 9 % median in L2 against the emulation.
+    assert r["train_logits_vs_emulation"] < 2e-2 * max(1.0, r["eval_logits_ref_max"]), r
+    assert r["n_vs_emulation"] > 90 and r["worst_l2_vs_emulation"][1] < 0.13 and r["median_l2_vs_emulation"] < 0.09, r
 
 
 def test_transducer_loss_end_to_end():
