@@ -49,6 +49,16 @@ def make_batches(utt_ids: List[str], n_samples: List[int], max_tokens: int, max_
     return batches
 
 
+def shard_batches(batches: List[List[int]], num_shards: int, shard_id: int) -> List[List[int]]:
+    """The batches of one decoding replica: espresso/speech_recognize.py:188-189 hands `num_shards = distributed_world_size`,
+    `shard_id = distributed_rank` to the batch iterator, whose ShardedIterator (fairseq/data/iterators.py:534-571) deals the
+    length-sorted batch list round-robin: replica i decodes batches i, i + n, i + 2n, ... (no collective: SURVEY 8(e) "replicas
+    only"); every replica scores its own shard."""
+    if not (0 <= shard_id < num_shards):
+        raise ValueError(f"--shard-id {shard_id} outside [0, --num-shards {num_shards})")
+    return batches[shard_id::num_shards]
+
+
 def recognize(task, model, generator, batches: Iterable[dict], dictionary, refs: Optional[Dict[str, str]] = None, out=sys.stdout,
               nbest: int = 1, quiet: bool = False, bpe_symbol=None):
     """The loop of espresso/speech_recognize.py:226-330.  `batches` yield dicts with `utt_ids`, `wav`, `wav_offsets`,
@@ -153,6 +163,10 @@ def get_parser():
     p.add_argument("--max-tokens", type=int, default=15000)
     p.add_argument("--batch-size", type=int, default=24)
     p.add_argument("--quiet", action="store_true")
+    p.add_argument("--num-shards", type=int, default=int(os.environ.get("WORLD_SIZE", "1")),
+                   help="decode replicas (default: WORLD_SIZE); each takes every num-shards-th batch")
+    p.add_argument("--shard-id", type=int, default=int(os.environ.get("RANK", "0")), help="this replica (default: RANK)")
+    p.add_argument("--device", default=None, help="default: cuda:LOCAL_RANK (cuda:0 outside a launcher)")
     return p
 
 
@@ -205,7 +219,9 @@ def main(argv=None):
     from .models.tensorized_lookahead_language_model import TensorizedLookaheadLanguageModel
     from .tasks.speech_recognition import SpeechRecognitionEspressoConfig, SpeechRecognitionEspressoTask
 
-    dev = torch.device("cuda:0")
+    dev = torch.device(args.device or "cuda:{}".format(int(os.environ.get("LOCAL_RANK", "0"))))
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
     paths = args.path.split(os.pathsep)  # `--path a.pt:b.pt` = an ensemble (fairseq utils.split_paths in speech_recognize.py:107)
     state = _load_file(paths[0])
     model_name, model_cfg = resolve_model_config(args.model, args.model_config, state)
@@ -249,7 +265,7 @@ def main(argv=None):
     waves = [read_wav(scp[u]) for u in utt_ids]
     refs = read_scp(args.text) if args.text else None
     task.build_frontend(dev)
-    batches = make_batches(utt_ids, [len(w) for w in waves], args.max_tokens, args.batch_size)
+    batches = shard_batches(make_batches(utt_ids, [len(w) for w in waves], args.max_tokens, args.batch_size), args.num_shards, args.shard_id)
     recognize(task, model, gen, (collate(b, utt_ids, waves, dev) for b in batches), task.target_dictionary, refs, out=sys.stdout,
               nbest=args.nbest, quiet=args.quiet)
 

@@ -229,6 +229,16 @@ def test_speech_recognize_host_pieces(tmp_path):
     a = sr.get_parser().parse_args(["--path", "m.pt", "--model-config", "m.yaml", "--dict", "d.txt", "--wav-scp", str(scp),
                                     "--lm-weight", "0.47", "--eos-factor", "1.5", "--beam", "60"])
     assert a.beam == 60 and a.lm_weight == 0.47 and a.eos_factor == 1.5 and a.search == "beam"
+    # sharded decoding (espresso/speech_recognize.py:188-189 -> ShardedIterator): replica i takes batches i, i+n, ...; together
+    # the replicas cover every batch exactly once; defaults come from the launcher's RANK / WORLD_SIZE
+    assert a.num_shards == 1 and a.shard_id == 0
+    bl = [[i] for i in range(7)]
+    parts = [sr.shard_batches(bl, 3, i) for i in range(3)]
+    assert parts[0] == [[0], [3], [6]] and parts[1] == [[1], [4]] and sorted(sum(sum(parts, []), [])) == list(range(7))
+    with pytest.raises(ValueError):
+        sr.shard_batches(bl, 2, 2)
+    a = sr.get_parser().parse_args(["--path", "m.pt", "--dict", "d.txt", "--wav-scp", str(scp), "--num-shards", "8", "--shard-id", "5"])
+    assert (a.num_shards, a.shard_id) == (8, 5)
 
 
 # ---- datasets / collater / task hooks (reference: tests/espresso/test_asr_dataset.py:102-189) -----------------------------
