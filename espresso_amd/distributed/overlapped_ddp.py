@@ -57,6 +57,7 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self._fired = [0] * len(flat.params)
         self.max_fired = 0
         self._hooks = {id(p): self._make_hook(p) for p in flat.params}
+        self._native_cache = {}
         if self.active:
             for p in flat.params:
                 p.register_post_accumulate_grad_hook(self._hooks[id(p)])
@@ -82,10 +83,31 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         return hook
 
     def _native_ready(self, params):
-        for p in params:
-            h = self._hooks.get(id(p))
-            if h is not None:
-                h(p)
+        """A native layer call reports ALL of its parameters at once (the same list object every step): the per-bucket
+        decrements of such a list are computed once and cached, so a layer costs a handful of dictionary operations instead of
+        ~30 hook calls (12 layers x 30 closures were 1.6 ms of host time per step next to a 16.5 ms GPU step)."""
+        if self.accumulate_grads:
+            return
+        ent = self._native_cache.get(id(params))
+        if ent is None or ent[0] is not params or len(params) != ent[3]:
+            counts, idx = {}, []
+            for p in params:
+                k = self._index.get(id(p))
+                if k is None:
+                    continue
+                idx.append(k)
+                for i in self._param_buckets[id(p)]:
+                    counts[i] = counts.get(i, 0) + 1
+            ent = (params, sorted(counts.items()), idx, len(params))
+            self._native_cache[id(params)] = ent
+        fired = self._fired
+        for k in ent[2]:
+            fired[k] += 1
+        pending = self._pending
+        for i, n in ent[1]:
+            pending[i] -= n
+            if pending[i] == 0:
+                self._launch(i)
 
     def _launch(self, i):
         if self._launched[i]:

@@ -27,3 +27,19 @@ for lo, hi in [(0, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 100), (100, 100
     print(f"  gaps {lo}-{hi} us: {m.sum() / nsteps:.0f} per step, {g[m].sum() / nsteps / 1e3:.2f} ms per step")
 for d, p, n in sorted(gaps, key=lambda x: -x[0])[:20]:
     print(f"{d / 1e3:9.1f} us  after {p[:70]:70s} before {n[:60]}")
+
+# kernels that run concurrently with the optimizer kernel (what shares HBM with the 2.7 GB Adam pass)
+ov = {}
+for a_s, a_e, _ in adam[-nsteps:]:
+    for s, e, n in rows:
+        if "adam_kernel" in n:
+            continue
+        o = min(e, a_e) - max(s, a_s)
+        if o > 0:
+            ov[n] = ov.get(n, 0) + o
+if ov:
+    print("kernels overlapping adam_kernel (us per step):")
+    for n, o in sorted(ov.items(), key=lambda kv: -kv[1])[:8]:
+        print(f"{o / nsteps / 1e3:9.1f} us  {n[:110]}")
+else:
+    print("no kernel overlaps adam_kernel")
