@@ -394,13 +394,15 @@ def main(argv=None):
         # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
         # command, tools/pmc_bench_traffic.sh; counters cannot be read from inside the process)
         traffic = None
-        tname = next((n for n in ("r02_gemm_traffic.json", "r01_gemm_traffic.json")
+        tname = next((n for n in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
                       if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n))), None)
         if tname:
             traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname))).get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel+gemm_glds_kernel+wgrad_group_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tname})",
+                    "traffic_source": "constant read from the committed rocprofv3 --pmc run named in traffic_unit (counters cannot be "
+                                      "read inside the process); achieved / frac / launches ARE measured live by this run",
                     "algorithmic_bytes_per_launch": alg.value / max(n, 1),
                     "traffic_over_algorithmic": (traffic / (alg.value / max(n, 1))) if traffic else None,
                     "launches_per_step": n / nrep, "avg_launch_us": tot_ms * 1e3 / max(n, 1),
@@ -409,6 +411,8 @@ def main(argv=None):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+        # the same CPU port at the recipe's batch size (24 utterances: the host cores are better fed); ~45 s of CPU work
+        cpu["at_recipe_batch"] = cpu_baseline(n_utts=24, steps=1)
     decode = None
     if rank == 0 and world == 1 and not args.no_decode:
         del trainer, model, criterion, samples  # the decode model gets the GPU to itself
