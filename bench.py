@@ -266,6 +266,8 @@ def main(argv=None):
     ap.add_argument("--no-decode", action="store_true", help="skip the config-5 decode block (beam-10 RTF)")
     ap.add_argument("--decode-utts", type=int, default=2864, help="utterances of the 2864-utterance decode workload (SURVEY 8d) to time; default: all of it")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BASELINE config 2 (Transformer enc-dec) and config 4 (Conformer-16 transducer) training blocks")
     ap.add_argument("--gemm-nt-bytes", type=int, default=None, help="diagnostic: non-temporal store threshold of the GEMM epilogue (0 = off)")
     ap.add_argument("--gemm-dump", default=None, help="write the per-launch GEMM records of the roofline replay to this file")
     ap.add_argument("--n-utts", type=int, default=20000)
@@ -420,6 +422,23 @@ def main(argv=None):
         decode, dmodel, ddict = decode_bench(device, n_utts=args.decode_utts)
         if not args.no_cpu_baseline:
             decode["cpu_baseline"] = decode_cpu_baseline(dmodel, ddict)
+        del dmodel
+    others = {}
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        # BASELINE configs 2 and 4 (same machinery, other model families): reported next to the headline, never part of `value`
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_encdec
+        import bench_transducer
+
+        if args.no_decode:
+            del trainer, model, criterion, samples
+        torch.cuda.empty_cache()
+        for key, mod in (("config2_encdec", bench_encdec), ("config4_transducer", bench_transducer)):
+            try:
+                others[key] = mod.run()
+            except Exception as e:  # a secondary block must not take the headline line down with it
+                others[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         value = audio / 3600.0 / elapsed
@@ -445,6 +464,7 @@ def main(argv=None):
             "roofline": roofline,
             "cpu_baseline": cpu,
             "decode": decode,
+            **others,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

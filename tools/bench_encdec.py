@@ -11,11 +11,9 @@ import torch
 VOCAB = 5003
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    args = ap.parse_args()
+def run(steps=10, warmup=3):
+    """-> the result dict (also what bench.py embeds as its `config2_encdec` block)"""
+    args = argparse.Namespace(steps=steps, warmup=warmup)
     dev = torch.device("cuda:0")
     import espresso_amd  # noqa: F401
     from espresso_amd.data import synthetic
@@ -93,13 +91,21 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     audio = sum(s["audio_seconds"] for s in samples[args.warmup:])
-    print(json.dumps({"metric": "audio-hours/sec training (LibriSpeech Transformer enc-dec, label-smoothed CE)", "value": audio / 3600 / el,
+    return ({"metric": "audio-hours/sec training (LibriSpeech Transformer enc-dec, label-smoothed CE)", "value": audio / 3600 / el,
                       "ms_per_step": el * 1e3 / args.steps, "first_visit_ms_per_step": first * 1e3 / args.steps,
                       "note": "value = second pass over the same batches (steady state); first_visit_ms_per_step = the pass in which every batch shape is new",
                       "steps": args.steps, "audio_seconds_per_step": audio / args.steps,
                       "loss_per_token": float(trainer._stats[1] / max(1.0, float(trainer._stats[2]))),
                       "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "dtype": "bf16", "data": "synthetic 16 kHz",
-                      "command": "python tools/bench_encdec.py"}))
+                      "command": "python tools/bench_encdec.py"})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    print(json.dumps(run(a.steps, a.warmup)))
 
 
 if __name__ == "__main__":

@@ -12,13 +12,9 @@ import torch
 VOCAB = 5004
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--max-product", type=int, default=590000)
-    ap.add_argument("--max-sentences", type=int, default=16)
-    args = ap.parse_args()
+def run(steps=8, warmup=3, max_product=590000, max_sentences=16):
+    """-> the result dict (also what bench.py embeds as its `config4_transducer` block)"""
+    args = argparse.Namespace(steps=steps, warmup=warmup, max_product=max_product, max_sentences=max_sentences)
     dev = torch.device("cuda:0")
     import espresso_amd  # noqa: F401
     from espresso_amd.data import synthetic
@@ -96,10 +92,20 @@ def main():
     el = time.perf_counter() - t0
     audio = sum(s["audio_seconds"] for s in samples[args.warmup:])
     nodes = [int(s["target"].shape[0]) for s in samples[args.warmup:]]
-    print(json.dumps({"metric": "audio-hours/sec training (LibriSpeech Conformer-16 transducer, RNN-T)", "value": audio / 3600 / el,
+    return ({"metric": "audio-hours/sec training (LibriSpeech Conformer-16 transducer, RNN-T)", "value": audio / 3600 / el,
                       "ms_per_step": el * 1e3 / args.steps, "steps": args.steps, "utts_per_step": float(np.mean(nodes)),
                       "audio_seconds_per_step": audio / args.steps, "loss_per_sentence": float(trainer._stats[1] / max(1.0, float(trainer._stats[0]))),
-                      "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "dtype": "bf16", "data": "synthetic 16 kHz"}))
+                      "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "dtype": "bf16", "data": "synthetic 16 kHz"})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--max-product", type=int, default=590000)
+    ap.add_argument("--max-sentences", type=int, default=16)
+    a = ap.parse_args()
+    print(json.dumps(run(a.steps, a.warmup, a.max_product, a.max_sentences)))
 
 
 if __name__ == "__main__":
