@@ -262,7 +262,7 @@ def test_incremental_decode_restatement_matches_full_forward(golden_dir):
 def test_trajectory_task_is_learnable_by_the_oracle():
     """tests/trajectory.py: the synthetic task the +n2 GPU test trains on is learned by the fp32 oracle (held-out greedy token
     error rate under 5 % after 80 updates, from a loss of ~ln(V) per token), and the fp32 and bf16-emulating oracle runs — same
-    arithmetic up to rounding — agree to 1.5 % per update over the first 24 updates (the plateau) and to 1 token per 100 at the end: the bounds
+    arithmetic up to rounding — agree to 1.5 % per update over the first 24 updates (the plateau) and to 2 tokens per 100 at the end: the bounds
     the GPU test holds the HIP path to are the ones two correct implementations meet"""
     from tests import trajectory as TR
     from tests.gpu_checks import load_fixture
@@ -274,7 +274,7 @@ def test_trajectory_task_is_learnable_by_the_oracle():
     assert l32[0] > 30 and sum(l32[-10:]) / 10 < 1.5, l32[::8]
     assert e32 / tot < 0.05, (e32, tot)
     assert max(abs(a - b) / b for a, b in zip(l32[:24], lem[:24])) < 1.5e-2
-    assert abs(e32 - eem) / tot <= 0.01, (e32, eem, tot)
+    assert abs(e32 - eem) / tot <= 0.02, (e32, eem, tot)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")

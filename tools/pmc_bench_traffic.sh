@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/pmc_traffic
 mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace -d $OUT/$C -o $C --output-format csv -- \
-    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-roofline > $OUT/$C.log 2>&1
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-other-configs --no-roofline > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
 python - <<PY

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-decode --no-roofline > $OUT.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-decode --no-other-configs --no-roofline > $OUT.log 2>&1
 DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
 echo "db=$DB"
 python $R/tools/rocpd_summary.py $DB $R/gpurun_out/${TAG}_summary.txt > /dev/null
