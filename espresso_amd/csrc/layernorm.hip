@@ -204,110 +204,75 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  // RW rows of a wavefront in flight at once (C <= 512: two): a row is one 16-byte load pair, two wavefront reductions and a
-  // store per lane — alone it is a chain of load / shuffle latencies with nothing to overlap (16.8 us for 6128 x 512)
-  constexpr int RW = MAXC8 == 1 ? 2 : 1;
-  for (int rowb = r0 + wave; rowb < r1; rowb += 4 * RW) {
-    float xh[RW][MAXC8][8], g[RW][MAXC8][8];
-    float s1[RW], s2[RW], rstd_r[RW];
-    uint4 ux[RW][MAXC8], ud[RW][MAXC8];
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const bool zero = row_zero && row_zero[row];
+    float xh[MAXC8][8], g[MAXC8][8];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < RW; ++q) {
-      const int row = min(rowb + 4 * q, M - 1);
+    for (int i = 0; i < MAXC8; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
+        const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * C + ch * 8);
+        const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
+        const uint32_t wd[4] = {ud.x, ud.y, ud.z, ud.w};
 #pragma unroll
-      for (int i = 0; i < MAXC8; ++i) {
-        const int ch = lane + 64 * i;
-        ux[q][i] = ud[q][i] = make_uint4(0, 0, 0, 0);
-        if (ch < nch) {
-          ux[q][i] = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
-          ud[q][i] = *reinterpret_cast<const uint4*>(dy + (long)row * C + ch * 8);
+        for (int e = 0; e < 8; ++e) {
+          const int c = ch * 8 + e;
+          const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
+          float dv = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
+          if (zero) dv = 0.f;
+          if (thr) dv *= ea_keep(seed, (uint64_t)row * C + c, thr, inv_keep);
+          const float h = (xv - mean) * rstd;
+          xh[i][e] = h;
+          dg[i][e] += dv * h;
+          db[i][e] += dv;
+          const float gv = dv * gam[i][e];
+          g[i][e] = gv;
+          s1 += gv;
+          s2 += gv * h;
         }
       }
     }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int q = 0; q < RW; ++q) {
-      const int row = rowb + 4 * q;
-      const bool live = row < r1;
-      const int rowc = min(row, M - 1);
-      const float mean = mean_in[rowc];
-      rstd_r[q] = rstd_in[rowc];
-      const bool zero = !live || (row_zero && row_zero[rowc]);
-      s1[q] = s2[q] = 0.f;
+    for (int i = 0; i < MAXC8; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[8];
 #pragma unroll
-      for (int i = 0; i < MAXC8; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-          const uint32_t wx[4] = {ux[q][i].x, ux[q][i].y, ux[q][i].z, ux[q][i].w};
-          const uint32_t wd[4] = {ud[q][i].x, ud[q][i].y, ud[q][i].z, ud[q][i].w};
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+        if (dx_add) {
+          const uint4 ua = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
+          const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o[e] += (e & 1) ? __uint_as_float(wa[e >> 1] & 0xffff0000u) : __uint_as_float(wa[e >> 1] << 16);
+        }
+        uint4 u;
+        u.x = pack_bf2(o[0], o[1]);
+        u.y = pack_bf2(o[2], o[3]);
+        u.z = pack_bf2(o[4], o[5]);
+        u.w = pack_bf2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(dx + (long)row * C + ch * 8) = u;
+        if (o2.out) {
+          const uint32_t wu[4] = {u.x, u.y, u.z, u.w};
+          float p2[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const int c = ch * 8 + e;
-            const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
-            float dv = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
-            if (zero) dv = 0.f;
-            if (thr) dv *= ea_keep(seed, (uint64_t)rowc * C + c, thr, inv_keep);
-            const float h = (xv - mean) * rstd_r[q];
-            xh[q][i][e] = h;
-            dg[i][e] += dv * h;
-            db[i][e] += dv;
-            const float gv = dv * gam[i][e];
-            g[q][i][e] = gv;
-            s1[q] += gv;
-            s2[q] += gv * h;
+            const float dv = (e & 1) ? __uint_as_float(wu[e >> 1] & 0xffff0000u) : __uint_as_float(wu[e >> 1] << 16);  // the rounded dx
+            float kk = 1.f;
+            if (o2.thr) kk = ea_keep(o2.seed, (uint64_t)row * C + ch * 8 + e, o2.thr, o2.inv_keep);
+            p2[e] = o2.a * dv * kk;
           }
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {  // the RW reductions interleaved
-#pragma unroll
-      for (int q = 0; q < RW; ++q) {
-        s1[q] += __shfl_xor(s1[q], o, 64);
-        s2[q] += __shfl_xor(s2[q], o, 64);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < RW; ++q) {
-      const int row = rowb + 4 * q;
-      if (row >= r1) continue;
-      const float rstd = rstd_r[q], m1 = s1[q] / (float)C, m2 = s2[q] / (float)C;
-#pragma unroll
-      for (int i = 0; i < MAXC8; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-          float o[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = rstd * (g[q][i][e] - m1 - xh[q][i][e] * m2);
-          if (dx_add) {
-            const uint4 ua = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
-            const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              o[e] += (e & 1) ? __uint_as_float(wa[e >> 1] & 0xffff0000u) : __uint_as_float(wa[e >> 1] << 16);
-          }
-          uint4 u;
-          u.x = pack_bf2(o[0], o[1]);
-          u.y = pack_bf2(o[2], o[3]);
-          u.z = pack_bf2(o[4], o[5]);
-          u.w = pack_bf2(o[6], o[7]);
-          *reinterpret_cast<uint4*>(dx + (long)row * C + ch * 8) = u;
-          if (o2.out) {
-            const uint32_t wu[4] = {u.x, u.y, u.z, u.w};
-            float p2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float dv = (e & 1) ? __uint_as_float(wu[e >> 1] & 0xffff0000u) : __uint_as_float(wu[e >> 1] << 16);  // the rounded dx
-              float kk = 1.f;
-              if (o2.thr) kk = ea_keep(o2.seed, (uint64_t)row * C + ch * 8 + e, o2.thr, o2.inv_keep);
-              p2[e] = o2.a * dv * kk;
-            }
-            uint4 u2;
-            u2.x = pack_bf2(p2[0], p2[1]);
-            u2.y = pack_bf2(p2[2], p2[3]);
-            u2.z = pack_bf2(p2[4], p2[5]);
-            u2.w = pack_bf2(p2[6], p2[7]);
-            *reinterpret_cast<uint4*>(o2.out + (long)row * C + ch * 8) = u2;
-          }
+          uint4 u2;
+          u2.x = pack_bf2(p2[0], p2[1]);
+          u2.y = pack_bf2(p2[2], p2[3]);
+          u2.z = pack_bf2(p2[4], p2[5]);
+          u2.w = pack_bf2(p2[6], p2[7]);
+          *reinterpret_cast<uint4*>(o2.out + (long)row * C + ch * 8) = u2;
         }
       }
     }
