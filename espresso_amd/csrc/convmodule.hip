@@ -29,28 +29,48 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16_t* __res
                                                              bf16_t* __restrict__ U, bf16_t* __restrict__ Z,
                                                              double* __restrict__ stats, int T, int C) {
   constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1;
-  __shared__ float su[ROWS][CT];
+  __shared__ __attribute__((aligned(16))) float su[ROWS][CT];
   __shared__ float sred[2][4][CT];
   const int c0 = blockIdx.x * CT, t0 = blockIdx.y * TTILE, b = blockIdx.z;
   const long rowbase = (long)b * T;
-  for (int i = threadIdx.x; i < ROWS * (CT / 2); i += 256) {
-    const int row = i / (CT / 2), cp = (i % (CT / 2)) * 2;
+  // staging: 8 channels (16 bytes of a and of g) per thread and row
+  const bool vec = (C & 7) == 0;
+  for (int i = threadIdx.x; i < ROWS * (CT / 8); i += 256) {
+    const int row = i / (CT / 8), c8 = (i % (CT / 8)) * 8;
     const int tin = t0 - PAD + row;
-    float u0 = 0.f, u1 = 0.f;
-    if (tin >= 0 && tin < T && c0 + cp < C) {
-      const bf16_t* yr = Y + (rowbase + tin) * (2L * C) + c0 + cp;
-      const uint32_t a = *reinterpret_cast<const uint32_t*>(yr);
-      const uint32_t g = *reinterpret_cast<const uint32_t*>(yr + C);
-      u0 = __uint_as_float(a << 16) * sigmoid_f(__uint_as_float(g << 16));
-      u1 = __uint_as_float(a & 0xffff0000u) * sigmoid_f(__uint_as_float(g & 0xffff0000u));
-      const uint32_t pk = pack_bf2(u0, u1);
-      if (row >= PAD && row < PAD + TTILE) *reinterpret_cast<uint32_t*>(U + (rowbase + tin) * C + c0 + cp) = pk;
+    float u[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] = 0.f;
+    if (tin >= 0 && tin < T && c0 + c8 < C) {
+      const bf16_t* yr = Y + (rowbase + tin) * (2L * C) + c0 + c8;
+      uint32_t pk[4] = {0, 0, 0, 0};
+      if (vec && c0 + c8 + 8 <= C) {
+        const uint4 av = *reinterpret_cast<const uint4*>(yr);
+        const uint4 gv = *reinterpret_cast<const uint4*>(yr + C);
+        const uint32_t aw[4] = {av.x, av.y, av.z, av.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pk[e] = pack_bf2(__uint_as_float(aw[e] << 16) * sigmoid_f(__uint_as_float(gw[e] << 16)),
+                           __uint_as_float(aw[e] & 0xffff0000u) * sigmoid_f(__uint_as_float(gw[e] & 0xffff0000u)));
+        if (row >= PAD && row < PAD + TTILE)
+          *reinterpret_cast<uint4*>(U + (rowbase + tin) * C + c0 + c8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      } else {
+        for (int e = 0; e < 8; ++e) {
+          if (c0 + c8 + e >= C) break;
+          const bf16_t ub = f2bf(bf2f(yr[e]) * sigmoid_f(bf2f(yr[C + e])));
+          if (row >= PAD && row < PAD + TTILE) U[(rowbase + tin) * C + c0 + c8 + e] = ub;
+          pk[e >> 1] |= (uint32_t)ub << (16 * (e & 1));
+        }
+      }
       // the conv consumes the bf16-rounded U (what backward will see)
-      u0 = __uint_as_float(pk << 16);
-      u1 = __uint_as_float(pk & 0xffff0000u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u[2 * e] = __uint_as_float(pk[e] << 16);
+        u[2 * e + 1] = __uint_as_float(pk[e] & 0xffff0000u);
+      }
     }
-    su[row][cp] = u0;
-    su[row][cp + 1] = u1;
+    *reinterpret_cast<float4*>(&su[row][c8]) = make_float4(u[0], u[1], u[2], u[3]);
+    *reinterpret_cast<float4*>(&su[row][c8 + 4]) = make_float4(u[4], u[5], u[6], u[7]);
   }
   const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;
   const int c = c0 + cl;
@@ -255,20 +275,33 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
                                                                   const float* __restrict__ w, bf16_t* __restrict__ dY,
                                                                   int T, int C) {
   constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1;
-  __shared__ float sd[ROWS][CT];
+  __shared__ __attribute__((aligned(16))) float sd[ROWS][CT];
   const int c0 = blockIdx.x * CT, t0 = blockIdx.y * TTILE, b = blockIdx.z;
   const long rowbase = (long)b * T;
-  for (int i = threadIdx.x; i < ROWS * (CT / 2); i += 256) {
-    const int row = i / (CT / 2), cp = (i % (CT / 2)) * 2;
+  const bool vec = (C & 7) == 0;
+  for (int i = threadIdx.x; i < ROWS * (CT / 8); i += 256) {
+    const int row = i / (CT / 8), c8 = (i % (CT / 8)) * 8;
     const int tin = t0 - PAD + row;
-    float d0 = 0.f, d1 = 0.f;
-    if (tin >= 0 && tin < T && c0 + cp < C) {
-      const uint32_t dd = *reinterpret_cast<const uint32_t*>(dZ + (rowbase + tin) * C + c0 + cp);
-      d0 = __uint_as_float(dd << 16);
-      d1 = __uint_as_float(dd & 0xffff0000u);
+    float d[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = 0.f;
+    if (tin >= 0 && tin < T && c0 + c8 < C) {
+      const bf16_t* src = dZ + (rowbase + tin) * C + c0 + c8;
+      if (vec && c0 + c8 + 8 <= C) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src);
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d[2 * e] = __uint_as_float(wv[e] << 16);
+          d[2 * e + 1] = __uint_as_float(wv[e] & 0xffff0000u);
+        }
+      } else {
+        for (int e = 0; e < 8; ++e)
+          if (c0 + c8 + e < C) d[e] = bf2f(src[e]);
+      }
     }
-    sd[row][cp] = d0;
-    sd[row][cp + 1] = d1;
+    *reinterpret_cast<float4*>(&sd[row][c8]) = make_float4(d[0], d[1], d[2], d[3]);
+    *reinterpret_cast<float4*>(&sd[row][c8 + 4]) = make_float4(d[4], d[5], d[6], d[7]);
   }
   const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;
   const int c = c0 + cl;
