@@ -433,7 +433,10 @@ def main(argv=None):
         if args.no_decode:
             del trainer, model, criterion, samples
         torch.cuda.empty_cache()
+        import gc
+
         for key, mod in (("config2_encdec", bench_encdec), ("config4_transducer", bench_transducer)):
+            gc.collect()  # (the decode block leaves ~10^6 short-lived hypothesis objects for the collector)
             try:
                 others[key] = mod.run()
             except Exception as e:  # a secondary block must not take the headline line down with it
