@@ -275,7 +275,6 @@ def main(argv=None):
     ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B switch: keep weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-fused-predrop", action="store_true", help="A/B switch: separate scale+dropout pass per residual block")
     ap.add_argument("--gemm-xcd-mask", type=int, default=None, help="A/B switch: XCD-aware tile order (bit 0 glds kernel, bit 1 register-staged)")
-    ap.add_argument("--gemm-pk", type=int, default=None, help="A/B switch: persistent GEMM kernel (0 off, 1 automatic, 2+c configuration c)")
     ap.add_argument("--deferred-inline", action="store_true", help="A/B switch: deferred side work on the main stream (no overlap)")
     ap.add_argument("--no-conv-igemm", action="store_true", help="A/B switch: im2col + GEMM + col2im sub-sampler (round 1) instead of the implicit GEMM")
     ap.add_argument("--no-deferred", action="store_true", help="A/B switch: layer backward joins its side work inside every call")
@@ -292,9 +291,6 @@ def main(argv=None):
     if args.no_fused_predrop:
         from espresso_amd._lib import lib as _ealib3
         _ealib3().ea_set_fused_predrop(0)
-    if args.gemm_pk is not None:
-        from espresso_amd._lib import lib as _ealib4
-        _ealib4().ea_set_gemm_persistent(args.gemm_pk)
     if args.deferred_inline:
         from espresso_amd._lib import lib as _ealib5
         _ealib5().ea_set_backward_deferred_inline(1)

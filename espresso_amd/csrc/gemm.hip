@@ -941,8 +941,6 @@ static bool glds_eligible(const EaGemmParams& q) {
          ((q.sA_hi | q.sA_lo | q.sB_hi | q.sB_lo) & 7) == 0 && ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) == 0;
 }
 
-int gemm_pk_try(const EaGemmParams& q, hipStream_t stream, int* cfg_used);  // gemm_pk.hip: persistent 8-wave kernel
-
 template <bool A_KS, bool B_KS>
 static void launch_gemm(dim3 grid, bool bm64, hipStream_t stream, const EaGemmParams& q) {
   // the remap helps when several n-tiles share a row block and the grid spans many row blocks (not for batched / split launches,
@@ -994,13 +992,6 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   }
   bool done = false;
   const bool kc_ok = glds_eligible(q);
-  if (kc_ok) {
-    int cfg = -1;
-    if (gemm_pk_try(q, stream, &cfg)) {
-      done = true;
-      pr.bm64 = 100 + cfg;
-    }
-  }
   if (!done && g_gemm_glds && kc_ok) {
     // XCD-aware tile order when the whole B operand fits every XCD's L2 next to the streamed A rows (few n-tiles): measured
     // L2 hit rate 58 -> 82 % and -10..-20 % time on the N = 512 projections; slower for square problems (B no longer stationary)

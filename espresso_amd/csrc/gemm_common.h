@@ -1,5 +1,5 @@
 // Pieces shared by the GEMM kernels (gemm.hip: register-staged / direct-to-LDS / grouped weight-gradient kernels;
-// gemm_pk.hip: persistent 8-wave kernel): the LDS tile image and the activation functions of the fused epilogues.
+// conv_igemm.hip: implicit-GEMM convolutions): the LDS tile image and the activation functions of the fused epilogues.
 #pragma once
 #include "common.h"
 #include "espresso_amd.h"

@@ -84,10 +84,6 @@ int ea_set_gemm_variant(int v);
 int ea_set_gemm_xcd_swizzle(int mask);
 /* tuning hook: direct-to-LDS ring kernel for launches whose operands are both k-contiguous (0 = off, 1 = automatic ring depth, 2..4 = forced number of stages); returns the previous value */
 int ea_set_gemm_glds(int stages);
-/* tuning hook: persistent 8-wave kernel (csrc/gemm_pk.hip) for launches whose operands are both k-contiguous: 0 = off,
- * 1 = automatic tile configuration, 2 + c = configuration c forced (0: 256x128, 1: 192x128, 2: 128x128 tiles);
- * returns the previous value */
-int ea_set_gemm_persistent(int mode);
 /* bf16 GEMM outputs of at least `bytes` are written with non-temporal stores (default 0 = never: measured neutral on the training step); returns the old value */
 long ea_set_gemm_nt_store_min_bytes(long bytes);
 int ea_gemm_profile_enable(int on);

@@ -54,44 +54,6 @@ def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, 
     return rel_err(C, ref)
 
 
-def check_gemm_epilogue_pairs(M=777, N=264, K=192, seed=0):
-    """The persistent kernel (whatever mode is set) against the general kernels (persistent path off) on the fused epilogues
-    the layer runtime uses — second output + activation + dropout (FFN W1 forward), aux + activation derivative + dropout (its
-    data gradient), bias + dropout + scaled residual (FFN W2 forward): same arithmetic on the same accumulators, same dropout
-    hash indices -> identical bf16 outputs."""
-    from espresso_amd import _lib
-    from espresso_amd import kernels as Kk
-
-    lib = _lib.lib()
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    A = bf(torch.randn(M, K, generator=g)).to(DEV)
-    B = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
-    bias = torch.randn(N, generator=g).to(DEV)
-    R = bf(torch.randn(M, N, generator=g)).to(DEV)
-    Z = bf(torch.randn(M, N, generator=g)).to(DEV)
-
-    def run():
-        outs = []
-        C, C2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV), torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        Kk.gemm(A, B, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, act="silu", C2=C2, ldc2=N, drop_p=0.1, drop_seed=11)
-        outs += [C.clone(), C2.clone()]
-        Kk.gemm(A, B, C, M, N, K, lda=K, ldb=K, ldc=N, aux=Z, ldaux=N, act="silu", drop_p=0.1, drop_seed=11)
-        outs.append(C.clone())
-        Kk.gemm(A, B, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, resid=R, ldr=N, out_scale=0.5, drop_p=0.1, drop_seed=13)
-        outs.append(C.clone())
-        torch.cuda.synchronize()
-        return outs
-
-    mine = run()
-    old = lib.ea_set_gemm_persistent(0)
-    try:
-        ref = run()
-    finally:
-        lib.ea_set_gemm_persistent(old)
-    d = [float((a.float() - b.float()).abs().max()) for a, b in zip(mine, ref)]
-    return {"c2_vs_general": max(d[0], d[1]), "aux_vs_general": d[2], "drop_vs_general": d[3]}
-
-
 def check_conv3x3(Cin=64, Cout=128, sy=2, sx=2, B=2, T=37, F=21, seed=0):
     """Implicit-GEMM 3x3 convolution (forward + BatchNorm sums, data gradient) vs torch conv2d / its autograd on the same bf16
     operands (fp32 CPU): odd T / F (ragged parity classes, padding taps on every border), strides 1 and 2."""

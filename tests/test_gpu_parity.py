@@ -82,29 +82,6 @@ def test_gemm_direct_to_lds_ring(stages, variant):
         _lib.lib().ea_set_gemm_glds(old)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])  # 256x128, 192x128, 128x128 tiles
-def test_gemm_persistent_kernel(cfg):
-    """csrc/gemm_pk.hip with each tile configuration forced: ragged M / N (clamped rows, guarded stores), several tiles per
-    workgroup (cross-tile prefetch through the ring), fused epilogues, fp32 / split-K / batched outputs."""
-    from espresso_amd import _lib
-
-    lib = _lib.lib()
-    old = lib.ea_set_gemm_persistent(2 + cfg)
-    try:
-        for (M, N, K) in ((200, 130, 64), (333, 257, 128), (129, 64, 1024), (1000, 96, 448), (5, 520, 192), (6128, 512, 2048),
-                          (6128, 2048, 512), (40000, 200, 192)):
-            assert G.check_gemm(M, N, K, False, False) < 1e-2, (M, N, K)
-            assert G.check_gemm(M, N, K, False, False, bias=True, act="silu", resid=True) < 1e-2, (M, N, K)
-            assert G.check_gemm(M, N, K, False, False, c_f32=True) < 2e-3, (M, N, K)
-            if K >= 192:
-                assert G.check_gemm(M, N, K, False, False, c_f32=True, splitk=3) < 2e-3, (M, N, K)
-        assert G.check_gemm(300, 200, 128, False, False, batch=3) < 1e-2
-        r = G.check_gemm_epilogue_pairs()
-        assert r["c2_vs_general"] == 0.0 and r["aux_vs_general"] == 0.0 and r["drop_vs_general"] == 0.0, r
-    finally:
-        lib.ea_set_gemm_persistent(old)
-
-
 def test_ctc_fp32():
     r = G.check_ctc()
     assert r["lprobs_abs"] < 1e-4, r

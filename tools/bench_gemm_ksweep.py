@@ -58,9 +58,7 @@ def timeit(p, iters=50):
 
 configs = [("old auto", dict(glds=1, variant=0, pk=0)), ("old reg bm64", dict(glds=0, variant=2, pk=0)),
            ("old glds2 bm64", dict(glds=2, variant=2, pk=0)), ("old glds3 bm64", dict(glds=3, variant=2, pk=0)),
-           ("old glds2 bm128", dict(glds=2, variant=1, pk=0)),
-           ("pk auto", dict(glds=1, variant=0, pk=1)), ("pk 256x128", dict(glds=1, variant=0, pk=2)),
-           ("pk 192x128", dict(glds=1, variant=0, pk=3)), ("pk 128x128", dict(glds=1, variant=0, pk=4))]
+           ("old glds2 bm128", dict(glds=2, variant=1, pk=0))]
 extra = os.environ.get("EXTRA_CONFIGS")
 for N, epi in ((512, None), (512, "w2"), (2048, None), (2048, "w1"), (1536, None), (1024, None)):
     print(f"--- M={M} N={N} epilogue={epi}")
@@ -68,7 +66,6 @@ for N, epi in ((512, None), (512, "w2"), (2048, None), (2048, "w1"), (1536, None
     for name, cfg in configs:
         lib.ea_set_gemm_glds(cfg["glds"])
         lib.ea_set_gemm_variant(cfg["variant"])
-        lib.ea_set_gemm_persistent(cfg["pk"])
         row = []
         for K in (64, 128, 256, 512, 1024, 2048):
             p, keep = params(N, K, epi)
@@ -76,4 +73,3 @@ for N, epi in ((512, None), (512, "w2"), (2048, None), (2048, "w1"), (1536, None
         print(f"{name:16s}" + "".join(f"  {t:7.1f}" for t in row))
 lib.ea_set_gemm_glds(1)
 lib.ea_set_gemm_variant(0)
-lib.ea_set_gemm_persistent(1)
