@@ -62,6 +62,13 @@ class EaGemmParams(ctypes.Structure):
         ("splitk", ctypes.c_int),
         ("kchunk", ctypes.c_int),
         ("workspace", ctypes.c_void_p),
+        ("q_u", ctypes.c_void_p),
+        ("q_v", ctypes.c_void_p),
+        ("pos_u", ctypes.c_void_p),
+        ("pos_v", ctypes.c_void_p),
+        ("ld_q", ctypes.c_long),
+        ("qsplit_n", ctypes.c_int),
+        ("qscale", ctypes.c_float),
     ]
 
 

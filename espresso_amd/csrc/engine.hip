@@ -150,6 +150,14 @@ struct G {
   G& c2(void* c, long ld) { p.C2 = c; p.ldc2 = ld; return *this; }
   G& aux(const void* x, long ld) { p.aux = x; p.ldaux = ld; return *this; }
   G& drop(float pr, uint64_t seed) { p.drop_thr = drop_thr(pr); p.drop_scale = drop_scale(pr); p.drop_seed = seed; return *this; }
+  // columns [0, n) leave as the attention kernels' query operands: q_u = (q + pos_u) * s, q_v = (q + pos_v) * s (no launch of
+  // ea_relpos_q_prep); false when the shape does not qualify (the caller then runs ea_relpos_q_prep)
+  bool qsplit(void* q_u, void* q_v, const float* pos_u, const float* pos_v, int n, long ld_q, float s) {
+    static const bool off = getenv("EA_NO_QSPLIT") != nullptr;  // (diagnostic A/B switch)
+    if (off || n % 128 || p.N % 8) return false;
+    p.q_u = q_u; p.q_v = q_v; p.pos_u = pos_u; p.pos_v = pos_v; p.qsplit_n = n; p.ld_q = ld_q; p.qscale = s;
+    return true;
+  }
   G& batch(int b, int zdiv, long ahi, long alo, long bhi, long blo, long chi, long clo) {
     p.batch = b; p.zdiv = zdiv; p.sA_hi = ahi; p.sA_lo = alo; p.sB_hi = bhi; p.sB_lo = blo; p.sC_hi = chi; p.sC_lo = clo;
     return *this;
@@ -420,14 +428,20 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, a.xn, a.mean, a.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   G gq(a.xn, w.wqkv, a.qkv, M, 3 * C, C, C, C, 3 * C);
   gq.bias(w.bqkv);
-  gemm(c, gq);
   // positional mode 1 (learned relative table, multihead_attention.py:806-818): `pe` IS the bf16 [2T-1][C] slice of the table,
   // plain scaled queries for both terms, no pos_proj / pos_bias_u / pos_bias_v
   const bool learned = sh.pos_mode == 1;
   const uint16_t* pp = learned ? (const uint16_t*)pe : a.pp;
   const uint16_t* qvv = learned ? a.qu : a.qv;
-  if (learned) RUN(ea_relpos_q_prep(a.qkv, 3 * C, nullptr, nullptr, a.qu, nullptr, M, C, scaling, c.s));
-  else RUN(ea_relpos_q_prep(a.qkv, 3 * C, w.pos_u, w.pos_v, a.qu, a.qv, M, C, scaling, c.s));
+  // q + pos_bias_u / q + pos_bias_v, scaled: written by the projection's epilogue (the q third of a.qkv then stays unwritten;
+  // nothing reads it), by ea_relpos_q_prep for widths the epilogue does not take
+  const bool split = learned ? gq.qsplit(a.qu, nullptr, nullptr, nullptr, C, C, scaling)
+                             : gq.qsplit(a.qu, a.qv, w.pos_u, w.pos_v, C, C, scaling);
+  gemm(c, gq);
+  if (!split) {
+    if (learned) RUN(ea_relpos_q_prep(a.qkv, 3 * C, nullptr, nullptr, a.qu, nullptr, M, C, scaling, c.s));
+    else RUN(ea_relpos_q_prep(a.qkv, 3 * C, w.pos_u, w.pos_v, a.qu, a.qv, M, C, scaling, c.s));
+  }
   if (attn_fused(sh)) {
     if (!learned) {
       G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
@@ -472,7 +486,7 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
 // shared tail of the attention backward: pos_proj / bias / qkv weight gradients, dq = t1 + t2, dgrad to the block input, LN
 static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw,
                           const void* x, const void* dy, void* dx, const void* pe, uint16_t* dqkv, uint16_t* t1, uint16_t* t2,
-                          uint16_t* dBD, const uint16_t* wqkvt, const Pre& next, float* dpe) {
+                          uint16_t* dBD, const uint16_t* wqkvt, const Pre& next, float* dpe, bool have_dq = false) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad8(R);
   Arena& sc = *c.scratch;
   const bool learned = sh.pos_mode == 1;
@@ -530,7 +544,7 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
     bias_grad(c, t1, gw.pos_u, M, C, C);
     bias_grad(c, t2, gw.pos_v, M, C, C);
   }
-  RUN(ea_add2_strided_bf16(t1, C, t2, C, dqkv, 3 * C, M, C, c.s));
+  if (!have_dq) RUN(ea_add2_strided_bf16(t1, C, t2, C, dqkv, 3 * C, M, C, c.s));
   fork(c);
   wgrad(c, dqkv, 3 * C, a.xn, C, gw.wqkv, M, 3 * C, C, gw.bqkv);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
@@ -563,12 +577,13 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     uint16_t* t2 = sc.get<uint16_t>((size_t)M * C);
     uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
     float* Dd = sc.get<float>((size_t)Z * T);
+    static const bool fused_dq = getenv("EA_NO_FUSED_DQ") == nullptr;  // (diagnostic A/B switch)
     RUN(ea_flash_attention_bwd(a.qu, sh.pos_mode == 1 ? a.qu : a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C,
                                sh.pos_mode == 1 ? (const uint16_t*)pe : a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
                                Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, (sh.scratch_clean && c.overlap) ? 2 : 0, scaling, seed + 3,
                                drop_thr(sh.p_attn),
-                               drop_scale(sh.p_attn), a.bits, c.s));
-    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next, dpe);
+                               drop_scale(sh.p_attn), a.bits, fused_dq ? dqkv : nullptr, 3 * C, c.s));  // dq = t1 + t2 -> q third of dqkv
+    attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next, dpe, fused_dq);
     release(c, mark);
     return;
   }
@@ -872,8 +887,9 @@ static int dlayer_fwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     RUN(ea_layernorm_fwd(x_in, w.ln_g, w.ln_b, D.sa.xn, D.sa.mean, D.sa.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
     G gq(D.sa.xn, w.wqkv, D.sa.qkv, M, 3 * C, C, C, C, 3 * C);
     gq.bias(w.bqkv);
+    const bool split = gq.qsplit(D.sa.qs, nullptr, nullptr, nullptr, C, C, scaling);  // scaled queries from the projection's epilogue
     gemm(c, gq);
-    RUN(ea_relpos_q_prep(D.sa.qkv, 3 * C, nullptr, nullptr, D.sa.qs, nullptr, M, C, scaling, c.s));
+    if (!split) RUN(ea_relpos_q_prep(D.sa.qkv, 3 * C, nullptr, nullptr, D.sa.qs, nullptr, M, C, scaling, c.s));
     RUN(ea_flash_attention_fwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, C, D.sa.lse, H,
                                B, T, T, dh, 1, seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
     G go(D.sa.o, w.wo, D.x1, M, C, C, C, C, C);
@@ -885,8 +901,9 @@ static int dlayer_fwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     RUN(ea_layernorm_fwd(D.x1, w.ln_g, w.ln_b, D.ca.xn, D.ca.mean, D.ca.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
     G gq(D.ca.xn, w.wq, D.ca.q, M, C, C, C, C, C);
     gq.bias(w.bq);
+    const bool split = gq.qsplit(D.ca.qs, nullptr, nullptr, nullptr, C, C, scaling);
     gemm(c, gq);
-    RUN(ea_relpos_q_prep(D.ca.q, C, nullptr, nullptr, D.ca.qs, nullptr, M, C, scaling, c.s));
+    if (!split) RUN(ea_relpos_q_prep(D.ca.q, C, nullptr, nullptr, D.ca.qs, nullptr, M, C, scaling, c.s));
     G gkv(enc, w.wkv, D.ca.kv, Ms, 2 * C, C, C, C, 2 * C);
     gkv.bias(w.bkv);
     gemm(c, gkv);
@@ -935,7 +952,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     float* Dd = sc.get<float>((size_t)Z * T);
     RUN(ea_flash_attention_bwd(D.ca.qs, nullptr, C, D.ca.kv, D.ca.kv + C, 2 * C, nullptr, 0, enc_len, D.ca.o, dO, C, D.ca.lse, Dd, dq,
                                nullptr, C, nullptr, 0, dkv, dkv + C, 2 * C, H, B, T, S, dh, 0, scaling, seed + 32 + 3, drop_thr(sh.p_attn),
-                               drop_scale(sh.p_attn), nullptr, c.s));
+                               drop_scale(sh.p_attn), nullptr, nullptr, 0, c.s));
     fork(c);
     wgrad(c, dq, C, D.ca.xn, C, gw.wq, M, C, C, gw.bq);
     wgrad(c, dkv, 2 * C, enc, C, gw.wkv, Ms, 2 * C, C, gw.bkv);
@@ -957,7 +974,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     // t1 (gradient of the scaled queries, already multiplied by the scale) goes straight into the q third of dqkv
     RUN(ea_flash_attention_bwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, dO, C, D.sa.lse,
                                Dd, dqkv, nullptr, 3 * C, nullptr, 0, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 1, scaling,
-                               seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
+                               seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, nullptr, 0, c.s));
     fork(c);
     wgrad(c, dqkv, 3 * C, D.sa.xn, C, gw.wqkv, M, 3 * C, C, gw.bqkv);
     uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);

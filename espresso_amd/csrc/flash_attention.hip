@@ -485,6 +485,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashBwdArgs 
         pk.y = pack_bf2(acc_t2[dt][2] * a.scaling, acc_t2[dt][3] * a.scaling);
         *reinterpret_cast<uint2*>(o2 + dt * 16 + g4 * 4) = pk;
       }
+      if (a.dq) {
+        bf16_t* oq = a.dq + ((long)b * T + i) * a.lddq + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 pk;
+          pk.x = pack_bf2((acc_t1[dt][0] + acc_t2[dt][0]) * a.scaling, (acc_t1[dt][1] + acc_t2[dt][1]) * a.scaling);
+          pk.y = pack_bf2((acc_t1[dt][2] + acc_t2[dt][2]) * a.scaling, (acc_t1[dt][3] + acc_t2[dt][3]) * a.scaling);
+          *reinterpret_cast<uint2*>(oq + dt * 16 + g4 * 4) = pk;
+        }
+      }
     }
   }
   if (RELPOS && !a.dbd_prezeroed) {
@@ -719,14 +729,15 @@ extern "C" int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, 
                                       const float* lse, float* D, void* t1, void* t2, long ldt, void* dBD, int ld_bd, void* dk,
                                       void* dv, long lddkv, int H, int B, int T, int S, int dh, int causal, float scaling,
                                       uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* keep_bits,
-                                      hipStream_t stream) {
+                                      void* dq, long lddq, hipStream_t stream) {
   if (H <= 0 || B <= 0 || T <= 0) return 0;
   const bool relpos = qv != nullptr;
   if (!ea_flash_attention_supported(dh, T, S, relpos)) return -2;
   if (relpos && (!pp || !t2 || !dBD || ld_bd < 2 * T - 1 || ld_bd % 8 || ((uintptr_t)dBD & 15))) return -2;
   if ((ldq | ldkv | ldo | ldt | lddkv) % 8 || (relpos && ldpp % 8)) return -2;
   if (((uintptr_t)qu | (uintptr_t)qv | (uintptr_t)k | (uintptr_t)v | (uintptr_t)pp | (uintptr_t)out | (uintptr_t)dout) & 15) return -2;
-  if (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)dk | (uintptr_t)dv) & 7) return -2;
+  if (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)dq) & 7) return -2;
+  if (dq && (!relpos || lddq % 4)) return -2;  // without the positional term t1 IS the query gradient
   FlashBwdArgs a;
   a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.ldq = ldq;
   a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldkv = ldkv;
@@ -735,6 +746,7 @@ extern "C" int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, 
   a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.ldo = ldo;
   a.lse = lse; a.D = D;
   a.t1 = (bf16_t*)t1; a.t2 = (bf16_t*)t2; a.ldt = ldt;
+  a.dq = (bf16_t*)dq; a.lddq = lddq;
   a.dBD = (bf16_t*)dBD; a.ld_bd = ld_bd;
   a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lddkv = lddkv;
   a.H = H; a.B = B; a.T = T; a.S = S; a.causal = causal & 1; a.dbd_prezeroed = (causal >> 1) & 1;

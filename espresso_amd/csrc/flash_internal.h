@@ -24,6 +24,7 @@ struct FlashBwdArgs {
   const float* lse;
   float* D;                       // [H*B][T]   (written by the Q kernel, read by the KV kernel)
   bf16_t* t1; bf16_t* t2; long ldt;  // [B*T][ldt] gradients of (q+u), (q+v) (unscaled q space)
+  bf16_t* dq; long lddq;             // optional [B*T][lddq]: t1 + t2 summed in fp32 (rel-pos only)
   bf16_t* dBD; int ld_bd;         // [H*B][T][ld_bd]
   bf16_t* dk; bf16_t* dv; long lddkv;
   int H, B, T, S, causal, nq, nk, dbd_prezeroed;

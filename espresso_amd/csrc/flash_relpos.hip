@@ -725,6 +725,16 @@ __global__ __launch_bounds__(256, 2) void rp_bwd_q_kernel(const FlashBwdArgs a) 
       pk.y = pack_bf2(acc_t2[dt][2] * a.scaling, acc_t2[dt][3] * a.scaling);
       *reinterpret_cast<uint2*>(o2 + dt * 16 + g4 * 4) = pk;
     }
+    if (a.dq) {  // the query projection's gradient, summed before rounding (saves the separate t1 + t2 pass)
+      bf16_t* oq = a.dq + ((long)b * T + i) * a.lddq + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = pack_bf2((acc_t1[dt][0] + acc_t2[dt][0]) * a.scaling, (acc_t1[dt][1] + acc_t2[dt][1]) * a.scaling);
+        pk.y = pack_bf2((acc_t1[dt][2] + acc_t2[dt][2]) * a.scaling, (acc_t1[dt][3] + acc_t2[dt][3]) * a.scaling);
+        *reinterpret_cast<uint2*>(oq + dt * 16 + g4 * 4) = pk;
+      }
+    }
   }
   PROF_MARK(9)
   if (!a.dbd_prezeroed) {

@@ -241,6 +241,21 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
   const bool has_drop = p.drop_thr != 0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias8[e];
+  if (p.q_u && n < p.qsplit_n) {
+    // rel-pos query columns (whole 128-column tiles: the branch is uniform per workgroup): q is rounded to bf16 exactly as the
+    // plain epilogue would store it, then the two biased, scaled copies the attention kernels read are written instead of it
+    float u8[8], b8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float q = __uint_as_float((uint32_t)f2bf(v[e]) << 16);
+      u8[e] = (q + (p.pos_u ? p.pos_u[n + e] : 0.f)) * p.qscale;
+      b8[e] = (q + (p.pos_v ? p.pos_v[n + e] : 0.f)) * p.qscale;
+    }
+    const bool qvec = (p.ld_q & 7) == 0 && ((((uintptr_t)p.q_u) | ((uintptr_t)p.q_v)) & 15) == 0;
+    store8_bf16(reinterpret_cast<bf16_t*>(p.q_u) + (long)m * p.ld_q + n, qvec, 8, u8, nt);
+    if (p.q_v) store8_bf16(reinterpret_cast<bf16_t*>(p.q_v) + (long)m * p.ld_q + n, qvec, 8, b8, nt);
+    return;
+  }
   const uint64_t didx = ((uint64_t)z * (uint64_t)p.M + (uint64_t)m) * (uint64_t)p.N + (uint64_t)n;
   const long co = coff + (long)m * p.ldc + n;
   if (p.splitk > 1) {  // split-K partial slab [ks][batch][M][N] fp32 (dense, ld = N); combined by splitk_reduce_kernel
@@ -960,6 +975,12 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   if (p.K <= 0 || p.zdiv <= 0) return -2;
   EaGemmParams q = p;
   if (q.splitk < 1) q.splitk = 1;
+  if (q.q_u) {
+    if (q.qsplit_n <= 0 || q.qsplit_n % 128 || q.qsplit_n > q.N || q.N % 8 || q.batch != 1 || q.splitk > 1 || q.c_f32 || q.ld_q < q.qsplit_n)
+      return -4;
+  } else {
+    q.qsplit_n = 0;
+  }
   if (q.splitk > 1) {
     // partial sums are combined with fp32 atomics: only the plain accumulate epilogue is legal
     if (!q.c_f32 || q.bias || q.resid || q.aux || q.C2 || q.act != EA_ACT_NONE || q.drop_thr || !q.workspace) return -4;

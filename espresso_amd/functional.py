@@ -133,6 +133,32 @@ def _side_stream(device):
     return st
 
 
+_aux_streams = {}
+_BRANCH_OVERLAP = os.environ.get("EA_BRANCH_OVERLAP", "1") != "0"
+
+
+def aux_stream(device, idx):
+    """Further per-device streams for whole independent branches of a model (idx 1: the transducer's predictor network, idx 2:
+    the joint network's weight gradient); `_side_stream` stays reserved for work that joins inside one backward call."""
+    key = (str(device), idx)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = _aux_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def set_branch_overlap(on: bool) -> bool:
+    """Run independent branches of the transducer (predictor network, joint weight gradient) on their own streams (default on;
+    A/B switch and the tests' way to get the single-stream schedule).  Returns the previous setting."""
+    global _BRANCH_OVERLAP
+    old, _BRANCH_OVERLAP = _BRANCH_OVERLAP, bool(on)
+    return old
+
+
+def branch_overlap() -> bool:
+    return _BRANCH_OVERLAP
+
+
 # ------------------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
     @staticmethod
@@ -345,7 +371,8 @@ class _RelPosMHSA(torch.autograd.Function):
         if fused:
             t1, t2, dBD = K.flash_attention_bwd(qu, qv if relpos else None, qkv[:, C:], qkv[:, 2 * C:], pp, key_len, o, do, lse,
                                                 dqkv[:, C:], dqkv[:, 2 * C:], H, B, T, T, C, 3 * C, 3 * C, ldpp=C, causal=causal,
-                                                scaling=scaling, drop_p=p_attn, drop_seed=sa, keep_bits=bits)
+                                                scaling=scaling, drop_p=p_attn, drop_seed=sa, keep_bits=bits,
+                                                dq=dqkv if relpos else None, lddq=3 * C)
         else:
             # dPd[z][i][j] = sum_d do[(b,i),h,d] v[(b,j),h,d]
             dPd = _new((Z * T, Sp), torch.float32, x)
@@ -379,7 +406,8 @@ class _RelPosMHSA(torch.autograd.Function):
                 dWpos = _wgrad(K.cast_f32_to_bf16(dpp32), pe, R, C, C)
                 du = K.colsum(t1, _zeros_f32(C, x), M, C, C)
                 dv = K.colsum(t2, _zeros_f32(C, x), M, C, C)
-            K.add2_strided(t1, C, t2, C, dqkv, 3 * C, M, C)
+            if not fused:  # (the fused backward wrote dq = t1 + t2 into the q third itself)
+                K.add2_strided(t1, C, t2, C, dqkv, 3 * C, M, C)
         else:
             K.add2_strided(t1, C, torch.zeros_like(t1), C, dqkv, 3 * C, M, C)
         dWqkv = _wgrad(dqkv, xn, M, 3 * C, C)
@@ -1716,8 +1744,9 @@ class _TransducerJoint(torch.autograd.Function):
     matrix), returns bf16 [B][T][U1][V] (what the reference's fc_out yields under bf16 autocast)."""
 
     @staticmethod
-    def forward(ctx, E, D, w, b, w16, B, T, U1):
+    def forward(ctx, E, D, w, b, w16, B, T, U1, late=None):
         V, J = w.shape
+        ctx.late = late
         Z = K.joint_add_relu(E.contiguous(), D.contiguous(), B, T, U1)
         n = B * T * U1
         # rows padded to a multiple of 64 columns (5004 -> 5056): 16-byte aligned rows for the epilogue stores and the loss kernels,
@@ -1751,10 +1780,70 @@ class _TransducerJoint(torch.autograd.Function):
         # dW [V][J] = dl^T Z over all B*T*U1 lattice nodes: split-K GEMM on the aligned (padded-pitch) gradient.  (The grouped
         # weight-gradient kernel was tried here: 632 tiles each walking 45 000 rows of a 10 KB-pitch operand ran at 115 TFLOP/s,
         # slower than the split-K launch.)
-        dw = _wgrad(dl, Z, n, V, J, ld_dy=Vp)
-        db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp) if has_bias else None
-        return dE, dD, dw, db, None, None, None, None
+        late = ctx.late
+        if late is not None and has_bias:
+            # optimizer-only product, 2 ms at the recipe's batch: launched on its own stream behind the data gradient (two
+            # device-filling GEMMs side by side only slow each other down), handed to autograd by the `_JointWeightLate` node,
+            # which the engine reaches after the encoder's and the predictor's backward passes
+            cur, side = torch.cuda.current_stream(dl.device), aux_stream(dl.device, 2)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                dw = _wgrad(dl, Z, n, V, J, ld_dy=Vp)
+                db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp)
+                late.event = side.record_event()
+            dw.record_stream(cur)
+            db.record_stream(cur)
+            late.dw, late.db, late.keep = dw, db, (dl, Z)  # operands stay allocated until the join
+            dw = db = None
+        else:
+            dw = _wgrad(dl, Z, n, V, J, ld_dy=Vp)
+            db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp) if has_bias else None
+        return dE, dD, dw, db, None, None, None, None, None
 
 
-def transducer_joint(E, D, w, b, B, T, U1):
-    return _TransducerJoint.apply(E, D, w, b, K.cast_f32_to_bf16(w.detach().contiguous()), B, T, U1)
+class _LateGrad:
+    """What `_TransducerJoint.backward` leaves for `_JointWeightLate.backward`: the gradients, the event that marks them
+    complete, and the operands the side stream is still reading."""
+    __slots__ = ("dw", "db", "event", "keep")
+
+    def __init__(self):
+        self.dw = self.db = self.event = self.keep = None
+
+
+class _JointWeightLate(torch.autograd.Function):
+    """Identity on the joint network's output weight and bias, created BEFORE the encoder and the predictor run.  The autograd
+    engine orders ready nodes by creation time, latest first, so this node's backward runs after the encoder's and the
+    predictor's; the weight gradient that `_TransducerJoint.backward` launched on a side stream is joined only here.
+    (If the engine ever reaches this node earlier the result is the same, the overlap is just shorter.)"""
+
+    @staticmethod
+    def forward(ctx, w, b, holder):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return w.view_as(w), b.view_as(b)
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        h = ctx.holder
+        if h.event is None:
+            return gw, gb, None
+        dev = h.dw.device
+        torch.cuda.current_stream(dev).wait_event(h.event)
+        dw, db = h.dw, h.db
+        h.dw = h.db = h.event = h.keep = None
+        if gw is not None:
+            dw = dw + gw
+        if gb is not None:
+            db = db + gb
+        return dw, db, None
+
+
+def joint_weight_late(w, b):
+    """-> (w', b', holder) for `transducer_joint(..., late=holder)`; call it before the branches that feed the joint network"""
+    holder = _LateGrad()
+    w2, b2 = _JointWeightLate.apply(w, b, holder)
+    return w2, b2, holder
+
+
+def transducer_joint(E, D, w, b, B, T, U1, late=None):
+    return _TransducerJoint.apply(E, D, w, b, K.cast_f32_to_bf16(w.detach().contiguous()), B, T, U1, late)

@@ -78,8 +78,11 @@ def gemm(
     drop_p: float = 0.0,
     drop_seed: int = 0,
     splitk: int = 1,
+    qsplit=None,
 ):
-    """C[z][m][n] = epi(alpha * sum_k A(z;m,k) B(z;n,k)).  Offsets (a_off, ...) are in elements."""
+    """C[z][m][n] = epi(alpha * sum_k A(z;m,k) B(z;n,k)).  Offsets (a_off, ...) are in elements.
+    qsplit = (q_u, q_v | None, pos_u | None, pos_v | None, n, ld_q, scale): columns [0, n) go to q_u / q_v as
+    (q + pos) * scale instead of C (EaGemmParams.q_u in the header)."""
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     assert C.dtype in (torch.bfloat16, torch.float32)
     p = EaGemmParams()
@@ -116,6 +119,12 @@ def gemm(
     if p.splitk > 1:
         ws = torch.empty(p.splitk * batch * M * N, dtype=torch.float32, device=C.device)
         p.workspace = ws.data_ptr()
+    if qsplit is not None:
+        q_u, q_v, pos_u, pos_v, qn, ld_q, qscale = qsplit
+        assert q_u.dtype == torch.bfloat16 and (q_v is None or q_v.dtype == torch.bfloat16)
+        assert (pos_u is None or pos_u.dtype == torch.float32) and (pos_v is None or pos_v.dtype == torch.float32)
+        p.q_u, p.q_v, p.pos_u, p.pos_v = _p(q_u), _p(q_v), _p(pos_u), _p(pos_v)
+        p.qsplit_n, p.ld_q, p.qscale = int(qn), int(ld_q), float(qscale)
     check(_lib.lib().ea_gemm_bf16(ctypes.byref(p), _stream()), "ea_gemm_bf16")
     return C
 
@@ -242,9 +251,10 @@ def flash_attention_fwd(qu, qv, k, v, pp, key_len, H, B, T, S, ldq, ldkv, ldpp=0
 
 
 def flash_attention_bwd(qu, qv, k, v, pp, key_len, out, dout, lse, dk, dv, H, B, T, S, ldq, ldkv, lddkv, ldpp=0, causal=False,
-                        scaling=1.0, drop_p=0.0, drop_seed=0, keep_bits=None):
+                        scaling=1.0, drop_p=0.0, drop_seed=0, keep_bits=None, dq=None, lddq=0):
     """Fused attention backward.  dk / dv: destination views (row stride lddkv).  keep_bits: the buffer flash_attention_fwd
-    returned with want_bits (None: the general kernels re-evaluate the dropout hash).  Returns (t1, t2, dBD)."""
+    returned with want_bits (None: the general kernels re-evaluate the dropout hash).  dq (rel-pos only): destination view for
+    t1 + t2 (row stride lddq).  Returns (t1, t2, dBD)."""
     dh = 64
     C = H * dh
     relpos = qv is not None
@@ -257,7 +267,8 @@ def flash_attention_bwd(qu, qv, k, v, pp, key_len, out, dout, lse, dk, dv, H, B,
     check(
         _lib.lib().ea_flash_attention_bwd(_p(qu), _p(qv), ldq, _p(k), _p(v), ldkv, _p(pp), ldpp, _p(key_len), _p(out), _p(dout),
                                           C, _p(lse), _p(D), _p(t1), _p(t2), C, _p(dBD), Rp, _p(dk), _p(dv), lddkv, H, B, T, S,
-                                          dh, int(causal), scaling, drop_seed, thr, scale, _p(keep_bits), _stream()),
+                                          dh, int(causal), scaling, drop_seed, thr, scale, _p(keep_bits), _p(dq), lddq,
+                                          _stream()),
         "ea_flash_attention_bwd",
     )
     return t1, t2, dBD

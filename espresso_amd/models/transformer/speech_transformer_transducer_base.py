@@ -93,16 +93,20 @@ class SpeechTransformerTransducerModelBase(nn.Module):
             return self.decoder.embed_tokens.weight, self.fc_out_bias
         return self.fc_out.effective_weight(), self.fc_out.bias
 
-    def joint(self, enc_bt, dec_bu, B, T, U1, apply_output_layer=True):
-        """enc_bt bf16 [B*T][C], dec_bu bf16 [B*U1][H] -> bf16 logits [B][T][U1][V] (:276-299)."""
+    def _joint_decoder_branch(self, dec_bu):
+        return F.layer_norm(F.linear(dec_bu, self.proj_decoder.weight, self.proj_decoder.bias), self.laynorm_proj_decoder.weight,
+                            self.laynorm_proj_decoder.bias)
+
+    def joint(self, enc_bt, dec_bu, B, T, U1, apply_output_layer=True, _D=None, _out=None):
+        """enc_bt bf16 [B*T][C], dec_bu bf16 [B*U1][H] -> bf16 logits [B][T][U1][V] (:276-299).
+        (_D: the predictor branch already projected + normalised; _out: (w, b, holder) from F.joint_weight_late — forward())"""
         E = F.layer_norm(F.linear(enc_bt, self.proj_encoder.weight, self.proj_encoder.bias), self.laynorm_proj_encoder.weight,
                          self.laynorm_proj_encoder.bias)
-        D = F.layer_norm(F.linear(dec_bu, self.proj_decoder.weight, self.proj_decoder.bias), self.laynorm_proj_decoder.weight,
-                         self.laynorm_proj_decoder.bias)
+        D = _D if _D is not None else self._joint_decoder_branch(dec_bu)
         if not apply_output_layer:
             raise NotImplementedError("joint features without the output layer are never materialised (B*T*U*J)")
-        w, b = self.fc_out_params()
-        return F.transducer_joint(E, D, w, b, B, T, U1)
+        w, b, late = _out if _out is not None else (self.fc_out_params() + (None,))
+        return F.transducer_joint(E, D, w, b, B, T, U1, late=late)
 
     # ---- inference helpers: the encoder branch of the joint is computed once per utterance batch, the predictor branch
     # once per expansion (espresso/tools/transducer_greedy_decoder.py:163-176 evaluates joint() on one frame at a time)
@@ -126,13 +130,30 @@ class SpeechTransformerTransducerModelBase(nn.Module):
 
     def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
         """-> (logits bf16 [B][T'][U+1][V], encoder_out_lengths [B])  (:221-243)"""
+        dev = src_tokens.device
+        B, U1 = prev_output_tokens.shape
+        if not (F.branch_overlap() and dev.type == "cuda" and torch.is_grad_enabled()):
+            enc = self.encoder(src_tokens, src_lengths)
+            x = enc["_x_bt"][0]
+            dec, _ = self.decoder.extract_features(prev_output_tokens)
+            return self.joint(x, dec.reshape(B * U1, -1), B, x.shape[0] // B, U1), enc["src_lengths"][0]
+        # The predictor network depends on the targets only: it runs on its own stream next to the encoder (5-6 utterances per
+        # product-rule batch leave most of the device idle under either), and autograd runs its backward pass on that stream
+        # too.  Host order: encoder first, predictor second -> the engine issues the predictor's backward first.  The output
+        # layer's weight gradient overlaps the encoder's backward pass the same way (F.joint_weight_late).
+        w, b = self.fc_out_params()
+        out = F.joint_weight_late(w, b) if (w.requires_grad and b is not None) else (w, b, None)
+        cur, side = torch.cuda.current_stream(dev), F.aux_stream(dev, 1)
+        start = cur.record_event()  # the inputs, the updated weights and the cleared accumulator pool are all behind this point
         enc = self.encoder(src_tokens, src_lengths)
         x = enc["_x_bt"][0]
-        B, U1 = prev_output_tokens.shape
-        T = x.shape[0] // B
-        dec, _ = self.decoder.extract_features(prev_output_tokens)
-        logits = self.joint(x, dec.reshape(B * U1, -1), B, T, U1)
-        return logits, enc["src_lengths"][0]
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            dec, _ = self.decoder.extract_features(prev_output_tokens)
+            D = self._joint_decoder_branch(dec.reshape(B * U1, -1))
+        cur.wait_stream(side)
+        D.record_stream(cur)
+        return self.joint(x, None, B, x.shape[0] // B, U1, _D=D, _out=out), enc["src_lengths"][0]
 
     def forward_encoder(self, src_tokens, src_lengths):
         return self.encoder(src_tokens, src_lengths)

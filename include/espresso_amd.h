@@ -70,6 +70,19 @@ typedef struct EaGemmParams {
    * (honouring `accumulate`).  Requires c_f32 and no other epilogue.  kchunk is filled in by the library. */
   int splitk, kchunk;
   void* workspace;
+  /* Relative-position query preparation fused into the QKV projection (fairseq/modules/multihead_attention.py:679-688:
+   * q_with_bias_u = q + pos_bias_u, q_with_bias_v = q + pos_bias_v, later scaled by head_dim ** -0.5).  When q_u != NULL,
+   * columns n < qsplit_n of the product are NOT written to C; the rounded bf16 value q = bf16(alpha * acc + bias[n]) is formed
+   * as usual and  q_u[m][n] = bf16((q + pos_u[n]) * qscale),  q_v[m][n] = bf16((q + pos_v[n]) * qscale)  go to two bf16
+   * [M][ld_q] buffers instead (pos_u / pos_v NULL: zeros; q_v NULL: q_u only) — exactly ea_relpos_q_prep applied to those
+   * columns.  Requires qsplit_n % 128 == 0, N % 8 == 0, batch == 1, no split-K; the other columns take the normal epilogue. */
+  void* q_u;
+  void* q_v;
+  const float* pos_u;
+  const float* pos_v;
+  long ld_q;
+  int qsplit_n;
+  float qscale;
 } EaGemmParams;
 
 int ea_gemm_bf16(const EaGemmParams* p, ea_stream_t stream);
@@ -202,13 +215,16 @@ int ea_flash_keep_bits(void* keep_bits, int H, int B, int T, uint64_t drop_seed,
  *               operand of the pos_proj weight gradient dpp[r] = sum_{b,i} dBD[.,i,r] qv[b,i]
  *   dk, dv    : bf16, row (b*S + j) * lddkv, head h at column h*dh (e.g. the k / v thirds of a packed dqkv buffer)  * ea_flash_attention_bwd `causal`: bit 0 = causal mask; bit 1 = the caller guarantees that the part of every dBD row outside
  * the band [T-1-i, T-1-i+S) is already zero (e.g. the same buffer was filled by a previous call with the same H, B, T, S and not
- * touched since), so the kernel only writes the band. */
+ * touched since), so the kernel only writes the band.
+ *   dq        : optional (NULL, or bf16 [B*T][lddq], head h at column h*dh; qv != NULL only): t1 + t2 with the sum formed in
+ *               fp32 — the gradient of the query projection's output, e.g. the q third of a packed dqkv buffer (without the
+ *               positional term t1 itself is that gradient) */
 int ea_flash_attention_bwd(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldkv,
                            const void* pp, long ldpp, const int* key_len, const void* out, const void* dout, long ldo,
                            const float* lse, float* D, void* t1, void* t2, long ldt, void* dBD, int ld_bd, void* dk,
                            void* dv, long lddkv, int H, int B, int T, int S, int dh, int causal, float scaling,
                            uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* keep_bits,
-                           ea_stream_t stream);
+                           void* dq, long lddq, ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Relative-position attention glue — fairseq/modules/multihead_attention.py:679-688 (q+u, q+v,

@@ -54,6 +54,37 @@ def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, 
     return rel_err(C, ref)
 
 
+def check_gemm_query_split(M=333, C=256, Kin=192, with_v=True, glds=1, seed=0):
+    """The QKV projection's query-split epilogue (EaGemmParams.q_u: columns [0, C) leave as (q + pos_u) * s and (q + pos_v) * s)
+    against the two-step path it replaces — plain projection, then ea_relpos_q_prep: bit-identical q_u / q_v, and the k / v
+    columns of the packed output unchanged."""
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = bf(torch.randn(M, Kin, generator=g)).to(DEV)
+    W = bf(torch.randn(3 * C, Kin, generator=g) * Kin ** -0.5).to(DEV)
+    bias = torch.randn(3 * C, generator=g).to(DEV)
+    u = torch.randn(C, generator=g).to(DEV)
+    v = torch.randn(C, generator=g).to(DEV) if with_v else None
+    s = 0.125
+    old = lib.ea_set_gemm_glds(glds)
+    try:
+        ref = torch.zeros(M, 3 * C, dtype=torch.bfloat16, device=DEV)
+        Kk.gemm(A, W, ref, M, 3 * C, Kin, lda=Kin, ldb=Kin, ldc=3 * C, bias=bias)
+        qu_ref, qv_ref = Kk.relpos_q_prep(ref, 3 * C, u, v, M, C, s, want_qv=with_v)
+        out = torch.full((M, 3 * C), 7.0, dtype=torch.bfloat16, device=DEV)
+        qu = torch.zeros(M, C, dtype=torch.bfloat16, device=DEV)
+        qv = torch.zeros(M, C, dtype=torch.bfloat16, device=DEV) if with_v else None
+        Kk.gemm(A, W, out, M, 3 * C, Kin, lda=Kin, ldb=Kin, ldc=3 * C, bias=bias, qsplit=(qu, qv, u, v, C, C, s))
+        torch.cuda.synchronize()
+    finally:
+        lib.ea_set_gemm_glds(old)
+    return {"qu_equal": bool((qu == qu_ref).all()), "qv_equal": bool((qv == qv_ref).all()) if with_v else True,
+            "kv_equal": bool((out[:, C:] == ref[:, C:]).all()), "q_third_untouched": bool((out[:, :C] == 7.0).all())}
+
+
 def check_conv3x3(Cin=64, Cout=128, sy=2, sx=2, B=2, T=37, F=21, seed=0):
     """Implicit-GEMM 3x3 convolution (forward + BatchNorm sums, data gradient) vs torch conv2d / its autograd on the same bf16
     operands (fp32 CPU): odd T / F (ragged parity classes, padding taps on every border), strides 1 and 2."""
@@ -1013,8 +1044,10 @@ def _check_flash_attention_bwd(K, B, H, T, S, relpos, causal, padded, drop_p, se
     out, lse, bits = K.flash_attention_fwd(qu, qv, k, v, pp, klen, H, B, T, S, C, 2 * C, C, causal=causal, drop_p=drop_p, drop_seed=77,
                                            want_bits=True)
     dkv = torch.full((B * S, 2 * C), float("nan"), dtype=torch.bfloat16, device=dev)
+    dq = torch.full((B * T, C + 8), float("nan"), dtype=torch.bfloat16, device=dev) if relpos else None  # (row pitch != C on purpose)
     t1, t2, dBD = K.flash_attention_bwd(qu, qv, k, v, pp, klen, out, dout, lse, dkv[:, :C], dkv[:, C:], H, B, T, S, C, 2 * C, 2 * C,
-                                        ldpp=C, causal=causal, scaling=scaling, drop_p=drop_p, drop_seed=77, keep_bits=bits)
+                                        ldpp=C, causal=causal, scaling=scaling, drop_p=drop_p, drop_seed=77, keep_bits=bits,
+                                        dq=dq, lddq=C + 8)
     # reference
     leaf = lambda x: x.float().clone().requires_grad_(True) if x is not None else None
     qu_r, qv_r, k_r, v_r, pp_r = leaf(qu), leaf(qv), leaf(k.contiguous()), leaf(v.contiguous()), leaf(pp)
@@ -1039,6 +1072,8 @@ def _check_flash_attention_bwd(K, B, H, T, S, relpos, causal, padded, drop_p, se
     }
     if relpos:
         res["t2"] = rel(t2, qv_r.grad * scaling)
+        res["dq"] = rel(dq[:, :C], (qu_r.grad + qv_r.grad) * scaling)
+        res["dq_pad_untouched"] = bool(torch.isnan(dq[:, C:].float()).all())
         R = 2 * T - 1
         d = dBD.float().view(H, B * T, -1)[:, :, :R]                       # [H][(b,i)][r]
         qvh = qv.float().view(B * T, H, dh).permute(1, 0, 2)               # [H][(b,i)][d]
@@ -1320,6 +1355,52 @@ def check_transducer_loss_step():
                                        blank=crit.blank_idx)
     finite = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
     return {"loss": float(loss), "oracle_loss": float(want), "finite": finite, "sample_size": sample_size}
+
+
+def check_transducer_branch_overlap():
+    """The transducer's multi-stream schedule (predictor network and the output layer's weight gradient on their own streams,
+    functional.set_branch_overlap) against the single-stream schedule: same weights, same batch, same dropout seed -> the
+    same loss and the same gradients up to the order of fp32 atomic adds in the split-K reductions.  Three passes each way
+    (gradients accumulate), so a missing join between streams shows up as a difference."""
+    from espresso_amd import functional as F
+    from espresso_amd.criterions.transducer_loss import TransducerLossCriterion
+
+    g = np.load(os.path.join(GOLD, "ref_conformer_transducer_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    task = _Task(40)
+    feats, lengths, prev = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"])
+    pad, eos = task.target_dictionary.pad(), task.target_dictionary.eos()
+    target = torch.full_like(prev, pad)
+    tl = []
+    for b in range(prev.shape[0]):
+        toks = [int(t) for t in prev[b, 1:] if int(t) != pad]
+        tl.append(len(toks))
+        target[b, : len(toks)] = torch.tensor(toks)
+        target[b, len(toks)] = eos
+    sample = {"net_input": {"src_tokens": feats.to(DEV), "src_lengths": lengths.to(DEV), "prev_output_tokens": prev.to(DEV)},
+              "target": target.to(DEV), "ntokens": int(sum(tl)) + len(tl)}
+    out = {}
+    for mode in (True, False):
+        old = F.set_branch_overlap(mode)
+        try:
+            model = build_tiny_transducer().to(DEV)
+            model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+            crit = TransducerLossCriterion(task)
+            model.train()
+            losses = []
+            for it in range(3):
+                F.set_dropout_seed(100 + it)
+                loss, _, _ = crit(model, sample)
+                loss.backward()
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            out[mode] = (losses, {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            F.set_branch_overlap(old)
+    (la, ga), (lb, gb) = out[True], out[False]
+    worst = max(((float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-20)), n) for n in gb), key=lambda kv: kv[0])
+    return {"loss_rel": max(abs(a - b) / abs(b) for a, b in zip(la, lb)), "worst_grad_rel": worst, "same_params": set(ga) == set(gb),
+            "n_grads": len(ga)}
 
 
 def check_transducer_greedy_decoder():

@@ -35,6 +35,13 @@ def test_gemm_epilogues():
     assert G.check_gemm(200, 136, 72, True, False, bias=True, act="relu", resid=True, variant=2) < 1e-2
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(with_v=False), dict(glds=0), dict(M=6128, C=512, Kin=512), dict(M=70, C=128, Kin=64)])
+def test_gemm_query_split_epilogue(kw):
+    """QKV projection writing the attention kernels' query operands directly == projection + ea_relpos_q_prep, bit for bit"""
+    r = G.check_gemm_query_split(**kw)
+    assert all(r.values()), r
+
+
 def test_gemm_splitk():
     assert G.check_gemm(130, 200, 5000, True, True, c_f32=True, splitk=7) < 2e-3
     assert G.check_gemm(64, 576, 20011, True, True, c_f32=True, splitk=33, batch=1) < 2e-3
@@ -297,6 +304,7 @@ def test_flash_attention_backward(kw):
     assert r.pop("finite"), r
     if "dBD_pad_zero" in r:
         assert r.pop("dBD_pad_zero"), r
+        assert r.pop("dq_pad_untouched"), r
     for name, err in r.items():
         assert err <= 2e-2, (name, r)
 
@@ -328,6 +336,14 @@ def test_lstm_persistent_kernels_vs_stepwise_path(shape):
     assert r.pop("barrier_timeouts") == 0, r
     for k, v in r.items():
         assert v < 1e-2, (k, r)
+
+
+def test_transducer_branch_overlap_equals_single_stream_schedule():
+    """predictor network + joint weight gradient on their own streams: results equal the single-stream schedule's"""
+    r = G.check_transducer_branch_overlap()
+    assert r["same_params"] and r["n_grads"] > 50, r
+    assert r["loss_rel"] < 1e-6, r
+    assert r["worst_grad_rel"][0] < 2e-3, r
 
 
 def test_transducer_vs_reference_fixture():

@@ -1,8 +1,8 @@
 """Training throughput of BASELINE config 4 (LibriSpeech Conformer-16 transducer, RNN-T loss) on one GPU: batches by the
 reference's product rule (sum over the batch of padded src_frames x tgt_len <= 590000, <= 16 utterances:
 examples/asr_librispeech/config/conformer_transducer_librispeech.yaml:28-50, espresso/data/asr_dataset.py:369-382),
-V = 5004, on-GPU fbank + SpecAugment, dropout 0.1, Adam.  Prints one JSON line (audio-hours/s); diagnostic tool, the
-contract metric is bench.py (config 3)."""
+V = 5004, on-GPU fbank + SpecAugment, dropout 0.1, Adam, two batches per update (the recipe's `update_freq: [2]`, :50).
+Prints one JSON line (audio-hours/s); diagnostic tool, the contract metric is bench.py (config 3)."""
 import argparse, json, os, sys, time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,9 +12,10 @@ import torch
 VOCAB = 5004
 
 
-def run(steps=8, warmup=3, max_product=590000, max_sentences=16):
-    """-> the result dict (also what bench.py embeds as its `config4_transducer` block)"""
+def run(steps=8, warmup=3, max_product=590000, max_sentences=16, update_freq=2):
+    """-> the result dict (also what bench.py embeds as its `config4_transducer` block); a step = one update = `update_freq` batches"""
     args = argparse.Namespace(steps=steps, warmup=warmup, max_product=max_product, max_sentences=max_sentences)
+    uf = max(1, int(update_freq))
     dev = torch.device("cuda:0")
     import espresso_amd  # noqa: F401
     from espresso_amd.data import synthetic
@@ -58,7 +59,7 @@ def run(steps=8, warmup=3, max_product=590000, max_sentences=16):
         mf, mt = nf, nt
     if cur:
         batches.append(np.array(cur))
-    need = args.steps + args.warmup
+    need = (args.steps + args.warmup) * uf
     # stratified over the length-sorted batch list (short many-utterance batches ... long single-utterance batches), then shuffled
     idx = np.linspace(0, len(batches) - 1, need).round().astype(int)
     batches = [batches[i] for i in idx]
@@ -83,17 +84,20 @@ def run(steps=8, warmup=3, max_product=590000, max_sentences=16):
     task.build_frontend(dev)
     task.begin_epoch(1)
     for i in range(args.warmup):
-        trainer.train_step([samples[i]])
+        trainer.train_step(samples[i * uf:(i + 1) * uf])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, need):
-        trainer.train_step([samples[i]])
+    for i in range(args.warmup, args.warmup + args.steps):
+        trainer.train_step(samples[i * uf:(i + 1) * uf])
+    host = time.perf_counter() - t0  # nothing in the loop waits for the device: this is what the host needs to enqueue the steps
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    audio = sum(s["audio_seconds"] for s in samples[args.warmup:])
-    nodes = [int(s["target"].shape[0]) for s in samples[args.warmup:]]
+    audio = sum(s["audio_seconds"] for s in samples[args.warmup * uf:])
+    nodes = [int(s["target"].shape[0]) for s in samples[args.warmup * uf:]]
     return ({"metric": "audio-hours/sec training (LibriSpeech Conformer-16 transducer, RNN-T)", "value": audio / 3600 / el,
-                      "ms_per_step": el * 1e3 / args.steps, "steps": args.steps, "utts_per_step": float(np.mean(nodes)),
+                      "ms_per_step": el * 1e3 / args.steps, "steps": args.steps, "update_freq": uf,
+                      "ms_per_batch": el * 1e3 / args.steps / uf,
+                      "host_enqueue_ms_per_step": host * 1e3 / args.steps, "utts_per_batch": float(np.mean(nodes)),
                       "audio_seconds_per_step": audio / args.steps, "loss_per_sentence": float(trainer._stats[1] / max(1.0, float(trainer._stats[0]))),
                       "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "dtype": "bf16", "data": "synthetic 16 kHz"})
 
@@ -104,8 +108,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--max-product", type=int, default=590000)
     ap.add_argument("--max-sentences", type=int, default=16)
+    ap.add_argument("--update-freq", type=int, default=2)
+    ap.add_argument("--no-branch-overlap", action="store_true", help="A/B: predictor and joint weight gradient on the main stream")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.warmup, a.max_product, a.max_sentences)))
+    if a.no_branch_overlap:
+        from espresso_amd import functional as F
+        F.set_branch_overlap(False)
+    print(json.dumps(run(a.steps, a.warmup, a.max_product, a.max_sentences, a.update_freq)))
 
 
 if __name__ == "__main__":
