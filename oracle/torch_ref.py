@@ -465,6 +465,16 @@ def lstm_predictor(prev_tokens, sd, p="decoder.", residual=False, pad_idx=1, sta
     return y, state
 
 
+def lstm_lm(tokens, sd, pad_idx=0, residual=False):
+    """espresso/models/lstm_lm.py:88-252 (`lstm_lm_espresso`): SpeechLSTMDecoder without attention over the whole padded token
+    matrix, then the output projection (tied to the embedding or `fc_out`).  tokens (B,U) -> logits (B,U,V)."""
+    sdd = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() and v.dtype != torch.float32 else v) for k, v in sd.items()}
+    y, _ = lstm_predictor(tokens, sdd, p="decoder.", residual=residual, pad_idx=pad_idx)
+    if "decoder.fc_out.weight" in sdd:
+        return _lin(y, sdd["decoder.fc_out.weight"], sdd["decoder.fc_out.bias"])
+    return _lin(y, sdd["decoder.embed_tokens.weight"])
+
+
 def transducer_joint(enc_btc, dec_buh, sd):
     """speech_transformer_transducer_base.py:276-299 with the weight-normed fc_out (weight = g * v / ||v||_row)."""
     # HIP: both projections, their LayerNorms, relu(E + D), the effective (weight-normed) matrix and the logits are stored in bf16
@@ -525,22 +535,24 @@ def speech_lstm_encoder(feats, lengths, sd, p="encoder.", residual=False, traini
         if (q + "weight_ih_l0_reverse") in enc_sd:
             outs.append(packed_lstm_direction(x, out_len, enc_sd, q, "_reverse", True))
         y = torch.cat(outs, -1)
-        x = y + x if (residual and i > 0) else y
+        x = _r(y + x) if (residual and i > 0) else y  # HIP: bf16 hidden states, bf16 residual sum
         i += 1
     return x, out_len
 
 
 def bahdanau_attention(query, value, sd, p, key_padding_mask=None):
     """espresso/modules/speech_attention.py:66-87 (normalize=True).  query (B,Hq); value (T,B,Cv); mask (T,B)."""
-    pq = F.linear(query, sd[p + "query_proj.weight"]).unsqueeze(0)
-    key = F.linear(value, sd[p + "value_proj.weight"])
+    # HIP (csrc/lstm.hip bahdanau kernels): the two projections are stored in bf16, scores / softmax / the weighted sum run in
+    # fp32 on those, the context is stored in bf16 (`_r` / `_lin`: plain fp32 outside bf16_emulation)
+    pq = _r(_lin(query, sd[p + "query_proj.weight"])).unsqueeze(0)
+    key = _r(_lin(value, sd[p + "value_proj.weight"]))
     v = sd[p + "v"]
     nv = sd[p + "g"] * v / torch.norm(v)
     scores = (nv * torch.tanh(pq + key + sd[p + "b"])).sum(2)
     if key_padding_mask is not None:
         scores = scores.masked_fill(key_padding_mask, float("-inf"))
     a = torch.softmax(scores, 0)
-    return (a.unsqueeze(2) * value).sum(0), a
+    return _r((a.unsqueeze(2) * value).sum(0)), a
 
 
 def speech_lstm_decoder(prev_tokens, enc_tbc, enc_lengths, sd, p="decoder.", residual=True, pad_idx=1, state=None):
@@ -548,7 +560,7 @@ def speech_lstm_decoder(prev_tokens, enc_tbc, enc_lengths, sd, p="decoder.", res
     T, B, Cv = enc_tbc.shape
     mask = torch.arange(T).unsqueeze(1) >= enc_lengths.unsqueeze(0)
     mask = mask if bool(mask.any()) else None
-    x = F.embedding(prev_tokens, sd[p + "embed_tokens.weight"], padding_idx=pad_idx).transpose(0, 1)
+    x = _r(F.embedding(prev_tokens, sd[p + "embed_tokens.weight"], padding_idx=pad_idx)).transpose(0, 1)
     nl = 0
     while (p + f"layers.{nl}.weight_ih") in sd:
         nl += 1
@@ -566,17 +578,17 @@ def speech_lstm_decoder(prev_tokens, enc_tbc, enc_lengths, sd, p="decoder.", res
                 ctx, _ = bahdanau_attention(h, enc_tbc, sd, p + "attention.", mask)
             inp = torch.cat((h, ctx), 1)
             if prev_in is not None:
-                inp = torch.cat((inp[:, :H] + prev_in, inp[:, H:]), 1)
+                inp = torch.cat((_r(inp[:, :H] + prev_in), inp[:, H:]), 1)
             state["h"][i], state["c"][i] = h, c
         state["feed"] = ctx
         outs.append(inp)
     y = torch.stack(outs, 0).transpose(0, 1)
     if (p + "additional_fc.weight") in sd:
-        y = F.linear(y, sd[p + "additional_fc.weight"], sd[p + "additional_fc.bias"])
-    if (p + "fc_out.weight") in sd:
-        y = F.linear(y, sd[p + "fc_out.weight"], sd[p + "fc_out.bias"])
+        y = _r(_lin(y, sd[p + "additional_fc.weight"], sd[p + "additional_fc.bias"]))
+    if (p + "fc_out.weight") in sd:  # (HIP: fp32 logits from bf16 operands)
+        y = _lin(y, sd[p + "fc_out.weight"], sd[p + "fc_out.bias"])
     else:
-        y = F.linear(y, sd[p + "embed_tokens.weight"])
+        y = _lin(y, sd[p + "embed_tokens.weight"])
     return y, state
 
 

@@ -1595,6 +1595,31 @@ def check_speech_lstm_vs_reference():
     res["worst_l2"] = max(rest.items(), key=lambda kv: kv[1])
     res["worst_l2_frontend"] = max(fe.items(), key=lambda kv: kv[1])
     res["worst_scale"] = max(((k, v) for k, v in scale.items() if not k.startswith("encoder.pre_encoder")), key=lambda kv: abs(kv[1] - 1.0))
+    # ---- the same pass on the bf16-emulating oracle (rounds where the HIP path stores: hidden states, attention projections,
+    # contexts, residual sums, additional_fc output; fp32 gates / cell state / scores / logits) ----
+    from oracle import torch_ref
+
+    sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    with torch_ref.bf16_emulation(True, flash=False):
+        el, _, _ = torch_ref.speech_lstm(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"]), sde,
+                                         enc_residual=True, dec_residual=True, pad_idx=0, training=True, update={})
+        le, _ = torch_ref.label_smoothed_nll(el.reshape(-1, el.shape[-1]), torch.from_numpy(g["target"]).reshape(-1), 0.1, 0)
+        le.backward()
+    res["train_logits_vs_emulation"] = float((lo.detach().float().cpu() - el.detach())[valid].abs().max())
+    res["loss_vs_emulation_rel"] = abs(float(loss) - float(le)) / float(le)
+    l2e = {}
+    for n, p in model.named_parameters():
+        if n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias"):
+            continue
+        r = sde[n].grad
+        l2e[n] = float((p.grad.float().cpu() - r).norm() / (r.norm() + 1e-12))
+    fe = {k: v for k, v in l2e.items() if k.startswith("encoder.pre_encoder")}
+    rest = {k: v for k, v in l2e.items() if not k.startswith("encoder.pre_encoder")}
+    res["emu_worst_l2"] = max(rest.items(), key=lambda kv: kv[1])
+    res["emu_median_l2"] = float(np.median(list(rest.values())))
+    res["emu_worst_l2_frontend"] = max(fe.items(), key=lambda kv: kv[1])
+    # how far the emulation itself is from the fp32 fixture (what bf16 storage alone does to these gradients)
+    res["emu_vs_fp32_worst_l2"] = max(((n, float((sde[n].grad - grads[n]).norm() / (grads[n].norm() + 1e-12))) for n in rest), key=lambda kv: kv[1])
     return res
 
 
@@ -2475,7 +2500,24 @@ def check_lstm_lm_training_vs_reference():
             err = float((p.grad.float() - rg).abs().max() / rg.abs().max().clamp_min(1e-6))
             if err > worst:
                 worst, worst_name = err, n
-        res[tag] = {"logits_abs": float((logits.float() - ref_logits)[valid].abs().max()), "logits_scale": float(ref_logits[valid].abs().max()),
+        # the same step on the bf16-emulating oracle (oracle/torch_ref.py lstm_lm, pinned to this fixture in fp32 by the CPU suite)
+        from oracle import torch_ref
+
+        sde = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        with torch_ref.bf16_emulation(True, flash=False):
+            el = torch_ref.lstm_lm(src.cpu(), sde, pad_idx=int(g["pad"]))
+            lp = torch.log_softmax(el.float(), -1)
+            le = -(lp.gather(-1, target.cpu().unsqueeze(-1)).squeeze(-1) * valid.cpu()).sum()
+            le.backward()
+        emu_worst, emu_name = 0.0, None
+        for n, p in lm.named_parameters():
+            r = sde[n].grad
+            err = float((p.grad.float().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-6))
+            if err > emu_worst:
+                emu_worst, emu_name = err, n
+        res[tag] = {"emu_grad_rel_worst": emu_worst, "emu_grad_worst_name": emu_name,
+                    "emu_logits_abs": float((logits.float().cpu() - el.detach())[valid.cpu()].abs().max()),
+                    "logits_abs": float((logits.float() - ref_logits)[valid].abs().max()), "logits_scale": float(ref_logits[valid].abs().max()),
                     "loss_rel": abs(float(loss) - float(g[tag + "::loss"])) / float(g[tag + "::loss"]), "sample_size": sample_size,
                     "ntokens": sample["ntokens"], "grad_rel_worst": worst, "grad_worst_name": worst_name,
                     "n_params": sum(1 for _ in lm.parameters())}

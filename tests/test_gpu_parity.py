@@ -420,6 +420,11 @@ def test_speech_lstm_vs_reference_fixture():
     assert r["worst_l2"][1] < 0.1, r
     assert r["worst_l2_frontend"][1] < 0.5, r   # same bound as the Conformer/Transformer encoder tests use for the conv/BN stack
     assert abs(r["worst_scale"][1] - 1.0) < 5e-2, r
+    # against the bf16-emulating oracle (rounds at the HIP storage points; measured: logits 3.5e-3, worst gradient 1.2 % L2,
+    # median 0.5 %, conv/BN front-end 3.3 % — the fp32 fixture itself is 4 % / 26 % away from the emulation)
+    assert r["train_logits_vs_emulation"] < 8e-3 and r["loss_vs_emulation_rel"] < 5e-4, r
+    assert r["emu_worst_l2"][1] < 3e-2 and r["emu_median_l2"] < 1.2e-2, r
+    assert r["emu_worst_l2_frontend"][1] < 8e-2, r
 
 
 def test_speech_lstm_beam_search_vs_reference():
@@ -501,7 +506,9 @@ def test_lstm_lm_training_step_vs_reference():
     for tag, v in r.items():
         assert v["logits_abs"] < 2e-2 * max(1.0, v["logits_scale"]), (tag, v)   # bf16 GEMMs vs the reference's fp32
         assert v["loss_rel"] < 1e-2 and v["sample_size"] == v["ntokens"] == 20, (tag, v)
-        assert v["grad_rel_worst"] < 5e-2, (tag, v)
+        assert v["grad_rel_worst"] < 1.5e-2, (tag, v)   # measured 0.5 % of each gradient's range against the reference's fp32 run
+        # bf16-emulating oracle: same logits (the hidden states round identically), gradients 0.3-0.5 % (measured)
+        assert v["emu_logits_abs"] < 1e-3 and v["emu_grad_rel_worst"] < 1.2e-2, (tag, v)
 
 
 def test_language_model_recipe_through_the_training_cli(tmp_path):

@@ -235,6 +235,27 @@ def test_speech_lstm_restatement_matches_reference(golden_dir):
         assert float((leaf[k].grad - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max())), k
 
 
+def test_lstm_lm_restatement_matches_reference(golden_dir):
+    """oracle/torch_ref.py lstm_lm (embedding -> LSTMCell stack over the padded token matrix -> tied / untied output projection)
+    vs the reference's lstm_lm_espresso training step: logits, summed NLL and every parameter gradient (fixture from
+    oracle/gen_golden.py lmtrain)."""
+    g = np.load(os.path.join(golden_dir, "ref_lstm_lm_train_tiny.npz"))
+    pad = int(g["pad"])
+    for tag in ("tied", "untied"):
+        sd = {k[len(tag) + 6:]: torch.from_numpy(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith(tag + "::sd::")}
+        src, target = torch.from_numpy(g[tag + "::src"]), torch.from_numpy(g[tag + "::target"])
+        lo = torch_ref.lstm_lm(src, sd, pad_idx=pad)
+        valid = target.ne(pad)
+        assert float((lo - torch.from_numpy(g[tag + "::logits"]))[valid].abs().max()) < 1e-5, tag
+        lp = torch.log_softmax(lo.float(), -1)
+        loss = -(lp.gather(-1, target.unsqueeze(-1)).squeeze(-1) * valid).sum()
+        assert float(loss.detach()) == pytest.approx(float(g[tag + "::loss"]), rel=1e-5), tag
+        loss.backward()
+        for k, v in sd.items():
+            ref = torch.from_numpy(g[f"{tag}::grad::{k}"])
+            assert float((v.grad - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (tag, k)
+
+
 def test_incremental_decode_restatement_matches_full_forward(golden_dir):
     """oracle/decode_ref.py (K/V-cached one-token-per-step decoder used by bench.py's CPU decode baseline) reproduces the
     teacher-forced log-probs of the full-forward decoder restatement, which is itself pinned to the reference's outputs."""

@@ -12,6 +12,7 @@ DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
 echo "db=$DB"
 python $R/tools/rocpd_summary.py $DB $R/gpurun_out/${TAG}_summary.txt > /dev/null
 python $R/tools/gap_analysis.py $DB 8 > $R/gpurun_out/${TAG}_gaps.txt 2>&1
+python $R/tools/stream_analysis.py $DB 8 > $R/gpurun_out/${TAG}_streams.txt 2>&1
 tail -1 $OUT.log | cut -c1-300
 head -45 $R/gpurun_out/${TAG}_summary.txt | cut -c1-200
 head -12 $R/gpurun_out/${TAG}_gaps.txt
