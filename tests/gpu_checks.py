@@ -804,9 +804,35 @@ def check_beam_search_vs_reference(fixture="ref_transformer_encdec_tiny"):
     for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)),
                     ("b3_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, eos_factor=1.5)),
                     ("b1", dict(beam_size=1, max_len_a=0.0, max_len_b=12))):
-        gen = SequenceGenerator([model], d, **kw)
+        from espresso_amd.sequence_generator import HipBeamSearch
+
+        class Recording(HipBeamSearch):
+            """records, per sentence, the smallest score gap the search ever cut through: between the last candidate inside the
+            beam and the first one outside it (all candidates, and non-EOS candidates only).  A search whose gaps all exceed the
+            bf16 noise of the scores makes the same decisions as the reference's fp32 run."""
+
+            def __init__(self, eos, beam):
+                self.eos, self.beam, self.min_gap, self.bsz0 = eos, beam, None, None
+
+            def step(self, step, lprobs, prev_scores, bsz, beam):
+                cs, ct, cb = super().step(step, lprobs, prev_scores, bsz, beam)
+                if self.bsz0 is None:
+                    self.bsz0, self.min_gap = bsz, [float("inf")] * bsz
+                if bsz == self.bsz0 and cs.shape[1] > beam:  # (after the batch shrinks rows no longer map to sentences: stop)
+                    c, t = cs.cpu(), ct.cpu()
+                    for i in range(bsz):
+                        gap = float(c[i, beam - 1] - c[i, beam])
+                        live = [float(x) for x, tk in zip(c[i], t[i]) if int(tk) != self.eos and x > -1e30]
+                        if len(live) > beam:
+                            gap = min(gap, live[beam - 1] - live[beam])
+                        if gap == gap:
+                            self.min_gap[i] = min(self.min_gap[i], gap)
+                return cs, ct, cb
+
+        rec = Recording(d.eos(), kw["beam_size"])
+        gen = SequenceGenerator([model], d, search=rec, **kw)
         hyps = gen.generate([model], sample)
-        top_equal, any_rank_equal, score_err = [], [], 0.0
+        top_equal, any_rank_equal, score_err, clear = [], [], 0.0, []
         for b, hl in enumerate(hyps):
             ref_tokens = []
             hi = 0
@@ -814,13 +840,18 @@ def check_beam_search_vs_reference(fixture="ref_transformer_encdec_tiny"):
                 ref_tokens.append((g[f"beam::{tag}::{b}::{hi}::tokens"].tolist(), float(g[f"beam::{tag}::{b}::{hi}::score"])))
                 hi += 1
             top_equal.append(hl[0]["tokens"].tolist() == ref_tokens[0][0])
+            # the reference's 1-best is "clear" when its (length-normalised) score leads its own runner-up by more than twice the
+            # score tolerance of this comparison (3e-2): then no bf16 realisation may rank another hypothesis first
+            margin = ref_tokens[0][1] - ref_tokens[1][1] if len(ref_tokens) > 1 else float("inf")
+            clear.append((round(margin, 4), margin > 0.06, top_equal[-1]))
             refset = {tuple(t): s for t, s in ref_tokens}
             any_rank_equal.append(sum(tuple(h["tokens"].tolist()) in refset for h in hl) / len(hl))
             for h in hl:
                 k = tuple(h["tokens"].tolist())
                 if k in refset:
                     score_err = max(score_err, abs(float(h["score"]) - refset[k]))
-        res[tag] = {"top1_tokens_equal": top_equal, "frac_hyps_in_reference_beam": any_rank_equal, "score_abs": score_err}
+        res[tag] = {"top1_tokens_equal": top_equal, "frac_hyps_in_reference_beam": any_rank_equal, "score_abs": score_err,
+                    "ref_margin_clear_equal": clear, "min_cut_gap": [round(x, 4) for x in rec.min_gap]}
     # Force-decode the reference's best hypotheses through the INCREMENTAL path (K/V caches, one-query attention) and
     # compare per-position log-probs with the reference generator's positional scores.
     ref_best = [torch.from_numpy(g[f"beam::b3::{b}::0::tokens"]) for b in range(3)]

@@ -228,11 +228,21 @@ def test_beam_search_vs_reference_generator(fixture):
     assert r["greedy_clear_margin_steps"] >= 5 and r["greedy_clear_margin_agree"] == 1.0, r
     if fixture.endswith("dh64"):  # no near-ties on this fixture's greedy paths: the decoded sequences themselves are identical
         assert all(r["b1"]["top1_tokens_equal"]), r
-    # The random-weight fixture has competing hypotheses 0.02 apart in normalised score (see oracle/gen_golden.py output), so
-    # token-level agreement of the beams is reported, not asserted; beam-search SEMANTICS are pinned by the scripted
+    # Token-level agreement of the beams, asserted wherever the search is DEFINED at this precision: the generator records the
+    # smallest score gap it ever cut through (last candidate kept vs first one dropped, per sentence); a sentence whose gaps
+    # all exceed twice the score error observed on hypotheses both generators found (and 0.008) must produce exactly the
+    # reference's hypotheses.  On these random-weight fixtures some sentences cut through exact ties (gap 0.000: tokens 14 and
+    # 15 tie for the third beam slot at step 0) — those are reported only; beam-search SEMANTICS are pinned by the scripted
     # known-answer tests (tests/test_sequence_generator.py).
+    n_defined = 0
     for tag in ("b3", "b3_eosf", "b1"):
         assert r[tag]["score_abs"] < 3e-2, r
+        thr = max(2.0 * r[tag]["score_abs"], 8e-3)
+        for b, gap in enumerate(r[tag]["min_cut_gap"]):
+            if gap > thr:
+                n_defined += 1
+                assert r[tag]["top1_tokens_equal"][b] and r[tag]["frac_hyps_in_reference_beam"][b] == 1.0, (tag, b, gap, r[tag])
+    assert n_defined >= 2, r   # (measured: 2 of 9 searches on the tiny fixture, 5 of 9 on dh64)
 
 
 def test_ensemble_beam_search_vs_reference_generator():
