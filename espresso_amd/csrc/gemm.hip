@@ -855,6 +855,247 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const EaWgradGroup g, 
   }
 }
 
+
+// ---- grouped weight gradients, direct-to-LDS + transposing reads ----------------------------------------------------------
+// Same contract as wgrad_group_kernel for problems whose tiles are whole (N % BM_ == 0, K % 128 == 0, 16-byte aligned rows).
+// Both operand tiles are [64 reduction rows][BM_ or 128 columns] AS THEY LIE IN MEMORY: global_load_lds moves them (no staging
+// registers, no register transpose, no ds_write), and the MFMA fragments — 8 consecutive reduction indices for one column —
+// come out of ds_read_b64_tr_b16 (lane (g, j) passes the address of [8g + (j>>2)][c + 4(j&3)] and receives
+// [8g + 0..3][c + j]; a second read 4 rows down completes the fragment).  A wave instruction of the load fills 1 KB = 4 (8)
+// image rows; the 16-byte slot s of row r holds source slot s ^ f(r), f chosen so that the 8 rows x 32 bytes a half-wave
+// reads hit 64 different banks (lane model + bank check: tools/emu_wgrad_tr.py, tests/test_kernel_models.py).  Rows past M
+// are fetched from a zero page.  The bias gradient is one more MFMA per A fragment against a fragment of ones.
+__device__ __attribute__((aligned(256))) unsigned char g_wgrad_zero_page[256];
+
+__device__ __forceinline__ int wg_f256(int r) { return ((r & 3) | ((r >> 1) & 4)) << 1; }
+__device__ __forceinline__ int wg_f128(int r) { return (((r >> 1) & 1) | ((r >> 2) & 2)) << 1; }
+// transposing reads from inline asm with their own wait (through the builtin hipcc drains vmcnt — the prefetch — first)
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void wg_trr16(const uint32_t (&ad)[4], uint2 (&o)[16]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%20\n\tds_read_b64_tr_b16 %1, %16 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %2, %16 offset:%22\n\tds_read_b64_tr_b16 %3, %16 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %4, %17 offset:%20\n\tds_read_b64_tr_b16 %5, %17 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %6, %17 offset:%22\n\tds_read_b64_tr_b16 %7, %17 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %8, %18 offset:%20\n\tds_read_b64_tr_b16 %9, %18 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %10, %18 offset:%22\n\tds_read_b64_tr_b16 %11, %18 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %12, %19 offset:%20\n\tds_read_b64_tr_b16 %13, %19 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %14, %19 offset:%22\n\tds_read_b64_tr_b16 %15, %19 offset:%23\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]),
+        "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
+      : "memory");
+}
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void wg_trr8(const uint32_t (&ad)[2], uint2 (&o)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %6, %9 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(ad[0]), "v"(ad[1]), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
+      : "memory");
+}
+__device__ __forceinline__ bf16x8_t wg_cat(uint2 lo, uint2 hi) {
+  const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+template <int BM_, int NST>
+__global__ __launch_bounds__(256, BM_ == 64 ? 3 : 2) void wgrad_group_tr_kernel(const EaWgradGroup g, const WgradTable tb) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];  // the ONLY LDS object (ring, then the fp32 output tile)
+  constexpr int NJ = BM_ == 128 ? 4 : 2;
+  constexpr int PA = BM_ * 2, PB = 256;                 // image row pitches (bytes)
+  constexpr int A_BYTES = 64 * PA, STAGE = A_BYTES + 64 * PB;
+  constexpr int NA = BM_ / 32, NB = 4;                  // load instructions per wave and stage
+  constexpr int SPR_A = PA / 16, RPI_A = 1024 / PA;     // 16-byte slots per A row, A rows per load instruction
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = BM_ == 128 ? (wave >> 1) : 0;
+  const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
+
+  int pi = 0;
+  const int total = gridDim.x, xcd = blockIdx.x & 7, xq = total >> 3, xr = total & 7;
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);  // see wgrad_group_kernel
+  while (pi + 1 < g.count && bid >= tb.start[pi + 1]) ++pi;
+  const EaWgradProblem P = g.p[pi];
+  const int local = bid - tb.start[pi];
+  const int tx = tb.tiles_x[pi];
+  const int tile_y = local / tx, tile_x = local - tile_y * tx;
+  const int R = P.N, Cn = P.K, Kr = P.M;
+  const int m0 = tile_y * BM_, n0 = tile_x * BN;
+  const long lda = P.ld_dy, ldb = P.ld_x;
+  const int nk = (Kr + BK - 1) / BK;
+
+  f32x4_t acc[4][NJ], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = P.dbias != nullptr && tile_x == 0;
+
+  // per-lane source pointers of this wave's load instructions (advance by 64 rows per stage)
+  const bf16_t* ap[NA];
+  const bf16_t* bp[NB];
+  int arow[NA], brow[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (wave + 4 * i) * RPI_A + lane / SPR_A, slot = lane % SPR_A;
+    arow[i] = row;
+    ap[i] = reinterpret_cast<const bf16_t*>(P.dy) + (long)row * lda + m0 + 8 * (slot ^ (BM_ == 128 ? wg_f256(row) : wg_f128(row)));
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (wave + 4 * i) * 4 + (lane >> 4), slot = lane & 15;
+    brow[i] = row;
+    bp[i] = reinterpret_cast<const bf16_t*>(P.x) + (long)row * ldb + n0 + 8 * (slot ^ wg_f256(row));
+  }
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_wgrad_zero_page) + (lane & 15) * 8;
+  auto issue = [&](int stage, int kt) {
+    char* base = dsm + stage * STAGE + wave * 1024;
+    const long roff = (long)kt * BK;
+    if ((kt + 1) * BK <= Kr) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + roff * lda), (lptr_t)(base + i * 4096), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + roff * ldb), (lptr_t)(base + A_BYTES + i * 4096), 16, 0, 0);
+    } else {  // last, partial stage: rows past M contribute zeros
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(kt * BK + arow[i] < Kr ? ap[i] + roff * lda : zero), (lptr_t)(base + i * 4096), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(kt * BK + brow[i] < Kr ? bp[i] + roff * ldb : zero), (lptr_t)(base + A_BYTES + i * 4096), 16,
+                                         0, 0);
+    }
+  };
+  // fragment addresses inside a stage (the swizzle term does not depend on the +4-row / +32-row immediates)
+  const int g4 = lane >> 4, lj = lane & 15, le = lj >> 2, lq = lj & 3, row0 = 8 * g4 + le;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)dsm;
+  uint32_t adA[4], adB[NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    adA[i] = lds0 + row0 * PA + (((((wm * 64 + 16 * i) >> 3) + (lq >> 1)) ^ (BM_ == 128 ? wg_f256(row0) : wg_f128(row0))) << 4) + (lq & 1) * 8;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    adB[j] = lds0 + A_BYTES + row0 * PB + (((((wcol + 16 * j) >> 3) + (lq >> 1)) ^ wg_f256(row0)) << 4) + (lq & 1) * 8;
+  const uint4 ones_u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue(s, s);
+  int stage = 0, fill = NST - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (NST > 2 && kt + NST - 2 < nk) {
+      if ((NST - 2) * (NA + NB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if ((NST - 2) * (NA + NB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // tile kt is in LDS for every wave; everyone is done reading the stage that is refilled next
+    if (kt + NST - 1 < nk) issue(fill, kt + NST - 1);
+    const uint32_t so = (uint32_t)(stage * STAGE);
+    uint32_t a4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] = adA[i] + so;
+    uint2 oa[16];
+    wg_trr16<0, 4 * PA, 32 * PA, 36 * PA>(a4, oa);
+    bf16x8_t bfr[2][NJ];
+    if constexpr (BM_ == 128) {
+      uint32_t b4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b4[j] = adB[j] + so;
+      uint2 ob[16];
+      wg_trr16<0, 4 * PB, 32 * PB, 36 * PB>(b4, ob);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[ks][j] = wg_cat(ob[j * 4 + 2 * ks], ob[j * 4 + 2 * ks + 1]);
+    } else {
+      uint32_t b2[2] = {adB[0] + so, adB[1] + so};
+      uint2 ob[8];
+      wg_trr8<0, 4 * PB, 32 * PB, 36 * PB>(b2, ob);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[ks][j] = wg_cat(ob[j * 4 + 2 * ks], ob[j * 4 + 2 * ks + 1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8_t af = wg_cat(oa[i * 4 + 2 * ks], oa[i * 4 + 2 * ks + 1]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af),
+              __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[ks][j]), acc[i][j], 0, 0, 0);
+        if (do_bias)
+          accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af),
+                                                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones), accb[i], 0, 0,
+                                                            0);
+      }
+    }
+    stage = stage + 1 == NST ? 0 : stage + 1;
+    fill = fill + 1 == NST ? 0 : fill + 1;
+  }
+
+  if (do_bias && lj == 0 && wcol == 0) {  // every output row of the tile sits in column 0 of exactly one wave's bias accumulators
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = m0 + wm * 64 + i * 16 + g4 * 4 + r;
+        if (n < R) P.dbias[n] += accb[i][r];
+      }
+  }
+  float* sC = reinterpret_cast<float*>(dsm);
+  const bool vec_ok = (P.ldw & 3) == 0 && (((uintptr_t)P.dW) & 15) == 0;
+#pragma unroll
+  for (int half = 0; half < BM_ / 64; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sC[(i * 16 + g4 * 4 + r) * BN + wcol + j * 16 + lj] = acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int rl = pass * 8 + (tid >> 5);
+      const int m = m0 + half * 64 + rl;
+      const int n = n0 + (tid & 31) * 4;
+      if (m < R && n < Cn) {
+        const float4 x = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 31) * 4);
+        float* C = P.dW + (long)m * P.ldw + n;
+        if (vec_ok && n + 4 <= Cn) {
+          float4 c = *reinterpret_cast<const float4*>(C);
+          c.x += x.x; c.y += x.y; c.z += x.z; c.w += x.w;
+          *reinterpret_cast<float4*>(C) = c;
+        } else {
+          const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < Cn) C[e] += v[e];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- optional live profiling of the dominant kernel (bench.py roofline): HIP events around every launch on
@@ -1053,6 +1294,12 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   return EA_CHECK_LAUNCH();
 }
 
+static int g_wgrad_tr = [] { const char* e = getenv("EA_WGRAD_TR"); return e ? atoi(e) : 1; }();
+extern "C" int ea_set_wgrad_transposing_reads(int on) {
+  const int old = g_wgrad_tr;
+  g_wgrad_tr = on;
+  return old;
+}
 // All weight / bias gradients of one layer in one launch (see wgrad_group_kernel).
 extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
   const EaWgradGroup& g = *gp;
@@ -1090,8 +1337,26 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
     pr.M = total; pr.N = g.count; pr.K = g.p[0].M; pr.batch = 1; pr.a_ks = 1; pr.b_ks = 1; pr.splitk = 1; pr.bm64 = bm64; pr.epi = 128;
     hipEventRecord(pr.e0, stream);
   }
-  if (bm64) hipLaunchKernelGGL((wgrad_group_kernel<64>), dim3(total), dim3(256), 0, stream, g, tb);
-  else hipLaunchKernelGGL((wgrad_group_kernel<128>), dim3(total), dim3(256), 0, stream, g, tb);
+  // whole tiles and 16-byte aligned rows everywhere: direct-to-LDS kernel with transposing fragment reads
+  bool tr_ok = g_wgrad_tr != 0;
+  for (int i = 0; i < g.count && tr_ok; ++i) {
+    const EaWgradProblem& p = g.p[i];
+    tr_ok = p.N % bm == 0 && p.K % BN == 0 && (p.ld_dy & 7) == 0 && (p.ld_x & 7) == 0 &&
+            ((reinterpret_cast<uintptr_t>(p.dy) | reinterpret_cast<uintptr_t>(p.x)) & 15) == 0;
+  }
+  if (tr_ok) {
+    constexpr int lds64 = 2 * (64 * 128 + 64 * 256), lds128 = 2 * (64 * 256 + 64 * 256);
+    static const bool attr_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_tr_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_tr_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128) == hipSuccess;
+    if (!attr_ok) tr_ok = false;
+    else if (bm64) hipLaunchKernelGGL((wgrad_group_tr_kernel<64, 2>), dim3(total), dim3(256), lds64, stream, g, tb);
+    else hipLaunchKernelGGL((wgrad_group_tr_kernel<128, 2>), dim3(total), dim3(256), lds128, stream, g, tb);
+  }
+  if (!tr_ok) {
+    if (bm64) hipLaunchKernelGGL((wgrad_group_kernel<64>), dim3(total), dim3(256), 0, stream, g, tb);
+    else hipLaunchKernelGGL((wgrad_group_kernel<128>), dim3(total), dim3(256), 0, stream, g, tb);
+  }
   if (g_prof_on) {
     hipEventRecord(pr.e1, stream);
     g_prof.push_back(pr);

@@ -126,6 +126,9 @@ typedef struct EaWgradGroup {
   EaWgradProblem p[EA_WGRAD_MAX];
 } EaWgradGroup;
 int ea_wgrad_group(const EaWgradGroup* group, ea_stream_t stream);
+/* tuning hook: 1 (default) = groups whose tiles are whole (N % tile height, K % 128, 16-byte aligned rows) take the
+ * direct-to-LDS kernel with transposing fragment reads, 0 = always the register-staged kernel; returns the previous value */
+int ea_set_wgrad_transposing_reads(int on);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused

@@ -125,9 +125,12 @@ def check_conv3x3(Cin=64, Cout=128, sy=2, sx=2, B=2, T=37, F=21, seed=0):
     return res
 
 
-def check_wgrad_group(seed=0, variant=0):
+def check_wgrad_group(seed=0, variant=0, aligned=False, tr=1):
     """ea_wgrad_group (all weight / bias gradients of a layer in one launch) vs fp32 torch on the same bf16 operands:
-    ragged N / K / M, padded leading dimensions, accumulation into non-zero dW / db, problems with and without bias."""
+    ragged N / K / M, padded leading dimensions, accumulation into non-zero dW / db, problems with and without bias.
+    aligned: whole-tile problems only (N % 128, K % 128, row pitches % 8) — the group then takes the direct-to-LDS kernel with
+    transposing fragment reads (tr = 1) or, for comparison, the register-staged kernel (tr = 0); M stays ragged (rows past M
+    come from the zero page), including M < 64 and M = 64 k + 1."""
     import ctypes
 
     from espresso_amd import _lib
@@ -139,6 +142,10 @@ def check_wgrad_group(seed=0, variant=0):
     # (M, N, K, pad_dy, pad_x, bias)
     probs = [(1000, 512, 128, 0, 0, True), (1000, 128, 512, 0, 8, True), (777, 200, 72, 8, 16, True), (333, 64, 136, 0, 0, False),
              (64, 136, 40, 8, 0, True), (4100, 256, 256, 0, 0, True), (1000, 96, 128, 32, 0, False)]
+    if aligned:
+        probs = [(1000, 512, 128, 0, 0, True), (777, 128, 512, 0, 8, True), (6128, 2048, 512, 0, 0, True), (333, 1536, 512, 16, 0, False),
+                 (64, 256, 128, 8, 0, True), (63, 128, 128, 0, 0, True), (129, 128, 256, 0, 0, True), (4100, 256, 256, 0, 0, True)]
+    old_tr = lib.ea_set_wgrad_transposing_reads(tr)
     grp = _lib.EaWgradGroup()
     grp.count = len(probs)
     keep, refs = [], []
@@ -157,6 +164,7 @@ def check_wgrad_group(seed=0, variant=0):
     _lib.check(lib.ea_wgrad_group(ctypes.byref(grp), Kk._stream()), "ea_wgrad_group")
     torch.cuda.synchronize()
     lib.ea_set_gemm_variant(0)
+    lib.ea_set_wgrad_transposing_reads(old_tr)
     worst_w = worst_b = 0.0
     for (dy, x, dW, db), (refW, refb) in zip(keep, refs):
         worst_w = max(worst_w, float((dW.double() - refW).abs().max() / refW.abs().max()))

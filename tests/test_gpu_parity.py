@@ -63,6 +63,15 @@ def test_wgrad_group(variant):
     assert r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("tr", [1, 0])
+def test_wgrad_group_whole_tile_problems(variant, tr):
+    """groups of whole-tile problems: direct-to-LDS kernel with transposing fragment reads (tr = 1; 128- and 64-row tiles) and
+    the register-staged kernel on the same problems (tr = 0), both against fp64 on the bf16 operands"""
+    r = G.check_wgrad_group(variant=variant, aligned=True, tr=tr)
+    assert r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
+
+
 @pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
 def test_deferred_backward_matches_immediate(layer_type):
     r = G.check_deferred_backward_matches_immediate(layer_type)

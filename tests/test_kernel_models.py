@@ -30,3 +30,14 @@ def test_flash_relpos_swizzle_is_conflict_free():
 
     for r in range(64):
         assert E.swz(r) == f(r)
+
+
+@pytest.mark.parametrize("BM", [64, 128])
+def test_wgrad_transposing_read_kernel_lane_model(BM):
+    """csrc/gemm.hip wgrad_group_tr_kernel on the lane model (tools/emu_wgrad_tr.py): global_load_lds slot placement with the
+    source-side swizzle, ds_read_b64_tr_b16 fragment addresses / immediate offsets, MFMA operand order, the ones-fragment bias
+    sums and the zero-page rows past M reproduce dy^T x (float64), and every fragment read is bank-conflict free."""
+    import emu_wgrad_tr as W
+
+    err, ways = W.run(M=150, BM=BM)
+    assert err < 1e-11 and ways == 1, (err, ways)
