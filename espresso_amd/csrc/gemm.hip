@@ -1341,7 +1341,9 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
   bool tr_ok = g_wgrad_tr != 0;
   for (int i = 0; i < g.count && tr_ok; ++i) {
     const EaWgradProblem& p = g.p[i];
-    tr_ok = p.N % bm == 0 && p.K % BN == 0 && (p.ld_dy & 7) == 0 && (p.ld_x & 7) == 0 &&
+    // (a ragged last tile may read the columns up to the next tile boundary when the row pitch covers them: those products only
+    // reach output rows / columns >= N / K, which are never stored)
+    tr_ok = (p.N + bm - 1) / bm * bm <= p.ld_dy && (p.K + BN - 1) / BN * BN <= p.ld_x && (p.ld_dy & 7) == 0 && (p.ld_x & 7) == 0 &&
             ((reinterpret_cast<uintptr_t>(p.dy) | reinterpret_cast<uintptr_t>(p.x)) & 15) == 0;
   }
   if (tr_ok) {

@@ -1788,17 +1788,37 @@ class _TransducerJoint(torch.autograd.Function):
             cur, side = torch.cuda.current_stream(dl.device), aux_stream(dl.device, 2)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                dw = _wgrad(dl, Z, n, V, J, ld_dy=Vp)
-                db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp)
+                dw, db = _joint_wgrad(dl, Z, n, V, J, Vp)
                 late.event = side.record_event()
             dw.record_stream(cur)
             db.record_stream(cur)
             late.dw, late.db, late.keep = dw, db, (dl, Z)  # operands stay allocated until the join
             dw = db = None
+        elif has_bias:
+            dw, db = _joint_wgrad(dl, Z, n, V, J, Vp)
         else:
-            dw = _wgrad(dl, Z, n, V, J, ld_dy=Vp)
-            db = K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp) if has_bias else None
+            dw, db = _wgrad(dl, Z, n, V, J, ld_dy=Vp), None
         return dE, dD, dw, db, None, None, None, None, None
+
+
+def _joint_wgrad(dl, Z, n, V, J, Vp):
+    """dW [V][J] = dl^T Z and db = column sums of dl over all n lattice nodes.  The reduction is cut into row slabs that go
+    through ONE grouped weight-gradient launch (direct-to-LDS kernel with transposing reads; the bias sums ride along as an
+    extra MFMA against ones), each slab into its own fp32 output, summed afterwards: ~950 tiles for 256 CUs instead of 316
+    long ones, no split-K workspace pass, no separate 1.5 GB column-sum pass."""
+    tiles = ((V + 63) // 64) * ((J + 127) // 128)
+    slabs = max(1, min(8, (768 + tiles - 1) // tiles, n // 4096))
+    if slabs == 1 or (Vp * 2) % 16 or (J * 2) % 16:
+        return _wgrad(dl, Z, n, V, J, ld_dy=Vp), K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp)
+    dws = torch.zeros(slabs, V, J, dtype=torch.float32, device=dl.device)
+    dbs = torch.zeros(slabs, V, dtype=torch.float32, device=dl.device)
+    per = (n + slabs - 1) // slabs
+    probs = []
+    for i in range(slabs):
+        r0, r1 = i * per, min(n, (i + 1) * per)
+        probs.append((dl[r0:r1], Z[r0:r1], dws[i], dbs[i], r1 - r0, V, J, Vp, J, J))
+    K.wgrad_group(probs)
+    return dws.sum(0), dbs.sum(0)
 
 
 class _LateGrad:

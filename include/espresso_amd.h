@@ -126,8 +126,9 @@ typedef struct EaWgradGroup {
   EaWgradProblem p[EA_WGRAD_MAX];
 } EaWgradGroup;
 int ea_wgrad_group(const EaWgradGroup* group, ea_stream_t stream);
-/* tuning hook: 1 (default) = groups whose tiles are whole (N % tile height, K % 128, 16-byte aligned rows) take the
- * direct-to-LDS kernel with transposing fragment reads, 0 = always the register-staged kernel; returns the previous value */
+/* tuning hook: 1 (default) = groups whose operand rows are 16-byte aligned and cover whole tiles (ld_dy >= N rounded up to the
+ * tile height, ld_x >= K rounded up to 128) take the direct-to-LDS kernel with transposing fragment reads, 0 = always the
+ * register-staged kernel; returns the previous value */
 int ea_set_wgrad_transposing_reads(int on);
 
 /* ------------------------------------------------------------------------------------------

@@ -173,6 +173,25 @@ def check_wgrad_group(seed=0, variant=0, aligned=False, tr=1):
     return {"dW_rel": worst_w, "db_rel": worst_b}
 
 
+def check_joint_wgrad(n=20000, V=5004, J=512, seed=0):
+    """functional._joint_wgrad (the transducer output layer's weight / bias gradient at recipe width: padded row pitch 5056, row
+    slabs through one grouped launch, slab outputs summed) against fp64 on the same bf16 operands."""
+    from espresso_amd import functional as F
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Vp = (V + 63) // 64 * 64
+    dl = torch.zeros(n, Vp, dtype=torch.bfloat16)
+    dl[:, :V] = bf(torch.randn(n, V, generator=g) * 0.1)
+    Z = bf(torch.relu(torch.randn(n, J, generator=g)))
+    dl, Z = dl.to(DEV), Z.to(DEV)
+    dw, db = F._joint_wgrad(dl, Z, n, V, J, Vp)
+    torch.cuda.synchronize()
+    ref_w = dl[:, :V].double().t() @ Z.double()
+    ref_b = dl[:, :V].double().sum(0)
+    return {"dW_rel": float((dw.double() - ref_w).abs().max() / ref_w.abs().max()),
+            "db_rel": float((db.double() - ref_b).abs().max() / ref_b.abs().max()), "shape_ok": tuple(dw.shape) == (V, J) and tuple(db.shape) == (V,)}
+
+
 def check_deferred_backward_matches_immediate(layer_type="conformer", p_drop=0.0):
     """The same update step with the layer backward's side work deferred (grouped weight-gradient launch, joined by the next
     layer's call / the end-of-backward flush) and immediate (split-K launches joined inside every call): same loss, same

@@ -72,6 +72,11 @@ def test_wgrad_group_whole_tile_problems(variant, tr):
     assert r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
 
 
+def test_transducer_joint_weight_gradient_at_recipe_width():
+    r = G.check_joint_wgrad()
+    assert r["shape_ok"] and r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
+
+
 @pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
 def test_deferred_backward_matches_immediate(layer_type):
     r = G.check_deferred_backward_matches_immediate(layer_type)

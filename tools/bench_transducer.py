@@ -83,15 +83,36 @@ def run(steps=8, warmup=3, max_product=590000, max_sentences=16, update_freq=2):
         samples.append(s)
     task.build_frontend(dev)
     task.begin_epoch(1)
+    # allocator pools sized once for the largest lattices (what speech_train does at start-up): the (B, T', U+1, V) logits and
+    # their gradient are 1.5 GB each and differ in size from batch to batch — without this every new maximum costs a 10 ms
+    # device allocation in the middle of the step (tools/bench_transducer.py EA_TD_HOST_PROFILE=1: torch.empty 10 ms per batch)
+    lattice = lambda s: int(s["target"].shape[0]) * int(s["target"].shape[1]) * max(int(x) for x in s["num_samples"])
+    trainer.reserve(sorted(samples, key=lattice, reverse=True)[:2])
     for i in range(args.warmup):
         trainer.train_step(samples[i * uf:(i + 1) * uf])
     torch.cuda.synchronize()
+    prof = None
+    if os.environ.get("EA_TD_HOST_PROFILE") == "1":  # diagnostic: cProfile of the host side -> gpurun_out/host_profile_td.txt
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         trainer.train_step(samples[i * uf:(i + 1) * uf])
     host = time.perf_counter() - t0  # nothing in the loop waits for the device: this is what the host needs to enqueue the steps
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if prof is not None:
+        import io, pstats
+        prof.disable()
+        out = io.StringIO()
+        out.write(f"host enqueue {host * 1e3 / args.steps:.2f} ms per update (under cProfile), {args.steps} updates of {uf} batches\n")
+        ps = pstats.Stats(prof, stream=out).sort_stats("cumulative")
+        ps.print_stats(60)
+        ps.sort_stats("tottime").print_stats(40)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        open(os.path.join(root, "gpurun_out", "host_profile_td.txt"), "w").write(out.getvalue())
     audio = sum(s["audio_seconds"] for s in samples[args.warmup * uf:])
     nodes = [int(s["target"].shape[0]) for s in samples[args.warmup * uf:]]
     return ({"metric": "audio-hours/sec training (LibriSpeech Conformer-16 transducer, RNN-T)", "value": audio / 3600 / el,
