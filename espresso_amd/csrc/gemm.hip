@@ -1177,7 +1177,7 @@ extern "C" int ea_set_gemm_variant(int v) {
 // direct-to-LDS ring kernel for launches with both operands k-contiguous: 0 off, 1 automatic ring depth (3 stages when at most
 // two workgroups land on a CU — long-K, few-tile launches such as the N = 512 projections, where a deeper ring replaces the
 // latency hiding of co-resident workgroups: 41 -> 33 us in the 12-layer FFN chain — else 2), 2..4 forced depth
-static int g_gemm_glds = 1;
+static int g_gemm_glds = [] { const char* e = getenv("EA_GEMM_GLDS"); return e ? atoi(e) : 1; }();  // (env: diagnostic override)
 extern "C" int ea_set_gemm_glds(int stages) {
   const int old = g_gemm_glds;
   g_gemm_glds = stages;
