@@ -207,6 +207,7 @@ inline void wgrad(Ctx& c, const void* dy, long ld_dy, const void* x, long ld_x, 
 }
 // side-stream work after the main chain of a layer backward: ONE fork, the grouped launches, the remaining small kernels; then
 // the main stream joins the side work of the PREVIOUS backward call (other scratch half), which ran next to this call's chain
+static bool g_defer_default = true;  // ea_set_backward_deferred
 static bool g_defer_inline = false;  // A/B switch: run the deferred work on the MAIN stream at the end of the layer (no overlap)
 static void run_deferred(Ctx& c, int half) {
   if (c.dry || !c.df) return;
@@ -498,13 +499,18 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
   if (sk < 1) sk = 1;
   if (learned) {
     // learned table: the fp32 result IS the gradient of the table slice (written to the caller's buffer, [R][C]) — the caller
-    // reads it right after this call returns, so this mode never runs deferred (checked at the entry points)
+    // reads it right after this call returns: in deferred mode (no join before the call returns) it is the one optimizer-only
+    // product that stays on the main stream
     G gpp(dBD, a.qu, dpe, R, dh, B * T, Rp, C, C);
     gpp.aks().bks().f32().batch(H, 1, (long)B * T * Rp, 0, dh, 0, dh, 0);
     gpp.p.splitk = sk;
     if (sk > 1) gpp.p.workspace = sc.get<float>((size_t)sk * H * R * dh);
-    fork(c);
-    gemm_on(c, gpp, wstream(c));
+    if (c.df) {
+      gemm(c, gpp);
+    } else {
+      fork(c);
+      gemm_on(c, gpp, wstream(c));
+    }
   } else {
     // sinusoidal table: the product is only needed for the pos_proj weight gradient, so it is formed TRANSPOSED,
     // dppT[h*dh+d][r]: the 64-wide head dimension becomes the row tile (64x128 tiles fully used instead of half-empty
@@ -933,6 +939,16 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
   const uint64_t seed = sh.seed;
   const DWT wt = dwt_view(L, sh);
   const bool dp = sh.p_drop > 0.f;
+  // The layer's optimizer-only products (seven weight + bias gradients, three LayerNorm parameter reduces) are collected while the
+  // data-gradient chain is enqueued and launched behind ONE fork as one grouped weight-gradient launch + one grouped reduce —
+  // instead of 7 split-K GEMMs, 7 slab reduces, 7 column sums and 3 reduces with a fork each; the call still joins them before
+  // it returns (the scratch arena is the caller's to reuse).
+  static Deferred local;  // one process drives one GPU from one thread (as in bwd_deferred)
+  const bool grouped = c.overlap && !c.dry && !c.df && g_defer_default;
+  if (grouped) {
+    local.clear();
+    c.df = &local;
+  }
   uint16_t* dA = sc.get<uint16_t>((size_t)M * C);  // gradient at x2
   uint16_t* dB = sc.get<uint16_t>((size_t)M * C);  // gradient at x1
   uint16_t* pca = dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
@@ -981,6 +997,14 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     dgrad(c, dqkv, w.wqkv, wt.wqkv, dxn, M, C, 3 * C);
     ln_bwd_block(c, x_in, dxn, w.ln_g, D.sa.mean, D.sa.rstd, dx, gw.ln_g, gw.ln_b, M, C, dB, none);
   }
+  if (grouped) {
+    stream_wait(c, c.side, c.s);
+    RUN(ea_wgrad_group(&local.grp, c.side));
+    RUN(ea_layernorm_param_reduce_group(&local.ln, c.side));
+    for (auto& op : local.ops) RUN(op(c.side));
+    local.clear();
+    c.df = nullptr;
+  }
   if (c.overlap) stream_wait(c, c.s, c.side);
   return c.rc;
 }
@@ -1000,7 +1024,6 @@ int ea_set_backward_overlap(int on) {
   g_overlap_default = on != 0;
   return old;
 }
-static bool g_defer_default = true;
 int ea_set_backward_deferred(int on) {
   const int old = g_defer_default;
   g_defer_default = on != 0;
@@ -1014,9 +1037,9 @@ int ea_set_backward_deferred_inline(int on) {
 }
 
 // deferred mode of one backward call: requested by the caller (shape.defer = 1 + scratch half), side stream available, not
-// disabled; the learned-table attention returns `dpe` to the caller and therefore always runs its side work before returning
+// disabled (the learned-table attention's `dpe`, which the caller reads right after the call, is computed on the main stream)
 static inline bool want_deferred(const EaLayerShape& sh, bool overlap) {
-  return overlap && g_defer_default && (sh.defer == 1 || sh.defer == 2) && sh.pos_mode != 1;
+  return overlap && g_defer_default && (sh.defer == 1 || sh.defer == 2);
 }
 // scratch sizing shared by the conformer / transformer workspace queries: the arena must hold either one immediate-mode
 // backward or two deferred-mode halves
@@ -1140,7 +1163,6 @@ int ea_transformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes,
   *scratch_bytes = scratch_need([&](Ctx& c) {
     Arena a{nullptr, 0, 0}, b{nullptr, 0, 0};
     tlayer_fwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, a);
-    if (sh.pos_mode == 1 && c.df) return;  // the learned-table layer never runs deferred
     tlayer_bwd(c, &L, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, b);
     if (a.peak > sv.peak) sv.peak = a.peak;
   });

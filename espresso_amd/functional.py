@@ -980,9 +980,9 @@ def set_backward_deferred(on: bool):
 
 def _native_bwd_begin(sh, dev, tag, deferrable):
     """Fills sh.defer / sh.scratch_clean for the backward call that follows; returns the scratch half or None (immediate mode).
-    Deferred mode needs the saved-activation arena to outlive the call (the binding's grow-only arena, not a private buffer)
-    and a layer without a learned positional table (its `dpe` is consumed by autograd right after the call)."""
-    deferred = _defer_enabled and deferrable and sh.pos_mode != 1
+    Deferred mode needs the saved-activation arena to outlive the call (the binding's grow-only arena, not a private buffer).
+    (A learned positional table's gradient `dpe`, consumed by autograd right after the call, is computed on the main stream.)"""
+    deferred = _defer_enabled and deferrable
     if not deferred:
         sh.defer = 0
         sh.scratch_clean = int(_scratch_tag.get(dev) == tag)  # consecutive layers of one backward pass share the layout

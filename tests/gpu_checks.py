@@ -691,6 +691,40 @@ def _encdec_for(fixture):
     return build_tiny_encdec(embed_dim=d, heads=H, ffn=ffn)
 
 
+def check_encdec_deferred_matches_immediate(fixture="ref_transformer_encdec_dh64"):
+    """Encoder-decoder model (learned relative-position tables in the encoder: the layer's `dpe` stays on the main stream in
+    deferred mode; decoder layers: their weight gradients as one grouped launch inside the call) with the side work deferred /
+    grouped vs immediate (split-K launches joined inside every call, functional.set_backward_deferred(False)): same loss, same
+    gradients up to the fp32 summation order.  Two passes each, so halves and scratch tags are in their steady state."""
+    from espresso_amd import functional as F
+
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    feats, lengths = torch.from_numpy(g["feats"]).to(DEV), torch.from_numpy(g["lengths"]).to(DEV)
+    prev, target = torch.from_numpy(g["prev"]).to(DEV), torch.from_numpy(g["target"]).to(DEV)
+    out = []
+    for deferred in (True, False):
+        F.set_backward_deferred(deferred)
+        try:
+            model = _encdec_for(fixture).to(DEV)
+            model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+            model.train()
+            for rep in range(2):
+                for p in model.parameters():
+                    p.grad = None
+                F.set_dropout_seed(7)
+                lo, extra = model(feats, lengths, prev)
+                loss, _ = F.label_smoothed_ce(extra["_logits_bu"], target.reshape(-1).to(torch.int32).contiguous(), 0, 0.1)
+                loss.backward()
+            torch.cuda.synchronize()
+            out.append((float(loss), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            F.set_backward_deferred(True)
+    (la, ga), (lb, gb) = out
+    worst = max(((float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-20)), n) for n in gb), key=lambda kv: kv[0])
+    return {"loss_rel": abs(la - lb) / abs(lb), "worst_grad_rel": worst, "same_params": set(ga) == set(gb), "n_grads": len(ga)}
+
+
 def check_encdec_vs_reference(fixture="ref_transformer_encdec_tiny"):
     """`ref_transformer_encdec_dh64`: head dim 64 -> native decoder-layer runtime (ea_decoder_layer_fwd/bwd) on the fused
     attention kernels, compared with the reference's own model outputs."""

@@ -232,6 +232,13 @@ def test_encdec_label_smoothed_ce_vs_reference_fixture(fixture):
     assert r["median_grad_vs_emulation"] < 1.5e-2 and r["worst_l2_vs_emulation"][1] < 0.10 and r["median_l2_vs_emulation"] < 1.5e-2, r
 
 
+def test_encdec_deferred_backward_matches_immediate():
+    """learned-table encoder layers in deferred mode + decoder layers with one grouped side launch == immediate mode"""
+    r = G.check_encdec_deferred_matches_immediate()
+    assert r["same_params"] and r["n_grads"] > 100, r
+    assert r["loss_rel"] < 1e-6 and r["worst_grad_rel"][0] < 2e-3, r
+
+
 @pytest.mark.parametrize("fixture", ["ref_transformer_encdec_tiny", "ref_transformer_encdec_dh64"])
 def test_beam_search_vs_reference_generator(fixture):
     r = G.check_beam_search_vs_reference(fixture)
