@@ -75,6 +75,33 @@ def global_cmvn(x, mean, std):
     return y.astype(np.float32)
 
 
+def _resize_rows_linear(x, h_out):
+    """cv2.resize(x, dsize=(x.shape[1], h_out), interpolation=cv2.INTER_LINEAR) for a float32 [h_in][w] image whose width is
+    kept: OpenCV's pixel-centre convention, fy = (y + 0.5) * h_in / h_out - 0.5 (double product, float coefficient), rows
+    clamped at both ends.  PARITY UNPINNED: cv2 is not installed in this image (the reference's own time warp cannot run
+    here either); this restates OpenCV's documented algorithm (modules/imgproc/src/resize.cpp, linear, float)."""
+    h_in = x.shape[0]
+    out = np.empty((h_out, x.shape[1]), dtype=np.float32)
+    scale = float(h_in) / float(h_out)
+    for y in range(h_out):
+        fy = np.float32((y + 0.5) * scale - 0.5)
+        sy = int(np.floor(fy))
+        a = np.float32(fy - np.float32(sy))
+        if sy < 0:
+            sy, a = 0, np.float32(0.0)
+        if sy >= h_in - 1:
+            sy, a = h_in - 1, np.float32(0.0)
+        out[y] = x[sy] * (np.float32(1.0) - a) + x[min(sy + 1, h_in - 1)] * a
+    return out
+
+
+def time_warp(spec, w0, w):
+    """espresso/data/feature_transforms/adaptive_specaugment.py:100-109: frames [0, w0) resized to w0 + w rows, the rest to
+    the remaining rows (so the length is preserved), concatenated."""
+    n = spec.shape[0]
+    return np.concatenate((_resize_rows_linear(spec[:w0], w0 + w), _resize_rows_linear(spec[w0:], n - w0 - w)), axis=0)
+
+
 def specaugment_apply(spec, freq_masks, time_masks, mask_value=None):
     """Mask fill of espresso/data/feature_transforms/adaptive_specaugment.py:111-134 given drawn masks."""
     out = spec.copy()

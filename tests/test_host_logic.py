@@ -169,6 +169,48 @@ def test_specaugment_rng_order_matches_reference_fixture(golden_dir):
         np.testing.assert_array_equal(fbank_ref.specaugment_apply(spec, fm, tm, None), out)
 
 
+def test_specaugment_time_warp():
+    """time_warp_W > 0 (adaptive_specaugment.py:94-109; no recipe uses it, cv2 is absent here: parity unpinned).  (1) RNG order:
+    w0 and w are drawn before the masks and only when 2 W < num_frames — checked against a literal transcription of the
+    reference's draws; (2) the source-row table + the torch gather / lerp of the front-end == the oracle's restatement of
+    cv2.resize(INTER_LINEAR) on both segments, bit for bit in float32; (3) length preserved, w = 0 is the identity, a linear ramp
+    stays monotonic."""
+    import torch
+
+    from espresso_amd.data.gpu_frontend import apply_time_warp
+    from oracle import fbank_ref
+
+    tr = AdaptiveSpecAugmentTransform.from_config_dict({"time_warp_W": 5, "freq_mask_N": 2, "freq_mask_F": 27, "time_mask_pm": 0.04,
+                                                        "time_mask_ps": 0.04})
+    rng = np.random.default_rng(0)
+    for m in (9, 10, 11, 40, 163):
+        np.random.seed(100 + m)
+        warp, fm, tm = tr.draw_masks(m, 80, with_warp=True)
+        np.random.seed(100 + m)  # literal transcription of the reference's draw order
+        want = None
+        if 2 * 5 < m:
+            want = (int(np.random.randint(5, m - 5)), int(np.random.randint(-5 + 1, 5)))
+        fm2 = []
+        for _ in range(2):
+            f = np.random.randint(0, 27)
+            fm2.append((int(np.random.randint(0, 80 - f)), int(f)))
+        assert warp == want and fm == fm2, (m, warp, want)
+        if warp is None:
+            assert m <= 10
+            continue
+        spec = rng.standard_normal((m, 80)).astype(np.float32)
+        ref = fbank_ref.time_warp(spec, *warp)
+        assert ref.shape == spec.shape
+        i0, i1, fr = tr.warp_indices(m, *warp)
+        got = apply_time_warp(torch.from_numpy(spec)[None], torch.from_numpy(i0)[None], torch.from_numpy(i1)[None],
+                              torch.from_numpy(fr)[None])[0].numpy()
+        np.testing.assert_array_equal(got, ref)
+        ramp = np.repeat(np.arange(m, dtype=np.float32)[:, None], 3, 1)
+        assert (np.diff(fbank_ref.time_warp(ramp, *warp)[:, 0]) >= 0).all()
+    spec = rng.standard_normal((30, 4)).astype(np.float32)
+    np.testing.assert_array_equal(fbank_ref.time_warp(spec, 12, 0), spec)
+
+
 def test_wer_scorer_counts():
     from espresso_amd.tools.wer import Scorer
 
