@@ -949,6 +949,15 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     local.clear();
     c.df = &local;
   }
+  // what has been collected so far goes to the side stream (behind everything the main stream has been given up to here)
+  auto flush_group = [&]() {
+    if (!grouped) return;
+    stream_wait(c, c.side, c.s);
+    RUN(ea_wgrad_group(&local.grp, c.side));
+    RUN(ea_layernorm_param_reduce_group(&local.ln, c.side));
+    for (auto& op : local.ops) RUN(op(c.side));
+    local.clear();
+  };
   uint16_t* dA = sc.get<uint16_t>((size_t)M * C);  // gradient at x2
   uint16_t* dB = sc.get<uint16_t>((size_t)M * C);  // gradient at x1
   uint16_t* pca = dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
@@ -977,6 +986,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     dgrad(c, dq, w.wq, wt.xq, dxn, M, C, C);
     ln_bwd_block(c, D.x1, dxn, w.ln_g, D.ca.mean, D.ca.rstd, dB, gw.ln_g, gw.ln_b, M, C, dA, to_self);
   }
+  flush_group();  // FFN + encoder-decoder attention products (five of the seven weight gradients) run next to the self-attention chain
   {  // causal self-attention block
     const EaAttnParams& w = L->self_attn;
     const EaAttnGrads& gw = L->g_self;
@@ -997,14 +1007,8 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     dgrad(c, dqkv, w.wqkv, wt.wqkv, dxn, M, C, 3 * C);
     ln_bwd_block(c, x_in, dxn, w.ln_g, D.sa.mean, D.sa.rstd, dx, gw.ln_g, gw.ln_b, M, C, dB, none);
   }
-  if (grouped) {
-    stream_wait(c, c.side, c.s);
-    RUN(ea_wgrad_group(&local.grp, c.side));
-    RUN(ea_layernorm_param_reduce_group(&local.ln, c.side));
-    for (auto& op : local.ops) RUN(op(c.side));
-    local.clear();
-    c.df = nullptr;
-  }
+  flush_group();
+  if (grouped) c.df = nullptr;
   if (c.overlap) stream_wait(c, c.s, c.side);
   return c.rc;
 }
