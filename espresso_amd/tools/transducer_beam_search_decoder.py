@@ -228,6 +228,52 @@ class TransducerBeamSearchDecoder:
         dev = x.device
         self._E = self.model.joint_encoder_branch(x).contiguous()  # [bsz * T'][J], row = utterance * T' + frame
         self._Tp = Tp
+        # Predictor / LM states live in append-only row pools that are released when a group of searches ends: frames x
+        # expansions x beam rows per utterance, (layers x H x 10 + H x 2) bytes per row.  The utterances of a batch are therefore
+        # searched in groups whose estimated pool size stays under `state_pool_budget_bytes` (one group for ordinary batches; the
+        # encoder pass above is shared), instead of letting a long or large batch grow the pools without bound.
+        want = [i for i in range(bsz) if (only is None or i in only)]
+        done = [(None, None)] * bsz
+        threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            for group in self._pool_groups(want, enc_len):
+                self._search_group(group, enc_len, bos_token, done, dev)
+        finally:
+            torch.set_num_threads(threads)
+            self._E = self._dec_pool = self._dec_state = self._lm_pool = self._lm_state = None
+        return [d[0] for d in done], [d[1] for d in done], None
+
+    state_pool_budget_bytes = 4 << 30
+
+    def _pool_row_bytes(self):
+        dec = self.model.decoder
+        n = sum(t.shape[1] * t.element_size() for v in dec.init_state(1, "cpu").values() for t in v)
+        n += 2 * (dec.hidden_size if not hasattr(dec, "additional_fc") else dec.additional_fc.weight.shape[0])
+        if self.lm_model is not None:
+            lmd = self.lm_model.decoder
+            n += sum(t.shape[1] * t.element_size() for v in lmd.init_state(1, "cpu").values() for t in v)
+            n += 2 * (lmd.hidden_size if not hasattr(lmd, "additional_fc") else lmd.additional_fc.weight.shape[0])
+        return n
+
+    def _pool_groups(self, want, enc_len):
+        """Utterance indices in batch order, cut so that the estimated pool rows of a group fit the budget (at least one each)."""
+        per_row = self._pool_row_bytes()
+        cap = max(1, int(self.state_pool_budget_bytes // per_row))
+        groups, cur, rows = [], [], 0
+        for i in want:
+            r = max(1, int(enc_len[i])) * self.max_num_expansions_per_step * self.beam_size
+            if cur and rows + r > cap:
+                groups.append(cur)
+                cur, rows = [], 0
+            cur.append(i)
+            rows += r
+        if cur:
+            groups.append(cur)
+        return groups
+
+    def _search_group(self, group, enc_len, bos_token, done, dev):
+        """The coroutine driver for one group of utterances; fills done[i] = (tokens, scores)."""
         dec = self.model.decoder
         Hd = dec.hidden_size if not hasattr(dec, "additional_fc") else dec.additional_fc.weight.shape[0]
         self._dec_pool, self._dec_state = _Pool(Hd, dev), _StatePools(dec, dev)
@@ -238,37 +284,27 @@ class TransducerBeamSearchDecoder:
             self._lm_pool, self._lm_state = _Pool(Hl, dev), _StatePools(lmd, dev)
         # the search's bookkeeping is many small host-tensor operations: run them on one thread (with the intra-op pool of a
         # 128-core host every `seqs[index]` / pad / topk above the parallel grain fans out and synchronises: 0.75 ms per select)
-        threads = torch.get_num_threads()
-        torch.set_num_threads(1)
-        try:
-            searches = [self._one(i, int(enc_len[i]), bos_token) if (only is None or i in only) else None for i in range(bsz)]
-            done = [(None, None)] * bsz
-            pending = {}
-            for i, g in enumerate(searches):
-                if g is None:
-                    continue
+        searches = {i: self._one(i, int(enc_len[i]), bos_token) for i in group}
+        pending = {}
+        for i, g in searches.items():
+            try:
+                pending[i] = next(g)
+            except StopIteration as e:  # (an utterance without frames)
+                done[i] = e.value
+        while pending:
+            kinds = defaultdict(list)
+            for i, req in pending.items():
+                kinds[req[0]].append((i, req))
+            answers = {}
+            for kind, items in kinds.items():
+                answers.update(self._serve(kind, items))
+            nxt = {}
+            for i, ans in answers.items():
                 try:
-                    pending[i] = next(g)
-                except StopIteration as e:  # (an utterance without frames)
+                    nxt[i] = searches[i].send(ans)
+                except StopIteration as e:
                     done[i] = e.value
-            while pending:
-                kinds = defaultdict(list)
-                for i, req in pending.items():
-                    kinds[req[0]].append((i, req))
-                answers = {}
-                for kind, items in kinds.items():
-                    answers.update(self._serve(kind, items))
-                nxt = {}
-                for i, ans in answers.items():
-                    try:
-                        nxt[i] = searches[i].send(ans)
-                    except StopIteration as e:
-                        done[i] = e.value
-                pending = nxt
-        finally:
-            torch.set_num_threads(threads)
-            self._E = self._dec_pool = self._dec_state = self._lm_pool = self._lm_state = None
-        return [d[0] for d in done], [d[1] for d in done], None
+            pending = nxt
 
     # ------------------------------------------------------------------ model compute on the device, batched over utterances
     def _joint_lprobs(self, frame_rows, dec_slots):

@@ -211,6 +211,40 @@ def test_specaugment_time_warp():
     np.testing.assert_array_equal(fbank_ref.time_warp(spec, 12, 0), spec)
 
 
+def test_transducer_beam_state_pools_are_bounded_by_grouping():
+    """The batched transducer beam search keeps predictor / LM states in append-only row pools (released when a group of
+    searches ends): a batch whose estimated pool size (frames x expansions x beam rows, (layers x H x 10 + H x 2) bytes each)
+    exceeds the budget is searched in several groups that share the encoder pass; ordinary batches stay one group."""
+    import torch
+
+    from espresso_amd.tools.transducer_beam_search_decoder import TransducerBeamSearchDecoder
+
+    class Dec:
+        hidden_size = 8
+        layers = [0, 1]
+
+        def init_state(self, n, device):
+            z = lambda dt: torch.zeros(n, self.hidden_size, dtype=dt)
+            return {"h16": [z(torch.bfloat16) for _ in self.layers], "h32": [z(torch.float32) for _ in self.layers],
+                    "c": [z(torch.float32) for _ in self.layers]}
+
+    class Model:
+        decoder = Dec()
+
+        def eval(self):
+            return self
+
+    d = AsrDictionary.from_symbols(list("abcdefgh"), enable_bos=True)
+    dec = TransducerBeamSearchDecoder([Model()], d, beam_size=5, max_num_expansions_per_step=2)
+    assert dec._pool_row_bytes() == 2 * 8 * (2 + 4 + 4) + 2 * 8
+    lens = [100, 250, 40, 300, 7]
+    assert dec._pool_groups(list(range(5)), lens) == [[0, 1, 2, 3, 4]]          # 4 GiB default: one group
+    dec.state_pool_budget_bytes = dec._pool_row_bytes() * 10 * 300               # room for 300 frame-rounds of 10 rows
+    groups = dec._pool_groups(list(range(5)), lens)
+    assert groups == [[0], [1, 2], [3], [4]], groups                             # batch order kept, every utterance exactly once
+    assert dec._pool_groups([1, 3], lens) == [[1], [3]]                          # `only`-restricted searches are grouped too
+
+
 def test_wer_scorer_counts():
     from espresso_amd.tools.wer import Scorer
 
