@@ -422,22 +422,22 @@ def main(argv=None):
     others = {}
     if rank == 0 and world == 1 and not args.no_other_configs:
         # BASELINE configs 2 and 4 (same machinery, other model families): reported next to the headline, never part of `value`
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-        import bench_encdec
-        import bench_transducer
+        # Each block runs in its own interpreter (tools/bench_encdec.py / bench_transducer.py print one JSON line): the transducer
+        # step is within 20 % of being host-bound, and inside this process — a heap of ~10^6 objects left by the decode block, the
+        # CPU baselines' thread pools — it measured 20.5 ms per batch against 17.9 ms on its own.
+        import subprocess
 
         if args.no_decode:
             del trainer, model, criterion, samples
         torch.cuda.empty_cache()
-        import gc
-
-        for key, mod in (("config2_encdec", bench_encdec), ("config4_transducer", bench_transducer)):
-            gc.collect()  # (the decode block leaves ~10^6 short-lived hypothesis objects for the collector)
+        here = os.path.dirname(os.path.abspath(__file__))
+        for key, script in (("config2_encdec", "bench_encdec.py"), ("config4_transducer", "bench_transducer.py")):
             try:
-                others[key] = mod.run()
+                out = subprocess.run([sys.executable, os.path.join(here, "tools", script)], capture_output=True, text=True, timeout=600)
+                last = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                others[key] = json.loads(last[-1]) if last else {"error": (out.stderr or out.stdout)[-300:]}
             except Exception as e:  # a secondary block must not take the headline line down with it
                 others[key] = {"error": f"{type(e).__name__}: {e}"}
-            torch.cuda.empty_cache()
 
     if rank == 0:
         value = audio / 3600.0 / elapsed

@@ -1311,10 +1311,11 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.dy || !p.x || !p.dW) return -2;
     tiles128 += (long)((p.N + 127) / 128) * ((p.K + BN - 1) / BN);
   }
-  // Tile height.  Register-staged kernel: 64-row tiles when 128-row tiles would leave CUs idle or badly balanced (each tile walks
-  // the whole reduction).  Direct-to-LDS kernel: 128-row tiles as soon as they cover the chip once — its two-stage ring is 64 KB
-  // per workgroup, two per CU, which leaves the main stream's kernels more of each CU than three 48 KB 64-row workgroups do
-  // (measured on the training step: 16.9 -> 16.7 ms).
+  // Tile height: 64-row tiles when 128-row tiles would leave CUs idle or badly balanced (each tile walks the whole reduction).
+  // Measured alternative for the direct-to-LDS kernel on the training step (EA_WGRAD_BM=128: two 64 KB workgroups per CU instead of
+  // three 48 KB ones leave the main stream's kernels more of each CU): the step gains 0.19 ms (16.9 -> 16.7) while the grouped
+  // launch itself stretches from 136 to 208 us next to them — the whole-step gain is inside the box-to-box spread, the GEMM-family
+  // time per step (the roofline figure of bench.py) gets 0.9 ms worse.  Not the default.
   static const int bm_env = [] { const char* e = getenv("EA_WGRAD_BM"); return e ? atoi(e) : 0; }();  // (diagnostic override)
   auto aligned_for = [&](int bm) {
     // (a ragged last tile may read the columns up to the next tile boundary when the row pitch covers them: those products only
@@ -1330,7 +1331,7 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
   bool tr_ok = g_wgrad_tr != 0;
   bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < 1024));
   if (tr_ok) {
-    const bool tr64 = bm_env == 64 ? true : bm_env == 128 ? false : g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < 300));
+    const bool tr64 = bm_env == 64 ? true : bm_env == 128 ? false : bm64;
     tr_ok = aligned_for(tr64 ? 64 : 128);
     if (tr_ok) bm64 = tr64;
   }
