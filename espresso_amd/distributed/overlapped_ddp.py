@@ -116,7 +116,16 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         s, e = self.buckets[i]
         view = self.flat.g32[s:e]
         if self._on_gpu:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            # the bucket's gradients were accumulated on the stream that reported last — and, for models that run independent
+            # branches on their own streams (the transducer's predictor network: autograd accumulates its parameters' gradients
+            # on that stream), possibly on others: wait for all of them
+            from .. import functional as F
+
+            cur = torch.cuda.current_stream()
+            self.comm_stream.wait_stream(cur)
+            for st in F.python_side_streams(view.device):
+                if st != cur:
+                    self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
         else:

@@ -147,6 +147,15 @@ def aux_stream(device, idx):
     return st
 
 
+def python_side_streams(device):
+    """Every stream this module has created for `device` (the per-call side stream of the Python-composed backward passes and
+    the branch streams above): gradient work may be in flight on any of them when a data-parallel bucket becomes complete."""
+    key = str(torch.device(device))
+    out = [st for k, st in _side_streams.items() if k == key]
+    out += [st for (k, _), st in _aux_streams.items() if k == key]
+    return out
+
+
 def set_branch_overlap(on: bool) -> bool:
     """Run independent branches of the transducer (predictor network, joint weight gradient) on their own streams (default on;
     A/B switch and the tests' way to get the single-stream schedule).  Returns the previous setting."""
