@@ -218,7 +218,22 @@ def install():
             self.inner.begin_epoch(epoch, model)
 
         def reduce_metrics(self, logging_outputs, criterion):
-            return self.inner.reduce_metrics(logging_outputs, criterion)
+            """fairseq_task.py:564-598 + espresso/tasks/speech_recognition.py:615-629: fairseq's trainer reads the step's statistics
+            from its metrics aggregators, so the reduced values (this package's criteria return them as a dict) are logged
+            there — words / sentences per batch like FairseqTask does, then every scalar of the reduced dict."""
+            out = self.inner.reduce_metrics(logging_outputs, criterion)
+            from fairseq.logging import metrics
+
+            if any("ntokens" in log for log in logging_outputs):
+                ntokens = sum(log.get("ntokens", 0) for log in logging_outputs)
+                metrics.log_scalar("wpb", ntokens, priority=180, round=1)
+                metrics.log_speed("wps", ntokens, priority=90, round=1)
+            if any("nsentences" in log for log in logging_outputs):
+                metrics.log_scalar("bsz", sum(log.get("nsentences", 0) for log in logging_outputs), priority=190, round=1)
+            for k, v in (out or {}).items():
+                if isinstance(v, (int, float)) or (torch.is_tensor(v) and v.numel() == 1):
+                    metrics.log_scalar(k, float(v), round=3)
+            return out
 
     FairseqTaskAdapter.__name__ = "SpeechRecognitionEspressoTask"
     name = "speech_recognition_espresso"

@@ -292,7 +292,8 @@ class SpeechRecognitionEspressoTask:
     def reduce_metrics(self, logging_outputs, criterion=None):
         """Sum over the data-parallel workers' logging outputs; adds wer / cer (speech_recognition.py:615-629)."""
         crit = criterion if criterion is not None else self.criterion
-        out = dict(crit.reduce_metrics(logging_outputs)) if crit is not None and hasattr(crit, "reduce_metrics") else {}
+        r = crit.reduce_metrics(logging_outputs) if crit is not None and hasattr(crit, "reduce_metrics") else None
+        out = dict(r) if r is not None else {}  # (a fairseq criterion logs into fairseq's aggregators itself and returns None)
         tot = {k: sum(log.get(k, 0) for log in logging_outputs) for k in ("word_error", "word_count", "char_error", "char_count")}
         if tot["word_count"] > 0:
             out["wer"] = float(tot["word_error"]) / tot["word_count"] * 100

@@ -154,3 +154,97 @@ def test_task_adapter_refuses_pytorch_ddp(fairseq_env, monkeypatch):
     with pytest.raises(NotImplementedError, match="legacy_ddp"):
         task._check_ddp(Proxy(wrapped))
     task._check_ddp(Proxy(torch.nn.Linear(2, 2)))  # anything else passes
+
+
+def test_train_step_through_fairseqs_own_trainer(fairseq_env):
+    """fairseq/trainer.py:801-953 `Trainer.train_step` driving the adapter task for five updates: fairseq's optimizer (FairseqAdam
+    built by fairseq over the model's parameters), its gradient clipping, its logging aggregation — with a model whose weight
+    gradient is written into `p.grad` behind autograd's back and never returned to autograd, which is what the HIP layer runtime
+    does (the real layers need the GPU; this stand-in keeps the contract and runs on the CPU).  Checks: the loss falls, the
+    behind-the-back parameter is updated by fairseq's optimizer, the update counter advances, the task's reduce_metrics feeds
+    fairseq's aggregators (wpb / bsz), and the gradient norm fairseq clips with includes that parameter."""
+    e = fairseq_env
+    import torch
+    from fairseq.criterions import FairseqCriterion
+    from fairseq.dataclass.configs import FairseqConfig
+    from fairseq.logging import metrics
+    from fairseq.models import BaseFairseqModel
+    from fairseq.trainer import Trainer
+
+    task = e["tasks"].setup_task(_cfg({"_name": "speech_recognition_espresso", "data": e["tmp"], "dict": os.path.join(e["tmp"], "dict.txt"),
+                                       "criterion_name": "ctc_loss"}))
+
+    class BehindAutograd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, holder):
+            ctx.save_for_backward(x)
+            ctx.holder = holder
+            return x @ holder.W.detach().t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            (x,) = ctx.saved_tensors
+            W = ctx.holder.W
+            if W.grad is None:
+                W.grad = torch.zeros_like(W)
+            W.grad += dy.t() @ x  # accumulated in place, nothing returned for W: the native runtime's pattern
+            return dy @ W.detach(), None
+
+    class Model(BaseFairseqModel):
+        def __init__(self):
+            super().__init__()
+            self.inp = torch.nn.Linear(8, 8)
+            self.W = torch.nn.Parameter(torch.randn(4, 8) * 0.3)
+
+        def forward(self, src_tokens, **kw):
+            return BehindAutograd.apply(torch.tanh(self.inp(src_tokens)), self)
+
+    class Crit(FairseqCriterion):
+        def forward(self, model, sample, reduce=True):
+            loss = ((model(**sample["net_input"]) - sample["target"]) ** 2).sum()
+            n = sample["target"].shape[0]
+            return loss, n, {"loss": loss.detach(), "ntokens": n, "nsentences": n, "sample_size": n}
+
+        @staticmethod
+        def reduce_metrics(logging_outputs):
+            metrics.log_scalar("loss", sum(float(log["loss"]) for log in logging_outputs))
+
+        @staticmethod
+        def logging_outputs_can_be_summed():
+            return True
+
+    torch.manual_seed(0)
+    cfg = FairseqConfig()
+    cfg.common.cpu = True
+    cfg.optimizer = _cfg({"_name": "adam", "lr": [0.01]})
+    cfg.lr_scheduler = _cfg({"_name": "fixed", "lr": [0.01]})
+    cfg.optimization.lr = [0.01]
+    cfg.optimization.clip_norm = 1.0
+    model, crit = Model(), Crit(task)
+    trainer = Trainer(cfg, task, model, crit)
+    X, T = torch.randn(16, 8), torch.randn(16, 4)
+    sample = {"net_input": {"src_tokens": X}, "target": T, "ntokens": 16, "id": torch.arange(16)}
+    w0 = model.W.detach().clone()
+    losses, gnorms = [], []
+    with metrics.aggregate("train_inner") as agg:
+        for _ in range(5):
+            trainer.train_step([sample])
+            with torch.no_grad():
+                losses.append(float(((model(X) - T) ** 2).sum()))
+        logged = agg.get_smoothed_values()
+    assert all(b < a for a, b in zip(losses, losses[1:])), losses
+    assert float((model.W - w0).abs().max()) > 1e-3          # fairseq's optimizer stepped the behind-the-back parameter
+    assert trainer.get_num_updates() == 5
+    assert logged.get("wpb") == 16 and logged.get("bsz") == 16 and "loss" in logged, logged
+    # the norm fairseq clips with covers W: the same step's gradient by hand (fairseq scales by 1 / sample_size before clipping)
+    trainer.zero_grad()
+    crit(model, sample)[0].backward()
+    assert model.W.grad is not None and float(model.W.grad.norm()) > 0
+    with_w = float(torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters() if p.grad is not None))) / 16
+    without_w = float(torch.sqrt(sum((p.grad ** 2).sum() for n, p in model.named_parameters() if p.grad is not None and n != "W"))) / 16
+    trainer.zero_grad()
+    with metrics.aggregate("one_step") as agg:
+        trainer.train_step([sample])
+        gnorm = float(agg.get_smoothed_values()["gnorm"])
+    assert abs(gnorm - with_w) <= 2e-3 * with_w + 1e-3, (gnorm, with_w, without_w)
+    assert abs(gnorm - without_w) > 10 * (2e-3 * with_w + 1e-3), (gnorm, with_w, without_w)
