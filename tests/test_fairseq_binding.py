@@ -248,3 +248,7 @@ def test_train_step_through_fairseqs_own_trainer(fairseq_env):
         gnorm = float(agg.get_smoothed_values()["gnorm"])
     assert abs(gnorm - with_w) <= 2e-3 * with_w + 1e-3, (gnorm, with_w, without_w)
     assert abs(gnorm - without_w) > 10 * (2e-3 * with_w + 1e-3), (gnorm, with_w, without_w)
+    # fairseq/trainer.py:1086-1150 valid_step -> task.valid_step(sample, model, criterion): eval mode, no gradient, statistics back
+    w1 = model.W.detach().clone()
+    stats = trainer.valid_step(sample)
+    assert "loss" in stats and float((model.W - w1).abs().max()) == 0.0 and not model.training
