@@ -252,3 +252,23 @@ def test_train_step_through_fairseqs_own_trainer(fairseq_env):
     w1 = model.W.detach().clone()
     stats = trainer.valid_step(sample)
     assert "loss" in stats and float((model.W - w1).abs().max()) == 0.0 and not model.training
+
+
+# ---- fairseq's legacy_ddp wrapper over gradients written behind autograd's back, two ranks (gloo) ---------------------------------
+def test_fairseq_legacy_ddp_reduces_gradients_written_behind_autograd(fairseq_env):
+    """`--ddp-backend legacy_ddp` (fairseq/distributed/legacy_distributed_data_parallel.py:76-165), which INTEGRATION.md prescribes
+    under fairseq's trainer: its explicit all_reduce_grads() reads `p.grad` after backward, so a weight gradient the layer runtime
+    accumulated in place — never returned to autograd — is averaged over the ranks like every other (world 2, gloo, with one
+    no_sync micro-batch; torch's reducer-based DDP is the backend the adapter refuses).  Ranks run tests/fairseq_legacy_ddp_worker.py."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fairseq_legacy_ddp_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
