@@ -13,7 +13,10 @@ from .. import kernels as K
 class SimpleGreedyDecoder:
     def __init__(self, models, dictionary, max_len_a=0, max_len_b=200, max_len=0, temperature=1.0, eos=None,
                  for_validation=True, **unused):
-        self.model = models[0] if isinstance(models, (list, tuple)) else models
+        # an ensemble decodes with the log of the mean member probability (the reference wraps the list in fairseq's EnsembleModel:
+        # espresso/tools/simple_greedy_decoder.py:47-52, fairseq/sequence_generator.py:837-939)
+        self.models = list(models) if isinstance(models, (list, tuple)) else [models]
+        self.model = self.models[0]
         self.pad, self.unk = dictionary.pad(), dictionary.unk()
         self.eos = dictionary.eos() if eos is None else eos
         self.vocab_size = len(dictionary)
@@ -28,18 +31,19 @@ class SimpleGreedyDecoder:
         src_tokens = net_input["src_tokens"]
         bsz, src_len = src_tokens.shape[:2]
         dev = src_tokens.device
-        encoder_out = self.model.forward_encoder(net_input["src_tokens"], net_input["src_lengths"])
+        encoder_outs = [m.forward_encoder(net_input["src_tokens"], net_input["src_lengths"]) for m in self.models]
+        encoder_out = encoder_outs[0]
         target = sample.get("target")
         assert target is not None or not self.for_validation
         max_enc = encoder_out["encoder_padding_mask"][0].shape[1]
         max_len = (max(max_enc, target.size(1)) if self.for_validation
                    else min(int(self.max_len_a * src_len + self.max_len_b), self.max_len - 1))
-        max_len = min(max_len, self.model.max_decoder_positions() - 1)
+        max_len = min(max_len, min(m.max_decoder_positions() for m in self.models) - 1)
         tokens = torch.full((bsz, max_len + 2), self.pad, dtype=torch.long, device=dev)
         tokens[:, 0] = self.eos if bos_token is None else bos_token
         lprobs = (torch.full((bsz, target.size(1), self.vocab_size), -math.log(self.vocab_size), device=dev)
                   if self.for_validation else None)
-        state = self.model.decoder.init_incremental(encoder_out, bsz, 1)
+        states = [m.decoder.init_incremental(eo, bsz, 1) for m, eo in zip(self.models, encoder_outs)]
         ident = torch.arange(bsz, device=dev)
         ones = torch.ones(bsz, dtype=torch.int32, device=dev)
         for step in range(max_len + 1):
@@ -47,7 +51,11 @@ class SimpleGreedyDecoder:
             if step > 0 and bool(is_eos.all()):
                 tokens = tokens[:, : step + 1]
                 break
-            lp = self.model.decoder.step(state, tokens[:, : step + 1], step, None if step == 0 else ident)  # fp32 [B][V]
+            parent = None if step == 0 else ident
+            lp = self.models[0].decoder.step(states[0], tokens[:, : step + 1], step, parent)  # fp32 [B][V]
+            if len(self.models) > 1:
+                every = [lp] + [m.decoder.step(st, tokens[:, : step + 1], step, parent) for m, st in zip(self.models[1:], states[1:])]
+                lp = torch.logsumexp(torch.stack(every, 0), dim=0) - math.log(len(every))
             best, _, _, _ = K.ctc_greedy_decode(lp, ones, bsz, 1, self.vocab_size, blank=-1, pad=self.pad, want_align=False)
             tokens[:, step + 1] = best[:, 0].long()
             if step > 0:

@@ -1027,8 +1027,12 @@ def check_simple_greedy_decoder():
     am = lo.float().argmax(-1)
     U = min(tokens.shape[1], lprobs.shape[1])
     agree = float((am[:, :U] == tokens[:, :U]).float().mean())
+    # an ensemble of the model with itself: log of the mean of two identical distributions -> the same tokens and log-probs
+    tok2, lp2, _ = SimpleGreedyDecoder([model, model], d, for_validation=True).decode([model, model], sample)
     return {"tokens_shape": tuple(tokens.shape), "lprobs_shape": tuple(lprobs.shape), "argmax_consistency": agree,
-            "lprobs_normalised": float(torch.logsumexp(lprobs, -1).abs().max())}
+            "lprobs_normalised": float(torch.logsumexp(lprobs, -1).abs().max()),
+            "ensemble_tokens_equal": bool(tok2.shape == tokens.shape and (tok2 == tokens).all()),
+            "ensemble_lprobs_abs": float((lp2 - lprobs).abs().max())}
 
 
 def _attn_reference(qu, qv, k, v, pp, klen, H, B, T, S, causal):

@@ -287,6 +287,7 @@ def test_simple_greedy_decoder():
     print(r)
     assert r["lprobs_shape"][1] == 8 and r["lprobs_normalised"] < 1e-3, r
     assert r["argmax_consistency"] > 0.9, r
+    assert r["ensemble_tokens_equal"] and r["ensemble_lprobs_abs"] < 1e-5, r   # [m, m] == [m]
 
 
 @pytest.mark.parametrize("kw", [
