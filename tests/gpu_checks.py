@@ -721,7 +721,8 @@ def check_encdec_deferred_matches_immediate(fixture="ref_transformer_encdec_dh64
         finally:
             F.set_backward_deferred(True)
     (la, ga), (lb, gb) = out
-    worst = max(((float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-20)), n) for n in gb), key=lambda kv: kv[0])
+    names = [n for n in gb if not (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias"))]  # (zero up to noise)
+    worst = max(((float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-20)), n) for n in names), key=lambda kv: kv[0])
     return {"loss_rel": abs(la - lb) / abs(lb), "worst_grad_rel": worst, "same_params": set(ga) == set(gb), "n_grads": len(ga)}
 
 
@@ -1494,7 +1495,9 @@ def check_transducer_branch_overlap():
         finally:
             F.set_branch_overlap(old)
     (la, ga), (lb, gb) = out[True], out[False]
-    worst = max(((float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-20)), n) for n in gb), key=lambda kv: kv[0])
+    # (the sub-sampler's convolution biases feed BatchNorm: their gradient is zero up to rounding noise, a ratio of two noises)
+    names = [n for n in gb if not (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias"))]
+    worst = max(((float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-20)), n) for n in names), key=lambda kv: kv[0])
     return {"loss_rel": max(abs(a - b) / abs(b) for a, b in zip(la, lb)), "worst_grad_rel": worst, "same_params": set(ga) == set(gb),
             "n_grads": len(ga)}
 

@@ -236,7 +236,7 @@ def test_encdec_deferred_backward_matches_immediate():
     """learned-table encoder layers in deferred mode + decoder layers with one grouped side launch == immediate mode"""
     r = G.check_encdec_deferred_matches_immediate()
     assert r["same_params"] and r["n_grads"] > 100, r
-    assert r["loss_rel"] < 1e-6 and r["worst_grad_rel"][0] < 2e-3, r
+    assert r["loss_rel"] < 1e-5 and r["worst_grad_rel"][0] < 2e-4, r   # (fp32 atomics: ~2e-7 run to run in the loss; measured 1.6e-5)
 
 
 @pytest.mark.parametrize("fixture", ["ref_transformer_encdec_tiny", "ref_transformer_encdec_dh64"])
@@ -374,8 +374,8 @@ def test_transducer_branch_overlap_equals_single_stream_schedule():
     """predictor network + joint weight gradient on their own streams: results equal the single-stream schedule's"""
     r = G.check_transducer_branch_overlap()
     assert r["same_params"] and r["n_grads"] > 50, r
-    assert r["loss_rel"] < 1e-6, r
-    assert r["worst_grad_rel"][0] < 2e-3, r
+    assert r["loss_rel"] < 1e-5, r
+    assert r["worst_grad_rel"][0] < 2e-4, r   # measured 1e-5 (fp32 summation order of the split reductions)
 
 
 def test_transducer_vs_reference_fixture():
