@@ -152,14 +152,14 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|long)\s+(ea_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|long|uint64_t)\s+(ea_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         args = " ".join(args.split())
         if args in ("void", ""):
             argtypes = []
         else:
             argtypes = [_ctype_of(a) for a in args.split(",")]
-        protos[name] = (ctypes.c_int if ret == "int" else ctypes.c_long, argtypes)
+        protos[name] = (_SCALARS[ret], argtypes)
     return protos
 
 

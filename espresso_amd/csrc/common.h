@@ -65,7 +65,7 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
 // (gfx950 has no 64-bit integer multiplier: a splitmix64 costs ~35 VALU ops per element, this one ~10, and the dropout
 // of the attention probabilities made the fused attention kernels VALU-bound); the high halves of seed / idx only
 // enter through a term that is loop invariant in every caller.
-__device__ __forceinline__ uint32_t ea_hash(uint64_t seed, uint64_t idx) {
+__host__ __device__ __forceinline__ uint32_t ea_hash(uint64_t seed, uint64_t idx) {
   const uint32_t hi = ((uint32_t)(idx >> 32) * 0x85EBCA77u) ^ (uint32_t)(seed >> 32) ^ ((uint32_t)seed * 0xC2B2AE3Du);
   uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
   x ^= x >> 16;

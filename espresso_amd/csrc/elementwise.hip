@@ -207,6 +207,11 @@ extern "C" int ea_cast_bf16_to_f32(const void* src, float* dst, long n, hipStrea
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 1)), dim3(256), 0, stream, (const bf16_t*)src, dst, n);
   return EA_CHECK_LAUNCH();
 }
+extern "C" int ea_dropout_hash_host(uint64_t seed, uint64_t idx0, long n, uint32_t* out) {
+  if (!out || n < 0) return -1;
+  for (long i = 0; i < n; ++i) out[i] = ea_hash(seed, idx0 + (uint64_t)i);
+  return 0;
+}
 extern "C" int ea_scale_dropout_bf16(const void* x, const void* y, void* out, long n, float a, float b,
                                      uint64_t seed, uint32_t thr, float inv_keep, hipStream_t stream) {
   if (n <= 0) return 0;

@@ -36,6 +36,12 @@ struct Arena {
 
 inline int pad8(int n) { return (n + 7) / 8 * 8; }
 
+// Dropout mask streams of a layer call.  Every dropout site of a layer draws its keep decisions from ea_keep(site seed, element
+// index) with site seed = EaLayerShape.seed + module base + site offset; the same sum is formed again in the backward pass, so
+// no mask is stored.  ea_layer_dropout_seed (below, C ABI) publishes the table: the parity tests rebuild every mask from it.
+constexpr uint64_t kFfn1 = 0, kAttn = 16, kConv = 32, kCross = 32, kFfn2 = 48;         // module bases
+constexpr uint64_t kAct = 1, kOut = 2, kProbs = 3, kAttnOut = 4, kConvOut = 5;           // site offsets inside a module
+
 // Deferred side work of ONE layer backward (round 2): everything that only feeds the optimizer — weight / bias gradients,
 // LayerNorm / BatchNorm / depthwise-filter parameter gradients, the pos_proj chain — is collected while the data-gradient chain
 // is enqueued on the main stream and launched afterwards on the side stream behind a single fork: all Linear weight and bias
@@ -329,10 +335,10 @@ static void ffn_fwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   uint16_t *xn = f.xn, *z = f.z, *h = f.h;
   RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, xn, mean, rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   G g1(xn, w.w1, z, M, F, C, C, C, F);
-  g1.bias(w.b1).act(act).c2(h, F).drop(sh.p_act, seed + 1);
+  g1.bias(w.b1).act(act).c2(h, F).drop(sh.p_act, seed + kAct);
   gemm(c, g1);
   G g2(h, w.w2, y, M, C, F, F, F, C);
-  g2.bias(w.b2).drop(sh.p_drop, seed + 2).scale(out_scale).resid(x, C);
+  g2.bias(w.b2).drop(sh.p_drop, seed + kOut).scale(out_scale).resid(x, C);
   gemm(c, g2);
 }
 
@@ -347,7 +353,7 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   const uint16_t* g2 = pre;  // out_scale * dropout(dy), already written by the previous block's LayerNorm backward
   if (!g2) {
     uint16_t* gb = sc.get<uint16_t>((size_t)M * C);
-    RUN(ea_scale_dropout_bf16(dy, nullptr, gb, (long)M * C, out_scale, 0.f, seed + 2, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+    RUN(ea_scale_dropout_bf16(dy, nullptr, gb, (long)M * C, out_scale, 0.f, seed + kOut, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
     g2 = gb;
   }
   fork(c);
@@ -355,7 +361,7 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   uint16_t* dz = sc.get<uint16_t>((size_t)M * F);
   G gd(g2, w2t ? (const void*)w2t : w.w2, dz, M, F, C, C, w2t ? C : F, F);
   if (!w2t) gd.bks();
-  gd.aux(z, F).act(act).drop(sh.p_act, seed + 1);
+  gd.aux(z, F).act(act).drop(sh.p_act, seed + kAct);
   gemm(c, gd);
   fork(c);
   wgrad(c, dz, F, xn, C, gw.w1, M, F, C, gw.b1);
@@ -423,7 +429,7 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     hipEvent_t e0 = g_side.ev[g_side.next];
     g_side.next = (g_side.next + 1) % 32;
     if (hipEventRecord(e0, c.s) != hipSuccess || hipStreamWaitEvent(g_side.stream, e0, 0) != hipSuccess) c.rc = -1;
-    RUN(ea_flash_keep_bits(a.bits, H, B, T, seed + 3, drop_thr(sh.p_attn), g_side.stream));
+    RUN(ea_flash_keep_bits(a.bits, H, B, T, seed + kProbs, drop_thr(sh.p_attn), g_side.stream));
     bits_on_side = true;
   }
   RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, a.xn, a.mean, a.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
@@ -454,9 +460,9 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
       if (c.rc == 0 && (hipEventRecord(e1, g_side.stream) != hipSuccess || hipStreamWaitEvent(c.s, e1, 0) != hipSuccess)) c.rc = -1;
     }
     RUN(ea_flash_attention_fwd(a.qu, qvv, C, a.qkv + C, a.qkv + 2 * C, 3 * C, pp, C, key_len, a.o, C, a.lse, H, B, T, T, dh,
-                               bits_on_side ? 4 : 0, seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), a.bits, c.s));
+                               bits_on_side ? 4 : 0, seed + kProbs, drop_thr(sh.p_attn), drop_scale(sh.p_attn), a.bits, c.s));
     G go(a.o, w.wo, y, M, C, C, C, C, C);
-    go.bias(w.bo).drop(sh.p_drop, seed + 4).resid(x, C);
+    go.bias(w.bo).drop(sh.p_drop, seed + kAttnOut).resid(x, C);
     gemm(c, go);
     sc.off = mark;
     return;
@@ -474,12 +480,12 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   gbd.f32().batch(Z, B, dh, (long)T * C, dh, 0, (long)B * T * Rp, (long)T * Rp);
   gemm(c, gbd);
   RUN(ea_relpos_softmax_fwd(ac, bd, key_len, attn_mask, a.P, sh.p_attn > 0.f ? a.Pd : nullptr, H, B, T, T, Sp, Rp, Sp, 0,
-                            seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+                            seed + kProbs, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
   G gpv(a.Pd, a.qkv + 2 * C, a.o, T, dh, T, Sp, 3 * C, C);
   gpv.bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * 3 * C, dh, (long)T * C);
   gemm(c, gpv);
   G go(a.o, w.wo, y, M, C, C, C, C, C);
-  go.bias(w.bo).drop(sh.p_drop, seed + 4).resid(x, C);
+  go.bias(w.bo).drop(sh.p_drop, seed + kAttnOut).resid(x, C);
   gemm(c, go);
   sc.off = mark;
 }
@@ -570,7 +576,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     g = pre;  // dropout(dy), already written by the previous block's LayerNorm backward
   } else if (sh.p_drop > 0.f) {
     uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
-    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 4, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + kAttnOut, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
     g = gg;
   }
   fork(c);
@@ -586,7 +592,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     static const bool fused_dq = getenv("EA_NO_FUSED_DQ") == nullptr;  // (diagnostic A/B switch)
     RUN(ea_flash_attention_bwd(a.qu, sh.pos_mode == 1 ? a.qu : a.qv, C, a.qkv + C, a.qkv + 2 * C, 3 * C,
                                sh.pos_mode == 1 ? (const uint16_t*)pe : a.pp, C, key_len, a.o, dO, C, a.lse, Dd, t1, t2, C, dBD,
-                               Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, (sh.scratch_clean && c.overlap) ? 2 : 0, scaling, seed + 3,
+                               Rp, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, (sh.scratch_clean && c.overlap) ? 2 : 0, scaling, seed + kProbs,
                                drop_thr(sh.p_attn),
                                drop_scale(sh.p_attn), a.bits, fused_dq ? dqkv : nullptr, 3 * C, c.s));  // dq = t1 + t2 -> q third of dqkv
     attn_bwd_tail(c, a, sh, w, gw, x, dy, dx, pe, dqkv, t1, t2, dBD, wqkvt, next, dpe, fused_dq);
@@ -603,7 +609,7 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   gemm(c, gdv);
   uint16_t* dAC = sc.get<uint16_t>((size_t)Z * T * Sp);
   uint16_t* dBD = sc.get<uint16_t>((size_t)Z * T * Rp);
-  RUN(ea_relpos_softmax_bwd(a.P, dPd, dAC, dBD, H, B, T, T, Sp, Sp, Rp, seed + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
+  RUN(ea_relpos_softmax_bwd(a.P, dPd, dAC, dBD, H, B, T, T, Sp, Sp, Rp, seed + kProbs, drop_thr(sh.p_attn), drop_scale(sh.p_attn), c.s));
   G gdk(dAC, a.qu, dqkv + C, T, dh, T, Sp, C, 3 * C);
   gdk.aks().bks().batch(Z, B, (long)B * T * Sp, (long)T * Sp, dh, (long)T * C, dh, (long)T * 3 * C);
   gemm(c, gdk);
@@ -654,7 +660,7 @@ static void conv_fwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   else RUN(ea_bn_from_running(w.bn_rm, w.bn_rv, s.mr, C, 1e-5f, c.s));
   RUN(ea_bn_act_fwd(s.Z, s.mr, w.bn_g, w.bn_b, s.Hh, M, C, EA_ACT_SILU, c.s));
   G g2(s.Hh, w.pw2, y, M, C, C, C, C, C);
-  g2.drop(sh.p_drop, seed + 5).resid(x, C);
+  g2.drop(sh.p_drop, seed + kConvOut).resid(x, C);
   gemm(c, g2);
   sc.off = mark;
 }
@@ -670,7 +676,7 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
     g = pre;
   } else if (sh.p_drop > 0.f) {
     uint16_t* gg = sc.get<uint16_t>((size_t)M * C);
-    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + 5, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
+    RUN(ea_scale_dropout_bf16(dy, nullptr, gg, (long)M * C, 1.f, 0.f, seed + kConvOut, drop_thr(sh.p_drop), drop_scale(sh.p_drop), c.s));
     g = gg;
   }
   fork(c);
@@ -736,10 +742,10 @@ static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   const int M = sh.B * sh.T, C = sh.C;
   LayerSaved S = layer_saved(sv, sh);
   const uint64_t seed = sh.seed;
-  ffn_fwd(c, S.f1, sh, L->ffn1, x_in, S.x1, seed + 0, 0.5f, EA_ACT_SILU);
-  attn_fwd(c, S.at, sh, L->attn, S.x1, S.x2, key_len, attn_mask, pe, seed + 16);
-  conv_fwd(c, S.cv, sh, L->conv, S.x2, S.x3, seed + 32);
-  ffn_fwd(c, S.f2, sh, L->ffn2, S.x3, S.x4, seed + 48, 0.5f, EA_ACT_SILU);
+  ffn_fwd(c, S.f1, sh, L->ffn1, x_in, S.x1, seed + kFfn1, 0.5f, EA_ACT_SILU);
+  attn_fwd(c, S.at, sh, L->attn, S.x1, S.x2, key_len, attn_mask, pe, seed + kAttn);
+  conv_fwd(c, S.cv, sh, L->conv, S.x2, S.x3, seed + kConv);
+  ffn_fwd(c, S.f2, sh, L->ffn2, S.x3, S.x4, seed + kFfn2, 0.5f, EA_ACT_SILU);
   RUN(ea_layernorm_fwd(S.x4, L->final_ln_g, L->final_ln_b, x_out, S.fmean, S.frstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   wt_refresh(c, L, sh);  // weights are cache-warm here; the backward of this step reads the k-contiguous copies
   return c.rc;
@@ -765,14 +771,14 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   uint16_t* pcv = fz && dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
   uint16_t* pat = fz && dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
   uint16_t* pf1 = fz ? sc.get<uint16_t>((size_t)M * C) : nullptr;
-  const Pre to_ffn2{pf2, 0.5f, seed + 48 + 2, sh.p_drop}, to_conv{pcv, 1.f, seed + 32 + 5, sh.p_drop};
-  const Pre to_attn{pat, 1.f, seed + 16 + 4, sh.p_drop}, to_ffn1{pf1, 0.5f, seed + 0 + 2, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
+  const Pre to_ffn2{pf2, 0.5f, seed + kFfn2 + kOut, sh.p_drop}, to_conv{pcv, 1.f, seed + kConv + kConvOut, sh.p_drop};
+  const Pre to_attn{pat, 1.f, seed + kAttn + kAttnOut, sh.p_drop}, to_ffn1{pf1, 0.5f, seed + kFfn1 + kOut, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
   ln_bwd_block(c, S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, to_ffn2);
   const WT wt = wt_view(L, sh);
-  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + 48, 0.5f, EA_ACT_SILU, wt.f2w1, wt.f2w2, pf2, to_conv);
-  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + 32, wt.pw1, wt.pw2, pcv, to_attn);
-  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + 16, wt.wqkv, wt.wo, pat, to_ffn1);
-  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + 0, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2, pf1, none);
+  ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + kFfn2, 0.5f, EA_ACT_SILU, wt.f2w1, wt.f2w2, pf2, to_conv);
+  conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + kConv, wt.pw1, wt.pw2, pcv, to_attn);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + kAttn, wt.wqkv, wt.wo, pat, to_ffn1);
+  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + kFfn1, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2, pf1, none);
   if (c.df) run_deferred(c, sh.defer - 1);
   else if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
@@ -812,8 +818,8 @@ static int tlayer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh,
                       const float* attn_mask, const void* pe, Arena& sv) {
   TLayerSaved S = tlayer_saved(sv, sh);
   const uint64_t seed = sh.seed;
-  attn_fwd(c, S.at, sh, L->attn, x_in, S.x1, key_len, attn_mask, pe, seed + 16);
-  ffn_fwd(c, S.f, sh, L->ffn1, S.x1, x_out, seed + 0, 1.f, sh.act);
+  attn_fwd(c, S.at, sh, L->attn, x_in, S.x1, key_len, attn_mask, pe, seed + kAttn);
+  ffn_fwd(c, S.f, sh, L->ffn1, S.x1, x_out, seed + kFfn1, 1.f, sh.act);
   const WT w = twt_view(L, sh);
   if (w.f1w1) {
     const int C = sh.C, F = sh.F;
@@ -832,10 +838,10 @@ static int tlayer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh,
   const uint64_t seed = sh.seed;
   uint16_t* dA = sc.get<uint16_t>((size_t)M * C);
   uint16_t* pat = sh.p_drop > 0.f ? sc.get<uint16_t>((size_t)M * C) : nullptr;
-  const Pre to_attn{pat, 1.f, seed + 16 + 4, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
+  const Pre to_attn{pat, 1.f, seed + kAttn + kAttnOut, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
   const WT wt = twt_view(L, sh);
-  ffn_bwd(c, S.f, sh, L->ffn1, L->grads.ffn1, S.x1, dy, dA, seed + 0, 1.f, sh.act, wt.f1w1, wt.f1w2, nullptr, to_attn);
-  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, x_in, dA, dx, key_len, pe, seed + 16, wt.wqkv, wt.wo, pat, none, dpe);
+  ffn_bwd(c, S.f, sh, L->ffn1, L->grads.ffn1, S.x1, dy, dA, seed + kFfn1, 1.f, sh.act, wt.f1w1, wt.f1w2, nullptr, to_attn);
+  attn_bwd(c, S.at, sh, L->attn, L->grads.attn, x_in, dA, dx, key_len, pe, seed + kAttn, wt.wqkv, wt.wo, pat, none, dpe);
   if (c.df) run_deferred(c, sh.defer - 1);
   else if (c.overlap) stream_wait(c, c.s, c.side);
   return c.rc;
@@ -897,9 +903,9 @@ static int dlayer_fwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     gemm(c, gq);
     if (!split) RUN(ea_relpos_q_prep(D.sa.qkv, 3 * C, nullptr, nullptr, D.sa.qs, nullptr, M, C, scaling, c.s));
     RUN(ea_flash_attention_fwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, C, D.sa.lse, H,
-                               B, T, T, dh, 1, seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
+                               B, T, T, dh, 1, seed + kAttn + kProbs, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
     G go(D.sa.o, w.wo, D.x1, M, C, C, C, C, C);
-    go.bias(w.bo).drop(sh.p_drop, seed + 16 + 4).resid(x_in, C);
+    go.bias(w.bo).drop(sh.p_drop, seed + kAttn + kAttnOut).resid(x_in, C);
     gemm(c, go);
   }
   {  // encoder-decoder attention block: x2 = x1 + dropout(out_proj(attn(q = LN(x1), k = v = enc)))
@@ -914,12 +920,12 @@ static int dlayer_fwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     gkv.bias(w.bkv);
     gemm(c, gkv);
     RUN(ea_flash_attention_fwd(D.ca.qs, nullptr, C, D.ca.kv, D.ca.kv + C, 2 * C, nullptr, 0, enc_len, D.ca.o, C, D.ca.lse, H, B, T, S,
-                               dh, 0, seed + 32 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
+                               dh, 0, seed + kCross + kProbs, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, c.s));
     G go(D.ca.o, w.wo, D.x2, M, C, C, C, C, C);
-    go.bias(w.bo).drop(sh.p_drop, seed + 32 + 4).resid(D.x1, C);
+    go.bias(w.bo).drop(sh.p_drop, seed + kCross + kAttnOut).resid(D.x1, C);
     gemm(c, go);
   }
-  ffn_fwd(c, D.f, sh, L->ffn, D.x2, x_out, seed + 0, 1.f, sh.act);
+  ffn_fwd(c, D.f, sh, L->ffn, D.x2, x_out, seed + kFfn1, 1.f, sh.act);
   const DWT w = dwt_view(L, sh);
   if (w.fc1) {
     const int F = sh.F;
@@ -962,8 +968,8 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
   uint16_t* dB = sc.get<uint16_t>((size_t)M * C);  // gradient at x1
   uint16_t* pca = dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
   uint16_t* psa = dp ? sc.get<uint16_t>((size_t)M * C) : nullptr;
-  const Pre to_cross{pca, 1.f, seed + 32 + 4, sh.p_drop}, to_self{psa, 1.f, seed + 16 + 4, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
-  ffn_bwd(c, D.f, sh, L->ffn, L->g_ffn, D.x2, dy, dA, seed + 0, 1.f, sh.act, wt.fc1, wt.fc2, nullptr, to_cross);
+  const Pre to_cross{pca, 1.f, seed + kCross + kAttnOut, sh.p_drop}, to_self{psa, 1.f, seed + kAttn + kAttnOut, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
+  ffn_bwd(c, D.f, sh, L->ffn, L->g_ffn, D.x2, dy, dA, seed + kFfn1, 1.f, sh.act, wt.fc1, wt.fc2, nullptr, to_cross);
   {  // encoder-decoder attention block
     const EaXAttnParams& w = L->cross;
     const EaXAttnGrads& gw = L->g_cross;
@@ -976,7 +982,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     uint16_t* dkv = sc.get<uint16_t>((size_t)Ms * 2 * C);
     float* Dd = sc.get<float>((size_t)Z * T);
     RUN(ea_flash_attention_bwd(D.ca.qs, nullptr, C, D.ca.kv, D.ca.kv + C, 2 * C, nullptr, 0, enc_len, D.ca.o, dO, C, D.ca.lse, Dd, dq,
-                               nullptr, C, nullptr, 0, dkv, dkv + C, 2 * C, H, B, T, S, dh, 0, scaling, seed + 32 + 3, drop_thr(sh.p_attn),
+                               nullptr, C, nullptr, 0, dkv, dkv + C, 2 * C, H, B, T, S, dh, 0, scaling, seed + kCross + kProbs, drop_thr(sh.p_attn),
                                drop_scale(sh.p_attn), nullptr, nullptr, 0, c.s));
     fork(c);
     wgrad(c, dq, C, D.ca.xn, C, gw.wq, M, C, C, gw.bq);
@@ -1000,7 +1006,7 @@ static int dlayer_bwd(Ctx& c, const EaDecoderLayer* L, const EaLayerShape& sh, c
     // t1 (gradient of the scaled queries, already multiplied by the scale) goes straight into the q third of dqkv
     RUN(ea_flash_attention_bwd(D.sa.qs, nullptr, C, D.sa.qkv + C, D.sa.qkv + 2 * C, 3 * C, nullptr, 0, nullptr, D.sa.o, dO, C, D.sa.lse,
                                Dd, dqkv, nullptr, 3 * C, nullptr, 0, dqkv + C, dqkv + 2 * C, 3 * C, H, B, T, T, dh, 1, scaling,
-                               seed + 16 + 3, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, nullptr, 0, c.s));
+                               seed + kAttn + kProbs, drop_thr(sh.p_attn), drop_scale(sh.p_attn), nullptr, nullptr, 0, c.s));
     fork(c);
     wgrad(c, dqkv, 3 * C, D.sa.xn, C, gw.wqkv, M, 3 * C, C, gw.bqkv);
     uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
@@ -1245,3 +1251,19 @@ int ea_decoder_layer_bwd(const EaDecoderLayer* layer, const EaLayerShape* shape,
 }
 
 }  // extern "C"
+
+// include/espresso_amd.h: seed of one dropout site of a layer call (EA_SITE_*), given EaLayerShape.seed
+extern "C" uint64_t ea_layer_dropout_seed(uint64_t layer_seed, int site) {
+  switch (site) {
+    case EA_SITE_FFN1_ACT: return layer_seed + kFfn1 + kAct;
+    case EA_SITE_FFN1_OUT: return layer_seed + kFfn1 + kOut;
+    case EA_SITE_ATTN_PROBS: return layer_seed + kAttn + kProbs;
+    case EA_SITE_ATTN_OUT: return layer_seed + kAttn + kAttnOut;
+    case EA_SITE_CONV_OUT: return layer_seed + kConv + kConvOut;
+    case EA_SITE_FFN2_ACT: return layer_seed + kFfn2 + kAct;
+    case EA_SITE_FFN2_OUT: return layer_seed + kFfn2 + kOut;
+    case EA_SITE_CROSS_PROBS: return layer_seed + kCross + kProbs;
+    case EA_SITE_CROSS_OUT: return layer_seed + kCross + kAttnOut;
+    default: return 0;
+  }
+}

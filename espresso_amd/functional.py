@@ -34,9 +34,42 @@ def set_dropout_seed(seed: int):
     _seed_state["counter"] = 0
 
 
-def _next_seed() -> int:
+_seed_trace = None
+
+
+class trace_dropout_seeds:
+    """Context manager for the parity tests: records (site, seed, p) for every dropout seed drawn inside it, in draw order
+    (`.entries`).  Sites: 'subsample.out', 'ln.out', 'dropout', 'ffn.act', 'ffn.out', 'attn.probs', 'attn.out', 'conv.out'
+    (per-kernel composition) and 'layer:conformer' / 'layer:transformer' / 'layer:decoder' (native layer runtime: p is the
+    dict of the layer's three probabilities, per-site seeds from `ea_layer_dropout_seed`, include/espresso_amd.h).  The
+    element index of each site's mask stream is the element's position in the dense activation the site writes (header,
+    "Dropout sites")."""
+
+    def __enter__(self):
+        global _seed_trace
+        self.prev, self.entries = _seed_trace, []
+        _seed_trace = self.entries
+        return self
+
+    def __exit__(self, *a):
+        global _seed_trace
+        _seed_trace = self.prev
+
+
+def _next_seed(site: str = "dropout", p=None) -> int:
     _seed_state["counter"] += 1
-    return ((_seed_state["base"] << 32) | (_seed_state["counter"] & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+    seed = ((_seed_state["base"] << 32) | (_seed_state["counter"] & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+    if _seed_trace is not None:
+        _seed_trace.append([site, seed, p])
+    return seed
+
+
+def _layer_seed(kind: str, p_drop, p_act, p_attn) -> int:
+    """EaLayerShape.seed of one native layer call: a multiple of 64, so that the site offsets (< 64) never collide."""
+    seed = _next_seed() * 64 % (1 << 63)
+    if _seed_trace is not None:
+        _seed_trace[-1][:] = ["layer:" + kind, seed, {"p_drop": float(p_drop), "p_act": float(p_act), "p_attn": float(p_attn)}]
+    return seed
 
 
 def bf16_weight(p: torch.Tensor) -> torch.Tensor:
@@ -213,7 +246,7 @@ def linear(x, w, b=None, out_f32=False):
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, eps, row_zero, drop_p):
-        seed = _next_seed() if drop_p > 0 else 0
+        seed = _next_seed("ln.out", drop_p) if drop_p > 0 else 0
         y, mean, rstd = K.layernorm_fwd(x, g, b, eps, row_zero, drop_p, seed)
         ctx.save_for_backward(x, g, mean, rstd, row_zero)
         ctx.drop = (drop_p, seed)
@@ -247,8 +280,8 @@ class _FFN(torch.autograd.Function):
             xn, mean, rstd = K.layernorm_fwd(x, ln_g, ln_b, eps)
         else:  # post-LN layer: the caller normalises the residual sum afterwards
             xn, mean, rstd = x, None, None
-        s1 = _next_seed() if p_act > 0 else 0
-        s2 = _next_seed() if p_out > 0 else 0
+        s1 = _next_seed("ffn.act", p_act) if p_act > 0 else 0
+        s2 = _next_seed("ffn.out", p_out) if p_out > 0 else 0
         z = _new((M, Fd), torch.bfloat16, x)
         h = _new((M, Fd), torch.bfloat16, x)
         K.gemm(xn, w1_16, z, M, Fd, C, lda=C, ldb=C, ldc=Fd, bias=b1, act=act, C2=h, ldc2=Fd, drop_p=p_act, drop_seed=s1)
@@ -332,7 +365,7 @@ class _RelPosMHSA(torch.autograd.Function):
             else:
                 pp = _new((R, C), torch.bfloat16, x)
                 K.gemm(pe, wpos16, pp, R, C, C, lda=C, ldb=C, ldc=C)
-        sa = _next_seed() if p_attn > 0 else 0
+        sa = _next_seed("attn.probs", p_attn) if p_attn > 0 else 0
         fused = attn_mask is None and K.flash_attention_supported(dh, T, T, relpos)
         P = Pd = lse = bits = None
         if fused:
@@ -352,7 +385,7 @@ class _RelPosMHSA(torch.autograd.Function):
             o = _new((M, C), torch.bfloat16, x)
             K.gemm(Pd, qkv, o, T, dh, T, lda=Sp, ldb=3 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * T * Sp, T * Sp),
                    sB=(dh, T * 3 * C), b_off=2 * C, sC=(dh, T * C))
-        so = _next_seed() if p_out > 0 else 0
+        so = _next_seed("attn.out", p_out) if p_out > 0 else 0
         y = _new((M, C), torch.bfloat16, x)
         K.gemm(o, wo16, y, M, C, C, lda=C, ldb=C, ldc=C, bias=bo, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
         ctx.save_for_backward(x, ln_g, mean, rstd, xn, qkv, qu, qv, pp, P, Pd, o, wqkv16, wo16, wpos16, pe, lse, key_len, bits)
@@ -459,7 +492,7 @@ class _ConvModule(torch.autograd.Function):
         else:
             mr = K.bn_from_running(running_mean, running_var, bn_eps)
         Hh = K.bn_act_fwd(Zt, mr, bn_g, bn_b, "silu")
-        so = _next_seed() if p_out > 0 else 0
+        so = _next_seed("conv.out", p_out) if p_out > 0 else 0
         y = _new((M, C), torch.bfloat16, x)
         K.gemm(Hh, wpw2_16, y, M, C, C, lda=C, ldb=C, ldc=C, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
         ctx.save_for_backward(x, ln_g, mean, rstd, xn, Y, U, Zt, mr, Hh, bn_g, bn_b, wdw2, wpw1_16, wpw2_16)
@@ -644,7 +677,7 @@ class _ConvSubsample(torch.autograd.Function):
             cfgs.append((Tc, Fc, Cc, To, Fo, Co, sy, sx))
             Tc, Fc, Cc = To, Fo, Co
         out = A.view(B * Tc, Fc * Cc)
-        seed = _next_seed() if (training and p_drop > 0) else 0
+        seed = _next_seed("subsample.out", p_drop) if (training and p_drop > 0) else 0
         if seed:
             out = K.scale_dropout(out, a=1.0, drop_p=p_drop, drop_seed=seed)
         if row_zero is not None:
@@ -905,7 +938,7 @@ class _ConformerLayerNative(torch.autograd.Function):
         sh.KW = module.conv_module.depthwise_conv.weight.shape[-1]
         sh.training = int(training)
         sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
-        sh.seed = _next_seed() * 64 % (1 << 63)
+        sh.seed = _layer_seed("conformer", p_drop, p_act, p_attn)
         sh.has_attn_mask = int(attn_mask is not None)
         nb_saved, nb_scratch = ctypes.c_long(0), ctypes.c_long(0)
         lib = _lib.lib()
@@ -1066,7 +1099,7 @@ class _TransformerLayerNative(torch.autograd.Function):
         sh.F, sh.KW = module.fc1.weight.shape[0], 0
         sh.training = int(training)
         sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
-        sh.seed = _next_seed() * 64 % (1 << 63)
+        sh.seed = _layer_seed("transformer", p_drop, p_act, p_attn)
         sh.has_attn_mask = int(attn_mask is not None)
         sh.pos_mode = 1 if learned else 0
         sh.act = K._ACT[act] if isinstance(act, str) else int(act)
@@ -1212,7 +1245,7 @@ class _DecoderLayerNative(torch.autograd.Function):
         sh.F, sh.KW = module.fc1.weight.shape[0], 0
         sh.training = int(training)
         sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
-        sh.seed = _next_seed() * 64 % (1 << 63)
+        sh.seed = _layer_seed("decoder", p_drop, p_act, p_attn)
         sh.act = K._ACT[act] if isinstance(act, str) else int(act)
         nb_saved, nb_scratch = ctypes.c_long(0), ctypes.c_long(0)
         lib = _lib.lib()
@@ -1289,13 +1322,13 @@ class _CrossMHA(torch.autograd.Function):
         ac = _new((Z * U, Sp), torch.float32, x)
         K.gemm(qs, kv, ac, U, S, dh, lda=C, ldb=2 * C, ldc=Sp, batch=Z, zdiv=B, sA=(dh, U * C), sB=(dh, S * 2 * C),
                sC=(B * U * Sp, U * Sp))
-        sa = _next_seed() if p_attn > 0 else 0
+        sa = _next_seed("attn.probs", p_attn) if p_attn > 0 else 0
         P, Pd = K.relpos_softmax_fwd(ac, None, key_len, None, H, B, U, S, Sp, 0, Sp, False, p_attn, sa)
         del ac
         o = _new((M, C), torch.bfloat16, x)
         K.gemm(Pd, kv, o, U, dh, S, lda=Sp, ldb=2 * C, ldc=C, b_kstrided=True, batch=Z, zdiv=B, sA=(B * U * Sp, U * Sp),
                sB=(dh, S * 2 * C), b_off=C, sC=(dh, U * C))
-        so = _next_seed() if p_out > 0 else 0
+        so = _next_seed("attn.out", p_out) if p_out > 0 else 0
         y = _new((M, C), torch.bfloat16, x)
         K.gemm(o, wo16, y, M, C, C, lda=C, ldb=C, ldc=C, bias=bo, drop_p=p_out, drop_seed=so, resid=x, ldr=C)
         ctx.save_for_backward(x, enc, ln_g, mean, rstd, xn, qs, kv, P, Pd, o, wq16, wkv16, wo16)
@@ -1428,7 +1461,7 @@ def dropout(x, p):
 class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p):
-        seed = _next_seed()
+        seed = _next_seed("dropout", p)
         ctx.cfg = (p, seed)
         return K.scale_dropout(x.contiguous(), a=1.0, drop_p=p, drop_seed=seed)
 

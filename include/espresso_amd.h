@@ -422,6 +422,26 @@ typedef struct EaLayerShape {
   int defer;
 } EaLayerShape;
 
+/* Dropout sites of a layer call (FairseqDropout calls of the reference, cited per site) and the mask stream each one uses.
+ * Every site keeps element `idx` iff ea_dropout_hash(site seed, idx) >= thr, thr = min(floor(p * 2^32), 2^32 - 1), and scales
+ * kept elements by 1 / (1 - p); site seed = ea_layer_dropout_seed(EaLayerShape.seed, site).  Element index per site, with
+ * activation rows m = b*T + t (batch-major):
+ *   *_ACT    m*F + f        fairseq/modules/conformer_layer.py:144 / transformer_layer.py:212 (activation_dropout, after the activation)
+ *   *_OUT    m*C + c        conformer_layer.py:146 / transformer_layer.py:216 (dropout on the FFN output, before 0.5*y + x)
+ *   *_PROBS  ((h*B + b)*T + i)*S + j   fairseq/modules/multihead_attention.py:874 (attention_dropout on the softmax output)
+ *   ATTN_OUT / CROSS_OUT  m*C + c      espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:125,
+ *                                      transformer_layer.py:196, 456, 481 (dropout on out_proj's output, before the residual)
+ *   CONV_OUT m*C + c        conformer_layer.py:100 (dropout at the end of the convolution module)
+ * The Transformer encoder / decoder layers use FFN1_* for their one FFN; CROSS_* exist in the decoder layer only. */
+enum {
+  EA_SITE_FFN1_ACT = 0, EA_SITE_FFN1_OUT = 1, EA_SITE_ATTN_PROBS = 2, EA_SITE_ATTN_OUT = 3, EA_SITE_CONV_OUT = 4,
+  EA_SITE_FFN2_ACT = 5, EA_SITE_FFN2_OUT = 6, EA_SITE_CROSS_PROBS = 7, EA_SITE_CROSS_OUT = 8
+};
+uint64_t ea_layer_dropout_seed(uint64_t layer_seed, int site);
+/* Host evaluation of the device's counter-based dropout hash (csrc/common.h ea_hash) for idx0 .. idx0 + n - 1: the pin for
+ * the tests' numpy restatement (oracle/dropout_ref.py); no GPU needed. */
+int ea_dropout_hash_host(uint64_t seed, uint64_t idx0, long n, uint32_t* out);
+
 /* tuning hook: run weight-gradient GEMMs / bias sums of the layer backward on a side stream (default on); returns the
  * previous value.  Sizes from ea_conformer_layer_workspace depend on this setting: query them after changing it. */
 int ea_set_backward_overlap(int on);

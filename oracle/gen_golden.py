@@ -274,6 +274,148 @@ def encdec_fixture(name="ref_transformer_encdec_tiny", dm=64, heads=4, ffn=128, 
     print([k for k in sd if k.startswith("decoder")][:40])
 
 
+# ------------------------------------------------------------------------------------------------
+# Training mode with dropout: the reference's own modules run with FairseqDropout fed from given masks
+class _FeedDropout:
+    """Replaces `torch.nn.functional.dropout` while active — the function behind FairseqDropout (fairseq_dropout.py:31-45),
+    torch.nn.Dropout (the Conformer FFN / convolution modules, conformer_layer.py:77,130-131) and the attention-probability
+    dropout inside `F.multi_head_attention_forward` (fairseq's plain MultiheadAttention, multihead_attention.py:590-640): the
+    k-th dropout call of the reference's forward multiplies by the k-th mask of `sites` — the mask oracle/dropout_ref.py
+    derives for (site seed, p) in the layout that call's tensor has — instead of drawing from torch's RNG.  `sites`:
+    [(site, layout, kwargs)] in the reference's call order; every entry must be consumed, a tensor whose shape does not fit
+    its layout raises.  `F.multi_head_attention_forward` is forced onto its explicit softmax -> dropout -> bmm branch
+    (need_weights=True; with False it calls the fused SDPA kernel whose dropout cannot be fed) — same arithmetic."""
+
+    def __init__(self, plan, sites):
+        self.plan, self.sites, self.k = plan, sites, 0
+
+    def __enter__(self):
+        import torch.nn.functional as TF
+
+        sys.path.insert(0, ROOT)
+        from oracle import torch_ref
+
+        feeder = self
+        self.orig, self.orig_mha = TF.dropout, TF.multi_head_attention_forward
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            if not (p > 0 and training):
+                return x
+            site, layout, kw = feeder.sites[feeder.k]
+            feeder.k += 1
+            with torch_ref.dropout_masks(feeder.plan):
+                y = torch_ref._drop(x, site, layout, **kw)
+            assert y is not x, (site, "the plan had no mask for this call")
+            return y
+
+        def mha_forward(*a, **kw):
+            a = list(a)
+            if len(a) > 15:
+                a[15] = True  # positional `need_weights` (multihead_attention.py:631)
+            else:
+                kw["need_weights"] = True
+            return feeder.orig_mha(*a, **kw)
+
+        TF.dropout, TF.multi_head_attention_forward = dropout, mha_forward
+        return self
+
+    def __exit__(self, *a):
+        import torch.nn.functional as TF
+
+        TF.dropout, TF.multi_head_attention_forward = self.orig, self.orig_mha
+        if a[0] is None:
+            assert self.k == len(self.sites), (self.k, len(self.sites))
+            self.plan.done()
+
+
+def _layer_site_list(kind, H, B):
+    at = [("attn.probs", "ZTS", dict(B=B, H=H)), ("attn.out", "TBC", {})]
+    ffn = [("ffn.act", "TBC", {}), ("ffn.out", "TBC", {})]
+    if kind == "conformer":
+        return ffn + at + [("conv.out", "BCT", {})] + ffn
+    if kind == "transformer":
+        return at + ffn
+    return at + at + ffn  # decoder: self-attention, encoder attention, FFN
+
+
+def _synthetic_trace(kinds, p, base=0x5EED00000000):
+    """(site, seed, p) entries as espresso_amd.functional.trace_dropout_seeds would report them for a model whose native layer
+    calls are `kinds`; seeds are arbitrary distinct numbers (layer seeds multiples of 64)."""
+    tr, c = [], 0
+    for k in kinds:
+        c += 1
+        if k.startswith("layer:"):
+            tr.append([k, (base + c) * 64 % (1 << 63), {"p_drop": p, "p_act": p, "p_attn": p}])
+        else:
+            tr.append([k, base + c, p])
+    return tr
+
+
+def dropout_fixtures(p=0.1):
+    """`ref_dropout_*`: the reference's encoder / encoder-decoder in TRAINING mode with dropout = attention_dropout =
+    activation_dropout = 0.1, every FairseqDropout call fed the mask of a counter-based stream (oracle/dropout_ref.py; torch.nn.Dropout calls too) —
+    weights and inputs are those of the existing dropout-off fixtures, so only the trace and the outputs are stored."""
+    sys.path.insert(0, ROOT)
+    from espresso_amd import _lib
+    from oracle import dropout_ref as D
+
+    seed_fn = _lib.lib().ea_layer_dropout_seed
+    for layer_type, src in (("conformer", "ref_conformer_ctc_tiny"), ("transformer", "ref_transformer_ctc_tiny")):
+        g = np.load(os.path.join(OUT, src + ".npz"))
+        sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+        cfg = ref_config(layer_type)
+        cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = p
+        enc = build_ref_encoder(cfg, 40)
+        enc.load_state_dict(sd)
+        feats, lengths, tgt = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["targets"])
+        B, H = feats.shape[0], 4
+        trace = _synthetic_trace(["subsample.out", "ln.out"] + ["layer:" + layer_type] * 2, p)
+        sites = [("subsample.out", "SUB", dict(C=16)), ("ln.out", "BTC", {})] + _layer_site_list(layer_type, H, B) * 2
+        enc.train()
+        with _FeedDropout(D.MaskPlan(trace, seed_fn), sites):
+            o = enc(feats, lengths)
+        logits = o["encoder_out"][0]
+        tl = (tgt != 1).sum(-1)
+        flat = torch.cat([tgt[b, : int(tl[b])] for b in range(B)])
+        loss = torch.nn.functional.ctc_loss(torch.log_softmax(logits.float(), -1), flat, o["src_lengths"][0], tl, blank=0,
+                                            reduction="sum", zero_infinity=True)
+        loss.backward()
+        name = src.replace("ref_", "ref_dropout_")
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), source=np.array(src), trace=np.array(json.dumps(trace)),
+                            **{"out::train_logits": logits.detach().numpy(), "out::train_loss": np.array(loss.item())},
+                            **{"grad::" + n: q.grad.numpy() for n, q in enc.named_parameters()})
+        print(name, "loss", loss.item(), "dropout-off loss", float(g["out::train_loss"]))
+    # encoder-decoder (speech_transformer_base + label-smoothed CE)
+    from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
+
+    src = "ref_transformer_encdec_tiny"
+    g = np.load(os.path.join(OUT, src + ".npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    torch.manual_seed(4321)
+    model, dic = _build_ref_encdec(64, 4, 128, 40)
+    model.load_state_dict(sd)
+    for m in model.modules():
+        if m.__class__.__name__ in ("FairseqDropout", "Dropout"):
+            m.p = p
+    feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
+    prev, target = torch.from_numpy(g["prev"]), torch.from_numpy(g["target"])
+    B, H = feats.shape[0], 4
+    trace = _synthetic_trace(["subsample.out", "ln.out"] + ["layer:transformer"] * 2 + ["ln.out"] + ["layer:decoder"] * 2, p)
+    sites = ([("subsample.out", "SUB", dict(C=16)), ("ln.out", "BTC", {})] + _layer_site_list("transformer", H, B) * 2
+             + [("ln.out", "BTC", {})] + _layer_site_list("decoder", H, B) * 2)
+    model.train()
+    with _FeedDropout(D.MaskPlan(trace, seed_fn), sites):
+        lo, _ = model(feats, lengths, prev)
+    loss, nll = label_smoothed_nll_loss(torch.log_softmax(lo.float(), -1).view(-1, 40), target.view(-1, 1), 0.1,
+                                        ignore_index=dic.pad(), reduce=True)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "ref_dropout_transformer_encdec_tiny.npz"), source=np.array(src),
+                        trace=np.array(json.dumps(trace)),
+                        **{"out::train_logits": lo.detach().numpy(), "out::loss": np.array(loss.item()), "out::nll": np.array(nll.item())},
+                        **{"grad::" + n: q.grad.numpy() for n, q in model.named_parameters() if q.grad is not None})
+    print("ref_dropout_transformer_encdec_tiny loss", loss.item(), "dropout-off", float(g["out::loss"]))
+
+
 def transducer_fixture(name="ref_conformer_transducer_tiny"):
     """speech_transformer_transducer_base (conv front-end + rel-pos Conformer encoder + 2-layer LSTM predictor + joint with a
     weight-normed fc_out): logits (B, T', U+1, V) in eval and train mode and every parameter gradient of
@@ -1151,6 +1293,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "transducer":
         transducer_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dropout":
+        dropout_fixtures()
         sys.exit(0)
     encoder_fixture("conformer", "ref_conformer_ctc_tiny")
     encoder_fixture("transformer", "ref_transformer_ctc_tiny")

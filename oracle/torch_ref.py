@@ -50,6 +50,54 @@ def _r(x):
     return _RoundBF16.apply(x) if _EMU["on"] and x.is_floating_point() else x
 
 
+# ---- training-mode dropout with the HIP path's masks ---------------------------------------------------------------------
+# The reference applies FairseqDropout (x * bernoulli(1-p) / (1-p), torch's Philox stream) at the sites cited below.  The HIP path
+# draws its keep decisions from a counter-based hash instead; with `dropout_masks(plan)` active this restatement applies the
+# reference's dropout at the reference's sites using the HIP path's decisions (oracle/dropout_ref.py rebuilds every mask from
+# the (site, seed) list the HIP forward reported).  Without a plan every site is the identity (dropout 0 / eval).
+_DROP = {"plan": None}
+
+
+class dropout_masks:
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        self.old = _DROP["plan"]
+        _DROP["plan"] = self.plan
+
+    def __exit__(self, *a):
+        _DROP["plan"] = self.old
+
+
+def _drop(x, site, layout, **kw):
+    """FairseqDropout at `site` on x.  layout: how x relates to the HIP path's dense [rows m = b*T + t][channels] activation:
+    'TBC', 'BTC', 'BCT' (convolution module), 'ZTS' (attention probabilities, z = b*H + h; needs B=, H=), 'SUB' (sub-sampler
+    output (B, T', C*F'), reference feature order c*F' + f; needs C=)."""
+    plan = _DROP["plan"]
+    if plan is None:
+        return x
+    from . import dropout_ref as D
+
+    sp = plan.seed_for(site)
+    if sp is None:
+        return x
+    seed, p = sp
+    if layout == "TBC":
+        m = D.rows_tbc(seed, p, *x.shape)
+    elif layout == "BTC":
+        m = D.rows_btc(seed, p, *x.shape)
+    elif layout == "BCT":
+        m = D.rows_btc(seed, p, x.shape[0], x.shape[2], x.shape[1]).transpose(1, 2)
+    elif layout == "ZTS":
+        m = D.probs_zts(seed, p, kw["B"], kw["H"], x.shape[1], x.shape[2])
+    elif layout == "SUB":
+        m = D.subsample_out(seed, p, x.shape[0], x.shape[1], x.shape[2] // kw["C"], kw["C"])
+    else:
+        raise ValueError(layout)
+    return x * m
+
+
 def _lin(x, w, b=None):
     """Linear on the (bf16 shadow of the) weight, fp32 accumulation; the caller rounds where the result is stored."""
     return F.linear(x, _r(w), b)
@@ -107,12 +155,13 @@ def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
         w = w + attn_mask.unsqueeze(0)
     if key_padding_mask is not None:
         w = w.view(B, H, T, T).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(B * H, T, T)
+    # attention dropout on the softmax output (multihead_attention.py:874): the normaliser is the sum of ALL probabilities
     if _EMU["on"] and _EMU["flash"]:
         # fused kernels: bf16 un-normalised probabilities feed P.V, the normaliser is the fp32 sum of the un-rounded ones
         pu = torch.exp(w.float() - w.float().max(dim=-1, keepdim=True).values)
-        a = torch.bmm(_r(pu), v) / pu.sum(-1, keepdim=True)
+        a = torch.bmm(_r(_drop(pu, "attn.probs", "ZTS", B=B, H=H)), v) / pu.sum(-1, keepdim=True)
     else:
-        p = _r(torch.softmax(w.float(), dim=-1))
+        p = _r(_drop(torch.softmax(w.float(), dim=-1), "attn.probs", "ZTS", B=B, H=H))
         a = torch.bmm(p, v)
     a = _r(a).transpose(0, 1).contiguous().view(T, B, C)
     return _lin(a, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
@@ -126,8 +175,9 @@ def _ffn_conformer(x, sd, p):
     """fairseq/modules/conformer_layer.py:134-146 (swish)."""
     y = _ln(x, sd, p + "layer_norm.")
     y = _lin(y, sd[p + "w_1.weight"], sd[p + "w_1.bias"])
-    y = _r(F.silu(y))  # (the HIP epilogue applies the activation to the fp32 accumulator and stores the result)
-    return _lin(y, sd[p + "w_2.weight"], sd[p + "w_2.bias"])
+    # (the HIP epilogue applies the activation and the activation dropout (:144) to the fp32 accumulator and stores the result)
+    y = _r(_drop(F.silu(y), "ffn.act", "TBC"))
+    return _drop(_lin(y, sd[p + "w_2.weight"], sd[p + "w_2.bias"]), "ffn.out", "TBC")  # :146
 
 
 def _bn(x, sd, p, training, dim_c=1, momentum=0.1, eps=1e-5, update=None):
@@ -148,31 +198,37 @@ def conv_module(x_btc, sd, p, training, update=None):
     y = _bn(y, sd, p + "batch_norm.", training, update=update)
     y = _r(F.silu(y))
     y = F.conv1d(y, _r(sd[p + "pointwise_conv2.weight"]))
-    return y.transpose(1, 2)
+    return _drop(y, "conv.out", "BCT").transpose(1, 2)  # :100
 
 
 def conformer_layer(x, sd, p, H, key_padding_mask, training, update=None, attn_mask=None):
     """espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:112-141.  x: (T,B,C)."""
     x = _r(0.5 * _ffn_conformer(x, sd, p + "ffn1.") + x)
-    x = _r(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x)
+    # (…encoder_layer.py:125: dropout on the attention block's output, before the residual)
+    x = _r(_drop(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask),
+                 "attn.out", "TBC") + x)
     x = _r(conv_module(x.transpose(0, 1), sd, p + "conv_module.", training, update).transpose(0, 1) + x)
     x = _r(0.5 * _ffn_conformer(x, sd, p + "ffn2.") + x)
     return _ln(x, sd, p + "final_layer_norm.")
 
 
 def transformer_layer(x, sd, p, H, key_padding_mask, activation="relu", attn_mask=None, normalize_before=True):
-    """fairseq/modules/transformer_layer.py:163-226 (pre-LN; post-LN when normalize_before is False)."""
+    """fairseq/modules/transformer_layer.py:163-226 (pre-LN; post-LN when normalize_before is False); dropout sites :196
+    (attention block output), :212 (activation_dropout), :216 (FFN output)."""
+    act = (lambda y: F.relu(y)) if activation == "relu" else (lambda y: F.silu(y))
     if not normalize_before:
-        x = _ln(_r(relpos_mhsa(x, sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x), sd, p + "self_attn_layer_norm.")
+        x = _ln(_r(_drop(relpos_mhsa(x, sd, p + "self_attn.", H, key_padding_mask, attn_mask), "attn.out", "TBC") + x), sd,
+                p + "self_attn_layer_norm.")
         y = _lin(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
-        y = _r(F.relu(y) if activation == "relu" else F.silu(y))
-        y = _lin(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+        y = _r(_drop(act(y), "ffn.act", "TBC"))
+        y = _drop(_lin(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"]), "ffn.out", "TBC")
         return _ln(_r(x + y), sd, p + "final_layer_norm.")
-    x = _r(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask) + x)
+    x = _r(_drop(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask),
+                 "attn.out", "TBC") + x)
     y = _ln(x, sd, p + "final_layer_norm.")
     y = _lin(y, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
-    y = _r(F.relu(y) if activation == "relu" else F.silu(y))
-    y = _lin(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    y = _r(_drop(act(y), "ffn.act", "TBC"))
+    y = _drop(_lin(y, sd[p + "fc2.weight"], sd[p + "fc2.bias"]), "ffn.out", "TBC")
     return _r(x + y)
 
 
@@ -237,7 +293,8 @@ def legacy_encoder_kwargs(meta, lengths, training, strides=((1, 1), (2, 2), (1, 
 def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activation="relu",
             strides=((1, 1), (2, 2), (1, 1), (2, 2)), update=None, normalize_before=True, attn_mask=None):
     """espresso/models/transformer/speech_transformer_encoder.py:298-409 + fc_out
-    (speech_transformer_encoder_model.py:207-208), dropout = 0.  Returns (logits (T',B,V), out_lengths)."""
+    (speech_transformer_encoder_model.py:207-208).  Dropout: identity unless a `dropout_masks` plan is active AND training
+    (then the reference's FairseqDropout sites with the HIP path's keep decisions).  Returns (logits (T',B,V), out_lengths)."""
     def _t(v):
         if not torch.is_tensor(v):
             v = torch.from_numpy(np.asarray(v))
@@ -245,6 +302,11 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
 
     sd = {k: _t(v) for k, v in sd.items()}
     x, out_len, pad = conv_bn_relu(feats.float(), lengths, sd, "pre_encoder.", strides, training, update)
+    if training:  # speech_transformer_encoder.py:342: dropout on fc0's input (the HIP path stores the dropped bf16 tensor)
+        nconv = 0
+        while f"pre_encoder.convolutions.{nconv}.weight" in sd:
+            nconv += 1
+        x = _r(_drop(x, "subsample.out", "SUB", C=sd[f"pre_encoder.convolutions.{nconv - 1}.weight"].shape[0]))
     x = _r(_lin(x, sd["fc0.weight"], sd["fc0.bias"]))
     if "embed_positions.weight" in sd or "embed_positions._float_tensor" in sd:
         # absolute positions of the legacy presets (speech_transformer_encoder.py:345-347; make_positions with padding_idx 0)
@@ -252,8 +314,15 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
         pos = torch.cumsum(valid, 1) * valid
         tab = sd["embed_positions.weight"] if "embed_positions.weight" in sd else sinusoidal_abs_pe(int(pos.max()) + 1, x.shape[-1], 0)
         x = _r(x + tab[pos])
+    # :348-350: layernorm_embedding, then dropout (the HIP LayerNorm kernel applies the mask before it stores)
     if "layernorm_embedding.weight" in sd:
-        x = _ln(x, sd, "layernorm_embedding.")
+        if training and _DROP["plan"] is not None:
+            x = _r(_drop(F.layer_norm(x, (x.shape[-1],), sd["layernorm_embedding.weight"], sd["layernorm_embedding.bias"], 1e-5),
+                         "ln.out", "BTC"))
+        else:
+            x = _ln(x, sd, "layernorm_embedding.")
+    elif training:
+        x = _r(_drop(x, "dropout", "BTC"))
     x = x * (1 - pad.unsqueeze(-1).float())
     x = x.transpose(0, 1)
     kpm = pad if bool(pad.any()) else None
@@ -377,16 +446,16 @@ def mha(q_in, kv_in, sd, p, H, key_padding_mask=None, causal=False):
         w = w.view(B, H, U, S).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(B * H, U, S)
     if _EMU["on"] and _EMU["flash"]:
         pu = torch.exp(w.float() - w.float().max(dim=-1, keepdim=True).values)
-        a = torch.bmm(_r(pu), v) / pu.sum(-1, keepdim=True)
+        a = torch.bmm(_r(_drop(pu, "attn.probs", "ZTS", B=B, H=H)), v) / pu.sum(-1, keepdim=True)
     else:
-        a = torch.bmm(_r(torch.softmax(w.float(), -1)), v)
+        a = torch.bmm(_r(_drop(torch.softmax(w.float(), -1), "attn.probs", "ZTS", B=B, H=H)), v)
     a = _r(a).transpose(0, 1).contiguous().view(U, B, C)
     return _lin(a, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
 
 
 def decoder(prev_tokens, enc_out, enc_pad, sd, H, pad_idx, p="decoder.", activation="relu"):
     """espresso/models/transformer/speech_transformer_decoder.py + fairseq transformer_decoder.py:254-370 and
-    transformer_layer.py:384-529 (pre-LN, cross attention, no layerdrop, dropout 0).  Returns logits (B,U,V).
+    transformer_layer.py:384-529 (pre-LN, cross attention, no layerdrop; dropout only under `dropout_masks`).  Returns logits (B,U,V).
     `_r` marks the tensors the HIP decoder stores in bf16 (csrc/engine.hip ea_decoder_layer_*): identity outside bf16_emulation."""
     B, U = prev_tokens.shape
     W = sd[p + "embed_tokens.weight"]
@@ -395,20 +464,29 @@ def decoder(prev_tokens, enc_out, enc_pad, sd, H, pad_idx, p="decoder.", activat
     mask = prev_tokens.ne(pad_idx).int()
     positions = (torch.cumsum(mask, 1) * mask).long() + pad_idx
     x = _r(x + sinusoidal_abs_pe(pad_idx + 1 + U, C, pad_idx)[positions])
+    # transformer_decoder.py:324-327: layernorm_embedding, then dropout (x is (B,U,C) here)
     if (p + "layernorm_embedding.weight") in sd:
-        x = _ln(x, sd, p + "layernorm_embedding.")
+        if _DROP["plan"] is not None:
+            x = _r(_drop(F.layer_norm(x, (C,), sd[p + "layernorm_embedding.weight"], sd[p + "layernorm_embedding.bias"], 1e-5),
+                         "ln.out", "BTC"))
+        else:
+            x = _ln(x, sd, p + "layernorm_embedding.")
+    else:
+        x = _r(_drop(x, "dropout", "BTC"))
     x = x.transpose(0, 1)
+    act = (lambda y: F.relu(y)) if activation == "relu" else (lambda y: F.silu(y))
     i = 0
     while (p + f"layers.{i}.fc1.weight") in sd:
         lp = p + f"layers.{i}."
+        # transformer_layer.py:384-529; dropout sites :456 (self-attention output), :481 (encoder attention output), :212-216 (FFN)
         y = _ln(x, sd, lp + "self_attn_layer_norm.")
-        x = _r(mha(y, y, sd, lp + "self_attn.", H, causal=True) + x)
+        x = _r(_drop(mha(y, y, sd, lp + "self_attn.", H, causal=True), "attn.out", "TBC") + x)
         y = _ln(x, sd, lp + "encoder_attn_layer_norm.")
-        x = _r(mha(y, enc_out, sd, lp + "encoder_attn.", H, key_padding_mask=enc_pad) + x)
+        x = _r(_drop(mha(y, enc_out, sd, lp + "encoder_attn.", H, key_padding_mask=enc_pad), "attn.out", "TBC") + x)
         y = _ln(x, sd, lp + "final_layer_norm.")
         y = _lin(y, sd[lp + "fc1.weight"], sd[lp + "fc1.bias"])
-        y = _r(F.relu(y) if activation == "relu" else F.silu(y))
-        x = _r(_lin(y, sd[lp + "fc2.weight"], sd[lp + "fc2.bias"]) + x)
+        y = _r(_drop(act(y), "ffn.act", "TBC"))
+        x = _r(_drop(_lin(y, sd[lp + "fc2.weight"], sd[lp + "fc2.bias"]), "ffn.out", "TBC") + x)
         i += 1
     if (p + "layer_norm.weight") in sd:
         x = _ln(x, sd, p + "layer_norm.")

@@ -54,6 +54,116 @@ def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, 
     return rel_err(C, ref)
 
 
+def _bf_ulp_ok(got, want_f32, ulps=1.0):
+    """got bf16 tensor vs the fp32 value it should be the rounding of: within `ulps` bf16 steps of that value's magnitude."""
+    got, want = got.float().cpu(), want_f32.float().cpu()
+    step = torch.exp2(torch.floor(torch.log2(want.abs().clamp_min(2.0 ** -60))) - 7)
+    return float(((got - want).abs() / step).max()) <= ulps + 1e-3
+
+
+def check_gemm_dropout(M=777, N=520, K=192, batch=2, p=0.1, seed=0, variant=0):
+    """The dropout of the GEMM epilogue (csrc/gemm.hip `has_drop`: FairseqDropout of conformer_layer.py:144,146 and of the
+    attention / conv-module output projections) against the restated mask stream (oracle/dropout_ref.py): keep decisions bit
+    for bit, keep rate, the 1/(1-p) scale, and the position of the dropout relative to bias / activation / scale / residual in
+    the four epilogue forms the layers use."""
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+    from oracle import dropout_ref as D
+
+    _lib.lib().ea_set_gemm_variant(variant)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    # positive operands: every accumulator is > 0, so "output == 0" <=> "dropped"
+    A = bf(torch.rand(batch, M, K, generator=g) + 0.1).to(DEV)
+    Bm = bf(torch.rand(batch, N, K, generator=g) + 0.1).to(DEV)
+    bvec = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    R = bf(torch.randn(batch, M, N, generator=g)).to(DEV)
+    dseed = (0x5EED << 32) | (1234 + seed)
+    kw = dict(lda=K, ldb=K, ldc=N, batch=batch, zdiv=1, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0))
+    mask = D.scale_mask(dseed, (batch, M, N), p)  # index (z*M + m)*N + n, value 0 or 1/(1-p)
+    keep = mask != 0
+    res = {"keep_rate": float(keep.float().mean())}
+
+    def run(drop, **extra):
+        C = torch.full((batch, M, N), float("nan"), dtype=extra.pop("cdtype", torch.float32), device=DEV)
+        Kk.gemm(A, Bm, C, M, N, K, drop_p=p if drop else 0.0, drop_seed=dseed if drop else 0, **kw, **extra)
+        torch.cuda.synchronize()
+        return C
+
+    # (1) plain fp32 output: y = acc * keep / (1-p)
+    y0, y = run(False).cpu(), run(True).cpu()
+    res["mask_bits_equal"] = bool(((y != 0) == keep).all())
+    res["scale_err"] = float(((y - y0 * mask).abs() / y0.abs()).max())
+    # (2) FFN first GEMM: C = acc + bias (pre-activation, not dropped), C2 = drop(act(acc + bias)) in bf16
+    C2 = torch.full((batch, M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    z = run(True, bias=bvec, act="silu", C2=C2, ldc2=N, cdtype=torch.bfloat16)
+    pre = y0 + bvec.cpu()
+    res["c2_pre_ok"] = _bf_ulp_ok(z, pre)
+    res["c2_drop_ok"] = _bf_ulp_ok(C2, torch.nn.functional.silu(pre) * mask) and bool(((C2.cpu().float() != 0) == keep).all())
+    # (3) FFN second GEMM: out = 0.5 * drop(acc + bias) + residual
+    o = run(True, bias=bvec, out_scale=0.5, resid=R, ldr=N, sR=(M * N, 0), cdtype=torch.bfloat16)
+    res["resid_ok"] = _bf_ulp_ok(o, 0.5 * (pre * mask) + R.float().cpu())
+    # (4) backward through activation + activation dropout: dz = drop(acc) * act'(aux)
+    aux = bf(torch.randn(batch, M, N, generator=g)).to(DEV)
+    d = run(True, aux=aux, ldaux=N, sX=(M * N, 0), act="silu", cdtype=torch.bfloat16)
+    xs = aux.float().cpu()
+    sg = torch.sigmoid(xs)
+    res["dact_ok"] = _bf_ulp_ok(d, y0 * mask * (sg * (1 + xs * (1 - sg))), ulps=2.0)
+    _lib.lib().ea_set_gemm_variant(0)
+    return res
+
+
+def check_elementwise_dropout(M=1501, C=512, p=0.1, seed=0):
+    """`ea_scale_dropout_bf16` (FairseqDropout backward + the 0.5 FFN scale), the LayerNorm kernel's fused output dropout
+    (speech_transformer_encoder.py:348-350), and the LayerNorm backward's second output (`ea_layernorm_bwd_dx2`) against the
+    restated mask stream."""
+    import ctypes
+
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+    from oracle import dropout_ref as D
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = bf(torch.randn(M, C, generator=g) + 3.0).to(DEV)  # away from zero: "== 0" <=> dropped
+    yb = bf(torch.randn(M, C, generator=g)).to(DEV)
+    s1, s2 = (0x5EED << 32) | 77, (0x5EED << 32) | 78
+    m1, m2 = D.scale_mask(s1, (M, C), p), D.scale_mask(s2, (M, C), p)
+    res = {}
+    o = Kk.scale_dropout(x, a=0.5, y=yb, b=1.0, drop_p=p, drop_seed=s1)
+    torch.cuda.synchronize()
+    res["scale_dropout_ok"] = _bf_ulp_ok(o, 0.5 * x.float().cpu() * m1 + yb.float().cpu())
+    o = Kk.scale_dropout(x, a=1.0, drop_p=p, drop_seed=s1)
+    res["scale_dropout_bits"] = bool(((o.float().cpu() != 0) == (m1 != 0)).all())
+    # LayerNorm forward with output dropout and zeroed rows
+    gam, bet = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.rand(C, generator=g) + 4.0).to(DEV)
+    rz = (torch.rand(M, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    yl, mean, rstd = Kk.layernorm_fwd(x, gam, bet, 1e-5, rz, p, s2)
+    ref = torch.nn.functional.layer_norm(x.float().cpu(), (C,), gam.cpu(), bet.cpu(), 1e-5) * m2 * (1 - rz.cpu().float()).unsqueeze(1)
+    res["ln_drop_ok"] = _bf_ulp_ok(yl, ref)
+    res["ln_drop_bits"] = bool(((yl.float().cpu() != 0) == ((m2 != 0) & (rz.cpu() == 0).unsqueeze(1))).all())
+    # LayerNorm backward through the same dropout: dx of y = drop(LN(x)) equals LN-backward of (dy * mask)
+    dy = bf(torch.randn(M, C, generator=g)).to(DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = Kk.layernorm_bwd(x, dy, gam, mean, rstd, dg, db, rz, p, s2)
+    xr = x.float().cpu().requires_grad_(True)
+    gr, br = gam.cpu().clone().requires_grad_(True), bet.cpu().clone().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5) * m2 * (1 - rz.cpu().float()).unsqueeze(1) * dy.float().cpu()).sum().backward()
+    res["ln_bwd_dx"] = rel_err(dx, xr.grad)
+    res["ln_bwd_dgamma"] = rel_err(dg, gr.grad)
+    res["ln_bwd_dbeta"] = rel_err(db, br.grad)
+    # second output of the LayerNorm backward: out2 = a2 * dropout(dx; seed2)
+    lib = _lib.lib()
+    ws = torch.empty(lib.ea_layernorm_bwd_workspace_bytes(M, C), dtype=torch.uint8, device=DEV)
+    dx2, out2 = torch.empty_like(x), torch.empty_like(x)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    thr, sc = Kk.drop_params(p)
+    _lib.check(lib.ea_layernorm_bwd_dx2(x.data_ptr(), dy.data_ptr(), gam.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx2.data_ptr(),
+                                        dg2.data_ptr(), db2.data_ptr(), M, C, None, ws.data_ptr(), out2.data_ptr(), 0.5, s1, thr, sc,
+                                        Kk._stream()), "ln_bwd_dx2")
+    torch.cuda.synchronize()
+    res["ln_bwd_out2_ok"] = _bf_ulp_ok(out2, 0.5 * dx2.float().cpu() * m1, ulps=1.0)
+    return res
+
+
 def check_gemm_query_split(M=333, C=256, Kin=192, with_v=True, glds=1, seed=0):
     """The QKV projection's query-split epilogue (EaGemmParams.q_u: columns [0, C) leave as (q + pos_u) * s and (q + pos_v) * s)
     against the two-step path it replaces — plain projection, then ea_relpos_q_prep: bit-identical q_u / q_v, and the k / v
@@ -249,7 +359,7 @@ class _Task:
         assert len(self.target_dictionary) == V
 
 
-def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128, learned_pos=False, legacy=None):
+def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128, learned_pos=False, legacy=None, dropout=0.0):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
     from espresso_amd.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderModel
 
@@ -259,7 +369,7 @@ def build_tiny_model(layer_type, V=40, embed_dim=64, heads=4, ffn=128, learned_p
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, layer_type
     e.learned_pos = learned_pos
     e.conv_channels = "[64, 64, 16, 16]"
-    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = dropout
     cfg.layernorm_embedding = True
     cfg.max_source_positions, cfg.max_target_positions = 3600, 200
     if legacy is not None:  # the options of a fixture written with `legacy=...` (oracle/gen_golden.py)
@@ -396,6 +506,93 @@ def check_encoder_vs_reference(layer_type="conformer", fixture=None):
     for k, v in bn_after.items():
         bn = max(bn, float((msd[k].float().cpu() - v).abs().max()))
     res["bn_running_abs"] = bn
+    return res
+
+
+def _grad_errors(named_params, oracle_sd, skip=lambda n: False):
+    """[(max |hip - oracle| / max |oracle|, name)] sorted worst first."""
+    errs = []
+    for n, p in named_params:
+        if skip(n) or p.grad is None:
+            continue
+        ge = oracle_sd[n].grad
+        errs.append((float((p.grad.float().cpu() - ge).abs().max() / (float(ge.abs().max()) + 1e-12)), n))
+    errs.sort(reverse=True)
+    return errs
+
+
+def _skip_zero_grad_params(n):
+    # true gradient exactly zero (a conv bias in front of BatchNorm, the key bias under softmax): the oracle's value is round-off
+    return (n.startswith("pre_encoder.convolutions.") and n.endswith(".bias")) or n.endswith("self_attn.k_proj.bias")
+
+
+def check_encoder_dropout_vs_oracle(layer_type="conformer", fixture=None, p=0.1, native=True, seed=4321):
+    """TRAINING-MODE parity (dropout = attention_dropout = activation_dropout = p, the recipes' 0.1): the HIP model's loss, logits
+    and every parameter gradient against the oracle running the reference's FairseqDropout sites with the HIP path's own keep
+    decisions (oracle/dropout_ref.py rebuilds every mask from the (site, seed) list the HIP forward reports; the hash itself is
+    pinned on the CPU and in check_gemm_dropout / check_elementwise_dropout).  Same bounds as the dropout-off comparison.
+    Control: the oracle with masks from different seeds must disagree far beyond the bound (the test can see a wrong mask)."""
+    from espresso_amd import _lib
+    from espresso_amd import functional as F
+    from oracle import dropout_ref as D
+    from oracle import torch_ref
+
+    name = fixture or f"ref_{layer_type}_ctc_tiny"
+    g, sd, _, _ = load_fixture(name)
+    learned = "learnedpos" in name
+    layer_type = layer_type.split("_")[0]
+    d, H, ffn = _fixture_shape(name)
+    model = build_tiny_model(layer_type, embed_dim=d, heads=H, ffn=ffn, learned_pos=learned, dropout=p).to(DEV)
+    load_ref_state(model, sd)
+    for l in model.encoder.layers:
+        l.use_native_runtime = native
+    feats, lengths = torch.from_numpy(g["feats"]).to(DEV), torch.from_numpy(g["lengths"]).to(DEV)
+    tgt = torch.from_numpy(g["targets"]).to(DEV)
+    tl = (tgt != 1).sum(-1)
+    model.train()
+    F.set_dropout_seed(seed)
+    with F.trace_dropout_seeds() as tr:
+        out = model(feats, lengths)
+    lo = out["encoder_out"][0].float().cpu().detach()
+    B, Tp = out["encoder_padding_mask"][0].shape
+    nll, _ = F.ctc_loss(out["_logits_bt"][0], tgt.to(torch.int32).contiguous(), out["src_lengths"][0].to(torch.int32),
+                        tl.to(torch.int32), B, Tp, blank=0)
+    loss = nll.sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    res = {"train_loss": float(loss.detach()), "sites": [e[0] for e in tr.entries]}
+    lib = _lib.lib()
+    flash = d // H == 64
+
+    def oracle(trace, emulate):
+        sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version"
+                   and not k.endswith("_float_tensor") else v.clone()) for k, v in sd.items()}
+        plan = D.MaskPlan(trace, lib.ea_layer_dropout_seed)
+        with torch_ref.bf16_emulation(emulate, flash=flash), torch_ref.dropout_masks(plan):
+            lt, ole = torch_ref.encoder(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), sde, H=H, layer_type=layer_type,
+                                        training=True)
+            tg = torch.from_numpy(g["targets"])
+            el = torch_ref.ctc_loss_sum(lt, tg, ole, (tg != 1).sum(-1))
+            el.backward()
+        plan.done()
+        return float(el.detach()), lt.detach(), sde, plan
+
+    emu_loss, emu_logits, sde, plan = oracle(tr.entries, True)
+    res["n_site_masks"] = len(plan.queue)
+    res["emu_loss"] = emu_loss
+    res["train_logits_vs_emulation"] = float((lo - emu_logits).abs().max())
+    errs = _grad_errors(model.encoder.named_parameters(), sde, _skip_zero_grad_params)
+    res["worst_grad_vs_emulation"] = (errs[0][1], errs[0][0])
+    res["median_grad_vs_emulation"] = errs[len(errs) // 2][0]
+    res["fp32_loss"], _, sdf, _ = oracle(tr.entries, False)
+    errs32 = _grad_errors(model.encoder.named_parameters(), sdf, _skip_zero_grad_params)
+    res["worst_grad_vs_fp32"] = (errs32[0][1], errs32[0][0])
+    # control: same sites, other seeds
+    wrong = [[s, sd_ + 977 * 64, pp] for s, sd_, pp in tr.entries]
+    res["wrong_mask_loss"], wl, sdw, _ = oracle(wrong, True)
+    errsw = _grad_errors(model.encoder.named_parameters(), sdw, _skip_zero_grad_params)
+    res["wrong_mask_median_grad"] = errsw[len(errsw) // 2][0]
+    res["wrong_mask_logits"] = float((lo - wl).abs().max())
     return res
 
 

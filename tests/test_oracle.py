@@ -174,6 +174,91 @@ def test_decoder_restatement_matches_reference(golden_dir):
     assert float(nll) == pytest.approx(float(g["out::nll"]), rel=1e-6)
 
 
+def test_dropout_hash_restatement_matches_the_library():
+    """oracle/dropout_ref.py `ea_hash` == csrc/common.h `ea_hash` (the library's host evaluation, no GPU): seeds with high words,
+    element indices beyond 2^32, the threshold rule, the seed table of the native layer runtime"""
+    import ctypes
+
+    from espresso_amd import _lib
+    from oracle import dropout_ref as D
+
+    lib = _lib.lib()
+    for seed in (0, 1, 0x5EED00000001, ((0x5EED << 32) | 7) * 64 % (1 << 63), 2 ** 64 - 1):
+        for idx0 in (0, 12345, 2 ** 32 - 5, 2 ** 40 + 3):
+            out = (ctypes.c_uint32 * 4096)()
+            assert lib.ea_dropout_hash_host(seed, idx0, 4096, out) == 0
+            assert (np.frombuffer(out, dtype=np.uint32) == D.ea_hash(seed, np.arange(idx0, idx0 + 4096, dtype=np.uint64))).all()
+    assert D.drop_threshold(0.0) == 0 and D.drop_threshold(0.1) == int(0.1 * 2 ** 32) and D.drop_threshold(1.0) == 2 ** 32 - 1
+    assert abs(float(D.keep_mask(99, 1 << 20, 0.1).mean()) - 0.9) < 1e-3
+    assert len({int(lib.ea_layer_dropout_seed(640, s)) for s in range(7)}) == 7  # the 7 conformer sites draw 7 different streams
+    assert all(640 < int(lib.ea_layer_dropout_seed(640, s)) < 704 for s in range(9))
+
+
+@pytest.mark.parametrize("name,layer_type", [("ref_dropout_conformer_ctc_tiny", "conformer"), ("ref_dropout_transformer_ctc_tiny", "transformer")])
+def test_encoder_restatement_with_dropout_matches_reference(golden_dir, name, layer_type):
+    """TRAINING mode with dropout 0.1: the reference's own encoder ran with every dropout call fed a given mask
+    (oracle/gen_golden.py dropout_fixtures); the restatement applies the same masks at its dropout sites and must reproduce
+    logits, loss and every gradient — pins WHERE the oracle drops (fc0 input, after the embedding LayerNorm, FFN activation /
+    output, attention probabilities / output, convolution-module output) and in which tensor layout, to the reference's code."""
+    import json
+
+    from espresso_amd import _lib
+    from oracle import dropout_ref as D
+
+    gd = np.load(os.path.join(golden_dir, name + ".npz"))
+    g, sd = _load(golden_dir, str(gd["source"]))
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and k != "version":
+            v.requires_grad_(True)
+    plan = D.MaskPlan(json.loads(str(gd["trace"])), _lib.lib().ea_layer_dropout_seed)
+    with torch_ref.dropout_masks(plan):
+        lo, ol = torch_ref.encoder(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), sd, H=4, layer_type=layer_type, training=True)
+    plan.done()
+    assert len(plan.queue) == (16 if layer_type == "conformer" else 10) and not plan.skipped
+    assert float((lo - torch.from_numpy(gd["out::train_logits"])).abs().max()) < 2e-5
+    assert float((lo - torch.from_numpy(g["out::train_logits"])).abs().max()) > 0.5  # (the masks do something)
+    tgt = torch.from_numpy(g["targets"])
+    loss = torch_ref.ctc_loss_sum(lo, tgt, ol, (tgt != 1).sum(-1))
+    assert float(loss) == pytest.approx(float(gd["out::train_loss"]), rel=1e-6)
+    loss.backward()
+    for k in gd.files:
+        if k.startswith("grad::"):
+            ref = torch.from_numpy(gd[k])
+            assert float((sd[k[6:]].grad - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6, k
+
+
+def test_decoder_restatement_with_dropout_matches_reference(golden_dir):
+    """the same for speech_transformer_base: encoder sites + decoder embedding dropout + self-attention / encoder-attention
+    probabilities and outputs + FFN of both decoder layers (fairseq transformer_decoder.py:324-327, transformer_layer.py:384-529)"""
+    import json
+
+    from espresso_amd import _lib
+    from oracle import dropout_ref as D
+
+    gd = np.load(os.path.join(golden_dir, "ref_dropout_transformer_encdec_tiny.npz"))
+    g, sd = _load(golden_dir, str(gd["source"]))
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.endswith("version") and "_float_tensor" not in k:
+            v.requires_grad_(True)
+    feats, lengths, prev, target = (torch.from_numpy(g[k]) for k in ("feats", "lengths", "prev", "target"))
+    plan = D.MaskPlan(json.loads(str(gd["trace"])), _lib.lib().ea_layer_dropout_seed)
+    with torch_ref.dropout_masks(plan):
+        lo = torch_ref.encdec(feats, lengths, prev, sd, 4, pad_idx=0, training=True)
+    plan.done()
+    assert len(plan.queue) == 2 + 2 * 4 + 1 + 2 * 6 and not plan.skipped
+    valid = target.ne(0)
+    assert float((lo - torch.from_numpy(gd["out::train_logits"]))[valid].abs().max()) < 2e-5
+    loss, nll = torch_ref.label_smoothed_nll(lo.reshape(-1, lo.shape[-1]), target.reshape(-1), 0.1, 0)
+    assert float(loss) == pytest.approx(float(gd["out::loss"]), rel=1e-6)
+    loss.backward()
+    worst = 0.0
+    for k in gd.files:
+        if k.startswith("grad::") and sd[k[6:]].grad is not None:
+            ref = torch.from_numpy(gd[k])
+            worst = max(worst, float((sd[k[6:]].grad - ref).abs().max() / (float(ref.abs().max()) + 1e-9)))
+    assert worst < 5e-4, worst
+
+
 def test_rnnt_restatement_vs_bruteforce_and_finite_differences():
     """Pins oracle/rnnt_ref.py: the alpha recursion equals an explicit sum over ALL alignments on tiny lattices, and the
     analytic gradient equals central finite differences."""
