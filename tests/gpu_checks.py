@@ -54,11 +54,12 @@ def check_gemm(M, N, K, a_ks, b_ks, batch=1, bias=False, act=None, resid=False, 
     return rel_err(C, ref)
 
 
-def _bf_ulp_ok(got, want_f32, ulps=1.0):
-    """got bf16 tensor vs the fp32 value it should be the rounding of: within `ulps` bf16 steps of that value's magnitude."""
+def _bf_ulp_ok(got, want_f32, ulps=1.0, atol=0.0):
+    """got bf16 tensor vs the fp32 value it should be the rounding of: within `ulps` bf16 steps of that value's magnitude
+    (+ `atol` where the value is a difference of larger terms: fp32 association / fma contraction differ there)."""
     got, want = got.float().cpu(), want_f32.float().cpu()
     step = torch.exp2(torch.floor(torch.log2(want.abs().clamp_min(2.0 ** -60))) - 7)
-    return float(((got - want).abs() / step).max()) <= ulps + 1e-3
+    return float((((got - want).abs() - atol).clamp_min(0) / step).max()) <= ulps + 1e-3
 
 
 def check_gemm_dropout(M=777, N=520, K=192, batch=2, p=0.1, seed=0, variant=0):
@@ -101,7 +102,7 @@ def check_gemm_dropout(M=777, N=520, K=192, batch=2, p=0.1, seed=0, variant=0):
     res["c2_drop_ok"] = _bf_ulp_ok(C2, torch.nn.functional.silu(pre) * mask) and bool(((C2.cpu().float() != 0) == keep).all())
     # (3) FFN second GEMM: out = 0.5 * drop(acc + bias) + residual
     o = run(True, bias=bvec, out_scale=0.5, resid=R, ldr=N, sR=(M * N, 0), cdtype=torch.bfloat16)
-    res["resid_ok"] = _bf_ulp_ok(o, 0.5 * (pre * mask) + R.float().cpu())
+    res["resid_ok"] = _bf_ulp_ok(o, 0.5 * (pre * mask) + R.float().cpu(), atol=1e-4)
     # (4) backward through activation + activation dropout: dz = drop(acc) * act'(aux)
     aux = bf(torch.randn(batch, M, N, generator=g)).to(DEV)
     d = run(True, aux=aux, ldaux=N, sX=(M * N, 0), act="silu", cdtype=torch.bfloat16)
@@ -130,7 +131,7 @@ def check_elementwise_dropout(M=1501, C=512, p=0.1, seed=0):
     res = {}
     o = Kk.scale_dropout(x, a=0.5, y=yb, b=1.0, drop_p=p, drop_seed=s1)
     torch.cuda.synchronize()
-    res["scale_dropout_ok"] = _bf_ulp_ok(o, 0.5 * x.float().cpu() * m1 + yb.float().cpu())
+    res["scale_dropout_ok"] = _bf_ulp_ok(o, 0.5 * x.float().cpu() * m1 + yb.float().cpu(), atol=2e-6)
     o = Kk.scale_dropout(x, a=1.0, drop_p=p, drop_seed=s1)
     res["scale_dropout_bits"] = bool(((o.float().cpu() != 0) == (m1 != 0)).all())
     # LayerNorm forward with output dropout and zeroed rows
