@@ -588,6 +588,15 @@ def check_encoder_dropout_vs_oracle(layer_type="conformer", fixture=None, p=0.1,
     res["fp32_loss"], _, sdf, _ = oracle(tr.entries, False)
     errs32 = _grad_errors(model.encoder.named_parameters(), sdf, _skip_zero_grad_params)
     res["worst_grad_vs_fp32"] = (errs32[0][1], errs32[0][0])
+    # how far the two ORACLE runs (fp32 / bf16-emulating: same arithmetic, same masks) are from each other, per tensor: a tensor
+    # on which they disagree by more than the 8 % bound is rounding-chaotic at this precision (ReLU / dropout kinks: a derivative
+    # flips when a pre-activation within one bf16 step of zero rounds to the other side), and no implementation can be held
+    # closer to either of them than they are to each other
+    gap = {n: float((sde[n].grad - sdf[n].grad).abs().max() / (float(sdf[n].grad.abs().max()) + 1e-12)) for _, n in errs}
+    res["worst_excess_over_bound"] = max(e / max(0.08, gap[n]) for e, n in errs)
+    res["oracle_gap_of_worst"] = gap[errs[0][1]]
+    gaps = sorted(gap.values())
+    res["median_oracle_gap"] = gaps[len(gaps) // 2]
     # control: same sites, other seeds
     wrong = [[s, sd_ + 977 * 64, pp] for s, sd_, pp in tr.entries]
     res["wrong_mask_loss"], wl, sdw, _ = oracle(wrong, True)
@@ -814,7 +823,7 @@ class _TaskAR:
         assert len(self.target_dictionary) == V
 
 
-def build_tiny_encdec(V=40, embed_dim=64, heads=4, learned_pos=False, ffn=128):
+def build_tiny_encdec(V=40, embed_dim=64, heads=4, learned_pos=False, ffn=128, dropout=0.0):
     from espresso_amd.models.transformer.speech_transformer_base import SpeechTransformerModelBase
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
 
@@ -826,7 +835,7 @@ def build_tiny_encdec(V=40, embed_dim=64, heads=4, learned_pos=False, ffn=128):
     e.conv_channels = "[64, 64, 16, 16]"
     d.embed_dim, d.ffn_embed_dim, d.layers, d.attention_heads, d.normalize_before = embed_dim, ffn, 2, heads, True
     d.input_dim = d.output_dim = embed_dim
-    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = dropout
     cfg.layernorm_embedding = True
     cfg.max_source_positions, cfg.max_target_positions = 3600, 200
     return SpeechTransformerModelBase.build_model(cfg, _TaskAR(V))
@@ -884,9 +893,9 @@ def check_legacy_speech_transformer_step(arch="speech_transformer_wsj"):
     return res
 
 
-def _encdec_for(fixture):
+def _encdec_for(fixture, dropout=0.0):
     d, H, ffn = _fixture_shape(fixture)
-    return build_tiny_encdec(embed_dim=d, heads=H, ffn=ffn)
+    return build_tiny_encdec(embed_dim=d, heads=H, ffn=ffn, dropout=dropout)
 
 
 def check_encdec_deferred_matches_immediate(fixture="ref_transformer_encdec_dh64"):
@@ -993,6 +1002,69 @@ def check_encdec_vs_reference(fixture="ref_transformer_encdec_tiny"):
     res["median_grad_vs_emulation"] = errs_emu[len(errs_emu) // 2][0]
     res["worst_l2_vs_emulation"] = (l2_emu[0][1], l2_emu[0][0])
     res["median_l2_vs_emulation"] = l2_emu[len(l2_emu) // 2][0]
+    return res
+
+
+def check_encdec_dropout_vs_oracle(fixture="ref_transformer_encdec_dh64", p=0.1, seed=99):
+    """speech_transformer_base in TRAINING mode with dropout = attention_dropout = activation_dropout = p: loss, logits and
+    every gradient vs the oracle running the reference's dropout sites (encoder + decoder embedding, self-attention,
+    encoder-decoder attention, FFN: fairseq transformer_decoder.py:324-327, transformer_layer.py:384-529) with the HIP path's
+    keep decisions; see check_encoder_dropout_vs_oracle."""
+    from espresso_amd import _lib
+    from espresso_amd import functional as F
+    from oracle import dropout_ref as D
+    from oracle import torch_ref
+
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = _encdec_for(fixture, dropout=p).to(DEV)
+    missing, unexpected = model.load_state_dict(model.upgrade_state_dict_named(dict(sd0), ""), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    feats, lengths = torch.from_numpy(g["feats"]).to(DEV), torch.from_numpy(g["lengths"]).to(DEV)
+    prev, target = torch.from_numpy(g["prev"]).to(DEV), torch.from_numpy(g["target"]).to(DEV)
+    valid = target.ne(0).cpu()
+    model.train()
+    F.set_dropout_seed(seed)
+    with F.trace_dropout_seeds() as tr:
+        lo, extra = model(feats, lengths, prev)
+    loss, nll = F.label_smoothed_ce(extra["_logits_bu"], target.reshape(-1).to(torch.int32).contiguous(), 0, 0.1)
+    loss.backward()
+    torch.cuda.synchronize()
+    lo = lo.detach().float().cpu()
+    res = {"loss": float(loss), "sites": [e[0] for e in tr.entries]}
+    d, H, _ = _fixture_shape(fixture)
+    lib = _lib.lib()
+    skip = lambda n: (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias")) or n.endswith("attn.k_proj.bias")
+
+    def oracle(trace, emulate):
+        sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version"
+                   and not k.endswith("_float_tensor") else v.clone()) for k, v in sd0.items()}
+        plan = D.MaskPlan(trace, lib.ea_layer_dropout_seed)
+        with torch_ref.bf16_emulation(emulate, flash=(d // H == 64)), torch_ref.dropout_masks(plan):
+            el = torch_ref.encdec(torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"]), sde, H, 0,
+                                  training=True)
+            eloss, _ = torch_ref.label_smoothed_nll(el.reshape(-1, el.shape[-1]), torch.from_numpy(g["target"]).reshape(-1), 0.1, 0)
+            eloss.backward()
+        plan.done()
+        return float(eloss.detach()), el.detach(), sde, plan
+
+    res["emu_loss"], el, sde, plan = oracle(tr.entries, True)
+    res["n_site_masks"] = len(plan.queue)
+    res["train_logits_vs_emulation"] = float((lo - el)[valid].abs().max())
+    errs = _grad_errors(model.named_parameters(), sde, skip)
+    res["worst_grad_vs_emulation"] = (errs[0][1], errs[0][0])
+    res["median_grad_vs_emulation"] = errs[len(errs) // 2][0]
+    res["fp32_loss"], _, sdf, _ = oracle(tr.entries, False)
+    gap = {n: float((sde[n].grad - sdf[n].grad).abs().max() / (float(sdf[n].grad.abs().max()) + 1e-12)) for _, n in errs}
+    res["worst_excess_over_bound"] = max(e / max(0.08, gap[n]) for e, n in errs)
+    res["oracle_gap_of_worst"] = gap[errs[0][1]]
+    gaps = sorted(gap.values())
+    res["median_oracle_gap"] = gaps[len(gaps) // 2]
+    wrong = [[s_, sd_ + 977 * 64, pp] for s_, sd_, pp in tr.entries]
+    res["wrong_mask_loss"], wl, sdw, _ = oracle(wrong, True)
+    errsw = _grad_errors(model.named_parameters(), sdw, skip)
+    res["wrong_mask_median_grad"] = errsw[len(errsw) // 2][0]
+    res["wrong_mask_logits"] = float((lo - wl)[valid].abs().max())
     return res
 
 
@@ -2361,25 +2433,28 @@ def check_fullsize_encoder_batch_independence(seed=0):
     return {"abs": worst, "scale": scale, "frames_checked": checked, "finite": bool(torch.isfinite(lo.float()).all())}
 
 
-def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0, layers=1, lens=(400, 333, 250, 120), tl=(9, 7, 5, 3)):
+def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0, layers=1, lens=(400, 333, 250, 120), tl=(9, 7, 5, 3), V=5004, dropout=0.0):
     """Config-3 LAYER dimensions (embed 512, 8 heads of 64, FFN 2048, depthwise kernel 31, conv front-end 64-64-128-128) in a
     one-layer model with random weights, HIP vs the pinned oracle (oracle/torch_ref.py) on the same weights and inputs: eval
     logits, train-mode CTC loss and every gradient, against the fp32 restatement (north_star's bf16 tolerance) and against its
-    bf16-emulating mode (tight).  The 12-layer model is the same layer 12 times; its full-size run is covered by the
-    size-independent properties (batch independence, row sums) and by bench.py's CPU leg."""
+    bf16-emulating mode (tight).  `layers=12`: the model bench.py times.  `V` = the recipe's 5004 (5000 unigram pieces + specials).
+    `dropout` > 0: the train-mode pass runs with dropout = attention_dropout = activation_dropout = that value (the recipe: 0.1) and
+    the oracle applies the reference's dropout sites with the HIP path's keep decisions (check_encoder_dropout_vs_oracle)."""
+    from espresso_amd import _lib
     from espresso_amd import functional as F
+    from oracle import dropout_ref as D
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
     from espresso_amd.models.transformer.speech_transformer_encoder_model import SpeechTransformerEncoderModel
     from oracle import torch_ref
 
     torch.manual_seed(seed)
-    V, H = 200, 8
+    H = 8
     cfg = SpeechTransformerConfig()
     e = cfg.encoder
     e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, layers, H
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, layer_type
     e.conv_channels = "[64, 64, 128, 128]"
-    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = dropout
     cfg.layernorm_embedding = True
     cfg.max_source_positions, cfg.max_target_positions = 3600, 200
     model = SpeechTransformerEncoderModel.build_model(cfg, _Task(V))
@@ -2405,7 +2480,9 @@ def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0, layers=1, len
         out = model(feats.to(DEV), lengths.to(DEV))
     hip_eval = out["encoder_out"][0].float().cpu()
     model.train()
-    out = model(feats.to(DEV), lengths.to(DEV))
+    F.set_dropout_seed(seed + 17)
+    with F.trace_dropout_seeds() as tr:
+        out = model(feats.to(DEV), lengths.to(DEV))
     B, Tp = out["encoder_padding_mask"][0].shape
     nll, _ = F.ctc_loss(out["_logits_bt"][0], tgt.to(DEV).to(torch.int32).contiguous(), out["src_lengths"][0].to(torch.int32),
                         torch.tensor(tl, dtype=torch.int32, device=DEV), B, Tp, blank=0)
@@ -2414,6 +2491,7 @@ def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0, layers=1, len
     torch.cuda.synchronize()
     hip_grads = {n: p.grad.float().cpu() for n, p in model.encoder.named_parameters() if p.grad is not None}
     res["hip_loss"] = float(loss.detach())
+    res["n_seed_draws"] = len(tr.entries)
     # ---- oracle: fp32 restatement and bf16 emulation ----
     for tag, emu in (("fp32", False), ("emu", True)):
         sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version" else v.clone())
@@ -2421,7 +2499,11 @@ def check_fullsize_layer_vs_oracle(layer_type="conformer", seed=0, layers=1, len
         with torch_ref.bf16_emulation(emu, flash=True):
             with torch.no_grad():
                 lo, ol = torch_ref.encoder(feats, lengths, sdo, H=H, layer_type=layer_type, training=False)
-            lt, ol = torch_ref.encoder(feats, lengths, sdo, H=H, layer_type=layer_type, training=True)
+            plan = D.MaskPlan(tr.entries, _lib.lib().ea_layer_dropout_seed)
+            with torch_ref.dropout_masks(plan if dropout > 0 else None):
+                lt, ol = torch_ref.encoder(feats, lengths, sdo, H=H, layer_type=layer_type, training=True)
+            plan.done()
+            res["n_site_masks"] = len(plan.queue)
             oloss = torch_ref.ctc_loss_sum(lt, tgt, ol, torch.tensor(tl))
             oloss.backward()
         res[f"{tag}_loss"] = float(oloss.detach())
@@ -2894,7 +2976,7 @@ model:
 
 
 # ------------------------------------------------------------------ training-trajectory parity (+n2)
-def check_training_trajectory(steps=None):
+def check_training_trajectory(steps=None, dropout=0.0):
     """tests/trajectory.py: `steps` Adam updates of the dh-64 Conformer-CTC on the learnable synthetic task, HIP path vs the
     oracle (fp32 and bf16-emulating), same initial weights, batches and order; held-out greedy token error rate at the end."""
     from espresso_amd import functional as F
@@ -2906,16 +2988,19 @@ def check_training_trajectory(steps=None):
     d, H, ffn = _fixture_shape(TR.FIXTURE)
     steps = steps or TR.STEPS
     train, heldout = TR.make_batches(TR.TRAIN_BATCHES, seed=0), TR.make_batches(TR.HELDOUT_BATCHES, seed=1)
-    model = build_tiny_model("conformer", embed_dim=d, heads=H, ffn=ffn).to(DEV)
+    model = build_tiny_model("conformer", embed_dim=d, heads=H, ffn=ffn, dropout=dropout).to(DEV)
     load_ref_state(model, sd)
     flat = FlatParams(model, DEV)
     opt = FlatAdam(flat, lr=TR.LR, betas=TR.BETAS, eps=TR.EPS)
     model.train()
-    losses = []
+    losses, traces = [], []
     for step in range(steps):
         feats, lens, tg = (t.to(DEV) for t in train[step % len(train)])
         F.begin_step(feats.device)
-        out = model(feats, lens)
+        F.set_dropout_seed(1 + step)  # (trainer.py: seed + num_updates)
+        with F.trace_dropout_seeds() as tr:
+            out = model(feats, lens)
+        traces.append(tr.entries)
         B, Tp = out["encoder_padding_mask"][0].shape
         nll, _ = F.ctc_loss(out["_logits_bt"][0], tg.to(torch.int32).contiguous(), out["src_lengths"][0].to(torch.int32),
                             (tg != 1).sum(-1).to(torch.int32), B, Tp, blank=0)
@@ -2934,8 +3019,11 @@ def check_training_trajectory(steps=None):
             tot += t_
     torch.cuda.synchronize()
     res = {"hip_losses": losses, "hip_ter": err / tot, "tokens": tot}
+    from espresso_amd import _lib
+
     for tag, emu in (("fp32", False), ("emu", True)):
-        ol, oe, ot = TR.train_oracle(sd, train, heldout, steps, emu)
+        ol, oe, ot = TR.train_oracle(sd, train, heldout, steps, emu, traces=traces if dropout > 0 else None,
+                                     layer_seed_fn=_lib.lib().ea_layer_dropout_seed)
         rel = [abs(a - b) / max(b, 1e-3) for a, b in zip(losses, ol)]
         half = lambda ls: next((i for i, x in enumerate(ls) if x < 0.5 * ls[5]), len(ls))
         res[tag] = {"losses": ol, "ter": oe / ot, "max_rel_first24": max(rel[:24]), "max_rel_all": max(rel),

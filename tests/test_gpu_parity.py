@@ -197,10 +197,27 @@ def test_encoder_training_mode_dropout_vs_oracle(layer_type, fixture, native):
     assert abs(r["train_loss"] - r["emu_loss"]) / r["emu_loss"] < 2e-3, r
     assert abs(r["train_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r  # north_star's bf16 tolerance vs the fp32 arithmetic
     assert r["train_logits_vs_emulation"] < 4e-2, r
-    assert r["worst_grad_vs_emulation"][1] < 8e-2 and r["median_grad_vs_emulation"] < 1.2e-2, r
+    # every gradient within 8 % of the tensor's scale — or, for a tensor on which the fp32 and the emulating ORACLE runs differ
+    # by more than that themselves (rounding-chaotic: ReLU kinks under activation dropout), within that gap; median 1.2 %
+    assert r["worst_excess_over_bound"] < 1.0, r
+    assert r["worst_grad_vs_emulation"][1] < 0.15, r
+    assert r["median_grad_vs_emulation"] < max(1.2e-2, 0.8 * r["median_oracle_gap"]), r
     # control: the same oracle with masks from other seeds is far outside those bounds
     assert abs(r["train_loss"] - r["wrong_mask_loss"]) / r["emu_loss"] > 1e-2 or r["wrong_mask_logits"] > 0.3, r
     assert r["wrong_mask_median_grad"] > 5 * 1.2e-2, r
+
+
+@pytest.mark.parametrize("fixture", ["ref_transformer_encdec_tiny", "ref_transformer_encdec_dh64"])
+def test_encdec_training_mode_dropout_vs_oracle(fixture):
+    r = G.check_encdec_dropout_vs_oracle(fixture, p=0.1)
+    print(r)
+    assert r["n_site_masks"] == 2 + 2 * 4 + 1 + 2 * 6, r
+    assert abs(r["loss"] - r["emu_loss"]) / r["emu_loss"] < 2e-3 and abs(r["loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r
+    assert r["train_logits_vs_emulation"] < 4e-2, r
+    assert r["worst_excess_over_bound"] < 1.0 and r["worst_grad_vs_emulation"][1] < 0.3, r
+    assert r["median_grad_vs_emulation"] < max(1.5e-2, 0.8 * r["median_oracle_gap"]), r
+    assert abs(r["loss"] - r["wrong_mask_loss"]) / r["emu_loss"] > 1e-2 or r["wrong_mask_logits"] > 0.3, r
+    assert r["wrong_mask_median_grad"] > 5 * 1.5e-2, r
 
 
 def test_conv1_fused_batchnorm_backward_and_weight_gradient():
@@ -625,12 +642,15 @@ def test_fullsize_attention_properties():
     assert r["finite"] and r["ones_abs"] < 1.6e-2 and r["pad_independence_abs"] == 0.0, r
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
 @pytest.mark.parametrize("layer_type", ["conformer", "transformer"])
-def test_fullsize_layer_vs_oracle(layer_type):
-    """embed 512 / 8 heads / FFN 2048 (config 3's layer) against the pinned oracle on the same random weights."""
-    r = G.check_fullsize_layer_vs_oracle(layer_type)
+def test_fullsize_layer_vs_oracle(layer_type, dropout):
+    """embed 512 / 8 heads / FFN 2048, V = 5004 (config 3's layer and vocabulary) against the pinned oracle on the same random
+    weights; dropout 0.1 = the recipe's training mode with the HIP path's masks fed to the oracle."""
+    r = G.check_fullsize_layer_vs_oracle(layer_type, dropout=dropout)
     print(r)
     assert r["n_grads"] > 30
+    assert r["n_site_masks"] == (0 if dropout == 0 else 2 + (7 if layer_type == "conformer" else 4)), r
     assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r          # north_star: 1e-2 (bf16) on losses
     assert r["eval_logits_vs_fp32"] < 1e-2 * max(4.0, r["logit_scale"]), r           # ... and log-probs, relative to their scale
     assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 2e-3, r
@@ -638,18 +658,20 @@ def test_fullsize_layer_vs_oracle(layer_type):
     assert r["worst_grad_vs_emu"][1] < 8e-2 and r["median_grad_vs_emu"] < 1.2e-2, r
 
 
-def test_fullsize_12_layer_model_vs_oracle():
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_fullsize_12_layer_model_vs_oracle(dropout):
     """The model bench.py times (12 Conformer layers, embed 512 / 8 heads / FFN 2048, 64-64-128-128 front-end) with random
     weights on two utterances, HIP vs the pinned oracle on the same weights: eval logits, train-mode CTC loss and every gradient
     (VERDICT r2 weak #4: the recipe-sized comparison used to stop at ONE layer)."""
-    r = G.check_fullsize_layer_vs_oracle("conformer", layers=12, lens=(330, 211), tl=(8, 5))
+    r = G.check_fullsize_layer_vs_oracle("conformer", layers=12, lens=(330, 211), tl=(8, 5), dropout=dropout)
     print(r)
     assert r["n_grads"] > 400
+    assert r["n_site_masks"] == (0 if dropout == 0 else 2 + 12 * 7), r
     assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r          # north_star: 1e-2 (bf16) on losses
     assert r["eval_logits_vs_fp32"] < 2e-2 * max(4.0, r["logit_scale"]), r           # 12 layers of bf16 activations
     assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 3e-3, r
     assert r["eval_logits_vs_emu"] < 1.5e-2 * max(4.0, r["logit_scale"]), r   # measured 0.047 at |logit| <= 3.1: 3 bf16 steps
-    assert r["worst_grad_vs_emu"][1] < 0.15 and r["median_grad_vs_emu"] < 2e-2, r
+    assert r["worst_grad_vs_emu"][1] < 8e-2 and r["median_grad_vs_emu"] < 1.2e-2, r  # (measured 4.9 % / 0.8 % at dropout 0)
 
 
 def test_fullsize_encoder_batch_independence():
@@ -680,7 +702,8 @@ def test_native_decoder_layer_matches_kernel_composition():
     assert r["pad_enc_grad"] == 0.0, r   # padded encoder frames get no gradient from the attention
 
 
-def test_training_trajectory_vs_oracle():
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_training_trajectory_vs_oracle(dropout):
     """+n2 (stand-in for "WER within 0.1 abs of the reference"): 80 Adam updates of the dh-64 Conformer-CTC on the learnable
     synthetic task of tests/trajectory.py, HIP path vs the oracle from the same weights / batches / order.  The loss sits on a
     plateau (~27 per sentence) for ~28 updates and then falls off a cliff; two runs that differ only in rounding leave the
@@ -689,8 +712,10 @@ def test_training_trajectory_vs_oracle():
     measured 0.3 %), position of the cliff (+-4 updates), area under the loss curve (6 %), end state: mean loss of the last 10
     updates within 0.3 and held-out greedy token error rate within 2 tokens per 100.  (The verdict asked for 1 per 100; that is
     the spread between two CORRECT runs: the fp32 and the emulating oracle end at 2.1 % / 1.3 % after 80 updates and at 1.9 % /
-    0.9 % after 120, and the HIP path has landed at 1.6 % and 2.7 % on two builds that differ in one LayerNorm reduction order.)"""
-    r = G.check_training_trajectory()
+    0.9 % after 120, and the HIP path has landed at 1.6 % and 2.7 % on two builds that differ in one LayerNorm reduction order.)
+    dropout 0.1: the same run in the recipes' training mode — every update's keep decisions (16 mask streams) go from the HIP
+    path to the oracle, so the two still see the same noise; same bounds."""
+    r = G.check_training_trajectory(dropout=dropout)
     print({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk != "losses"}) for k, v in r.items() if k != "hip_losses"})
     print("hip ", [round(x, 2) for x in r["hip_losses"][::4]])
     print("emu ", [round(x, 2) for x in r["emu"]["losses"][::4]])

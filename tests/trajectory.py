@@ -4,7 +4,8 @@ corpus and no trained checkpoint in this environment).
 Task: every target token owns a random 80-dimensional template; an utterance is its token sequence with each template held
 for 8 frames plus Gaussian noise (sigma 2.5: neighbouring tokens are confusable), ragged lengths, no repeated neighbours.  A 2-layer
 Conformer-CTC (the weights of tests/golden/ref_conformer_ctc_dh64.npz: head dim 64, i.e. the fused rel-pos attention kernels)
-is trained from the same initial weights on the same batches in the same order, dropout 0, by
+is trained from the same initial weights on the same batches in the same order, with dropout 0 or with dropout 0.1 and the
+HIP path's own keep decisions handed to the oracle, by
   * the HIP path: model forward / CTC / backward through the C ABI, FlatAdam (csrc/optim.hip), and
   * the oracle: oracle/torch_ref.py (fp32, or rounding to bf16 at the HIP storage points) + a restatement of
     fairseq/utils.py:347-397 (clip) and fairseq/optim/adam.py:215-240 (Adam).
@@ -68,8 +69,10 @@ def greedy_errors(logits_tbv, out_len, targets):
     return err, tot
 
 
-def train_oracle(sd, train, heldout, steps, emulate):
-    from oracle import torch_ref
+def train_oracle(sd, train, heldout, steps, emulate, traces=None, layer_seed_fn=None):
+    """`traces`: per update, the (site, seed, p) list the HIP path's forward drew (dropout on): the oracle then applies the
+    reference's dropout sites with those keep decisions (oracle/dropout_ref.py); None = dropout 0."""
+    from oracle import dropout_ref, torch_ref
 
     P = {k: (v.clone().float().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("_float_tensor")
              and k != "version" else v.clone()) for k, v in sd.items()}
@@ -80,9 +83,12 @@ def train_oracle(sd, train, heldout, steps, emulate):
     for step in range(steps):
         feats, lens, tg = train[step % len(train)]
         upd = {}
-        with torch_ref.bf16_emulation(emulate, flash=True):
+        plan = dropout_ref.MaskPlan(traces[step], layer_seed_fn) if traces is not None else None
+        with torch_ref.bf16_emulation(emulate, flash=True), torch_ref.dropout_masks(plan):
             lt, ol = torch_ref.encoder(feats, lens, P, H=HEADS, layer_type="conformer", training=True, update=upd)
             loss = torch_ref.ctc_loss_sum(lt, tg, ol, (tg != 1).sum(-1))
+        if plan is not None:
+            plan.done()
         for k in names:
             P[k].grad = None
         loss.backward()
