@@ -230,9 +230,26 @@ def install():
                 metrics.log_speed("wps", ntokens, priority=90, round=1)
             if any("nsentences" in log for log in logging_outputs):
                 metrics.log_scalar("bsz", sum(log.get("nsentences", 0) for log in logging_outputs), priority=190, round=1)
+            # weights as in the reference's criteria (espresso/criterions/ctc_loss.py:146-160, label_smoothed_cross_entropy_v2.py,
+            # transducer_loss.py: loss per sample_size, nll_loss per token) and task (speech_recognition.py:615-629: wer per
+            # word, cer per character): fairseq's meters average log_scalar values by weight over an epoch / validation pass,
+            # and --best-checkpoint-metric / reduce_lr_on_plateau read those averages
+            tot = lambda k: sum(log.get(k, 0) for log in logging_outputs)
+            weights = {"loss": tot("sample_size"), "nll_loss": tot("ntokens"), "wer": tot("word_count"), "cer": tot("char_count")}
             for k, v in (out or {}).items():
-                if isinstance(v, (int, float)) or (torch.is_tensor(v) and v.numel() == 1):
-                    metrics.log_scalar(k, float(v), round=3)
+                if not (isinstance(v, (int, float)) or (torch.is_tensor(v) and v.numel() == 1)):
+                    continue
+                if k in ("sample_size", "ppl", "word_error", "word_count", "char_error", "char_count"):
+                    continue  # (ppl is derived below; the reference logs neither the raw error counts nor sample_size)
+                if k in weights:
+                    metrics.log_scalar(k, float(v), float(weights[k]) if weights[k] else 1, round=4 if k in ("wer", "cer") else 3)
+                else:
+                    metrics.log_scalar(k, float(v))
+            if out and ("nll_loss" in out or "ppl" in out):
+                from fairseq import utils as fq_utils
+
+                key = "nll_loss" if "nll_loss" in out else "loss"
+                metrics.log_derived("ppl", lambda meters, key=key: fq_utils.get_perplexity(meters[key].avg))
             return out
 
     FairseqTaskAdapter.__name__ = "SpeechRecognitionEspressoTask"
