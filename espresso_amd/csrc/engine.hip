@@ -35,6 +35,10 @@ struct Arena {
 };
 
 inline int pad8(int n) { return (n + 7) / 8 * 8; }
+// Row pitch of the attention backward's dBD buffer (gradient of the raw positional logits, [H*B][T][pitch], 2T-1 columns used):
+// whole 128-column tiles, so that the pos_proj gradient product over it can ride in the layer's grouped weight-gradient launch
+// (direct-to-LDS kernel: ea_wgrad_group needs ld_x >= K rounded up to 128); the pad columns are never read as results.
+inline int pad_bd(int r) { return (r + 127) / 128 * 128; }
 
 // Dropout mask streams of a layer call.  Every dropout site of a layer draws its keep decisions from ea_keep(site seed, element
 // index) with site seed = EaLayerShape.seed + module base + site offset; the same sum is formed again in the backward pass, so
@@ -51,9 +55,10 @@ constexpr uint64_t kAct = 1, kOut = 2, kProbs = 3, kAttnOut = 4, kConvOut = 5;  
 struct Deferred {
   EaWgradGroup grp;
   EaLnReduceGroup ln;
-  std::vector<std::function<int(hipStream_t)>> ops;
+  std::vector<std::function<int(hipStream_t)>> pre;  // before the grouped launch (e.g. zeroing an fp32 product it accumulates into)
+  std::vector<std::function<int(hipStream_t)>> ops;  // after it, in order
   Deferred() { clear(); }
-  void clear() { grp.count = 0; ln.count = 0; ops.clear(); }
+  void clear() { grp.count = 0; ln.count = 0; pre.clear(); ops.clear(); }
 };
 
 struct Ctx {
@@ -226,6 +231,7 @@ static void run_deferred(Ctx& c, int half) {
     return;
   }
   stream_wait(c, c.side, c.s);
+  for (auto& op : d.pre) RUN(op(c.side));
   RUN(ea_wgrad_group(&d.grp, c.side));
   RUN(ea_layernorm_param_reduce_group(&d.ln, c.side));
   for (auto& op : d.ops) RUN(op(c.side));
@@ -494,7 +500,7 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
 static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw,
                           const void* x, const void* dy, void* dx, const void* pe, uint16_t* dqkv, uint16_t* t1, uint16_t* t2,
                           uint16_t* dBD, const uint16_t* wqkvt, const Pre& next, float* dpe, bool have_dq = false) {
-  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad8(R);
+  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, R = 2 * T - 1, Rp = pad_bd(R);
   Arena& sc = *c.scratch;
   const bool learned = sh.pos_mode == 1;
   // dpp[r][h*dh+d] = sum_{b,i} dBD[h][(b,i)][r] qv[(b,i),h,d]: tiny output (R x C), reduction over all B*T frames -> split-K
@@ -536,7 +542,30 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
     gw2.bks().f32().acc();
     gw2.p.splitk = sk2;
     if (sk2 > 1) gw2.p.workspace = sc.get<float>((size_t)sk2 * C * C);
-    if (c.df) {
+    // Deferred mode: the product rides in the layer's grouped weight-gradient launch as one problem per head —
+    // dppT32[h*dh + d][r] += sum_m qv[m][h*dh + d] * dBD[h][m][r] is a "weight gradient" with dy = the head's 64 qv columns,
+    // x = the head's dBD slab (both [reduction rows][columns] as they lie in memory: global_load_lds + transposing LDS reads
+    // instead of the register-transposed split-K GEMM + slab reduce: 75 -> ~25 us per layer on the side stream)
+    static const bool gpp_grouped = getenv("EA_GPP_SPLITK") == nullptr;  // (diagnostic A/B switch)
+    const bool in_group = c.df && gpp_grouped && dh % 64 == 0 && c.df->grp.count + H + 3 <= EA_WGRAD_MAX;
+    if (in_group) {
+      for (int h = 0; h < H; ++h) {
+        EaWgradProblem& q = c.df->grp.p[c.df->grp.count++];
+        if (c.dry) continue;
+        q.dy = a.qv + (size_t)h * dh; q.x = dBD + (size_t)h * B * T * Rp; q.dW = dppT32 + (size_t)h * dh * Rp; q.dbias = nullptr;
+        q.M = B * T; q.N = dh; q.K = R; q.ld_dy = C; q.ld_x = Rp; q.ldw = Rp;
+      }
+      if (!c.dry) {
+        const EaGemmParams p2 = gw2.p;
+        const long ncast = (long)C * Rp;
+        c.df->pre.push_back([=](hipStream_t st) { return hipMemsetAsync(dppT32, 0, (size_t)ncast * sizeof(float), st) == hipSuccess ? 0 : -1; });
+        c.df->ops.push_back([=](hipStream_t st) {
+          int rc = ea_cast_f32_to_bf16(dppT32, dppT, ncast, st);  // pad columns R..Rp-1 are never read
+          if (rc == 0) rc = ea_gemm_bf16(&p2, st);
+          return rc;
+        });
+      }
+    } else if (c.df) {
       if (!c.dry) {
         const EaGemmParams p1 = gpp.p, p2 = gw2.p;
         const long ncast = (long)C * Rp;
@@ -567,7 +596,7 @@ static void attn_bwd_tail(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, co
 static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const EaAttnGrads& gw, const void* x,
                      const void* dy, void* dx, const int* key_len, const void* pe, uint64_t seed, const uint16_t* wqkvt,
                      const uint16_t* wot, const uint16_t* pre, const Pre& next, float* dpe = nullptr) {
-  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
+  const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad_bd(R);
   const float scaling = 1.0f / sqrtf((float)dh);
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;

@@ -20,6 +20,7 @@
 // being staged (4x8 block per thread -> eight ds_write_b64), which is what lets dgrad / wgrad /
 // P·V run without materialising transposed copies in HBM.
 #include <cstdio>
+#include <type_traits>
 #include "common.h"
 #include "espresso_amd.h"
 #include "gemm_common.h"
@@ -993,6 +994,10 @@ __global__ __launch_bounds__(256, BM_ == 64 ? 3 : 2) void wgrad_group_tr_kernel(
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) issue(s, s);
+  // the k-loop exists twice: with and without the bias MFMAs (a per-MFMA-pair branch on the workgroup-uniform `do_bias` broke
+  // the back-to-back MFMA issue of every tile, and only the tiles of column 0 ever take it)
+  auto kloop = [&](auto bias_tag) {
+  constexpr bool DO_BIAS = decltype(bias_tag)::value;
   int stage = 0, fill = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
     if (NST > 2 && kt + NST - 2 < nk) {
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(256, BM_ == 64 ? 3 : 2) void wgrad_group_tr_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af),
               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, bfr[ks][j]), acc[i][j], 0, 0, 0);
-        if (do_bias)
+        if constexpr (DO_BIAS)
           accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, af),
                                                             __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones), accb[i], 0, 0,
                                                             0);
@@ -1049,6 +1054,9 @@ __global__ __launch_bounds__(256, BM_ == 64 ? 3 : 2) void wgrad_group_tr_kernel(
     stage = stage + 1 == NST ? 0 : stage + 1;
     fill = fill + 1 == NST ? 0 : fill + 1;
   }
+  };
+  if (do_bias) kloop(std::true_type{});
+  else kloop(std::false_type{});
 
   if (do_bias && lj == 0 && wcol == 0) {  // every output row of the tile sits in column 0 of exactly one wave's bias accumulators
 #pragma unroll
