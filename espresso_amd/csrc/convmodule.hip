@@ -173,6 +173,69 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
   }
 }
 
+// Training-mode BatchNorm forward in ONE launch: every thread derives mean / rstd of its 8 channels from the fp64 batch sums
+// (what bn_finalize_kernel did in a launch of its own), block 0 also records mean / rstd for the backward pass and updates the
+// running statistics, and all blocks clear `zero_next` (the statistics buffer of the NEXT BatchNorm forward: two buffers take
+// turns, so no fill launch precedes the accumulating kernel).
+__global__ __launch_bounds__(256) void bn_act_fwd_stats_kernel(const bf16_t* __restrict__ Z, const double* __restrict__ stats,
+                                                               float* __restrict__ mean_rstd, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16_t* __restrict__ Hout, long M,
+                                                               int C, int act, float n, float eps, float momentum,
+                                                               double* __restrict__ zero_next, int zero_n) {
+  extern __shared__ float s_scsh[];  // [2][C]: scale, shift of every channel (once per block, not once per thread)
+  const int nch = C >> 3;
+  const long total = M * nch;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const double inv_n = 1.0 / (double)n;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    // (bn_finalize_kernel's arithmetic with the fp64 divisions replaced by products with 1/n)
+    const double m1 = stats[c] * inv_n;
+    const float mean = (float)m1;
+    float var = (float)(stats[C + c] * inv_n - m1 * m1);
+    var = fmaxf(var, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float scv = rstd * gamma[c];
+    s_scsh[c] = scv;
+    s_scsh[C + c] = beta[c] - mean * scv;
+    if (blockIdx.x == 0) {  // one block records mean / rstd for the backward pass and updates the running statistics
+      mean_rstd[c] = mean;
+      mean_rstd[C + c] = rstd;
+      if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        const float unb = n > 1.f ? var * n / (n - 1.f) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int ch = (int)(gtid % nch);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = s_scsh[ch * 8 + e];
+    sh[e] = s_scsh[C + ch * 8 + e];
+  }
+  for (long i = gtid; i < total; i += stride) {
+    const long m = i / nch;
+    const uint4 u = *reinterpret_cast<const uint4*>(Z + m * C + ch * 8);
+    const uint32_t wv[4] = {u.x, u.y, u.z, u.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float z = (e & 1) ? __uint_as_float(wv[e >> 1] & 0xffff0000u) : __uint_as_float(wv[e >> 1] << 16);
+      const float y = z * sc[e] + sh[e];
+      o[e] = act == 2 ? silu_f(y) : (act == 1 ? fmaxf(y, 0.f) : y);
+    }
+    uint4 r;
+    r.x = pack_bf2(o[0], o[1]); r.y = pack_bf2(o[2], o[3]); r.z = pack_bf2(o[4], o[5]); r.w = pack_bf2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(Hout + m * C + ch * 8) = r;
+  }
+  if (zero_next)  // (the whole buffer, not 2*C entries: the next user may have more channels than this call)
+    for (long i = gtid; i < zero_n; i += stride) zero_next[i] = 0.0;
+}
+
 // BN backward pass 1: red[0][c] += sum dy, red[1][c] += sum dy*xhat, dy = dH * act'(y)
 // A thread owns one 8-channel chunk (16-byte loads of Z and dH, per-channel constants hoisted) and walks rows in steps of the
 // block's row lanes; per-block partial sums meet in LDS and cost 2*C atomics per block, so blocks take >= 32 rows per lane
@@ -235,12 +298,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16_t* __r
                                                                const float* __restrict__ mean_rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ red, bf16_t* __restrict__ dZ,
-                                                               long M, int C, int act, float n) {
+                                                               long M, int C, int act, float n,
+                                                               float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr,
+                                                               float* __restrict__ zero_next = nullptr, int zero_n = 0) {
   const int nch = C >> 3;
   const long total = M * nch;
   const float invn = n > 0.f ? 1.f / n : 0.f;
   const long stride = (long)gridDim.x * blockDim.x;
-  const int ch = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % nch);  // constant per thread (stride % nch == 0)
+  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ch = (int)(gtid % nch);  // constant per thread (stride % nch == 0)
   float mu[8], rs[8], ga[8], be[8], r0[8], r1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -248,6 +314,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16_t* __r
     mu[e] = mean_rstd[c]; rs[e] = mean_rstd[C + c]; ga[e] = gamma[c]; be[e] = beta[c];
     r0[e] = red[c] * invn; r1[e] = red[C + c] * invn;
   }
+  if (blockIdx.x == 0 && (dgamma || dbeta)) {  // fused bn_param_grad_kernel (one block; a workgroup-uniform branch off the main path)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (dbeta) dbeta[c] += red[c];
+      if (dgamma) dgamma[c] += red[C + c];
+    }
+  }
+  if (zero_next && blockIdx.x == gridDim.x - 1)  // the whole sum buffer of the NEXT BatchNorm backward (two buffers take turns)
+    for (int i = threadIdx.x; i < zero_n; i += 256) zero_next[i] = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const long m = i / nch;
     const uint4 uz = *reinterpret_cast<const uint4*>(Z + m * C + ch * 8);
@@ -512,6 +586,15 @@ extern "C" int ea_bn_act_fwd(const void* Z, const float* mean_rstd, const float*
 extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rstd, const float* gamma,
                              const float* beta, float* red /*[2][C] zeroed*/, void* dZ, float* dgamma, float* dbeta,
                              long M, int C, int act, int training, hipStream_t stream);
+extern "C" int ea_bn_act_fwd_train(const void* Z, const double* stats, float* mean_rstd, float* running_mean, float* running_var,
+                                   const float* gamma, const float* beta, void* H, long M, int C, int act, float n, float eps,
+                                   float momentum, double* zero_next, int zero_n, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 8) return -2;
+  hipLaunchKernelGGL(bn_act_fwd_stats_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), (size_t)2 * C * sizeof(float), stream, (const bf16_t*)Z, stats,
+                     mean_rstd, running_mean, running_var, gamma, beta, (bf16_t*)H, M, C, act, n, eps, momentum, zero_next, zero_n);
+  return EA_CHECK_LAUNCH();
+}
 
 namespace {
 // BatchNorm (+ activation) backward of the FIRST sub-sampler layer fused with that convolution's weight gradient
@@ -680,6 +763,20 @@ extern "C" int ea_bn_act_bwd(const void* Z, const void* dH, const float* mean_rs
 
 // First sub-sampler layer: BatchNorm (+ activation) backward and the 3x3 / 1-channel convolution's weight (and bias) gradient in
 // one pass over Z and dH (conv1_bn_bwd_wgrad_kernel); `red` (fp32 [2 C], zeroed by the caller) receives BatchNorm's two sums.
+// ea_bn_act_bwd in two launches instead of three or four: the parameter gradients are added by the apply kernel's first
+// threads, which also clear `zero_next` (fp32 [2 C] or NULL) for the next call
+extern "C" int ea_bn_act_bwd_fused(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
+                                   float* red, void* dZ, float* dgamma, float* dbeta, long M, int C, int act, int training,
+                                   float* zero_next, int zero_n, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 8) return -2;
+  launch_bn_bwd_reduce(Z, dH, mean_rstd, gamma, beta, red, M, C, act, stream);
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(egrid_ch(M * (C / 8), C / 8)), dim3(256), 0, stream, (const bf16_t*)Z,
+                     (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, M, C, act, training ? (float)M : 0.f, dgamma, dbeta,
+                     zero_next, zero_n);
+  return EA_CHECK_LAUNCH();
+}
+
 extern "C" int ea_conv1_bn_bwd(const float* X, const void* Z, const void* dH, const float* mean_rstd, const float* gamma,
                                const float* beta, float* red, float* dgamma, float* dbeta, float* dW, float* dbias, int B, int T,
                                int F, int CO, int sy, int sx, int act, int training, hipStream_t stream) {

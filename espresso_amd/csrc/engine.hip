@@ -654,6 +654,43 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   release(c, mark);
 }
 
+// BatchNorm accumulators of the convolution module without fill launches: two fp64 statistics buffers (forward) and two fp32
+// sum buffers (backward) take turns; the kernel that CONSUMES one buffer clears the other for the next call (ea_bn_act_fwd_train
+// / ea_bn_act_bwd_fused), so the kernel that accumulates always finds zeros.  Process-wide like the side stream; cleared once at
+// creation on the caller's stream.  Channel counts above the capacity fall back to a fill per call.
+struct BnRing {
+  double* st[2] = {nullptr, nullptr};
+  float* red[2] = {nullptr, nullptr};
+  int si = 0, ri = 0, cap = 0;
+  bool ok = false, failed = false;
+};
+static BnRing g_bn;
+static bool bn_ring(hipStream_t owner, int C) {
+  if (g_bn.ok) return C <= g_bn.cap;
+  if (g_bn.failed) return false;
+  const int cap = C > 2048 ? C : 2048;
+  int cur = 0, dev = 0;
+  if (hipGetDevice(&cur) != hipSuccess) { g_bn.failed = true; return false; }
+  dev = cur;
+  if (owner != nullptr) {
+    hipDevice_t d;
+    if (hipStreamGetDevice(owner, &d) == hipSuccess) dev = (int)d;
+  }
+  if (dev != cur && hipSetDevice(dev) != hipSuccess) { g_bn.failed = true; return false; }
+  const size_t bytes = 2 * (size_t)(2 * cap) * (sizeof(double) + sizeof(float));
+  char* base = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&base), bytes) == hipSuccess && hipMemsetAsync(base, 0, bytes, owner) == hipSuccess;
+  if (dev != cur) (void)hipSetDevice(cur);
+  if (!ok) { g_bn.failed = true; return false; }
+  g_bn.st[0] = reinterpret_cast<double*>(base);
+  g_bn.st[1] = g_bn.st[0] + 2 * cap;
+  g_bn.red[0] = reinterpret_cast<float*>(g_bn.st[1] + 2 * cap);
+  g_bn.red[1] = g_bn.red[0] + 2 * cap;
+  g_bn.cap = cap;
+  g_bn.ok = true;
+  return true;
+}
+
 struct ConvSaved {
   float *mean, *rstd, *mr;
   uint16_t *xn, *Y, *U, *Z, *Hh;
@@ -679,15 +716,29 @@ static void conv_fwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, s.xn, s.mean, s.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   G g1(s.xn, w.pw1, s.Y, M, 2 * C, C, C, C, 2 * C);
   gemm(c, g1);
-  double* stats = nullptr;  // BatchNorm batch statistics: fp64 (sum, sum of squares) accumulators
-  if (sh.training) {
+  // BatchNorm batch statistics: fp64 (sum, sum of squares) accumulators; mean / rstd, the running statistics and the normalised
+  // activation come out of ONE launch behind the depthwise kernel (no fill, no finalize launch)
+  static const bool bn_fused = getenv("EA_BN_UNFUSED") == nullptr;  // (diagnostic A/B switch)
+  const bool ring = sh.training && bn_fused && C <= 2048;  // (same decision in the sizing pass: the arena walk must not differ)
+  if (ring && !c.dry && c.rc == 0 && !bn_ring(c.s, C)) c.rc = -1;
+  double* stats = nullptr;
+  if (sh.training && !ring) {
     stats = sc.get<double>(2 * C);
     if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(stats, 0, 2 * C * sizeof(double), c.s) == hipSuccess ? 0 : -1;
   }
+  if (ring && !c.dry && c.rc == 0) stats = g_bn.st[g_bn.si];
   RUN(ea_glu_dwconv_fwd(s.Y, w.dw, s.U, s.Z, stats, B, T, C, sh.KW, c.s));
-  if (sh.training) RUN(ea_bn_finalize(stats, s.mr, w.bn_rm, w.bn_rv, C, (float)M, 1e-5f, 0.1f, c.s));
-  else RUN(ea_bn_from_running(w.bn_rm, w.bn_rv, s.mr, C, 1e-5f, c.s));
-  RUN(ea_bn_act_fwd(s.Z, s.mr, w.bn_g, w.bn_b, s.Hh, M, C, EA_ACT_SILU, c.s));
+  if (ring) {
+    if (!c.dry && c.rc == 0) {
+      RUN(ea_bn_act_fwd_train(s.Z, stats, s.mr, w.bn_rm, w.bn_rv, w.bn_g, w.bn_b, s.Hh, M, C, EA_ACT_SILU, (float)M, 1e-5f, 0.1f,
+                              g_bn.st[g_bn.si ^ 1], 2 * g_bn.cap, c.s));
+      g_bn.si ^= 1;
+    }
+  } else {
+    if (sh.training) RUN(ea_bn_finalize(stats, s.mr, w.bn_rm, w.bn_rv, C, (float)M, 1e-5f, 0.1f, c.s));
+    else RUN(ea_bn_from_running(w.bn_rm, w.bn_rv, s.mr, C, 1e-5f, c.s));
+    RUN(ea_bn_act_fwd(s.Z, s.mr, w.bn_g, w.bn_b, s.Hh, M, C, EA_ACT_SILU, c.s));
+  }
   G g2(s.Hh, w.pw2, y, M, C, C, C, C, C);
   g2.drop(sh.p_drop, seed + kConvOut).resid(x, C);
   gemm(c, g2);
@@ -712,10 +763,27 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   wgrad(c, g, C, s.Hh, C, gw.pw2, M, C, C);
   uint16_t* dH = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, g, w.pw2, pw2t, dH, M, C, C);
-  float* red = sc.get<float>(2 * C);
-  if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(red, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
+  // BatchNorm backward: the two per-channel sums go to a buffer the previous call's apply kernel cleared; the apply kernel adds
+  // the BatchNorm parameter gradients itself (no fill launch, no bn_param_grad launch)
+  static const bool bn_fused = getenv("EA_BN_UNFUSED") == nullptr;  // (diagnostic A/B switch)
+  const bool ring = bn_fused && C <= 2048;
+  if (ring && !c.dry && c.rc == 0 && !bn_ring(c.s, C)) c.rc = -1;
+  float* red = nullptr;
+  if (!ring) {
+    red = sc.get<float>(2 * C);
+    if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(red, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
+  }
   uint16_t* dZ = sc.get<uint16_t>((size_t)M * C);
-  RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, nullptr, nullptr, M, C, EA_ACT_SILU, sh.training, c.s));
+  if (ring) {
+    if (!c.dry && c.rc == 0) {
+      red = g_bn.red[g_bn.ri];
+      RUN(ea_bn_act_bwd_fused(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, gw.bn_g, gw.bn_b, M, C, EA_ACT_SILU, sh.training,
+                              g_bn.red[g_bn.ri ^ 1], 2 * g_bn.cap, c.s));
+      g_bn.ri ^= 1;
+    }
+  } else {
+    RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, nullptr, nullptr, M, C, EA_ACT_SILU, sh.training, c.s));
+  }
   uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
   char* wws = sc.get<char>((size_t)ea_dwconv_wgrad_workspace_bytes(B, T, C, sh.KW));
   RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, nullptr, wws, B, T, C, sh.KW, c.s));
@@ -725,14 +793,14 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
       const uint16_t* U = s.U;
       const int KW = sh.KW;
       c.df->ops.push_back([=](hipStream_t st) {
-        int rc = ea_bn_param_grad(red, gwv.bn_g, gwv.bn_b, C, st);
+        int rc = ring ? 0 : ea_bn_param_grad(red, gwv.bn_g, gwv.bn_b, C, st);
         if (rc == 0) rc = ea_dwconv_bwd_weight(dZ, U, gwv.dw, wws, B, T, C, KW, st);
         return rc;
       });
     }
   } else {
     fork(c);  // BatchNorm / depthwise-filter / pointwise-1 parameter gradients: optimizer-only
-    RUN(ea_bn_param_grad(red, gw.bn_g, gw.bn_b, C, wstream(c)));
+    if (!ring) RUN(ea_bn_param_grad(red, gw.bn_g, gw.bn_b, C, wstream(c)));
     RUN(ea_dwconv_bwd_weight(dZ, s.U, gw.dw, wws, B, T, C, sh.KW, wstream(c)));
   }
   wgrad(c, dY, 2 * C, s.xn, C, gw.pw1, M, 2 * C, C);

@@ -271,6 +271,18 @@ int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, const float*
                       void* wgrad_ws, int B, int T, int C, int KW, ea_stream_t stream);
 /* ea_glu_dwconv_bwd with dw == NULL computes dY only; the depthwise weight gradient (optimizer-only) on its own: */
 int ea_dwconv_bwd_weight(const void* dZ, const void* U, float* dw, void* wgrad_ws, int B, int T, int C, int KW, ea_stream_t stream);
+/* Training-mode BatchNorm + activation forward in one launch (ea_bn_finalize + ea_bn_act_fwd): mean / rstd come straight from
+ * the fp64 batch sums `stats` ([2][C]: sum, sum of squares over n rows), are recorded in mean_rstd for the backward pass, the
+ * running statistics are updated (torch.nn.BatchNorm1d: momentum, unbiased variance), and zero_next (fp64 [zero_n] or NULL) is
+ * cleared — the statistics buffer of the next call, so that no fill launch precedes the kernel that accumulates into it. */
+int ea_bn_act_fwd_train(const void* Z, const double* stats, float* mean_rstd, float* running_mean, float* running_var,
+                        const float* gamma, const float* beta, void* H, long M, int C, int act, float n, float eps,
+                        float momentum, double* zero_next, int zero_n, ea_stream_t stream);
+/* ea_bn_act_bwd with the parameter gradients added by the apply kernel itself (no third launch) and zero_next (fp32 [zero_n]
+ * or NULL) cleared for the next call's `red`. */
+int ea_bn_act_bwd_fused(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
+                        float* red, void* dZ, float* dgamma, float* dbeta, long M, int C, int act, int training,
+                        float* zero_next, int zero_n, ea_stream_t stream);
 /* ea_bn_act_bwd with dgamma == dbeta == NULL skips the parameter gradients; they are then taken from `red` by: */
 int ea_bn_param_grad(const float* red, float* dgamma, float* dbeta, int C, ea_stream_t stream);
 /* First sub-sampler layer (espresso/modules/speech_convolutions.py:78-102, layer 0): BatchNorm (+ activation) backward and the

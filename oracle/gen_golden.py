@@ -303,6 +303,10 @@ class _FeedDropout:
                 return x
             site, layout, kw = feeder.sites[feeder.k]
             feeder.k += 1
+            if callable(layout):  # a mask the caller cut out of a larger stream (per-step calls of the LSTM decoder)
+                m = layout(x)
+                assert tuple(m.shape) == tuple(x.shape), (site, m.shape, x.shape)
+                return x * m
             with torch_ref.dropout_masks(feeder.plan):
                 y = torch_ref._drop(x, site, layout, **kw)
             assert y is not x, (site, "the plan had no mask for this call")
@@ -414,19 +418,50 @@ def dropout_fixtures(p=0.1):
                         **{"out::train_logits": lo.detach().numpy(), "out::loss": np.array(loss.item()), "out::nll": np.array(nll.item())},
                         **{"grad::" + n: q.grad.numpy() for n, q in model.named_parameters() if q.grad is not None})
     print("ref_dropout_transformer_encdec_tiny loss", loss.item(), "dropout-off", float(g["out::loss"]))
+    # transducer (Conformer encoder + LSTM predictor): predictor dropout_in on the embeddings, dropout_out after every layer at
+    # every step (espresso/models/speech_lstm.py:811,866) — the reference calls it per (step, layer) on (B, H); the mask stream
+    # is one [U*B][H] tensor per layer (time-major), cut into its step rows here
+    src = "ref_conformer_transducer_tiny"
+    g = np.load(os.path.join(OUT, src + ".npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    torch.manual_seed(2468)
+    model, dic = _ref_transducer_model(40)
+    torch.nn.Module.load_state_dict(model, sd)  # (fairseq's override walks upgrade_state_dict_named, which the Conformer layer lacks)
+    for m in model.modules():
+        if m.__class__.__name__ in ("FairseqDropout", "Dropout"):
+            m.p = p
+    feats, lengths, prev = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"])
+    B, U1 = prev.shape
+    E, Hd, nl = 48, 64, 2
+    trace = _synthetic_trace(["subsample.out", "ln.out"] + ["layer:conformer"] * 2 + ["dropout"] * (1 + nl), p)
+    plan = D.MaskPlan(trace, seed_fn)
+    enc_sites = [("subsample.out", "SUB", dict(C=16)), ("ln.out", "BTC", {})] + _layer_site_list("conformer", 4, B) * 2
+    pred_q = plan.queue[len(enc_sites):]
+    m_in = D.scale_mask(pred_q[0][1], (U1, B, E), p)
+    m_out = [D.scale_mask(pred_q[1 + i][1], (U1, B, Hd), p) for i in range(nl)]
+    sites = list(enc_sites) + [("dropout", (lambda x: m_in.transpose(0, 1)), {})]
+    for j in range(U1):
+        for i in range(nl):
+            sites.append(("dropout", (lambda x, i=i, j=j: m_out[i][j]), {}))
+    model.train()
+    with _FeedDropout(plan, sites) as fd:
+        lo, olen = model(feats, lengths, prev)
+        plan.pos = len(plan.queue)  # (the predictor's masks were taken from the queue by hand above)
+    R = torch.from_numpy(g["R"])
+    (lo * R).sum().backward()
+    np.savez_compressed(os.path.join(OUT, "ref_dropout_conformer_transducer_tiny.npz"), source=np.array(src),
+                        trace=np.array(json.dumps(trace)), **{"out::train_logits": lo.detach().numpy()},
+                        **{"grad::" + n: q.grad.numpy() for n, q in model.named_parameters() if q.grad is not None})
+    print("ref_dropout_conformer_transducer_tiny logits", float(lo.abs().max()), "vs dropout-off diff",
+          float((lo.detach() - torch.from_numpy(g["out::train_logits"])).abs().max()))
 
 
-def transducer_fixture(name="ref_conformer_transducer_tiny"):
-    """speech_transformer_transducer_base (conv front-end + rel-pos Conformer encoder + 2-layer LSTM predictor + joint with a
-    weight-normed fc_out): logits (B, T', U+1, V) in eval and train mode and every parameter gradient of
-    sum(logits * R) for a fixed random R, all from the reference's own modules.  (torchaudio is not installable here, so the
-    RNN-T loss itself is pinned separately: oracle/rnnt_ref.py against brute-force alignment sums.)"""
+def _ref_transducer_model(V=40):
+    """The reference's speech_transformer_transducer_base at test size (the configuration of `transducer_fixture`); -> (model, dictionary)."""
     from espresso.data.asr_dictionary import AsrDictionary
     from espresso.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase
     from espresso.models.transformer.speech_transformer_transducer_config import SpeechTransformerTransducerConfig
 
-    torch.manual_seed(2468)
-    V = 40
     base = ref_config("conformer")
     cfg = SpeechTransformerTransducerConfig()
     cfg.encoder = base.encoder
@@ -460,6 +495,21 @@ def transducer_fixture(name="ref_conformer_transducer_tiny"):
     T.target_dictionary = dic
     assert len(dic) == V, len(dic)
     model = SpeechTransformerTransducerModelBase.build_model(cfg, T)
+    return model, dic
+
+
+def transducer_fixture(name="ref_conformer_transducer_tiny"):
+    """speech_transformer_transducer_base (conv front-end + rel-pos Conformer encoder + 2-layer LSTM predictor + joint with a
+    weight-normed fc_out): logits (B, T', U+1, V) in eval and train mode and every parameter gradient of
+    sum(logits * R) for a fixed random R, all from the reference's own modules.  (torchaudio is not installable here, so the
+    RNN-T loss itself is pinned separately: oracle/rnnt_ref.py against brute-force alignment sums.)"""
+    from espresso.data.asr_dictionary import AsrDictionary
+    from espresso.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase
+    from espresso.models.transformer.speech_transformer_transducer_config import SpeechTransformerTransducerConfig
+
+    torch.manual_seed(2468)
+    V = 40
+    model, dic = _ref_transducer_model(V)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if p.dim() == 1 and "weight_g" not in n:

@@ -72,3 +72,28 @@ def rnnt_loss_bruteforce(logits_tuv, target, blank=0):
         s += lp[T - 1, U, blank]
         total = np.logaddexp(total, s)
     return -total
+
+
+def rnnt_loss_torch(logits_tuv, target, blank=0):
+    """The same negative log-likelihood as `rnnt_loss_one` as a differentiable torch expression (float64 inside; autograd gives
+    d loss / d logits): alpha recursion over anti-diagonal-free (t, u) order — for the model-level gradient checks."""
+    import torch
+
+    lp = torch.log_softmax(logits_tuv.double(), -1)
+    T, U1, _ = lp.shape
+    tgt = torch.as_tensor(list(target), dtype=torch.long)
+    lb = lp[:, :, blank]                                   # (T, U+1): emit blank at (t, u)
+    ly = lp[:, : U1 - 1, :].gather(2, tgt.view(1, -1, 1).expand(T, -1, 1)).squeeze(2) if U1 > 1 else lp.new_zeros(T, 0)
+    alpha = [[None] * U1 for _ in range(T)]
+    alpha[0][0] = lp.new_zeros(())
+    for t in range(T):
+        for u in range(U1):
+            if t == 0 and u == 0:
+                continue
+            terms = []
+            if t > 0:
+                terms.append(alpha[t - 1][u] + lb[t - 1, u])
+            if u > 0:
+                terms.append(alpha[t][u - 1] + ly[t, u - 1])
+            alpha[t][u] = terms[0] if len(terms) == 1 else torch.logaddexp(terms[0], terms[1])
+    return -(alpha[T - 1][U1 - 1] + lb[T - 1, U1 - 1])

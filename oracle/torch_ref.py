@@ -98,6 +98,17 @@ def _drop(x, site, layout, **kw):
     return x * m
 
 
+def _drop_mask(site, shape):
+    """The multiplier (0 or 1/(1-p)) of one dropout call over a dense row-major tensor of `shape`, or None (no plan / p = 0 there)."""
+    plan = _DROP["plan"]
+    if plan is None:
+        return None
+    from . import dropout_ref as D
+
+    sp = plan.seed_for(site)
+    return None if sp is None else D.scale_mask(sp[0], tuple(shape), sp[1])
+
+
 def _lin(x, w, b=None):
     """Linear on the (bf16 shadow of the) weight, fp32 accumulation; the caller rounds where the result is stored."""
     return F.linear(x, _r(w), b)
@@ -515,24 +526,32 @@ def lstm_cell(x, h, c, sd, p):
 
 
 def lstm_predictor(prev_tokens, sd, p="decoder.", residual=False, pad_idx=1, state=None):
-    """espresso/models/speech_lstm.py:766-919 with encoder_out None (no attention, no input feeding), dropout 0:
-    the per-step loop over the LSTMCell stack.  Returns (features (B,U,H), final state [(h, c)] per layer)."""
+    """espresso/models/speech_lstm.py:766-919 with encoder_out None (no attention, no input feeding): the per-step loop over the
+    LSTMCell stack.  Returns (features (B,U,H), final state [(h, c)] per layer).  Dropout (only under `dropout_masks`): on the
+    embeddings (:811 dropout_in), on every layer's output at every step (:866 dropout_out; the recurrent state stays un-dropped)
+    and after additional_fc (:909) — the HIP path draws one mask per layer over the time-major [U*B][H] sequence, so step j of
+    layer i uses rows j*B .. (j+1)*B of that layer's mask."""
     emb = sd[p + "embed_tokens.weight"]
     x = _r(F.embedding(prev_tokens, emb, padding_idx=pad_idx)).transpose(0, 1)  # U x B x E
     nl = 0
     while (p + f"layers.{nl}.weight_ih") in sd:
         nl += 1
     B = prev_tokens.shape[0]
+    U = x.shape[0]
     Hd = sd[p + "layers.0.weight_hh"].shape[1]
+    m_in = _drop_mask("dropout", (U, B, x.shape[2]))
+    if m_in is not None:
+        x = _r(x * m_in)
+    m_out = [_drop_mask("dropout", (U, B, Hd)) for _ in range(nl)]
     if state is None:
         state = [(x.new_zeros(B, Hd), x.new_zeros(B, Hd)) for _ in range(nl)]
     outs = []
-    for j in range(x.shape[0]):
+    for j in range(U):
         inp = x[j]
         for i in range(nl):
             h, c = lstm_cell(inp, state[i][0], state[i][1], sd, p + f"layers.{i}.")
             prev_in = inp
-            inp = h
+            inp = h if m_out[i] is None else _r(h * m_out[i][j])
             if residual and i > 0:
                 inp = _r(inp + prev_in)
             state[i] = (h, c)
@@ -540,6 +559,9 @@ def lstm_predictor(prev_tokens, sd, p="decoder.", residual=False, pad_idx=1, sta
     y = torch.stack(outs, 0).transpose(0, 1)
     if (p + "additional_fc.weight") in sd:
         y = _r(_lin(y, sd[p + "additional_fc.weight"], sd[p + "additional_fc.bias"]))
+        m_fc = _drop_mask("dropout", tuple(y.shape))
+        if m_fc is not None:
+            y = _r(y * m_fc)
     return y, state
 
 

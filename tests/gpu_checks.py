@@ -1595,7 +1595,7 @@ def check_conv1_fused_backward(B=3, T=53, Fd=80, seed=0):
     return res
 
 
-def build_tiny_transducer(V=40, embed_dim=64, heads=4):
+def build_tiny_transducer(V=40, embed_dim=64, heads=4, dropout=0.0):
     from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerTransducerConfig
     from espresso_amd.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase
 
@@ -1604,9 +1604,9 @@ def build_tiny_transducer(V=40, embed_dim=64, heads=4):
     e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = embed_dim, 128, 2, heads
     e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "conformer"
     e.conv_channels = "[64, 64, 16, 16]"
-    d.embed_dim, d.hidden_size, d.layers, d.residual, d.dropout_in, d.dropout_out = 48, 64, 2, True, 0.0, 0.0
+    d.embed_dim, d.hidden_size, d.layers, d.residual, d.dropout_in, d.dropout_out = 48, 64, 2, True, dropout, dropout
     cfg.joint_dim = 64
-    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = 0.0
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = dropout
     cfg.max_source_positions, cfg.max_target_positions = 3600, 200
     return SpeechTransformerTransducerModelBase.build_model(cfg, _Task(V))
 
@@ -1722,6 +1722,246 @@ def check_transducer_loss_step():
                                        blank=crit.blank_idx)
     finite = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
     return {"loss": float(loss), "oracle_loss": float(want), "finite": finite, "sample_size": sample_size}
+
+
+def _oracle_sd(model, prefix=""):
+    """The HIP model's parameters / buffers under the reference's names as an oracle state dict with gradients enabled."""
+    sd = {}
+    for k, v in model.state_dict().items():
+        if not k.startswith(prefix):
+            continue
+        v = v.detach().float().cpu().clone() if v.is_floating_point() else v.detach().cpu().clone()
+        if v.is_floating_point() and "running" not in k and not k.endswith("version") and not k.endswith("_float_tensor"):
+            v.requires_grad_(True)
+        sd[k[len(prefix):]] = v
+    return sd
+
+
+def _grad_report(named_params, sde, sdf, skip):
+    errs = _grad_errors(named_params, sde, skip)
+    gap = {n: float((sde[n].grad - sdf[n].grad).abs().max() / (float(sdf[n].grad.abs().max()) + 1e-12)) for _, n in errs}
+    gaps = sorted(gap.values())
+    return {"worst_grad_vs_emulation": (errs[0][1], errs[0][0]), "median_grad_vs_emulation": errs[len(errs) // 2][0],
+            "worst_excess_over_bound": max(e / max(0.08, gap[n]) for e, n in errs), "oracle_gap_of_worst": gap[errs[0][1]],
+            "median_oracle_gap": gaps[len(gaps) // 2], "n_grads": len(errs)}
+
+
+def check_transducer_dropout_vs_oracle(p=0.1, seed=77):
+    """speech_transformer_transducer_base (tiny fixture) in TRAINING mode with dropout everywhere (encoder sites, predictor
+    dropout_in / dropout_out): logits and the gradients of sum(logits * R) vs the oracle with the HIP path's keep decisions."""
+    from espresso_amd import _lib
+    from espresso_amd import functional as F
+    from oracle import dropout_ref as D
+    from oracle import torch_ref
+
+    g = np.load(os.path.join(GOLD, "ref_conformer_transducer_tiny.npz"))
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = build_tiny_transducer(dropout=p).to(DEV)
+    missing, unexpected = model.load_state_dict(model.upgrade_state_dict_named(dict(sd0), ""), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    feats, lengths, prev = (torch.from_numpy(g[k]) for k in ("feats", "lengths", "prev"))
+    R = torch.from_numpy(g["R"])
+    model.train()
+    F.set_dropout_seed(seed)
+    with F.trace_dropout_seeds() as tr:
+        lo, olen = model(feats.to(DEV), lengths.to(DEV), prev.to(DEV))
+    (lo.float() * R.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    lo = lo.detach().float().cpu()
+    res = {"sites": [e[0] for e in tr.entries]}
+    lib = _lib.lib()
+    skip = lambda n: (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias")) or n.endswith("attn.k_proj.bias")
+
+    def oracle(trace, emulate):
+        sde = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "version" else v.clone())
+               for k, v in sd0.items()}
+        plan = D.MaskPlan(trace, lib.ea_layer_dropout_seed)
+        with torch_ref.bf16_emulation(emulate, flash=False), torch_ref.dropout_masks(plan):
+            el, ol = torch_ref.transducer(feats, lengths, prev, sde, H=4, residual=True, training=True)
+            (el * R).sum().backward()
+        plan.done()
+        return el.detach(), ol, sde, plan
+
+    el, ol, sde, plan = oracle(tr.entries, True)
+    res["n_site_masks"] = len(plan.queue)
+    valid = torch.zeros(el.shape[:3], dtype=torch.bool)
+    for b in range(el.shape[0]):
+        valid[b, : int(ol[b])] = True
+    res["train_logits_vs_emulation"] = float((lo - el)[valid].abs().max())
+    l2 = sorted(((float((p_.grad.float().cpu() - sde[n].grad).norm() / (float(sde[n].grad.norm()) + 1e-12)), n)
+                 for n, p_ in model.named_parameters() if not skip(n) and sde[n].grad is not None), reverse=True)
+    res["worst_l2_vs_emulation"] = (l2[0][1], l2[0][0])
+    res["median_l2_vs_emulation"] = l2[len(l2) // 2][0]
+    wl, _, sdw, _ = oracle([[s_, sd_ + 977 * 64, pp] for s_, sd_, pp in tr.entries], True)
+    l2w = sorted(float((p_.grad.float().cpu() - sdw[n].grad).norm() / (float(sdw[n].grad.norm()) + 1e-12))
+                 for n, p_ in model.named_parameters() if not skip(n) and sdw[n].grad is not None)
+    res["wrong_mask_median_l2"] = l2w[len(l2w) // 2]
+    res["wrong_mask_logits"] = float((lo - wl)[valid].abs().max())
+    return res
+
+
+def check_fullsize_encdec_vs_oracle(dropout=0.0, seed=0, lens=(330, 211), tl=(8, 5), V=5003):
+    """BASELINE config 2 at the recipe's size (examples/asr_librispeech/config/transformer_librispeech.yaml: 12 Transformer
+    encoder layers with LEARNED relative-position tables, 6 decoder layers, 512 / 8 / 2048, V = 5003 sentence pieces + specials)
+    with random weights on two utterances: eval logits, label-smoothed CE and every gradient vs the pinned oracle (fp32 and
+    bf16-emulating); `dropout` > 0: the recipe's training mode with the HIP path's keep decisions fed to the oracle."""
+    from espresso_amd import _lib
+    from espresso_amd import functional as F
+    from espresso_amd.models.transformer.speech_transformer_base import SpeechTransformerModelBase
+    from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerConfig
+    from oracle import dropout_ref as D
+    from oracle import torch_ref
+
+    torch.manual_seed(seed)
+    H = 8
+    cfg = SpeechTransformerConfig()
+    e, dc = cfg.encoder, cfg.decoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, 12, H
+    e.normalize_before, e.relative_positional_embeddings, e.layer_type, e.learned_pos = True, True, "transformer", True
+    e.conv_channels = "[64, 64, 128, 128]"
+    dc.embed_dim, dc.ffn_embed_dim, dc.layers, dc.attention_heads, dc.normalize_before = 512, 2048, 6, H, True
+    dc.input_dim = dc.output_dim = 512
+    cfg.layernorm_embedding = True
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = dropout
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 1024
+    model = SpeechTransformerModelBase.build_model(cfg, _TaskAR(V))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g = torch.Generator().manual_seed(seed + 1)
+    feats = torch.zeros(len(lens), max(lens), 80)
+    for b, n in enumerate(lens):
+        feats[b, :n] = torch.randn(n, 80, generator=g)
+    lengths = torch.tensor(lens)
+    U = max(tl) + 1
+    target = torch.zeros(len(lens), U, dtype=torch.long)  # pad = 0, eos = 1 (dictionary without <s>)
+    prev = torch.zeros(len(lens), U, dtype=torch.long)
+    for b, n in enumerate(tl):
+        toks = torch.randint(3, V, (n,), generator=g)
+        target[b, :n], target[b, n] = toks, 1
+        prev[b, 0], prev[b, 1:n + 1] = 1, toks
+    valid = target.ne(0)
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        lo, _ = model(feats.to(DEV), lengths.to(DEV), prev.to(DEV))
+    hip_eval = lo.float().cpu()
+    model.train()
+    F.set_dropout_seed(seed + 17)
+    with F.trace_dropout_seeds() as tr:
+        lo, extra = model(feats.to(DEV), lengths.to(DEV), prev.to(DEV))
+    loss, nll = F.label_smoothed_ce(extra["_logits_bu"], target.reshape(-1).to(DEV).to(torch.int32).contiguous(), 0, 0.1)
+    loss.backward()
+    torch.cuda.synchronize()
+    res["hip_loss"] = float(loss.detach())
+    skip = lambda n: (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias")) or n.endswith("attn.k_proj.bias")
+    out = {}
+    for tag, emu in (("fp32", False), ("emu", True)):
+        sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("version")
+                   and not k.endswith("_float_tensor") else v.clone()) for k, v in sd0.items()}
+        with torch_ref.bf16_emulation(emu, flash=True):
+            with torch.no_grad():
+                le = torch_ref.encdec(feats, lengths, prev, sdo, H, 0, training=False)
+            plan = D.MaskPlan(tr.entries, _lib.lib().ea_layer_dropout_seed)
+            with torch_ref.dropout_masks(plan if dropout > 0 else None):
+                lt = torch_ref.encdec(feats, lengths, prev, sdo, H, 0, training=True)
+            plan.done()
+            oloss, _ = torch_ref.label_smoothed_nll(lt.reshape(-1, lt.shape[-1]), target.reshape(-1), 0.1, 0)
+            oloss.backward()
+        res[f"{tag}_loss"] = float(oloss.detach())
+        res[f"eval_logits_vs_{tag}"] = float((hip_eval - le)[valid].abs().max())
+        res["logit_scale"] = float(le[valid].abs().max())
+        res["n_site_masks"] = len(plan.queue)
+        out[tag] = sdo
+    res.update(_grad_report(model.named_parameters(), out["emu"], out["fp32"], skip))
+    return res
+
+
+def check_fullsize_transducer_vs_oracle(dropout=0.0, seed=0, lens=(200, 140), tl=(6, 4), V=5004, layers=16):
+    """BASELINE config 4 at the recipe's size (conformer_transducer_librispeech.yaml:66-88: Conformer-16 512 / 8 / 2048, LSTM
+    predictor 2 x 512, joint 512, V = 5004 -> the 5056-column logit pitch) with random weights on one short utterance pair: the
+    `transducer_loss` criterion's value and every gradient vs the pinned oracle (encoder + predictor + joint restatement, RNN-T
+    loss restatement oracle/rnnt_ref.py), fp32 and bf16-emulating; `dropout` > 0: with the HIP path's keep decisions."""
+    from espresso_amd import _lib
+    from espresso_amd import functional as F
+    from espresso_amd.criterions.transducer_loss import TransducerLossCriterion
+    from espresso_amd.models.transformer.speech_transformer_config import SpeechTransformerTransducerConfig
+    from espresso_amd.models.transformer.speech_transformer_transducer_base import SpeechTransformerTransducerModelBase
+    from oracle import dropout_ref as D
+    from oracle import rnnt_ref, torch_ref
+
+    torch.manual_seed(seed)
+    H = 8
+    cfg = SpeechTransformerTransducerConfig()
+    e, dc = cfg.encoder, cfg.decoder
+    e.embed_dim, e.ffn_embed_dim, e.layers, e.attention_heads = 512, 2048, layers, H
+    e.normalize_before, e.relative_positional_embeddings, e.layer_type = True, True, "conformer"
+    e.conv_channels = "[64, 64, 128, 128]"
+    dc.embed_dim, dc.hidden_size, dc.layers, dc.dropout_in, dc.dropout_out = 512, 512, 2, dropout, dropout
+    cfg.joint_dim = 512
+    cfg.dropout = cfg.attention_dropout = cfg.activation_dropout = dropout
+    cfg.max_source_positions, cfg.max_target_positions = 3600, 200
+    task = _Task(V)
+    model = SpeechTransformerTransducerModelBase.build_model(cfg, task)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "weight_g" not in n:
+                p.add_(0.1 * torch.randn_like(p))
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    crit = TransducerLossCriterion(task)
+    pad, eos = task.target_dictionary.pad(), task.target_dictionary.eos()
+    g = torch.Generator().manual_seed(seed + 1)
+    feats = torch.zeros(len(lens), max(lens), 80)
+    for b, n in enumerate(lens):
+        feats[b, :n] = torch.randn(n, 80, generator=g)
+    lengths = torch.tensor(lens)
+    U1 = max(tl) + 1
+    prev = torch.full((len(lens), U1), pad, dtype=torch.long)
+    target = torch.full((len(lens), U1), pad, dtype=torch.long)
+    for b, n in enumerate(tl):
+        toks = torch.randint(5, V, (n,), generator=g)
+        prev[b, 0], prev[b, 1:n + 1] = eos, toks
+        target[b, :n], target[b, n] = toks, eos
+    sample = {"net_input": {"src_tokens": feats.to(DEV), "src_lengths": lengths.to(DEV), "prev_output_tokens": prev.to(DEV)},
+              "target": target.to(DEV), "ntokens": int(sum(tl)) + len(tl)}
+    model.train()
+    F.set_dropout_seed(seed + 17)
+    with F.trace_dropout_seeds() as tr:
+        loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    res = {"hip_loss": float(loss.detach()), "n_seed_draws": len(tr.entries)}
+    skip = lambda n: (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias")) or n.endswith("attn.k_proj.bias")
+    out = {}
+    for tag, emu in (("fp32", False), ("emu", True)):
+        sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("version")
+                   else v.clone()) for k, v in sd0.items()}
+        plan = D.MaskPlan(tr.entries, _lib.lib().ea_layer_dropout_seed)
+        with torch_ref.bf16_emulation(emu, flash=True), torch_ref.dropout_masks(plan if dropout > 0 else None):
+            lt, ol = torch_ref.transducer(feats, lengths, prev, sdo, H=H, pad_idx=pad, residual=False, training=True, update={})
+        plan.done()
+        oloss = 0.0
+        for b in range(len(lens)):
+            oloss = oloss + rnnt_ref.rnnt_loss_torch(lt[b, : int(ol[b]), : tl[b] + 1], target[b, : tl[b]].tolist(), crit.blank_idx)
+        oloss.backward()
+        res[f"{tag}_loss"] = float(oloss.detach())
+        res["n_site_masks"] = len(plan.queue)
+        out[tag] = sdo
+    res.update(_grad_report(model.named_parameters(), out["emu"], out["fp32"], skip))
+    # relu(E + D) kinks make every upstream gradient noisy (measured on the tiny fixture): the L2 view as in check_transducer_vs_reference
+    l2 = sorted(((float((p_.grad.float().cpu() - out["emu"][n].grad).norm() / (float(out["emu"][n].grad.norm()) + 1e-12)), n)
+                 for n, p_ in model.named_parameters() if not skip(n) and p_.grad is not None and out["emu"][n].grad is not None), reverse=True)
+    res["worst_l2_vs_emulation"] = (l2[0][1], l2[0][0])
+    res["median_l2_vs_emulation"] = l2[len(l2) // 2][0]
+    l2g = sorted(float((out["emu"][n].grad - out["fp32"][n].grad).norm() / (float(out["fp32"][n].grad.norm()) + 1e-12))
+                 for _, n in l2)
+    res["median_l2_oracle_gap"] = l2g[len(l2g) // 2]
+    res["worst_l2_oracle_gap"] = l2g[-1]
+    return res
 
 
 def check_transducer_branch_overlap():

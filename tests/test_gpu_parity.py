@@ -220,6 +220,47 @@ def test_encdec_training_mode_dropout_vs_oracle(fixture):
     assert r["wrong_mask_median_grad"] > 5 * 1.5e-2, r
 
 
+def test_transducer_training_mode_dropout_vs_oracle():
+    """encoder dropout sites + the LSTM predictor's dropout_in / dropout_out (espresso/models/speech_lstm.py:811,866) at 0.1"""
+    r = G.check_transducer_dropout_vs_oracle()
+    print(r)
+    assert r["n_site_masks"] == 2 + 2 * 7 + 3, r
+    assert r["train_logits_vs_emulation"] < 5e-2, r
+    # relu(E + D) kink noise (measured dropout-off: 13 % worst / 9 % median L2 against the emulation); wrong masks: far outside
+    assert r["worst_l2_vs_emulation"][1] < 0.16 and r["median_l2_vs_emulation"] < 0.11, r
+    assert r["wrong_mask_median_l2"] > 4 * r["median_l2_vs_emulation"] and r["wrong_mask_logits"] > 0.3, r
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_fullsize_encdec_config2_vs_oracle(dropout):
+    """recipe-sized parity for BASELINE config 2 (12 + 6 layers, 512 / 8 / 2048, V = 5003)"""
+    r = G.check_fullsize_encdec_vs_oracle(dropout=dropout)
+    print(r)
+    assert r["n_grads"] > 300 and r["n_site_masks"] == (0 if dropout == 0 else 2 + 12 * 4 + 1 + 6 * 6), r
+    assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r        # north_star: 1e-2 (bf16) on losses
+    assert r["eval_logits_vs_fp32"] < 2e-2 * max(4.0, r["logit_scale"]), r
+    assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 3e-3, r
+    assert r["eval_logits_vs_emu"] < 1.5e-2 * max(4.0, r["logit_scale"]), r
+    # per tensor: 8 % of its scale, or the gap between the two ORACLE runs where that is larger (ReLU-kink tensors)
+    assert r["worst_excess_over_bound"] < 1.0 and r["worst_grad_vs_emulation"][1] < 0.35, r
+    assert r["median_grad_vs_emulation"] < max(1.5e-2, 0.8 * r["median_oracle_gap"]), r
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_fullsize_transducer_config4_vs_oracle(dropout):
+    """recipe-sized parity for BASELINE config 4 (Conformer-16 + predictor + joint, V = 5004 / pitch 5056,
+    RNN-T loss through the criterion)"""
+    r = G.check_fullsize_transducer_vs_oracle(dropout=dropout)
+    print(r)
+    assert r["n_grads"] > 500 and r["n_site_masks"] == (0 if dropout == 0 else 2 + 16 * 7 + 3), r
+    assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r        # north_star: 1e-2 (bf16) on losses
+    assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 3e-3, r
+    # gradients: relu(E + D) kink noise on every upstream tensor (the tiny fixture measures 13 % / 9 % L2 against the emulation,
+    # the two oracle runs differ by as much between themselves): L2 within 1.5 x the oracles' own gap, worst tensor 0.3
+    assert r["median_l2_vs_emulation"] < max(0.05, 1.5 * r["median_l2_oracle_gap"]), r
+    assert r["worst_l2_vs_emulation"][1] < max(0.3, 1.5 * r["worst_l2_oracle_gap"]), r
+
+
 def test_conv1_fused_batchnorm_backward_and_weight_gradient():
     """csrc/convmodule.hip conv1_bn_bwd_wgrad_kernel vs bn_act_bwd + conv1_wgrad (training and eval statistics): same bf16 dZ
     values -> gradients equal to fp32 atomics / summation order (1e-3 of each tensor's scale; the conv bias gradient is exactly

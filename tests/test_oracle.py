@@ -259,6 +259,58 @@ def test_decoder_restatement_with_dropout_matches_reference(golden_dir):
     assert worst < 5e-4, worst
 
 
+def test_transducer_restatement_with_dropout_matches_reference(golden_dir):
+    """speech_transformer_transducer_base in training mode with dropout 0.1: encoder sites + the LSTM predictor's dropout_in on
+    the embeddings and dropout_out after every layer at every step (espresso/models/speech_lstm.py:811,866), masks fed to the
+    reference's own modules (oracle/gen_golden.py dropout_fixtures) — logits and every gradient of sum(logits * R)."""
+    import json
+
+    from espresso_amd import _lib
+    from oracle import dropout_ref as D
+
+    gd = np.load(os.path.join(golden_dir, "ref_dropout_conformer_transducer_tiny.npz"))
+    g, sd = _load(golden_dir, str(gd["source"]))
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.endswith("version"):
+            v.requires_grad_(True)
+    feats, lengths, prev = (torch.from_numpy(g[k]) for k in ("feats", "lengths", "prev"))
+    plan = D.MaskPlan(json.loads(str(gd["trace"])), _lib.lib().ea_layer_dropout_seed)
+    with torch_ref.dropout_masks(plan):
+        lo, ol = torch_ref.transducer(feats, lengths, prev, sd, H=4, residual=True, training=True)
+    plan.done()
+    assert len(plan.queue) == 2 + 2 * 7 + 3 and not plan.skipped
+    valid = torch.zeros(lo.shape[:3], dtype=torch.bool)
+    for b in range(lo.shape[0]):
+        valid[b, : int(ol[b])] = True
+    ref = torch.from_numpy(gd["out::train_logits"])
+    assert float((lo.detach() - ref)[valid].abs().max()) < 5e-5
+    (lo * torch.from_numpy(g["R"])).sum().backward()
+    worst = 0.0
+    for k in gd.files:
+        # (conv biases in front of BatchNorm and the key bias have an exactly zero true gradient: both sides hold round-off)
+        if k.startswith("grad::") and sd[k[6:]].grad is not None and not (k.endswith("k_proj.bias") or (".convolutions." in k and k.endswith(".bias"))):
+            r = torch.from_numpy(gd[k])
+            worst = max(worst, float((sd[k[6:]].grad - r).abs().max() / (float(r.abs().max()) + 1e-9)))
+    assert worst < 1e-4, worst
+
+
+def test_rnnt_torch_loss_equals_the_numpy_restatement():
+    """oracle/rnnt_ref.py rnnt_loss_torch (differentiable, used by the model-level gradient checks) == rnnt_loss_one: value and
+    gradient w.r.t. the logits"""
+    from oracle import rnnt_ref
+
+    rng = np.random.default_rng(3)
+    for T, U, V in ((9, 4, 11), (5, 1, 7), (3, 0, 5)):
+        lg = rng.standard_normal((T, U + 1, V))
+        tgt = [int(t) for t in rng.integers(1, V, U)]
+        want, gw = rnnt_ref.rnnt_loss_one(lg, tgt, blank=0, want_grad=True)
+        x = torch.tensor(lg, requires_grad=True)
+        got = rnnt_ref.rnnt_loss_torch(x, tgt, 0)
+        got.backward()
+        assert float(got.detach()) == pytest.approx(want, rel=1e-12)
+        assert float(np.abs(gw - x.grad.numpy()).max()) < 1e-12
+
+
 def test_rnnt_restatement_vs_bruteforce_and_finite_differences():
     """Pins oracle/rnnt_ref.py: the alpha recursion equals an explicit sum over ALL alignments on tiny lattices, and the
     analytic gradient equals central finite differences."""
