@@ -423,7 +423,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
   }
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, long n, int nsplit) {
+// cin > 0: dW is in the parameter's own layout [Cout][Cin][3][3] (torch Conv2d) instead of the kernels' [Cout][3][3][Cin] —
+// the sums are scattered there, so that the gradient needs no permuting copy and no separate accumulate launch afterwards
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, long n, int nsplit,
+                                                                int cin = 0) {
   // grid (column blocks, slab groups): a workgroup adds up its group of slabs for 1024 outputs; groups meet in dW with fp32
   // atomics (a 64 x 64 x 9 gradient split 512 ways is 75 MB of slabs over 36 column blocks: one block per column chunk walked
   // all of them serially and took longer than the MFMA kernel itself)
@@ -435,6 +438,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   for (int z = z0 + 1; z < z1; ++z) {
     const float4 x = *reinterpret_cast<const float4*>(slab + (long)z * n + i);
     s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+  }
+  if (cin > 0) {  // i = (co*9 + tap)*cin + ci, 4 consecutive ci (cin % 4 == 0)  ->  (co*cin + ci)*9 + tap
+    const long ct = i / cin;
+    const int ci = (int)(i - ct * cin), tap = (int)(ct % 9);
+    const long co = ct / 9;
+    float* d = dW + (co * cin + ci) * 9 + tap;
+    const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (gridDim.y == 1) d[9 * e] += v[e];
+      else atomicAdd(d + 9 * e, v[e]);
+    }
+    return;
   }
   if (gridDim.y == 1) {
     float4 d = *reinterpret_cast<const float4*>(dW + i);
@@ -524,8 +540,19 @@ extern "C" long ea_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, i
 
 // Weight gradient: dW fp32 [Cout][3][3][Cin] += sum over positions of dZ (x) X-taps.  (The bias gradient of a convolution that
 // feeds BatchNorm is available from BatchNorm's own sums — exactly zero in training mode — and is not computed here.)
+static int conv3x3_wgrad_impl(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin, int Cout,
+                              int sy, int sx, int param_layout, hipStream_t stream);
 extern "C" int ea_conv3x3_wgrad(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin, int Cout,
                                 int sy, int sx, hipStream_t stream) {
+  return conv3x3_wgrad_impl(X, dZ, dW, workspace, B, T, F, Cin, Cout, sy, sx, 0, stream);
+}
+// the same with dW in the parameter's own layout [Cout][Cin][3][3] (+=): written straight into the parameter's gradient
+extern "C" int ea_conv3x3_wgrad_param_layout(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin,
+                                             int Cout, int sy, int sx, hipStream_t stream) {
+  return conv3x3_wgrad_impl(X, dZ, dW, workspace, B, T, F, Cin, Cout, sy, sx, 1, stream);
+}
+static int conv3x3_wgrad_impl(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin, int Cout,
+                              int sy, int sx, int param_layout, hipStream_t stream) {
   if (B <= 0 || T <= 0 || F <= 0) return 0;
   if (Cin % 64 || Cout % 64 || sy < 1 || sx < 1 || !workspace) return -2;
   ConvWgradArgs a;
@@ -547,6 +574,7 @@ extern "C" int ea_conv3x3_wgrad(const void* X, const void* dZ, float* dW, void* 
   int zg = (int)(1024 / blocks);  // ~1024 workgroups in all
   if (zg > nsplit / 4) zg = nsplit / 4;
   if (zg < 1) zg = 1;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks, zg), dim3(256), 0, stream, (const float*)workspace, dW, n, nsplit);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks, zg), dim3(256), 0, stream, (const float*)workspace, dW, n, nsplit,
+                     param_layout ? Cin : 0);
   return EA_CHECK_LAUNCH();
 }

@@ -104,12 +104,12 @@ def _auto_splitk(tiles, Kred):
     return max(1, min((768 + tiles - 1) // tiles, Kred // 256))
 
 
-def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None, out=None):
-    """dW[N_out][K_in] (fp32) = dy[M][N_out]^T x[M][K_in]   (split-K over the long M reduction)"""
+def _wgrad(dy, x, M, N_out, K_in, ld_dy=None, ld_x=None, out=None, accumulate=False):
+    """dW[N_out][K_in] (fp32) = dy[M][N_out]^T x[M][K_in]   (split-K over the long M reduction); accumulate: dW += ..."""
     dW = out if out is not None else torch.empty((N_out, K_in), dtype=torch.float32, device=dy.device)
     tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
     K.gemm(dy, x, dW, N_out, K_in, M, lda=ld_dy or N_out, ldb=ld_x or K_in, ldc=K_in, a_kstrided=True, b_kstrided=True,
-           splitk=_auto_splitk(tiles, M))
+           splitk=_auto_splitk(tiles, M), accumulate=accumulate)
     return dW
 
 
@@ -152,6 +152,35 @@ def _pool_zeros(shape, dtype, device):
 
 def _zeros_f32(n, like):
     return _pool_zeros((n,), torch.float32, like.device)
+
+
+# Parameter gradients written straight into `p.grad` (the flat gradient buffer's view) by the accumulating kernels of the
+# Python-composed backward passes, instead of into a pooled zero buffer that autograd then adds to `p.grad` with one ATen launch
+# per parameter (22 launches at the very end of the Conformer-CTC backward, in front of the optimizer).  A parameter handled this
+# way gets None from the autograd Function and is reported to the data-parallel wrapper through `_grad_ready_callback`, like the
+# native layer runtime's.  EA_DIRECT_GRADS=0: the autograd route (A/B switch, tests).
+_DIRECT_GRADS = os.environ.get("EA_DIRECT_GRADS", "1") != "0"
+
+
+def set_direct_param_grads(on: bool) -> bool:
+    global _DIRECT_GRADS
+    old, _DIRECT_GRADS = _DIRECT_GRADS, bool(on)
+    return old
+
+
+def _grad_sink(p, n=None):
+    """The fp32 buffer a kernel may ACCUMULATE parameter `p`'s gradient into directly (flat view of p.grad), or None."""
+    if not _DIRECT_GRADS or p is None or not getattr(p, "requires_grad", False):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda or (n is not None and g.numel() != n):
+        return None
+    return g.view(-1)
+
+
+def _report_direct(params):
+    if params and _grad_ready_callback is not None:
+        _grad_ready_callback(list(params))
 
 
 _side_streams = {}
@@ -214,6 +243,7 @@ class _Linear(torch.autograd.Function):
         K.gemm(x, w16, buf, M, N, Kin, lda=Kin, ldb=Kin, ldc=ld, bias=b)
         ctx.save_for_backward(x, w16)
         ctx.has_bias = b is not None
+        ctx.params = (w, b)
         return buf if ld == N else buf[:, :N]
 
     @staticmethod
@@ -226,14 +256,28 @@ class _Linear(torch.autograd.Function):
         if dy.stride(1) != 1 or dy.stride(0) % 8 != 0:
             dy = dy.contiguous()
         ld = dy.stride(0)
-        dW = _wgrad(dy, x, M, N, Kin, ld_dy=ld)
-        db = None
-        if ctx.has_bias:
-            db = K.colsum(dy, _zeros_f32(N, dy), M, N, ld)
+        pw, pb = ctx.params
+        sW = _grad_sink(pw, N * Kin)
+        sb = _grad_sink(pb, N) if ctx.has_bias else None
+        direct = []
+        if sW is not None and (sb is not None or not ctx.has_bias):
+            # a leaf parameter with its gradient buffer in place (fc_out): accumulate there, nothing returned to autograd
+            _wgrad(dy, x, M, N, Kin, ld_dy=ld, out=sW.view(N, Kin), accumulate=True)
+            dW, db = None, None
+            direct.append(pw)
+            if ctx.has_bias:
+                K.colsum(dy, sb, M, N, ld)
+                direct.append(pb)
+        else:
+            dW = _wgrad(dy, x, M, N, Kin, ld_dy=ld)
+            db = None
+            if ctx.has_bias:
+                db = K.colsum(dy, _zeros_f32(N, dy), M, N, ld)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _new((M, Kin), torch.bfloat16, x)
             K.gemm(dy, w16, dx, M, Kin, N, lda=ld, ldb=Kin, ldc=Kin, b_kstrided=True)
+        _report_direct(direct)
         return dx, dW, db, None, None
 
 
@@ -250,14 +294,20 @@ class _LayerNorm(torch.autograd.Function):
         y, mean, rstd = K.layernorm_fwd(x, g, b, eps, row_zero, drop_p, seed)
         ctx.save_for_backward(x, g, mean, rstd, row_zero)
         ctx.drop = (drop_p, seed)
+        ctx.params = (g, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, mean, rstd, row_zero = ctx.saved_tensors
         C = x.shape[1]
-        dg, db = _zeros_f32(C, x), _zeros_f32(C, x)
+        sg, sb = _grad_sink(ctx.params[0], C), _grad_sink(ctx.params[1], C)
+        direct = sg is not None and sb is not None
+        dg, db = (sg, sb) if direct else (_zeros_f32(C, x), _zeros_f32(C, x))
         dx = K.layernorm_bwd(x, dy.contiguous(), g, mean, rstd, dg, db, row_zero, ctx.drop[0], ctx.drop[1])
+        if direct:
+            _report_direct(list(ctx.params))
+            return dx, None, None, None, None, None
         return dx, dg, db, None, None, None
 
 
@@ -687,6 +737,7 @@ class _ConvSubsample(torch.autograd.Function):
         ctx.cfg = (B, cfgs, p_drop, seed, training, [tuple(p.shape) for p in params[0::4]])
         ctx.igemm = [i > 0 and _conv_igemm_ok(cfgs[i][2], cfgs[i][5], cfgs[i][6], cfgs[i][7]) for i in range(L)]
         ctx.weights = [params[4 * i] for i in range(L)]
+        ctx.params = list(params)
         return out
 
     @staticmethod
@@ -714,16 +765,33 @@ class _ConvSubsample(torch.autograd.Function):
         cur = torch.cuda.current_stream(X.device)
         side = _side_stream(X.device)
         keep = []
+        direct = []  # parameters whose gradient the kernels accumulated straight into p.grad
         for i in range(L - 1, -1, -1):
             Zi, mr, col, w16, g, beta = per[i]
             Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[i]
-            dg, dbeta = _zeros_f32(Co, X), _zeros_f32(Co, X)
+            pw, pb, pg, pbe = ctx.params[4 * i: 4 * i + 4]
+            sg, sbe = _grad_sink(pg, Co), _grad_sink(pbe, Co)
+            if sg is not None and sbe is not None:  # BatchNorm parameter gradients accumulate straight into p.grad
+                dg, dbeta = sg, sbe
+                direct += [pg, pbe]
+            else:
+                sg = sbe = None
+                dg, dbeta = _zeros_f32(Co, X), _zeros_f32(Co, X)
             if i == 0 and Co % 64 == 0 and _CONV1_FUSED_BWD:
                 # first layer: BatchNorm backward + conv1 weight gradient in one pass (csrc/convmodule.hip conv1_bn_bwd_wgrad_kernel):
                 # no dZ tensor, and the weight gradient is no longer the last, un-overlapped kernel of the backward pass
-                db, dW = _zeros_f32(Co, X), _zeros_f32(Co * 9, X)
+                sW, sb = _grad_sink(pw, Co * 9), _grad_sink(pb, Co)
+                if sW is not None and sb is not None:
+                    db, dW = sb, sW
+                    direct += [pw, pb]
+                else:
+                    sW = None
+                    db, dW = _zeros_f32(Co, X), _zeros_f32(Co * 9, X)
                 K.conv1_bn_bwd(X, Zi, dA, mr, g, beta, dg, dbeta, dW, db, B, Tc, Fc, Co, sy, sx, "relu", training)
-                grads[0], grads[1], grads[2], grads[3] = dW.view(wshapes[0]), db, dg, dbeta
+                if sW is None:
+                    grads[0], grads[1] = dW.view(wshapes[0]), db
+                if sg is None:
+                    grads[2], grads[3] = dg, dbeta
                 continue
             dZ = K.bn_act_bwd(Zi, dA, mr, g, beta, dg, dbeta, "relu", training)
             keep.append(dZ)
@@ -740,13 +808,22 @@ class _ConvSubsample(torch.autograd.Function):
                 # the input and dZ; data gradient: gather GEMM per parity class of the input position.  The bias gradient of a
                 # convolution feeding BatchNorm comes from BatchNorm's own sums: sum_p dZ = gamma * rstd * (dbeta - dbeta) = 0 with
                 # batch statistics (the batch mean removes the bias), gamma * rstd * dbeta with running statistics.
-                dWp = _zeros_f32(Co * 9 * Cc, X).view(Co, 9 * Cc)
+                sW = _grad_sink(pw, Co * 9 * Cc)
                 side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    K.conv3x3_wgrad(col, dZ, dWp, B, Tc, Fc, Cc, Co, sy, sx)
-                grads[4 * i] = dWp.view(Co, 3, 3, Cc).permute(0, 3, 1, 2)
+                if sW is not None:  # the slab reduce scatters into the parameter's [Co][Cc][3][3] gradient itself
+                    with torch.cuda.stream(side):
+                        K.conv3x3_wgrad(col, dZ, sW, B, Tc, Fc, Cc, Co, sy, sx, param_layout=True)
+                    direct.append(pw)
+                else:
+                    dWp = _zeros_f32(Co * 9 * Cc, X).view(Co, 9 * Cc)
+                    with torch.cuda.stream(side):
+                        K.conv3x3_wgrad(col, dZ, dWp, B, Tc, Fc, Cc, Co, sy, sx)
+                    grads[4 * i] = dWp.view(Co, 3, 3, Cc).permute(0, 3, 1, 2)
                 if not training:
                     db = g.detach() * mr[1] * dbeta
+                elif _grad_sink(pb, Co) is not None:
+                    db = None  # exactly zero with batch statistics: nothing to add to p.grad
+                    direct.append(pb)
                 wd16 = K.cast_f32_to_bf16(ctx.weights[i].detach().permute(1, 2, 3, 0).reshape(Cc, 9 * Co).contiguous())
                 dA = K.conv3x3_dgrad(dZ, wd16, B, Tc, Fc, Cc, Co, sy, sx)
             else:
@@ -760,10 +837,12 @@ class _ConvSubsample(torch.autograd.Function):
                 K.gemm(dZ, w16, dcol, n, 9 * Cc, Co, lda=Co, ldb=9 * Cc, ldc=9 * Cc, b_kstrided=True)
                 dA = K.col2im3x3(dcol, B, Tc, Fc, Cc, sy, sx)
             grads[4 * i + 1] = db
-            grads[4 * i + 2] = dg
-            grads[4 * i + 3] = dbeta
+            if sg is None:
+                grads[4 * i + 2] = dg
+                grads[4 * i + 3] = dbeta
         cur.wait_stream(side)
         del keep
+        _report_direct(direct)
         return (None,) * 8 + tuple(grads)
 
 

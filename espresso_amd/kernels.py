@@ -384,12 +384,14 @@ def conv3x3_dgrad(dZ, Wd16, B, T, F, Cin, Cout, sy, sx):
     return dX
 
 
-def conv3x3_wgrad(X, dZ, dW, B, T, F, Cin, Cout, sy, sx):
-    """dW fp32 [Cout][9*Cin] += weight gradient of the 3x3 conv from X bf16 [B*T*F][Cin] and dZ bf16 [B*To*Fo][Cout]."""
+def conv3x3_wgrad(X, dZ, dW, B, T, F, Cin, Cout, sy, sx, param_layout=False):
+    """dW fp32 [Cout][9*Cin] += weight gradient of the 3x3 conv from X bf16 [B*T*F][Cin] and dZ bf16 [B*To*Fo][Cout];
+    param_layout: dW is the parameter's gradient itself, [Cout][Cin][3][3]."""
     lib = _lib.lib()
     nb = lib.ea_conv3x3_wgrad_workspace_bytes(B, T, F, Cin, Cout, sy, sx)
     ws = torch.empty(nb, dtype=torch.uint8, device=X.device)
-    check(lib.ea_conv3x3_wgrad(_p(X), _p(dZ), _p(dW), _p(ws), B, T, F, Cin, Cout, sy, sx, _stream()), "ea_conv3x3_wgrad")
+    fn = lib.ea_conv3x3_wgrad_param_layout if param_layout else lib.ea_conv3x3_wgrad
+    check(fn(_p(X), _p(dZ), _p(dW), _p(ws), B, T, F, Cin, Cout, sy, sx, _stream()), "ea_conv3x3_wgrad")
     return dW
 
 

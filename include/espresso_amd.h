@@ -316,6 +316,10 @@ int ea_conv3x3_dgrad(const void* dZ, const void* Wd, void* dX, int B, int T, int
 long ea_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout, int sy, int sx);
 int ea_conv3x3_wgrad(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin, int Cout, int sy,
                      int sx, ea_stream_t stream);
+/* ea_conv3x3_wgrad with dW in the parameter's own layout [Cout][Cin][3][3] (torch.nn.Conv2d, +=): written straight into the
+ * parameter's gradient, no permuting copy and no accumulate launch afterwards */
+int ea_conv3x3_wgrad_param_layout(const void* X, const void* dZ, float* dW, void* workspace, int B, int T, int F, int Cin, int Cout,
+                                  int sy, int sx, ea_stream_t stream);
 int ea_im2col3x3(const void* A, void* col, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
 int ea_col2im3x3(const void* dcol, void* dA, int B, int T, int F, int C, int sy, int sx, ea_stream_t stream);
 int ea_colstats_bf16(const void* X, double* stats, long M, int C, ea_stream_t stream);
