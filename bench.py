@@ -436,9 +436,15 @@ def main(argv=None):
             del trainer, model, criterion, samples
         torch.cuda.empty_cache()
         here = os.path.dirname(os.path.abspath(__file__))
-        for key, script in (("config2_encdec", "bench_encdec.py"), ("config4_transducer", "bench_transducer.py")):
+        # f3: the transducer beam search (beam 5, 2 expansions per frame, the reference decoder's defaults) batched
+        # across utterances, over 18 batches = 210 utterances of the decode workload; random-init weights = the WORST case (a
+        # near-uniform joint's length-normalised scores prefer the longest hypothesis: every frame spends both expansions, 50
+        # emitted tokens per audio second against ~4.5 for a trained model — tools/bench_transducer_decode.py)
+        for key, script in (("config2_encdec", ["bench_encdec.py"]), ("config4_transducer", ["bench_transducer.py"]),
+                            ("f3_transducer_beam_search", ["bench_transducer_decode.py", "--beam-only", "--all-utts", "--batches", "18"])):
             try:
-                out = subprocess.run([sys.executable, os.path.join(here, "tools", script)], capture_output=True, text=True, timeout=600)
+                out = subprocess.run([sys.executable, os.path.join(here, "tools", script[0])] + script[1:], capture_output=True, text=True,
+                                     timeout=600)
                 last = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
                 others[key] = json.loads(last[-1]) if last else {"error": (out.stderr or out.stdout)[-300:]}
             except Exception as e:  # a secondary block must not take the headline line down with it

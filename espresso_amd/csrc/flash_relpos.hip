@@ -262,29 +262,33 @@ __device__ __forceinline__ float fand(float x, uint32_t m) { return __uint_as_fl
 // ---- keep bits --------------------------------------------------------------------------------------------------------
 // bits[((z*nkt + kt)*Tpad + i)*4 + g] : bit (jt*4 + r) = keep decision of key j = kt*64 + jt*16 + g*4 + r for query row i of
 // (head, sentence) z — exactly the 16 elements lane (i & 15, g) of the attention kernels holds for key tile kt.
+// Grid-stride over a CAPPED grid (2 workgroups per CU): the kernel runs on the side stream next to the QKV projection of the
+// same layer; one workgroup per 256 pieces (5 488 workgroups at the recipe's batch) took every wave slot of the device and the
+// projection's workgroups queued behind them (53 us in the step against 27 alone).
 __global__ __launch_bounds__(256) void keep_bits_kernel(uint16_t* bits, uint64_t seed, uint32_t thr, int Z, int T, int nkt) {
   const int Tpad = nkt * 64;
   const long n = (long)Z * nkt * Tpad * 4;
-  const long id = (long)blockIdx.x * 256 + threadIdx.x;
-  if (id >= n) return;
-  const int g = (int)(id & 3);
-  long t = id >> 2;
-  const int i = (int)(t % Tpad);
-  t /= Tpad;
-  const int kt = (int)(t % nkt);
-  const int z = (int)(t / nkt);
-  uint32_t piece = 0;
-  if (i < T) {
-    const uint64_t rowbase = ((uint64_t)z * T + (uint64_t)i) * (uint64_t)T;
+  const long stride = (long)gridDim.x * 256;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < n; id += stride) {
+    const int g = (int)(id & 3);
+    long t = id >> 2;
+    const int i = (int)(t % Tpad);
+    t /= Tpad;
+    const int kt = (int)(t % nkt);
+    const int z = (int)(t / nkt);
+    uint32_t piece = 0;
+    if (i < T) {
+      const uint64_t rowbase = ((uint64_t)z * T + (uint64_t)i) * (uint64_t)T;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kt * 64 + jt * 16 + g * 4 + r;
-        if (j < T && ea_hash(seed, rowbase + (uint64_t)j) >= thr) piece |= 1u << (jt * 4 + r);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt * 64 + jt * 16 + g * 4 + r;
+          if (j < T && ea_hash(seed, rowbase + (uint64_t)j) >= thr) piece |= 1u << (jt * 4 + r);
+        }
+    }
+    bits[id] = (uint16_t)piece;
   }
-  bits[id] = (uint16_t)piece;
 }
 
 // ======================================================================================================================
@@ -972,7 +976,10 @@ bool ea_rp_eligible(bool relpos, int T, int S, int causal, uint32_t thr, const v
 int ea_rp_keep_bits(uint16_t* bits, int H, int B, int T, uint64_t seed, uint32_t thr, hipStream_t stream) {
   const int nkt = (T + TK - 1) / TK;
   const long n = (long)H * B * nkt * (nkt * 64) * 4;
-  hipLaunchKernelGGL(keep_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, bits, seed, thr, H * B, T, nkt);
+  static const long cap = [] { const char* e = getenv("EA_KEEP_BITS_WGS"); return e ? atol(e) : 256L; }();  // (diagnostic override)
+  long blocks = (n + 255) / 256;
+  if (cap > 0 && blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(keep_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, seed, thr, H * B, T, nkt);
   return EA_CHECK_LAUNCH();
 }
 

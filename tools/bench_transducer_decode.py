@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=15000)
     ap.add_argument("--batch-size", type=int, default=24)
     ap.add_argument("--emit-rate", type=float, default=0.0, help="calibrate the blank bias to this many emitted tokens per audio second")
+    ap.add_argument("--beam-only", action="store_true", help="time the beam search only (bench.py's f3 block)")
+    ap.add_argument("--all-utts", action="store_true", help="beam search over EVERY utterance of the timed batches (f3 block: >= 200 utterances)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     import espresso_amd  # noqa: F401
@@ -66,7 +68,9 @@ def main():
             rate = n_emitted(g.generate([model], s0)) / samples[0]["audio_seconds"]
             lo, hi = (mid, hi) if rate > args.emit_rate else (lo, mid)
     decoders = [("greedy", TransducerGreedyDecoder([model], d, **common), samples),
-                ("beam", TransducerBeamSearchDecoder([model], d, beam_size=args.beam, **common), None)]
+                ("beam", TransducerBeamSearchDecoder([model], d, beam_size=args.beam, **common), samples if args.all_utts else None)]
+    if args.beam_only:
+        decoders = decoders[1:]
     for name, dec, use in decoders:
         if use is None:  # a few utterances of the first timed batch
             s = samples[1]
