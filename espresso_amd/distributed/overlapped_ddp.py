@@ -15,16 +15,19 @@ API mirrors the wrappers in fairseq/models/distributed_fairseq_model.py:35-147: 
 """
 import contextlib
 import os
+import queue
+import threading
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
+from .. import functional as _F
 from ..optim.flat import FlatParams
 
 
 class OverlappedDistributedDataParallel(torch.nn.Module):
-    def __init__(self, module: torch.nn.Module, flat: FlatParams, process_group=None, bucket_mb: float = 64.0):
+    def __init__(self, module: torch.nn.Module, flat: FlatParams, process_group=None, bucket_mb: float = 64.0, last_bucket_mb: float = 8.0):
         super().__init__()
         self.module = module
         self.flat = flat
@@ -37,7 +40,9 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self._on_gpu = flat.g32.is_cuda
         self.comm_stream = torch.cuda.Stream() if self._on_gpu else None
         elems = max(1, int(bucket_mb * 1024 * 1024 / 4))
-        self.buckets = flat.slices_in_backward_order(elems)
+        # the last bucket to complete (sub-sampler, fc0: the end of backward) is all-reduced with nothing left to hide it behind:
+        # keep it small (8 MB: ~30 us over seven xGMI links instead of ~0.25 ms for 64 MB)
+        self.buckets = flat.slices_in_backward_order(elems, int(last_bucket_mb * 1024 * 1024 / 4) if last_bucket_mb < bucket_mb else 0)
         # map each parameter to the bucket(s) that contain it
         self._param_buckets = {}
         self._bucket_total = [0] * len(self.buckets)
@@ -58,14 +63,19 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self.max_fired = 0
         self._hooks = {id(p): self._make_hook(p) for p in flat.params}
         self._native_cache = {}
+        # RCCL enqueues leave the thread that drives the step: `_launch` records where the gradient streams stand (events) and hands
+        # the bucket to a helper thread that makes the communication stream wait for them and issues the all-reduce (the call
+        # releases the GIL inside RCCL; five enqueues per step were ~1 ms of the main thread's time).  EA_DDP_THREAD=0: inline.
+        self._use_thread = self._on_gpu and os.environ.get("EA_DDP_THREAD", "1") != "0"
+        self._q: Optional[queue.Queue] = None
+        self._thread: Optional[threading.Thread] = None
+        self._thread_err: List = []
         if self.active:
             for p in flat.params:
                 p.register_post_accumulate_grad_hook(self._hooks[id(p)])
             # gradients written directly by the native layer runtime never pass through autograd's
             # AccumulateGrad, so the runtime reports them here
-            from .. import functional as F
-
-            F.set_grad_ready_callback(self._native_ready)
+            _F.set_grad_ready_callback(self._native_ready)
 
     def _make_hook(self, p):
         ids = self._param_buckets[id(p)]
@@ -88,8 +98,9 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         ~30 hook calls (12 layers x 30 closures were 1.6 ms of host time per step next to a 16.5 ms GPU step)."""
         if self.accumulate_grads:
             return
-        ent = self._native_cache.get(id(params))
-        if ent is None or ent[0] is not params or len(params) != ent[3]:
+        key = tuple(map(id, params))  # (the parameters themselves, not the list object: a list mutated in place or a fresh list
+        ent = self._native_cache.get(key)  # per call must not meet a stale or a never-matching entry)
+        if ent is None:
             counts, idx = {}, []
             for p in params:
                 k = self._index.get(id(p))
@@ -98,8 +109,8 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
                 idx.append(k)
                 for i in self._param_buckets[id(p)]:
                     counts[i] = counts.get(i, 0) + 1
-            ent = (params, sorted(counts.items()), idx, len(params))
-            self._native_cache[id(params)] = ent
+            ent = (tuple(params), sorted(counts.items()), idx, len(params))
+            self._native_cache[key] = ent
         fired = self._fired
         for k in ent[2]:
             fired[k] += 1
@@ -108,6 +119,25 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
             pending[i] -= n
             if pending[i] == 0:
                 self._launch(i)
+
+    def _worker(self):
+        dev = self.flat.g32.device
+        torch.cuda.set_device(dev)
+        while True:
+            item = self._q.get()
+            if item is None:
+                self._q.task_done()
+                return
+            view, events = item
+            try:
+                with torch.cuda.stream(self.comm_stream):
+                    for ev in events:
+                        self.comm_stream.wait_event(ev)
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+            except BaseException as e:  # surfaced by all_reduce_grads on the main thread
+                self._thread_err.append(e)
+            finally:
+                self._q.task_done()
 
     def _launch(self, i):
         if self._launched[i]:
@@ -119,13 +149,17 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
             # the bucket's gradients were accumulated on the stream that reported last — and, for models that run independent
             # branches on their own streams (the transducer's predictor network: autograd accumulates its parameters' gradients
             # on that stream), possibly on others: wait for all of them
-            from .. import functional as F
-
             cur = torch.cuda.current_stream()
-            self.comm_stream.wait_stream(cur)
-            for st in F.python_side_streams(view.device):
-                if st != cur:
-                    self.comm_stream.wait_stream(st)
+            streams = [cur] + [st for st in _F.python_side_streams(view.device) if st != cur]
+            if self._use_thread:
+                if self._thread is None:
+                    self._q = queue.Queue()
+                    self._thread = threading.Thread(target=self._worker, name="ea-ddp-launch", daemon=True)
+                    self._thread.start()
+                self._q.put((view, [st.record_event() for st in streams]))
+                return
+            for st in streams:
+                self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
         else:
@@ -158,6 +192,10 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)
+            if self._q is not None:
+                self._q.join()  # every bucket handed to the helper thread has been issued
+                if self._thread_err:
+                    raise self._thread_err.pop()
             for w in self._works:
                 w.wait()
             if self._on_gpu:

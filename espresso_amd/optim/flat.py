@@ -81,12 +81,17 @@ class FlatParams:
         self.g32.zero_()
         self.rebind_grads()
 
-    def slices_in_backward_order(self, bucket_elems: int):
-        """[(start, end)] element ranges covering the buffer, last parameters first, ~bucket_elems each."""
+    def slices_in_backward_order(self, bucket_elems: int, last_elems: int = 0):
+        """[(start, end)] element ranges covering the buffer, last parameters first, ~bucket_elems each.  `last_elems` > 0: the
+        FINAL range (the first parameters of the model, whose gradients the backward pass produces last, so that nothing is left
+        to overlap its all-reduce with) holds at most that many elements."""
         out = []
         end = self.numel
-        while end > 0:
-            start = max(0, end - bucket_elems)
+        tail = min(max(0, int(last_elems)), self.numel) if last_elems and self.numel > bucket_elems else 0
+        while end > tail:
+            start = max(tail, end - bucket_elems)
             out.append((start, end))
             end = start
+        if tail:
+            out.append((0, tail))
         return out
