@@ -157,8 +157,9 @@ def _zeros_f32(n, like):
 # Parameter gradients written straight into `p.grad` (the flat gradient buffer's view) by the accumulating kernels of the
 # Python-composed backward passes, instead of into a pooled zero buffer that autograd then adds to `p.grad` with one ATen launch
 # per parameter (22 launches at the very end of the Conformer-CTC backward, in front of the optimizer).  A parameter handled this
-# way gets None from the autograd Function and is reported to the data-parallel wrapper through `_grad_ready_callback`, like the
-# native layer runtime's.  EA_DIRECT_GRADS=0: the autograd route (A/B switch, tests).
+# way gets None from the autograd Function; autograd still runs its AccumulateGrad node — nothing to add — and with it the
+# post-accumulate-grad hook the data-parallel wrapper counts bucket completion with (tests/test_host_logic.py pins that
+# behaviour of torch), at the same point of the stream order as before.  EA_DIRECT_GRADS=0: the autograd route (A/B switch, tests).
 _DIRECT_GRADS = os.environ.get("EA_DIRECT_GRADS", "1") != "0"
 
 
@@ -172,15 +173,14 @@ def _grad_sink(p, n=None):
     """The fp32 buffer a kernel may ACCUMULATE parameter `p`'s gradient into directly (flat view of p.grad), or None."""
     if not _DIRECT_GRADS or p is None or not getattr(p, "requires_grad", False):
         return None
+    if not p.is_leaf:
+        return None
     g = p.grad
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda or (n is not None and g.numel() != n):
         return None
     return g.view(-1)
 
 
-def _report_direct(params):
-    if params and _grad_ready_callback is not None:
-        _grad_ready_callback(list(params))
 
 
 _side_streams = {}
@@ -277,7 +277,6 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _new((M, Kin), torch.bfloat16, x)
             K.gemm(dy, w16, dx, M, Kin, N, lda=ld, ldb=Kin, ldc=Kin, b_kstrided=True)
-        _report_direct(direct)
         return dx, dW, db, None, None
 
 
@@ -306,7 +305,6 @@ class _LayerNorm(torch.autograd.Function):
         dg, db = (sg, sb) if direct else (_zeros_f32(C, x), _zeros_f32(C, x))
         dx = K.layernorm_bwd(x, dy.contiguous(), g, mean, rstd, dg, db, row_zero, ctx.drop[0], ctx.drop[1])
         if direct:
-            _report_direct(list(ctx.params))
             return dx, None, None, None, None, None
         return dx, dg, db, None, None, None
 
@@ -842,7 +840,6 @@ class _ConvSubsample(torch.autograd.Function):
                 grads[4 * i + 3] = dbeta
         cur.wait_stream(side)
         del keep
-        _report_direct(direct)
         return (None,) * 8 + tuple(grads)
 
 

@@ -354,12 +354,13 @@ def check_direct_param_grads(fixture="ref_conformer_ctc_dh64"):
     for direct in (True, False):
         old = F.set_direct_param_grads(direct)
         seen = []
-        F.set_grad_ready_callback(lambda ps, seen=seen: seen.extend(ps))
         try:
             model = build_tiny_model("conformer", embed_dim=d, heads=H, ffn=ffn).to(DEV)
             load_ref_state(model, sd)
             flat = FlatParams(model, DEV)
             flat.zero_grad()
+            for p_ in flat.params:  # what the data-parallel wrapper registers: must fire once per backward either way
+                p_.register_post_accumulate_grad_hook(lambda q, seen=seen: seen.append(q))
             model.train()
             for rep in range(2):
                 o = model(feats, lengths)
@@ -368,10 +369,12 @@ def check_direct_param_grads(fixture="ref_conformer_ctc_dh64"):
             torch.cuda.synchronize()
             out.append({n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
             ids = {id(p): n for n, p in model.named_parameters()}
-            reported.append(sorted({ids[id(p)] for p in seen if id(p) in ids and "layers." not in ids[id(p)]}))
+            import collections
+
+            cnt = collections.Counter(ids[id(p)] for p in seen if id(p) in ids and "layers." not in ids[id(p)])
+            reported.append(dict(cnt))
         finally:
             F.set_direct_param_grads(old)
-            F.set_grad_ready_callback(None)
     worst = ("", 0.0)
     for n in out[1]:
         if (".pre_encoder.convolutions." in n and n.endswith(".bias")) or n.endswith("self_attn.k_proj.bias"):
@@ -380,7 +383,7 @@ def check_direct_param_grads(fixture="ref_conformer_ctc_dh64"):
         e = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         if e > worst[1]:
             worst = (n, e)
-    return {"worst_grad": worst, "n": len(out[1]), "reported_direct": reported[0], "reported_autograd_route": reported[1]}
+    return {"worst_grad": worst, "n": len(out[1]), "hook_counts_direct": reported[0], "hook_counts_autograd_route": reported[1]}
 
 
 # ------------------------------------------------------------------ model-level parity vs the reference fixture

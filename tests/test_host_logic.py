@@ -1240,3 +1240,31 @@ def test_asr_collate_matches_the_reference_collate(golden_dir):
     b = collate(nt, pad_idx=pad, eos_idx=eos)
     assert b["id"].tolist() == g["notgt::id"].tolist() and b["net_input"]["src_lengths"].tolist() == g["notgt::src_lengths"].tolist()
     assert sorted(b.keys()) == g["notgt::keys"].tolist() and b["target"] is None
+
+
+
+def test_post_accumulate_grad_hook_fires_for_a_parameter_whose_function_returned_none():
+    """espresso_amd.functional._grad_sink: kernels accumulate some parameter gradients straight into `p.grad` and the autograd
+    Function returns None for them; the data-parallel wrapper still learns that the gradient is complete from the
+    post-accumulate-grad hook — autograd runs the parameter's AccumulateGrad node (and its hooks) even for an undefined
+    gradient.  Pinned here because the bucket accounting of OverlappedDistributedDataParallel depends on it."""
+    import torch
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.params = (w, b)
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, dy):
+            ctx.params[0].grad += 1.0  # "the kernel wrote it"
+            return dy * 2, None, None
+
+    w, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(3))
+    w.grad, b.grad = torch.zeros(3), torch.zeros(3)
+    fired = []
+    w.register_post_accumulate_grad_hook(lambda p: fired.append("w"))
+    b.register_post_accumulate_grad_hook(lambda p: fired.append("b"))
+    Fn.apply(torch.ones(3, requires_grad=True), w, b).sum().backward()
+    assert sorted(fired) == ["b", "w"] and float(w.grad.sum()) == 3.0
