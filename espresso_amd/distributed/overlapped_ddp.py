@@ -63,10 +63,12 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self.max_fired = 0
         self._hooks = {id(p): self._make_hook(p) for p in flat.params}
         self._native_cache = {}
-        # RCCL enqueues leave the thread that drives the step: `_launch` records where the gradient streams stand (events) and hands
-        # the bucket to a helper thread that makes the communication stream wait for them and issues the all-reduce (the call
-        # releases the GIL inside RCCL; five enqueues per step were ~1 ms of the main thread's time).  EA_DDP_THREAD=0: inline.
-        self._use_thread = self._on_gpu and os.environ.get("EA_DDP_THREAD", "1") != "0"
+        # EA_DDP_THREAD=1: the RCCL enqueues leave the thread that drives the step — `_launch` records where the gradient streams
+        # stand (events) and hands the bucket to a helper thread that makes the communication stream wait for them and issues the
+        # all-reduce.  Measured on a one-rank RCCL group (round 4, profiles/r04_ddp_one_rank_overhead.json): no difference
+        # (21.2 / 21.5 ms with the thread, 21.2 / 21.5 inline, 18.9 without the wrapper) — the cost of the one-rank path is the
+        # RCCL kernels themselves moving 320 MB next to the backward pass, not the five host enqueues.  Off by default.
+        self._use_thread = self._on_gpu and os.environ.get("EA_DDP_THREAD", "0") == "1"
         self._q: Optional[queue.Queue] = None
         self._thread: Optional[threading.Thread] = None
         self._thread_err: List = []
