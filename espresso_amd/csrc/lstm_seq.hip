@@ -291,8 +291,14 @@ int launch_bwd(const LstmSeqBwdArgs& a, hipStream_t stream) {
 
 // 1 when the persistent kernels cover this shape (H a multiple of 32 among the instantiated sizes, at most 64 batch rows) AND the
 // device can hold the whole grid at once: the grid barrier needs every workgroup resident (up to H / 16 = 64 workgroups of 256
-// threads; one per CU is always placeable on an otherwise idle device, so the CU count of the current device is the gate —
-// small or partitioned devices fall back to the per-step path)
+// threads, 2 KB of LDS each; the CU count of the current device is the gate — small or partitioned devices fall back to the
+// per-step path).  The device need NOT be idle: since round 3 the transducer's predictor LSTM runs on its own stream next to
+// encoder kernels, the layer runtime's side stream and the joint's weight-gradient stream.  A workgroup of this grid then
+// becomes resident as soon as any CU has 4 free wave slots; the kernels that hold them are ordinary launches that depend on
+// nothing in this grid and end within a millisecond, so the whole grid is resident after at most that long, while grid_wait
+// gives up (and traps, so that a broken launch cannot continue on stale state) only after ~2^26 polls of >= 64 cycles = several
+// SECONDS.  What must never share the device with this kernel is another grid-barrier kernel whose grid cannot be placed
+// next to it — the library has none: forward and backward recurrences of one model are ordered by autograd.
 extern "C" int ea_lstm_seq_supported(int B, int H) {
   if (B < 1 || B > 64) return 0;
   static const int cus = [] {

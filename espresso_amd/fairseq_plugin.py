@@ -62,8 +62,10 @@ def adapt_cfg(cfg, target_cls, ref_defaults=None, where=""):
     return target_cls(**kw)
 
 
-def _model_entry(name, cls):
-    """What fairseq.models.build_model calls `.build_model(cfg, task)` on: adapts the merged config, builds OUR model."""
+def _model_entry(name, cls, owner=None):
+    """What fairseq.models.build_model calls `.build_model(cfg, task)` on: adapts the merged config, builds OUR model.
+    `owner`: the registered model an architecture alias belongs to — the reference's dataclass (whose defaults decide which
+    foreign keys may be ignored) is registered under the MODEL's name, not under the alias."""
     cfg_cls = getattr(cls, "config_class", None)
 
     class Entry(cls):  # a subclass so that isinstance / registry introspection still see the espresso_amd model
@@ -73,8 +75,20 @@ def _model_entry(name, cls):
             if cfg_cls is not None and not isinstance(cfg, cfg_cls):
                 import fairseq.models as fm
 
-                ref_dc = fm.MODEL_DATACLASS_REGISTRY.get(name)
-                cfg = adapt_cfg(cfg, cfg_cls, _plain(ref_dc()) if ref_dc is not None else None, "model.")
+                ref_dc = fm.MODEL_DATACLASS_REGISTRY.get(name) or (fm.MODEL_DATACLASS_REGISTRY.get(owner) if owner else None)
+                if ref_dc is None and not dataclasses.is_dataclass(cfg):
+                    # nothing to tell a harmless default from an unimplemented option (legacy Namespace configs, aliases without
+                    # a reference dataclass): keep the keys this model knows, as before round 3's strict check, and say so
+                    import logging
+
+                    known = {f.name for f in dataclasses.fields(cfg_cls)}
+                    dropped = sorted(k for k, v in _plain(cfg).items() if k not in known and v is not None)
+                    if dropped:
+                        logging.getLogger(__name__).warning("model %r: no reference dataclass to check against; ignoring config keys %s",
+                                                            name, dropped)
+                    cfg = adapt_cfg({k: v for k, v in _plain(cfg).items() if k in known}, cfg_cls, None, "model.")
+                else:
+                    cfg = adapt_cfg(cfg, cfg_cls, _plain(ref_dc()) if ref_dc is not None else None, "model.")
             elif cfg_cls is None:
                 cfg = _plain(cfg)
             return cls.build_model(cfg, inner_task)
@@ -263,7 +277,7 @@ def install():
         fm.ARCH_MODEL_NAME_REGISTRY[mname] = mname
     for aname, cls in registry.ARCH_MODEL_REGISTRY.items():
         owner = next((n for n, c in registry.MODEL_REGISTRY.items() if c is cls), aname)
-        fm.ARCH_MODEL_REGISTRY[aname] = fm.MODEL_REGISTRY.get(owner, _model_entry(aname, cls))
+        fm.ARCH_MODEL_REGISTRY[aname] = fm.MODEL_REGISTRY.get(owner, _model_entry(aname, cls, owner=owner))
         fm.ARCH_MODEL_NAME_REGISTRY[aname] = owner
         fm.ARCH_CONFIG_REGISTRY[aname] = registry.ARCH_CONFIG_REGISTRY[aname]
 

@@ -221,6 +221,8 @@ def main(argv=None):
 
     dev = torch.device(args.device or "cuda:{}".format(int(os.environ.get("LOCAL_RANK", "0"))))
     if dev.type == "cuda":
+        if dev.index is None:  # `--device cuda`: set_device needs an explicit index
+            dev = torch.device("cuda", torch.cuda.current_device())
         torch.cuda.set_device(dev)
     paths = args.path.split(os.pathsep)  # `--path a.pt:b.pt` = an ensemble (fairseq utils.split_paths in speech_recognize.py:107)
     state = _load_file(paths[0])
@@ -266,6 +268,9 @@ def main(argv=None):
     refs = read_scp(args.text) if args.text else None
     task.build_frontend(dev)
     batches = shard_batches(make_batches(utt_ids, [len(w) for w in waves], args.max_tokens, args.batch_size), args.num_shards, args.shard_id)
+    if args.num_shards > 1:  # (the defaults come from WORLD_SIZE / RANK: say that this process decodes — and scores — a part only)
+        print(f"| decoding shard {args.shard_id} of {args.num_shards}: {sum(len(b) for b in batches)} of {len(utt_ids)} utterances; "
+              "WER / CER below cover this shard only", file=sys.stderr)
     recognize(task, model, gen, (collate(b, utt_ids, waves, dev) for b in batches), task.target_dictionary, refs, out=sys.stdout,
               nbest=args.nbest, quiet=args.quiet)
 
