@@ -235,8 +235,36 @@ __device__ __forceinline__ void load_bias8(const EaGemmParams& p, int n, float (
   }
 }
 
+// positional biases of the 8 query columns a thread owns (query-split epilogue): loaded once like the bias (they were 16 scalar
+// loads per 8-column chunk and pass: 38.8 us against 26.2 us for the same projection with the plain epilogue, isolated)
+__device__ __forceinline__ void load_pos8(const EaGemmParams& p, int n, float (&u)[8], float (&w)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) u[e] = w[e] = 0.f;
+  if (!p.q_u || n >= p.qsplit_n) return;  // (qsplit_n % 128 == 0: a thread's 8 columns are all query columns or none)
+  const bool al = ((((uintptr_t)p.pos_u) | ((uintptr_t)p.pos_v)) & 15) == 0;
+  if (p.pos_u) {
+    if (al) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p.pos_u + n), x1 = *reinterpret_cast<const float4*>(p.pos_u + n + 4);
+      u[0] = x0.x; u[1] = x0.y; u[2] = x0.z; u[3] = x0.w; u[4] = x1.x; u[5] = x1.y; u[6] = x1.z; u[7] = x1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = p.pos_u[n + e];
+    }
+  }
+  if (p.pos_v) {
+    if (al) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p.pos_v + n), x1 = *reinterpret_cast<const float4*>(p.pos_v + n + 4);
+      w[0] = x0.x; w[1] = x0.y; w[2] = x0.z; w[3] = x0.w; w[4] = x1.x; w[5] = x1.y; w[6] = x1.z; w[7] = x1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = p.pos_v[n + e];
+    }
+  }
+}
+
 __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int ks_id, int zhi, int zlo, long coff, int m,
-                                               int n, float (&v)[8], const float (&bias8)[8], bool vec_ok, bool nt = false) {
+                                               int n, float (&v)[8], const float (&bias8)[8], const float (&posu8)[8],
+                                               const float (&posv8)[8], bool vec_ok, bool nt = false) {
   const int cnt = min(8, p.N - n);
   const bool vec = vec_ok && cnt == 8;
   const bool has_drop = p.drop_thr != 0;
@@ -249,8 +277,8 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float q = __uint_as_float((uint32_t)f2bf(v[e]) << 16);
-      u8[e] = (q + (p.pos_u ? p.pos_u[n + e] : 0.f)) * p.qscale;
-      b8[e] = (q + (p.pos_v ? p.pos_v[n + e] : 0.f)) * p.qscale;
+      u8[e] = (q + posu8[e]) * p.qscale;
+      b8[e] = (q + posv8[e]) * p.qscale;
     }
     const bool qvec = (p.ld_q & 7) == 0 && ((((uintptr_t)p.q_u) | ((uintptr_t)p.q_v)) & 15) == 0;
     store8_bf16(reinterpret_cast<bf16_t*>(p.q_u) + (long)m * p.ld_q + n, qvec, 8, u8, nt);
@@ -464,6 +492,8 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
   const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
   float bias8[8];
   load_bias8(p, n0 + (tid & 15) * 8, bias8);
+  float posu8[8], posv8[8];
+  load_pos8(p, n0 + (tid & 15) * 8, posu8, posv8);
 #pragma unroll
   for (int half = 0; half < BM_ / 64; ++half) {
     __syncthreads();
@@ -488,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok, (xcd_swizzle & 2) != 0);
+          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
         }
       }
     }
@@ -621,6 +651,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
   const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
   float bias8[8];
   load_bias8(p, n0 + (tid & 15) * 8, bias8);
+  float posu8[8], posv8[8];
+  load_pos8(p, n0 + (tid & 15) * 8, posu8, posv8);
 #pragma unroll
   for (int half = 0; half < BM_ / 64; ++half) {
     __syncthreads();
@@ -645,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, vec_ok, (xcd_swizzle & 2) != 0);
+          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
         }
       }
     }

@@ -58,6 +58,7 @@ def cases():
         (C, F, "ffn W2 fwd: bias+drop, 0.5*y + resid", "w2"),
         (C, F, "ffn W1 dgrad: plain", "plain"),
         (3 * C, C, "qkv projection: bias", "bias"),
+        (3 * C, C, "qkv projection: bias + query split (in-step form)", "qsplit"),
         (2 * C, C, "conv pointwise 1: plain", "plain"),
         (C, C, "out_proj / pointwise 2: bias+drop+resid", "w2"),
         (C, C, "dgrad of a C x C projection: plain", "plain"),
@@ -77,6 +78,9 @@ def cases():
             args.update(bias=torch.randn(N, device=DEV), resid=bf(M, N), ldr=N, out_scale=0.5, drop_p=0.1, drop_seed=9)
         elif kw == "bias":
             args.update(bias=torch.randn(N, device=DEV))
+        elif kw == "qsplit":  # the q third goes to two scaled, position-biased copies instead of C (EaGemmParams.q_u)
+            qu, qv = torch.empty(M, C, dtype=torch.bfloat16, device=DEV), torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+            args.update(bias=torch.randn(N, device=DEV), qsplit=(qu, qv, torch.randn(C, device=DEV), torch.randn(C, device=DEV), C, C, 0.125))
         out.append((N, Kd, tag, a, w, c, args))
     return out
 
