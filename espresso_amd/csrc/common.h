@@ -81,9 +81,36 @@ __device__ __forceinline__ float ea_keep(uint64_t seed, uint64_t idx, uint32_t t
   return ea_hash(seed, idx) >= thr ? inv_keep : 0.f;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// (v_rcp_f32, 1 ulp, instead of the IEEE division sequence — two v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup per
+// call: the GEMM epilogues alone held 1 344 of them; the result is rounded to bf16 by every caller)
+// keep-scales of 8 CONSECUTIVE elements idx0 .. idx0+7 — bit for bit ea_keep(seed, idx0 + e): the first multiply of the hash is
+// linear in the index ((lo + e) * K = lo * K + e * K mod 2^32) and the high-word term is the same for all eight when the low
+// word does not wrap, so a chunk costs 1 + 16 quarter-rate multiplies instead of 32 and no 64-bit additions
+__device__ __forceinline__ void ea_keep8(uint64_t seed, uint64_t idx0, uint32_t thr, float inv_keep, float (&k)[8]) {
+  const uint32_t lo = (uint32_t)idx0;
+  if (lo > 0xFFFFFFF7u) {  // the low word wraps inside the chunk: element-wise
+#pragma unroll
+    for (int e = 0; e < 8; ++e) k[e] = ea_keep(seed, idx0 + (uint64_t)e, thr, inv_keep);
+    return;
+  }
+  const uint32_t hi = ((uint32_t)(idx0 >> 32) * 0x85EBCA77u) ^ (uint32_t)(seed >> 32) ^ ((uint32_t)seed * 0xC2B2AE3Du);
+  uint32_t x0 = lo * 0x9E3779B1u + (uint32_t)seed;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    uint32_t x = x0 + (uint32_t)e * 0x9E3779B1u;
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= hi;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    k[e] = x >= thr ? inv_keep : 0.f;
+  }
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
-  float s = 1.f / (1.f + __expf(-x));
+  float s = __builtin_amdgcn_rcpf(1.f + __expf(-x));
   return s * (1.f + x * (1.f - s));
 }
 

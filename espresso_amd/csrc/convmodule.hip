@@ -14,7 +14,7 @@ namespace {
 
 constexpr int KMAX = 31;
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }  // (v_rcp_f32, see silu_f)
 
 // Depthwise-conv tiles: one workgroup = CT channels x TTILE output steps of one utterance; the input rows (plus the KW-1
 // halo) are staged once in LDS with every global load in flight at once, then each thread produces TPT consecutive outputs

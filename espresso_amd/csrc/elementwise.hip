@@ -49,13 +49,13 @@ __global__ __launch_bounds__(256) void scale_dropout_kernel(const bf16_t* __rest
       if (y) uy = *reinterpret_cast<const uint4*>(y + i);
       const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
       const uint32_t wy[4] = {uy.x, uy.y, uy.z, uy.w};
-      float o[8];
+      float o[8], k8[8];
+      if (thr) ea_keep8(seed, (uint64_t)i, thr, inv_keep, k8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
         const float yv = (e & 1) ? __uint_as_float(wy[e >> 1] & 0xffff0000u) : __uint_as_float(wy[e >> 1] << 16);
-        float k = 1.f;
-        if (thr) k = ea_keep(seed, (uint64_t)(i + e), thr, inv_keep);
+        const float k = thr ? k8[e] : 1.f;
         o[e] = a * xv * k + b * yv;
       }
       uint4 u;

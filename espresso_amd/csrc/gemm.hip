@@ -298,13 +298,15 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
     }
     return;
   }
+  float keep8[8];
+  if (has_drop) ea_keep8(p.drop_seed, didx, p.drop_thr, p.drop_scale, keep8);
   if (p.aux) {
     float zz[8];
     load8_bf16(reinterpret_cast<const bf16_t*>(p.aux) + (long)zhi * p.sX_hi + (long)zlo * p.sX_lo + (long)m * p.ldaux + n,
                vec && (p.ldaux & 7) == 0 && ((((uintptr_t)p.aux) & 15) == 0) && (((p.sX_hi | p.sX_lo) & 7) == 0), cnt, zz);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (has_drop) v[e] *= ea_keep(p.drop_seed, didx + e, p.drop_thr, p.drop_scale);
+      if (has_drop) v[e] *= keep8[e];
       v[e] *= apply_dact(zz[e], p.act);
     }
   } else {
@@ -313,7 +315,7 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[e] = apply_act(v[e], p.act);
-        if (has_drop) v[e] *= ea_keep(p.drop_seed, didx + e, p.drop_thr, p.drop_scale);
+        if (has_drop) v[e] *= keep8[e];
       }
       store8_bf16(reinterpret_cast<bf16_t*>(p.C2) + coff + (long)m * p.ldc2 + n,
                   vec && (p.ldc2 & 7) == 0 && ((((uintptr_t)p.C2) & 15) == 0), cnt, v, nt);
@@ -322,7 +324,7 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       v[e] = apply_act(v[e], p.act);
-      if (has_drop) v[e] *= ea_keep(p.drop_seed, didx + e, p.drop_thr, p.drop_scale);
+      if (has_drop) v[e] *= keep8[e];
     }
   }
 #pragma unroll

@@ -155,11 +155,12 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(
     }
     if (!on) continue;
     const bool zero = row_zero && row_zero[row];
-    float o[8];
+    float o[8], k8[8];
+    if (thr) ea_keep8(seed, (uint64_t)row * C + lane * 8, thr, inv_keep, k8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = (v[r][e] - mean[r]) * rstd * ga[e] + be[e];
-      if (thr) t *= ea_keep(seed, (uint64_t)row * C + lane * 8 + e, thr, inv_keep);
+      if (thr) t *= k8[e];
       o[e] = zero ? 0.f : t;
     }
     uint4 u;
@@ -217,13 +218,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * C + ch * 8);
         const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
         const uint32_t wd[4] = {ud.x, ud.y, ud.z, ud.w};
+        float k8[8];
+        if (thr) ea_keep8(seed, (uint64_t)row * C + ch * 8, thr, inv_keep, k8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int c = ch * 8 + e;
           const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
           float dv = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
           if (zero) dv = 0.f;
-          if (thr) dv *= ea_keep(seed, (uint64_t)row * C + c, thr, inv_keep);
+          if (thr) dv *= k8[e];
           const float h = (xv - mean) * rstd;
           xh[i][e] = h;
           dg[i][e] += dv * h;
@@ -259,13 +261,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         *reinterpret_cast<uint4*>(dx + (long)row * C + ch * 8) = u;
         if (o2.out) {
           const uint32_t wu[4] = {u.x, u.y, u.z, u.w};
-          float p2[8];
+          float p2[8], kk8[8];
+          if (o2.thr) ea_keep8(o2.seed, (uint64_t)row * C + ch * 8, o2.thr, o2.inv_keep, kk8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float dv = (e & 1) ? __uint_as_float(wu[e >> 1] & 0xffff0000u) : __uint_as_float(wu[e >> 1] << 16);  // the rounded dx
-            float kk = 1.f;
-            if (o2.thr) kk = ea_keep(o2.seed, (uint64_t)row * C + ch * 8 + e, o2.thr, o2.inv_keep);
-            p2[e] = o2.a * dv * kk;
+            p2[e] = o2.a * dv * (o2.thr ? kk8[e] : 1.f);
           }
           uint4 u2;
           u2.x = pack_bf2(p2[0], p2[1]);
