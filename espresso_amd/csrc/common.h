@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #define EA_WAVE 64
@@ -27,6 +28,22 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
 }
 
+// Sum over the 64 lanes, returned to every lane, on the DPP path: four row-local steps (quad permutes, row rotates), two
+// row-broadcast steps, one v_readlane — ~7 dependent VALU operations instead of six ds_bpermute round trips through the LDS
+// crossbar (what __shfl_xor compiles to).  The summation ORDER differs from wave_sum's butterfly (fp32: last-bit differences).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl, auto rmask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xF, false));
+  };
+  using std::integral_constant;
+  v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, integral_constant<int, 0x124>{}, integral_constant<int, 0xF>{});  // row_ror:4
+  v += dpp(v, integral_constant<int, 0x128>{}, integral_constant<int, 0xF>{});  // row_ror:8  -> every lane holds its row's sum
+  v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});  // row_bcast:15 into rows 1 and 3
+  v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
