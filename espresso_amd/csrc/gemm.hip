@@ -262,11 +262,15 @@ __device__ __forceinline__ void load_pos8(const EaGemmParams& p, int n, float (&
   }
 }
 
+// FAST (host-checked, fast_epilogue_ok): bf16 output, no split-K, N a multiple of 128 and every operand of the epilogue 16-byte
+// aligned with 8-element pitches — the chunk is always whole and vector-accessible, so the ragged / scalar / fp32-output /
+// split-K paths (three quarters of the kernel's 10 000 instructions, re-walked by every workgroup) are not instantiated.
+template <bool FAST = false>
 __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int ks_id, int zhi, int zlo, long coff, int m,
                                                int n, float (&v)[8], const float (&bias8)[8], const float (&posu8)[8],
                                                const float (&posv8)[8], bool vec_ok, bool nt = false) {
-  const int cnt = min(8, p.N - n);
-  const bool vec = vec_ok && cnt == 8;
+  const int cnt = FAST ? 8 : min(8, p.N - n);
+  const bool vec = FAST ? true : (vec_ok && cnt == 8);
   const bool has_drop = p.drop_thr != 0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias8[e];
@@ -280,14 +284,14 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
       u8[e] = (q + posu8[e]) * p.qscale;
       b8[e] = (q + posv8[e]) * p.qscale;
     }
-    const bool qvec = (p.ld_q & 7) == 0 && ((((uintptr_t)p.q_u) | ((uintptr_t)p.q_v)) & 15) == 0;
+    const bool qvec = FAST ? true : ((p.ld_q & 7) == 0 && ((((uintptr_t)p.q_u) | ((uintptr_t)p.q_v)) & 15) == 0);
     store8_bf16(reinterpret_cast<bf16_t*>(p.q_u) + (long)m * p.ld_q + n, qvec, 8, u8, nt);
     if (p.q_v) store8_bf16(reinterpret_cast<bf16_t*>(p.q_v) + (long)m * p.ld_q + n, qvec, 8, b8, nt);
     return;
   }
   const uint64_t didx = ((uint64_t)z * (uint64_t)p.M + (uint64_t)m) * (uint64_t)p.N + (uint64_t)n;
   const long co = coff + (long)m * p.ldc + n;
-  if (p.splitk > 1) {  // split-K partial slab [ks][batch][M][N] fp32 (dense, ld = N); combined by splitk_reduce_kernel
+  if (!FAST && p.splitk > 1) {  // split-K partial slab [ks][batch][M][N] fp32 (dense, ld = N); combined by splitk_reduce_kernel
     float* W = reinterpret_cast<float*>(p.workspace) + (((long)ks_id * p.batch + z) * p.M + m) * (long)p.N + n;
     if (cnt == 8 && (p.N & 3) == 0) {
       *reinterpret_cast<float4*>(W) = make_float4(v[0], v[1], v[2], v[3]);
@@ -303,7 +307,7 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
   if (p.aux) {
     float zz[8];
     load8_bf16(reinterpret_cast<const bf16_t*>(p.aux) + (long)zhi * p.sX_hi + (long)zlo * p.sX_lo + (long)m * p.ldaux + n,
-               vec && (p.ldaux & 7) == 0 && ((((uintptr_t)p.aux) & 15) == 0) && (((p.sX_hi | p.sX_lo) & 7) == 0), cnt, zz);
+               FAST ? true : (vec && (p.ldaux & 7) == 0 && ((((uintptr_t)p.aux) & 15) == 0) && (((p.sX_hi | p.sX_lo) & 7) == 0)), cnt, zz);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (has_drop) v[e] *= keep8[e];
@@ -318,7 +322,7 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
         if (has_drop) v[e] *= keep8[e];
       }
       store8_bf16(reinterpret_cast<bf16_t*>(p.C2) + coff + (long)m * p.ldc2 + n,
-                  vec && (p.ldc2 & 7) == 0 && ((((uintptr_t)p.C2) & 15) == 0), cnt, v, nt);
+                  FAST ? true : (vec && (p.ldc2 & 7) == 0 && ((((uintptr_t)p.C2) & 15) == 0)), cnt, v, nt);
       return;
     }
 #pragma unroll
@@ -331,7 +335,7 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
   for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
   if (p.resid) {
     const long ro = (long)zhi * p.sR_hi + (long)zlo * p.sR_lo + (long)m * p.ldr + n;
-    if (p.resid_f32) {
+    if (!FAST && p.resid_f32) {
       const float* r = reinterpret_cast<const float*>(p.resid) + ro;
       if (cnt == 8 && ((((uintptr_t)r) & 15) == 0)) {
         const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
@@ -343,12 +347,12 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
     } else {
       float rr[8];
       load8_bf16(reinterpret_cast<const bf16_t*>(p.resid) + ro,
-                 vec && (p.ldr & 7) == 0 && ((((uintptr_t)p.resid) & 15) == 0) && (((p.sR_hi | p.sR_lo) & 7) == 0), cnt, rr);
+                 FAST ? true : (vec && (p.ldr & 7) == 0 && ((((uintptr_t)p.resid) & 15) == 0) && (((p.sR_hi | p.sR_lo) & 7) == 0)), cnt, rr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rr[e];
     }
   }
-  if (p.c_f32) {
+  if (!FAST && p.c_f32) {
     float* C = reinterpret_cast<float*>(p.C) + co;
     if (cnt == 8 && ((((uintptr_t)C) & 15) == 0)) {
       if (p.accumulate) {
@@ -368,7 +372,7 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
 
 // BM_ = 128: 2x2 wavefronts of 64x64 (acc 4x4 MFMA tiles).  BM_ = 64: 1x4 wavefronts of 64x32 (acc 4x2) — twice
 // as many workgroups for GEMMs whose output has too few 128x128 tiles to fill 256 CUs (N = 512 projections).
-template <bool A_KS, bool B_KS, int BM_>
+template <bool A_KS, bool B_KS, int BM_, bool FAST = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p, const int xcd_swizzle) {
   constexpr int NJ = BM_ == 128 ? 4 : 2;  // n-tiles per wave
   __shared__ __attribute__((aligned(16))) char smem[2 * BM * ROW_BYTES];  // A tile (<=128 rows) + B tile ; reused as fp32 C tile
@@ -510,17 +514,17 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
     }
     __syncthreads();
     if (m0 + half * 64 < p.M) {
-#pragma unroll
+#pragma unroll 1  // (a real loop: four inlined copies of the epilogue were most of the kernel's code)
       for (int pass = 0; pass < 4; ++pass) {
         const int rl = pass * 16 + (tid >> 4);
         const int m = m0 + half * 64 + rl;
         const int n = n0 + (tid & 15) * 8;
-        if (m < p.M && n < p.N) {
+        if (m < p.M && (FAST || n < p.N)) {
           float v[8];
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
+          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
         }
       }
     }
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
 // 16-byte slot l&7, so the XOR swizzle is applied to the SOURCE address (lane fetches chunk slot ^ (r&7) ^ ((r>>4)&7)).
 // Rows past M / N are clamped to the last valid row (their outputs are never stored).  Requires K % 64 == 0, leading
 // dimensions % 8 == 0 and 16-byte aligned bases (checked on the host; other launches use gemm_bf16_kernel).
-template <int BM_, int NST>
+template <int BM_, int NST, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p, const int xcd_swizzle) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];  // the ONLY LDS object (ring, then the fp32 C tile)
   constexpr int NJ = BM_ == 128 ? 4 : 2;
@@ -669,17 +673,17 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
     }
     __syncthreads();
     if (m0 + half * 64 < p.M) {
-#pragma unroll
+#pragma unroll 1  // (a real loop: four inlined copies of the epilogue were most of the kernel's code)
       for (int pass = 0; pass < 4; ++pass) {
         const int rl = pass * 16 + (tid >> 4);
         const int m = m0 + half * 64 + rl;
         const int n = n0 + (tid & 15) * 8;
-        if (m < p.M && n < p.N) {
+        if (m < p.M && (FAST || n < p.N)) {
           float v[8];
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
+          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
         }
       }
     }
@@ -1225,13 +1229,27 @@ extern "C" int ea_set_gemm_glds(int stages) {
   g_gemm_glds = stages;
   return old;
 }
+// every operand of the epilogue whole and vector-accessible: the lean instantiation (see epilogue_chunk<FAST>)
+static int g_fast_epi = [] { const char* e = getenv("EA_GEMM_FAST_EPI"); return e ? atoi(e) : 1; }();  // (diagnostic A/B switch)
+static bool fast_epilogue_ok(const EaGemmParams& q) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return g_fast_epi && !q.c_f32 && q.splitk == 1 && !q.resid_f32 && q.N % 128 == 0 && (q.ldc & 7) == 0 && al(q.C) &&
+         ((q.sC_hi | q.sC_lo) & 7) == 0 && (!q.bias || al(q.bias)) &&
+         (!q.aux || ((q.ldaux & 7) == 0 && al(q.aux) && ((q.sX_hi | q.sX_lo) & 7) == 0)) &&
+         (!q.resid || ((q.ldr & 7) == 0 && al(q.resid) && ((q.sR_hi | q.sR_lo) & 7) == 0)) &&
+         (!q.C2 || ((q.ldc2 & 7) == 0 && al(q.C2))) &&
+         (!q.q_u || ((q.ld_q & 7) == 0 && al(q.q_u) && al(q.q_v) && al(q.pos_u) && al(q.pos_v)));
+}
 template <int BM_, int NST>
 static bool launch_glds(dim3 grid, hipStream_t stream, const EaGemmParams& q, int sw) {
   constexpr int bytes = NST * (BM_ + BN) * ROW_BYTES;
   static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM_, NST>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM_, NST, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
   if (!attr_ok) return false;
-  hipLaunchKernelGGL((gemm_glds_kernel<BM_, NST>), grid, dim3(256), bytes, stream, q, sw);
+  if (fast_epilogue_ok(q)) hipLaunchKernelGGL((gemm_glds_kernel<BM_, NST, true>), grid, dim3(256), bytes, stream, q, sw);
+  else hipLaunchKernelGGL((gemm_glds_kernel<BM_, NST>), grid, dim3(256), bytes, stream, q, sw);
   return true;
 }
 static bool glds_eligible(const EaGemmParams& q) {
@@ -1244,6 +1262,11 @@ static void launch_gemm(dim3 grid, bool bm64, hipStream_t stream, const EaGemmPa
   // the remap helps when several n-tiles share a row block and the grid spans many row blocks (not for batched / split launches,
   // whose z index already separates the operands)
   const int sw = ((g_xcd_swizzle & 2) && grid.x <= 16 && (long)grid.x * grid.y * grid.z >= 64 ? 1 : 0) | nt_flag(q);
+  if (!A_KS && !B_KS && fast_epilogue_ok(q)) {  // (the k-strided launches of the hot path are fp32 weight gradients: never FAST)
+    if (bm64) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 64, true>), grid, dim3(256), 0, stream, q, sw);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 128, true>), grid, dim3(256), 0, stream, q, sw);
+    return;
+  }
   if (bm64) hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 64>), grid, dim3(256), 0, stream, q, sw);
   else hipLaunchKernelGGL((gemm_bf16_kernel<A_KS, B_KS, 128>), grid, dim3(256), 0, stream, q, sw);
 }
