@@ -105,7 +105,7 @@ __device__ __forceinline__ float ea_keep(uint64_t seed, uint64_t idx, uint32_t t
 // word does not wrap, so a chunk costs 1 + 16 quarter-rate multiplies instead of 32 and no 64-bit additions
 __device__ __forceinline__ void ea_keep8(uint64_t seed, uint64_t idx0, uint32_t thr, float inv_keep, float (&k)[8]) {
   const uint32_t lo = (uint32_t)idx0;
-  if (lo > 0xFFFFFFF7u) {  // the low word wraps inside the chunk: element-wise
+  if (__builtin_expect(lo > 0xFFFFFFF7u, 0)) {  // the low word wraps inside the chunk: element-wise (laid out of line)
 #pragma unroll
     for (int e = 0; e < 8; ++e) k[e] = ea_keep(seed, idx0 + (uint64_t)e, thr, inv_keep);
     return;

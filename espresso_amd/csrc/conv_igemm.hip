@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const ConvGatherArg
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wcol = (wave & 1) * (BN_ / 2);
-  const long M = (long)a.RB * a.RT * a.RF;
-  const long m0 = (long)blockIdx.x * BM_;
+  const uint32_t M = (uint32_t)a.RB * a.RT * a.RF;  // (< 2^31: checked by the launcher — 32-bit divisions below)
+  const uint32_t m0 = blockIdx.x * BM_;
   const int cpt = a.SC / BK;  // 64-channel chunks per tap
   const int nk = a.ntaps * cpt;
 
@@ -66,12 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const ConvGatherArg
   for (int i = 0; i < NA; ++i) {
     const int r = (wave + 4 * i) * 8 + (lane >> 3);
     cs[i] = (lane & 7) ^ (r & 7) ^ ((r >> 4) & 7);
-    const long p = m0 + r;
+    const uint32_t p = m0 + r;
     if (p < M) {
-      const int rf = (int)(p % a.RF);
-      const long q = p / a.RF;
-      const int rt = (int)(q % a.RT);
-      rowb[i] = (int)(q / a.RT) * a.ST;
+      const uint32_t q = p / (uint32_t)a.RF, b = q / (uint32_t)a.RT;
+      const int rf = (int)(p - q * a.RF), rt = (int)(q - b * a.RT);
+      rowb[i] = (int)b * a.ST;
       rowt[i] = rt * a.at;
       rowf[i] = rf * a.af;
     } else {
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const ConvGatherArg
     bias8[e] = a.bias ? a.bias[cg * 8 + e] : 0.f;
     s8[e] = q8[e] = 0.f;
   }
-#pragma unroll
+#pragma unroll 1  // (real loops: eight unrolled copies of the row arithmetic were most of this kernel's code)
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
     if (wm == half) {
@@ -165,16 +164,14 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const ConvGatherArg
           for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * BN_ + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll 1
     for (int pass = 0; pass < 64 / RL; ++pass) {
       const int rl = pass * RL + rlane;
-      const long p = m0 + half * 64 + rl;
+      const uint32_t p = m0 + half * 64 + rl;
       if (p < M) {
-        const int rf = (int)(p % a.RF);
-        const long q = p / a.RF;
-        const int rt = (int)(q % a.RT);
-        const long b = q / a.RT;
-        const long orow = (b * a.OT + (long)rt * a.ot_mul + a.ot_add) * a.OF + (long)rf * a.of_mul + a.of_add;
+        const uint32_t q = p / (uint32_t)a.RF, b = q / (uint32_t)a.RT;
+        const int rf = (int)(p - q * a.RF), rt = (int)(q - b * a.RT);
+        const long orow = ((long)b * a.OT + (long)rt * a.ot_mul + a.ot_add) * a.OF + (long)rf * a.of_mul + a.of_add;
         const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN_ + cg * 8);
         const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN_ + cg * 8 + 4);
         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -231,6 +228,7 @@ int launch_gather(const ConvGatherArgs& a, hipStream_t stream) {
   if (!attr_ok) return -1;
   const long M = (long)a.RB * a.RT * a.RF;
   if (M <= 0) return 0;
+  if (M >= (1L << 31) - 128) return -1;  // the kernel's row arithmetic is 32-bit
   hipLaunchKernelGGL((conv_gather_kernel<BN_>), dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, stream, a);
   return EA_CHECK_LAUNCH();
 }
@@ -306,12 +304,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
     for (int i = 0; i < 2; ++i) {
       const long p = (chunk0 + ch) * 64 + rr[i];
       rowp[i] = p;
-      if (p < M) {
-        const int rf = (int)(p % a.RF);
-        const long q = p / a.RF;
-        rowb[i] = (int)(q / a.RT) * a.ST;
-        rowt[i] = (int)(q % a.RT) * a.at;
-        rowf[i] = rf * a.af;
+      if (p < M) {  // (M < 2^31, checked by the launcher: 32-bit divisions — the 64-bit ones were a third of this kernel's code)
+        const uint32_t q = (uint32_t)p / (uint32_t)a.RF, b = q / (uint32_t)a.RT;
+        rowb[i] = (int)b * a.ST;
+        rowt[i] = (int)(q - b * a.RT) * a.at;
+        rowf[i] = (int)((uint32_t)p - q * a.RF) * a.af;
       } else {
         rowb[i] = -1;
         rowt[i] = rowf[i] = 0;
@@ -565,6 +562,7 @@ static int conv3x3_wgrad_impl(const void* X, const void* dZ, float* dW, void* wo
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) { a.bt[ky * 3 + kx] = ky - 1; a.bf[ky * 3 + kx] = kx - 1; }
   const long M = (long)B * To * Fo;
+  if (M >= (1L << 31) - 128) return -2;  // the kernel decodes positions with 32-bit divisions
   const int nsplit = wgrad_split(M, Cin, Cout);
   const long chunks = (M + 63) / 64;
   a.chunks_per_wg = (int)((chunks + nsplit - 1) / nsplit);

@@ -25,6 +25,27 @@
 #include "espresso_amd.h"
 #include "gemm_common.h"
 
+// Development probe (tools/probes/gemm_timing.hip compiles this file with -DEA_GEMM_TIMING): thread 0 of every workgroup stamps the
+// 100 MHz device clock at entry / first tile in LDS / end of the k loop / end of the epilogue.  Compiled out of the library.
+#ifdef EA_GEMM_TIMING
+__device__ unsigned long long* g_ea_timing = nullptr;  // [workgroup][8]
+__device__ __forceinline__ void ea_stamp(int slot) {
+  if (threadIdx.x == 0 && g_ea_timing) {
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    g_ea_timing[wg * 8 + slot] = wall_clock64();
+    if (slot == 0) {
+      uint32_t hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_ea_timing[wg * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+}
+#define EA_STAMP(slot) ea_stamp(slot)
+#else
+#define EA_STAMP(slot)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -205,6 +226,14 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* q, bool vec, int cnt, f
     for (int e = 0; e < 8; ++e) o[e] = e < cnt ? bf2f(q[e]) : 0.f;
   }
 }
+__device__ __forceinline__ void unpack8_bf16(const uint4& u, float (&o)[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[2 * e] = __uint_as_float(w[e] << 16);
+    o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+}
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store8_bf16(bf16_t* q, bool vec, int cnt, const float (&v)[8], bool nt = false) {
   if (vec) {
@@ -268,7 +297,10 @@ __device__ __forceinline__ void load_pos8(const EaGemmParams& p, int n, float (&
 template <bool FAST = false>
 __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int ks_id, int zhi, int zlo, long coff, int m,
                                                int n, float (&v)[8], const float (&bias8)[8], const float (&posu8)[8],
-                                               const float (&posv8)[8], bool vec_ok, bool nt = false) {
+                                               const float (&posv8)[8], bool vec_ok, bool nt = false, int pre_kind = 0,
+                                               uint4 pre = uint4{0, 0, 0, 0}) {
+  // pre_kind (FAST only): 1 = `pre` holds this chunk's 8 residual values, 2 = its 8 auxiliary values — fetched by the kernel for
+  // all four passes at once before the accumulators go through LDS, instead of one dependent round trip per pass in here
   const int cnt = FAST ? 8 : min(8, p.N - n);
   const bool vec = FAST ? true : (vec_ok && cnt == 8);
   const bool has_drop = p.drop_thr != 0;
@@ -303,33 +335,34 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
     return;
   }
   float keep8[8];
-  if (has_drop) ea_keep8(p.drop_seed, didx, p.drop_thr, p.drop_scale, keep8);
+  if (has_drop) {
+    ea_keep8(p.drop_seed, didx, p.drop_thr, p.drop_scale, keep8);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) keep8[e] = 1.f;  // (x * 1.0f is exact: one uniform branch here instead of one per element below)
+  }
   if (p.aux) {
     float zz[8];
+    if (FAST && pre_kind == 2) unpack8_bf16(pre, zz);
+    else
     load8_bf16(reinterpret_cast<const bf16_t*>(p.aux) + (long)zhi * p.sX_hi + (long)zlo * p.sX_lo + (long)m * p.ldaux + n,
                FAST ? true : (vec && (p.ldaux & 7) == 0 && ((((uintptr_t)p.aux) & 15) == 0) && (((p.sX_hi | p.sX_lo) & 7) == 0)), cnt, zz);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (has_drop) v[e] *= keep8[e];
-      v[e] *= apply_dact(zz[e], p.act);
-    }
+    for (int e = 0; e < 8; ++e) v[e] *= keep8[e];
+    mul_dact8(v, zz, p.act);
   } else {
     if (p.C2) {
       store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v, nt);
+      apply_act8(v, p.act);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = apply_act(v[e], p.act);
-        if (has_drop) v[e] *= keep8[e];
-      }
+      for (int e = 0; e < 8; ++e) v[e] *= keep8[e];
       store8_bf16(reinterpret_cast<bf16_t*>(p.C2) + coff + (long)m * p.ldc2 + n,
                   FAST ? true : (vec && (p.ldc2 & 7) == 0 && ((((uintptr_t)p.C2) & 15) == 0)), cnt, v, nt);
       return;
     }
+    apply_act8(v, p.act);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[e] = apply_act(v[e], p.act);
-      if (has_drop) v[e] *= keep8[e];
-    }
+    for (int e = 0; e < 8; ++e) v[e] *= keep8[e];
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
@@ -346,6 +379,8 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
       }
     } else {
       float rr[8];
+      if (FAST && pre_kind == 1) unpack8_bf16(pre, rr);
+      else
       load8_bf16(reinterpret_cast<const bf16_t*>(p.resid) + ro,
                  FAST ? true : (vec && (p.ldr & 7) == 0 && ((((uintptr_t)p.resid) & 15) == 0) && (((p.sR_hi | p.sR_lo) & 7) == 0)), cnt, rr);
 #pragma unroll
@@ -378,6 +413,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
   __shared__ __attribute__((aligned(16))) char smem[2 * BM * ROW_BYTES];  // A tile (<=128 rows) + B tile ; reused as fp32 C tile
   char* sA = smem;
   char* sB = smem + BM * ROW_BYTES;
+  EA_STAMP(0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -392,15 +428,15 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
     const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
     const int xcd = lin & 7, q = total >> 3, r = total & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-    tile_z = v / gxy;
+    tile_z = FAST ? 0 : v / gxy;  // (FAST launches have gridDim.z == 1: no batch / split-K index arithmetic at all)
     const int rem = v - tile_z * gxy;
     tile_y = rem / gx;
     tile_x = rem - tile_y * gx;
   }
   const int m0 = tile_y * BM_, n0 = tile_x * BN;
-  const int z = tile_z / p.splitk;
-  const int ks_id = tile_z % p.splitk;
-  const int zhi = z / p.zdiv, zlo = z % p.zdiv;
+  const int z = FAST ? 0 : tile_z / p.splitk;
+  const int ks_id = FAST ? 0 : tile_z % p.splitk;
+  const int zhi = FAST ? 0 : z / p.zdiv, zlo = FAST ? 0 : z % p.zdiv;
 
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)zhi * p.sA_hi + (long)zlo * p.sA_lo;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long)zhi * p.sB_hi + (long)zlo * p.sB_lo;
@@ -488,9 +524,11 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
     storeA(ra);
     storeB(rb);
     __syncthreads();
+    if (kt == 0) EA_STAMP(1);
     if (kt + 1 < nk) { loadA(kbeg + (kt + 1) * BK, ra); loadB(kbeg + (kt + 1) * BK, rb); }
     compute();
   }
+  EA_STAMP(2);
 
   // ---- epilogue: accumulators -> fp32 LDS tile (64 rows at a time) -> coalesced 16/32-byte stores ----
   // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wcol + j*16 + (lane&15)]
@@ -500,9 +538,25 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
   load_bias8(p, n0 + (tid & 15) * 8, bias8);
   float posu8[8], posv8[8];
   load_pos8(p, n0 + (tid & 15) * 8, posu8, posv8);
+  // FAST: the residual (else the auxiliary) rows of the four passes are fetched here, in one round trip that overlaps the LDS
+  // bounce, and rotate through the rolled pass loop (probe tools/probes/gemm_timing.hip: the epilogue of a 64 x 128 tile took
+  // 3.0 us plain and 5.0 us with a residual — one dependent L2 / MALL round trip per pass)
+  const int pre_kind = !FAST ? 0 : p.resid ? 1 : p.aux ? 2 : 0;
+  const bf16_t* pre_base = pre_kind == 1 ? reinterpret_cast<const bf16_t*>(p.resid) : reinterpret_cast<const bf16_t*>(p.aux);
+  const long pre_ld = pre_kind == 1 ? p.ldr : p.ldaux;
 #pragma unroll
   for (int half = 0; half < BM_ / 64; ++half) {
+    uint4 pre0 = uint4{0, 0, 0, 0}, pre1 = pre0, pre2 = pre0, pre3 = pre0;
+    if (FAST && pre_kind) {
+      const bf16_t* q = pre_base + n0 + (tid & 15) * 8;
+      const int mr = m0 + half * 64 + (tid >> 4), ml = p.M - 1;
+      pre0 = *reinterpret_cast<const uint4*>(q + (long)min(mr, ml) * pre_ld);
+      pre1 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 16, ml) * pre_ld);
+      pre2 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 32, ml) * pre_ld);
+      pre3 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 48, ml) * pre_ld);
+    }
     __syncthreads();
+    if (half == 0) EA_STAMP(5);
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -513,6 +567,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
             sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
     }
     __syncthreads();
+    if (half == 0) EA_STAMP(6);
     if (m0 + half * 64 < p.M) {
 #pragma unroll 1  // (a real loop: four inlined copies of the epilogue were most of the kernel's code)
       for (int pass = 0; pass < 4; ++pass) {
@@ -524,11 +579,13 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
+          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0, pre_kind, pre0);
         }
+        pre0 = pre1; pre1 = pre2; pre2 = pre3;
       }
     }
   }
+  EA_STAMP(3);
 }
 
 // ---- direct-to-LDS variant (both operands k-contiguous) ------------------------------------------------------------
@@ -545,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
   constexpr int A_BYTES = BM_ * ROW_BYTES;
   constexpr int STAGE = A_BYTES + BN * ROW_BYTES;
   constexpr int NA = BM_ / 32, NB = BN / 32;  // glds instructions per wave and k-tile
+  EA_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = BM_ == 128 ? (wave >> 1) : 0;
@@ -558,15 +616,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
     const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
     const int xcd = lin & 7, q = total >> 3, r = total & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-    tile_z = v / gxy;
+    tile_z = FAST ? 0 : v / gxy;  // (FAST launches have gridDim.z == 1: no batch / split-K index arithmetic at all)
     const int rem = v - tile_z * gxy;
     tile_y = rem / gx;
     tile_x = rem - tile_y * gx;
   }
   const int m0 = tile_y * BM_, n0 = tile_x * BN;
-  const int z = tile_z / p.splitk;
-  const int ks_id = tile_z % p.splitk;
-  const int zhi = z / p.zdiv, zlo = z % p.zdiv;
+  const int z = FAST ? 0 : tile_z / p.splitk;
+  const int ks_id = FAST ? 0 : tile_z % p.splitk;
+  const int zhi = FAST ? 0 : z / p.zdiv, zlo = FAST ? 0 : z % p.zdiv;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)zhi * p.sA_hi + (long)zlo * p.sA_lo;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long)zhi * p.sB_hi + (long)zlo * p.sB_lo;
   const long coff = (long)zhi * p.sC_hi + (long)zlo * p.sC_lo;
@@ -632,6 +690,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // every wave's part of tile kt is in LDS; everyone is done reading tile kt-1's stage
+    if (kt == 0) EA_STAMP(1);
     if (kt + NST - 1 < nk) issue(fill, kt + NST - 1);
     const char* st = dsm + stage * STAGE;
 #pragma unroll
@@ -652,6 +711,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
     stage = stage + 1 == NST ? 0 : stage + 1;
     fill = fill + 1 == NST ? 0 : fill + 1;
   }
+  EA_STAMP(2);
 
   float* sC = reinterpret_cast<float*>(dsm);  // [64][128] fp32 = 32 KiB
   const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
@@ -659,9 +719,25 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
   load_bias8(p, n0 + (tid & 15) * 8, bias8);
   float posu8[8], posv8[8];
   load_pos8(p, n0 + (tid & 15) * 8, posu8, posv8);
+  // FAST: the residual (else the auxiliary) rows of the four passes are fetched here, in one round trip that overlaps the LDS
+  // bounce, and rotate through the rolled pass loop (probe tools/probes/gemm_timing.hip: the epilogue of a 64 x 128 tile took
+  // 3.0 us plain and 5.0 us with a residual — one dependent L2 / MALL round trip per pass)
+  const int pre_kind = !FAST ? 0 : p.resid ? 1 : p.aux ? 2 : 0;
+  const bf16_t* pre_base = pre_kind == 1 ? reinterpret_cast<const bf16_t*>(p.resid) : reinterpret_cast<const bf16_t*>(p.aux);
+  const long pre_ld = pre_kind == 1 ? p.ldr : p.ldaux;
 #pragma unroll
   for (int half = 0; half < BM_ / 64; ++half) {
+    uint4 pre0 = uint4{0, 0, 0, 0}, pre1 = pre0, pre2 = pre0, pre3 = pre0;
+    if (FAST && pre_kind) {
+      const bf16_t* q = pre_base + n0 + (tid & 15) * 8;
+      const int mr = m0 + half * 64 + (tid >> 4), ml = p.M - 1;
+      pre0 = *reinterpret_cast<const uint4*>(q + (long)min(mr, ml) * pre_ld);
+      pre1 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 16, ml) * pre_ld);
+      pre2 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 32, ml) * pre_ld);
+      pre3 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 48, ml) * pre_ld);
+    }
     __syncthreads();
+    if (half == 0) EA_STAMP(5);
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -672,6 +748,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
             sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
     }
     __syncthreads();
+    if (half == 0) EA_STAMP(6);
     if (m0 + half * 64 < p.M) {
 #pragma unroll 1  // (a real loop: four inlined copies of the epilogue were most of the kernel's code)
       for (int pass = 0; pass < 4; ++pass) {
@@ -683,11 +760,13 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
           const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0);
+          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0, pre_kind, pre0);
         }
+        pre0 = pre1; pre1 = pre2; pre2 = pre3;
       }
     }
   }
+  EA_STAMP(3);
 }
 
 // C[z][m][n] (+)= sum_s W[s][z][m][n]      (VEC: N % 4 == 0 and 16-byte aligned C rows -> float4 per thread)
@@ -1233,7 +1312,7 @@ extern "C" int ea_set_gemm_glds(int stages) {
 static int g_fast_epi = [] { const char* e = getenv("EA_GEMM_FAST_EPI"); return e ? atoi(e) : 1; }();  // (diagnostic A/B switch)
 static bool fast_epilogue_ok(const EaGemmParams& q) {
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  return g_fast_epi && !q.c_f32 && q.splitk == 1 && !q.resid_f32 && q.N % 128 == 0 && (q.ldc & 7) == 0 && al(q.C) &&
+  return g_fast_epi && !q.c_f32 && q.splitk == 1 && q.batch == 1 && !q.resid_f32 && q.N % 128 == 0 && (q.ldc & 7) == 0 && al(q.C) &&
          ((q.sC_hi | q.sC_lo) & 7) == 0 && (!q.bias || al(q.bias)) &&
          (!q.aux || ((q.ldaux & 7) == 0 && al(q.aux) && ((q.sX_hi | q.sX_lo) & 7) == 0)) &&
          (!q.resid || ((q.ldr & 7) == 0 && al(q.resid) && ((q.sR_hi | q.sR_lo) & 7) == 0)) &&

@@ -27,5 +27,25 @@ __device__ __forceinline__ float apply_dact(float z, int act) {
   if (act == EA_ACT_SILU) return dsilu_f(z);
   return 1.f;
 }
+// the same on a chunk of eight, with ONE uniform branch on the activation (the per-element form above compiled to a scalar
+// branch per element inside the GEMM epilogue's unrolled loops: ~25 taken branches per 8-column chunk)
+__device__ __forceinline__ void apply_act8(float (&v)[8], int act) {
+  if (act == EA_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+  } else if (act == EA_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+}
+__device__ __forceinline__ void mul_dact8(float (&v)[8], const float (&z)[8], int act) {  // v *= act'(z)
+  if (act == EA_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= dsilu_f(z[e]);
+  } else if (act == EA_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= z[e] > 0.f ? 1.f : 0.f;
+  }
+}
 
 }  // namespace

@@ -1,0 +1,110 @@
+// Development probe, not part of the library: where does a GEMM workgroup spend its life?  Compiles espresso_amd/csrc/gemm.hip
+// with -DEA_GEMM_TIMING (thread 0 of every workgroup stamps the 100 MHz device clock at entry / first tile in LDS / end of the
+// k loop / end of the epilogue, plus its XCC and CU) and prints, per hot shape of the Conformer step:
+//   kernel span, workgroup lifetime, the three phases, how many workgroups start late (a second "round"), workgroups per CU.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DEA_GEMM_TIMING -Iespresso_amd/csrc -Iinclude tools/probes/gemm_timing.hip -o tools/probes/gemm_timing
+#include "../../espresso_amd/csrc/gemm.hip"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static void* dalloc(size_t bytes, int fill) {
+  void* p;
+  CK(hipMalloc(&p, bytes));
+  CK(hipMemset(p, fill, bytes));
+  return p;
+}
+
+struct Case { const char* name; int N, K; int epi; int variant, glds; };  // epi: 0 plain, 1 bias, 2 W1 (bias+silu+drop+2 outputs), 3 W2 (bias+drop+resid), 4 W2 dgrad (drop * silu'(aux))
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 6240;
+  const int MAXN = 5056, MAXK = 2560;
+  // bf16 0x3c00-ish small values: memset byte 0x3c gives 0x3c3c = ~0.0115
+  void* A = dalloc((size_t)M * MAXK * 2, 0x3c);
+  void* W = dalloc((size_t)MAXN * MAXK * 2, 0x3c);
+  void* C = dalloc((size_t)M * MAXN * 2, 0);
+  void* C2 = dalloc((size_t)M * MAXN * 2, 0);
+  void* R = dalloc((size_t)M * MAXN * 2, 0x3c);
+  float* bias = (float*)dalloc((size_t)MAXN * 4, 0);
+  const size_t max_wg = 1 << 16;
+  unsigned long long* tbuf = (unsigned long long*)dalloc(max_wg * 8 * 8, 0);
+  std::vector<unsigned long long> host(max_wg * 8);
+  const Case cases[] = {
+      {"W1 fwd 2048x512 bias+silu+drop+2out", 2048, 512, 2, 0, 1},
+      {"W1 shape plain 2048x512", 2048, 512, 0, 0, 1},
+      {"W2 dgrad 2048x512 drop*silu'(aux)", 2048, 512, 4, 0, 1},
+      {"qkv 1536x512 bias", 1536, 512, 1, 0, 1},
+      {"pw1 1024x512 plain", 1024, 512, 0, 0, 1},
+      {"W2 fwd 512x2048 bias+drop+resid", 512, 2048, 3, 0, 1},
+      {"W1 dgrad 512x2048 plain", 512, 2048, 0, 0, 1},
+      {"out_proj 512x512 plain", 512, 512, 0, 0, 1},
+      {"W1 shape plain 2048x512, 128-row tile", 2048, 512, 0, 1, 1},
+      {"W1 dgrad 512x2048 plain, ring of 2", 512, 2048, 0, 0, 2},
+  };
+  for (const Case& c : cases) {
+    EaGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.B = W; p.C = C;
+    p.M = M; p.N = c.N; p.K = c.K; p.batch = 1; p.zdiv = 1; p.splitk = 1;
+    p.lda = c.K; p.ldb = c.K; p.ldc = c.N;
+    p.alpha = 1.f; p.out_scale = 1.f;
+    if (c.epi >= 1) p.bias = bias;
+    if (c.epi == 2) { p.act = 2; p.C2 = C2; p.ldc2 = c.N; p.drop_seed = 7; p.drop_thr = 429496729u; p.drop_scale = 1.f / 0.9f; }
+    if (c.epi == 4) { p.act = 2; p.aux = R; p.ldaux = c.N; p.drop_seed = 7; p.drop_thr = 429496729u; p.drop_scale = 1.f / 0.9f; }
+    if (c.epi == 3) { p.resid = R; p.ldr = c.N; p.out_scale = 0.5f; p.drop_seed = 9; p.drop_thr = 429496729u; p.drop_scale = 1.f / 0.9f; }
+    ea_set_gemm_variant(c.variant);
+    ea_set_gemm_glds(c.glds);
+    unsigned long long* null_ptr = nullptr;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_ea_timing), &null_ptr, sizeof(null_ptr)));
+    for (int i = 0; i < 5; ++i) if (ea_gemm_bf16(&p, 0) != 0) { printf("launch failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, ev1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&ev1));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) ea_gemm_bf16(&p, 0);
+    CK(hipEventRecord(ev1, 0));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, ev1));
+    CK(hipMemset(tbuf, 0, max_wg * 64));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_ea_timing), &tbuf, sizeof(tbuf)));
+    for (int i = 0; i < 3; ++i) ea_gemm_bf16(&p, 0);  // the stamps of the last (hot) launch survive
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(host.data(), tbuf, max_wg * 64, hipMemcpyDeviceToHost));
+    size_t nwg = 0;
+    while (nwg < max_wg && host[nwg * 8 + 3]) ++nwg;
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (size_t w = 0; w < nwg; ++w) { t_min = std::min(t_min, host[w * 8]); t_max = std::max(t_max, host[w * 8 + 3]); }
+    double life = 0, ph1 = 0, ph2 = 0, ph3 = 0, e1 = 0, e2 = 0, e3 = 0;
+    std::vector<double> starts, lifes;
+    std::map<unsigned long long, int> per_cu;
+    for (size_t w = 0; w < nwg; ++w) {
+      const unsigned long long* t = &host[w * 8];
+      life += (t[3] - t[0]); ph1 += (t[1] - t[0]); ph2 += (t[2] - t[1]); ph3 += (t[3] - t[2]);
+      e1 += (t[5] - t[2]); e2 += (t[6] - t[5]); e3 += (t[3] - t[6]);
+      starts.push_back((t[0] - t_min) * 0.01);
+      lifes.push_back((t[3] - t[0]) * 0.01);
+      // HW_ID (gfx9): [3:0] wave, [5:4] simd, [7:6] pipe, [11:8] cu, [12] sh, [15:13] se ; XCC_ID [3:0]
+      const unsigned hw = (unsigned)t[4], xcc = (unsigned)(t[4] >> 32) & 15;
+      per_cu[((unsigned long long)xcc << 16) | (hw & 0xff00)]++;
+    }
+    std::sort(starts.begin(), starts.end());
+    std::sort(lifes.begin(), lifes.end());
+    int cu_max = 0;
+    for (auto& kv : per_cu) cu_max = std::max(cu_max, kv.second);
+    const double span = (t_max - t_min) * 0.01;
+    int late = 0;
+    for (double s : starts) if (s > 0.25 * span) ++late;
+    printf("%-44s %5.1f us/launch | stamped span %5.1f us, %4zu WGs on %3zu CUs (max %d per CU) | life mean %5.2f p50 %5.2f p95 %5.2f us = load+first tile %5.2f "
+           "+ k loop %5.2f + epilogue %5.2f (to barrier %4.2f, acc->LDS %4.2f, passes %4.2f) | starts: p50 %5.2f p90 %5.2f max %5.2f us, %d WGs start after 25%% of the span\n",
+           c.name, ms * 1e3 / 20, span, nwg, per_cu.size(), cu_max, life * 0.01 / nwg, lifes[nwg / 2], lifes[nwg * 95 / 100], ph1 * 0.01 / nwg,
+           ph2 * 0.01 / nwg, ph3 * 0.01 / nwg, e1 * 0.01 / nwg, e2 * 0.01 / nwg, e3 * 0.01 / nwg, starts[nwg / 2], starts[nwg * 9 / 10], starts[nwg - 1], late);
+  }
+  return 0;
+}
