@@ -407,6 +407,70 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
 
 // BM_ = 128: 2x2 wavefronts of 64x64 (acc 4x4 MFMA tiles).  BM_ = 64: 1x4 wavefronts of 64x32 (acc 4x2) — twice
 // as many workgroups for GEMMs whose output has too few 128x128 tiles to fill 256 CUs (N = 512 projections).
+// ---- tile epilogue shared by the GEMM kernels: accumulators -> fp32 LDS tile (64 rows at a time) -> coalesced 16-byte stores ----
+// acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wcol + j*16 + (lane&15)]; sC = 32 KiB of LDS no wave still reads
+// operands from once it has passed the first barrier in here.
+template <int BM_, bool FAST>
+__device__ __forceinline__ void gemm_tile_epilogue(const EaGemmParams& p, const f32x4_t (&acc)[4][BM_ == 128 ? 4 : 2], float* sC, int m0,
+                                                   int n0, int z, int ks_id, int zhi, int zlo, long coff, int xcd_swizzle) {
+  constexpr int NJ = BM_ == 128 ? 4 : 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = BM_ == 128 ? (wave >> 1) : 0;
+  const int wcol = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
+  const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
+  float bias8[8];
+  load_bias8(p, n0 + (tid & 15) * 8, bias8);
+  float posu8[8], posv8[8];
+  load_pos8(p, n0 + (tid & 15) * 8, posu8, posv8);
+  // FAST: the residual (else the auxiliary) rows of the four passes are fetched here, in one round trip that overlaps the LDS
+  // bounce, and rotate through the rolled pass loop (probe tools/probes/gemm_timing.hip: the epilogue of a 64 x 128 tile took
+  // 3.0 us plain and 5.0 us with a residual — one dependent L2 / MALL round trip per pass)
+  const int pre_kind = !FAST ? 0 : p.resid ? 1 : p.aux ? 2 : 0;
+  const bf16_t* pre_base = pre_kind == 1 ? reinterpret_cast<const bf16_t*>(p.resid) : reinterpret_cast<const bf16_t*>(p.aux);
+  const long pre_ld = pre_kind == 1 ? p.ldr : p.ldaux;
+#pragma unroll
+  for (int half = 0; half < BM_ / 64; ++half) {
+    uint4 pre0 = uint4{0, 0, 0, 0}, pre1 = pre0, pre2 = pre0, pre3 = pre0;
+    if (FAST && pre_kind) {
+      const bf16_t* q = pre_base + n0 + (tid & 15) * 8;
+      const int mr = m0 + half * 64 + (tid >> 4), ml = p.M - 1;
+      pre0 = *reinterpret_cast<const uint4*>(q + (long)min(mr, ml) * pre_ld);
+      pre1 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 16, ml) * pre_ld);
+      pre2 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 32, ml) * pre_ld);
+      pre3 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 48, ml) * pre_ld);
+    }
+    __syncthreads();
+    if (half == 0) EA_STAMP(5);
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (half == 0) EA_STAMP(6);
+    if (m0 + half * 64 < p.M) {
+#pragma unroll 1  // (a real loop: four inlined copies of the epilogue were most of the kernel's code)
+      for (int pass = 0; pass < 4; ++pass) {
+        const int rl = pass * 16 + (tid >> 4);
+        const int m = m0 + half * 64 + rl;
+        const int n = n0 + (tid & 15) * 8;
+        if (m < p.M && (FAST || n < p.N)) {
+          float v[8];
+          const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
+          const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0, pre_kind, pre0);
+        }
+        pre0 = pre1; pre1 = pre2; pre2 = pre3;
+      }
+    }
+  }
+}
+
 template <bool A_KS, bool B_KS, int BM_, bool FAST = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p, const int xcd_swizzle) {
   constexpr int NJ = BM_ == 128 ? 4 : 2;  // n-tiles per wave
@@ -533,58 +597,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(const EaGemmParams p,
   // ---- epilogue: accumulators -> fp32 LDS tile (64 rows at a time) -> coalesced 16/32-byte stores ----
   // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wcol + j*16 + (lane&15)]
   float* sC = reinterpret_cast<float*>(smem);  // [64][128] fp32 = 32 KiB
-  const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
-  float bias8[8];
-  load_bias8(p, n0 + (tid & 15) * 8, bias8);
-  float posu8[8], posv8[8];
-  load_pos8(p, n0 + (tid & 15) * 8, posu8, posv8);
-  // FAST: the residual (else the auxiliary) rows of the four passes are fetched here, in one round trip that overlaps the LDS
-  // bounce, and rotate through the rolled pass loop (probe tools/probes/gemm_timing.hip: the epilogue of a 64 x 128 tile took
-  // 3.0 us plain and 5.0 us with a residual — one dependent L2 / MALL round trip per pass)
-  const int pre_kind = !FAST ? 0 : p.resid ? 1 : p.aux ? 2 : 0;
-  const bf16_t* pre_base = pre_kind == 1 ? reinterpret_cast<const bf16_t*>(p.resid) : reinterpret_cast<const bf16_t*>(p.aux);
-  const long pre_ld = pre_kind == 1 ? p.ldr : p.ldaux;
-#pragma unroll
-  for (int half = 0; half < BM_ / 64; ++half) {
-    uint4 pre0 = uint4{0, 0, 0, 0}, pre1 = pre0, pre2 = pre0, pre3 = pre0;
-    if (FAST && pre_kind) {
-      const bf16_t* q = pre_base + n0 + (tid & 15) * 8;
-      const int mr = m0 + half * 64 + (tid >> 4), ml = p.M - 1;
-      pre0 = *reinterpret_cast<const uint4*>(q + (long)min(mr, ml) * pre_ld);
-      pre1 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 16, ml) * pre_ld);
-      pre2 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 32, ml) * pre_ld);
-      pre3 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 48, ml) * pre_ld);
-    }
-    __syncthreads();
-    if (half == 0) EA_STAMP(5);
-    if (wm == half) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (half == 0) EA_STAMP(6);
-    if (m0 + half * 64 < p.M) {
-#pragma unroll 1  // (a real loop: four inlined copies of the epilogue were most of the kernel's code)
-      for (int pass = 0; pass < 4; ++pass) {
-        const int rl = pass * 16 + (tid >> 4);
-        const int m = m0 + half * 64 + rl;
-        const int n = n0 + (tid & 15) * 8;
-        if (m < p.M && (FAST || n < p.N)) {
-          float v[8];
-          const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
-          const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
-          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0, pre_kind, pre0);
-        }
-        pre0 = pre1; pre1 = pre2; pre2 = pre3;
-      }
-    }
-  }
+  gemm_tile_epilogue<BM_, FAST>(p, acc, sC, m0, n0, z, ks_id, zhi, zlo, coff, xcd_swizzle);
   EA_STAMP(3);
 }
 
@@ -714,58 +727,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const EaGemmParams p,
   EA_STAMP(2);
 
   float* sC = reinterpret_cast<float*>(dsm);  // [64][128] fp32 = 32 KiB
-  const bool vec_ok = (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 && ((p.sC_hi | p.sC_lo) & 7) == 0;
-  float bias8[8];
-  load_bias8(p, n0 + (tid & 15) * 8, bias8);
-  float posu8[8], posv8[8];
-  load_pos8(p, n0 + (tid & 15) * 8, posu8, posv8);
-  // FAST: the residual (else the auxiliary) rows of the four passes are fetched here, in one round trip that overlaps the LDS
-  // bounce, and rotate through the rolled pass loop (probe tools/probes/gemm_timing.hip: the epilogue of a 64 x 128 tile took
-  // 3.0 us plain and 5.0 us with a residual — one dependent L2 / MALL round trip per pass)
-  const int pre_kind = !FAST ? 0 : p.resid ? 1 : p.aux ? 2 : 0;
-  const bf16_t* pre_base = pre_kind == 1 ? reinterpret_cast<const bf16_t*>(p.resid) : reinterpret_cast<const bf16_t*>(p.aux);
-  const long pre_ld = pre_kind == 1 ? p.ldr : p.ldaux;
-#pragma unroll
-  for (int half = 0; half < BM_ / 64; ++half) {
-    uint4 pre0 = uint4{0, 0, 0, 0}, pre1 = pre0, pre2 = pre0, pre3 = pre0;
-    if (FAST && pre_kind) {
-      const bf16_t* q = pre_base + n0 + (tid & 15) * 8;
-      const int mr = m0 + half * 64 + (tid >> 4), ml = p.M - 1;
-      pre0 = *reinterpret_cast<const uint4*>(q + (long)min(mr, ml) * pre_ld);
-      pre1 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 16, ml) * pre_ld);
-      pre2 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 32, ml) * pre_ld);
-      pre3 = *reinterpret_cast<const uint4*>(q + (long)min(mr + 48, ml) * pre_ld);
-    }
-    __syncthreads();
-    if (half == 0) EA_STAMP(5);
-    if (wm == half) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            sC[(i * 16 + (lane >> 4) * 4 + r) * BN + wcol + j * 16 + (lane & 15)] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (half == 0) EA_STAMP(6);
-    if (m0 + half * 64 < p.M) {
-#pragma unroll 1  // (a real loop: four inlined copies of the epilogue were most of the kernel's code)
-      for (int pass = 0; pass < 4; ++pass) {
-        const int rl = pass * 16 + (tid >> 4);
-        const int m = m0 + half * 64 + rl;
-        const int n = n0 + (tid & 15) * 8;
-        if (m < p.M && (FAST || n < p.N)) {
-          float v[8];
-          const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8);
-          const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * BN + (tid & 15) * 8 + 4);
-          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk<FAST>(p, z, ks_id, zhi, zlo, coff, m, n, v, bias8, posu8, posv8, vec_ok, (xcd_swizzle & 2) != 0, pre_kind, pre0);
-        }
-        pre0 = pre1; pre1 = pre2; pre2 = pre3;
-      }
-    }
-  }
+  gemm_tile_epilogue<BM_, FAST>(p, acc, sC, m0, n0, z, ks_id, zhi, zlo, coff, xcd_swizzle);
   EA_STAMP(3);
 }
 

@@ -38,14 +38,13 @@ int main(int argc, char** argv) {
   const Case cases[] = {
       {"W1 fwd 2048x512 bias+silu+drop+2out", 2048, 512, 2, 0, 1},
       {"W1 shape plain 2048x512", 2048, 512, 0, 0, 1},
+      {"  .. ring kernel, 3 stages", 2048, 512, 0, 2, 3},
       {"W2 dgrad 2048x512 drop*silu'(aux)", 2048, 512, 4, 0, 1},
       {"qkv 1536x512 bias", 1536, 512, 1, 0, 1},
       {"pw1 1024x512 plain", 1024, 512, 0, 0, 1},
       {"W2 fwd 512x2048 bias+drop+resid", 512, 2048, 3, 0, 1},
       {"W1 dgrad 512x2048 plain", 512, 2048, 0, 0, 1},
       {"out_proj 512x512 plain", 512, 512, 0, 0, 1},
-      {"W1 shape plain 2048x512, 128-row tile", 2048, 512, 0, 1, 1},
-      {"W1 dgrad 512x2048 plain, ring of 2", 512, 2048, 0, 0, 2},
   };
   for (const Case& c : cases) {
     EaGemmParams p;
