@@ -208,6 +208,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   const int r1 = min(M, r0 + rows_per_block);
   const float inv_c = __builtin_amdgcn_rcpf((float)C);
   for (int row = r0 + wave; row < r1; row += 4) {
+    // every load of the row is requested up front — the residual-path gradient too, which used to be fetched only after the two
+    // wave reductions (a second exposed round trip per row), and the padding flag last (its first use is a branch: a wait)
+    uint4 ux_[MAXC8], ud_[MAXC8], ua_[MAXC8];
+#pragma unroll
+    for (int i = 0; i < MAXC8; ++i) {
+      const int ch = lane + 64 * i;
+      ux_[i] = ud_[i] = ua_[i] = uint4{0, 0, 0, 0};
+      if (ch < nch) {
+        ux_[i] = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
+        ud_[i] = *reinterpret_cast<const uint4*>(dy + (long)row * C + ch * 8);
+        if (dx_add) ua_[i] = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
+      }
+    }
     const float mean = mean_in[row], rstd = rstd_in[row];
     const bool zero = row_zero && row_zero[row];
     float xh[MAXC8][8], g[MAXC8][8];
@@ -216,8 +229,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     for (int i = 0; i < MAXC8; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
-        const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
-        const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * C + ch * 8);
+        const uint4 ux = ux_[i];
+        const uint4 ud = ud_[i];
         const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
         const uint32_t wd[4] = {ud.x, ud.y, ud.z, ud.w};
         float k8[8];
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
         if (dx_add) {
-          const uint4 ua = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
+          const uint4 ua = ua_[i];
           const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
 #pragma unroll
           for (int e = 0; e < 8; ++e)
