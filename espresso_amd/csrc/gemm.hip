@@ -352,7 +352,9 @@ __device__ __forceinline__ void epilogue_chunk(const EaGemmParams& p, int z, int
     mul_dact8(v, zz, p.act);
   } else {
     if (p.C2) {
-      store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v, nt);
+      // the pre-activation copy is only read again by the backward pass, milliseconds and gigabytes later: streamed past the caches
+      // so that it does not evict the operands and the activated copy the next GEMM reads
+      store8_bf16(reinterpret_cast<bf16_t*>(p.C) + co, vec, cnt, v, true);
       apply_act8(v, p.act);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= keep8[e];

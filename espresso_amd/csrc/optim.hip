@@ -49,8 +49,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const int cnt = (int)((n - i) < 4 ? (n - i) : 4);
     float pv[4], gv[4], mv[4], vv[4];
     if (cnt == 4) {
-      const float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
-      const float4 c = *reinterpret_cast<const float4*>(m + i), d = *reinterpret_cast<const float4*>(v + i);
+      // (non-temporal: 2.7 GB stream through once per step — master weights, both moments, the gradient — and should not push the
+      // 157 MB of bf16 weights written below, which the next forward pass reads, out of the 256 MB last-level cache)
+      const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p + i));
+      const f32x4_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(g + i));
+      const f32x4_t c = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(m + i));
+      const f32x4_t d = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(v + i));
       pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
       gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
       mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
@@ -73,10 +77,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
       }
     }
     if (cnt == 4) {
-      *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-      *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-      *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_nontemporal_store((f32x4_t){pv[0], pv[1], pv[2], pv[3]}, reinterpret_cast<f32x4_t*>(p + i));
+      __builtin_nontemporal_store((f32x4_t){mv[0], mv[1], mv[2], mv[3]}, reinterpret_cast<f32x4_t*>(m + i));
+      __builtin_nontemporal_store((f32x4_t){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f32x4_t*>(v + i));
+      if (zero_grad) __builtin_nontemporal_store((f32x4_t){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4_t*>(g + i));
       if (p_bf16) *reinterpret_cast<uint2*>(p_bf16 + i) = make_uint2(pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]));
     } else {
       for (int e = 0; e < cnt; ++e) {
