@@ -397,7 +397,7 @@ def main(argv=None):
         # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
         # command, tools/pmc_bench_traffic.sh; counters cannot be read from inside the process)
         traffic = None
-        tname = next((n for n in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
+        tname = next((n for n in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
                       if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n))), None)
         if tname:
             traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname))).get("hbm_bytes_per_launch")

@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
   if (row0 >= M) return;
   float v[RW][8], s[RW];
+  bool zr[RW];  // padding flags, requested with the rows (a load at its first use, in the store loop, is a round trip per row)
+#pragma unroll
+  for (int r = 0; r < RW; ++r) zr[r] = row_zero && row_zero[min(row0 + r, M - 1)];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int row = min(row0 + r, M - 1);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(
       if (rstd_out) rstd_out[row] = rstd;
     }
     if (!on) continue;
-    const bool zero = row_zero && row_zero[row];
+    const bool zero = zr[r];
     float o[8], k8[8];
     if (thr) ea_keep8(seed, (uint64_t)row * C + lane * 8, thr, inv_keep, k8);
 #pragma unroll
