@@ -1419,12 +1419,14 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.dy || !p.x || !p.dW) return -2;
     tiles128 += (long)((p.N + 127) / 128) * ((p.K + BN - 1) / BN);
   }
-  // Tile height: 64-row tiles when 128-row tiles would leave CUs idle or badly balanced (each tile walks the whole reduction).
-  // Measured alternative for the direct-to-LDS kernel on the training step (EA_WGRAD_BM=128: two 64 KB workgroups per CU instead of
-  // three 48 KB ones leave the main stream's kernels more of each CU): the step gains 0.19 ms (16.9 -> 16.7) while the grouped
-  // launch itself stretches from 136 to 208 us next to them — the whole-step gain is inside the box-to-box spread, the GEMM-family
-  // time per step (the roofline figure of bench.py) gets 0.9 ms worse.  Not the default.
+  // Tile height: 64-row tiles when 128-row tiles would leave CUs idle (each tile walks the whole reduction): fewer than ~1.25
+  // 128-row tiles per CU.  Round 4, same box, same minute: the Conformer layer's group (380 tiles of 128 rows) with 128-row tiles
+  // 13.79 vs 13.96 ms per step, GEMM-family time 9.0 vs 10.0 ms, live roofline 0.132 vs 0.118 (a 128-row tile sends a third less
+  // through the CU's LDS port per flop, which is what the co-running main-stream GEMMs are short of); the Transformer layer's
+  // group of the enc-dec recipe (192 tiles) 13.10 vs 12.94 ms the other way round.  (Round 3 measured the same switch at
+  // +-0.2 ms across boxes with the old forward kernels and left it off.)
   static const int bm_env = [] { const char* e = getenv("EA_WGRAD_BM"); return e ? atoi(e) : 0; }();  // (diagnostic override)
+  static const long wgrad_bm_thr = [] { const char* e = getenv("EA_WGRAD_BM_THR"); return e ? atol(e) : 320L; }();  // (128-row tiles from here)
   auto aligned_for = [&](int bm) {
     // (a ragged last tile may read the columns up to the next tile boundary when the row pitch covers them: those products only
     // reach output rows / columns >= N / K, which are never stored)
@@ -1437,7 +1439,7 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
     return true;
   };
   bool tr_ok = g_wgrad_tr != 0;
-  bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < 1024));
+  bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < wgrad_bm_thr));
   if (tr_ok) {
     const bool tr64 = bm_env == 64 ? true : bm_env == 128 ? false : bm64;
     tr_ok = aligned_for(tr64 ? 64 : 128);

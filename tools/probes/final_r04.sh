@@ -14,6 +14,7 @@ for i in 1 2; do
 echo "== new"; run . A=1
 echo "== old (round-3 tree)"; run _old A=1
 done
+echo "== new, EA_WGRAD_BM=128 (diagnostic)"; run . EA_WGRAD_BM=128; run . EA_WGRAD_BM=128
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/r04_trace_final
 rm -rf $O; mkdir -p $O
@@ -29,3 +30,4 @@ python tools/bench_gemm_shapes.py > gpurun_out/r04_gemm_isolated.txt 2>&1; tail 
 timeout 120 tools/probes/gemm_timing 6240 > gpurun_out/r04_gemm_wg_timing.txt 2>&1
 ( time python -m pytest tests -m gpu -q -x > gpurun_out/r04_pytest_gpu.txt 2>&1 ) 2>&1 | grep real
 tail -5 gpurun_out/r04_pytest_gpu.txt
+
