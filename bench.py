@@ -260,8 +260,8 @@ def main(argv=None):
         os.environ.pop("NCCL_DEBUG")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the config-5 decode block (beam-10 RTF)")
     ap.add_argument("--decode-utts", type=int, default=2864, help="utterances of the 2864-utterance decode workload (SURVEY 8d) to time; default: all of it")
