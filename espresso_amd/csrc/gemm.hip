@@ -1441,8 +1441,15 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
   bool tr_ok = g_wgrad_tr != 0;
   bool bm64 = g_gemm_variant == 2 ? true : (g_gemm_variant == 1 ? false : (tiles128 < wgrad_bm_thr));
   if (tr_ok) {
-    const bool tr64 = bm_env == 64 ? true : bm_env == 128 ? false : bm64;
+    // the direct-to-LDS kernel needs whole tiles inside the row pitch: the preferred height first, then the other one (the
+    // transducer's output layer, pitch 5056 = 79 x 64, has no whole 128-row tiling: it must not drop to the register-staged
+    // kernel — 3.2 ms against 2.7 ms per batch — just because its group is large enough to prefer 128 rows)
+    bool tr64 = bm_env == 64 ? true : bm_env == 128 ? false : bm64;
     tr_ok = aligned_for(tr64 ? 64 : 128);
+    if (!tr_ok && bm_env == 0) {
+      tr64 = !tr64;
+      tr_ok = aligned_for(tr64 ? 64 : 128);
+    }
     if (tr_ok) bm64 = tr64;
   }
   const int bm = bm64 ? 64 : 128;
