@@ -259,15 +259,12 @@ class _Linear(torch.autograd.Function):
         pw, pb = ctx.params
         sW = _grad_sink(pw, N * Kin)
         sb = _grad_sink(pb, N) if ctx.has_bias else None
-        direct = []
         if sW is not None and (sb is not None or not ctx.has_bias):
             # a leaf parameter with its gradient buffer in place (fc_out): accumulate there, nothing returned to autograd
             _wgrad(dy, x, M, N, Kin, ld_dy=ld, out=sW.view(N, Kin), accumulate=True)
             dW, db = None, None
-            direct.append(pw)
             if ctx.has_bias:
                 K.colsum(dy, sb, M, N, ld)
-                direct.append(pb)
         else:
             dW = _wgrad(dy, x, M, N, Kin, ld_dy=ld)
             db = None
@@ -763,7 +760,6 @@ class _ConvSubsample(torch.autograd.Function):
         cur = torch.cuda.current_stream(X.device)
         side = _side_stream(X.device)
         keep = []
-        direct = []  # parameters whose gradient the kernels accumulated straight into p.grad
         for i in range(L - 1, -1, -1):
             Zi, mr, col, w16, g, beta = per[i]
             Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[i]
@@ -771,7 +767,6 @@ class _ConvSubsample(torch.autograd.Function):
             sg, sbe = _grad_sink(pg, Co), _grad_sink(pbe, Co)
             if sg is not None and sbe is not None:  # BatchNorm parameter gradients accumulate straight into p.grad
                 dg, dbeta = sg, sbe
-                direct += [pg, pbe]
             else:
                 sg = sbe = None
                 dg, dbeta = _zeros_f32(Co, X), _zeros_f32(Co, X)
@@ -781,7 +776,6 @@ class _ConvSubsample(torch.autograd.Function):
                 sW, sb = _grad_sink(pw, Co * 9), _grad_sink(pb, Co)
                 if sW is not None and sb is not None:
                     db, dW = sb, sW
-                    direct += [pw, pb]
                 else:
                     sW = None
                     db, dW = _zeros_f32(Co, X), _zeros_f32(Co * 9, X)
@@ -811,7 +805,6 @@ class _ConvSubsample(torch.autograd.Function):
                 if sW is not None:  # the slab reduce scatters into the parameter's [Co][Cc][3][3] gradient itself
                     with torch.cuda.stream(side):
                         K.conv3x3_wgrad(col, dZ, sW, B, Tc, Fc, Cc, Co, sy, sx, param_layout=True)
-                    direct.append(pw)
                 else:
                     dWp = _zeros_f32(Co * 9 * Cc, X).view(Co, 9 * Cc)
                     with torch.cuda.stream(side):
@@ -821,7 +814,6 @@ class _ConvSubsample(torch.autograd.Function):
                     db = g.detach() * mr[1] * dbeta
                 elif _grad_sink(pb, Co) is not None:
                     db = None  # exactly zero with batch statistics: nothing to add to p.grad
-                    direct.append(pb)
                 wd16 = K.cast_f32_to_bf16(ctx.weights[i].detach().permute(1, 2, 3, 0).reshape(Cc, 9 * Co).contiguous())
                 dA = K.conv3x3_dgrad(dZ, wd16, B, Tc, Fc, Cc, Co, sy, sx)
             else:

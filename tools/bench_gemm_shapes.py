@@ -4,7 +4,8 @@ runtime gives it, isolated on an otherwise idle device —
   * cold : after 300 MB of writes that push everything out of the L2s and the 256 MB infinity cache,
 for the kernel the dispatcher picks (`auto`) and for every forced variant (tile height 64 / 128 x register-staged / direct-to-LDS
 ring of 2, 3, 4 stages), next to the vendor library on the plain product (torch.mm -> hipBLASLt; diagnostic ceiling only, not on
-the product path).  The in-step columns of profiles/r04_gemm_shapes.txt come from `bench.py --gemm-dump` (tools/gemm_shape_report.py).
+the product path).  The in-step part of profiles/r04_gemm_shapes.txt comes from a kernel trace (tools/gemm_instep_report.py), the
+workgroup timing from tools/probes/gemm_timing.hip.
     python tools/bench_gemm_shapes.py [M]"""
 import os
 import sys
