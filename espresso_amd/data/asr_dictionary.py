@@ -1,7 +1,7 @@
 """AsrDictionary — symbol/index layout of espresso/data/asr_dictionary.py:18-142 on top of the
 fairseq Dictionary contract (fairseq/data/dictionary.py): with a blank symbol the specials are
 <s>=0 (blank), <pad>=1, </s>=2, <unk>=3, <space> appended; without: <pad>=0, </s>=1, <unk>=2."""
-from typing import List, Optional
+from typing import List
 
 import torch
 

@@ -5,10 +5,9 @@ fairseq/data/data_utils_fast.pyx:20-103 (`batch_by_size_vec`): scan indices in t
 close a batch when adding the next sample would exceed max_tokens (max_len_in_batch * n) or
 max_sentences, keeping batch sizes a multiple of bsz_mult.  collate_tokens: data_utils.py:37-77."""
 import contextlib
-from typing import List, Optional
+from typing import List
 
 import numpy as np
-import torch
 
 
 @contextlib.contextmanager

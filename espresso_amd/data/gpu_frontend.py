@@ -4,7 +4,7 @@ Replaces the per-utterance CPU pipeline of espresso/data/feat_text_dataset.py:12
 (get_waveform -> torchaudio fbank -> numpy_seed(seed, epoch, index) -> GlobalCMVN -> AdaptiveSpecAugment
 -> .float()) and the padding of espresso/tools/utils.py:97-113.  The dataset hands over raw int16-scale
 float waveforms; mask positions are drawn on the host from the reference's RNG stream."""
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

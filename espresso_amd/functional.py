@@ -15,9 +15,6 @@ Internal activation layout is [B*T][C] (batch-major rows, bf16); weights are fp3
 with a bf16 shadow (see FlatParams in espresso_amd/optim/flat.py).  Dropout masks are never stored:
 a per-call 64-bit seed is saved and the kernels re-derive the mask from (seed, element index).
 """
-import math
-from typing import Optional
-
 import collections
 
 import os

@@ -4,7 +4,7 @@ espresso/tasks/speech_recognition.py:272-687 for the parts the hot path touches:
 registries, train_step / valid_step, max_positions.  Datasets hand over RAW waveforms; the task's
 `prepare_sample` hook runs the fused GPU front-end (fbank + CMVN + SpecAugment + padding) right
 before `model(**net_input)`, so `net_input` keeps the reference's keys (src_tokens, src_lengths)."""
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional
 
 import numpy as np

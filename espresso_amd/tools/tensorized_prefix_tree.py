@@ -5,7 +5,7 @@ covers (0, len(word_dict)-1); words containing an unknown sub-word are skipped; 
 lexical order so that every prefix owns a contiguous id range).
 
 The trie is built directly in flat arrays (edge dictionary keyed by (parent, sub-word)) and then renumbered."""
-from typing import Callable, List, Optional
+from typing import Callable, List
 
 import numpy as np
 import torch
