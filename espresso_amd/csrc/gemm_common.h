@@ -4,6 +4,29 @@
 #include "common.h"
 #include "espresso_amd.h"
 
+// Development probe (tools/probes/gemm_timing.hip compiles gemm.hip / gemm_w8.hip with -DEA_GEMM_TIMING): thread 0 of every workgroup stamps the
+// 100 MHz device clock at entry / first tile in LDS / end of the k loop / end of the epilogue.  Compiled out of the library.
+#ifdef EA_GEMM_TIMING
+__device__ unsigned long long* g_ea_timing = nullptr;  // [workgroup][8]
+__device__ unsigned long long* g_ea_seg = nullptr;     // [workgroup][half][5] shader-clock cycles per segment of the ping-pong loop
+__device__ __forceinline__ void ea_stamp(int slot) {
+  if (threadIdx.x == 0 && g_ea_timing) {
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    g_ea_timing[wg * 8 + slot] = wall_clock64();
+    if (slot == 0) {
+      uint32_t hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_ea_timing[wg * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+}
+#define EA_STAMP(slot) ea_stamp(slot)
+#else
+#define EA_STAMP(slot)
+#endif
+
+
 namespace {
 
 constexpr int BK = 64;

@@ -761,7 +761,9 @@ class _ConvSubsample(torch.autograd.Function):
             Zi, mr, col, w16, g, beta = per[i]
             Tc, Fc, Cc, To, Fo, Co, sy, sx = cfgs[i]
             pw, pb, pg, pbe = ctx.params[4 * i: 4 * i + 4]
-            sg, sbe = _grad_sink(pg, Co), _grad_sink(pbe, Co)
+            # running statistics (training=False): the conv bias gradient below is derived from THIS call's dbeta, so dbeta must
+            # not be the live p.grad view (it may already hold earlier micro-batches: update_freq > 1 / no_sync accumulation)
+            sg, sbe = (_grad_sink(pg, Co), _grad_sink(pbe, Co)) if training else (None, None)
             if sg is not None and sbe is not None:  # BatchNorm parameter gradients accumulate straight into p.grad
                 dg, dbeta = sg, sbe
             else:

@@ -99,6 +99,10 @@ int ea_set_gemm_xcd_swizzle(int mask);
 int ea_set_gemm_glds(int stages);
 /* bf16 GEMM outputs of at least `bytes` are written with non-temporal stores (default 0 = never: measured neutral on the training step); returns the old value */
 long ea_set_gemm_nt_store_min_bytes(long bytes);
+/* tuning hook: 8-wavefront large-tile kernels (csrc/gemm_w8.hip) for launches with both operands k-contiguous and the lean bf16
+ * epilogue: 0 = never, 1 = automatic (default: a 256 x 256 or 128 x 128 tile per CU when that grid fills the chip), 2..6 = forced
+ * tile configuration (diagnostic); returns the previous value */
+int ea_set_gemm_w8(int mode);
 int ea_gemm_profile_enable(int on);
 long ea_gemm_profile_read(double* total_ms, double* total_flops);
 /* algorithmic HBM bytes of the recorded launches (operands read once, outputs written once) */

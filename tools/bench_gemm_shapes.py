@@ -86,20 +86,60 @@ def cases():
     return out
 
 
+W8 = (("256sq", 2), ("128sq/4", 3), ("256x128", 4), ("128x256", 5))
+QUICK = os.environ.get("QUICK", "0") == "1"  # skip the forced 4-wave variants (round-4 columns)
 print(f"# M = {M}; microseconds per launch, isolated (idle device); TFLOP/s of the auto choice in brackets")
-print(f"# {'N':>5} {'K':>5}  {'epilogue':44s} {'auto hot':>14s} {'auto cold':>9s} | {'vendor hot':>10s} {'cold':>6s} | "
+print(f"# w8 columns: 8-wave large-tile kernels (csrc/gemm_w8.hip), forced configuration; ' ' = output bit-identical to the 4-wave kernel, '~' = differs by bf16 rounding only (< 2e-2 relative), '!' = wrong")
+print(f"# {'N':>5} {'K':>5}  {'epilogue':44s} {'auto hot':>14s} {'auto cold':>9s} | {'4-wave hot':>10s} | {'vendor hot':>10s} {'cold':>6s} | "
+      + " ".join(f"{h:>10s}" for h, _ in W8) + " | "
       + " ".join(f"{h:>7s}" for h in ("64/reg", "64/g2", "64/g3", "64/g4", "128/reg", "128/g2", "128/g3", "128/g4")))
+
+
+def outputs(c, args):
+    outs = [c]
+    if "C2" in args:
+        outs.append(args["C2"])
+    if "qsplit" in args:
+        outs += [args["qsplit"][0], args["qsplit"][1]]
+    return outs
+
+
 for N, Kd, tag, a, w, c, args in cases():
     fn = lambda: K.gemm(a, w, c, M, N, Kd, **args)
     lib.ea_set_gemm_variant(0)
     lib.ea_set_gemm_glds(1)
+    lib.ea_set_gemm_w8(0)
+    for o in outputs(c, args):
+        o.fill_(7.0)
+    fn()
+    torch.cuda.synchronize()
+    ref = [o.clone() for o in outputs(c, args)]
+    old_hot = timeit(fn)
+    w8cells = []
+    for name, cfg in W8:
+        lib.ea_set_gemm_w8(cfg)
+        for o in outputs(c, args):
+            o.fill_(7.0)
+        fn()
+        torch.cuda.synchronize()
+        same = all(torch.equal(o, r) for o, r in zip(outputs(c, args), ref))
+        if not same:  # (ping-pong kernels add even and odd k-tiles separately: last-bit differences in fp32 -> some bf16 roundings flip)
+            worst = max(((o.float() - r.float()).abs() / (r.float().abs() + 1.0)).max().item() for o, r in zip(outputs(c, args), ref))
+            flag = "~" if worst < 2e-2 else "!"
+        else:
+            flag = " "
+        w8cells.append(f"{timeit(fn, iters=20):9.1f}{flag}")
+    lib.ea_set_gemm_w8(1)
     hot, cold = timeit(fn), timeit(fn, cold=True)
     wt = w.t()
     vfn = lambda: torch.mm(a, wt, out=c)
     vhot, vcold = timeit(vfn), timeit(vfn, cold=True)
     cells = []
+    lib.ea_set_gemm_w8(0)
     for variant in (2, 1):
         for g in (0, 2, 3, 4):
+            if QUICK:
+                continue
             lib.ea_set_gemm_variant(variant)
             lib.ea_set_gemm_glds(g)
             try:
@@ -108,5 +148,7 @@ for N, Kd, tag, a, w, c, args in cases():
                 cells.append("    err")
     lib.ea_set_gemm_variant(0)
     lib.ea_set_gemm_glds(1)
+    lib.ea_set_gemm_w8(1)
     fl = 2.0 * M * N * Kd
-    print(f"  {N:5d} {Kd:5d}  {tag:44s} {hot:7.1f} ({fl / hot / 1e6:4.0f}) {cold:9.1f} | {vhot:10.1f} {vcold:6.1f} | " + " ".join(cells))
+    print(f"  {N:5d} {Kd:5d}  {tag:44s} {hot:7.1f} ({fl / hot / 1e6:4.0f}) {cold:9.1f} | {old_hot:10.1f} | {vhot:10.1f} {vcold:6.1f} | " + " ".join(w8cells)
+          + " | " + " ".join(cells), flush=True)
