@@ -29,6 +29,31 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
   }
 }
 
+// row-pitched variant: src fp32 [M][ld_src] (N valid columns) -> dst bf16 [M][ld_dst]; columns N .. ld_dst-1 are zero-filled (the
+// vocabulary gradient, N = 5004, goes to a pitch of 5008 so that every later 16-byte access of the weight / data gradient GEMMs
+// stays aligned).  One block per row slice of 2048 columns.
+__global__ __launch_bounds__(256) void cast_f32_bf16_rows_kernel(const float* __restrict__ src, long ld_src, bf16_t* __restrict__ dst,
+                                                                 long ld_dst, int N) {
+  const long m = blockIdx.y;
+  const float* s = src + m * ld_src;
+  bf16_t* d = dst + m * ld_dst;
+  const bool vec = (ld_src & 3) == 0 && (ld_dst & 7) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  for (int n = (blockIdx.x * 256 + threadIdx.x) * 8; n < ld_dst; n += gridDim.x * 256 * 8) {
+    if (vec && n + 8 <= N) {
+      const float4 a = *reinterpret_cast<const float4*>(s + n);
+      const float4 b = *reinterpret_cast<const float4*>(s + n + 4);
+      uint4 u;
+      u.x = pack_bf2(a.x, a.y);
+      u.y = pack_bf2(a.z, a.w);
+      u.z = pack_bf2(b.x, b.y);
+      u.w = pack_bf2(b.z, b.w);
+      *reinterpret_cast<uint4*>(d + n) = u;
+    } else {
+      for (int j = n; j < n + 8 && j < ld_dst; ++j) d[j] = j < N ? f2bf(s[j]) : (bf16_t)0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src,
                                                             float* __restrict__ dst, long n) {
   const long stride = (long)gridDim.x * blockDim.x;
@@ -200,6 +225,13 @@ extern "C" int ea_transpose_bf16_batch(const void* const* src, void* const* dst,
 extern "C" int ea_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 8)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_cast_f32_to_bf16_rows(const float* src, long ld_src, void* dst, long ld_dst, long M, int N, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (ld_dst < N || ld_src < N || M > 65535) return -2;
+  const int bx = (int)((ld_dst + 2047) / 2048);
+  hipLaunchKernelGGL(cast_f32_bf16_rows_kernel, dim3(bx, (unsigned)M), dim3(256), 0, stream, src, ld_src, (bf16_t*)dst, ld_dst, N);
   return EA_CHECK_LAUNCH();
 }
 extern "C" int ea_cast_bf16_to_f32(const void* src, float* dst, long n, hipStream_t stream) {

@@ -14,9 +14,13 @@
 #include <string.h>
 
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "espresso_amd.h"
+
+void ea_gemm_corun_hint(int on);  // gemm.hip: the launches that follow share the device with side-stream work
 
 namespace {
 
@@ -175,7 +179,11 @@ struct G {
   }
 };
 
-inline void gemm(Ctx& c, G& g) { RUN(ea_gemm_bf16(&g.p, c.s)); }
+inline void gemm(Ctx& c, G& g) {
+  if (!c.dry && c.rc == 0) ea_gemm_corun_hint(c.overlap || c.df != nullptr);
+  RUN(ea_gemm_bf16(&g.p, c.s));
+  if (!c.dry) ea_gemm_corun_hint(0);
+}
 inline void gemm_on(Ctx& c, G& g, hipStream_t st) { RUN(ea_gemm_bf16(&g.p, st)); }
 
 // dW[N_out][K_in] += dy^T x (and dbias[N_out] += column sums of dy).  Deferred mode: one more problem of the layer's grouped
@@ -656,39 +664,51 @@ static void attn_bwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
 
 // BatchNorm accumulators of the convolution module without fill launches: two fp64 statistics buffers (forward) and two fp32
 // sum buffers (backward) take turns; the kernel that CONSUMES one buffer clears the other for the next call (ea_bn_act_fwd_train
-// / ea_bn_act_bwd_fused), so the kernel that accumulates always finds zeros.  Process-wide like the side stream; cleared once at
-// creation on the caller's stream.  Channel counts above the capacity fall back to a fill per call.
+// / ea_bn_act_bwd_fused), so the kernel that accumulates always finds zeros.  One ring per (device, stream), allocated
+// and cleared on first use (so: not inside a hipGraph capture — run one eager call first); a call that fails between the two
+// launches marks the ring dirty and the next user re-zeroes it.  Channel counts above the capacity fall back to a fill per call.
 struct BnRing {
   double* st[2] = {nullptr, nullptr};
   float* red[2] = {nullptr, nullptr};
   int si = 0, ri = 0, cap = 0;
-  bool ok = false, failed = false;
+  bool ok = false, failed = false, dirty = false;
 };
-static BnRing g_bn;
-static bool bn_ring(hipStream_t owner, int C) {
-  if (g_bn.ok) return C <= g_bn.cap;
-  if (g_bn.failed) return false;
-  const int cap = C > 2048 ? C : 2048;
+// one ring per (device, stream): the zero-on-entry invariant only holds among launches that are ordered on ONE stream
+static std::mutex g_bn_mu;
+static std::map<std::pair<int, hipStream_t>, BnRing> g_bn_rings;
+static BnRing* bn_ring(hipStream_t owner, int C) {
   int cur = 0, dev = 0;
-  if (hipGetDevice(&cur) != hipSuccess) { g_bn.failed = true; return false; }
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
   dev = cur;
   if (owner != nullptr) {
     hipDevice_t d;
     if (hipStreamGetDevice(owner, &d) == hipSuccess) dev = (int)d;
   }
-  if (dev != cur && hipSetDevice(dev) != hipSuccess) { g_bn.failed = true; return false; }
-  const size_t bytes = 2 * (size_t)(2 * cap) * (sizeof(double) + sizeof(float));
-  char* base = nullptr;
-  bool ok = hipMalloc(reinterpret_cast<void**>(&base), bytes) == hipSuccess && hipMemsetAsync(base, 0, bytes, owner) == hipSuccess;
-  if (dev != cur) (void)hipSetDevice(cur);
-  if (!ok) { g_bn.failed = true; return false; }
-  g_bn.st[0] = reinterpret_cast<double*>(base);
-  g_bn.st[1] = g_bn.st[0] + 2 * cap;
-  g_bn.red[0] = reinterpret_cast<float*>(g_bn.st[1] + 2 * cap);
-  g_bn.red[1] = g_bn.red[0] + 2 * cap;
-  g_bn.cap = cap;
-  g_bn.ok = true;
-  return true;
+  std::lock_guard<std::mutex> lk(g_bn_mu);
+  BnRing& R = g_bn_rings[std::make_pair(dev, owner)];
+  if (R.failed) return nullptr;
+  if (!R.ok) {
+    const int cap = 2048;
+    if (dev != cur && hipSetDevice(dev) != hipSuccess) { R.failed = true; return nullptr; }
+    const size_t bytes = 2 * (size_t)(2 * cap) * (sizeof(double) + sizeof(float));
+    char* base = nullptr;
+    const bool ok = hipMalloc(reinterpret_cast<void**>(&base), bytes) == hipSuccess && hipMemsetAsync(base, 0, bytes, owner) == hipSuccess;
+    if (dev != cur) (void)hipSetDevice(cur);
+    if (!ok) { R.failed = true; return nullptr; }
+    R.st[0] = reinterpret_cast<double*>(base);
+    R.st[1] = R.st[0] + 2 * cap;
+    R.red[0] = reinterpret_cast<float*>(R.st[1] + 2 * cap);
+    R.red[1] = R.red[0] + 2 * cap;
+    R.cap = cap;
+    R.ok = true;
+  }
+  if (C > R.cap) return nullptr;
+  if (R.dirty) {  // a call failed between the accumulating and the consuming launch: start from zeros again
+    const size_t bytes = 2 * (size_t)(2 * R.cap) * (sizeof(double) + sizeof(float));
+    if (hipMemsetAsync(R.st[0], 0, bytes, owner) != hipSuccess) return nullptr;
+    R.dirty = false;
+  }
+  return &R;
 }
 
 struct ConvSaved {
@@ -720,19 +740,21 @@ static void conv_fwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   // activation come out of ONE launch behind the depthwise kernel (no fill, no finalize launch)
   static const bool bn_fused = getenv("EA_BN_UNFUSED") == nullptr;  // (diagnostic A/B switch)
   const bool ring = sh.training && bn_fused && C <= 2048;  // (same decision in the sizing pass: the arena walk must not differ)
-  if (ring && !c.dry && c.rc == 0 && !bn_ring(c.s, C)) c.rc = -1;
+  BnRing* R = nullptr;
+  if (ring && !c.dry && c.rc == 0 && !(R = bn_ring(c.s, C))) c.rc = -1;
   double* stats = nullptr;
   if (sh.training && !ring) {
     stats = sc.get<double>(2 * C);
     if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(stats, 0, 2 * C * sizeof(double), c.s) == hipSuccess ? 0 : -1;
   }
-  if (ring && !c.dry && c.rc == 0) stats = g_bn.st[g_bn.si];
+  if (R && c.rc == 0) stats = R->st[R->si];
   RUN(ea_glu_dwconv_fwd(s.Y, w.dw, s.U, s.Z, stats, B, T, C, sh.KW, c.s));
   if (ring) {
-    if (!c.dry && c.rc == 0) {
-      RUN(ea_bn_act_fwd_train(s.Z, stats, s.mr, w.bn_rm, w.bn_rv, w.bn_g, w.bn_b, s.Hh, M, C, EA_ACT_SILU, (float)M, 1e-5f, 0.1f,
-                              g_bn.st[g_bn.si ^ 1], 2 * g_bn.cap, c.s));
-      g_bn.si ^= 1;
+    if (R) {
+      if (c.rc == 0) RUN(ea_bn_act_fwd_train(s.Z, stats, s.mr, w.bn_rm, w.bn_rv, w.bn_g, w.bn_b, s.Hh, M, C, EA_ACT_SILU, (float)M, 1e-5f, 0.1f,
+                                             R->st[R->si ^ 1], 2 * R->cap, c.s));
+      if (c.rc == 0) R->si ^= 1;  // (flipped only when both launches are queued)
+      else R->dirty = true;
     }
   } else {
     if (sh.training) RUN(ea_bn_finalize(stats, s.mr, w.bn_rm, w.bn_rv, C, (float)M, 1e-5f, 0.1f, c.s));
@@ -767,7 +789,8 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   // the BatchNorm parameter gradients itself (no fill launch, no bn_param_grad launch)
   static const bool bn_fused = getenv("EA_BN_UNFUSED") == nullptr;  // (diagnostic A/B switch)
   const bool ring = bn_fused && C <= 2048;
-  if (ring && !c.dry && c.rc == 0 && !bn_ring(c.s, C)) c.rc = -1;
+  BnRing* R = nullptr;
+  if (ring && !c.dry && c.rc == 0 && !(R = bn_ring(c.s, C))) c.rc = -1;
   float* red = nullptr;
   if (!ring) {
     red = sc.get<float>(2 * C);
@@ -775,11 +798,12 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
   }
   uint16_t* dZ = sc.get<uint16_t>((size_t)M * C);
   if (ring) {
-    if (!c.dry && c.rc == 0) {
-      red = g_bn.red[g_bn.ri];
+    if (R && c.rc == 0) {
+      red = R->red[R->ri];
       RUN(ea_bn_act_bwd_fused(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, gw.bn_g, gw.bn_b, M, C, EA_ACT_SILU, sh.training,
-                              g_bn.red[g_bn.ri ^ 1], 2 * g_bn.cap, c.s));
-      g_bn.ri ^= 1;
+                              R->red[R->ri ^ 1], 2 * R->cap, c.s));
+      if (c.rc == 0) R->ri ^= 1;
+      else R->dirty = true;
     }
   } else {
     RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, nullptr, nullptr, M, C, EA_ACT_SILU, sh.training, c.s));

@@ -28,6 +28,13 @@
 
 // 8-wave large-tile kernels (gemm_w8.hip): takes the launch (returns 1) or leaves it to the kernels below (0)
 int ea_gemm_w8_try(const EaGemmParams& q, int nt_flag, hipStream_t stream, int* cfg_out);
+// Hint from the layer runtime (engine.hip): the launches that follow run NEXT TO side-stream work (the backward pass: grouped weight
+// gradients of 2 x 64 KB of LDS per CU).  A one-workgroup-per-CU kernel with 128 - 144 KB of LDS cannot share a CU with them: it
+// waits for both to drain and then keeps them out, so the 8-wave kernels, 10 - 15 % faster alone, lose in that half of the step
+// (round 5, same box: 14.18 ms per step with them everywhere, 13.91 without).  Thread-local: one host thread drives one stream.
+static thread_local int g_gemm_corun = 0;
+void ea_gemm_corun_hint(int on) { g_gemm_corun = on; }
+static const int g_w8_corun = [] { const char* e = getenv("EA_GEMM_W8_CORUN"); return e ? atoi(e) : 0; }();  // (diagnostic: 1 = use them there too)
 
 namespace {
 
@@ -1150,7 +1157,7 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   }
   bool done = false;
   const bool kc_ok = glds_eligible(q);
-  if (kc_ok && fast_epilogue_ok(q)) {  // one 512-thread workgroup per CU on a 256 x 256 / 128 x 128 tile when the grid fits the chip
+  if (kc_ok && fast_epilogue_ok(q) && (!g_gemm_corun || g_w8_corun)) {  // one 512-thread workgroup per CU on a large tile when the grid fits the chip
     int cfg = 0;
     if (ea_gemm_w8_try(q, nt_flag(q), stream, &cfg)) {
       done = true;

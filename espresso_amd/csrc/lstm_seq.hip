@@ -268,19 +268,37 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const LstmSeqBwdArgs 
   }
 }
 
+// The grid barrier needs every workgroup of the grid resident at the same time: the launch is refused (-> the caller's per-step
+// path) unless the runtime's own occupancy answer for THIS kernel says the whole grid fits the device with room to spare (one
+// workgroup per CU is all these grids ask for: nwg <= 64; the query guards against a build whose register / LDS use changed).
+template <typename K>
+static bool grid_fits(K kernel, int nwg) {
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) return false;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  return nwg <= cus;  // (one slot per CU is enough; per_cu >= 1 was checked above)
+}
 template <int KS, int MT>
-int launch_fwd(const LstmSeqFwdArgs& a, hipStream_t stream) {
+int launch_fwd(const LstmSeqFwdArgs& a, hipStream_t stream, bool probe_only = false) {
   const int nwg = a.H / (16 * MT);
   const int ng = (a.B + 15) / 16;
+  static const bool ok1 = grid_fits(lstm_seq_fwd_kernel<KS, MT, 1>, 64), ok2 = grid_fits(lstm_seq_fwd_kernel<KS, MT, 2>, 64),
+                    ok4 = grid_fits(lstm_seq_fwd_kernel<KS, MT, 4>, 64);
+  if (!(ng == 1 ? ok1 : ng == 2 ? ok2 : ok4)) return -2;
+  if (probe_only) return 0;
   if (ng == 1) hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS, MT, 1>), dim3(nwg), dim3(256), 0, stream, a);
   else if (ng == 2) hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS, MT, 2>), dim3(nwg), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS, MT, 4>), dim3(nwg), dim3(256), 0, stream, a);
   return 0;
 }
 template <int KS>
-int launch_bwd(const LstmSeqBwdArgs& a, hipStream_t stream) {
+int launch_bwd(const LstmSeqBwdArgs& a, hipStream_t stream, bool probe_only = false) {
   const int nwg = a.H / 16;
   const int ng = (a.B + 15) / 16;
+  static const bool ok1 = grid_fits(lstm_seq_bwd_kernel<KS, 1>, 64), ok2 = grid_fits(lstm_seq_bwd_kernel<KS, 2>, 64),
+                    ok4 = grid_fits(lstm_seq_bwd_kernel<KS, 4>, 64);
+  if (!(ng == 1 ? ok1 : ng == 2 ? ok2 : ok4)) return -2;
+  if (probe_only) return 0;
   if (ng == 1) hipLaunchKernelGGL((lstm_seq_bwd_kernel<KS, 1>), dim3(nwg), dim3(256), 0, stream, a);
   else if (ng == 2) hipLaunchKernelGGL((lstm_seq_bwd_kernel<KS, 2>), dim3(nwg), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((lstm_seq_bwd_kernel<KS, 4>), dim3(nwg), dim3(256), 0, stream, a);
@@ -299,6 +317,31 @@ int launch_bwd(const LstmSeqBwdArgs& a, hipStream_t stream) {
 // gives up (and traps, so that a broken launch cannot continue on stale state) only after ~2^26 polls of >= 64 cycles = several
 // SECONDS.  What must never share the device with this kernel is another grid-barrier kernel whose grid cannot be placed
 // next to it — the library has none: forward and backward recurrences of one model are ordered by autograd.
+static int dispatch_fwd(const LstmSeqFwdArgs& a, hipStream_t stream, bool probe_only) {
+  switch (a.H / 32) {
+    case 8: return launch_fwd<8, 2>(a, stream, probe_only);
+    case 10: return launch_fwd<10, 1>(a, stream, probe_only);  // 320 = 20 x 16: one tile per wave keeps every wave busy
+    case 16: return launch_fwd<16, 2>(a, stream, probe_only);
+    case 20: return launch_fwd<20, 1>(a, stream, probe_only);
+    case 24: return launch_fwd<24, 1>(a, stream, probe_only);
+    case 25: return launch_fwd<25, 1>(a, stream, probe_only);
+    case 32: return launch_fwd<32, 1>(a, stream, probe_only);
+    default: return -2;
+  }
+}
+static int dispatch_bwd(const LstmSeqBwdArgs& a, hipStream_t stream, bool probe_only) {
+  switch (a.H / 32) {
+    case 8: return launch_bwd<8>(a, stream, probe_only);
+    case 10: return launch_bwd<10>(a, stream, probe_only);
+    case 16: return launch_bwd<16>(a, stream, probe_only);
+    case 20: return launch_bwd<20>(a, stream, probe_only);
+    case 24: return launch_bwd<24>(a, stream, probe_only);
+    case 25: return launch_bwd<25>(a, stream, probe_only);
+    case 32: return launch_bwd<32>(a, stream, probe_only);
+    default: return -2;
+  }
+}
+
 extern "C" int ea_lstm_seq_supported(int B, int H) {
   if (B < 1 || B > 64) return 0;
   static const int cus = [] {
@@ -309,9 +352,15 @@ extern "C" int ea_lstm_seq_supported(int B, int H) {
   }();
   if (cus < H / 16) return 0;
   switch (H) {
-    case 256: case 320: case 512: case 640: case 768: case 800: case 1024: return 1;
+    case 256: case 320: case 512: case 640: case 768: case 800: case 1024: break;
     default: return 0;
   }
+  // the runtime's occupancy answer for the very kernels this shape would launch (see grid_fits)
+  LstmSeqFwdArgs fa{};
+  fa.B = B; fa.H = H;
+  LstmSeqBwdArgs ba{};
+  ba.B = B; ba.H = H;
+  return dispatch_fwd(fa, nullptr, true) == 0 && dispatch_bwd(ba, nullptr, true) == 0 ? 1 : 0;
 }
 
 extern "C" int ea_lstm_seq_fwd(const float* gx, const void* w_hh, const void* h0, const float* c0, const uint8_t* frozen, void* hs,
@@ -322,16 +371,7 @@ extern "C" int ea_lstm_seq_fwd(const float* gx, const void* w_hh, const void* h0
   LstmSeqFwdArgs a{gx, (const bf16_t*)w_hh, (const bf16_t*)h0, c0, frozen, (bf16_t*)hs, cs, act, h_last, counter,
                    B, U, H, reverse, frozen_out_zero};
   if (hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), stream) != hipSuccess) return -1;
-  switch (H / 32) {
-    case 8: launch_fwd<8, 2>(a, stream); break;
-    case 10: launch_fwd<10, 1>(a, stream); break;  // 320 = 20 x 16: one tile per wave keeps every wave busy
-    case 16: launch_fwd<16, 2>(a, stream); break;
-    case 20: launch_fwd<20, 1>(a, stream); break;
-    case 24: launch_fwd<24, 1>(a, stream); break;
-    case 25: launch_fwd<25, 1>(a, stream); break;
-    case 32: launch_fwd<32, 1>(a, stream); break;
-    default: return -2;
-  }
+  if (dispatch_fwd(a, stream, false) != 0) return -2;
   return EA_CHECK_LAUNCH();
 }
 
@@ -343,15 +383,6 @@ extern "C" int ea_lstm_seq_bwd(const void* dhs, const float* dh_last, const floa
   LstmSeqBwdArgs a{(const bf16_t*)dhs, dh_last, dc_last, act, cs, c0, frozen, (const bf16_t*)w_hhT, (bf16_t*)dG, dh0, dc0, counter,
                    B, U, H, reverse};
   if (hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), stream) != hipSuccess) return -1;
-  switch (H / 32) {
-    case 8: launch_bwd<8>(a, stream); break;
-    case 10: launch_bwd<10>(a, stream); break;
-    case 16: launch_bwd<16>(a, stream); break;
-    case 20: launch_bwd<20>(a, stream); break;
-    case 24: launch_bwd<24>(a, stream); break;
-    case 25: launch_bwd<25>(a, stream); break;
-    case 32: launch_bwd<32>(a, stream); break;
-    default: return -2;
-  }
+  if (dispatch_bwd(a, stream, false) != 0) return -2;
   return EA_CHECK_LAUNCH();
 }

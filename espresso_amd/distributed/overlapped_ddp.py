@@ -15,8 +15,6 @@ API mirrors the wrappers in fairseq/models/distributed_fairseq_model.py:35-147: 
 """
 import contextlib
 import os
-import queue
-import threading
 from typing import List, Optional
 
 import torch
@@ -63,15 +61,6 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self.max_fired = 0
         self._hooks = {id(p): self._make_hook(p) for p in flat.params}
         self._native_cache = {}
-        # EA_DDP_THREAD=1: the RCCL enqueues leave the thread that drives the step — `_launch` records where the gradient streams
-        # stand (events) and hands the bucket to a helper thread that makes the communication stream wait for them and issues the
-        # all-reduce.  Measured on a one-rank RCCL group (round 4, profiles/r04_ddp_one_rank_overhead.json): no difference
-        # (21.2 / 21.5 ms with the thread, 21.2 / 21.5 inline, 18.9 without the wrapper) — the cost of the one-rank path is the
-        # RCCL kernels themselves moving 320 MB next to the backward pass, not the five host enqueues.  Off by default.
-        self._use_thread = self._on_gpu and os.environ.get("EA_DDP_THREAD", "0") == "1"
-        self._q: Optional[queue.Queue] = None
-        self._thread: Optional[threading.Thread] = None
-        self._thread_err: List = []
         if self.active:
             for p in flat.params:
                 p.register_post_accumulate_grad_hook(self._hooks[id(p)])
@@ -122,25 +111,6 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
             if pending[i] == 0:
                 self._launch(i)
 
-    def _worker(self):
-        dev = self.flat.g32.device
-        torch.cuda.set_device(dev)
-        while True:
-            item = self._q.get()
-            if item is None:
-                self._q.task_done()
-                return
-            view, events = item
-            try:
-                with torch.cuda.stream(self.comm_stream):
-                    for ev in events:
-                        self.comm_stream.wait_event(ev)
-                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
-            except BaseException as e:  # surfaced by all_reduce_grads on the main thread
-                self._thread_err.append(e)
-            finally:
-                self._q.task_done()
-
     def _launch(self, i):
         if self._launched[i]:
             return
@@ -153,13 +123,6 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
             # on that stream), possibly on others: wait for all of them
             cur = torch.cuda.current_stream()
             streams = [cur] + [st for st in _F.python_side_streams(view.device) if st != cur]
-            if self._use_thread:
-                if self._thread is None:
-                    self._q = queue.Queue()
-                    self._thread = threading.Thread(target=self._worker, name="ea-ddp-launch", daemon=True)
-                    self._thread.start()
-                self._q.put((view, [st.record_event() for st in streams]))
-                return
             for st in streams:
                 self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
@@ -194,10 +157,6 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)
-            if self._q is not None:
-                self._q.join()  # every bucket handed to the helper thread has been issued
-                if self._thread_err:
-                    raise self._thread_err.pop()
             for w in self._works:
                 w.wait()
             if self._on_gpu:

@@ -255,10 +255,12 @@ def install():
                     continue
                 if k in ("sample_size", "ppl", "word_error", "word_count", "char_error", "char_count"):
                     continue  # (ppl is derived below; the reference logs neither the raw error counts nor sample_size)
+                if k in ("wer", "cer") and not weights[k]:
+                    continue  # (no reference words / characters in these batches: the reference logs no error rate then)
                 if k in weights:
                     metrics.log_scalar(k, float(v), float(weights[k]) if weights[k] else 1, round=4 if k in ("wer", "cer") else 3)
                 else:
-                    metrics.log_scalar(k, float(v))
+                    metrics.log_scalar(k, float(v), round=3)
             if out and ("nll_loss" in out or "ppl" in out):
                 from fairseq import utils as fq_utils
 

@@ -249,7 +249,10 @@ class _Linear(torch.autograd.Function):
         M, Kin = x.shape
         N = w16.shape[0]
         if dy.dtype != torch.bfloat16:
-            dy = K.cast_f32_to_bf16(dy.contiguous())
+            # fp32 output (vocabulary logits): one pass to bf16 at a row pitch of a multiple of 8 elements
+            if dy.stride(1) != 1:
+                dy = dy.contiguous()
+            dy = K.cast_f32_to_bf16_rows(dy, _pad8(N)) if M <= 65535 else K.cast_f32_to_bf16(dy.contiguous())
         if dy.stride(1) != 1 or dy.stride(0) % 8 != 0:
             dy = dy.contiguous()
         ld = dy.stride(0)

@@ -165,6 +165,15 @@ def cast_f32_to_bf16(src, dst=None):
     return dst
 
 
+def cast_f32_to_bf16_rows(src, ld_dst):
+    """src fp32 [M][N] (row stride src.stride(0)) -> bf16 [M][ld_dst] buffer (columns N.. zero); returns the [M][N] view."""
+    M, N = src.shape
+    assert src.dtype == torch.float32 and src.stride(1) == 1 and ld_dst >= N
+    dst = torch.empty(M, ld_dst, dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().ea_cast_f32_to_bf16_rows(_p(src), src.stride(0), _p(dst), ld_dst, M, N, _stream()), "ea_cast_f32_to_bf16_rows")
+    return dst if ld_dst == N else dst[:, :N]
+
+
 def cast_bf16_to_f32(src, dst=None):
     if dst is None:
         dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)

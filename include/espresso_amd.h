@@ -175,6 +175,10 @@ int ea_cast_f32_to_bf16(const float* src, void* dst, long n, ea_stream_t stream)
 /* n <= 8 bf16 matrices in one launch: dst[i][c][r] = src[i][r][c] (rows[i] x cols[i], dense).  Used for the k-contiguous
  * copies of the Linear weights that the backward data-gradient GEMMs read (nn.Linear backward, x_grad = y_grad @ W). */
 int ea_transpose_bf16_batch(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, ea_stream_t stream);
+/* fp32 [M][ld_src] -> bf16 [M][ld_dst], N valid columns per row, columns N .. ld_dst-1 zero-filled (M <= 65535): the fp32
+ * gradient of the vocabulary logits re-pitched for the bf16 weight / data gradient GEMMs of the output layer
+ * (espresso/models/transformer/speech_transformer_encoder_model.py:207-208 fc_out, torch autograd of F.linear). */
+int ea_cast_f32_to_bf16_rows(const float* src, long ld_src, void* dst, long ld_dst, long M, int N, ea_stream_t stream);
 int ea_cast_bf16_to_f32(const void* src, float* dst, long n, ea_stream_t stream);
 /* out = a*x*keep(idx) + b*y  (bf16; y may be NULL) */
 int ea_scale_dropout_bf16(const void* x, const void* y, void* out, long n, float a, float b, uint64_t seed,

@@ -4,6 +4,7 @@ modules (tests/golden/ref_*_ctc_tiny.npz, see oracle/gen_golden.py) in tests/tes
 
 Each function cites the reference code it follows (paths relative to the reference root)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -48,6 +49,22 @@ class _RoundBF16(torch.autograd.Function):
 def _r(x):
     """Storage point: identity in the fp32 restatement, bf16 round trip under emulation."""
     return _RoundBF16.apply(x) if _EMU["on"] and x.is_floating_point() else x
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _rg(x):
+    """A value the HIP path keeps in fp32 whose GRADIENT it stores in bf16 (the encoder's vocabulary logits under EA_LOGITS_F32=1:
+    the output GEMM writes fp32 rows, the loss gradient is cast to bf16 for the weight / data gradient GEMMs)."""
+    return _RoundGradBF16.apply(x) if _EMU["on"] and x.is_floating_point() else x
 
 
 # ---- training-mode dropout with the HIP path's masks ---------------------------------------------------------------------
@@ -348,7 +365,8 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
     if "layer_norm.weight" in sd:
         x = _ln(x, sd, "layer_norm.")
     if "fc_out.weight" in sd:
-        x = _r(_lin(x, sd["fc_out.weight"], sd["fc_out.bias"]))
+        y = _lin(x, sd["fc_out.weight"], sd["fc_out.bias"])
+        x = _rg(y) if os.environ.get("EA_LOGITS_F32", "0") == "1" else _r(y)
     return x, out_len
 
 

@@ -196,6 +196,56 @@ def check_gemm_query_split(M=333, C=256, Kin=192, with_v=True, glds=1, seed=0):
             "kv_equal": bool((out[:, C:] == ref[:, C:]).all()), "q_third_untouched": bool((out[:, :C] == 7.0).all())}
 
 
+def check_gemm_w8(cfg, kind, M=777, N=640, K=192, seed=0):
+    """The 8-wavefront large-tile kernels (csrc/gemm_w8.hip, forced tile configuration `cfg`) against the 4-wave kernels on the
+    same launch: every output bit for bit (same products, same rounding points, same accumulation order along k; the epilogue runs
+    from registers on transposed accumulators).  kind: plain | bias_relu | qsplit | act2 (bias + SiLU + dropout, two outputs) |
+    aux (dropout * SiLU'(aux)) | resid (bias + dropout, 0.5 y + residual).  Ragged M; N a multiple of 128, not always of 256."""
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    extra = bf(torch.randn(M, N, generator=g)).to(DEV)
+
+    def run():
+        C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        outs = [C]
+        kw = dict(lda=K, ldb=K, ldc=N)
+        if kind == "bias_relu":
+            kw.update(bias=bias, act="relu")
+        elif kind == "qsplit":
+            qn = 256 if N >= 384 else 128
+            qu = torch.full((M, qn), 7.0, dtype=torch.bfloat16, device=DEV)
+            qv = torch.full((M, qn), 7.0, dtype=torch.bfloat16, device=DEV)
+            kw.update(bias=bias, qsplit=(qu, qv, bias[:qn].contiguous(), (bias[:qn] * 0.5).contiguous(), qn, qn, 0.125))
+            outs += [qu, qv]
+        elif kind == "act2":
+            C2 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+            kw.update(bias=bias, act="silu", C2=C2, ldc2=N, drop_p=0.1, drop_seed=1234 + seed)
+            outs.append(C2)
+        elif kind == "aux":
+            kw.update(aux=extra, ldaux=N, act="silu", drop_p=0.1, drop_seed=77 + seed)
+        elif kind == "resid":
+            kw.update(bias=bias, resid=extra, ldr=N, out_scale=0.5, drop_p=0.1, drop_seed=9 + seed)
+        Kk.gemm(A, W, C, M, N, K, **kw)
+        torch.cuda.synchronize()
+        return outs
+
+    old = lib.ea_set_gemm_w8(0)
+    try:
+        ref = run()
+        lib.ea_set_gemm_w8(cfg)
+        got = run()
+    finally:
+        lib.ea_set_gemm_w8(old)
+    return {"equal": all(bool(torch.equal(a, b)) for a, b in zip(got, ref)), "finite": all(bool(torch.isfinite(a.float()).all()) for a in got),
+            "written": any(bool((a != 7.0).any()) for a in got)}
+
+
 def check_conv3x3(Cin=64, Cout=128, sy=2, sx=2, B=2, T=37, F=21, seed=0):
     """Implicit-GEMM 3x3 convolution (forward + BatchNorm sums, data gradient) vs torch conv2d / its autograd on the same bf16
     operands (fp32 CPU): odd T / F (ragged parity classes, padding taps on every border), strides 1 and 2."""

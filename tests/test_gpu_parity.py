@@ -42,6 +42,15 @@ def test_gemm_query_split_epilogue(kw):
     assert all(r.values()), r
 
 
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+@pytest.mark.parametrize("kind", ["plain", "bias_relu", "qsplit", "act2", "aux", "resid"])
+def test_gemm_8wave_large_tiles_bit_identical_to_4wave(cfg, kind):
+    """csrc/gemm_w8.hip (256x256 / 128x128 / 256x128 / 128x256 tiles, register epilogue) == csrc/gemm.hip on the same launch"""
+    for (M, N, K) in ((777, 640, 192), (130, 128, 64), (1500, 1024, 512)):
+        r = G.check_gemm_w8(cfg, kind, M, N, K)
+        assert r["equal"] and r["finite"] and r["written"], (cfg, kind, M, N, K, r)
+
+
 def test_gemm_splitk():
     assert G.check_gemm(130, 200, 5000, True, True, c_f32=True, splitk=7) < 2e-3
     assert G.check_gemm(64, 576, 20011, True, True, c_f32=True, splitk=33, batch=1) < 2e-3
