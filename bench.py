@@ -440,7 +440,9 @@ def main(argv=None):
         # across utterances, over 18 batches = 210 utterances of the decode workload; random-init weights = the WORST case (a
         # near-uniform joint's length-normalised scores prefer the longest hypothesis: every frame spends both expansions, 50
         # emitted tokens per audio second against ~4.5 for a trained model — tools/bench_transducer_decode.py)
-        for key, script in (("config2_encdec", ["bench_encdec.py"]), ("config4_transducer", ["bench_transducer.py"]),
+        # ingest: the same update step fed by speech_train.py's data path from 2 048 WAV files on local disk
+        # (tools/bench_ingest.py) next to the same batches resident in HBM
+        for key, script in (("ingest", ["bench_ingest.py"]), ("config2_encdec", ["bench_encdec.py"]), ("config4_transducer", ["bench_transducer.py"]),
                             ("f3_transducer_beam_search", ["bench_transducer_decode.py", "--beam-only", "--all-utts", "--batches", "18"])):
             try:
                 out = subprocess.run([sys.executable, os.path.join(here, "tools", script[0])] + script[1:], capture_output=True, text=True,

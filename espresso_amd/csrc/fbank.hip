@@ -23,9 +23,11 @@ constexpr int NFFT = 512, LOG2N = 9, WAVES = 4;
 
 __device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> (32 - LOG2N)); }
 
-// wav: concatenated fp32 samples; off[b]..off[b+1] = utterance b.  feat: [B][Tmax][nmel]
+// wav: concatenated samples (fp32 at int16 scale, or the int16 samples themselves as the waveform readers of ingest.hip deliver
+// them: half the bytes over PCIe and from HBM, the conversion is exact); off[b]..off[b+1] = utterance b.  feat: [B][Tmax][nmel]
+template <typename TS>
 __global__ __launch_bounds__(256) void fbank_kernel(
-    const float* __restrict__ wav, const long* __restrict__ off, const float* __restrict__ window /*[flen]*/,
+    const TS* __restrict__ wav, const long* __restrict__ off, const float* __restrict__ window /*[flen]*/,
     const float2* __restrict__ twiddle /*[256] (cos,-sin)(2*pi*k/512)*/, const int* __restrict__ mel_start,
     const int* __restrict__ mel_len, const int* __restrict__ mel_woff, const float* __restrict__ mel_w,
     const float* __restrict__ cmvn_mean, const float* __restrict__ cmvn_std, float* __restrict__ feat,
@@ -50,11 +52,11 @@ __global__ __launch_bounds__(256) void fbank_kernel(
     // ---- load frame, remove DC ----
     float x[8];
     float sum = 0.f;
-    const float* src = wav + s0 + (long)f * fshift;
+    const TS* src = wav + s0 + (long)f * fshift;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = lane + 64 * k;
-      x[k] = (valid && i < flen) ? src[i] : 0.f;
+      x[k] = (valid && i < flen) ? (float)src[i] : 0.f;
       sum += x[k];
     }
     const float mean = wave_sum(sum) / (float)flen;
@@ -189,19 +191,35 @@ extern "C" int ea_feature_stats(const float* feat, const int* lengths, double* a
   return EA_CHECK_LAUNCH();
 }
 
+template <typename TS>
+static int fbank_launch(const TS* wav, const long* offsets, int B, const float* window, const float* twiddle, const int* mel_start,
+                        const int* mel_len, const int* mel_woff, const float* mel_w, const float* cmvn_mean, const float* cmvn_std,
+                        float* feat, float* utt_sum, int* out_len, int Tmax, int nmel, int frame_len, int frame_shift, float preemph,
+                        float log_floor, hipStream_t stream) {
+  if (B <= 0 || Tmax <= 0) return 0;
+  if (frame_len > NFFT || nmel > 128) return -2;
+  const int fpb = 16;
+  dim3 grid((Tmax + fpb - 1) / fpb, B);
+  hipLaunchKernelGGL(fbank_kernel<TS>, grid, dim3(256), 0, stream, wav, offsets, window, (const float2*)twiddle, mel_start,
+                     mel_len, mel_woff, mel_w, cmvn_mean, cmvn_std, feat, utt_sum, out_len, Tmax, nmel, frame_len,
+                     frame_shift, preemph, log_floor, fpb);
+  return EA_CHECK_LAUNCH();
+}
 extern "C" int ea_fbank_batch(const float* wav, const long* offsets, int B, const float* window,
                               const float* twiddle, const int* mel_start, const int* mel_len, const int* mel_woff,
                               const float* mel_w, const float* cmvn_mean, const float* cmvn_std, float* feat,
                               float* utt_sum, int* out_len, int Tmax, int nmel, int frame_len, int frame_shift,
                               float preemph, float log_floor, hipStream_t stream) {
-  if (B <= 0 || Tmax <= 0) return 0;
-  if (frame_len > NFFT || nmel > 128) return -2;
-  const int fpb = 16;
-  dim3 grid((Tmax + fpb - 1) / fpb, B);
-  hipLaunchKernelGGL(fbank_kernel, grid, dim3(256), 0, stream, wav, offsets, window, (const float2*)twiddle, mel_start,
-                     mel_len, mel_woff, mel_w, cmvn_mean, cmvn_std, feat, utt_sum, out_len, Tmax, nmel, frame_len,
-                     frame_shift, preemph, log_floor, fpb);
-  return EA_CHECK_LAUNCH();
+  return fbank_launch<float>(wav, offsets, B, window, twiddle, mel_start, mel_len, mel_woff, mel_w, cmvn_mean, cmvn_std, feat, utt_sum,
+                             out_len, Tmax, nmel, frame_len, frame_shift, preemph, log_floor, stream);
+}
+extern "C" int ea_fbank_batch_i16(const int16_t* wav, const long* offsets, int B, const float* window,
+                                  const float* twiddle, const int* mel_start, const int* mel_len, const int* mel_woff,
+                                  const float* mel_w, const float* cmvn_mean, const float* cmvn_std, float* feat,
+                                  float* utt_sum, int* out_len, int Tmax, int nmel, int frame_len, int frame_shift,
+                                  float preemph, float log_floor, hipStream_t stream) {
+  return fbank_launch<int16_t>(wav, offsets, B, window, twiddle, mel_start, mel_len, mel_woff, mel_w, cmvn_mean, cmvn_std, feat, utt_sum,
+                               out_len, Tmax, nmel, frame_len, frame_shift, preemph, log_floor, stream);
 }
 
 extern "C" int ea_specaugment(float* feat, const int* lengths, const float* utt_sum, const int* fmask,

@@ -488,11 +488,12 @@ def fbank_batch(wav, offsets, B, tables, cmvn_mean, cmvn_std, Tmax, nmel=80, fra
     feat = torch.empty(B, Tmax, nmel, dtype=torch.float32, device=dev)
     utt_sum = torch.zeros(B, dtype=torch.float32, device=dev) if want_sum else None
     out_len = torch.empty(B, dtype=torch.int32, device=dev)
+    assert wav.dtype in (torch.float32, torch.int16)
+    fn = _lib.lib().ea_fbank_batch if wav.dtype == torch.float32 else _lib.lib().ea_fbank_batch_i16
     check(
-        _lib.lib().ea_fbank_batch(_p(wav), _p(offsets), B, _p(tables["window"]), _p(tables["twiddle"]),
-                                  _p(tables["mel_start"]), _p(tables["mel_len"]), _p(tables["mel_woff"]),
-                                  _p(tables["mel_w"]), _p(cmvn_mean), _p(cmvn_std), _p(feat), _p(utt_sum), _p(out_len),
-                                  Tmax, nmel, frame_len, frame_shift, preemph, log_floor, _stream()),
+        fn(_p(wav), _p(offsets), B, _p(tables["window"]), _p(tables["twiddle"]), _p(tables["mel_start"]), _p(tables["mel_len"]),
+           _p(tables["mel_woff"]), _p(tables["mel_w"]), _p(cmvn_mean), _p(cmvn_std), _p(feat), _p(utt_sum), _p(out_len), Tmax, nmel,
+           frame_len, frame_shift, preemph, log_floor, _stream()),
         "ea_fbank_batch",
     )
     return feat, out_len, utt_sum

@@ -39,10 +39,17 @@ def log(rank, kind, **kv):
 
 
 class Prefetcher:
-    """Collates batches on a host thread (`dataset.num_workers` of the reference: there, DataLoader worker processes running
-    fbank on the CPU; here only file reads + packing into a pinned buffer, the features are computed on the GPU)."""
+    """Collates batches ahead of the training loop (`dataset.num_workers` of the reference: there, DataLoader worker processes
+    running get_waveform + fbank on the CPU).  Here a batch is file decoding + packing into a pinned int16 buffer — the features
+    are computed on the GPU — and `num_workers` is the number of decoder threads of the library's batch reader
+    (csrc/ingest.hip ea_audio_read_batch_i16: one ctypes call per batch, outside the interpreter lock), driven by ONE host
+    thread that stays `depth` batches ahead."""
 
-    def __init__(self, dataset, batches, depth=4):
+    def __init__(self, dataset, batches, depth=4, num_workers=1):
+        src = getattr(dataset, "src", None)
+        if getattr(src, "is_wave", False):
+            src.lazy = True  # file entries reach the collater unread: it decodes the whole batch in parallel
+            src.num_workers = max(1, int(num_workers))
         self.q = queue.Queue(maxsize=max(1, depth))
         self.t = threading.Thread(target=self._run, args=(dataset, batches), daemon=True)
         self.t.start()
@@ -123,7 +130,8 @@ def validate(cfg, trainer, task, subsets, device, world, rank):
     for subset in subsets:
         ds = task.dataset(subset)
         logs = []
-        for sample in Prefetcher(ds, [b for b in _plan(task, ds, cfg, 1, world, rank, train=False) if len(b) > 0]):
+        for sample in Prefetcher(ds, [b for b in _plan(task, ds, cfg, 1, world, rank, train=False) if len(b) > 0],
+                                 num_workers=cfg["dataset"].get("num_workers", 1) or 1):
             _, _, lg = trainer.valid_step(task.to_device(sample, device))
             logs.append({k: float(v) for k, v in lg.items() if isinstance(v, (int, float)) or torch.is_tensor(v) and v.numel() == 1})
         if world > 1:
@@ -272,7 +280,8 @@ def main(argv=None):
         dummy_src = next((b for b in batches if len(b) > 0), None)
         todo = batches[skip:]
         done = skip
-        stream = iter(Prefetcher(train_ds, [b if len(b) > 0 else dummy_src for b in todo], depth=cfg["dataset"].get("data_buffer_size", 4) or 4))
+        stream = iter(Prefetcher(train_ds, [b if len(b) > 0 else dummy_src for b in todo], depth=cfg["dataset"].get("data_buffer_size", 4) or 4,
+                                 num_workers=cfg["dataset"].get("num_workers", 1) or 1))
         for size in update_group_sizes(len(batches), skip, uf):
             group = []
             for b in batches[done:done + size]:

@@ -175,6 +175,22 @@ int ea_cast_f32_to_bf16(const float* src, void* dst, long n, ea_stream_t stream)
 /* n <= 8 bf16 matrices in one launch: dst[i][c][r] = src[i][r][c] (rows[i] x cols[i], dense).  Used for the k-contiguous
  * copies of the Linear weights that the backward data-gradient GEMMs read (nn.Linear backward, x_grad = y_grad @ W). */
 int ea_transpose_bf16_batch(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, ea_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * Waveform ingestion (host code: no device work, no stream) for the `wave` entries of the data json —
+ * fairseq/data/audio/audio_utils.py:74-118 get_waveform (soundfile: PCM WAV and FLAC, mono = channel 0 as
+ * espresso/tools/utils.py:438-440, normalization=False -> int16 scale) called per utterance by
+ * espresso/data/feat_text_dataset.py:128-155 from `dataset.num_workers` DataLoader worker processes.  Files are decoded to int16
+ * straight into the caller's (pinned) staging buffer; the batch call decodes many files on `num_threads` host threads without
+ * touching Python objects.  Error codes: -1 unreadable, -3 not a WAV / FLAC file, -4 unsupported sample format, -5 capacity too
+ * small, -6 malformed FLAC stream, -7 FLAC frame checksum mismatch. */
+int ea_audio_probe(const char* path, long* num_samples, int* sample_rate, int* channels, int* bits);
+long ea_audio_read_i16(const char* path, int16_t* dst, long capacity, int* sample_rate);
+/* 1: the MD5 of the decoded audio equals the signature in the FLAC STREAMINFO block (or none is recorded; WAV: always 1), 0: differs */
+int ea_audio_verify(const char* path);
+/* file i -> dst[offsets[i] .. offsets[i+1]); lengths[i] = samples decoded (or the file's negative error); returns the failures */
+int ea_audio_read_batch_i16(const char* const* paths, int n, int16_t* dst, const long* offsets, int num_threads, long* lengths,
+                            int* sample_rates);
+
 /* fp32 [M][ld_src] -> bf16 [M][ld_dst], N valid columns per row, columns N .. ld_dst-1 zero-filled (M <= 65535): the fp32
  * gradient of the vocabulary logits re-pitched for the bf16 weight / data gradient GEMMs of the output layer
  * (espresso/models/transformer/speech_transformer_encoder_model.py:207-208 fc_out, torch autograd of F.linear). */
@@ -373,6 +389,12 @@ int ea_label_smoothed_ce(const void* logits, long ld, int logits_bf16, const int
  * the mean mask value); out_len int32 [B] = 1+(N-frame_len)/frame_shift.  window/twiddle/mel_* are
  * host-built tables (espresso_amd/data/fbank_tables.py).  Mask lists: int32 [B][n][2] = (start,width). */
 int ea_fbank_batch(const float* wav, const long* offsets, int B, const float* window, const float* twiddle,
+                   const int* mel_start, const int* mel_len, const int* mel_woff, const float* mel_w,
+                   const float* cmvn_mean, const float* cmvn_std, float* feat, float* utt_sum, int* out_len,
+                   int Tmax, int nmel, int frame_len, int frame_shift, float preemph, float log_floor,
+                   ea_stream_t stream);
+/* the same on int16 samples (what ea_audio_read_batch_i16 delivers): the conversion to fp32 is exact, half the bytes move */
+int ea_fbank_batch_i16(const int16_t* wav, const long* offsets, int B, const float* window, const float* twiddle,
                    const int* mel_start, const int* mel_len, const int* mel_woff, const float* mel_w,
                    const float* cmvn_mean, const float* cmvn_std, float* feat, float* utt_sum, int* out_len,
                    int Tmax, int nmel, int frame_len, int frame_shift, float preemph, float log_floor,
