@@ -274,6 +274,72 @@ def encdec_fixture(name="ref_transformer_encdec_tiny", dm=64, heads=4, ffn=128, 
     print([k for k in sd if k.startswith("decoder")][:40])
 
 
+def encdec_trained_fixture(name="ref_transformer_encdec_trained", dm=64, heads=4, ffn=128, updates=4000, noise=1.0):
+    """beam-search fixtures from a model that has LEARNED something, so that the margins at the beam edge are
+    real (random-weight fixtures tie there).  The reference's speech_transformer_base is trained here, with the reference's own
+    criterion arithmetic (label_smoothed_nll_loss, eps 0.1) and torch Adam, on the learnable synthetic task of tests/trajectory.py
+    (every token owns an 80-dim template held for 8 frames + noise); then the reference's SequenceGenerator decodes 9 held-out
+    utterances (3 batches of 3) with beam 3, beam 3 + eos_factor 1.5 and beam 1.  The fixture holds the TRAINED weights."""
+    from espresso.criterions.label_smoothed_cross_entropy_v2 import label_smoothed_nll_loss
+    from fairseq.sequence_generator import SequenceGenerator
+
+    sys.path.insert(0, ROOT)
+    from tests import trajectory as TJ
+
+    torch.manual_seed(2024)
+    V = 40
+    model, dic = _build_ref_encdec(dm, heads, ffn, V)
+    pad, eos = dic.pad(), dic.eos()
+    train = TJ.make_batches(500, seed=11, noise=noise)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3, betas=(0.9, 0.98), eps=1e-8)
+    model.train()
+    for it in range(updates):
+        feats, lens, tg = train[it % len(train)]
+        B, U = tg.shape
+        target = torch.full((B, U + 1), pad, dtype=torch.long)
+        prev = torch.full((B, U + 1), pad, dtype=torch.long)
+        for b in range(B):
+            L = int((tg[b] != 1).sum())
+            target[b, :L] = tg[b, :L]
+            target[b, L] = eos
+            prev[b, 0] = eos
+            prev[b, 1:L + 1] = tg[b, :L]
+        lo, _ = model(feats, lens, prev)
+        lprobs = torch.log_softmax(lo.float(), -1).view(-1, V)
+        loss, nll = label_smoothed_nll_loss(lprobs, target.view(-1, 1), 0.1, ignore_index=pad, reduce=True)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0)
+        opt.step()
+        if it % 50 == 0 or it == updates - 1:
+            print(f"update {it}: loss/token {loss.item() / (target != pad).sum().item():.3f} nll/token {nll.item() / (target != pad).sum().item():.3f}")
+    model.eval()
+    held = TJ.make_batches(3, seed=99, B=3, noise=noise)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    out = {}
+    n_right = n_tot = 0
+    for gi, (feats, lens, tg) in enumerate(held):
+        out[f"g{gi}::feats"], out[f"g{gi}::lengths"], out[f"g{gi}::target"] = feats.numpy(), lens.numpy(), tg.numpy()
+        for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)),
+                        ("b3_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, eos_factor=1.5)),
+                        ("b1", dict(beam_size=1, max_len_a=0.0, max_len_b=12))):
+            gen = SequenceGenerator([model], dic, **kw)
+            with torch.no_grad():
+                hyps = gen.generate([model], {"net_input": {"src_tokens": feats, "src_lengths": lens}})
+            for bi, hl in enumerate(hyps):
+                for hi, hyp in enumerate(hl):
+                    out[f"g{gi}::beam::{tag}::{bi}::{hi}::tokens"] = hyp["tokens"].numpy()
+                    out[f"g{gi}::beam::{tag}::{bi}::{hi}::score"] = np.array(float(hyp["score"]))
+                    out[f"g{gi}::beam::{tag}::{bi}::{hi}::pos"] = hyp["positional_scores"].numpy()
+                if tag == "b3":
+                    ref = [int(t) for t in tg[bi] if t != 1]
+                    n_right += int(hl[0]["tokens"].tolist()[:-1] == ref)
+                    n_tot += 1
+            print(gi, tag, [[h["tokens"].tolist() for h in hl][:2] for hl in hyps], [[round(float(h["score"]), 3) for h in hl] for hl in hyps])
+    print(f"{n_right} of {n_tot} held-out utterances decoded exactly by the reference's own beam search")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), groups=np.array(len(held)), **out, **{"sd::" + k: v.numpy() for k, v in sd.items()})
+
+
 # ------------------------------------------------------------------------------------------------
 # Training mode with dropout: the reference's own modules run with FairseqDropout fed from given masks
 class _FeedDropout:
@@ -1292,6 +1358,9 @@ if __name__ == "__main__":
         encoder_fixture("conformer", "ref_conformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
         encoder_fixture("transformer", "ref_transformer_ctc_dh64", d=128, heads=2, ffn=256, frames=300)
         encdec_fixture("ref_transformer_encdec_dh64", dm=128, heads=2, ffn=256, frames=300)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "encdec_trained":
+        encdec_trained_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ensemble":
         ensemble_fixture()

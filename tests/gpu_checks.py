@@ -1344,6 +1344,88 @@ def check_beam_search_vs_reference(fixture="ref_transformer_encdec_tiny"):
     return res
 
 
+def check_beam_search_trained(fixture="ref_transformer_encdec_trained"):
+    """Beam search on a TRAINED model: tests/golden/ref_transformer_encdec_trained.npz holds the weights of
+    the reference's speech_transformer_base after 4 000 updates on the learnable synthetic task (oracle/gen_golden.py
+    encdec_trained: the reference's own beam search decodes all 9 held-out utterances exactly) and what the reference's
+    SequenceGenerator returned for 9 utterances x {beam 3, beam 3 + eos_factor 1.5, beam 1}.  The HIP generator must return the
+    same best hypothesis for every one of the 27 searches, token for token; whole beams are compared wherever the search never
+    cut through a gap smaller than the score noise; greedy arg-max identity is counted over ALL decoding steps."""
+    from espresso_amd.sequence_generator import HipBeamSearch, SequenceGenerator
+
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    model = build_tiny_encdec(embed_dim=64, heads=4, ffn=128).to(DEV)
+    model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+    model.eval()
+    d = _TaskAR(40).target_dictionary
+
+    class Recording(HipBeamSearch):
+        def __init__(self, eos, beam):
+            self.eos, self.beam, self.min_gap, self.bsz0 = eos, beam, None, None
+
+        def step(self, step, lprobs, prev_scores, bsz, beam):
+            cs, ct, cb = super().step(step, lprobs, prev_scores, bsz, beam)
+            if self.bsz0 is None:
+                self.bsz0, self.min_gap = bsz, [float("inf")] * bsz
+            if bsz == self.bsz0 and cs.shape[1] > beam:
+                c, t = cs.cpu(), ct.cpu()
+                for i in range(bsz):
+                    gap = float(c[i, beam - 1] - c[i, beam])
+                    live = [float(x) for x, tk in zip(c[i], t[i]) if int(tk) != self.eos and x > -1e30]
+                    if len(live) > beam:
+                        gap = min(gap, live[beam - 1] - live[beam])
+                    if gap == gap:
+                        self.min_gap[i] = min(self.min_gap[i], gap)
+            return cs, ct, cb
+
+    top1, beams_equal_defined, n_defined, score_abs, n_steps, n_agree, exact_ref = [], [], 0, 0.0, 0, 0, 0
+    for gi in range(int(g["groups"])):
+        feats, lengths = torch.from_numpy(g[f"g{gi}::feats"]).to(DEV), torch.from_numpy(g[f"g{gi}::lengths"]).to(DEV)
+        sample = {"net_input": {"src_tokens": feats, "src_lengths": lengths}}
+        B = feats.shape[0]
+        for tag, kw in (("b3", dict(beam_size=3, max_len_a=0.0, max_len_b=12)),
+                        ("b3_eosf", dict(beam_size=3, max_len_a=0.0, max_len_b=12, eos_factor=1.5)),
+                        ("b1", dict(beam_size=1, max_len_a=0.0, max_len_b=12))):
+            rec = Recording(d.eos(), kw["beam_size"])
+            hyps = SequenceGenerator([model], d, search=rec, **kw).generate([model], sample)
+            for b, hl in enumerate(hyps):
+                ref, hi = [], 0
+                while f"g{gi}::beam::{tag}::{b}::{hi}::tokens" in g.files:
+                    ref.append((g[f"g{gi}::beam::{tag}::{b}::{hi}::tokens"].tolist(), float(g[f"g{gi}::beam::{tag}::{b}::{hi}::score"])))
+                    hi += 1
+                top1.append(hl[0]["tokens"].tolist() == ref[0][0])
+                score_abs = max(score_abs, abs(float(hl[0]["score"]) - ref[0][1]))
+                if rec.min_gap[b] > 0.03:
+                    n_defined += 1
+                    beams_equal_defined.append([h["tokens"].tolist() for h in hl] == [t for t, _ in ref])
+                if tag == "b3":
+                    tgt = [int(t) for t in g[f"g{gi}::target"][b] if t != 1]
+                    exact_ref += int(ref[0][0][:-1] == tgt)
+        # greedy identity over ALL steps: the reference's beam-1 tokens walked through the incremental decoder
+        ref_b1 = [torch.from_numpy(g[f"g{gi}::beam::b1::{b}::0::tokens"]) for b in range(B)]
+        L1 = max(t.numel() for t in ref_b1)
+        tk1 = torch.stack([torch.nn.functional.pad(t, (0, L1 - t.numel()), value=d.pad()) for t in ref_b1]).to(DEV)
+        with torch.no_grad():
+            enc_out = model.forward_encoder(feats, lengths)
+            st = model.decoder.init_incremental(enc_out, B, 1)
+            cur = torch.full((B, 1), d.eos(), dtype=torch.long, device=DEV)
+            for step in range(L1):
+                lp = model.decoder.step(st, cur, step, None if step == 0 else torch.arange(B, device=DEV)).float()
+                lp[:, d.pad()] = -math.inf
+                if step == 0:
+                    lp[:, d.eos()] = -math.inf  # min_len = 1
+                am = lp.argmax(-1)
+                for bi in range(B):
+                    if step < ref_b1[bi].numel():
+                        n_steps += 1
+                        n_agree += int(am[bi]) == int(tk1[bi, step])
+                cur = torch.cat([cur, tk1[:, step:step + 1]], 1)
+    return {"searches": len(top1), "top1_equal": sum(top1), "defined": n_defined, "defined_beams_equal": sum(beams_equal_defined),
+            "top1_score_abs": score_abs, "greedy_steps": n_steps, "greedy_agree": n_agree / max(1, n_steps),
+            "reference_decodes_target_exactly": exact_ref}
+
+
 # ------------------------------------------------------------------ RNN-T loss
 def check_rnnt(seed=0):
     from espresso_amd import functional as F

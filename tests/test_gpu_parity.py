@@ -360,6 +360,20 @@ def test_encdec_deferred_backward_matches_immediate():
     assert r["loss_rel"] < 1e-5 and r["worst_grad_rel"][0] < 2e-4, r   # (fp32 atomics: ~2e-7 run to run in the loss; measured 1.6e-5)
 
 
+
+def test_beam_search_on_a_trained_model_every_best_hypothesis_identical():
+    """on the reference's model TRAINED on the learnable task (its own beam search decodes the 9 held-out
+    utterances exactly), all 27 searches return the reference's best hypothesis token for token, every beam that was never cut
+    through a gap below the score noise is the reference's beam hypothesis for hypothesis, and the greedy arg-max equals the
+    reference's token on >= 99 % of ALL decoding steps."""
+    r = G.check_beam_search_trained()
+    print(r)
+    assert r["searches"] == 27 and r["reference_decodes_target_exactly"] == 9, r
+    assert r["top1_equal"] == 27 and r["top1_score_abs"] < 3e-2, r
+    assert r["defined"] >= 9 and r["defined_beams_equal"] == r["defined"], r
+    assert r["greedy_steps"] >= 60 and r["greedy_agree"] >= 0.99, r
+
+
 @pytest.mark.parametrize("fixture", ["ref_transformer_encdec_tiny", "ref_transformer_encdec_dh64"])
 def test_beam_search_vs_reference_generator(fixture):
     r = G.check_beam_search_vs_reference(fixture)
