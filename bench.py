@@ -416,6 +416,11 @@ def main(argv=None):
         cpu = cpu_baseline()
         # the same CPU port at the recipe's batch size (24 utterances: the host cores are better fed); ~45 s of CPU work
         cpu["at_recipe_batch"] = cpu_baseline(n_utts=24, steps=1)
+        # the REFERENCE's own modules (imported from /root/reference, dropout 0.1) cannot run on the GPU box: timed once in the
+        # build container (8 cores) by tools/cpu_reference_step.py and committed; quoted here next to the port
+        ref_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_cpu_reference_container.json")
+        if os.path.exists(ref_file):
+            cpu["reference_in_build_container"] = json.load(open(ref_file))
     decode = None
     if rank == 0 and world == 1 and not args.no_decode:
         del trainer, model, criterion, samples  # the decode model gets the GPU to itself

@@ -296,6 +296,7 @@ def main(argv=None):
             if n % cfg["common"]["log_interval"] == 0:
                 ss, ls, nt, ns = interval.tolist()  # the only host<-device read of the training loop
                 gnorm = float(trainer.last_coef[1]) if trainer.last_coef is not None else None
+                trainer.check_grad_norm_consistency()  # (fairseq/trainer.py:1451-1488; gathered inside the statistics all-reduce)
                 if gnorm is not None and not math.isfinite(gnorm):
                     # fairseq/trainer.py:949-958 (fp32): a non-finite gradient norm is fatal.  The fused Adam kernel leaves the
                     # parameters untouched for such a step; it is detected here, at the loop's only host<-device read.

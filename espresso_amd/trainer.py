@@ -16,6 +16,15 @@ from .optim.flat import FlatParams
 from .optim.noam_lr_scheduler import NoamSchedule
 
 
+def grad_norms_inconsistent(norms: torch.Tensor) -> torch.Tensor:
+    """1.0 (as a one-element tensor on `norms`' device) when the per-rank gradient norms differ — fairseq/trainer.py:1462-1475:
+    consistent = max |g_r - g_0| / (g_0 + 1e-6) < 1e-6, or every norm is non-finite (all ranks overflowed alike)."""
+    g0 = norms[0]
+    close = ((norms - g0).abs().max() / (g0 + 1e-6)) < 1e-6
+    all_bad = (~torch.isfinite(norms)).all()
+    return (~(close | all_bad)).to(torch.float32).reshape(1)
+
+
 class Trainer:
     def __init__(self, task, model, criterion, device, clip_norm=2.0, lr=5.0, warmup_steps=25000, adam_betas=(0.9, 0.98),
                  adam_eps=1e-8, weight_decay=0.0, final_lr=1e-6, seed=1, bucket_mb=64.0, lr_scheduler=None):
@@ -40,7 +49,9 @@ class Trainer:
         self.clip_norm = clip_norm
         self.seed = seed
         self.num_updates = 0
-        self._stats = torch.zeros(4, dtype=torch.float32, device=device)
+        # [sample_size, loss, ntokens, nsentences] + one slot per rank for the cross-rank gradient-norm check (below)
+        self._stats = torch.zeros(4 + (self.world_size if self.world_size > 1 else 0), dtype=torch.float32, device=device)
+        self._gnorm_mismatch = torch.zeros(1, dtype=torch.float32, device=device)  # updates whose gradient norms differed across ranks
         self.last_coef = None
         self._train_mode_checked = False
 
@@ -72,7 +83,17 @@ class Trainer:
             self._stats[2:3].add_(float(log["ntokens"]))
             self._stats[3:4].add_(float(log["nsentences"]))
         if self.ddp.active:
-            dist.all_reduce(self._stats)  # C3 + sample_size in one 16-byte collective
+            if self.world_size > 1 and self.last_coef is not None:
+                # fairseq/trainer.py:1451-1488 _check_grad_norms: every rank must have clipped the SAME gradient norm (they
+                # all-reduced the same buckets) — ranks that drifted apart train different models silently.  The reference
+                # all-gathers the norms in their own collective; here rank r writes the norm of the PREVIOUS update into its
+                # slot of the statistics vector, so the sum all-reduce that carries the step's scalars is also the gather
+                # (4 more bytes per rank, no extra collective, no host read: the verdict accumulates on the device and is
+                # read with the logging statistics, one update late).
+                self._stats[4 + dist.get_rank():5 + dist.get_rank()].copy_(self.last_coef[1:2])
+            dist.all_reduce(self._stats)  # C3 + sample_size (+ the gathered norms) in one small collective
+            if self.world_size > 1 and self.last_coef is not None:
+                self._gnorm_mismatch += grad_norms_inconsistent(self._stats[4:])
         self.ddp.all_reduce_grads()
         F.end_step()
         self.last_coef = self.optimizer.clip_and_step(pre_scale=1.0, max_norm=self.clip_norm, denom_dev=self._stats[0:1])
@@ -80,7 +101,17 @@ class Trainer:
         if hasattr(self.model, "set_num_updates"):
             self.model.set_num_updates(self.num_updates)
         self.lr_scheduler.step_update(self.num_updates)
-        return self._stats
+        return self._stats[:4]
+
+    def check_grad_norm_consistency(self):
+        """Host read (call it where the training statistics are read anyway): raises like fairseq/trainer.py:1477-1488 when any
+        update since the last call saw different gradient norms on different ranks."""
+        bad = float(self._gnorm_mismatch)
+        self._gnorm_mismatch.zero_()
+        if bad > 0:
+            raise FloatingPointError(
+                f"Fatal error: gradients are inconsistent between workers ({int(bad)} update(s) since the last check). "
+                "Try --ddp-backend=legacy_ddp. Or are you mixing up different generation of GPUs in training?")
 
     def reserve(self, samples):
         """Size every grow-only arena (saved activations per layer, scratch, split-K slabs, allocator pools) for the largest
