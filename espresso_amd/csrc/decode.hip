@@ -58,6 +58,111 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const bf16_t* __r
   if (lane < dh) out[(long)n * ldq + h * dh + lane] = f2bf(acc / sum);
 }
 
+// The same for head dims 16 / 32 / 64 with 16-byte aligned rows (every recipe): the kernel above moves ONE bf16 per lane and key
+// and folds 64 lanes per key (six shuffles inside a serial loop over the keys: 183 us per call in the config-5 decode block, 59 %
+// of its kernel time — round 5 trace).  Here a wavefront takes 16 keys per trip: lane = (key group l >> 2, channel quarter l & 3)
+// loads DH / 4 channels of its key in one 8 / 16 / 32-byte piece (a key's row = 4 neighbouring lanes: whole 128-byte lines), two
+// shuffle steps finish a score, and the P·V pass accumulates DH / 4 channels per lane over its keys (four shuffle steps at the end).
+template <int DH>
+__global__ __launch_bounds__(256) void decode_attention_vec_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ K,
+                                                                   const bf16_t* __restrict__ V, const int* __restrict__ kv_row,
+                                                                   const int* __restrict__ len, bf16_t* __restrict__ out, int N, int H,
+                                                                   long ldq, long row_stride, long ldkv, int koff, int voff, int fixed_len) {
+  constexpr int E = DH / 4;  // channels per lane
+  extern __shared__ float sprob[];  // [4 waves][Lpad]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 4 + wave;
+  if (gw >= N * H) return;
+  const int n = gw / H, h = gw % H;
+  const int r = kv_row ? kv_row[n] : n;
+  const int L = len ? len[r] : fixed_len;
+  float* pr = sprob + (long)wave * ((fixed_len + 63) / 64 * 64);
+  const int kg = lane >> 2, cq = lane & 3;
+  auto load_e = [&](const bf16_t* p, float (&o)[E]) {
+    if constexpr (E == 4) {
+      const uint2 u = *reinterpret_cast<const uint2*>(p);
+      o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+      o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+#pragma unroll
+      for (int c = 0; c < E / 8; ++c) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p + c * 8);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[c * 8 + 2 * e] = __uint_as_float(w[e] << 16);
+          o[c * 8 + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        }
+      }
+    }
+  };
+  float qv[E];
+  load_e(q + (long)n * ldq + h * DH + cq * E, qv);
+  const bf16_t* Kb = K + (long)r * row_stride + koff + h * DH + cq * E;
+  const bf16_t* Vb = V + (long)r * row_stride + voff + h * DH + cq * E;
+  float mx = -INFINITY;
+  for (int j0 = 0; j0 < L; j0 += 32) {  // two key groups per trip: both loads are in flight before the first dot product
+    const int ja = j0 + kg, jb = ja + 16;
+    float ka[E], kb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) ka[e] = kb[e] = 0.f;
+    if (ja < L) load_e(Kb + (long)ja * ldkv, ka);
+    if (jb < L) load_e(Kb + (long)jb * ldkv, kb);
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      pa += qv[e] * ka[e];
+      pb += qv[e] * kb[e];
+    }
+    pa += __shfl_xor(pa, 1, 64);
+    pb += __shfl_xor(pb, 1, 64);
+    pa += __shfl_xor(pa, 2, 64);
+    pb += __shfl_xor(pb, 2, 64);
+    if (ja < L) {
+      if (cq == 0) pr[ja] = pa;
+      mx = fmaxf(mx, pa);
+    }
+    if (jb < L) {
+      if (cq == 0) pr[jb] = pb;
+      mx = fmaxf(mx, pb);
+    }
+  }
+  mx = wave_max(mx);
+  __builtin_amdgcn_wave_barrier();
+  float sum = 0.f;
+  for (int j = lane; j < L; j += 64) {
+    const float e = __expf(pr[j] - mx);
+    pr[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll 4
+  for (int j0 = 0; j0 < L; j0 += 16) {
+    const int j = j0 + kg;
+    if (j < L) {
+      float vv[E];
+      load_e(Vb + (long)j * ldkv, vv);
+      const float pj = pr[j];
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] += pj * vv[e];
+    }
+  }
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += __shfl_xor(acc[e], m, 64);
+  if (kg == 0) {
+    const float inv = 1.f / sum;
+    bf16_t* o = out + (long)n * ldq + h * DH + cq * E;
+#pragma unroll
+    for (int e = 0; e < E; e += 2) *reinterpret_cast<uint32_t*>(o + e) = pack_bf2(acc[e] * inv, acc[e + 1] * inv);
+  }
+}
+
 // new_cache[n][0:L] = old_cache[parent[n]][0:L] ; new_cache[n][L] = kv_new[n]    (row = 2C bf16: k | v)
 __global__ __launch_bounds__(256) void kv_append_reorder_kernel(const bf16_t* __restrict__ old_cache, bf16_t* __restrict__ new_cache,
                                                                 const bf16_t* __restrict__ kv_new, const int* __restrict__ parent,
@@ -157,6 +262,17 @@ extern "C" int ea_decode_attention(const void* q, const void* K, const void* V, 
   if (dh > 64 || max_len <= 0) return -2;
   const size_t lds = (size_t)4 * ((max_len + 63) / 64 * 64) * sizeof(float);
   if (lds > 64 * 1024) return -3;
+  static const int vec_on = [] { const char* e = getenv("EA_DECODE_ATTN_VEC"); return e ? atoi(e) : 1; }();  // (diagnostic A/B switch)
+  const bool aligned = ((ldq | row_stride | ldkv | koff | voff) & 7) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec_on && aligned && (dh == 64 || dh == 32 || dh == 16)) {
+    const dim3 grid((N * H + 3) / 4), block(256);
+#define EA_DA(D) hipLaunchKernelGGL(decode_attention_vec_kernel<D>, grid, block, lds, stream, (const bf16_t*)q, (const bf16_t*)K, (const bf16_t*)V, \
+                                    kv_row, len, (bf16_t*)out, N, H, ldq, row_stride, ldkv, koff, voff, max_len)
+    if (dh == 64) EA_DA(64); else if (dh == 32) EA_DA(32); else EA_DA(16);
+#undef EA_DA
+    return EA_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(decode_attention_kernel, dim3((N * H + 3) / 4), dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)K,
                      (const bf16_t*)V, kv_row, len, (bf16_t*)out, N, H, dh, ldq, row_stride, ldkv, koff, voff, max_len);
   return EA_CHECK_LAUNCH();

@@ -8,7 +8,11 @@ nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 c = sqlite3.connect(db)
 rows = c.execute("select start, end, name from kernels order by start").fetchall()
 adam = [r for r in rows if "adam_kernel" in r[2]]
-t0, t1 = adam[-nsteps - 1][1], adam[-1][1]
+if len(adam) > nsteps:
+    t0, t1 = adam[-nsteps - 1][1], adam[-1][1]
+else:  # not a training trace (e.g. the decode block): the whole trace after the first tenth (start-up) as ONE "step"
+    nsteps = 1
+    t0, t1 = rows[len(rows) // 10][0], rows[-1][1]
 sel = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 busy, cur_end, gaps, prev = 0, t0, [], "<step start>"
 for s, e, n in sel:
