@@ -26,6 +26,7 @@ import torch.distributed as dist  # noqa: E402
 
 VOCAB = 5004
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0  # HBM3E peak, same guide
 
 
 def build(device, seed=1):
@@ -209,7 +210,40 @@ def decode_bench(device, n_utts=200, beam=10, seed=3):
                          "<=15000 frames & <=24 utts per batch, max_len 0.08*frames, conv4 + Transformer-12 encoder + 6-layer decoder, "
                          "bf16, random init (every hypothesis runs to max_len: worst case)",
              "target_rtf": 0.05}
+    block["roofline"] = decode_attention_roofline(device, beam)
     return block, model, d
+
+
+def decode_attention_roofline(device, beam, n_sent=24, S=156, H=8, dh=64, reps=50):
+    """HBM roofline of the decode path's dominant kernel (profiles/r05_decode_kernel_trace.txt): the cross-attention launch of one
+    decoding step of a full batch — `n_sent * beam` single-row queries against the beam-deduplicated encoder K/V of `n_sent`
+    utterances (S = 15000 frames / 24 utterances / 4 positions).  Algorithmic bytes = every K/V row once + q + out (the `beam`
+    hypotheses of an utterance share its rows through L2); timed with events on the launch stream."""
+    from espresso_amd import kernels as K
+
+    C, N = H * dh, n_sent * beam
+    g = torch.Generator(device="cpu").manual_seed(11)
+    kv = torch.randn(n_sent, S, 2 * C, generator=g).to(device=device, dtype=torch.bfloat16)
+    q = (torch.randn(N, C, generator=g) * dh ** -0.5).to(device=device, dtype=torch.bfloat16)
+    kv_row = (torch.arange(N, device=device, dtype=torch.int32) // beam).contiguous()
+    lens = torch.full((n_sent,), S, device=device, dtype=torch.int32)
+    for _ in range(5):
+        K.decode_attention(q, kv, None, kv_row, lens, N, H, dh, S * 2 * C, 2 * C, 0, C, S)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        K.decode_attention(q, kv, None, kv_row, lens, N, H, dh, S * 2 * C, 2 * C, 0, C, S)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    nbytes = kv.numel() * 2 + 2 * q.numel() * 2
+    ach = nbytes / us * 1e-3
+    return {"bound": "hbm", "kernel": "decode_attention_vec_kernel<64> (cross-attention of one decoding step)", "achieved": ach,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None, "us_per_launch": us,
+            "algorithmic_bytes_per_launch": nbytes, "lane_bytes_per_launch": kv.numel() * 2 * beam + 2 * q.numel() * 2,
+            "shape": f"{N} hypotheses ({n_sent} utterances x beam {beam}), {H} heads x {dh}, {S} encoder positions",
+            "note": "back-to-back launches on one stream (includes the ~2 us launch boundary); 1920 single-wave blocks: latency- "
+                    "and occupancy-bound, not bandwidth-bound"}
 
 
 def decode_cpu_baseline(model, d, n_utts=6, seconds=6.4, beam=10):
@@ -397,11 +431,11 @@ def main(argv=None):
         # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
         # command, tools/pmc_bench_traffic.sh; counters cannot be read from inside the process)
         traffic = None
-        tname = next((n for n in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
+        tname = next((n for n in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
                       if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n))), None)
         if tname:
             traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname))).get("hbm_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel+gemm_glds_kernel+wgrad_group_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel+gemm_glds_kernel+gemm_w8_kernel+wgrad_group_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tname})",
                     "traffic_source": "constant read from the committed rocprofv3 --pmc run named in traffic_unit (counters cannot be "
