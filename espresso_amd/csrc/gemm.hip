@@ -28,6 +28,7 @@
 
 // 8-wave large-tile kernels (gemm_w8.hip): takes the launch (returns 1) or leaves it to the kernels below (0)
 int ea_gemm_w8_try(const EaGemmParams& q, int nt_flag, hipStream_t stream, int* cfg_out);
+int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out);  // wgrad_w8.hip
 // Hint from the layer runtime (engine.hip): the launches that follow run NEXT TO side-stream work (the backward pass: grouped weight
 // gradients of 2 x 64 KB of LDS per CU).  A one-workgroup-per-CU kernel with 128 - 144 KB of LDS cannot share a CU with them: it
 // waits for both to drain and then keeps them out, so the 8-wave kernels, 10 - 15 % faster alone, lose in that half of the step
@@ -1077,6 +1078,14 @@ static bool fast_epilogue_ok(const EaGemmParams& q) {
          (!q.C2 || ((q.ldc2 & 7) == 0 && al(q.C2))) &&
          (!q.q_u || ((q.ld_q & 7) == 0 && al(q.q_u) && al(q.q_v) && al(q.pos_u) && al(q.pos_v)));
 }
+// the 8-wave kernels' register epilogue also takes a plain (bias / activation / dropout only) product whose N is not a multiple of 128
+// when the row pitch covers the last 32-column store group (the transducer joint's vocabulary projection: N = 5004, pitch 5056):
+// the columns N .. pitch - 1 of a row are padding, whatever lands there is never read
+static bool w8_ragged_ok(const EaGemmParams& q) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return g_fast_epi && !q.c_f32 && q.splitk == 1 && q.batch == 1 && !q.resid && !q.aux && !q.C2 && !q.q_u && q.N % 4 == 0 &&
+         (q.ldc & 7) == 0 && q.ldc >= (q.N + 31) / 32 * 32 && al(q.C) && (!q.bias || al(q.bias));
+}
 template <int BM_, int NST>
 static bool launch_glds(dim3 grid, hipStream_t stream, const EaGemmParams& q, int sw) {
   constexpr int bytes = NST * (BM_ + BN) * ROW_BYTES;
@@ -1157,7 +1166,7 @@ extern "C" int ea_gemm_bf16(const EaGemmParams* pp, hipStream_t stream) {
   }
   bool done = false;
   const bool kc_ok = glds_eligible(q);
-  if (kc_ok && fast_epilogue_ok(q) && (!g_gemm_corun || g_w8_corun)) {  // one 512-thread workgroup per CU on a large tile when the grid fits the chip
+  if (kc_ok && (fast_epilogue_ok(q) || w8_ragged_ok(q)) && (!g_gemm_corun || g_w8_corun)) {  // one 512-thread workgroup per CU on a large tile when the grid fits the chip
     int cfg = 0;
     if (ea_gemm_w8_try(q, nt_flag(q), stream, &cfg)) {
       done = true;
@@ -1277,6 +1286,15 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
     }
     pr.M = total; pr.N = g.count; pr.K = g.p[0].M; pr.batch = 1; pr.a_ks = 1; pr.b_ks = 1; pr.splitk = 1; pr.bm64 = bm64; pr.epi = 128;
     hipEventRecord(pr.e0, stream);
+  }
+  // long reductions over chip-filling 256 x 256 tile grids (the transducer joint's slabs): the 8-wave kernel of wgrad_w8.hip
+  if (ea_wgrad_w8_try(g, stream, nullptr)) {
+    if (g_prof_on) {
+      pr.bm64 = 108;
+      hipEventRecord(pr.e1, stream);
+      g_prof.push_back(pr);
+    }
+    return EA_CHECK_LAUNCH();
   }
   // rows 16-byte aligned and whole tiles readable everywhere: direct-to-LDS kernel with transposing fragment reads
   if (tr_ok) {

@@ -19,6 +19,7 @@
 // 0 = never, 1 = automatic (default), 2 .. 5 = forced tile configuration (diagnostic): 2 = 256x256 / 2 stages, 3 = 128x128 / 4 stages,
 // 4 = 256x128 / 3 stages, 5 = 128x256 / 3 stages
 static int g_gemm_w8 = [] { const char* e = getenv("EA_GEMM_W8"); return e ? atoi(e) : 1; }();
+static long g_w8_many = [] { const char* e = getenv("EA_GEMM_W8_MANY"); return e ? atol(e) : 1024L; }();  // tiles from which "many rounds" applies
 
 namespace {
 
@@ -49,74 +50,6 @@ __device__ __forceinline__ void w8_sched_groups() {
     if constexpr (G + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, AG + ((G + 1) % GPK == 0 ? NJ : 0), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, AG * NJ, 0);
     w8_sched_groups<NG, GPK, AG, NJ, G + 1>();
-  }
-}
-
-// Tile epilogue: accumulators -> fp32 LDS slab of 64 rows (row pitch BN_ + 4 floats: the four 4-row groups of an MFMA tile land on
-// banks 16 apart) -> every thread finishes one 8-column chunk of a row per pass through epilogue_chunk<true>.
-// acc[i][j][r] = C[m0 + row0 + i*16 + (lane>>4)*4 + r][n0 + col0 + j*16 + (lane&15)] for a wavefront that owns a TM x TN piece at
-// (row0, col0) of the BM_ x BN_ tile; `active` = this wavefront holds accumulators at all (ping-pong kernel: one half only).
-template <int BM_, int BN_, int TM, int TN>
-__device__ __forceinline__ void w8_tile_epilogue(const EaGemmParams& p, const f32x4_t (&acc)[TM / 16][TN / 16], float* sC, int m0, int n0, bool nt,
-                                                 bool active, int row0, int col0) {
-  constexpr int NJ = TN / 16;
-  constexpr int PITCH = BN_ + 4;         // floats
-  constexpr int CH = BN_ / 8;            // 8-column chunks per row
-  constexpr int RPP = 512 / CH;          // rows per pass
-  constexpr int NP = 64 / RPP;           // passes per 64-row slab
-  static_assert(TM == 64 || TM == 128, "a 64-row slab must belong to one row of wavefronts");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int cc = tid % CH, rr = tid / CH;
-  const int n = n0 + cc * 8;
-  float bias8[8], posu8[8], posv8[8];
-  load_bias8(p, n, bias8);
-  load_pos8(p, n, posu8, posv8);
-  const int pre_kind = p.resid ? 1 : p.aux ? 2 : 0;
-  const bf16_t* pre_base = pre_kind == 1 ? reinterpret_cast<const bf16_t*>(p.resid) : reinterpret_cast<const bf16_t*>(p.aux);
-  const long pre_ld = pre_kind == 1 ? p.ldr : p.ldaux;
-  const bool col_ok = n < p.N;  // (N % 8 == 0: a chunk is whole or absent)
-#pragma unroll
-  for (int slab = 0; slab < BM_ / 64; ++slab) {
-    uint4 pre[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) pre[q] = uint4{0, 0, 0, 0};
-    if (pre_kind && col_ok) {  // residual (else auxiliary) rows of all passes in one round trip, under the LDS bounce
-      const bf16_t* q0 = pre_base + n;
-      const int mr = m0 + slab * 64 + rr, ml = p.M - 1;
-#pragma unroll
-      for (int q = 0; q < NP; ++q) pre[q] = *reinterpret_cast<const uint4*>(q0 + (long)min(mr + q * RPP, ml) * pre_ld);
-    }
-    __syncthreads();  // (slab 0: every wavefront has finished reading operand stages; later: the previous slab has been read out)
-    if (slab == 0) EA_STAMP(5);
-    constexpr int IPS = 4;  // 16-row MFMA tiles per slab
-    if (active && row0 == (TM == 64 ? slab * 64 : (slab / 2) * 128)) {
-#pragma unroll
-      for (int ii = 0; ii < IPS; ++ii) {
-        const int i = TM == 64 ? ii : (slab % 2) * 4 + ii;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sC[(ii * 16 + (lane >> 4) * 4 + r) * PITCH + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
-      }
-    }
-    __syncthreads();
-    if (slab == 0) EA_STAMP(6);
-    if (m0 + slab * 64 < p.M && col_ok) {
-#pragma unroll 1
-      for (int pass = 0; pass < NP; ++pass) {
-        const int rl = pass * RPP + rr;
-        const int m = m0 + slab * 64 + rl;
-        if (m < p.M) {
-          float v[8];
-          const float4 x0 = *reinterpret_cast<const float4*>(sC + rl * PITCH + cc * 8);
-          const float4 x1 = *reinterpret_cast<const float4*>(sC + rl * PITCH + cc * 8 + 4);
-          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          epilogue_chunk<true>(p, 0, 0, 0, 0, 0L, m, n, v, bias8, posu8, posv8, true, nt, pre_kind, pre[0]);
-        }
-#pragma unroll
-        for (int q = 0; q + 1 < NP; ++q) pre[q] = pre[q + 1];
-      }
-    }
   }
 }
 
@@ -224,7 +157,7 @@ __device__ __forceinline__ void w8_reg_epilogue(const EaGemmParams& p, const f32
     }
 #pragma unroll
     for (int jp = 0; jp < NJ / 2; ++jp) {
-      if (n0 + col0 + jp * 32 >= p.N) continue;  // (N % 128 == 0: a pair of tiles is whole or absent; uniform per wavefront)
+      if (n0 + col0 + jp * 32 >= p.N) continue;  // (uniform per wavefront; a pair that straddles N stores into the row's padding: w8_ragged_ok)
       const int ns = npair + jp * 32;
       // operand of the epilogue in the stored layout -> swap -> this lane's 4 columns of tile 2jp (.x/.y of r0) and 2jp+1 (r1)
       float opnd[2][4];
@@ -320,12 +253,11 @@ __device__ __forceinline__ void w8_reg_epilogue(const EaGemmParams& p, const f32
 // grid: 1-D, one workgroup per output tile (tiles_n fastest); flags bit 0: XCD-aware tile order, bit 1: non-temporal stores
 template <int BM_, int BN_, int WM_, int WN_, int NST, int PIPE, int KIND>
 __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(const EaGemmParams p, const int tiles_n, const int flags) {
-  extern __shared__ __attribute__((aligned(16))) char dsm[];  // the ONLY LDS object: ring of operand stages, then the fp32 slab
+  extern __shared__ __attribute__((aligned(16))) char dsm[];  // the ONLY LDS object: ring of operand stages
   constexpr int TM = BM_ / WM_, TN = BN_ / WN_, MI = TM / 16, NJ = TN / 16;
   constexpr int A_BYTES = BM_ * 128, STAGE = (BM_ + BN_) * 128;
   constexpr int NA = BM_ / 64, NB = BN_ / 64;  // load instructions per wavefront and stage (one instruction = 8 rows of 128 B)
   static_assert(WM_ * WN_ == 8 && NST >= 2, "eight wavefronts");
-  static_assert(64 * (BN_ + 4) * 4 <= NST * STAGE, "the fp32 slab reuses the ring");
   EA_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -506,10 +438,17 @@ int ea_gemm_w8_try(const EaGemmParams& q, int nt_flag, hipStream_t stream, int* 
     // one tile's epilogue with another's k loop.
     const long rm256 = (q.M + 255) / 256, rm128 = (q.M + 127) / 128, cn256 = (q.N + 255) / 256, cn128 = (q.N + 127) / 128;
     auto fits = [](long tiles) { return tiles > 128 && tiles <= 256; };
-    if (fits(rm256 * cn256)) cfg = 2;
-    else if (fits(rm256 * cn128)) cfg = 4;
-    else if (fits(rm128 * cn256)) cfg = 5;
-    else if (fits(rm128 * cn128)) cfg = 3;
+    const bool whole = q.N % 128 == 0;  // (a ragged N is only taken in the many-round case below)
+    if (whole && fits(rm256 * cn256)) cfg = 2;
+    else if (whole && fits(rm256 * cn128)) cfg = 4;
+    else if (whole && fits(rm128 * cn256)) cfg = 5;
+    else if (whole && fits(rm128 * cn128)) cfg = 3;
+    // Many dispatch rounds (the transducer joint at 70 000 lattice rows: 5 480 tiles of 256 x 256 forward, 1 096 of 256 x 128 for
+    // the data gradient): the round quantisation and the lock-step epilogues of the single-round case wash out, what counts is
+    // operand bytes per flop — forward 722 -> 489 us isolated (profiles/r05_joint_gemm_probe.txt); the data gradient (N = 512,
+    // K = 5056) gains nothing (417 -> 406 .. 419 us) and stays eligible only because its tile count says so
+    else if (rm256 * cn256 >= g_w8_many && q.N >= 1024) cfg = 2;
+    else if (rm256 * cn128 >= g_w8_many) cfg = 4;
     else return 0;
   }
   const int flags = 1 | nt_flag;

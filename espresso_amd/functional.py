@@ -1916,10 +1916,12 @@ class _TransducerJoint(torch.autograd.Function):
 def _joint_wgrad(dl, Z, n, V, J, Vp):
     """dW [V][J] = dl^T Z and db = column sums of dl over all n lattice nodes.  The reduction is cut into row slabs that go
     through ONE grouped weight-gradient launch (direct-to-LDS kernel with transposing reads; the bias sums ride along as an
-    extra MFMA against ones), each slab into its own fp32 output, summed afterwards: ~950 tiles for 256 CUs instead of 316
-    long ones, no split-K workspace pass, no separate 1.5 GB column-sum pass."""
-    tiles = ((V + 63) // 64) * ((J + 127) // 128)
-    slabs = max(1, min(8, (768 + tiles - 1) // tiles, n // 4096))
+    extra MFMA against ones), each slab into its own fp32 output, summed afterwards: no split-K workspace pass, no separate
+    1.5 GB column-sum pass."""
+    # as many slabs as put one 256 x 256 tile of the 8-wave kernel (csrc/wgrad_w8.hip) on every CU: 40 tiles x 6 slabs for V = 5004,
+    # J = 512 (with the 64 x 128 tiles of the 4-wave kernel the same slabs are ~1 900 short tiles: it takes either)
+    tiles = ((V + 255) // 256) * ((J + 255) // 256)
+    slabs = max(1, min(8, 256 // tiles, n // 4096))
     if slabs == 1 or (Vp * 2) % 16 or (J * 2) % 16:
         return _wgrad(dl, Z, n, V, J, ld_dy=Vp), K.colsum(dl, torch.zeros(V, dtype=torch.float32, device=dl.device), n, V, Vp)
     dws = torch.zeros(slabs, V, J, dtype=torch.float32, device=dl.device)

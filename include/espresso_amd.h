@@ -134,6 +134,10 @@ int ea_wgrad_group(const EaWgradGroup* group, ea_stream_t stream);
  * tile height, ld_x >= K rounded up to 128) take the direct-to-LDS kernel with transposing fragment reads, 0 = always the
  * register-staged kernel; returns the previous value */
 int ea_set_wgrad_transposing_reads(int on);
+/* tuning hook for the 8-wavefront 256 x 256 kernel (csrc/wgrad_w8.hip: groups of long reductions whose 256 x 256 tile grid fills
+ * the chip — the transducer joint's output layer cut into row slabs): 0 = never, 1 (default) = automatic, 2 = every group whose
+ * operands are 16-byte aligned; returns the previous value.  Results are bit-identical to the 4-wave kernels. */
+int ea_set_wgrad_w8(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — fairseq/modules/layer_norm.py:28-33; with optional fused

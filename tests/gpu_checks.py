@@ -286,6 +286,61 @@ def check_conv3x3(Cin=64, Cout=128, sy=2, sx=2, B=2, T=37, F=21, seed=0):
     return res
 
 
+def check_wgrad_w8(seed=0):
+    """The 8-wavefront 256 x 256 weight-gradient kernel (csrc/wgrad_w8.hip, forced) against the 4-wave transposing kernel on the
+    same group: dW bit for bit, db within fp32 reassociation (1e-6 relative), and both against fp64 torch.  Ragged M (rows past M
+    from the zero page: M = 64 k + 1, M < 64), N / K that are not multiples of 256, row pitches shorter than the last tile
+    (the joint's 5004 columns at pitch 5056), accumulation into non-zero dW / db, problems with and without bias."""
+    import ctypes
+
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    # (M, N, K, pad_dy, pad_x, bias)
+    probs = [(4161, 1256, 512, 24, 0, True), (777, 512, 384, 0, 8, True), (63, 256, 256, 0, 0, True), (1000, 296, 128, 24, 0, False),
+             (129, 640, 768, 0, 0, True), (520, 5004, 512, 52, 0, True)]
+    data = []
+    for (M, N, K, pdy, px, bias) in probs:
+        dy = bf(torch.randn(M, N + pdy, generator=g)).to(DEV)
+        x = bf(torch.randn(M, K + px, generator=g)).to(DEV)
+        dW0 = torch.randn(N, K, generator=g).to(DEV)
+        db0 = torch.randn(N, generator=g).to(DEV) if bias else None
+        data.append((dy, x, dW0, db0))
+
+    def run(mode):
+        old = lib.ea_set_wgrad_w8(mode)
+        grp = _lib.EaWgradGroup()
+        grp.count = len(probs)
+        outs = []
+        for i, ((M, N, K, pdy, px, bias), (dy, x, dW0, db0)) in enumerate(zip(probs, data)):
+            dW, db = dW0.clone(), (db0.clone() if bias else None)
+            q = grp.p[i]
+            q.dy, q.x, q.dW, q.dbias = dy.data_ptr(), x.data_ptr(), dW.data_ptr(), (db.data_ptr() if bias else None)
+            q.M, q.N, q.K, q.ld_dy, q.ld_x, q.ldw = M, N, K, N + pdy, K + px, K
+            outs.append((dW, db))
+        try:
+            _lib.check(lib.ea_wgrad_group(ctypes.byref(grp), Kk._stream()), "ea_wgrad_group")
+            torch.cuda.synchronize()
+        finally:
+            lib.ea_set_wgrad_w8(old)
+        return outs
+
+    ref = run(0)
+    got = run(2)
+    out = {"dW_bits_differ": 0, "db_rel_vs_4wave": 0.0, "dW_rel": 0.0, "db_rel": 0.0}
+    for (M, N, K, pdy, px, bias), (dy, x, dW0, db0), (rW, rb), (gW, gb) in zip(probs, data, ref, got):
+        out["dW_bits_differ"] += int((rW.view(torch.int32) != gW.view(torch.int32)).sum())
+        r64 = dW0.double() + dy[:, :N].double().t() @ x[:, :K].double()
+        out["dW_rel"] = max(out["dW_rel"], float((gW.double() - r64).abs().max() / r64.abs().max()))
+        if bias:
+            out["db_rel_vs_4wave"] = max(out["db_rel_vs_4wave"], float((gb - rb).abs().max() / rb.abs().max()))
+            b64 = db0.double() + dy[:, :N].double().sum(0)
+            out["db_rel"] = max(out["db_rel"], float((gb.double() - b64).abs().max() / b64.abs().max()))
+    return out
+
+
 def check_wgrad_group(seed=0, variant=0, aligned=False, tr=1):
     """ea_wgrad_group (all weight / bias gradients of a layer in one launch) vs fp32 torch on the same bf16 operands:
     ragged N / K / M, padded leading dimensions, accumulation into non-zero dW / db, problems with and without bias.

@@ -81,8 +81,16 @@ def test_wgrad_group_whole_tile_problems(variant, tr):
     assert r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
 
 
+def test_wgrad_8wave_256_tiles_bit_identical_to_4wave():
+    r = G.check_wgrad_w8()
+    print(r)
+    assert r["dW_bits_differ"] == 0 and r["db_rel_vs_4wave"] < 1e-6 and r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
+
+
 def test_transducer_joint_weight_gradient_at_recipe_width():
     r = G.check_joint_wgrad()
+    assert r["shape_ok"] and r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
+    r = G.check_joint_wgrad(n=33000, seed=1)  # six slabs x 40 tiles of 256 x 256: the 8-wave kernel's automatic case
     assert r["shape_ok"] and r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
 
 
