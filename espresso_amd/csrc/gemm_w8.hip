@@ -443,12 +443,10 @@ int ea_gemm_w8_try(const EaGemmParams& q, int nt_flag, hipStream_t stream, int* 
     else if (whole && fits(rm256 * cn128)) cfg = 4;
     else if (whole && fits(rm128 * cn256)) cfg = 5;
     else if (whole && fits(rm128 * cn128)) cfg = 3;
-    // Many dispatch rounds (the transducer joint at 70 000 lattice rows: 5 480 tiles of 256 x 256 forward, 1 096 of 256 x 128 for
-    // the data gradient): the round quantisation and the lock-step epilogues of the single-round case wash out, what counts is
+    // Many dispatch rounds (the transducer joint's vocabulary projection at 70 000 lattice rows: 5 480 tiles of 256 x 256): the round quantisation and the lock-step epilogues of the single-round case wash out, what counts is
     // operand bytes per flop — forward 722 -> 489 us isolated (profiles/r05_joint_gemm_probe.txt); the data gradient (N = 512,
-    // K = 5056) gains nothing (417 -> 406 .. 419 us) and stays eligible only because its tile count says so
+    // K = 5056) gains nothing from any 8-wave tile (417 -> 406 .. 460 us) and stays with the 4-wave kernel
     else if (rm256 * cn256 >= g_w8_many && q.N >= 1024) cfg = 2;
-    else if (rm256 * cn128 >= g_w8_many) cfg = 4;
     else return 0;
   }
   const int flags = 1 | nt_flag;

@@ -39,25 +39,61 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(const TIn* __restrict__ l
   float mx = -INFINITY, s = 0.f;
   if constexpr (sizeof(TIn) == 2) {
     if ((ld & 7) == 0 && (((uintptr_t)logits) & 15) == 0) {
-      // rows padded to a multiple of 8 elements: 16-byte loads (8 logits per lane and step; the second pass hits L1 / L2)
+      // rows padded to a multiple of 8 elements: 16-byte loads, 8 logits per lane and chunk
       const int nch = (V + 7) >> 3;
-      for (int c = lane; c < nch; c += 64) {
-        const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+      constexpr int MAXC = 12;  // chunks per lane held in registers: rows up to 6144 logits make ONE trip to memory
+      if (nch <= 64 * MAXC) {
+        // every load of the row is requested before the first is used (the two-pass loop below waits for each 16-byte load in
+        // turn: 20 dependent round trips per 10 KB row — 465 us for the recipe's 708 MB of logits, 1.5 TB/s); the arithmetic and
+        // its order are those of the loop below: same bits
+        uint4 q[MAXC];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
-          if (c * 8 + e < V) mx = fmaxf(mx, x);
+        for (int k = 0; k < MAXC; ++k) {
+          const int c = lane + 64 * k;
+          q[k] = c < nch ? *reinterpret_cast<const uint4*>(z + c * 8) : make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);
         }
-      }
-      mx = wave_max(mx);
-      for (int c = lane; c < nch; c += 64) {
-        const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
-          if (c * 8 + e < V) s += expf(x - mx);
+        for (int k = 0; k < MAXC; ++k) {
+          const int c = lane + 64 * k;
+          const uint32_t w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+            if (c * 8 + e < V) mx = fmaxf(mx, x);
+          }
+        }
+        mx = wave_max(mx);
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+          const int c = lane + 64 * k;
+          if (c < nch) {
+            const uint32_t w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+              if (c * 8 + e < V) s += expf(x - mx);
+            }
+          }
+        }
+      } else {
+        for (int c = lane; c < nch; c += 64) {
+          const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
+          const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+            if (c * 8 + e < V) mx = fmaxf(mx, x);
+          }
+        }
+        mx = wave_max(mx);
+        for (int c = lane; c < nch; c += 64) {
+          const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
+          const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+            if (c * 8 + e < V) s += expf(x - mx);
+          }
         }
       }
       s = wave_sum(s);
@@ -174,7 +210,34 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const TIn* __restrict__ 
   if constexpr (sizeof(TIn) == 2 && sizeof(TOut) == 2) {
     if ((ld & 7) == 0 && ((((uintptr_t)logits) | ((uintptr_t)grad)) & 15) == 0) {
       const int nch = (int)(ld >> 3);
-      for (int c = lane; c < nch; c += 64) {
+      constexpr int MAXC = 12;
+      uint4 pre[MAXC];  // the row's loads requested together (rows up to 6144 columns; longer rows load in the loop)
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        const int c = lane + 64 * k;
+        pre[k] = c < nch ? *reinterpret_cast<const uint4*>(z + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        const int c = lane + 64 * k;
+        if (c >= nch) break;
+        const uint4 q = pre[k];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int v = c * 8 + e;
+          const float x = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+          float gv = expf(x - l + occ);
+          if (v == blank) gv -= cb;
+          if (v == y) gv -= cy;
+          o[e] = v < V ? gv * scale : 0.f;
+        }
+        uint4 r;
+        r.x = pack_bf2(o[0], o[1]); r.y = pack_bf2(o[2], o[3]); r.z = pack_bf2(o[4], o[5]); r.w = pack_bf2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(g + c * 8) = r;
+      }
+      for (int c = lane + 64 * MAXC; c < nch; c += 64) {
         const uint4 q = *reinterpret_cast<const uint4*>(z + c * 8);
         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
         float o[8];

@@ -34,6 +34,7 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         # EA_DDP_FORCE=1: run the bucket hooks and collectives even with a single rank (exercises the RCCL / stream path on
         # a one-GPU box; the reduction itself is then the identity)
         self.active = self.world_size > 1 or (dist.is_initialized() and os.environ.get("EA_DDP_FORCE") == "1")
+        self._rs_ag = os.environ.get("EA_DDP_COLLECTIVE", "all_reduce") == "rs_ag"
         self.accumulate_grads = False
         self._on_gpu = flat.g32.is_cuda
         self.comm_stream = torch.cuda.Stream() if self._on_gpu else None
@@ -126,7 +127,16 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
             for st in streams:
                 self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
-                w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+                n = (e - s) // self.world_size
+                if self._rs_ag and n * self.world_size == e - s:
+                    # diagnostic (EA_DDP_COLLECTIVE=rs_ag): the same sum as reduce-scatter + all-gather, in place (rank r's shard
+                    # is its own slice of the bucket); measured against the all-reduce in profiles/r05_ddp_one_rank_channels.json
+                    r = dist.get_rank(self.process_group)
+                    shard = view[r * n:(r + 1) * n]
+                    self._works.append(dist.reduce_scatter_tensor(shard, view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+                    w = dist.all_gather_into_tensor(view, shard, group=self.process_group, async_op=True)
+                else:
+                    w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
         else:
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
         self._works.append(w)

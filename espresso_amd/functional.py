@@ -156,7 +156,8 @@ def _zeros_f32(n, like):
 # per parameter (22 launches at the very end of the Conformer-CTC backward, in front of the optimizer).  A parameter handled this
 # way gets None from the autograd Function; autograd still runs its AccumulateGrad node — nothing to add — and with it the
 # post-accumulate-grad hook the data-parallel wrapper counts bucket completion with (tests/test_host_logic.py pins that
-# behaviour of torch), at the same point of the stream order as before.  EA_DIRECT_GRADS=0: the autograd route (A/B switch, tests).
+# behaviour of torch), at the same point of the stream order as before.  Only inside an `accumulating_backward()` scope (the trainer's
+# backward calls); EA_DIRECT_GRADS=0: the autograd route everywhere (A/B switch, tests).
 _DIRECT_GRADS = os.environ.get("EA_DIRECT_GRADS", "1") != "0"
 
 
@@ -166,9 +167,29 @@ def set_direct_param_grads(on: bool) -> bool:
     return old
 
 
+_sink_scope = 0
+
+
+class accumulating_backward:
+    """`with accumulating_backward(): loss.backward()` — the caller declares that this backward pass ACCUMULATES into the
+    parameters' `.grad` buffers (what `Tensor.backward()` does under a trainer that owns those buffers).  Only inside this scope
+    do the kernels write parameter gradients behind autograd's back; anywhere else (`torch.autograd.grad`, `backward(inputs=…)`,
+    a foreign training loop) every parameter gradient goes through autograd as usual."""
+
+    def __enter__(self):
+        global _sink_scope
+        _sink_scope += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _sink_scope
+        _sink_scope -= 1
+        return False
+
+
 def _grad_sink(p, n=None):
     """The fp32 buffer a kernel may ACCUMULATE parameter `p`'s gradient into directly (flat view of p.grad), or None."""
-    if not _DIRECT_GRADS or p is None or not getattr(p, "requires_grad", False):
+    if not _DIRECT_GRADS or _sink_scope <= 0 or p is None or not getattr(p, "requires_grad", False):
         return None
     if not p.is_leaf:
         return None

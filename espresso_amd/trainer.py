@@ -74,7 +74,8 @@ class Trainer:
                 loss, sample_size, log = self.criterion(self.ddp, sample)
                 if dummy:
                     loss = loss * 0.0
-                loss.backward()
+                with F.accumulating_backward():  # (this trainer owns the flat gradient buffer the kernels write into)
+                    loss.backward()
             if dummy:
                 continue
             # (in-place adds on one-element views: `stats[i] += x` would be view + add + copy-back, two launches each)
@@ -124,7 +125,8 @@ class Trainer:
             for sample in samples:
                 sample = self.task.prepare_sample(sample, train=True)
                 loss, _, _ = self.criterion(self.ddp, sample)
-                loss.backward()
+                with F.accumulating_backward():
+                    loss.backward()
         self.flat.zero_grad()
         with torch.no_grad():
             for n, b in self.model.named_buffers():

@@ -429,7 +429,8 @@ def check_deferred_backward_matches_immediate(layer_type="conformer", p_drop=0.0
                     p.grad = None
                 o = model(feats, lengths)
                 lo = o["encoder_out"][0].float()
-                (lo * torch.linspace(-1, 1, lo.shape[-1], device=DEV)).sum().backward()
+                with F.accumulating_backward():  # (the scope a trainer opens; outside it the sink is never used)
+                    (lo * torch.linspace(-1, 1, lo.shape[-1], device=DEV)).sum().backward()
             torch.cuda.synchronize()
             out.append({n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
         finally:
@@ -470,7 +471,8 @@ def check_direct_param_grads(fixture="ref_conformer_ctc_dh64"):
             for rep in range(2):
                 o = model(feats, lengths)
                 lo = o["encoder_out"][0].float()
-                (lo * torch.linspace(-1, 1, lo.shape[-1], device=DEV)).sum().backward()
+                with F.accumulating_backward():  # (the scope a trainer opens; outside it the sink is never used)
+                    (lo * torch.linspace(-1, 1, lo.shape[-1], device=DEV)).sum().backward()
             torch.cuda.synchronize()
             out.append({n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
             ids = {id(p): n for n, p in model.named_parameters()}
