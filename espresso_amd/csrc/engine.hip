@@ -94,6 +94,25 @@ struct SideRes {
   bool pending[2] = {false, false};  // ... and the main stream has not joined it yet
 };
 static SideRes g_side;
+// The side stream must not share a hardware queue with the caller's stream, or nothing overlaps.  HIP deals the streams of ONE
+// priority class onto GPU_MAX_HW_QUEUES (4) queues by load, so whether two streams collide depends on how many streams the
+// process created before (measured, round 5, profiles/r05_side_stream_priority.txt: with a one-rank RCCL group in the process the
+// weight-gradient launches landed on the main stream's queue — 13.7 -> 15.3 ms per step; raising GPU_MAX_HW_QUEUES instead makes it
+// 29 ms).  Queues are pooled per priority class: a low- or high-priority side stream cannot collide with a default-priority
+// caller (13.9 - 14.0 ms with the group).  Alone in the process the default class is 0.05 ms faster, so: 0 = default class
+// (default), 1 = low (what the data-parallel wrapper selects), 2 = high; EA_SIDE_PRIORITY = normal | low | high overrides.
+static int g_side_prio_mode = [] {
+  const char* e = getenv("EA_SIDE_PRIORITY");
+  return !e ? 0 : e[0] == 'l' ? 1 : e[0] == 'h' ? 2 : 0;
+}();
+static const bool g_side_prio_env = getenv("EA_SIDE_PRIORITY") != nullptr;
+static bool side_stream_create() {  // (current device = the owner's)
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  const int prio = g_side_prio_mode == 1 ? least : g_side_prio_mode == 2 ? greatest : 0;
+  return (prio == 0 ? hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking)
+                    : hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio)) == hipSuccess;
+}
 static bool side_init(hipStream_t owner) {
   if (g_side.ok) return true;
   int cur = 0, dev = 0;
@@ -104,7 +123,7 @@ static bool side_init(hipStream_t owner) {
     if (hipStreamGetDevice(owner, &d) == hipSuccess) dev = (int)d;
   }
   if (dev != cur && hipSetDevice(dev) != hipSuccess) return false;
-  bool ok = hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = side_stream_create();
   for (auto& e : g_side.ev)
     ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& e : g_side.done)
@@ -1161,6 +1180,26 @@ int ea_set_backward_deferred(int on) {
   return old;
 }
 int ea_backward_flush(hipStream_t stream) { return join_all(stream); }
+int ea_set_side_stream_priority(int mode) {
+  const int old = g_side_prio_mode;
+  if (g_side_prio_env || mode < 0 || mode > 2 || mode == old) return old;  // (the environment variable wins)
+  g_side_prio_mode = mode;
+  if (g_side.ok) {
+    // replace the stream between passes: everything enqueued on the old one finishes first (the caller is not inside a layer call:
+    // pending deferred work was joined by ea_backward_flush at the end of its backward pass)
+    int cur = 0;
+    hipDevice_t d = 0;
+    (void)hipGetDevice(&cur);
+    const bool sw = hipStreamGetDevice(g_side.stream, &d) == hipSuccess && (int)d != cur;
+    if (sw) (void)hipSetDevice((int)d);
+    (void)hipStreamSynchronize(g_side.stream);
+    hipStream_t prev = g_side.stream;
+    if (side_stream_create()) (void)hipStreamDestroy(prev);
+    else g_side.stream = prev;
+    if (sw) (void)hipSetDevice(cur);
+  }
+  return old;
+}
 int ea_set_backward_deferred_inline(int on) {
   const int old = g_defer_inline;
   g_defer_inline = on != 0;

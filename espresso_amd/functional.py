@@ -202,6 +202,21 @@ def _grad_sink(p, n=None):
 
 
 _side_streams = {}
+_side_priority = 0
+
+
+def set_side_stream_priority(priority: int) -> int:
+    """Priority class of the streams this module creates from now on (0 = default, -1 = high).  Hardware queues are pooled per
+    class, so side streams of another class than the compute stream cannot land on its queue; the data-parallel wrapper selects
+    -1 because a process group's own streams crowd the default class (csrc/engine.hip `side_stream_create` has the measurement).
+    Streams created earlier are dropped (they are re-created on next use; work already enqueued on them completes)."""
+    global _side_priority
+    old = _side_priority
+    if int(priority) != old:
+        _side_priority = int(priority)
+        _side_streams.clear()
+        _aux_streams.clear()
+    return old
 
 
 def _side_stream(device):
@@ -209,7 +224,7 @@ def _side_stream(device):
     key = str(device)
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
+        st = _side_streams[key] = torch.cuda.Stream(device=device, priority=_side_priority)
     return st
 
 
@@ -223,7 +238,7 @@ def aux_stream(device, idx):
     key = (str(device), idx)
     st = _aux_streams.get(key)
     if st is None:
-        st = _aux_streams[key] = torch.cuda.Stream(device=device)
+        st = _aux_streams[key] = torch.cuda.Stream(device=device, priority=_side_priority)
     return st
 
 
