@@ -94,24 +94,63 @@ struct SideRes {
   bool pending[2] = {false, false};  // ... and the main stream has not joined it yet
 };
 static SideRes g_side;
-// The side stream must not share a hardware queue with the caller's stream, or nothing overlaps.  HIP deals the streams of ONE
-// priority class onto GPU_MAX_HW_QUEUES (4) queues by load, so whether two streams collide depends on how many streams the
-// process created before (measured, round 5, profiles/r05_side_stream_priority.txt: with a one-rank RCCL group in the process the
-// weight-gradient launches landed on the main stream's queue — 13.7 -> 15.3 ms per step; raising GPU_MAX_HW_QUEUES instead makes it
-// 29 ms).  Queues are pooled per priority class: a low- or high-priority side stream cannot collide with a default-priority
-// caller (13.9 - 14.0 ms with the group).  Alone in the process the default class is 0.05 ms faster, so: 0 = default class
-// (default), 1 = low (what the data-parallel wrapper selects), 2 = high; EA_SIDE_PRIORITY = normal | low | high overrides.
-static int g_side_prio_mode = [] {
-  const char* e = getenv("EA_SIDE_PRIORITY");
-  return !e ? 0 : e[0] == 'l' ? 1 : e[0] == 'h' ? 2 : 0;
-}();
-static const bool g_side_prio_env = getenv("EA_SIDE_PRIORITY") != nullptr;
-static bool side_stream_create() {  // (current device = the owner's)
-  int least = 0, greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  const int prio = g_side_prio_mode == 1 ? least : g_side_prio_mode == 2 ? greatest : 0;
-  return (prio == 0 ? hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking)
-                    : hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio)) == hipSuccess;
+// The side stream must not share a HARDWARE QUEUE with the caller's stream, or nothing overlaps.  HIP deals a process's streams
+// onto GPU_MAX_HW_QUEUES (4) queues by load, so whether two streams collide depends on how many streams the process created before
+// (measured, round 5, profiles/r05_side_stream_queues.txt: with a one-rank RCCL group in the process the weight-gradient launches
+// landed on the main stream's queue — 13.7 -> 15.3 ms per step).  Neither cure offered by the runtime is safe: more hardware queues
+// (GPU_MAX_HW_QUEUES = 8) or streams in other priority classes (queues are pooled per class) put MORE than four queues to work and
+// the command processor time-slices them — config 3 with a process group 29 ms, the transducer step 76 ms instead of 30.  So the
+// collision is MEASURED: a candidate stream is accepted when a tiny kernel on it finishes while a 200 us spin kernel is still
+// running on the caller's stream; up to 8 candidates (streams are created round-robin over the queues).
+__global__ void ea_queue_probe_spin(long ticks) {  // one wavefront, ~ticks of the 100 MHz constant clock
+  const long t0 = (long)wall_clock64();
+  while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void ea_queue_probe_nop() {}
+}  // namespace
+// 1: work on `b` waits for work on `a` (same hardware queue), 0: they run side by side, < 0: error.  Blocks the host until `a`
+// reaches the probe (once per stream pair, at set-up).
+extern "C" int ea_streams_share_queue(hipStream_t a, hipStream_t b) {
+  if (a == b) return 1;
+  hipEvent_t a0, a1, b1;
+  if (hipEventCreate(&a0) != hipSuccess) return -1;
+  if (hipEventCreate(&a1) != hipSuccess) { (void)hipEventDestroy(a0); return -1; }
+  if (hipEventCreate(&b1) != hipSuccess) { (void)hipEventDestroy(a0); (void)hipEventDestroy(a1); return -1; }
+  int rc = -1;
+  float spin_ms = 0.f, b_ms = 0.f;
+  // b is idle-waited first so that only the queue placement, not b's own backlog, decides when its kernel runs
+  if (hipStreamSynchronize(b) == hipSuccess && hipEventRecord(a0, a) == hipSuccess) {
+    hipLaunchKernelGGL(ea_queue_probe_spin, dim3(1), dim3(64), 0, a, 20000L);
+    if (hipEventRecord(a1, a) == hipSuccess) {
+      hipLaunchKernelGGL(ea_queue_probe_nop, dim3(1), dim3(64), 0, b);
+      if (hipEventRecord(b1, b) == hipSuccess && hipEventSynchronize(a1) == hipSuccess && hipEventSynchronize(b1) == hipSuccess &&
+          hipEventElapsedTime(&spin_ms, a0, a1) == hipSuccess && hipEventElapsedTime(&b_ms, a0, b1) == hipSuccess)
+        rc = b_ms >= 0.75f * spin_ms ? 1 : 0;  // (b_ms < 0: b finished before a even reached the probe)
+    }
+  }
+  (void)hipEventDestroy(a0);
+  (void)hipEventDestroy(a1);
+  (void)hipEventDestroy(b1);
+  return rc;
+}
+namespace {
+static const bool g_side_probe = [] { const char* e = getenv("EA_SIDE_STREAM_PROBE"); return !(e && e[0] == '0'); }();
+static bool side_stream_create(hipStream_t owner) {  // (current device = the owner's)
+  hipStream_t rejected[8];
+  int nrej = 0;
+  bool ok = false;
+  for (int t = 0; t < 8; ++t) {
+    hipStream_t cand = nullptr;
+    if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+    if (!g_side_probe || t == 7 || ea_streams_share_queue(owner, cand) != 1) {
+      g_side.stream = cand;
+      ok = true;
+      break;
+    }
+    rejected[nrej++] = cand;  // (kept alive until the choice is made: a destroyed stream's queue slot would be dealt again)
+  }
+  for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+  return ok;
 }
 static bool side_init(hipStream_t owner) {
   if (g_side.ok) return true;
@@ -123,7 +162,7 @@ static bool side_init(hipStream_t owner) {
     if (hipStreamGetDevice(owner, &d) == hipSuccess) dev = (int)d;
   }
   if (dev != cur && hipSetDevice(dev) != hipSuccess) return false;
-  bool ok = side_stream_create();
+  bool ok = side_stream_create(owner);
   for (auto& e : g_side.ev)
     ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& e : g_side.done)
@@ -1180,26 +1219,6 @@ int ea_set_backward_deferred(int on) {
   return old;
 }
 int ea_backward_flush(hipStream_t stream) { return join_all(stream); }
-int ea_set_side_stream_priority(int mode) {
-  const int old = g_side_prio_mode;
-  if (g_side_prio_env || mode < 0 || mode > 2 || mode == old) return old;  // (the environment variable wins)
-  g_side_prio_mode = mode;
-  if (g_side.ok) {
-    // replace the stream between passes: everything enqueued on the old one finishes first (the caller is not inside a layer call:
-    // pending deferred work was joined by ea_backward_flush at the end of its backward pass)
-    int cur = 0;
-    hipDevice_t d = 0;
-    (void)hipGetDevice(&cur);
-    const bool sw = hipStreamGetDevice(g_side.stream, &d) == hipSuccess && (int)d != cur;
-    if (sw) (void)hipSetDevice((int)d);
-    (void)hipStreamSynchronize(g_side.stream);
-    hipStream_t prev = g_side.stream;
-    if (side_stream_create()) (void)hipStreamDestroy(prev);
-    else g_side.stream = prev;
-    if (sw) (void)hipSetDevice(cur);
-  }
-  return old;
-}
 int ea_set_backward_deferred_inline(int on) {
   const int old = g_defer_inline;
   g_defer_inline = on != 0;

@@ -37,17 +37,8 @@ class OverlappedDistributedDataParallel(torch.nn.Module):
         self._rs_ag = os.environ.get("EA_DDP_COLLECTIVE", "all_reduce") == "rs_ag"
         self.accumulate_grads = False
         self._on_gpu = flat.g32.is_cuda
-        # Hardware queues are pooled per stream-priority class (4 queues per class): streams of ONE class are dealt onto them by
-        # load, and with the streams a process group brings the layer runtime's side stream ended up on the main stream's queue
-        # (one-rank RCCL group: 13.7 -> 15.3 ms per step, no overlap left; profiles/r05_side_stream_priority.txt).  Three classes
-        # cannot collide: compute on the default class, collectives on a high-priority stream (they are short and everything
-        # waits for the last one), the optimizer-only weight-gradient stream on the low class.
-        self.comm_stream = torch.cuda.Stream(priority=-1) if self._on_gpu else None
-        if self._on_gpu and self.active:
-            from .. import _lib
-
-            _lib.lib().ea_set_side_stream_priority(1)
-            _F.set_side_stream_priority(-1)
+        # (a stream that provably does not share a hardware queue with the compute stream: functional.new_side_stream)
+        self.comm_stream = _F.new_side_stream(flat.g32.device) if self._on_gpu else None
         elems = max(1, int(bucket_mb * 1024 * 1024 / 4))
         # the last bucket to complete (sub-sampler, fc0: the end of backward) is all-reduced with nothing left to hide it behind:
         # keep it small (8 MB: ~30 us over seven xGMI links instead of ~0.25 ms for 64 MB)

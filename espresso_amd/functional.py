@@ -17,6 +17,7 @@ a per-call 64-bit seed is saved and the kernels re-derive the mask from (seed, e
 """
 import collections
 
+import ctypes
 import os
 
 import torch
@@ -202,21 +203,27 @@ def _grad_sink(p, n=None):
 
 
 _side_streams = {}
-_side_priority = 0
 
 
-def set_side_stream_priority(priority: int) -> int:
-    """Priority class of the streams this module creates from now on (0 = default, -1 = high).  Hardware queues are pooled per
-    class, so side streams of another class than the compute stream cannot land on its queue; the data-parallel wrapper selects
-    -1 because a process group's own streams crowd the default class (csrc/engine.hip `side_stream_create` has the measurement).
-    Streams created earlier are dropped (they are re-created on next use; work already enqueued on them completes)."""
-    global _side_priority
-    old = _side_priority
-    if int(priority) != old:
-        _side_priority = int(priority)
-        _side_streams.clear()
-        _aux_streams.clear()
-    return old
+def new_side_stream(device):
+    """A stream that does not share a HARDWARE queue with the current stream.  HIP deals a process's streams onto four hardware
+    queues by load; two streams on one queue run one after the other, silently (round 5: a process group's streams pushed the
+    weight-gradient stream onto the compute stream's queue, +1.5 ms per step; csrc/engine.hip `side_stream_create`).  Candidates
+    come from torch's pool in turn; each is accepted when `ea_streams_share_queue` sees a tiny kernel on it finish beside a spin
+    kernel on the current stream.  Blocks the host once, at set-up."""
+    st = torch.cuda.Stream(device=device)
+    if os.environ.get("EA_SIDE_STREAM_PROBE", "1") == "0":
+        return st
+    from . import _lib
+
+    cur = torch.cuda.current_stream(device)
+    lib = _lib.lib()
+    with torch.cuda.device(device):
+        for _ in range(7):
+            if lib.ea_streams_share_queue(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(st.cuda_stream)) != 1:
+                break
+            st = torch.cuda.Stream(device=device)
+    return st
 
 
 def _side_stream(device):
@@ -224,7 +231,7 @@ def _side_stream(device):
     key = str(device)
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device, priority=_side_priority)
+        st = _side_streams[key] = new_side_stream(device)
     return st
 
 
@@ -238,7 +245,7 @@ def aux_stream(device, idx):
     key = (str(device), idx)
     st = _aux_streams.get(key)
     if st is None:
-        st = _aux_streams[key] = torch.cuda.Stream(device=device, priority=_side_priority)
+        st = _aux_streams[key] = new_side_stream(device)
     return st
 
 

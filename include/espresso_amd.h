@@ -501,11 +501,12 @@ int ea_set_backward_deferred(int on);
 int ea_set_backward_deferred_inline(int on);
 /* make `stream` wait for all deferred side work issued so far (call after the last layer backward of a pass) */
 int ea_backward_flush(ea_stream_t stream);
-/* priority class of the layer runtime's side stream: 0 = default class (default), 1 = low, 2 = high; returns the previous
- * value.  HIP pools hardware queues per priority class, so a side stream of another class than the caller's stream can never
- * share its queue (which would serialise the two): select 1 when the process creates many streams of the default class — an
- * RCCL process group does.  Call between backward passes.  The environment variable EA_SIDE_PRIORITY (normal|low|high) wins. */
-int ea_set_side_stream_priority(int mode);
+/* Do two streams share a HARDWARE queue?  1 = work on `b` waits for work on `a`, 0 = they run side by side, < 0 = error.
+ * HIP deals a process's streams onto 4 hardware queues by load; two streams on one queue serialise silently.  The layer
+ * runtime picks its side stream with this probe (a tiny kernel on `b` must finish while a 200 us spin kernel runs on `a`); callers
+ * that create their own side streams can do the same.  Blocks the host until `a` reaches the probe; EA_SIDE_STREAM_PROBE=0
+ * disables the runtime's own use of it. */
+int ea_streams_share_queue(ea_stream_t a, ea_stream_t b);
 int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
                            const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
