@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <functional>
+#include <cstdio>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -118,7 +119,9 @@ extern "C" int ea_streams_share_queue(hipStream_t a, hipStream_t b) {
   if (hipEventCreate(&b1) != hipSuccess) { (void)hipEventDestroy(a0); (void)hipEventDestroy(a1); return -1; }
   int rc = -1;
   float spin_ms = 0.f, b_ms = 0.f;
-  // b is idle-waited first so that only the queue placement, not b's own backlog, decides when its kernel runs
+  // b is warmed (a stream's first launch creates its queue: milliseconds) and idle-waited first, so that only the queue
+  // placement, not b's own start-up or backlog, decides when its kernel runs
+  hipLaunchKernelGGL(ea_queue_probe_nop, dim3(1), dim3(64), 0, b);
   if (hipStreamSynchronize(b) == hipSuccess && hipEventRecord(a0, a) == hipSuccess) {
     hipLaunchKernelGGL(ea_queue_probe_spin, dim3(1), dim3(64), 0, a, 20000L);
     if (hipEventRecord(a1, a) == hipSuccess) {
@@ -126,6 +129,9 @@ extern "C" int ea_streams_share_queue(hipStream_t a, hipStream_t b) {
       if (hipEventRecord(b1, b) == hipSuccess && hipEventSynchronize(a1) == hipSuccess && hipEventSynchronize(b1) == hipSuccess &&
           hipEventElapsedTime(&spin_ms, a0, a1) == hipSuccess && hipEventElapsedTime(&b_ms, a0, b1) == hipSuccess)
         rc = b_ms >= 0.75f * spin_ms ? 1 : 0;  // (b_ms < 0: b finished before a even reached the probe)
+      static const bool dbg = getenv("EA_SIDE_STREAM_DEBUG") != nullptr;
+      if (dbg) fprintf(stderr, "[espresso_amd] queue probe %p vs %p: spin %.3f ms, other stream done after %.3f ms -> %s\n", (void*)a, (void*)b,
+                       spin_ms, b_ms, rc == 1 ? "SAME queue" : rc == 0 ? "separate queues" : "error");
     }
   }
   (void)hipEventDestroy(a0);
