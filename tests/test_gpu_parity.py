@@ -81,6 +81,29 @@ def test_wgrad_group_whole_tile_problems(variant, tr):
     assert r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
 
 
+def test_side_streams_do_not_share_the_compute_streams_hardware_queue():
+    """HIP deals streams onto four hardware queues; two streams on one queue serialise silently (round 5: that cost the whole
+    weight-gradient overlap as soon as a process group was in the process).  The probe must call a stream against itself
+    'same queue', and every side stream the runtime hands out must measure as 'separate' against the compute stream — also after
+    many other streams have been created."""
+    import ctypes
+
+    from espresso_amd import _lib
+    from espresso_amd import functional as F
+
+    lib = _lib.lib()
+    cur = torch.cuda.current_stream()
+    h = lambda st: ctypes.c_void_p(st.cuda_stream)
+    assert lib.ea_streams_share_queue(h(cur), h(cur)) == 1
+    crowd = [torch.cuda.Stream() for _ in range(9)]  # shift the deal, as a process group's streams do
+    verdicts = [lib.ea_streams_share_queue(h(cur), h(st)) for st in crowd]
+    print("share the compute stream's queue:", verdicts)  # (nine streams on four queues: normally two or three do)
+    assert all(v in (0, 1) for v in verdicts), verdicts
+    for _ in range(3):
+        st = F.new_side_stream(torch.device("cuda:0"))
+        assert lib.ea_streams_share_queue(h(cur), h(st)) == 0
+
+
 def test_wgrad_8wave_256_tiles_bit_identical_to_4wave():
     r = G.check_wgrad_w8()
     print(r)
