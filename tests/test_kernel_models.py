@@ -41,3 +41,15 @@ def test_wgrad_transposing_read_kernel_lane_model(BM):
 
     err, ways = W.run(M=150, BM=BM)
     assert err < 1e-11 and ways == 1, (err, ways)
+
+
+@pytest.mark.parametrize("kw", [dict(M=150, R=300, Cn=264, pad_dy=4), dict(M=64, R=256, Cn=256, pad_dy=0), dict(M=65, R=40, Cn=512, pad_dy=0)])
+def test_wgrad_8wave_kernel_lane_model(kw):
+    """csrc/wgrad_w8.hip wgrad_w8_kernel on the lane model (tools/emu_wgrad_w8.py): 512-byte-pitch images with the source-side slot
+    swizzle, the column clamp at the row pitch (the joint's 5004 columns at pitch 5056 in small), zero-page rows past M, fragment
+    addresses and immediates, swapped MFMA operands, bias sums routed to wavefront wn — reproduce dy^T x and the column sums
+    (float64), and every transposing fragment read is bank-conflict free."""
+    import emu_wgrad_w8 as W
+
+    err, ways = W.run(**kw)
+    assert err < 1e-11 and ways == 1, (err, ways)
