@@ -3511,6 +3511,63 @@ def check_training_trajectory(steps=None, dropout=0.0):
     return res
 
 
+def check_encdec_training_trajectory(steps=60):
+    """tests/trajectory.py, encoder-decoder edition (+n2 beyond CTC): `steps` Adam updates of the dh-64 Transformer encoder-decoder
+    with label-smoothed CE on the learnable synthetic task, teacher-forced, HIP path (native encoder / decoder layers, fused
+    attention, LS-CE kernel, FlatAdam) vs the oracle (fp32 and bf16-emulating) from the same weights, batches and order; per-update
+    loss per token, and held-out NLL per token / teacher-forced token accuracy (BatchNorm on batch statistics both sides)."""
+    from espresso_amd import functional as F
+    from espresso_amd.optim.adam import FlatAdam
+    from espresso_amd.optim.flat import FlatParams
+    from tests import trajectory as TR
+
+    g = np.load(os.path.join(GOLD, TR.ENCDEC_FIXTURE + ".npz"))
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    train, heldout = TR.make_batches(TR.TRAIN_BATCHES, seed=0), TR.make_batches(TR.HELDOUT_BATCHES, seed=1)
+    model = _encdec_for(TR.ENCDEC_FIXTURE).to(DEV)
+    missing, unexpected = model.load_state_dict(model.upgrade_state_dict_named(dict(sd0), ""), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    flat = FlatParams(model, DEV)
+    opt = FlatAdam(flat, lr=TR.LR, betas=TR.BETAS, eps=TR.EPS)
+    model.train()
+
+    def run(batch, backward):
+        feats, lens, tg = batch
+        target, prev = TR.encdec_targets(tg)
+        lo, extra = model(feats.to(DEV), lens.to(DEV), prev.to(DEV))
+        loss, nll = F.label_smoothed_ce(extra["_logits_bu"], target.reshape(-1).to(torch.int32).to(DEV).contiguous(), TR.ENCDEC_PAD, TR.LS_EPS)
+        n = int((target != TR.ENCDEC_PAD).sum())
+        if backward:
+            loss.backward()
+        return lo, loss, nll, n, target
+
+    losses = []
+    for step in range(steps):
+        F.begin_step(DEV)
+        F.set_dropout_seed(1 + step)
+        _, loss, _, n, _ = run(train[step % len(train)], True)
+        F.end_step()
+        opt.clip_and_step(pre_scale=1.0, max_norm=TR.CLIP, denom_dev=torch.full((1,), float(n), device=DEV))
+        losses.append(float(loss.detach()) / n)
+    nll = tok = hit = 0.0
+    with torch.no_grad():
+        for batch in heldout:
+            lo, _, nl, n, target = run(batch, False)
+            valid = target != TR.ENCDEC_PAD
+            nll += float(nl)
+            tok += n
+            hit += int((lo.float().cpu().argmax(-1) == target)[valid].sum())
+    torch.cuda.synchronize()
+    res = {"hip_losses": losses, "hip_heldout_nll": nll / tok, "hip_heldout_acc": hit / tok, "tokens": int(tok),
+           "hip_final_loss": sum(losses[-10:]) / 10}
+    for tag, emu in (("fp32", False), ("emu", True)):
+        ol, onll, oacc = TR.train_oracle_encdec(sd0, train, heldout, steps, emu)
+        rel = [abs(a - b) / max(b, 1e-3) for a, b in zip(losses, ol)]
+        res[tag] = {"losses": ol, "heldout_nll": onll, "heldout_acc": oacc, "max_rel_first24": max(rel[:24]), "max_rel_all": max(rel),
+                    "auc_rel": abs(sum(losses) - sum(ol)) / sum(ol), "final_loss": sum(ol[-10:]) / 10}
+    return res
+
+
 def check_conv_subsample_nondefault_channels(channels=(64, 192, 128, 64), strides=(1, 2, 1, 2)):
     """A sub-sampler whose middle layers the implicit-GEMM kernels accept only partly (192 input channels: forward yes, data
     gradient no; the last layer, 128 -> 64, takes them): forward and backward must pick the same lowering per layer.  Compared with the same stack on the im2col

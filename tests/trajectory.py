@@ -116,3 +116,69 @@ def train_oracle(sd, train, heldout, steps, emulate, traces=None, layer_seed_fn=
             err += e
             tot += t_
     return losses, err, tot
+
+
+# ---- encoder-decoder (label-smoothed CE) trajectory: the same synthetic task, teacher-forced ------------------------------
+ENCDEC_FIXTURE = "ref_transformer_encdec_dh64"
+ENCDEC_PAD, ENCDEC_EOS, LS_EPS = 0, 1, 0.1
+
+
+def encdec_targets(tg):
+    """CTC-style targets (pad 1) -> (target with EOS, prev_output_tokens) in the attention model's dictionary (pad 0, eos 1)."""
+    B, U = tg.shape
+    lens = (tg != 1).sum(1)
+    target = torch.full((B, U + 1), ENCDEC_PAD, dtype=torch.long)
+    prev = torch.full((B, U + 1), ENCDEC_PAD, dtype=torch.long)
+    for b in range(B):
+        n = int(lens[b])
+        target[b, :n], target[b, n] = tg[b, :n], ENCDEC_EOS
+        prev[b, 0], prev[b, 1:n + 1] = ENCDEC_EOS, tg[b, :n]
+    return target, prev
+
+
+def train_oracle_encdec(sd, train, heldout, steps, emulate):
+    """oracle/torch_ref.py encdec + label_smoothed_nll (espresso/criterions/label_smoothed_cross_entropy_v2.py:94-119), clip and
+    Adam as in train_oracle; gradients are normalised by the number of target tokens.  -> per-update loss per token, held-out
+    (nll per token, teacher-forced token accuracy) with BatchNorm on batch statistics (training mode, dropout 0)."""
+    from oracle import torch_ref
+
+    P = {k: (v.clone().float().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("_float_tensor")
+             and k != "version" else v.clone()) for k, v in sd.items()}
+    names = [k for k, v in P.items() if v.requires_grad]
+    m = {k: torch.zeros_like(P[k]) for k in names}
+    v2 = {k: torch.zeros_like(P[k]) for k in names}
+    losses = []
+    for step in range(steps):
+        feats, lens, tg = train[step % len(train)]
+        target, prev = encdec_targets(tg)
+        with torch_ref.bf16_emulation(emulate, flash=True):
+            lo = torch_ref.encdec(feats, lens, prev, P, HEADS, ENCDEC_PAD, training=True)
+            loss, _ = torch_ref.label_smoothed_nll(lo.reshape(-1, lo.shape[-1]), target.reshape(-1), LS_EPS, ENCDEC_PAD)
+        for k in names:
+            P[k].grad = None
+        loss.backward()
+        n = int((target != ENCDEC_PAD).sum())
+        with torch.no_grad():
+            gn = math.sqrt(sum(float((P[k].grad / n).pow(2).sum()) for k in names if P[k].grad is not None))
+            coef = min(1.0, CLIP / (gn + 1e-6)) / n
+            t = step + 1
+            ss = LR * math.sqrt(1 - BETAS[1] ** t) / (1 - BETAS[0] ** t)
+            for k in names:
+                if P[k].grad is None:
+                    continue
+                gk = P[k].grad * coef
+                m[k].mul_(BETAS[0]).add_(gk, alpha=1 - BETAS[0])
+                v2[k].mul_(BETAS[1]).addcmul_(gk, gk, value=1 - BETAS[1])
+                P[k].addcdiv_(m[k], v2[k].sqrt().add_(EPS), value=-ss)
+        losses.append(float(loss.detach()) / n)
+    nll = tok = hit = 0.0
+    with torch.no_grad(), torch_ref.bf16_emulation(emulate, flash=True):
+        for feats, lens, tg in heldout:
+            target, prev = encdec_targets(tg)
+            lo = torch_ref.encdec(feats, lens, prev, P, HEADS, ENCDEC_PAD, training=True)
+            _, nl = torch_ref.label_smoothed_nll(lo.reshape(-1, lo.shape[-1]), target.reshape(-1), LS_EPS, ENCDEC_PAD)
+            valid = target != ENCDEC_PAD
+            nll += float(nl)
+            tok += int(valid.sum())
+            hit += int((lo.argmax(-1) == target)[valid].sum())
+    return losses, nll / tok, hit / tok
