@@ -3568,6 +3568,59 @@ def check_encdec_training_trajectory(steps=60):
     return res
 
 
+def check_transducer_training_trajectory(steps=60):
+    """tests/trajectory.py, transducer edition (+n2 beyond CTC): `steps` Adam updates of the tiny Conformer transducer (LSTM
+    predictor, joint network, RNN-T loss through the `transducer_loss` criterion) on the learnable synthetic task, HIP path vs the
+    oracle (fp32 and bf16-emulating) from the same weights, batches and order; per-update loss per sentence and held-out loss."""
+    from espresso_amd import functional as F
+    from espresso_amd.criterions.transducer_loss import TransducerLossCriterion
+    from espresso_amd.optim.adam import FlatAdam
+    from espresso_amd.optim.flat import FlatParams
+    from tests import trajectory as TR
+
+    g = np.load(os.path.join(GOLD, TR.TD_FIXTURE + ".npz"))
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    train, heldout = TR.make_batches(TR.TRAIN_BATCHES, seed=0), TR.make_batches(4, seed=1)
+    model = build_tiny_transducer().to(DEV)
+    missing, unexpected = model.load_state_dict(model.upgrade_state_dict_named(dict(sd0), ""), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    crit = TransducerLossCriterion(_Task(40))
+    assert (crit.blank_idx, crit.pad_idx, crit.eos_idx) == (TR.TD_BLANK, TR.TD_PAD, TR.TD_EOS)
+    flat = FlatParams(model, DEV)
+    opt = FlatAdam(flat, lr=TR.LR, betas=TR.BETAS, eps=TR.EPS)
+    model.train()
+
+    def sample_of(batch):
+        feats, lens, tg = batch
+        target, prev, tl = TR.transducer_targets(tg)
+        return {"net_input": {"src_tokens": feats.to(DEV), "src_lengths": lens.to(DEV), "prev_output_tokens": prev.to(DEV)},
+                "target": target.to(DEV), "ntokens": int(tl.sum()) + len(tl)}
+
+    losses = []
+    for step in range(steps):
+        F.begin_step(DEV)
+        F.set_dropout_seed(1 + step)
+        loss, B, _ = crit(model, sample_of(train[step % len(train)]))
+        loss.backward()
+        F.end_step()
+        opt.clip_and_step(pre_scale=1.0, max_norm=TR.CLIP, denom_dev=torch.full((1,), float(B), device=DEV))
+        losses.append(float(loss.detach()) / B)
+    tot = n = 0.0
+    with torch.no_grad():
+        for batch in heldout:
+            loss, B, _ = crit(model, sample_of(batch))
+            tot += float(loss)
+            n += B
+    torch.cuda.synchronize()
+    res = {"hip_losses": losses, "hip_heldout": tot / n, "hip_final_loss": sum(losses[-10:]) / 10}
+    for tag, emu in (("fp32", False), ("emu", True)):
+        ol, oh = TR.train_oracle_transducer(sd0, train, heldout, steps, emu)
+        rel = [abs(a - b) / max(b, 1e-3) for a, b in zip(losses, ol)]
+        res[tag] = {"losses": ol, "heldout": oh, "max_rel_first24": max(rel[:24]), "max_rel_all": max(rel),
+                    "auc_rel": abs(sum(losses) - sum(ol)) / sum(ol), "final_loss": sum(ol[-10:]) / 10}
+    return res
+
+
 def check_conv_subsample_nondefault_channels(channels=(64, 192, 128, 64), strides=(1, 2, 1, 2)):
     """A sub-sampler whose middle layers the implicit-GEMM kernels accept only partly (192 input channels: forward yes, data
     gradient no; the last layer, 128 -> 64, takes them): forward and backward must pick the same lowering per layer.  Compared with the same stack on the im2col

@@ -182,3 +182,75 @@ def train_oracle_encdec(sd, train, heldout, steps, emulate):
             tok += int(valid.sum())
             hit += int((lo.argmax(-1) == target)[valid].sum())
     return losses, nll / tok, hit / tok
+
+
+# ---- transducer (RNN-T loss) trajectory -------------------------------------------------------------------------------------
+TD_FIXTURE = "ref_conformer_transducer_tiny"
+TD_HEADS, TD_BLANK, TD_PAD, TD_EOS = 4, 0, 1, 2
+
+
+def transducer_targets(tg):
+    """CTC-style targets (pad 1) -> (target = tokens + EOS, prev_output_tokens = EOS + tokens, token counts); the transducer
+    criterion drops the EOS again (espresso/criterions/transducer_loss.py:73-90)."""
+    B, U = tg.shape
+    lens = (tg != 1).sum(1)
+    target = torch.full((B, U + 1), TD_PAD, dtype=torch.long)
+    prev = torch.full((B, U + 1), TD_PAD, dtype=torch.long)
+    for b in range(B):
+        n = int(lens[b])
+        target[b, :n], target[b, n] = tg[b, :n], TD_EOS
+        prev[b, 0], prev[b, 1:n + 1] = TD_EOS, tg[b, :n]
+    return target, prev, lens
+
+
+def train_oracle_transducer(sd, train, heldout, steps, emulate):
+    """oracle/torch_ref.py transducer + oracle/rnnt_ref.py rnnt_loss_torch (sum over the batch), clip and Adam as above,
+    normalised by the number of sentences.  -> per-update loss per sentence, held-out loss per sentence (training-mode BatchNorm)."""
+    from oracle import rnnt_ref, torch_ref
+
+    P = {k: (v.clone().float().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("_float_tensor")
+             and k != "version" else v.clone()) for k, v in sd.items()}
+    names = [k for k, v in P.items() if v.requires_grad]
+    m = {k: torch.zeros_like(P[k]) for k in names}
+    v2 = {k: torch.zeros_like(P[k]) for k in names}
+
+    def batch_loss(batch, update):
+        feats, lens, tg = batch
+        target, prev, tl = transducer_targets(tg)
+        with torch_ref.bf16_emulation(emulate, flash=False):
+            lo, ol = torch_ref.transducer(feats, lens, prev, P, H=TD_HEADS, pad_idx=TD_PAD, residual=True, training=True, update=update)
+        tot = 0.0
+        for b in range(feats.shape[0]):
+            n = int(tl[b])
+            tot = tot + rnnt_ref.rnnt_loss_torch(lo[b, : int(ol[b]), : n + 1], target[b, :n].tolist(), blank=TD_BLANK)
+        return tot, feats.shape[0]
+
+    losses = []
+    for step in range(steps):
+        upd = {}
+        loss, B = batch_loss(train[step % len(train)], upd)
+        for k in names:
+            P[k].grad = None
+        loss.backward()
+        with torch.no_grad():
+            gn = math.sqrt(sum(float((P[k].grad / B).pow(2).sum()) for k in names if P[k].grad is not None))
+            coef = min(1.0, CLIP / (gn + 1e-6)) / B
+            t = step + 1
+            ss = LR * math.sqrt(1 - BETAS[1] ** t) / (1 - BETAS[0] ** t)
+            for k in names:
+                if P[k].grad is None:
+                    continue
+                gk = P[k].grad.float() * coef
+                m[k].mul_(BETAS[0]).add_(gk, alpha=1 - BETAS[0])
+                v2[k].mul_(BETAS[1]).addcmul_(gk, gk, value=1 - BETAS[1])
+                P[k].addcdiv_(m[k], v2[k].sqrt().add_(EPS), value=-ss)
+            for k, val in upd.items():
+                P[k] = val
+        losses.append(float(loss.detach()) / B)
+    tot = n = 0.0
+    with torch.no_grad():
+        for batch in heldout:
+            l, B = batch_loss(batch, {})
+            tot += float(l)
+            n += B
+    return losses, tot / n
