@@ -861,10 +861,10 @@ def test_transducer_training_trajectory_vs_oracle():
     ~25 per sentence in the first ten updates and keeps falling slowly (23 after 60).  Two ORACLE runs (fp32 vs emulation) differ
     by 0.5 % per update at most.  The HIP path is noisier and not bit-reproducible from run to run: the joint's relu sits on bf16
     activations (derivative flips within an ulp of the kink: zero-mean gradient noise of ~10 %, see
-    test_transducer_vs_reference_fixture) and the weight-gradient sums are ordered by the hardware.  Two leases measured, against
-    the fp32 / emulating oracle: worst single update 5.2 - 7.9 %, area under the loss curve 0.2 - 0.5 %, mean of the last ten
-    updates 0.9 - 2.6 %, held-out loss over 32 sentences 0.6 - 6.5 %.  Bounds (about 3 x the larger figure; the integrated
-    quantities are the meaningful ones): 25 % per update, 3 % area, 8 % end state, 15 % held-out."""
+    test_transducer_vs_reference_fixture) and the weight-gradient sums are ordered by the hardware.  Three leases measured, against
+    the fp32 / emulating oracle: worst single update 5.2 - 8.8 %, area under the loss curve 0.2 - 0.5 %, mean of the last ten
+    updates 0.9 - 3.8 % (HIP 22.96 / 23.76 / 24.04 vs 23.16), held-out loss over 32 sentences 0.6 - 7.4 %.  Bounds (2 - 3 x the
+    largest figure; the integrated quantities are the meaningful ones): 25 % per update, 3 % area, 8 % end state, 15 % held-out."""
     r = G.check_transducer_training_trajectory()
     print({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk != "losses"}) for k, v in r.items() if k != "hip_losses"})
     print("hip ", [round(x, 2) for x in r["hip_losses"][::4]])
