@@ -97,6 +97,7 @@ static long wav_decode(const Bytes& b, int16_t* dst, long cap, Info& in) {
   if (in.frames > cap) return -5;
   const uint8_t* p = b.d.data() + w.data_off;
   const int step = w.bits / 8 * w.channels;
+  if (!dst || in.frames == 0) return in.frames;  // (header-only use: ea_audio_verify)
   if (w.bits == 16 && w.channels == 1) {
     memcpy(dst, p, (size_t)in.frames * 2);  // (little-endian host)
     return in.frames;
@@ -354,9 +355,9 @@ static bool flac_subframe(BitReader& br, int32_t* out, int blocksize, int bps) {
     for (int j = 0; j < order; ++j) coef[j] = (int32_t)br.sbits(prec);
     if (!flac_residual(br, out, blocksize, order)) return false;
     for (int i = order; i < blocksize; ++i) {
-      int64_t acc = 0;
-      for (int j = 0; j < order; ++j) acc += (int64_t)coef[j] * out[i - 1 - j];
-      out[i] = (int32_t)((int64_t)out[i] + (acc >> shift));
+      uint64_t acc = 0;  // (wrapping sums: a corrupt stream must not reach signed overflow; valid streams never wrap)
+      for (int j = 0; j < order; ++j) acc += (uint64_t)((int64_t)coef[j] * out[i - 1 - j]);
+      out[i] = (int32_t)(uint32_t)((uint64_t)(int64_t)out[i] + (uint64_t)((int64_t)acc >> shift));
     }
   } else {
     return false;  // reserved subframe type
@@ -438,14 +439,15 @@ static long flac_decode(const Bytes& b, int16_t* dst, long cap, Info& in, int* m
     if (!br.ok || crc16(p + off, body) != want16) return -7;
     int32_t* c0 = ch.data();
     int32_t* c1 = ch.data() + 65536;
-    if (ca == 8) { for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i]; }
-    else if (ca == 9) { for (int i = 0; i < blocksize; ++i) c0[i] = c0[i] + c1[i]; }
+    // (two's-complement wrapping arithmetic: exact for valid streams, defined for corrupt ones)
+    if (ca == 8) { for (int i = 0; i < blocksize; ++i) c1[i] = (int32_t)((uint32_t)c0[i] - (uint32_t)c1[i]); }
+    else if (ca == 9) { for (int i = 0; i < blocksize; ++i) c0[i] = (int32_t)((uint32_t)c0[i] + (uint32_t)c1[i]); }
     else if (ca == 10) {
       for (int i = 0; i < blocksize; ++i) {
-        const int32_t side = c1[i];
-        const int32_t mid = (int32_t)(((uint32_t)c0[i] << 1) | (uint32_t)(side & 1));
-        c0[i] = (mid + side) >> 1;
-        c1[i] = (mid - side) >> 1;
+        const int64_t side = c1[i];
+        const int64_t mid = (int64_t)c0[i] * 2 + (side & 1);
+        c0[i] = (int32_t)((mid + side) >> 1);
+        c1[i] = (int32_t)((mid - side) >> 1);
       }
     }
     long take = blocksize;
@@ -454,7 +456,7 @@ static long flac_decode(const Bytes& b, int16_t* dst, long cap, Info& in, int* m
       if (written + take > cap) return -5;
       if (in.bits == 16) for (long i = 0; i < take; ++i) dst[written + i] = (int16_t)c0[i];
       else if (in.bits > 16) for (long i = 0; i < take; ++i) dst[written + i] = clamp16(c0[i] >> (in.bits - 16));
-      else for (long i = 0; i < take; ++i) dst[written + i] = clamp16((long)c0[i] << (16 - in.bits));
+      else for (long i = 0; i < take; ++i) dst[written + i] = clamp16((long)c0[i] * (1L << (16 - in.bits)));
     }
     if (md5_ok) {
       pcm.resize((size_t)take * nch * bytes_ps);
