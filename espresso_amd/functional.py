@@ -169,6 +169,36 @@ def set_direct_param_grads(on: bool) -> bool:
 
 
 _sink_scope = 0
+_none_grad_hooks_ok = None  # lazily: does this torch fire post-accumulate-grad hooks for a parameter whose Function returned None?
+
+
+def _none_grad_hooks_fire() -> bool:
+    """Capability check behind the direct-gradient route: the data-parallel wrapper counts a bucket down from the parameter's
+    post-accumulate-grad hook, which must therefore fire although the autograd Function returned None for that parameter (the
+    kernel has already written `p.grad`).  torch 2.x does; the answer is measured once on a two-element CPU example instead of
+    assumed, and the direct route is switched off if it ever changes (tests/test_host_logic.py pins the same behaviour)."""
+    global _none_grad_hooks_ok
+    if _none_grad_hooks_ok is None:
+        class _Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                return x * 2
+
+            @staticmethod
+            def backward(ctx, dy):
+                return dy * 2, None
+
+        fired = []
+        try:
+            w = torch.nn.Parameter(torch.ones(2))
+            w.grad = torch.zeros(2)
+            w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+            with torch.enable_grad():
+                _Probe.apply(torch.ones(2, requires_grad=True), w).sum().backward()
+        except Exception:
+            fired = []
+        _none_grad_hooks_ok = bool(fired)
+    return _none_grad_hooks_ok
 
 
 class accumulating_backward:
@@ -179,6 +209,7 @@ class accumulating_backward:
 
     def __enter__(self):
         global _sink_scope
+        _none_grad_hooks_fire()  # (cached after the first call)
         _sink_scope += 1
         return self
 
@@ -191,6 +222,8 @@ class accumulating_backward:
 def _grad_sink(p, n=None):
     """The fp32 buffer a kernel may ACCUMULATE parameter `p`'s gradient into directly (flat view of p.grad), or None."""
     if not _DIRECT_GRADS or _sink_scope <= 0 or p is None or not getattr(p, "requires_grad", False):
+        return None
+    if not _none_grad_hooks_ok:  # (measured by accumulating_backward.__enter__, outside the autograd engine)
         return None
     if not p.is_leaf:
         return None

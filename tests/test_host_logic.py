@@ -1268,3 +1268,32 @@ def test_post_accumulate_grad_hook_fires_for_a_parameter_whose_function_returned
     b.register_post_accumulate_grad_hook(lambda p: fired.append("b"))
     Fn.apply(torch.ones(3, requires_grad=True), w, b).sum().backward()
     assert sorted(fired) == ["b", "w"] and float(w.grad.sum()) == 3.0
+
+
+def test_direct_gradient_route_is_gated_on_the_scope_and_the_measured_torch_capability():
+    """`functional._grad_sink` hands a kernel the live `p.grad` only inside `accumulating_backward()` (what a trainer
+    that owns the gradient buffers opens around `loss.backward()`), and only when this torch was MEASURED to fire post-accumulate-grad
+    hooks for a parameter whose Function returned None (`_none_grad_hooks_fire`, the pin above as a runtime check).  On CPU tensors
+    the sink is never used (`g.is_cuda`), so what is checked here is the gating and the scope's nesting."""
+    import torch
+
+    from espresso_amd import functional as F
+
+    assert F._sink_scope == 0
+    assert F._none_grad_hooks_fire() is True and F._none_grad_hooks_ok is True
+    p = torch.nn.Parameter(torch.ones(4))
+    p.grad = torch.zeros(4)
+    assert F._grad_sink(p, 4) is None  # outside the scope
+    with F.accumulating_backward():
+        assert F._sink_scope == 1
+        with F.accumulating_backward():
+            assert F._sink_scope == 2
+        assert F._sink_scope == 1
+        assert F._grad_sink(p, 4) is None  # CPU gradient: autograd route
+    assert F._sink_scope == 0
+    try:
+        with F.accumulating_backward():
+            raise RuntimeError("backward failed")
+    except RuntimeError:
+        pass
+    assert F._sink_scope == 0  # the scope closes on errors too
