@@ -290,7 +290,10 @@ def main(argv=None):
                     sample["_dummy"] = True
                 group.append(sample)
             done += size
-            interval += trainer.train_step(group)
+            stats = trainer.train_step(group)
+            if stats is None:  # out of memory in forward / backward: the update was skipped (fairseq/trainer.py:842-857)
+                continue
+            interval += stats
             n_interval += 1
             n = trainer.num_updates
             if n % cfg["common"]["log_interval"] == 0:

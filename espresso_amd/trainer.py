@@ -53,6 +53,7 @@ class Trainer:
         self._stats = torch.zeros(4 + (self.world_size if self.world_size > 1 else 0), dtype=torch.float32, device=device)
         self._gnorm_mismatch = torch.zeros(1, dtype=torch.float32, device=device)  # updates whose gradient norms differed across ranks
         self.last_coef = None
+        self.ooms = 0  # updates skipped after an out-of-memory error (fairseq/trainer.py:797,850)
         self._train_mode_checked = False
 
     def train_step(self, samples):
@@ -69,13 +70,19 @@ class Trainer:
             last = i == len(samples) - 1
             ctx = contextlib.nullcontext() if last else self.ddp.no_sync()
             dummy = bool(sample.get("_dummy", False))  # rank ran out of batches: same collectives, no contribution (trainer.py:873-877)
-            with ctx:
-                sample = self.task.prepare_sample(sample, train=True)
-                loss, sample_size, log = self.criterion(self.ddp, sample)
-                if dummy:
-                    loss = loss * 0.0
-                with F.accumulating_backward():  # (this trainer owns the flat gradient buffer the kernels write into)
-                    loss.backward()
+            try:
+                with ctx:
+                    sample = self.task.prepare_sample(sample, train=True)
+                    loss, sample_size, log = self.criterion(self.ddp, sample)
+                    if dummy:
+                        loss = loss * 0.0
+                    with F.accumulating_backward():  # (this trainer owns the flat gradient buffer the kernels write into)
+                        loss.backward()
+            except RuntimeError as e:
+                if "out of memory" not in str(e).lower():
+                    raise
+                self._recover_from_oom(e)  # raises on more than one rank
+                return None
             if dummy:
                 continue
             # (in-place adds on one-element views: `stats[i] += x` would be view + add + copy-back, two launches each)
@@ -103,6 +110,32 @@ class Trainer:
             self.model.set_num_updates(self.num_updates)
         self.lr_scheduler.step_update(self.num_updates)
         return self._stats[:4]
+
+    def _recover_from_oom(self, exc):
+        """fairseq/trainer.py:842-857: a device out-of-memory error in the forward / backward pass of a micro-batch is logged, the
+        gradients accumulated so far are dropped, the allocator cache is released and — with ONE worker — the update is skipped
+        (`train_step` returns None, the loop carries on with the next batch).  With more workers the reference lets the worker
+        contribute zeros to its end-of-backward all-reduce; here buckets of this update may already be in flight when the error
+        arrives (that overlap is the point of the wrapper), so the update cannot be withdrawn on one rank only: the error is
+        re-raised with that explanation."""
+        import sys
+
+        self.ooms += 1
+        print(f"| WARNING: ran out of memory in the forward/backward pass of update {self.num_updates + 1} ({exc}); "
+              f"{'skipping the update' if self.world_size == 1 else 'cannot skip on one rank of ' + str(self.world_size)}", file=sys.stderr)
+        if self.world_size > 1:
+            raise RuntimeError("out of memory on one data-parallel rank: gradient buckets of this update may already be in flight, "
+                               "the update cannot be skipped consistently (lower max_tokens / batch_size)") from exc
+        F.end_step()
+        for m in self.model.modules():  # layers whose forward ran but whose backward never did: their saved-activation arenas are free again
+            b = getattr(m, "_ea_binding", None)
+            if b is not None:
+                b.saved_busy = False
+        self.flat.zero_grad()
+        self._stats.zero_()
+        if self._stats.is_cuda:
+            torch.cuda.synchronize(self._stats.device)
+            torch.cuda.empty_cache()
 
     def check_grad_norm_consistency(self):
         """Host read (call it where the training statistics are read anyway): raises like fairseq/trainer.py:1477-1488 when any

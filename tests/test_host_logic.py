@@ -1297,3 +1297,55 @@ def test_direct_gradient_route_is_gated_on_the_scope_and_the_measured_torch_capa
     except RuntimeError:
         pass
     assert F._sink_scope == 0  # the scope closes on errors too
+
+
+def test_trainer_skips_the_update_after_an_out_of_memory_error(capsys):
+    """fairseq/trainer.py:842-857 with one worker: an out-of-memory RuntimeError raised in the forward / backward pass of a
+    micro-batch is logged, accumulated gradients are dropped, `train_step` returns None (no optimizer update, no statistics) and
+    the next call trains normally; any other RuntimeError propagates."""
+    import torch.nn as nn
+
+    from espresso_amd.trainer import Trainer
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(8, 4)
+
+        def forward(self, x):
+            return self.a(x)
+
+    class Task:
+        def prepare_sample(self, sample, train=True):
+            return sample
+
+    class Crit:
+        def __init__(self):
+            self.fail = None
+
+        def __call__(self, model, sample):
+            loss = model(sample["x"]).pow(2).sum()
+            if self.fail == "oom_after_backward_of_part":
+                (loss * 0.5).backward()  # gradients of an earlier micro-batch are sitting in the buffer when the error arrives
+                raise RuntimeError("HIP out of memory. Tried to allocate 1.50 GiB")
+            if self.fail == "other":
+                raise RuntimeError("shape mismatch")
+            return loss, 2, {"ntokens": 5, "nsentences": 2}
+
+    torch.manual_seed(0)
+    crit = Crit()
+    t = Trainer(Task(), M(), crit, torch.device("cpu"), lr=1e-3, lr_scheduler=("tri_stage", dict(warmup_steps=10, hold_steps=10, decay_steps=10)))
+    sample = {"x": torch.randn(2, 8)}
+    stepped = []
+    t.optimizer.clip_and_step = lambda **kw: stepped.append(kw) or torch.zeros(2)  # (the fused optimizer kernel needs a GPU; not under test)
+    crit.fail = "oom_after_backward_of_part"
+    assert t.train_step([sample]) is None
+    assert t.ooms == 1 and t.num_updates == 0 and not stepped
+    assert float(t.flat.g32.abs().sum()) == 0.0 and all(float(p.grad.abs().sum()) == 0.0 for p in t.model.parameters())
+    assert "ran out of memory" in capsys.readouterr().err
+    crit.fail = None
+    out = t.train_step([sample])
+    assert out is not None and t.num_updates == 1 and len(stepped) == 1 and float(out[0]) == 2.0 and float(t.flat.g32.abs().sum()) > 0
+    crit.fail = "other"
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        t.train_step([sample])
