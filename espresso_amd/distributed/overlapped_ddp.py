@@ -15,7 +15,7 @@ API mirrors the wrappers in fairseq/models/distributed_fairseq_model.py:35-147: 
 """
 import contextlib
 import os
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.distributed as dist

@@ -1,6 +1,6 @@
 """GPU idle-gap analysis of a rocprofv3 kernel trace (rocpd sqlite): busy time vs wall per training step (steps are
 delimited by the adam kernel), histogram of the idle gaps and the largest ones.  Usage: gap_analysis.py <db> [nsteps]"""
-import glob, sqlite3, sys
+import sqlite3, sys
 import numpy as np
 
 db = sys.argv[1]
