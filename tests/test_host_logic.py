@@ -1349,3 +1349,8 @@ def test_trainer_skips_the_update_after_an_out_of_memory_error(capsys):
     crit.fail = "other"
     with pytest.raises(RuntimeError, match="shape mismatch"):
         t.train_step([sample])
+    # more than one rank: buckets of the update may already be in flight — the error is re-raised, with the reason
+    t.world_size, crit.fail = 2, "oom_after_backward_of_part"
+    with pytest.raises(RuntimeError, match="cannot be skipped consistently"):
+        t.train_step([sample])
+    assert t.ooms == 2
