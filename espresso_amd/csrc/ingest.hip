@@ -125,6 +125,18 @@ struct BitReader {
   BitReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
   inline size_t pos() const { return next * 8 - (size_t)cbits; }  // bits consumed so far
   inline void refill() {
+    if (next + 8 <= n) {  // one unaligned big-endian load tops the window up to 57 .. 64 bits
+      uint64_t w;
+      memcpy(&w, p + next, 8);
+      w = __builtin_bswap64(w);
+      const int take = (64 - cbits) >> 3;  // whole bytes that fit
+      if (take > 0) {
+        cache |= cbits ? (take == 8 ? w : (w >> (64 - 8 * take))) << (64 - cbits - 8 * take) : w;
+        next += (size_t)take;
+        cbits += 8 * take;
+      }
+      return;
+    }
     while (cbits <= 56 && next < n) {
       cache |= (uint64_t)p[next++] << (56 - cbits);
       cbits += 8;
@@ -184,7 +196,7 @@ static uint8_t crc8(const uint8_t* p, size_t n) {
   return c;
 }
 static uint16_t crc16(const uint8_t* p, size_t n) {
-  static uint16_t tab[256];
+  static uint16_t tab[1024];  // tab[256 k + i]: the CRC of byte i followed by k zero bytes
   static std::atomic<bool> ready{false};
   if (!ready.load(std::memory_order_acquire)) {
     for (int i = 0; i < 256; ++i) {
@@ -192,10 +204,20 @@ static uint16_t crc16(const uint8_t* p, size_t n) {
       for (int b = 0; b < 8; ++b) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1));
       tab[i] = c;
     }
+    for (int k = 1; k < 4; ++k)
+      for (int i = 0; i < 256; ++i) {
+        const uint16_t v = tab[256 * (k - 1) + i];
+        tab[256 * k + i] = (uint16_t)((v << 8) ^ tab[v >> 8]);
+      }
     ready.store(true, std::memory_order_release);
   }
   uint16_t c = 0;
-  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ tab[(c >> 8) ^ p[i]]);
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4) {  // slicing by four: the table lookups of a step do not depend on each other
+    const uint16_t t = (uint16_t)(c ^ (uint16_t)((p[i] << 8) | p[i + 1]));
+    c = (uint16_t)(tab[768 + (t >> 8)] ^ tab[512 + (t & 0xff)] ^ tab[256 + p[i + 2]] ^ tab[p[i + 3]]);
+  }
+  for (; i < n; ++i) c = (uint16_t)((c << 8) ^ tab[(c >> 8) ^ p[i]]);
   return c;
 }
 
@@ -307,14 +329,50 @@ static bool flac_residual(BitReader& br, int32_t* out, int blocksize, int order)
       for (; cnt > 0; --cnt) out[i++] = (int32_t)br.sbits(nb);
     } else {
       for (; cnt > 0; --cnt) {
-        const uint32_t q = br.unary();
-        const uint32_t u = (q << k) | (uint32_t)br.bits(k);
+        uint32_t q, r;
+        if (br.cbits < 48) br.refill();
+        const int lz = br.cache ? __builtin_clzll(br.cache) : 64;
+        if (lz + 1 + k <= br.cbits) {  // the whole code word (unary part + stop bit + k binary bits) sits in the window
+          q = (uint32_t)lz;
+          const uint64_t rest = lz == 63 ? 0 : br.cache << (lz + 1);
+          r = k ? (uint32_t)(rest >> (64 - k)) : 0u;
+          br.cache = k ? rest << k : rest;
+          br.cbits -= lz + 1 + k;
+        } else {
+          q = br.unary();
+          r = (uint32_t)br.bits(k);
+        }
+        const uint32_t u = (q << k) | r;
         out[i++] = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
       }
     }
     if (!br.ok) return false;
   }
   return i == blocksize;
+}
+// out[i] += (sum_j coef[j] * out[i - 1 - j]) >> shift for i >= order, with the order known at compile time (the loop over j unrolls,
+// the products overlap; only the last one waits for out[i - 1]).  Wrapping 64-bit sums: a corrupt stream must not reach signed
+// overflow; valid streams never wrap.
+template <int ORDER>
+static void lpc_restore_n(int32_t* out, int blocksize, const int32_t* coef, int shift) {
+  int64_t c[ORDER];
+  for (int j = 0; j < ORDER; ++j) c[j] = coef[j];
+  for (int i = ORDER; i < blocksize; ++i) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int j = ORDER - 1; j >= 0; --j) acc += (uint64_t)(c[j] * out[i - 1 - j]);  // (oldest sample first: the newest arrives last)
+    out[i] = (int32_t)(uint32_t)((uint64_t)(int64_t)out[i] + (uint64_t)((int64_t)acc >> shift));
+  }
+}
+static void lpc_restore(int32_t* out, int blocksize, int order, const int32_t* coef, int shift) {
+  switch (order) {
+#define EA_LPC(N) case N: lpc_restore_n<N>(out, blocksize, coef, shift); return;
+    EA_LPC(1) EA_LPC(2) EA_LPC(3) EA_LPC(4) EA_LPC(5) EA_LPC(6) EA_LPC(7) EA_LPC(8) EA_LPC(9) EA_LPC(10) EA_LPC(11) EA_LPC(12)
+    EA_LPC(13) EA_LPC(14) EA_LPC(15) EA_LPC(16) EA_LPC(17) EA_LPC(18) EA_LPC(19) EA_LPC(20) EA_LPC(21) EA_LPC(22) EA_LPC(23) EA_LPC(24)
+    EA_LPC(25) EA_LPC(26) EA_LPC(27) EA_LPC(28) EA_LPC(29) EA_LPC(30) EA_LPC(31) EA_LPC(32)
+#undef EA_LPC
+    default: return;
+  }
 }
 static bool flac_subframe(BitReader& br, int32_t* out, int blocksize, int bps) {
   if (br.bit()) return false;  // padding bit
@@ -354,11 +412,7 @@ static bool flac_subframe(BitReader& br, int32_t* out, int blocksize, int bps) {
     int32_t coef[32];
     for (int j = 0; j < order; ++j) coef[j] = (int32_t)br.sbits(prec);
     if (!flac_residual(br, out, blocksize, order)) return false;
-    for (int i = order; i < blocksize; ++i) {
-      uint64_t acc = 0;  // (wrapping sums: a corrupt stream must not reach signed overflow; valid streams never wrap)
-      for (int j = 0; j < order; ++j) acc += (uint64_t)((int64_t)coef[j] * out[i - 1 - j]);
-      out[i] = (int32_t)(uint32_t)((uint64_t)(int64_t)out[i] + (uint64_t)((int64_t)acc >> shift));
-    }
+    lpc_restore(out, blocksize, order, coef, shift);
   } else {
     return false;  // reserved subframe type
   }
