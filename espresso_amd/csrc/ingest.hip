@@ -196,7 +196,7 @@ static uint8_t crc8(const uint8_t* p, size_t n) {
   return c;
 }
 static uint16_t crc16(const uint8_t* p, size_t n) {
-  static uint16_t tab[1024];  // tab[256 k + i]: the CRC of byte i followed by k zero bytes
+  static uint16_t tab[2048];  // tab[256 k + i]: the CRC of byte i followed by k zero bytes
   static std::atomic<bool> ready{false};
   if (!ready.load(std::memory_order_acquire)) {
     for (int i = 0; i < 256; ++i) {
@@ -204,7 +204,7 @@ static uint16_t crc16(const uint8_t* p, size_t n) {
       for (int b = 0; b < 8; ++b) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1));
       tab[i] = c;
     }
-    for (int k = 1; k < 4; ++k)
+    for (int k = 1; k < 8; ++k)
       for (int i = 0; i < 256; ++i) {
         const uint16_t v = tab[256 * (k - 1) + i];
         tab[256 * k + i] = (uint16_t)((v << 8) ^ tab[v >> 8]);
@@ -213,9 +213,10 @@ static uint16_t crc16(const uint8_t* p, size_t n) {
   }
   uint16_t c = 0;
   size_t i = 0;
-  for (; i + 4 <= n; i += 4) {  // slicing by four: the table lookups of a step do not depend on each other
+  for (; i + 8 <= n; i += 8) {  // slicing by eight: the table lookups of a step do not depend on each other
     const uint16_t t = (uint16_t)(c ^ (uint16_t)((p[i] << 8) | p[i + 1]));
-    c = (uint16_t)(tab[768 + (t >> 8)] ^ tab[512 + (t & 0xff)] ^ tab[256 + p[i + 2]] ^ tab[p[i + 3]]);
+    c = (uint16_t)(tab[1792 + (t >> 8)] ^ tab[1536 + (t & 0xff)] ^ tab[1280 + p[i + 2]] ^ tab[1024 + p[i + 3]] ^ tab[768 + p[i + 4]] ^
+                   tab[512 + p[i + 5]] ^ tab[256 + p[i + 6]] ^ tab[p[i + 7]]);
   }
   for (; i < n; ++i) c = (uint16_t)((c << 8) ^ tab[(c >> 8) ^ p[i]]);
   return c;
@@ -328,23 +329,45 @@ static bool flac_residual(BitReader& br, int32_t* out, int blocksize, int order)
       const int nb = (int)br.bits(5);
       for (; cnt > 0; --cnt) out[i++] = (int32_t)br.sbits(nb);
     } else {
-      for (; cnt > 0; --cnt) {
+      // the window lives in locals for the partition: `out` is an int32_t*, the reader's counters are ints — through the struct
+      // every store to out[] would force them back to memory
+      uint64_t cache = br.cache;
+      int cbits = br.cbits;
+      size_t next = br.next;
+      const uint8_t* const bp = br.p;
+      const size_t bn = br.n;
+      int32_t* o = out + i;
+      int32_t* const oe = o + cnt;
+      while (o < oe) {
+        if (cbits < 48 && next + 8 <= bn) {  // top the window up to 57 .. 64 bits with one unaligned big-endian load
+          uint64_t w;
+          memcpy(&w, bp + next, 8);
+          w = __builtin_bswap64(w);
+          const int take = (64 - cbits) >> 3;
+          cache |= cbits ? (w >> (64 - 8 * take)) << (64 - cbits - 8 * take) : w;
+          next += (size_t)take;
+          cbits += 8 * take;
+        }
+        const int lz = cache ? __builtin_clzll(cache) : 64;
         uint32_t q, r;
-        if (br.cbits < 48) br.refill();
-        const int lz = br.cache ? __builtin_clzll(br.cache) : 64;
-        if (lz + 1 + k <= br.cbits) {  // the whole code word (unary part + stop bit + k binary bits) sits in the window
+        if (k > 0 && lz + 1 + k <= cbits && lz < 32) {  // the whole code word (unary part, stop bit, k binary bits) sits in the window
           q = (uint32_t)lz;
-          const uint64_t rest = lz == 63 ? 0 : br.cache << (lz + 1);
-          r = k ? (uint32_t)(rest >> (64 - k)) : 0u;
-          br.cache = k ? rest << k : rest;
-          br.cbits -= lz + 1 + k;
-        } else {
+          const uint64_t rest = cache << (lz + 1);
+          r = (uint32_t)(rest >> (64 - k));
+          cache = rest << k;
+          cbits -= lz + 1 + k;
+        } else {  // k = 0, a long code word or the tail of the buffer: the general reader
+          br.cache = cache; br.cbits = cbits; br.next = next;
           q = br.unary();
           r = (uint32_t)br.bits(k);
+          cache = br.cache; cbits = br.cbits; next = br.next;
+          if (!br.ok) break;
         }
         const uint32_t u = (q << k) | r;
-        out[i++] = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
+        *o++ = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
       }
+      br.cache = cache; br.cbits = cbits; br.next = next;
+      i += cnt;
     }
     if (!br.ok) return false;
   }
