@@ -11,6 +11,13 @@
 //
 // Same products, same rounding points, same accumulation order along k (BK = 64, two 16x16x32 MFMAs per accumulator and k-tile)
 // as the 4-wave kernels: outputs are bit-identical to theirs (checked by tests/test_gpu_parity.py).
+//
+// Where it is used (ea_gemm_w8_try; measurements in DESIGN.md 3.1b and profiles/r05_*): launches whose tile grid is ONE dispatch
+// round on the chip (128 < tiles <= 256: the encoder layers' forward products at M ~ 6 200 rows) while nothing else runs GEMMs
+// beside them (the layer runtime's co-run hint: backward keeps the 4-wave kernels, whose 24 - 72 KB workgroups still find room
+// next to a weight-gradient launch), and launches of >= 1 024 tiles with N >= 1 024 (the transducer joint's vocabulary projection,
+// also with a ragged N inside a padded row pitch).  8 - 24 % faster than the 4-wave kernels in isolation, 1.3 % of the update step:
+// the step's GEMMs are bound by cold first tiles, the per-CU L2 -> LDS rate and lock-step epilogue writes, not by the k loop.
 #include "common.h"
 #include "espresso_amd.h"
 #include "gemm_common.h"
