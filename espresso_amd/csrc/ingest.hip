@@ -69,7 +69,10 @@ static int wav_parse(const uint8_t* p, size_t n, size_t file_len, WavFmt& w) {
       if (off + 8 + 16 > n) return -3;
       const uint8_t* q = p + off + 8;
       w.format = le16(q); w.channels = le16(q + 2); w.rate = (int)le32(q + 4); w.block = le16(q + 12); w.bits = le16(q + 14);
-      if (w.format == 0xFFFE && len >= 26) w.format = le16(q + 24);  // WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first word
+      if (w.format == 0xFFFE) {  // WAVE_FORMAT_EXTENSIBLE: the sub-format GUID's first word — only when the chunk really holds it
+        if (len < 26 || off + 8 + 26 > n) return -3;
+        w.format = le16(q + 24);
+      }
       have_fmt = true;
     } else if (memcmp(p + off, "data", 4) == 0) {
       if (!have_fmt) return -3;
@@ -94,10 +97,10 @@ static long wav_decode(const Bytes& b, int16_t* dst, long cap, Info& in) {
   int rc = wav_parse(b.d.data(), b.d.size(), b.d.size(), w);
   if (rc == 0) rc = wav_info(w, in);
   if (rc) return rc;
+  if (!dst || in.frames == 0) return in.frames;  // (header-only use: ea_audio_verify)
   if (in.frames > cap) return -5;
   const uint8_t* p = b.d.data() + w.data_off;
   const int step = w.bits / 8 * w.channels;
-  if (!dst || in.frames == 0) return in.frames;  // (header-only use: ea_audio_verify)
   if (w.bits == 16 && w.channels == 1) {
     memcpy(dst, p, (size_t)in.frames * 2);  // (little-endian host)
     return in.frames;
@@ -195,10 +198,9 @@ static uint8_t crc8(const uint8_t* p, size_t n) {
   }
   return c;
 }
-static uint16_t crc16(const uint8_t* p, size_t n) {
-  static uint16_t tab[2048];  // tab[256 k + i]: the CRC of byte i followed by k zero bytes
-  static std::atomic<bool> ready{false};
-  if (!ready.load(std::memory_order_acquire)) {
+struct Crc16Table {  // tab[256 k + i]: the CRC of byte i followed by k zero bytes
+  uint16_t tab[2048];
+  Crc16Table() {
     for (int i = 0; i < 256; ++i) {
       uint16_t c = (uint16_t)(i << 8);
       for (int b = 0; b < 8; ++b) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1));
@@ -209,8 +211,11 @@ static uint16_t crc16(const uint8_t* p, size_t n) {
         const uint16_t v = tab[256 * (k - 1) + i];
         tab[256 * k + i] = (uint16_t)((v << 8) ^ tab[v >> 8]);
       }
-    ready.store(true, std::memory_order_release);
   }
+};
+static uint16_t crc16(const uint8_t* p, size_t n) {
+  static const Crc16Table T;  // (function-local static: built once, thread-safe by C++11 — the batch reader's threads all start here)
+  const uint16_t* tab = T.tab;
   uint16_t c = 0;
   size_t i = 0;
   for (; i + 8 <= n; i += 8) {  // slicing by eight: the table lookups of a step do not depend on each other
@@ -402,6 +407,7 @@ static bool flac_subframe(BitReader& br, int32_t* out, int blocksize, int bps) {
   const int type = (int)br.bits(6);
   int wasted = 0;
   if (br.bit()) wasted = (int)br.unary() + 1;
+  if (wasted > 31 || wasted >= bps) return false;  // (a shift by the type width is undefined; a subframe keeps at least one bit)
   bps -= wasted;
   if (bps < 1 || bps > 33) return false;
   if (type == 0) {
@@ -501,11 +507,12 @@ static long flac_decode(const Bytes& b, int16_t* dst, long cap, Info& in, int* m
       default: bps = -1; break;
     }
     if (bps < 0 || !br.ok) { ++off; continue; }
+    const bool bps_mismatch = bps != in.bits;  // (decided after the CRC-8: only a REAL frame header may fail the stream)
     const size_t hdr_bytes = br.pos() >> 3;
     const uint8_t want8 = (uint8_t)br.bits(8);
     if (!br.ok || crc8(p + off, hdr_bytes) != want8) { ++off; continue; }  // not a frame header after all
     const int nch = ca < 8 ? ca + 1 : 2;
-    if (nch != in.channels || blocksize > 65536) return -6;
+    if (nch != in.channels || blocksize > 65536 || bps_mismatch) return -6;  // frames must agree with STREAMINFO (channels, sample size)
     for (int c = 0; c < nch; ++c) {
       const int side = (ca == 8 && c == 1) || (ca == 9 && c == 0) || (ca == 10 && c == 1);
       if (!flac_subframe(br, ch.data() + (size_t)c * 65536, blocksize, bps + side)) return -6;

@@ -94,7 +94,9 @@ def _decode(w: "wave.Wave_read") -> Tuple[np.ndarray, int]:
 
 def get_waveform(source: Union[str, bytes, io.BytesIO]) -> Tuple[np.ndarray, int]:
     """`source`: a WAV / FLAC path, WAV bytes, or a shell command ending with `|` that writes a WAV to stdout.
-    Returns fp32 samples at int16 scale (`normalization=False`) and the sample rate."""
+    Returns fp32 samples at int16 scale (`normalization=False`) and the sample rate.
+    FLAC wider than 16 bits is TRUNCATED to its top 16 bits by the int16 reader (LibriSpeech and every corpus of the recipes is
+    16-bit; a 24-bit WAV keeps its low-order bits as a fraction, as soundfile * 2^15 does in the reference)."""
     if _is_file(source):
         bits = probe(source)[3]
         with open(source, "rb") as f:

@@ -58,6 +58,10 @@ typedef struct EaGemmParams {
   const void* aux;    /* bf16 pre-activation [M][ldaux] or NULL */
   int M, N, K, batch, zdiv;
   int a_kstrided, b_kstrided, c_f32, accumulate, resid_f32, act;
+  /* Row pitches in elements.  CONTRACT for ldc > N (a padded output pitch): the columns N .. ldc - 1 of a row are PADDING that
+   * the library may overwrite with unspecified finite-or-not values (the 8-wave kernels store whole 32-column groups when
+   * N % 4 == 0 and ldc >= roundup32(N)); a caller that later reduces over the pitch instead of over N must zero the pad itself
+   * (as ea_rnnt_grad does for the joint's gradient). */
   long lda, ldb, ldc, ldc2, ldr, ldaux;
   long sA_hi, sA_lo, sB_hi, sB_lo, sC_hi, sC_lo, sR_hi, sR_lo, sX_hi, sX_lo;
   float alpha, out_scale;

@@ -225,3 +225,57 @@ def test_readers_survive_corrupt_files_under_sanitizers(tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", LD_PRELOAD=""))
     assert run.returncode == 0 and "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, (run.stdout[-500:], run.stderr[-3000:])
     assert "2700 mutants" in run.stdout, run.stdout
+
+
+def test_advice_r5_wav_header_edge_cases(tmp_path):
+    """(1) a WAVE_FORMAT_EXTENSIBLE `fmt ` chunk that is declared long but truncated after its first 16 bytes
+    must be rejected (-3), not read past the buffer (found under ASan); (2) ea_audio_verify of a WAV is 1 ("WAV: always 1"),
+    not the -5 of a capacity check that ran before the header-only early-out; (3) a FLAC frame whose sample size disagrees with
+    STREAMINFO fails the stream (-6) instead of being silently truncated."""
+    import ctypes
+
+    from espresso_amd import _lib
+
+    lib = _lib.lib()
+    p = str(tmp_path / "trunc.wav")
+    fmt16 = struct.pack("<HHIIHH", 0xFFFE, 1, 16000, 32000, 2, 16)
+    open(p, "wb").write(b"RIFF" + struct.pack("<I", 28) + b"WAVE" + b"fmt " + struct.pack("<I", 40) + fmt16)  # 36 bytes
+    n, sr, ch, bits = ctypes.c_long(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.ea_audio_probe(p.encode(), ctypes.byref(n), ctypes.byref(sr), ctypes.byref(ch), ctypes.byref(bits)) != 0
+    buf = np.zeros(16, dtype=np.int16)
+    assert lib.ea_audio_read_i16(p.encode(), buf.ctypes.data_as(ctypes.c_void_p), 16, ctypes.byref(sr)) < 0
+    # a complete EXTENSIBLE header still reads
+    x = _signal(100)
+    q = str(tmp_path / "ext.wav")
+    _write_wav(q, x, extensible=True)
+    assert np.array_equal(AU.read_i16(q)[0], x)
+    assert lib.ea_audio_verify(q.encode()) == 1
+    w = str(tmp_path / "plain.wav")
+    _write_wav(w, x)
+    assert lib.ea_audio_verify(w.encode()) == 1
+    # FLAC: flip the frame header's sample-size code of a 16-bit stream to "24 bits" and repair the header CRC-8
+    f = bytearray(FE.encode(_signal(4096, seed=3), blocksize=4096))
+    i = f.index(b"\xff\xf8", 42)
+    hdr_len = None
+    for L in range(5, 17):  # the header ends where its CRC-8 matches
+        c = 0
+        for byte in f[i:i + L]:
+            c ^= byte
+            for _ in range(8):
+                c = ((c << 1) ^ 0x07) & 0xFF if c & 0x80 else (c << 1) & 0xFF
+        if c == f[i + L]:
+            hdr_len = L
+            break
+    assert hdr_len is not None
+    assert (f[i + 3] >> 1) & 7 in (0, 4)
+    f[i + 3] = (f[i + 3] & 0xF1) | (6 << 1)
+    c = 0
+    for byte in f[i:i + hdr_len]:
+        c ^= byte
+        for _ in range(8):
+            c = ((c << 1) ^ 0x07) & 0xFF if c & 0x80 else (c << 1) & 0xFF
+    f[i + hdr_len] = c
+    g = str(tmp_path / "bps.flac")
+    open(g, "wb").write(bytes(f))
+    out = np.zeros(4096, dtype=np.int16)
+    assert lib.ea_audio_read_i16(g.encode(), out.ctypes.data_as(ctypes.c_void_p), 4096, ctypes.byref(sr)) == -6
