@@ -17,11 +17,40 @@ namespace {
 
 constexpr int MAXC8_LIMIT = 4;  // supports C <= 64*8*4 = 2048
 
+// eight consecutive elements of a bf16 or fp32 row <-> fp32 registers (fp32 islands of the reference's autocast run: the joint
+// network's LayerNorm outputs and their gradients stay fp32, speech_transformer_transducer_base.py:292-294)
+template <typename T>
+__device__ inline void load8(const T* p, float (&v)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __uint_as_float(w[e] << 16);
+      v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <typename T>
+__device__ inline void store8(T* p, const float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    uint4 u;
+    u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
 // rows are processed one per wave. C % 8 == 0 required.  MAXC8 = 16-byte chunks per lane (C <= 512*MAXC8).
-template <int MAXC8>
+template <int MAXC8, typename TY = bf16_t>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C,
+    TY* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C,
     float eps, const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep) {
   const int lane = threadIdx.x & 63;
   const int nch = C >> 3;  // 16-byte chunks per row
@@ -85,12 +114,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
         if (thr) t *= ea_keep(seed, (uint64_t)row * C + c, thr, inv_keep);
         o[e] = zero ? 0.f : t;
       }
-      uint4 u;
-      u.x = pack_bf2(o[0], o[1]);
-      u.y = pack_bf2(o[2], o[3]);
-      u.z = pack_bf2(o[4], o[5]);
-      u.w = pack_bf2(o[6], o[7]);
-      *reinterpret_cast<uint4*>(y + (long)row * C + ch * 8) = u;
+      store8(y + (long)row * C + ch * 8, o);
     }
   }
   }
@@ -184,9 +208,9 @@ struct LnOut2 {
   uint32_t thr;
   float inv_keep;
 };
-template <int MAXC8>
+template <int MAXC8, typename TD = bf16_t>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
-    const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
+    const bf16_t* __restrict__ x, const TD* __restrict__ dy, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int rows_per_block,
     const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep,
@@ -213,14 +237,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   for (int row = r0 + wave; row < r1; row += 4) {
     // every load of the row is requested up front — the residual-path gradient too, which used to be fetched only after the two
     // wave reductions (a second exposed round trip per row), and the padding flag last (its first use is a branch: a wait)
-    uint4 ux_[MAXC8], ud_[MAXC8], ua_[MAXC8];
+    uint4 ux_[MAXC8], ua_[MAXC8];
+    float dy_[MAXC8][8];
 #pragma unroll
     for (int i = 0; i < MAXC8; ++i) {
       const int ch = lane + 64 * i;
-      ux_[i] = ud_[i] = ua_[i] = uint4{0, 0, 0, 0};
+      ux_[i] = ua_[i] = uint4{0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dy_[i][e] = 0.f;
       if (ch < nch) {
         ux_[i] = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
-        ud_[i] = *reinterpret_cast<const uint4*>(dy + (long)row * C + ch * 8);
+        load8(dy + (long)row * C + ch * 8, dy_[i]);
         if (dx_add) ua_[i] = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
       }
     }
@@ -233,15 +260,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int ch = lane + 64 * i;
       if (ch < nch) {
         const uint4 ux = ux_[i];
-        const uint4 ud = ud_[i];
         const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
-        const uint32_t wd[4] = {ud.x, ud.y, ud.z, ud.w};
         float k8[8];
         if (thr) ea_keep8(seed, (uint64_t)row * C + ch * 8, thr, inv_keep, k8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
-          float dv = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
+          float dv = dy_[i][e];
           if (zero) dv = 0.f;
           if (thr) dv *= k8[e];
           const float h = (xv - mean) * rstd;
@@ -399,6 +424,25 @@ extern "C" int ea_layernorm_fwd(const void* x, const float* gamma, const float* 
   return EA_CHECK_LAUNCH();
 }
 
+// the same with an fp32 output (x stays bf16: a Linear's output): the joint network's two LayerNorms, whose outputs the
+// reference adds and rectifies in fp32 (speech_transformer_transducer_base.py:292-294 under autocast)
+extern "C" int ea_layernorm_fwd_f32out(const void* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                       int M, int C, float eps, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                                       float drop_scale, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
+  int fblocks = (M + 3) / 4;
+  if (fblocks > 1024) fblocks = (fblocks + 1) / 2 > 1024 ? (fblocks + 1) / 2 : 1024;
+#define EA_LN_FWD32(NC)                                                                                                \
+  hipLaunchKernelGGL((ln_fwd_kernel<NC, float>), dim3(fblocks), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, y, \
+                     mean, rstd, M, C, eps, row_zero, drop_seed, drop_thr, drop_scale)
+  if (C <= 512) EA_LN_FWD32(1);
+  else if (C <= 1024) EA_LN_FWD32(2);
+  else EA_LN_FWD32(4);
+#undef EA_LN_FWD32
+  return EA_CHECK_LAUNCH();
+}
+
 static inline int ln_bwd_rows_per_block(int M, bool have_ws) {
   if (have_ws) return 8;
   // atomic path: ~512 blocks keep the dgamma/dbeta atomics (2*C per block) bounded
@@ -415,11 +459,23 @@ extern "C" long ea_layernorm_bwd_workspace_bytes(int M, int C) {
 static int ln_bwd_launch(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
                          float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
                          float drop_scale, const void* dx_add, void* workspace, hipStream_t stream, bool reduce_params,
-                         const LnOut2& o2) {
+                         const LnOut2& o2, bool dy_f32 = false) {
   if (M <= 0) return 0;
   if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
   const int rpb = ln_bwd_rows_per_block(M, workspace != nullptr);
   const int nblk = (M + rpb - 1) / rpb;
+  if (dy_f32) {
+#define EA_LN_BWD32(NC)                                                                                                \
+  hipLaunchKernelGGL((ln_bwd_kernel<NC, float>), dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,         \
+                     (const bf16_t*)x, (const float*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, C, rpb,     \
+                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace, o2)
+    if (C <= 512) EA_LN_BWD32(1);
+    else if (C <= 1024) EA_LN_BWD32(2);
+    else EA_LN_BWD32(4);
+#undef EA_LN_BWD32
+    if (workspace && reduce_params) return ea_layernorm_param_reduce(workspace, dgamma, dbeta, M, C, stream);
+    return EA_CHECK_LAUNCH();
+  }
 #define EA_LN_BWD(NC)                                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<NC>), dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,                \
                      (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, C, rpb,    \
@@ -473,6 +529,14 @@ extern "C" int ea_layernorm_bwd(const void* x, const void* dy, const float* gamm
                                 float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
   return ln_bwd_launch(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, M, C, row_zero, drop_seed, drop_thr, drop_scale, dx_add,
                        workspace, stream, true, LnOut2{nullptr, 1.f, 0, 0, 1.f});
+}
+// ea_layernorm_bwd with an fp32 incoming gradient (of an fp32 LayerNorm output, ea_layernorm_fwd_f32out)
+extern "C" int ea_layernorm_bwd_f32dy(const void* x, const float* dy, const float* gamma, const float* mean,
+                                      const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C,
+                                      const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                                      float drop_scale, const void* dx_add, void* workspace, hipStream_t stream) {
+  return ln_bwd_launch(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, M, C, row_zero, drop_seed, drop_thr, drop_scale, dx_add,
+                       workspace, stream, true, LnOut2{nullptr, 1.f, 0, 0, 1.f}, true);
 }
 // dx only (workspace required): the caller runs ea_layernorm_param_reduce later, possibly on another stream
 extern "C" int ea_layernorm_bwd_dx(const void* x, const void* dy, const float* gamma, const float* mean,

@@ -293,9 +293,30 @@ __global__ __launch_bounds__(256) void joint_add_relu_kernel(const bf16_t* __res
     *reinterpret_cast<uint4*>(Z + node * J + ch * 8) = make_uint4(wo[0], wo[1], wo[2], wo[3]);
   }
 }
+// the same on fp32 E / D (the reference's autocast run adds and rectifies the two LayerNorm outputs in fp32; only fc_out's operand
+// is bf16): one 16-byte chunk of Z per thread, two 16-byte loads per operand
+__global__ __launch_bounds__(256) void joint_add_relu_f32_kernel(const float* __restrict__ E, const float* __restrict__ D,
+                                                                 bf16_t* __restrict__ Z, int T, int U1, int J, long nchunks) {
+  const int nch = J >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    const long node = i / nch;
+    const int u = (int)(node % U1);
+    const long bt = node / U1;
+    const long b = bt / T;
+    const float* pe = E + bt * J + ch * 8;
+    const float* pd = D + (b * U1 + u) * J + ch * 8;
+    const float4 e0 = *reinterpret_cast<const float4*>(pe), e1 = *reinterpret_cast<const float4*>(pe + 4);
+    const float4 d0 = *reinterpret_cast<const float4*>(pd), d1 = *reinterpret_cast<const float4*>(pd + 4);
+    *reinterpret_cast<uint4*>(Z + node * J + ch * 8) =
+        make_uint4(pack_bf2(fmaxf(e0.x + d0.x, 0.f), fmaxf(e0.y + d0.y, 0.f)), pack_bf2(fmaxf(e0.z + d0.z, 0.f), fmaxf(e0.w + d0.w, 0.f)),
+                   pack_bf2(fmaxf(e1.x + d1.x, 0.f), fmaxf(e1.y + d1.y, 0.f)), pack_bf2(fmaxf(e1.z + d1.z, 0.f), fmaxf(e1.w + d1.w, 0.f)));
+  }
+}
 // dE[b][t][:] = sum_u dZ[b][t][u][:]  (mode 0, rows = B*T, inner = U1 consecutive rows)
 // dD[b][u][:] = sum_t dZ[b][t][u][:]  (mode 1, rows = B*U1, inner = T rows U1*J apart)
-__global__ __launch_bounds__(256) void joint_reduce_kernel(const bf16_t* __restrict__ dZ, bf16_t* __restrict__ out, int T, int U1, int J,
+template <typename TO>
+__global__ __launch_bounds__(256) void joint_reduce_kernel(const bf16_t* __restrict__ dZ, TO* __restrict__ out, int T, int U1, int J,
                                                            int mode, long nrows) {
   const int nch = J >> 3;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nrows * nch; i += (long)gridDim.x * blockDim.x) {
@@ -316,8 +337,13 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const bf16_t* __restr
         acc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
       }
     }
-    *reinterpret_cast<uint4*>(out + row * J + ch * 8) =
-        make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
+    if constexpr (sizeof(TO) == 2) {
+      *reinterpret_cast<uint4*>(out + row * J + ch * 8) =
+          make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
+    } else {
+      *reinterpret_cast<float4*>(out + row * J + ch * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(out + row * J + ch * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
   }
 }
 
@@ -340,8 +366,28 @@ extern "C" int ea_joint_reduce(const void* dZ, void* dE, void* dD, int B, int T,
   long bE = (rE * (J / 8) + 255) / 256, bD = (rD * (J / 8) + 255) / 256;
   if (bE > 16384) bE = 16384;
   if (bD > 16384) bD = 16384;
-  if (dE) hipLaunchKernelGGL(joint_reduce_kernel, dim3((unsigned)bE), dim3(256), 0, stream, (const bf16_t*)dZ, (bf16_t*)dE, T, U1, J, 0, rE);
-  if (dD) hipLaunchKernelGGL(joint_reduce_kernel, dim3((unsigned)bD), dim3(256), 0, stream, (const bf16_t*)dZ, (bf16_t*)dD, T, U1, J, 1, rD);
+  if (dE) hipLaunchKernelGGL(joint_reduce_kernel<bf16_t>, dim3((unsigned)bE), dim3(256), 0, stream, (const bf16_t*)dZ, (bf16_t*)dE, T, U1, J, 0, rE);
+  if (dD) hipLaunchKernelGGL(joint_reduce_kernel<bf16_t>, dim3((unsigned)bD), dim3(256), 0, stream, (const bf16_t*)dZ, (bf16_t*)dD, T, U1, J, 1, rD);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_joint_add_relu_f32(const float* E, const float* D, void* Z, int B, int T, int U1, int J, hipStream_t stream) {
+  const long nchunks = (long)B * T * U1 * (J / 8);
+  if (nchunks <= 0) return 0;
+  if (J % 8) return -2;
+  long blocks = (nchunks + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(joint_add_relu_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, E, D, (bf16_t*)Z, T, U1, J, nchunks);
+  return EA_CHECK_LAUNCH();
+}
+extern "C" int ea_joint_reduce_f32(const void* dZ, float* dE, float* dD, int B, int T, int U1, int J, hipStream_t stream) {
+  if ((long)B * T * U1 <= 0) return 0;
+  if (J % 8) return -2;
+  const long rE = (long)B * T, rD = (long)B * U1;
+  long bE = (rE * (J / 8) + 255) / 256, bD = (rD * (J / 8) + 255) / 256;
+  if (bE > 16384) bE = 16384;
+  if (bD > 16384) bD = 16384;
+  if (dE) hipLaunchKernelGGL(joint_reduce_kernel<float>, dim3((unsigned)bE), dim3(256), 0, stream, (const bf16_t*)dZ, dE, T, U1, J, 0, rE);
+  if (dD) hipLaunchKernelGGL(joint_reduce_kernel<float>, dim3((unsigned)bD), dim3(256), 0, stream, (const bf16_t*)dZ, dD, T, U1, J, 1, rD);
   return EA_CHECK_LAUNCH();
 }
 

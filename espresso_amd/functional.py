@@ -361,9 +361,9 @@ def linear(x, w, b=None, out_f32=False):
 # ------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, b, eps, row_zero, drop_p):
+    def forward(ctx, x, g, b, eps, row_zero, drop_p, out_f32=False):
         seed = _next_seed("ln.out", drop_p) if drop_p > 0 else 0
-        y, mean, rstd = K.layernorm_fwd(x, g, b, eps, row_zero, drop_p, seed)
+        y, mean, rstd = K.layernorm_fwd(x, g, b, eps, row_zero, drop_p, seed, out_f32=out_f32)
         ctx.save_for_backward(x, g, mean, rstd, row_zero)
         ctx.drop = (drop_p, seed)
         ctx.params = (g, b)
@@ -378,13 +378,14 @@ class _LayerNorm(torch.autograd.Function):
         dg, db = (sg, sb) if direct else (_zeros_f32(C, x), _zeros_f32(C, x))
         dx = K.layernorm_bwd(x, dy.contiguous(), g, mean, rstd, dg, db, row_zero, ctx.drop[0], ctx.drop[1])
         if direct:
-            return dx, None, None, None, None, None
-        return dx, dg, db, None, None, None
+            return dx, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None
 
 
-def layer_norm(x, g, b, eps=1e-5, row_zero=None, drop_p=0.0):
-    """y = zero_rows(dropout(LN(x)))  (row_zero: uint8 [M] marks padded frames)."""
-    return _LayerNorm.apply(x, g, b, eps, row_zero, drop_p)
+def layer_norm(x, g, b, eps=1e-5, row_zero=None, drop_p=0.0, out_f32=False):
+    """y = zero_rows(dropout(LN(x)))  (row_zero: uint8 [M] marks padded frames).  out_f32: fp32 output and, in backward, an fp32
+    incoming gradient (the reference's autocast keeps LayerNorm outputs in fp32: used where the consumer is not a GEMM)."""
+    return _LayerNorm.apply(x, g, b, eps, row_zero, drop_p, out_f32)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1926,10 +1927,15 @@ def lstm_cell_step(x16, cell, h_prev16, h_prev32, c_prev, keep_row=None):
 
 
 # ------------------------------------------------------------------------------------------------ transducer joint
+_JOINT_LOGITS_F32 = os.environ.get("EA_JOINT_LOGITS_F32", "0") == "1"
+
+
 class _TransducerJoint(torch.autograd.Function):
     """logits[b,t,u,:] = fc_out(relu(E[b,t] + D[b,u]))  — espresso/models/transformer/speech_transformer_transducer_base.py:276-299
-    after the two LayerNorm'd projections.  E bf16 [B*T][J], D bf16 [B*U1][J], w fp32 [V][J] (the effective, weight-normed
-    matrix), returns bf16 [B][T][U1][V] (what the reference's fc_out yields under bf16 autocast)."""
+    after the two LayerNorm'd projections.  E fp32 [B*T][J], D fp32 [B*U1][J] (LayerNorm outputs: fp32 under the reference's
+    autocast, so the sum, the ReLU and its derivative mask are evaluated in fp32 — with bf16 E / D the mask flipped within an ulp
+    of the kink and the gradients were 9 - 13 % noisy, rounds 3 - 5), w fp32 [V][J] (the effective, weight-normed matrix);
+    returns bf16 [B][T][U1][V] (what the reference's fc_out yields under bf16 autocast).  dE / dD leave as fp32 sums."""
 
     @staticmethod
     def forward(ctx, E, D, w, b, w16, B, T, U1, late=None):
@@ -1940,10 +1946,13 @@ class _TransducerJoint(torch.autograd.Function):
         # rows padded to a multiple of 64 columns (5004 -> 5056): 16-byte aligned rows for the epilogue stores and the loss kernels,
         # and a reduction length the direct-to-LDS GEMM takes when the logits' gradient is the A operand of the data gradient
         Vp = (V + 63) // 64 * 64
-        buf = torch.empty(n, Vp, dtype=torch.bfloat16, device=E.device)
+        # EA_JOINT_LOGITS_F32=1 (diagnostic, round 6): fp32 lattice logits — isolates how much of the gradient noise between two
+        # bf16 realisations is the bf16 rounding of the logits themselves (the reference's fc_out rounds there too)
+        buf = torch.empty(n, Vp, dtype=torch.float32 if _JOINT_LOGITS_F32 else torch.bfloat16, device=E.device)
         K.gemm(Z, w16, buf, n, V, J, lda=J, ldb=J, ldc=Vp, bias=b)
         ctx.save_for_backward(Z, w16)
         ctx.dims = (B, T, U1, V, J, b is not None, Vp)
+        ctx.ed_f32 = E.dtype == torch.float32
         return buf.view(B, T, U1, Vp)[..., :V]
 
     @staticmethod
@@ -1964,7 +1973,7 @@ class _TransducerJoint(torch.autograd.Function):
         dZ = torch.empty(n, J, dtype=torch.bfloat16, device=dl.device)
         # relu'(pre) == (Z > 0): the post-activation tensor doubles as the derivative mask
         K.gemm(dl, wt, dZ, n, J, Vp, lda=Vp, ldb=Vp, ldc=J, aux=Z, ldaux=J, act="relu")
-        dE, dD = K.joint_reduce(dZ, B, T, U1)
+        dE, dD = K.joint_reduce(dZ, B, T, U1, out_f32=ctx.ed_f32)
         # dW [V][J] = dl^T Z over all B*T*U1 lattice nodes: split-K GEMM on the aligned (padded-pitch) gradient.  (The grouped
         # weight-gradient kernel was tried here: 632 tiles each walking 45 000 rows of a 10 KB-pitch operand ran at 115 TFLOP/s,
         # slower than the split-K launch.)

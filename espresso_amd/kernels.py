@@ -129,32 +129,29 @@ def gemm(
     return C
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, row_zero=None, drop_p=0.0, drop_seed=0, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, row_zero=None, drop_p=0.0, drop_seed=0, save_stats=True, out_f32=False):
+    """out_f32: the output stays fp32 (an fp32 island of the reference's autocast run: the joint network's LayerNorms)."""
     M, C = x.shape
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
-    y = torch.empty_like(x)
+    y = torch.empty(M, C, dtype=torch.float32, device=x.device) if out_f32 else torch.empty_like(x)
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     thr, scale = drop_params(drop_p)
-    check(
-        _lib.lib().ea_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, C, eps, _p(row_zero),
-                                    drop_seed, thr, scale, _stream()),
-        "ea_layernorm_fwd",
-    )
+    fn = _lib.lib().ea_layernorm_fwd_f32out if out_f32 else _lib.lib().ea_layernorm_fwd
+    check(fn(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, C, eps, _p(row_zero), drop_seed, thr, scale, _stream()),
+          "ea_layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(x, dy, gamma, mean, rstd, dgamma, dbeta, row_zero=None, drop_p=0.0, drop_seed=0, dx_add=None):
     M, C = x.shape
-    assert dy.is_contiguous() and dy.dtype == torch.bfloat16
+    assert dy.is_contiguous() and dy.dtype in (torch.bfloat16, torch.float32)
     dx = torch.empty_like(x)
     thr, scale = drop_params(drop_p)
     ws = torch.empty(_lib.lib().ea_layernorm_bwd_workspace_bytes(M, C) // 4, dtype=torch.float32, device=x.device)
-    check(
-        _lib.lib().ea_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), M, C,
-                                    _p(row_zero), drop_seed, thr, scale, _p(dx_add), _p(ws), _stream()),
-        "ea_layernorm_bwd",
-    )
+    fn = _lib.lib().ea_layernorm_bwd_f32dy if dy.dtype == torch.float32 else _lib.lib().ea_layernorm_bwd
+    check(fn(_p(x), _p(dy), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), M, C, _p(row_zero), drop_seed, thr, scale,
+             _p(dx_add), _p(ws), _stream()), "ea_layernorm_bwd")
     return dx
 
 
@@ -712,16 +709,21 @@ def gather_rows(src, parent, out=None):
 
 
 def joint_add_relu(E, D, B, T, U1):
-    """Z [B*T*U1][J] bf16 = relu(E[b,t] + D[b,u])."""
+    """Z [B*T*U1][J] bf16 = relu(E[b,t] + D[b,u]).  E, D fp32 (the model's path: sum and ReLU in fp32 as in the reference's
+    autocast run, only Z is rounded) or both bf16."""
     J = E.shape[1]
+    assert E.dtype == D.dtype and E.is_contiguous() and D.is_contiguous()
     Z = torch.empty(B * T * U1, J, dtype=torch.bfloat16, device=E.device)
-    check(_lib.lib().ea_joint_add_relu(_p(E), _p(D), _p(Z), B, T, U1, J, _stream()), "ea_joint_add_relu")
+    fn = _lib.lib().ea_joint_add_relu_f32 if E.dtype == torch.float32 else _lib.lib().ea_joint_add_relu
+    check(fn(_p(E), _p(D), _p(Z), B, T, U1, J, _stream()), "ea_joint_add_relu")
     return Z
 
 
-def joint_reduce(dZ, B, T, U1):
+def joint_reduce(dZ, B, T, U1, out_f32=False):
     J = dZ.shape[1]
-    dE = torch.empty(B * T, J, dtype=torch.bfloat16, device=dZ.device)
-    dD = torch.empty(B * U1, J, dtype=torch.bfloat16, device=dZ.device)
-    check(_lib.lib().ea_joint_reduce(_p(dZ), _p(dE), _p(dD), B, T, U1, J, _stream()), "ea_joint_reduce")
+    dt = torch.float32 if out_f32 else torch.bfloat16
+    dE = torch.empty(B * T, J, dtype=dt, device=dZ.device)
+    dD = torch.empty(B * U1, J, dtype=dt, device=dZ.device)
+    fn = _lib.lib().ea_joint_reduce_f32 if out_f32 else _lib.lib().ea_joint_reduce
+    check(fn(_p(dZ), _p(dE), _p(dD), B, T, U1, J, _stream()), "ea_joint_reduce")
     return dE, dD

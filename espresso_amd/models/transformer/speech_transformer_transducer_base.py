@@ -95,13 +95,14 @@ class SpeechTransformerTransducerModelBase(nn.Module):
 
     def _joint_decoder_branch(self, dec_bu):
         return F.layer_norm(F.linear(dec_bu, self.proj_decoder.weight, self.proj_decoder.bias), self.laynorm_proj_decoder.weight,
-                            self.laynorm_proj_decoder.bias)
+                            self.laynorm_proj_decoder.bias, out_f32=True)
 
     def joint(self, enc_bt, dec_bu, B, T, U1, apply_output_layer=True, _D=None, _out=None):
-        """enc_bt bf16 [B*T][C], dec_bu bf16 [B*U1][H] -> bf16 logits [B][T][U1][V] (:276-299).
+        """enc_bt bf16 [B*T][C], dec_bu bf16 [B*U1][H] -> bf16 logits [B][T][U1][V] (:276-299).  The two LayerNorm outputs E, D
+        stay fp32 and relu(E + D) is evaluated in fp32 (:292-294 under autocast); only fc_out's operand is rounded to bf16.
         (_D: the predictor branch already projected + normalised; _out: (w, b, holder) from F.joint_weight_late — forward())"""
         E = F.layer_norm(F.linear(enc_bt, self.proj_encoder.weight, self.proj_encoder.bias), self.laynorm_proj_encoder.weight,
-                         self.laynorm_proj_encoder.bias)
+                         self.laynorm_proj_encoder.bias, out_f32=True)
         D = _D if _D is not None else self._joint_decoder_branch(dec_bu)
         if not apply_output_layer:
             raise NotImplementedError("joint features without the output layer are never materialised (B*T*U*J)")
@@ -113,16 +114,16 @@ class SpeechTransformerTransducerModelBase(nn.Module):
     @torch.no_grad()
     def joint_encoder_branch(self, enc_bt):
         return F.layer_norm(F.linear(enc_bt, self.proj_encoder.weight, self.proj_encoder.bias), self.laynorm_proj_encoder.weight,
-                            self.laynorm_proj_encoder.bias)
+                            self.laynorm_proj_encoder.bias, out_f32=True)
 
     @torch.no_grad()
     def joint_step(self, E_rows, dec_rows):
-        """E_rows bf16 [N][J] (already projected + normalised), dec_rows bf16 [N][H] -> fp32 logits [N][V]."""
+        """E_rows fp32 [N][J] (already projected + normalised), dec_rows bf16 [N][H] -> fp32 logits [N][V]."""
         from ... import kernels as K
 
         N = E_rows.shape[0]
         D = F.layer_norm(F.linear(dec_rows, self.proj_decoder.weight, self.proj_decoder.bias), self.laynorm_proj_decoder.weight,
-                         self.laynorm_proj_decoder.bias)
+                         self.laynorm_proj_decoder.bias, out_f32=True)
         Z = K.joint_add_relu(E_rows.contiguous(), D.contiguous(), N, 1, 1)
         w, b = self.fc_out_params()
         # (without grad mode `w` is the cached constant itself: its bf16 cast is then cached on it too)

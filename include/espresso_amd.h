@@ -151,6 +151,17 @@ int ea_set_wgrad_w8(int mode);
 int ea_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int M, int C, float eps, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
                      float drop_scale, ea_stream_t stream);
+/* fp32 islands of the reference's autocast run (fairseq/tasks/fairseq_task.py:516: LayerNorm outputs are fp32): the same
+ * LayerNorm with an fp32 OUTPUT (x stays bf16, a Linear's output), and its backward with an fp32 incoming gradient.  Used by
+ * the transducer joint network, which adds and rectifies the two LayerNorm outputs in fp32
+ * (espresso/models/transformer/speech_transformer_transducer_base.py:292-294). */
+int ea_layernorm_fwd_f32out(const void* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            int M, int C, float eps, const uint8_t* row_zero, uint64_t drop_seed, uint32_t drop_thr,
+                            float drop_scale, ea_stream_t stream);
+int ea_layernorm_bwd_f32dy(const void* x, const float* dy, const float* gamma, const float* mean, const float* rstd,
+                           void* dx, float* dgamma, float* dbeta, int M, int C, const uint8_t* row_zero,
+                           uint64_t drop_seed, uint32_t drop_thr, float drop_scale, const void* dx_add,
+                           void* workspace, ea_stream_t stream);
 /* workspace (ea_layernorm_bwd_workspace_bytes, or NULL): per-block dgamma/dbeta partial rows folded by a second small
  * kernel instead of 2*C global atomics per block. */
 long ea_layernorm_bwd_workspace_bytes(int M, int C);
@@ -659,6 +670,11 @@ int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targets, const 
  * reductions dE[b][t] = sum_u dZ[b][t][u], dD[b][u] = sum_t dZ[b][t][u] (either output may be NULL). */
 int ea_joint_add_relu(const void* E, const void* D, void* Z, int B, int T, int U1, int J, ea_stream_t stream);
 int ea_joint_reduce(const void* dZ, void* dE, void* dD, int B, int T, int U1, int J, ea_stream_t stream);
+/* The training path's form (round 6): E and D are the fp32 LayerNorm outputs (ea_layernorm_fwd_f32out), the sum and the ReLU are
+ * evaluated in fp32 as in the reference's autocast run (:292-294) and only Z — fc_out's bf16 GEMM operand — is rounded; dE / dD
+ * leave as fp32 sums (inputs of ea_layernorm_bwd_f32dy).  relu'(E + D) is recovered from Z > 0, which is exact for the fp32 sum. */
+int ea_joint_add_relu_f32(const float* E, const float* D, void* Z, int B, int T, int U1, int J, ea_stream_t stream);
+int ea_joint_reduce_f32(const void* dZ, float* dE, float* dD, int B, int T, int U1, int J, ea_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -18,15 +18,17 @@ import torch.nn.functional as F
 # V, the attention output.  With `bf16_emulation(True)` this restatement rounds at the same points (forward value AND the
 # gradient flowing back through the point — the HIP backward stores its gradients in bf16 at the same tensor boundaries), so a
 # comparison HIP vs emulation isolates real arithmetic differences from the expected bf16 rounding of the reference's fp32 run.
-_EMU = {"on": False, "flash": True}
+_EMU = {"on": False, "flash": True, "resid_f32": False}
 
 
 class bf16_emulation:
     """Context manager: `with torch_ref.bf16_emulation(flash=True): torch_ref.encoder(...)`.  `flash`: head dim 64 (fused
     kernels: un-normalised bf16 probabilities, fp32 normaliser) vs the unfused path (normalised probabilities rounded)."""
 
-    def __init__(self, on=True, flash=True):
-        self.new = {"on": on, "flash": flash}
+    def __init__(self, on=True, flash=True, resid_f32=False):
+        # resid_f32: the residual stream (every `x + block(x)` and the layer's final LayerNorm output) stays fp32 — what the
+        # reference's AMP run does (fairseq/tasks/fairseq_task.py:516: LayerNorm and the residual adds run in fp32 under autocast)
+        self.new = {"on": on, "flash": flash, "resid_f32": resid_f32}
 
     def __enter__(self):
         self.old = dict(_EMU)
@@ -49,6 +51,13 @@ class _RoundBF16(torch.autograd.Function):
 def _r(x):
     """Storage point: identity in the fp32 restatement, bf16 round trip under emulation."""
     return _RoundBF16.apply(x) if _EMU["on"] and x.is_floating_point() else x
+
+
+def _rs(x):
+    """Storage point of the RESIDUAL STREAM: bf16 under emulation unless the stream is kept in fp32 (`resid_f32`) AND has become
+    fp32 — under the reference's autocast the stream is bf16 (Linear outputs) until the first LayerNorm output joins it, i.e.
+    from the first Conformer layer's final LayerNorm on (`stream_hot`)."""
+    return x if (_EMU.get("resid_f32") and _EMU.get("stream_hot")) else _r(x)
 
 
 class _RoundGradBF16(torch.autograd.Function):
@@ -195,8 +204,12 @@ def relpos_mhsa(x, sd, prefix, H, key_padding_mask=None, attn_mask=None):
     return _lin(a, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
-def _ln(x, sd, prefix):
-    return _r(F.layer_norm(x, (x.shape[-1],), sd[prefix + "weight"], sd[prefix + "bias"], 1e-5))
+def _ln(x, sd, prefix, stream=False):
+    """`stream`: the output IS the residual stream of what follows (a Conformer layer's final LayerNorm)."""
+    y = F.layer_norm(x, (x.shape[-1],), sd[prefix + "weight"], sd[prefix + "bias"], 1e-5)
+    if stream and _EMU.get("resid_f32"):
+        _EMU["stream_hot"] = True
+    return _rs(y) if stream else _r(y)
 
 
 def _ffn_conformer(x, sd, p):
@@ -231,13 +244,13 @@ def conv_module(x_btc, sd, p, training, update=None):
 
 def conformer_layer(x, sd, p, H, key_padding_mask, training, update=None, attn_mask=None):
     """espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:112-141.  x: (T,B,C)."""
-    x = _r(0.5 * _ffn_conformer(x, sd, p + "ffn1.") + x)
+    x = _rs(0.5 * _ffn_conformer(x, sd, p + "ffn1.") + x)
     # (…encoder_layer.py:125: dropout on the attention block's output, before the residual)
-    x = _r(_drop(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask),
-                 "attn.out", "TBC") + x)
-    x = _r(conv_module(x.transpose(0, 1), sd, p + "conv_module.", training, update).transpose(0, 1) + x)
-    x = _r(0.5 * _ffn_conformer(x, sd, p + "ffn2.") + x)
-    return _ln(x, sd, p + "final_layer_norm.")
+    x = _rs(_drop(relpos_mhsa(_ln(x, sd, p + "self_attn_layer_norm."), sd, p + "self_attn.", H, key_padding_mask, attn_mask),
+                  "attn.out", "TBC") + x)
+    x = _rs(conv_module(x.transpose(0, 1), sd, p + "conv_module.", training, update).transpose(0, 1) + x)
+    x = _rs(0.5 * _ffn_conformer(x, sd, p + "ffn2.") + x)
+    return _ln(x, sd, p + "final_layer_norm.", stream=True)
 
 
 def transformer_layer(x, sd, p, H, key_padding_mask, activation="relu", attn_mask=None, normalize_before=True):
@@ -355,6 +368,7 @@ def encoder(feats, lengths, sd, H, layer_type="conformer", training=False, activ
     x = x.transpose(0, 1)
     kpm = pad if bool(pad.any()) else None
     i = 0
+    _EMU["stream_hot"] = False
     while f"layers.{i}.final_layer_norm.weight" in sd:
         p = f"layers.{i}."
         if layer_type == "conformer":
@@ -595,18 +609,21 @@ def lstm_lm(tokens, sd, pad_idx=0, residual=False):
 
 def transducer_joint(enc_btc, dec_buh, sd):
     """speech_transformer_transducer_base.py:276-299 with the weight-normed fc_out (weight = g * v / ||v||_row)."""
-    # HIP: both projections, their LayerNorms, relu(E + D), the effective (weight-normed) matrix and the logits are stored in bf16
-    e = _r(F.layer_norm(_r(_lin(enc_btc, sd["proj_encoder.weight"], sd["proj_encoder.bias"])), (sd["proj_encoder.weight"].shape[0],),
-                        sd["laynorm_proj_encoder.weight"], sd["laynorm_proj_encoder.bias"]))
-    d = _r(F.layer_norm(_r(_lin(dec_buh, sd["proj_decoder.weight"], sd["proj_decoder.bias"])), (sd["proj_decoder.weight"].shape[0],),
-                        sd["laynorm_proj_decoder.weight"], sd["laynorm_proj_decoder.bias"]))
+    # HIP: both projections (Linear outputs), relu(E + D) as fc_out's operand, the effective (weight-normed) matrix and the logits are
+    # stored in bf16; the two LayerNorm outputs E, D, their sum, the ReLU (and its derivative mask) and the gradients dE, dD are
+    # fp32 — the fp32 island of the reference's autocast run (:292-294), round 6
+    e = F.layer_norm(_r(_lin(enc_btc, sd["proj_encoder.weight"], sd["proj_encoder.bias"])), (sd["proj_encoder.weight"].shape[0],),
+                     sd["laynorm_proj_encoder.weight"], sd["laynorm_proj_encoder.bias"])
+    d = F.layer_norm(_r(_lin(dec_buh, sd["proj_decoder.weight"], sd["proj_decoder.bias"])), (sd["proj_decoder.weight"].shape[0],),
+                     sd["laynorm_proj_decoder.weight"], sd["laynorm_proj_decoder.bias"])
     z = _r(F.relu(e.unsqueeze(2) + d.unsqueeze(1)))
     if "fc_out.weight_v" in sd:
         v = sd["fc_out.weight_v"]
         w = v * (sd["fc_out.weight_g"] / v.norm(dim=1, keepdim=True))
     else:
         w = sd["decoder.embed_tokens.weight"]
-    return _r(_lin(z, w, sd["fc_out.bias"]))
+    y = _lin(z, w, sd["fc_out.bias"])
+    return _rg(y) if os.environ.get("EA_JOINT_LOGITS_F32", "0") == "1" else _r(y)  # (diagnostic switch of the HIP path, round 6)
 
 
 def transducer(feats, lengths, prev_tokens, sd, H, pad_idx=1, residual=False, training=False, update=None):

@@ -2535,7 +2535,10 @@ def check_transducer_beam_search():
             strip = lambda row: tuple(int(t) for t in row if int(t) != d.pad())
             refset = {strip(rt[j]): float(rs[j]) for j in range(rt.shape[0])}
             mine = [strip(toks_l[b][j].tolist()) for j in range(toks_l[b].shape[0])]
-            best_equal.append(mine[0] == strip(rt[0]))
+            # identical 1-best — or, where the reference's own best two hypotheses are closer than the bf16 noise of a score
+            # (b2_nonorm, utterance 0: -5.393725 vs -5.393900 on this random-init model), one of those tied hypotheses
+            tied = mine[0] in refset and abs(refset[mine[0]] - float(rs[0])) < 2e-3
+            best_equal.append(mine[0] == strip(rt[0]) or tied)
             nbest_in_ref.append(sum(m in refset for m in mine) / len(mine))
             for j, m in enumerate(mine):
                 if m in refset:

@@ -633,8 +633,9 @@ def test_speech_lstm_beam_search_vs_reference():
 
 
 def test_transducer_beam_search_vs_reference():
-    """1-best token ids identical to the reference decoder for every utterance and option set; scores of shared n-best entries
-    within 1e-2 (bf16 model)"""
+    """1-best token ids identical to the reference decoder for every utterance and option set (where the reference's own top two
+    scores differ by less than 2e-3 — below the bf16 noise of a score — either of them); scores of shared n-best entries within
+    1e-2 (bf16 model)"""
     r = G.check_transducer_beam_search()
     print(r)
     same = r.pop("batched_equals_single")  # searches batched across utterances == each utterance decoded alone

@@ -480,3 +480,36 @@ def test_encoder_restatement_matches_reference_at_8_heads(layer_type):
     worst = max(float((sdo[n].grad - g).abs().max() / (g.abs().max() + 1e-12)) for n, g in ref_grads.items() if sdo[n].grad is not None)
     assert worst < 2e-4, worst
     assert sum(sdo[n].grad is not None for n in ref_grads) == len(ref_grads)
+
+
+def test_bf16_floor_of_the_logit_tolerance(golden_dir):
+    """Round 6, the experiment behind the GPU tests' logit bounds — CPU only, on the emulating oracle, whose
+    eval-logit error tracks the HIP path's (0.0231 / 0.0306 / 0.0210 here vs 0.0271 / 0.0312 / 0.0225 measured on the MI355X for
+    the tiny / dh 64 / 12-layer encoders, profiles/r05_logits_f32_ab.txt).  north_star asks for log-probs within 1e-2 of the
+    reference's fp32 run in bf16.  Three facts, pinned on the dh-64 fixture (tools/probes/resid_f32_emulation.py prints all
+    sizes, profiles/r06_resid_f32_emulation.json):
+      * bf16 WEIGHTS ALONE (every activation, statistic and sum in fp32) already move the logits by ~1.0e-2: no bf16 run — the
+        reference's own autocast run included — can sit inside 1e-2 with margin;
+      * keeping the residual stream in fp32, as the reference's autocast run does from the first layer's final LayerNorm on
+        (`bf16_emulation(resid_f32=True)`), brings 0.031 -> 0.024 (12 layers: 0.021 -> 0.0135): closer, still above 1e-2;
+      * fp32 logits on top change nothing (the error is accumulated upstream).
+    So the fp32 stream was priced and NOT built (+ ~19 MB of HBM traffic per sub-layer, ~0.5 ms per update step, for a bound
+    that stays unmet), and the GPU tests state absolute bounds from these measurements instead of a rescaled 1e-2."""
+    g = np.load(os.path.join(golden_dir, "ref_conformer_ctc_dh64.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    feats, lengths = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"])
+    ref = torch.from_numpy(g["out::eval_logits"])
+
+    def err(sdx, **kw):
+        with torch.no_grad(), torch_ref.bf16_emulation(**kw):
+            lo, _ = torch_ref.encoder(feats, lengths, sdx, H=2, layer_type="conformer", training=False)
+        return float((lo - ref).abs().max()), float((torch.log_softmax(lo, -1) - torch.log_softmax(ref, -1)).abs().max())
+
+    w16 = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() and v.dim() >= 2 else v) for k, v in sd.items()}
+    floor, floor_lp = err(w16, on=False)
+    bf16_stream, _ = err(sd, on=True, flash=True)
+    f32_stream, f32_stream_lp = err(sd, on=True, flash=True, resid_f32=True)
+    assert err(sd, on=False)[0] == 0.0                       # (the restatement itself is pinned: exactly the reference's logits)
+    assert 7e-3 < floor < 1.4e-2 and 7e-3 < floor_lp < 1.4e-2, (floor, floor_lp)
+    assert 2.5e-2 < bf16_stream < 3.6e-2, bf16_stream        # the HIP path's rounding points (GPU test bound: 3.5e-2)
+    assert 1.2e-2 < f32_stream < bf16_stream and f32_stream_lp > 1e-2, (f32_stream, f32_stream_lp)
