@@ -28,15 +28,20 @@ class TransducerLossCriterion:
         return self.forward(model, sample, reduce)
 
     def forward(self, model, sample, reduce=True):
-        net_output, encoder_out_lengths = model(**sample["net_input"])  # (B, T', U+1, V), (B,)
+        # (lazy_joint: the model returns the joint network's branches + output layer instead of the (B, T', U+1, V) logits, and the
+        # loss below runs the output layer itself, fused with the log-sum-exp / gradient — the logits never reach HBM)
+        inner = getattr(model, "module", model)  # (the data-parallel wrapper passes keyword arguments through)
+        kw = {"lazy_joint": True} if getattr(inner, "supports_lazy_joint", False) else {}
+        net_output, encoder_out_lengths = model(**sample["net_input"], **kw)
         if self.include_eos:
             target = sample["target"]
             target_lengths = sample["target"].ne(self.pad_idx).sum(-1)
         else:
             target = sample["target"][:, :-1].contiguous() if sample["target"].size(1) > 1 else sample["target"]
             target_lengths = (sample["target"].ne(self.pad_idx) & sample["target"].ne(self.eos_idx)).sum(-1)
-        loss = F.rnnt_loss(net_output, target.to(torch.int32).contiguous(), encoder_out_lengths.to(torch.int32).contiguous(),
-                           target_lengths.to(torch.int32).contiguous(), blank=self.blank_idx).sum()
+        loss_fn = F.joint_rnnt_loss if isinstance(net_output, F.LazyJointLogits) else F.rnnt_loss
+        loss = loss_fn(net_output, target.to(torch.int32).contiguous(), encoder_out_lengths.to(torch.int32).contiguous(),
+                       target_lengths.to(torch.int32).contiguous(), blank=self.blank_idx).sum()
         nsentences = sample["target"].size(0)
         sample_size = nsentences if self.sentence_avg else sample["ntokens"]
         return loss, sample_size, {"loss": loss.detach(), "ntokens": sample["ntokens"], "nsentences": nsentences,

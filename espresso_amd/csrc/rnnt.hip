@@ -13,7 +13,8 @@
 // HBM-bound on the (B,T,U+1,V) logits: (1) one wavefront per lattice node computes logsumexp over V and keeps only
 // the two log-probs the recursion needs; (2) one workgroup per utterance sweeps anti-diagonals (one lane per u, LDS
 // hand-off between neighbours) for alpha and beta concurrently; (3) one wavefront per node streams V once more to write
-// the gradient.  A joint-network-fused variant (logits never materialised) is the planned next step.
+// the gradient.  The joint-network-fused variant (logits never materialised) is csrc/joint_rnnt.hip (round 6); this file stays
+// the path for logits that exist (criterion called on a tensor, shapes the fused kernels do not take) and the test reference.
 #include "common.h"
 #include "espresso_amd.h"
 
@@ -393,6 +394,18 @@ extern "C" int ea_joint_reduce_f32(const void* dZ, float* dE, float* dD, int B, 
 
 extern "C" long ea_rnnt_workspace_bytes(int B, int T, int U1) { return 5L * B * T * U1 * (long)sizeof(float); }
 
+// alpha / beta sweep + per-utterance loss from the two log-probabilities per lattice node (shared with csrc/joint_rnnt.hip, whose
+// fused vocabulary projection produces lpb / lpy without materialising the logits)
+extern "C" int ea_rnnt_scan(const float* lpb, const float* lpy, const int* logit_lengths, const int* target_lengths, float* alpha,
+                            float* beta, float* loss, int B, int T, int U1, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (T <= 0 || U1 <= 0 || U1 > 512) return -2;
+  const int UP = (U1 + 63) / 64 * 64;
+  hipLaunchKernelGGL(rnnt_scan_kernel, dim3(B), dim3(2 * UP), (size_t)4 * (UP + 2) * sizeof(float), stream, lpb, lpy,
+                     logit_lengths, target_lengths, alpha, beta, loss, T, U1, UP);
+  return EA_CHECK_LAUNCH();
+}
+
 extern "C" int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths,
                             const int* target_lengths, float* loss /*[B]*/, void* workspace, int B, int T, int U1, int V, long ld,
                             int Umax, int blank, hipStream_t stream) {
@@ -410,10 +423,7 @@ extern "C" int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targ
   else
     hipLaunchKernelGGL(rnnt_lse_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const float*)logits, targets,
                        logit_lengths, target_lengths, lse, lpb, lpy, T, U1, V, ld, Umax, blank, n);
-  const int UP = (U1 + 63) / 64 * 64;
-  hipLaunchKernelGGL(rnnt_scan_kernel, dim3(B), dim3(2 * UP), (size_t)4 * (UP + 2) * sizeof(float), stream, lpb, lpy,
-                     logit_lengths, target_lengths, alpha, beta, loss, T, U1, UP);
-  return EA_CHECK_LAUNCH();
+  return ea_rnnt_scan(lpb, lpy, logit_lengths, target_lengths, alpha, beta, loss, B, T, U1, stream);
 }
 
 extern "C" int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths,

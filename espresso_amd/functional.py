@@ -1966,36 +1966,111 @@ class _TransducerJoint(torch.autograd.Function):
         else:
             dl = torch.zeros(n, Vp, dtype=torch.bfloat16, device=dlogits.device)
             dl[:, :V] = dlogits.reshape(n, V)
-        # data gradient: dZ = dl W through the k-contiguous form (the weight's transposed, zero-padded bf16 copy [J][Vp]):
-        # both operands k-contiguous and K = Vp a multiple of 64 -> direct-to-LDS ring kernel
-        wt = torch.zeros(J, Vp, dtype=torch.bfloat16, device=dl.device)
-        wt[:, :V] = w16.t()
-        dZ = torch.empty(n, J, dtype=torch.bfloat16, device=dl.device)
-        # relu'(pre) == (Z > 0): the post-activation tensor doubles as the derivative mask
-        K.gemm(dl, wt, dZ, n, J, Vp, lda=Vp, ldb=Vp, ldc=J, aux=Z, ldaux=J, act="relu")
-        dE, dD = K.joint_reduce(dZ, B, T, U1, out_f32=ctx.ed_f32)
-        # dW [V][J] = dl^T Z over all B*T*U1 lattice nodes: split-K GEMM on the aligned (padded-pitch) gradient.  (The grouped
-        # weight-gradient kernel was tried here: 632 tiles each walking 45 000 rows of a 10 KB-pitch operand ran at 115 TFLOP/s,
-        # slower than the split-K launch.)
-        late = ctx.late
-        if late is not None and has_bias:
-            # optimizer-only product, 2 ms at the recipe's batch: launched on its own stream behind the data gradient (two
-            # device-filling GEMMs side by side only slow each other down), handed to autograd by the `_JointWeightLate` node,
-            # which the engine reaches after the encoder's and the predictor's backward passes
-            cur, side = torch.cuda.current_stream(dl.device), aux_stream(dl.device, 2)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                dw, db = _joint_wgrad(dl, Z, n, V, J, Vp)
-                late.event = side.record_event()
-            dw.record_stream(cur)
-            db.record_stream(cur)
-            late.dw, late.db, late.keep = dw, db, (dl, Z)  # operands stay allocated until the join
-            dw = db = None
-        elif has_bias:
-            dw, db = _joint_wgrad(dl, Z, n, V, J, Vp)
-        else:
-            dw, db = _wgrad(dl, Z, n, V, J, ld_dy=Vp), None
+        dE, dD, dw, db = _joint_backward_from_dl(dl, Z, w16, ctx.dims, ctx.late, ctx.ed_f32)
         return dE, dD, dw, db, None, None, None, None, None
+
+
+def _joint_backward_from_dl(dl, Z, w16, dims, late, ed_f32):
+    """Everything behind the gradient of the lattice logits `dl` (bf16 [n][Vp], pad columns zero): dZ through the output layer and
+    the ReLU, its two reductions dE / dD, and the output layer's weight / bias gradient (on a side stream when `late`)."""
+    B, T, U1, V, J, has_bias, Vp = dims
+    n = B * T * U1
+    # data gradient: dZ = dl W through the k-contiguous form (the weight's transposed, zero-padded bf16 copy [J][Vp]):
+    # both operands k-contiguous and K = Vp a multiple of 64 -> direct-to-LDS ring kernel
+    wt = torch.zeros(J, Vp, dtype=torch.bfloat16, device=dl.device)
+    wt[:, :V] = w16.t()
+    dZ = torch.empty(n, J, dtype=torch.bfloat16, device=dl.device)
+    # relu'(pre) == (Z > 0): the post-activation tensor doubles as the derivative mask
+    K.gemm(dl, wt, dZ, n, J, Vp, lda=Vp, ldb=Vp, ldc=J, aux=Z, ldaux=J, act="relu")
+    dE, dD = K.joint_reduce(dZ, B, T, U1, out_f32=ed_f32)
+    # dW [V][J] = dl^T Z over all B*T*U1 lattice nodes: split-K GEMM on the aligned (padded-pitch) gradient.  (The grouped
+    # weight-gradient kernel was tried here: 632 tiles each walking 45 000 rows of a 10 KB-pitch operand ran at 115 TFLOP/s,
+    # slower than the split-K launch.)
+    if late is not None and has_bias:
+        # optimizer-only product, 2 ms at the recipe's batch: launched on its own stream behind the data gradient (two
+        # device-filling GEMMs side by side only slow each other down), handed to autograd by the `_JointWeightLate` node,
+        # which the engine reaches after the encoder's and the predictor's backward passes
+        cur, side = torch.cuda.current_stream(dl.device), aux_stream(dl.device, 2)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            dw, db = _joint_wgrad(dl, Z, n, V, J, Vp)
+            late.event = side.record_event()
+        dw.record_stream(cur)
+        db.record_stream(cur)
+        late.dw, late.db, late.keep = dw, db, (dl, Z)  # operands stay allocated until the join
+        dw = db = None
+    elif has_bias:
+        dw, db = _joint_wgrad(dl, Z, n, V, J, Vp)
+    else:
+        dw, db = _wgrad(dl, Z, n, V, J, ld_dy=Vp), None
+    return dE, dD, dw, db
+
+
+class LazyJointLogits:
+    """What the transducer model hands the `transducer_loss` criterion instead of the (B, T', U+1, V) logits when asked to
+    (`model(..., lazy_joint=True)`): the joint network's two fp32 branches and its output layer.  `joint_rnnt_loss` consumes it
+    without ever writing the logits (csrc/joint_rnnt.hip); `materialize()` is the ordinary tensor for any other consumer."""
+
+    def __init__(self, E, D, w, b, B, T, U1, late=None):
+        self.E, self.D, self.w, self.b, self.B, self.T, self.U1, self.late = E, D, w, b, B, T, U1, late
+
+    @property
+    def shape(self):
+        return (self.B, self.T, self.U1, self.w.shape[0])
+
+    def materialize(self):
+        return transducer_joint(self.E, self.D, self.w, self.b, self.B, self.T, self.U1, late=self.late)
+
+
+_JOINT_FUSED = os.environ.get("EA_JOINT_FUSED", "1") != "0"  # (A/B switch: 0 = always materialise the logits)
+
+
+def set_joint_fused(on: bool) -> bool:
+    """A/B switch of `joint_rnnt_loss` (tests, tools): False = materialise the logits and run the unfused loss kernels."""
+    global _JOINT_FUSED
+    old, _JOINT_FUSED = _JOINT_FUSED, bool(on)
+    return old
+
+
+class _JointRNNTLoss(torch.autograd.Function):
+    """loss[b] = RNN-T negative log-likelihood of logits[b,t,u,:] = fc_out(relu(E[b,t] + D[b,u])) with the logits never written:
+    espresso/models/transformer/speech_transformer_transducer_base.py:276-299 + espresso/criterions/transducer_loss.py:130-140.
+    Forward: Z = relu(E + D) (bf16, saved), the vocabulary projection on the 8-wave GEMM with a log-sum-exp epilogue, the
+    alpha / beta sweep.  Backward: the projection again with the loss-gradient epilogue -> dl bf16, then the joint's backward."""
+
+    @staticmethod
+    def forward(ctx, E, D, w, b, w16, targets, logit_lengths, target_lengths, B, T, U1, blank, late):
+        V, J = w.shape
+        Z = K.joint_add_relu(E.contiguous(), D.contiguous(), B, T, U1)
+        loss, ws = K.joint_rnnt_loss_fwd(Z, w16, b, targets, logit_lengths, target_lengths, B, T, U1, blank)
+        ctx.save_for_backward(Z, w16, targets, logit_lengths, target_lengths, loss, ws)
+        ctx.bias = b
+        ctx.dims = (B, T, U1, V, J, b is not None, (V + 63) // 64 * 64)
+        ctx.blank, ctx.late, ctx.ed_f32 = blank, late, E.dtype == torch.float32
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        Z, w16, targets, logit_lengths, target_lengths, loss, ws = ctx.saved_tensors
+        B, T, U1, V, J, has_bias, Vp = ctx.dims
+        # the criterion sums the per-utterance losses: dloss is a broadcast scalar, applied on the device
+        dl = K.joint_rnnt_loss_grad(Z, w16, ctx.bias, targets, logit_lengths, target_lengths, loss, ws, B, T, U1, ctx.blank, Vp,
+                                    grad_scale_dev=dloss.float().contiguous())
+        dE, dD, dw, db = _joint_backward_from_dl(dl, Z, w16, ctx.dims, ctx.late, ctx.ed_f32)
+        return (dE, dD, dw, db) + (None,) * 9
+
+
+def joint_rnnt_loss(lazy, targets, logit_lengths, target_lengths, blank=0):
+    """Per-utterance RNN-T loss of a `LazyJointLogits`: fused (no logits in HBM) for the shapes the kernels take, else
+    materialise + `rnnt_loss`."""
+    w16 = K.cast_f32_to_bf16(lazy.w.detach().contiguous())
+    J = lazy.w.shape[1]
+    ok = (_JOINT_FUSED and lazy.E.is_cuda and J % 64 == 0 and lazy.E.dtype == torch.float32 and lazy.D.dtype == torch.float32
+          and lazy.U1 <= 512 and lazy.B * lazy.T * lazy.U1 * J < 2 ** 31)
+    if not ok:
+        return rnnt_loss(lazy.materialize(), targets, logit_lengths, target_lengths, blank)
+    return _JointRNNTLoss.apply(lazy.E, lazy.D, lazy.w, lazy.b, w16, targets, logit_lengths, target_lengths, lazy.B, lazy.T, lazy.U1,
+                                blank, lazy.late)
 
 
 def _joint_wgrad(dl, Z, n, V, J, Vp):

@@ -636,6 +636,36 @@ def rnnt_loss_grad(logits, targets, logit_lengths, target_lengths, loss, ws, bla
     return grad if ld == V else grad[..., :V]
 
 
+def joint_rnnt_supported(Z, w16) -> bool:
+    """Shapes the fused joint + RNN-T kernels take (csrc/joint_rnnt.hip): joint dim a multiple of 64, 16-byte aligned operands."""
+    J = Z.shape[1]
+    return (Z.is_cuda and Z.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and J % 64 == 0 and Z.is_contiguous()
+            and w16.is_contiguous() and Z.data_ptr() % 16 == 0 and w16.data_ptr() % 16 == 0 and Z.shape[0] * J < 2 ** 31)
+
+
+def joint_rnnt_loss_fwd(Z, w16, bias, targets, logit_lengths, target_lengths, B, T, U1, blank):
+    """Per-utterance RNN-T loss of logits = Z w16^T + bias WITHOUT materialising them (fp32 accumulators -> log-sum-exp per vocabulary
+    tile -> alpha / beta).  Z bf16 [B*T*U1][J].  Returns (loss [B], workspace kept for joint_rnnt_loss_grad)."""
+    V, J = w16.shape
+    Umax = targets.shape[1]
+    assert U1 == Umax + 1 and Z.shape[0] == B * T * U1
+    loss = torch.empty(B, dtype=torch.float32, device=Z.device)
+    ws = torch.empty(int(_lib.lib().ea_joint_rnnt_workspace_bytes(B, T, U1, V)), dtype=torch.uint8, device=Z.device)
+    check(_lib.lib().ea_joint_rnnt_loss(_p(Z), _p(w16), _p(bias), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws),
+                                        B, T, U1, V, J, Umax, blank, _stream()), "ea_joint_rnnt_loss")
+    return loss, ws
+
+
+def joint_rnnt_loss_grad(Z, w16, bias, targets, logit_lengths, target_lengths, loss, ws, B, T, U1, blank, ld, grad_scale_dev=None):
+    """d loss / d logits as bf16 [B*T*U1][ld] (pad columns V .. ld - 1 zero), the logits recomputed tile by tile."""
+    V, J = w16.shape
+    dl = torch.empty(B * T * U1, ld, dtype=torch.bfloat16, device=Z.device)
+    check(_lib.lib().ea_joint_rnnt_grad(_p(Z), _p(w16), _p(bias), _p(targets), _p(logit_lengths), _p(target_lengths), _p(loss), _p(ws),
+                                        _p(dl), ld, B, T, U1, V, J, targets.shape[1], blank, 1.0, _p(grad_scale_dev), _stream()),
+          "ea_joint_rnnt_grad")
+    return dl
+
+
 # ------------------------------------------------------------------------------------------------ LSTM
 def lstm_cell_fwd(gates_pre, c_prev, c_out, h_f32, h_bf16, ldh, gates_act, B, H, keep_row=None, h_prev_f32=None, ldg=None,
                   frozen_out_zero=False):

@@ -97,7 +97,7 @@ class SpeechTransformerTransducerModelBase(nn.Module):
         return F.layer_norm(F.linear(dec_bu, self.proj_decoder.weight, self.proj_decoder.bias), self.laynorm_proj_decoder.weight,
                             self.laynorm_proj_decoder.bias, out_f32=True)
 
-    def joint(self, enc_bt, dec_bu, B, T, U1, apply_output_layer=True, _D=None, _out=None):
+    def joint(self, enc_bt, dec_bu, B, T, U1, apply_output_layer=True, _D=None, _out=None, lazy=False):
         """enc_bt bf16 [B*T][C], dec_bu bf16 [B*U1][H] -> bf16 logits [B][T][U1][V] (:276-299).  The two LayerNorm outputs E, D
         stay fp32 and relu(E + D) is evaluated in fp32 (:292-294 under autocast); only fc_out's operand is rounded to bf16.
         (_D: the predictor branch already projected + normalised; _out: (w, b, holder) from F.joint_weight_late — forward())"""
@@ -107,6 +107,8 @@ class SpeechTransformerTransducerModelBase(nn.Module):
         if not apply_output_layer:
             raise NotImplementedError("joint features without the output layer are never materialised (B*T*U*J)")
         w, b, late = _out if _out is not None else (self.fc_out_params() + (None,))
+        if lazy:  # the criterion fuses the output layer with the loss (F.joint_rnnt_loss): the logits are never written
+            return F.LazyJointLogits(E, D, w, b, B, T, U1, late=late)
         return F.transducer_joint(E, D, w, b, B, T, U1, late=late)
 
     # ---- inference helpers: the encoder branch of the joint is computed once per utterance batch, the predictor branch
@@ -129,15 +131,19 @@ class SpeechTransformerTransducerModelBase(nn.Module):
         # (without grad mode `w` is the cached constant itself: its bf16 cast is then cached on it too)
         return F.linear(Z, w.detach() if w.requires_grad else w, b, out_f32=True)
 
-    def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
-        """-> (logits bf16 [B][T'][U+1][V], encoder_out_lengths [B])  (:221-243)"""
+    supports_lazy_joint = True  # forward(..., lazy_joint=True) -> F.LazyJointLogits for the fused loss (criterions/transducer_loss.py)
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens, lazy_joint=False, **kwargs):
+        """-> (logits bf16 [B][T'][U+1][V], encoder_out_lengths [B])  (:221-243).  lazy_joint (set by the `transducer_loss`
+        criterion): the first element is a `F.LazyJointLogits` — the joint's two branches and output layer, for the fused loss."""
         dev = src_tokens.device
+        lazy_joint = bool(lazy_joint) and torch.is_grad_enabled()
         B, U1 = prev_output_tokens.shape
         if not (F.branch_overlap() and dev.type == "cuda" and torch.is_grad_enabled()):
             enc = self.encoder(src_tokens, src_lengths)
             x = enc["_x_bt"][0]
             dec, _ = self.decoder.extract_features(prev_output_tokens)
-            return self.joint(x, dec.reshape(B * U1, -1), B, x.shape[0] // B, U1), enc["src_lengths"][0]
+            return self.joint(x, dec.reshape(B * U1, -1), B, x.shape[0] // B, U1, lazy=lazy_joint), enc["src_lengths"][0]
         # The predictor network depends on the targets only: it runs on its own stream next to the encoder (5-6 utterances per
         # product-rule batch leave most of the device idle under either), and autograd runs its backward pass on that stream
         # too.  Host order: encoder first, predictor second -> the engine issues the predictor's backward first.  The output
@@ -154,7 +160,7 @@ class SpeechTransformerTransducerModelBase(nn.Module):
             D = self._joint_decoder_branch(dec.reshape(B * U1, -1))
         cur.wait_stream(side)
         D.record_stream(cur)
-        return self.joint(x, None, B, x.shape[0] // B, U1, _D=D, _out=out), enc["src_lengths"][0]
+        return self.joint(x, None, B, x.shape[0] // B, U1, _D=D, _out=out, lazy=lazy_joint), enc["src_lengths"][0]
 
     def forward_encoder(self, src_tokens, src_lengths):
         return self.encoder(src_tokens, src_lengths)

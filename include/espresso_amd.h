@@ -665,6 +665,25 @@ int ea_rnnt_loss(const void* logits, int logits_bf16, const int* targets, const 
 int ea_rnnt_grad(const void* logits, int logits_bf16, const int* targets, const int* logit_lengths, const int* target_lengths,
                  const float* loss, const void* workspace, void* grad, int grad_bf16, int B, int T, int U1, int V, long ld,
                  int Umax, int blank, float grad_scale, const float* grad_scale_dev, ea_stream_t stream);
+/* The alpha / beta sweep of ea_rnnt_loss alone: lpb / lpy fp32 [B][T][U1] = log p(blank | t,u), log p(y_{u+1} | t,u). */
+int ea_rnnt_scan(const float* lpb, const float* lpy, const int* logit_lengths, const int* target_lengths, float* alpha,
+                 float* beta, float* loss, int B, int T, int U1, ea_stream_t stream);
+/* Joint output layer FUSED with the RNN-T loss (csrc/joint_rnnt.hip, round 6): replaces fc_out of
+ * espresso/models/transformer/speech_transformer_transducer_base.py:276-299 followed by torchaudio.functional.rnnt_loss
+ * (espresso/criterions/transducer_loss.py:130-140) without ever writing the (B, T, U1, V) logits.
+ *   Z bf16 [B*T*U1][J] = relu(E + D) (ea_joint_add_relu_f32), W bf16 [V][J], bias fp32 [V] or NULL; J % 64 == 0, 16-byte aligned.
+ * ea_joint_rnnt_loss: loss[b] as ea_rnnt_loss, computed from the fp32 accumulators of the product (the unfused path rounds the
+ *   logits to bf16 first); the workspace keeps lse / log-probs / alpha / beta for the gradient call.
+ * ea_joint_rnnt_grad: dl bf16 [B*T*U1][ld] = d loss / d logits * grad_scale (* grad_scale_dev[0]); ld % 32 == 0, ld >= V, columns
+ *   V .. ld - 1 are written as zeros (dl is the operand of the joint's data- and weight-gradient GEMMs, which reduce over ld).
+ * Both return -2 for shapes they do not take (the caller then materialises the logits and uses ea_rnnt_loss / ea_rnnt_grad). */
+long ea_joint_rnnt_workspace_bytes(int B, int T, int U1, int V);
+int ea_joint_rnnt_loss(const void* Z, const void* W, const float* bias, const int* targets, const int* logit_lengths,
+                       const int* target_lengths, float* loss, void* workspace, int B, int T, int U1, int V, int J, int Umax,
+                       int blank, ea_stream_t stream);
+int ea_joint_rnnt_grad(const void* Z, const void* W, const float* bias, const int* targets, const int* logit_lengths,
+                       const int* target_lengths, const float* loss, void* workspace, void* dl, long ld, int B, int T, int U1,
+                       int V, int J, int Umax, int blank, float grad_scale, const float* grad_scale_dev, ea_stream_t stream);
 /* Joint network element-wise stages (espresso/models/transformer/speech_transformer_transducer_base.py:276-299):
  * Z[b][t][u] = relu(E[b][t] + D[b][u]) (bf16, E [B*T][J], D [B*U1][J], Z [B*T*U1][J], J % 8 == 0) and its backward
  * reductions dE[b][t] = sum_u dZ[b][t][u], dD[b][u] = sum_t dZ[b][t][u] (either output may be NULL). */

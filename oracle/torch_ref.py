@@ -18,17 +18,20 @@ import torch.nn.functional as F
 # V, the attention output.  With `bf16_emulation(True)` this restatement rounds at the same points (forward value AND the
 # gradient flowing back through the point — the HIP backward stores its gradients in bf16 at the same tensor boundaries), so a
 # comparison HIP vs emulation isolates real arithmetic differences from the expected bf16 rounding of the reference's fp32 run.
-_EMU = {"on": False, "flash": True, "resid_f32": False}
+_EMU = {"on": False, "flash": True, "resid_f32": False, "joint_logits_f32": False}
 
 
 class bf16_emulation:
     """Context manager: `with torch_ref.bf16_emulation(flash=True): torch_ref.encoder(...)`.  `flash`: head dim 64 (fused
     kernels: un-normalised bf16 probabilities, fp32 normaliser) vs the unfused path (normalised probabilities rounded)."""
 
-    def __init__(self, on=True, flash=True, resid_f32=False):
+    def __init__(self, on=True, flash=True, resid_f32=False, joint_logits_f32=False):
         # resid_f32: the residual stream (every `x + block(x)` and the layer's final LayerNorm output) stays fp32 — what the
         # reference's AMP run does (fairseq/tasks/fairseq_task.py:516: LayerNorm and the residual adds run in fp32 under autocast)
-        self.new = {"on": on, "flash": flash, "resid_f32": resid_f32}
+        # joint_logits_f32: the transducer's lattice logits are not rounded — what the `transducer_loss` criterion sees on the HIP path
+        # since round 6 (csrc/joint_rnnt.hip: output layer fused with the loss on the fp32 accumulators; the logits' GRADIENT is
+        # still stored in bf16)
+        self.new = {"on": on, "flash": flash, "resid_f32": resid_f32, "joint_logits_f32": joint_logits_f32}
 
     def __enter__(self):
         self.old = dict(_EMU)
@@ -623,7 +626,8 @@ def transducer_joint(enc_btc, dec_buh, sd):
     else:
         w = sd["decoder.embed_tokens.weight"]
     y = _lin(z, w, sd["fc_out.bias"])
-    return _rg(y) if os.environ.get("EA_JOINT_LOGITS_F32", "0") == "1" else _r(y)  # (diagnostic switch of the HIP path, round 6)
+    # (fp32 logits: the fused criterion path, or the diagnostic switch EA_JOINT_LOGITS_F32=1 of the unfused one)
+    return _rg(y) if (_EMU.get("joint_logits_f32") or os.environ.get("EA_JOINT_LOGITS_F32", "0") == "1") else _r(y)
 
 
 def transducer(feats, lengths, prev_tokens, sd, H, pad_idx=1, residual=False, training=False, update=None):

@@ -1918,6 +1918,10 @@ def check_transducer_vs_reference():
     res["n_vs_emulation"] = len(l2e)
     res["worst_l2_vs_emulation"] = max(l2e.items(), key=lambda kv: kv[1])
     res["median_l2_vs_emulation"] = sorted(l2e.values())[len(l2e) // 2]
+    # the yardstick: how far the two ORACLE runs (the reference's fp32 gradients of the fixture vs the bf16-emulating restatement)
+    # are apart on the same tensors — two bf16 realisations of a ReLU-kink network cannot agree better than bf16 agrees with fp32
+    gap = sorted(float((sde[n].grad - grads[n]).norm() / (grads[n].norm() + 1e-12)) for n in l2e)
+    res["oracle_gap_median_l2"], res["oracle_gap_worst_l2"] = gap[len(gap) // 2], gap[-1]
     res["worst_max_vs_emulation"] = max(mxe.items(), key=lambda kv: kv[1])
     res["median_max_vs_emulation"] = sorted(mxe.values())[len(mxe) // 2]
     return res
@@ -2178,7 +2182,8 @@ def check_fullsize_transducer_vs_oracle(dropout=0.0, seed=0, lens=(200, 140), tl
         sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("version")
                    else v.clone()) for k, v in sd0.items()}
         plan = D.MaskPlan(tr.entries, _lib.lib().ea_layer_dropout_seed)
-        with torch_ref.bf16_emulation(emu, flash=True), torch_ref.dropout_masks(plan if dropout > 0 else None):
+        # (joint_logits_f32: the criterion fuses the output layer with the loss — the lattice logits stay fp32 accumulators)
+        with torch_ref.bf16_emulation(emu, flash=True, joint_logits_f32=True), torch_ref.dropout_masks(plan if dropout > 0 else None):
             lt, ol = torch_ref.transducer(feats, lengths, prev, sdo, H=H, pad_idx=pad, residual=False, training=True, update={})
         plan.done()
         oloss = 0.0
@@ -2199,6 +2204,84 @@ def check_fullsize_transducer_vs_oracle(dropout=0.0, seed=0, lens=(200, 140), tl
     res["median_l2_oracle_gap"] = l2g[len(l2g) // 2]
     res["worst_l2_oracle_gap"] = l2g[-1]
     return res
+
+
+def check_joint_rnnt_fused(B=3, T=37, U1=9, V=40, J=64, seed=0):
+    """csrc/joint_rnnt.hip (output layer fused with the RNN-T loss, logits never written) against the unfused kernels of
+    csrc/rnnt.hip fed with the SAME logits in fp32 (torch fp32 product of the bf16 operands): per-utterance loss, the gradient of
+    the logits (bf16, padded pitch, pad columns and rows outside the lattice zero) on ragged lengths."""
+    from espresso_amd import kernels as K
+
+    g = torch.Generator().manual_seed(seed)
+    n = B * T * U1
+    Z = (torch.randn(n, J, generator=g).clamp_min(0) * 0.7).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(V, J, generator=g) * (2.0 / J ** 0.5)).to(torch.bfloat16).to(DEV)
+    bias = (torch.randn(V, generator=g) * 0.3).to(DEV)
+    Tl = torch.tensor([T] + [max(1, T - 3 - 5 * i) for i in range(1, B)], dtype=torch.int32)
+    Ul = torch.tensor([U1 - 1] + [max(0, U1 - 2 - 2 * i) for i in range(1, B)], dtype=torch.int32)
+    blank = 0
+    tg = torch.randint(1, V, (B, U1 - 1), generator=g, dtype=torch.int32)
+    tgd, Tld, Uld = tg.to(DEV), Tl.to(DEV), Ul.to(DEV)
+    logits = (Z.float() @ W.float().t() + bias).view(B, T, U1, V).contiguous()
+    loss_u, ws_u = K.rnnt_loss_fwd(logits, tgd, Tld, Uld, blank)
+    scale = torch.full((1,), 0.37, device=DEV)
+    grad_u = K.rnnt_loss_grad(logits, tgd, Tld, Uld, loss_u, ws_u, blank, grad_scale_dev=scale, grad_bf16=False).reshape(n, V)
+    assert K.joint_rnnt_supported(Z, W)
+    loss_f, ws_f = K.joint_rnnt_loss_fwd(Z, W, bias, tgd, Tld, Uld, B, T, U1, blank)
+    Vp = (V + 63) // 64 * 64
+    dl = K.joint_rnnt_loss_grad(Z, W, bias, tgd, Tld, Uld, loss_f, ws_f, B, T, U1, blank, Vp, grad_scale_dev=scale)
+    torch.cuda.synchronize()
+    gu, gf = grad_u.float().cpu(), dl[:, :V].float().cpu()
+    # bf16 storage of the fused gradient: half a unit in the last place of each element (2^-9 relative) + fp32 summation order
+    tol = gu.abs() * 2.0 ** -8 + 1e-6 * float(gu.abs().max())
+    inside = torch.zeros(B, T, U1, dtype=torch.bool)
+    for b in range(B):
+        inside[b, : int(Tl[b]), : int(Ul[b]) + 1] = True
+    return {"loss_rel": float(((loss_f - loss_u).abs() / loss_u.abs().clamp_min(1e-6)).max()), "loss": loss_u.cpu().tolist(),
+            "grad_excess": float(((gf - gu).abs() - tol).max()), "grad_scale": float(gu.abs().max()),
+            "pad_zero": bool((dl[:, V:] == 0).all()), "outside_zero": bool((dl.view(B, T, U1, Vp)[~inside.to(DEV)] == 0).all()),
+            "finite": bool(torch.isfinite(dl.float()).all() and torch.isfinite(loss_f).all())}
+
+
+def check_transducer_fused_vs_materialised_criterion():
+    """`transducer_loss` on the tiny transducer with the fused output layer + loss (default) vs the materialised logits
+    (F.set_joint_fused(False)): same weights, same batch -> the same loss up to the bf16 rounding of the logits the unfused path
+    stores, gradients within the noise of that rounding."""
+    from espresso_amd import functional as F
+    from espresso_amd.criterions.transducer_loss import TransducerLossCriterion
+
+    g = np.load(os.path.join(GOLD, "ref_conformer_transducer_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    task = _Task(40)
+    feats, lengths, prev = torch.from_numpy(g["feats"]), torch.from_numpy(g["lengths"]), torch.from_numpy(g["prev"])
+    pad, eos = task.target_dictionary.pad(), task.target_dictionary.eos()
+    target = torch.full_like(prev, pad)
+    tl = []
+    for b in range(prev.shape[0]):
+        toks = [int(t) for t in prev[b, 1:] if int(t) != pad]
+        tl.append(len(toks))
+        target[b, : len(toks)] = torch.tensor(toks)
+        target[b, len(toks)] = eos
+    sample = {"net_input": {"src_tokens": feats.to(DEV), "src_lengths": lengths.to(DEV), "prev_output_tokens": prev.to(DEV)},
+              "target": target.to(DEV), "ntokens": int(sum(tl)) + len(tl)}
+    out = {}
+    for fused in (True, False):
+        old = F.set_joint_fused(fused)
+        try:
+            model = build_tiny_transducer().to(DEV)
+            model.load_state_dict(model.upgrade_state_dict_named(dict(sd), ""), strict=False)
+            model.train()
+            loss, _, _ = TransducerLossCriterion(task)(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+            out[fused] = (float(loss), {n: p.grad.float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            F.set_joint_fused(old)
+    (la, ga), (lb, gb) = out[True], out[False]
+    names = [n for n in gb if not (n.startswith("encoder.pre_encoder.convolutions.") and n.endswith(".bias")) and not n.endswith("attn.k_proj.bias")]
+    l2 = sorted(float((ga[n] - gb[n]).norm() / (gb[n].norm() + 1e-12)) for n in names)
+    return {"loss_fused": la, "loss_materialised": lb, "loss_rel": abs(la - lb) / abs(lb), "median_l2": l2[len(l2) // 2], "worst_l2": l2[-1],
+            "same_params": set(ga) == set(gb), "n_grads": len(ga)}
 
 
 def check_transducer_branch_overlap():

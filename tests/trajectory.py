@@ -217,7 +217,8 @@ def train_oracle_transducer(sd, train, heldout, steps, emulate):
     def batch_loss(batch, update):
         feats, lens, tg = batch
         target, prev, tl = transducer_targets(tg)
-        with torch_ref.bf16_emulation(emulate, flash=False):
+        # (joint_logits_f32: the criterion's fused output layer + loss works on the fp32 accumulators — csrc/joint_rnnt.hip)
+        with torch_ref.bf16_emulation(emulate, flash=False, joint_logits_f32=True):
             lo, ol = torch_ref.transducer(feats, lens, prev, P, H=TD_HEADS, pad_idx=TD_PAD, residual=True, training=True, update=update)
         tot = 0.0
         for b in range(feats.shape[0]):
