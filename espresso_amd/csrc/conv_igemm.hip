@@ -270,9 +270,16 @@ __device__ __forceinline__ void ds_read_tr16_x8(const uint32_t (&ad)[8], uint2 (
       : "memory");
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs a) {
   constexpr int TILE = 64 * ROW_BYTES;  // 8 KiB: 64 position rows x 64 channels
-  __shared__ __attribute__((aligned(16))) char lds[3 * TILE];  // [A][B0][B1]
+  // Ring: two dZ tiles (a chunk's tile serves its nine taps) + four X tiles, loads issued THREE steps ahead (round 6).  Rounds 2 - 5
+  // double-buffered the X tile and waited for vmcnt(0) at every step: 8 MFMAs per wavefront (~150 cycles) between a load's issue and
+  // its wait against ~2 us of last-level-cache latency — 222 us per launch, 9 % of the MFMA peak, 8 KB in flight per workgroup.
+  // (DEPTH = 1: the round 2 - 5 schedule, kept as the A/B reference: EA_CONV_WGRAD_DEPTH=1)
+  constexpr int NBUF = 4;
+  static_assert(DEPTH >= 1 && DEPTH <= 3, "ring of four X tiles");
+  __shared__ __attribute__((aligned(16))) char lds[(2 + NBUF) * TILE];  // [A0][A1][B0][B1][B2][B3]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // wave tile: cout rows wr*32.., cin cols wc*32..
   const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
@@ -315,11 +322,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
       }
     }
   };
-  auto issue_A = [&]() {  // dZ rows of the decoded chunk
+  auto issue_A = [&](int abuf) {  // dZ rows of the decoded chunk
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bf16_t* s = rowb[i] >= 0 ? a.dZ + rowp[i] * a.Cout + co0 + cs[i] * 8 : a.zero + cs[i] * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + (wave + 4 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + abuf * TILE + (wave + 4 * i) * 1024), 16, 0, 0);
     }
   };
   auto issue_B = [&](int buf, int tap) {  // X rows the decoded chunk's positions read through `tap`
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
       const int st = rowt[i] + a.bt[tap], sf = rowf[i] + a.bf[tap];
       const bool ok = rowb[i] >= 0 && (unsigned)st < (unsigned)a.ST && (unsigned)sf < (unsigned)a.SF;
       const bf16_t* s = ok ? a.X + (((long)(rowb[i] + st)) * a.SF + sf) * a.Cin + ci0 + cs[i] * 8 : a.zero + cs[i] * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + (1 + buf) * TILE + (wave + 4 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + (2 + buf) * TILE + (wave + 4 * i) * 1024), 16, 0, 0);
     }
   };
   // transposing fragment reads: tile at byte offset tile_off, the wave's 32 channels [c0, c0 + 32) (two 16-channel tiles) x 64
@@ -356,32 +363,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
   };
 
   const int nsteps = (int)nch * a.ntaps;
-  if (nsteps > 0) {
-    decode(0);
-    issue_A();
-    issue_B(0, 0);
-  }
+  // issue cursor: the loads of step `is` (chunk ich, tap itap) — the chunk's dZ tile first when the step opens a chunk, then the X
+  // tile of the tap; loads return in order, so waiting for a step's X tile also covers the dZ tile issued just before it
+  int is = 0, itap = 0;
+  long ich = 0;
+  auto issue_next = [&]() {
+    if (is >= nsteps) return;
+    if (itap == 0) {
+      decode(ich);
+      issue_A((int)(ich & 1));
+    }
+    issue_B(is & (NBUF - 1), itap);
+    ++is;
+    if (++itap == a.ntaps) { itap = 0; ++ich; }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue_next();
   uint4 fa[2][2];  // dZ fragments of the current chunk: [ksub][cout tile]
-  int buf = 0;
   long ch = 0;
   int tap = 0;
   for (int s = 0; s < nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // this step's tiles are complete; everyone is done with the other B buffer (and with A when tap == 0 was read)
-    if (tap == 0) read_frags(0, wr * 32, fa);
+    // instructions issued after this step's X tile: the X tiles of the next two steps (2 each) + the dZ tile of a chunk one of
+    // them opens (2)
+    const int tap1 = tap + 1 == a.ntaps ? 0 : tap + 1, tap2 = tap1 + 1 == a.ntaps ? 0 : tap1 + 1;
+    int pend = 0;
+    if (DEPTH >= 2 && s + 1 < nsteps) pend += 2 + (tap1 == 0 ? 2 : 0);
+    if (DEPTH >= 3 && s + 2 < nsteps) pend += 2 + (tap2 == 0 ? 2 : 0);
+    if (pend >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (pend == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // this step's tiles are complete in every wavefront's part; everyone is done with step s - 1's X tile
+    if (tap == 0) read_frags((int)(ch & 1) * TILE, wr * 32, fa);
     uint4 fb[2][2];
-    read_frags((1 + buf) * TILE, wc * 32, fb);
+    read_frags((2 + (s & (NBUF - 1))) * TILE, wc * 32, fb);
     __builtin_amdgcn_sched_barrier(0);
-    // next step's loads (A of the next chunk goes out one step early: its fragments were copied to registers at tap 0, but other
-    // waves may still be reading the A tile during step (ch, 0) — so never before the barrier of step (ch, 1))
-    const int ntap = tap + 1 == a.ntaps ? 0 : tap + 1;
-    if (s + 1 < nsteps) {
-      if (ntap == 0) {
-        decode(ch + 1);
-        issue_A();
-      }
-      issue_B(buf ^ 1, ntap);
-    }
+    // step s + 3 goes into the ring slot step s - 1 used (free since the barrier above); a dZ tile goes into the slot chunk ch - 1
+    // used, whose fragments every wavefront copied to registers eight or more steps ago
+    issue_next();
     // acc[tap] += dZ_tile^T X_tile   (static tap index: the accumulators are registers)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -397,9 +417,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
                   __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[ks][j]), acc[t][i][j], 0, 0, 0);
       }
     }
-    buf ^= 1;
-    tap = ntap;
-    if (ntap == 0) ++ch;
+    tap = tap1;
+    if (tap1 == 0) ++ch;
   }
 
   // partial sums -> slab[z][cout][tap][cin]: lane holds acc[t][i][j][r] = (cout wr*32 + i*16 + (lane>>4)*4 + r, cin wc*32 + j*16 + (lane&15))
@@ -566,7 +585,10 @@ static int conv3x3_wgrad_impl(const void* X, const void* dZ, float* dW, void* wo
   const int nsplit = wgrad_split(M, Cin, Cout);
   const long chunks = (M + 63) / 64;
   a.chunks_per_wg = (int)((chunks + nsplit - 1) / nsplit);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
+  static const int depth = [] { const char* e = getenv("EA_CONV_WGRAD_DEPTH"); return e ? atoi(e) : 3; }();  // (diagnostic A/B switch)
+  if (depth == 1) hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
+  else if (depth == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
   const long n = (long)Cout * 9 * Cin;
   const long blocks = (n / 4 + 255) / 256;
   int zg = (int)(1024 / blocks);  // ~1024 workgroups in all

@@ -4,8 +4,8 @@
 // Reference: espresso/models/transformer/speech_transformer_transducer_base.py:276-299 (fc_out on relu(E + D)) feeding
 // espresso/criterions/transducer_loss.py:130-140 (torchaudio.functional.rnnt_loss with fused_log_softmax).  The unfused path
 // (csrc/rnnt.hip) writes the logits as bf16 [n][V] (708 MB at the recipe's 70 000 lattice nodes), reads them back for the
-// log-sum-exp and once more for the gradient; their bf16 rounding is also the largest remaining difference between two bf16
-// realisations of the loss gradient (a flipped last bit of a logit of magnitude 4 - 8 moves exp() by 1.5 - 3 %).  Here
+// log-sum-exp and once more for the gradient, each logit rounded to bf16 in between (a last bit of a logit of magnitude 4 - 8 is
+// 1.5 - 3 % of exp()).  Here
 //   forward   logits tile = Z W^T + bias on the 8-wavefront 256 x 256 GEMM of gemm_w8.hip; the epilogue keeps, per lattice node
 //             and vocabulary tile, (max, sum of exp) in fp32 plus the two logits the recursion needs (blank, next label); a small
 //             kernel folds the tiles into lse / log p(blank) / log p(label); alpha / beta by rnnt_scan_kernel (csrc/rnnt.hip).
@@ -144,20 +144,33 @@ __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, c
   const int row0 = wm * JTM, col0 = wn * JTN;
   const int nown = n0 + col0 + g * 4;
   float bias4[JNJ][4];
+  const bool bias_vec = a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0;
 #pragma unroll
-  for (int j = 0; j < JNJ; ++j)
+  for (int j = 0; j < JNJ; ++j) {
+    const int c = nown + j * 16;
+    if (bias_vec && c + 3 < a.V) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+      bias4[j][0] = b.x; bias4[j][1] = b.y; bias4[j][2] = b.z; bias4[j][3] = b.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = nown + j * 16 + e;
-      bias4[j][e] = (a.bias && c < a.V) ? a.bias[c] : 0.f;
+      for (int e = 0; e < 4; ++e) bias4[j][e] = (a.bias && c + e < a.V) ? a.bias[c + e] : 0.f;
     }
+  }
   if constexpr (KIND == J_LSE) {
     __syncthreads();  // every wavefront is done with the ring: its first 8 KB become the [256 rows][4 column waves] partial table
     float2* tab = reinterpret_cast<float2*>(dsm);
+    // the rows' labels are requested together, before the first store (the compiler may not move a load above a store through
+    // another pointer: fetched inside the loop they were eight dependent round trips per wavefront)
+    int ycs[JMI];
 #pragma unroll
     for (int i = 0; i < JMI; ++i) {
       const int m = m0 + row0 + i * 16 + r16;
-      const int yc = m < a.M ? a.ycol[m] : -1;
+      ycs[i] = m < a.M ? __builtin_nontemporal_load(a.ycol + m) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < JMI; ++i) {
+      const int m = m0 + row0 + i * 16 + r16;
+      const int yc = ycs[i];
       float x[JNJ][4];
       float mx = -INFINITY;
 #pragma unroll
@@ -167,11 +180,19 @@ __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, c
           const int c = nown + j * 16 + e;
           x[j][e] = acc[i][j][e] + bias4[j][e];
           if (c < a.V) mx = fmaxf(mx, x[j][e]);
-          if (m < a.M) {
+        }
+      // the two logits the recursion needs: only the wavefront whose 64 columns hold blank / the row's label looks for them
+      // (one of 80 vocabulary slabs: the 32 compare + predicated-store pairs per row are skipped everywhere else)
+      if (m < a.M && ((unsigned)(a.blank - (n0 + col0)) < (unsigned)JTN || (unsigned)(yc - (n0 + col0)) < (unsigned)JTN)) {
+#pragma unroll
+        for (int j = 0; j < JNJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = nown + j * 16 + e;
             if (c == a.blank) a.lpb[m] = x[j][e];
             if (c == yc) a.lpy[m] = x[j][e];
           }
-        }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float s = 0.f;
@@ -203,11 +224,17 @@ __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, c
     float scale = a.scale;
     if (a.scale_dev) scale *= a.scale_dev[0];
     const int npair = n0 + col0 + (g & 1) * 16 + (g >> 1) * 8;
+    float4 rcs[JMI];  // (all eight rows' constants requested before the first store, as the labels above)
+#pragma unroll
+    for (int i = 0; i < JMI; ++i) {
+      const int m = m0 + row0 + i * 16 + r16;
+      rcs[i] = m < a.M ? a.rowc[m] : make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
+    }
 #pragma unroll
     for (int i = 0; i < JMI; ++i) {
       const int m = m0 + row0 + i * 16 + r16;
       const bool mv = m < a.M;
-      const float4 rc = mv ? a.rowc[m] : make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
+      const float4 rc = rcs[i];
       const int y = __float_as_int(rc.w);
 #pragma unroll
       for (int jp = 0; jp < JNJ / 2; ++jp) {

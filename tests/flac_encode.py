@@ -220,6 +220,8 @@ def encode(samples, sample_rate=16000, bits=16, blocksize=1152, stereo_mode="ind
             kind = p["kind"]
             if kind == "constant" and len(set(int(v) for v in chans[c])) != 1:
                 kind = "verbatim"
+            if order > m:  # a last block shorter than the predictor order (RFC 9639 9.2.6: warm-up samples must fit the block)
+                kind, po, esc = "verbatim", 0, None
             _subframe(w, chans[c], sub_bps[c], kind, po, esc, p["wasted"], p["rice2"])
         w.align()
         body = bytes(w.buf)

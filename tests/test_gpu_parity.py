@@ -178,10 +178,13 @@ def test_encoder_vs_reference_fixture(layer_type, fixture):
     r = G.check_encoder_vs_reference(layer_type, fixture=fixture)
     print(r)
     assert r["eval_lengths_equal"]
-    # (a) bf16 compute vs the reference's own fp32 outputs: north_star tolerance 1e-2 on losses / log-probs.  Logits here have
-    #     magnitude up to 4, where ONE bf16 step is 0.0156-0.031: 1e-2 relative to the logit scale = 4e-2 absolute.
+    # (a) bf16 compute vs the reference's own fp32 outputs.  Losses: north_star's 1e-2.  Logits / log-probs: ABSOLUTE bounds from
+    #     measurements (round 6, tools/probes/r06_logit_errors.py: eval 0.027 - 0.031, train-mode 0.037 - 0.049 on these fixtures).
+    #     north_star's 1e-2 on log-probs is below what bf16 WEIGHTS alone cost (0.010 - 0.012 with every activation in fp32) and
+    #     below what the reference's own autocast rounding points give (0.013 - 0.024): tests/test_oracle.py
+    #     test_bf16_floor_of_the_logit_tolerance pins both on the CPU, DESIGN.md section 5 has the table.
     assert abs(r["train_loss"] - r["ref_loss"]) / r["ref_loss"] < 1e-2, r
-    assert r["eval_logits_abs"] < 4e-2 and r["train_logits_abs"] < 5e-2, r
+    assert r["eval_logits_abs"] < 3.5e-2 and r["train_logits_abs"] < 5.5e-2, r
     # greedy ids identical to the reference's wherever its own top-2 margin exceeds the bf16 noise floor
     assert r["clear_margin_frames"] >= 30 and r["eval_greedy_agree_clear_margin"] == 1.0, r
     assert r["eval_greedy_agree"] > 0.9, r
@@ -279,9 +282,9 @@ def test_fullsize_encdec_config2_vs_oracle(dropout):
     print(r)
     assert r["n_grads"] > 300 and r["n_site_masks"] == (0 if dropout == 0 else 2 + 12 * 4 + 1 + 6 * 6), r
     assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r        # north_star: 1e-2 (bf16) on losses
-    assert r["eval_logits_vs_fp32"] < 2e-2 * max(4.0, r["logit_scale"]), r
+    assert r["eval_logits_vs_fp32"] < 6e-2, r      # (absolute; measured 0.042 at |logit| <= 4.25, where one bf16 step is 0.031)
     assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 3e-3, r
-    assert r["eval_logits_vs_emu"] < 1.5e-2 * max(4.0, r["logit_scale"]), r
+    assert r["eval_logits_vs_emu"] < 6e-2, r       # (measured 0.039: one bf16 step at |logit| > 4 plus one at 2 - 4)
     # per tensor: 8 % of its scale, or 1.5 x the distance between the two ORACLE runs where that is larger: with 41 target
     # positions the decoder's ReLU-FFN gradients are rounding-chaotic (a pre-activation within one bf16 step of zero flips its
     # derivative) — the fp32 and the emulating oracle are 25-30 % apart on decoder.layers.*.fc1.weight themselves, and HIP vs
@@ -333,7 +336,7 @@ def test_legacy_speech_transformer_preset_training_step():
     r = G.check_legacy_speech_transformer_step()
     print(r)
     assert r["loss_finite"] and not r["params_without_gradient"], r
-    assert r["eval_logits_abs_valid"] < 4e-2 * max(1.0, r["ref_logit_scale"] / 4.0), r
+    assert r["eval_logits_abs_valid"] < (4e-2 if r["ref_logit_scale"] <= 4.0 else 6e-2), r  # (one more bf16 exponent above |logit| = 4)
 
 
 def test_native_layer_runtime_matches_kernel_composition():
@@ -783,9 +786,9 @@ def test_fullsize_layer_vs_oracle(layer_type, dropout):
     assert r["n_grads"] > 30
     assert r["n_site_masks"] == (0 if dropout == 0 else 2 + (7 if layer_type == "conformer" else 4)), r
     assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r          # north_star: 1e-2 (bf16) on losses
-    assert r["eval_logits_vs_fp32"] < 1e-2 * max(4.0, r["logit_scale"]), r           # ... and log-probs, relative to their scale
+    assert r["eval_logits_vs_fp32"] < 2e-2, r   # absolute (measured 0.0128 at |logit| <= 1.95; the bf16-weights-only floor is 0.009)
     assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 2e-3, r
-    assert r["eval_logits_vs_emu"] < 8e-3 * max(4.0, r["logit_scale"]), r
+    assert r["eval_logits_vs_emu"] < 1.6e-2, r  # two bf16 steps at |logit| in 1 - 2 (measured 0.0078 / 0.0088)
     assert r["worst_grad_vs_emu"][1] < 8e-2 and r["median_grad_vs_emu"] < 1.2e-2, r
 
 
@@ -799,9 +802,9 @@ def test_fullsize_12_layer_model_vs_oracle(dropout):
     assert r["n_grads"] > 400
     assert r["n_site_masks"] == (0 if dropout == 0 else 2 + 12 * 7), r
     assert abs(r["hip_loss"] - r["fp32_loss"]) / r["fp32_loss"] < 1e-2, r          # north_star: 1e-2 (bf16) on losses
-    assert r["eval_logits_vs_fp32"] < 2e-2 * max(4.0, r["logit_scale"]), r           # 12 layers of bf16 activations
+    assert r["eval_logits_vs_fp32"] < 3e-2, r   # absolute: 12 layers of bf16 activations (measured 0.0207 - 0.0225 at |logit| <= 1.75)
     assert abs(r["hip_loss"] - r["emu_loss"]) / r["emu_loss"] < 3e-3, r
-    assert r["eval_logits_vs_emu"] < 1.5e-2 * max(4.0, r["logit_scale"]), r   # measured 0.047 at |logit| <= 3.1: 3 bf16 steps
+    assert r["eval_logits_vs_emu"] < 5e-2, r    # measured 0.018 (round 6) and 0.047 (round 5, |logit| <= 3.1: three bf16 steps)
     assert r["worst_grad_vs_emu"][1] < 8e-2 and r["median_grad_vs_emu"] < 1.2e-2, r  # (measured 4.9 % / 0.8 % at dropout 0)
 
 
