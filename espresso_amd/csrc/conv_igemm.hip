@@ -585,7 +585,11 @@ static int conv3x3_wgrad_impl(const void* X, const void* dZ, float* dW, void* wo
   const int nsplit = wgrad_split(M, Cin, Cout);
   const long chunks = (M + 63) / 64;
   a.chunks_per_wg = (int)((chunks + nsplit - 1) / nsplit);
-  static const int depth = [] { const char* e = getenv("EA_CONV_WGRAD_DEPTH"); return e ? atoi(e) : 3; }();  // (diagnostic A/B switch)
+  // ring depth by shape (round 6, isolated at the recipe batch, us per call incl. the slab reduce, depth 1 / 3): conv 2 (64 -> 64
+  // channels, 520 k positions) 236 / 215, conv 3 (64 -> 128) 281 / 308, conv 4 (128 -> 128, 130 k positions) 174 / 178 — the kernel is
+  // bound by its LDS fragment reads and the barrier per tap, not by load latency; only the 64-output-channel shape gains
+  static const int depth_env = [] { const char* e = getenv("EA_CONV_WGRAD_DEPTH"); return e ? atoi(e) : 0; }();  // (diagnostic A/B switch)
+  const int depth = depth_env ? depth_env : (Cout <= 64 ? 3 : 1);
   if (depth == 1) hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
   else if (depth == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);

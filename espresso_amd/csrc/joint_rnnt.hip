@@ -50,6 +50,26 @@ struct JointArgs {
 
 enum { J_LSE = 0, J_GRAD = 1 };
 
+// butterfly steps across the four 16-lane groups of a wavefront on the VALU (v_permlane16_swap / v_permlane32_swap, lane semantics
+// pinned on hardware by tools/probes/permlane_probe.hip: swap(x, x) returns {rows 0,0,2,2 ; rows 1,1,3,3} resp. {lower half twice ;
+// upper half twice}) — __shfl_xor goes through ds_bpermute: an LDS round trip per step, 32 of them per lane in this epilogue
+__device__ __forceinline__ float xor16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -73,6 +93,27 @@ __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, c
   for (int i = 0; i < JMI; ++i)
 #pragma unroll
     for (int j = 0; j < JNJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- everything the epilogue reads from memory is fetched HERE, before the k loop, into 6 KB of LDS behind the ring: one
+  // 512-thread workgroup owns the CU, so a load issued in the epilogue is a round trip nothing overlaps (measured: label / constant
+  // loads inside the row loop made the two kernels 1005 / 910 us per launch, against 776 us for the plain product with its 708 MB
+  // store); held in registers across the k loop they cost 32 VGPRs and spilled.  The k loop's barriers publish the LDS writes.
+  const int g = lane >> 4, r16 = lane & 15;
+  const int row0 = wm * JTM, col0 = wn * JTN;
+  const int nown = n0 + col0 + g * 4;
+  float4* x_rowc = reinterpret_cast<float4*>(dsm + JNST * STAGE);            // [256] (J_GRAD)
+  int* x_ycol = reinterpret_cast<int*>(dsm + JNST * STAGE + JBM * 16);       // [256] (J_LSE)
+  float* x_bias = reinterpret_cast<float*>(dsm + JNST * STAGE + JBM * 20);   // [256]
+  if (tid < JBM) {
+    const int m = m0 + tid;
+    if constexpr (KIND == J_LSE) x_ycol[tid] = m < a.M ? a.ycol[m] : -1;
+    else x_rowc[tid] = m < a.M ? a.rowc[m] : make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
+  } else {
+    const int c = n0 + tid - JBM;
+    x_bias[tid - JBM] = (a.bias && c < a.V) ? a.bias[c] : 0.f;
+  }
+  float scale = a.scale;
+  if (KIND == J_GRAD && a.scale_dev) scale *= a.scale_dev[0];
 
   const int src_chunk = (lane & 7) ^ (lane >> 3);
   const bf16_t* ap[NA];
@@ -140,50 +181,33 @@ __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, c
   }
 
   // ---- epilogue from registers: acc[i][j][e] = logit[m0 + row0 + i*16 + (lane & 15)][n0 + col0 + j*16 + (lane >> 4)*4 + e] - bias ----
-  const int g = lane >> 4, r16 = lane & 15;
-  const int row0 = wm * JTM, col0 = wn * JTN;
-  const int nown = n0 + col0 + g * 4;
+  __syncthreads();  // every wavefront is done with the ring (J_LSE reuses its first 8 KB); the constants written above are visible
   float bias4[JNJ][4];
-  const bool bias_vec = a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0;
 #pragma unroll
   for (int j = 0; j < JNJ; ++j) {
-    const int c = nown + j * 16;
-    if (bias_vec && c + 3 < a.V) {
-      const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
-      bias4[j][0] = b.x; bias4[j][1] = b.y; bias4[j][2] = b.z; bias4[j][3] = b.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bias4[j][e] = (a.bias && c + e < a.V) ? a.bias[c + e] : 0.f;
-    }
+    const float4 b = *reinterpret_cast<const float4*>(x_bias + col0 + j * 16 + g * 4);
+    bias4[j][0] = b.x; bias4[j][1] = b.y; bias4[j][2] = b.z; bias4[j][3] = b.w;
   }
+  // EDGE: the tile holds columns >= V (the last vocabulary tile only): everything else runs without a per-element column test
+  const bool edge = n0 + JBN > a.V;
+  const int slab0 = n0 + col0;                                             // first column of this wavefront's 64
+  const bool blank_here = (unsigned)(a.blank - slab0) < (unsigned)JTN;     // (uniform per wavefront)
   if constexpr (KIND == J_LSE) {
-    __syncthreads();  // every wavefront is done with the ring: its first 8 KB become the [256 rows][4 column waves] partial table
-    float2* tab = reinterpret_cast<float2*>(dsm);
-    // the rows' labels are requested together, before the first store (the compiler may not move a load above a store through
-    // another pointer: fetched inside the loop they were eight dependent round trips per wavefront)
     int ycs[JMI];
 #pragma unroll
-    for (int i = 0; i < JMI; ++i) {
-      const int m = m0 + row0 + i * 16 + r16;
-      ycs[i] = m < a.M ? __builtin_nontemporal_load(a.ycol + m) : -1;
-    }
+    for (int i = 0; i < JMI; ++i) ycs[i] = x_ycol[row0 + i * 16 + r16];
+    float2* tab = reinterpret_cast<float2*>(dsm);  // [256 rows][4 column waves] partial (max, sum) table
 #pragma unroll
     for (int i = 0; i < JMI; ++i) {
       const int m = m0 + row0 + i * 16 + r16;
       const int yc = ycs[i];
       float x[JNJ][4];
-      float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < JNJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = nown + j * 16 + e;
-          x[j][e] = acc[i][j][e] + bias4[j][e];
-          if (c < a.V) mx = fmaxf(mx, x[j][e]);
-        }
+        for (int e = 0; e < 4; ++e) x[j][e] = acc[i][j][e] + bias4[j][e];
       // the two logits the recursion needs: only the wavefront whose 64 columns hold blank / the row's label looks for them
-      // (one of 80 vocabulary slabs: the 32 compare + predicated-store pairs per row are skipped everywhere else)
-      if (m < a.M && ((unsigned)(a.blank - (n0 + col0)) < (unsigned)JTN || (unsigned)(yc - (n0 + col0)) < (unsigned)JTN)) {
+      if (m < a.M && (blank_here || (unsigned)(yc - slab0) < (unsigned)JTN)) {
 #pragma unroll
         for (int j = 0; j < JNJ; ++j)
 #pragma unroll
@@ -193,18 +217,26 @@ __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, c
             if (c == yc) a.lpy[m] = x[j][e];
           }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (edge) {
+#pragma unroll
+        for (int j = 0; j < JNJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nown + j * 16 + e >= a.V) x[j][e] = -INFINITY;
+      }
+      float mx = x[0][0];
+#pragma unroll
+      for (int j = 0; j < JNJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, x[j][e]);
+      mx = xor32_max(xor16_max(mx));  // over the four 16-lane groups that share the row
+      const float ms = mx > -INFINITY ? mx : 0.f;  // (a slab wholly past V: every term below is exp(-inf) = 0)
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < JNJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = nown + j * 16 + e;
-          if (c < a.V) s += __expf(x[j][e] - mx);  // (mx is finite whenever one column of the wavefront's 64 is inside V)
-        }
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+        for (int e = 0; e < 4; ++e) s += __expf(x[j][e] - ms);
+      s = xor32_sum(xor16_sum(s));
       if (g == 0) tab[(row0 + i * 16 + r16) * JWN + wn] = make_float2(mx, s);
     }
     __syncthreads();
@@ -221,40 +253,42 @@ __global__ __launch_bounds__(512, 2) void joint_rnnt_kernel(const JointArgs a, c
       a.part[(long)(m0 + tid) * tiles_n + tile_x] = make_float2(mx, s);
     }
   } else {
-    float scale = a.scale;
-    if (a.scale_dev) scale *= a.scale_dev[0];
     const int npair = n0 + col0 + (g & 1) * 16 + (g >> 1) * 8;
-    float4 rcs[JMI];  // (all eight rows' constants requested before the first store, as the labels above)
-#pragma unroll
-    for (int i = 0; i < JMI; ++i) {
-      const int m = m0 + row0 + i * 16 + r16;
-      rcs[i] = m < a.M ? a.rowc[m] : make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
-    }
 #pragma unroll
     for (int i = 0; i < JMI; ++i) {
       const int m = m0 + row0 + i * 16 + r16;
       const bool mv = m < a.M;
-      const float4 rc = rcs[i];
+      const float4 rc = x_rowc[row0 + i * 16 + r16];
       const int y = __float_as_int(rc.w);
+      float v[JNJ][4];
 #pragma unroll
-      for (int jp = 0; jp < JNJ / 2; ++jp) {
-        if (n0 + col0 + jp * 32 >= (int)a.ld) continue;  // (uniform per wavefront: whole 32-column groups past the row pitch)
-        uint2 out[2];
+      for (int j = 0; j < JNJ; ++j)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int j = 2 * jp + t;
-          float v[4];
+        for (int e = 0; e < 4; ++e) v[j][e] = __expf(acc[i][j][e] + bias4[j][e] + rc.x);
+      if (blank_here || (unsigned)(y - slab0) < (unsigned)JTN) {  // the two columns with a subtracted term: one slab in 80
+#pragma unroll
+        for (int j = 0; j < JNJ; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int c = nown + j * 16 + e;
-            float gv = __expf(acc[i][j][e] + bias4[j][e] + rc.x);
-            if (c == a.blank) gv -= rc.y;
-            if (c == y) gv -= rc.z;
-            v[e] = c < a.V ? gv * scale : 0.f;
+            if (c == a.blank) v[j][e] -= rc.y;
+            if (c == y) v[j][e] -= rc.z;
           }
-          out[t] = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-        }
-        const u32x4_t o = w8_swap_pair(out[0], out[1]);
+      }
+      if (edge) {
+#pragma unroll
+        for (int j = 0; j < JNJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nown + j * 16 + e >= a.V) v[j][e] = 0.f;
+      }
+#pragma unroll
+      for (int jp = 0; jp < JNJ / 2; ++jp) {
+        if (edge && n0 + col0 + jp * 32 >= (int)a.ld) continue;  // (uniform per wavefront: whole 32-column groups past the row pitch)
+        const uint2 o0 = make_uint2(pack_bf2(v[2 * jp][0] * scale, v[2 * jp][1] * scale), pack_bf2(v[2 * jp][2] * scale, v[2 * jp][3] * scale));
+        const uint2 o1 = make_uint2(pack_bf2(v[2 * jp + 1][0] * scale, v[2 * jp + 1][1] * scale),
+                                    pack_bf2(v[2 * jp + 1][2] * scale, v[2 * jp + 1][3] * scale));
+        const u32x4_t o = w8_swap_pair(o0, o1);
         if (mv) w8_store16(a.dl + (long)m * a.ld + npair + jp * 32, o, false);
       }
     }
@@ -348,7 +382,7 @@ bool joint_shape_ok(const void* Z, const void* W, long n, int V, int J) {
 }
 template <int KIND>
 bool joint_launch(const JointArgs& a, hipStream_t stream) {
-  constexpr int bytes = JNST * (JBM + JBN) * 128;
+  constexpr int bytes = JNST * (JBM + JBN) * 128 + JBM * 24;  // ring + [rowc | ycol | bias] of the tile
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_rnnt_kernel<KIND>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
   if (!attr_ok) return false;
