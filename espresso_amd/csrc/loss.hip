@@ -116,8 +116,13 @@ __global__ void ctc_scan_kernel(const float* __restrict__ G, const int* __restri
     buf0[s] = v;
     if (s < S) Ob[(long)t * Smax + s] = v;
   }
-  float lp_next = -INFINITY;
-  if (Tb > 1 && s < S) lp_next = Gb[(long)(t + step) * Smax + s];
+  // the emission log-probabilities do not depend on the recursion: requested three frames ahead, and the barrier of a frame waits
+  // for the LDS hand-off only (round 6: __syncthreads() also drains the vector-memory counter, i.e. the prefetch AND the store of
+  // the frame's row — a memory round trip per frame, 0.5 us, where the arithmetic needs 0.15)
+  auto fetch = [&](int it) -> float {
+    return (it < Tb && s < S) ? Gb[(long)(dir ? Tb - 1 - it : it) * Smax + s] : -INFINITY;
+  };
+  float lp1 = fetch(1), lp2 = fetch(2), lp3 = fetch(3);
   __syncthreads();
   float* rd = buf0;
   float* wr = buf1;
@@ -125,8 +130,10 @@ __global__ void ctc_scan_kernel(const float* __restrict__ G, const int* __restri
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   for (int it = 1; it < Tb; ++it) {
     t += step;
-    const float lp = lp_next;
-    if (it + 1 < Tb && s < S) lp_next = Gb[(long)(t + step) * Smax + s];
+    const float lp = lp1;
+    lp1 = lp2;
+    lp2 = lp3;
+    lp3 = fetch(it + 3);
     float v = -INFINITY;
     if (s < S) {
       const float a0 = rd[s];
@@ -139,9 +146,11 @@ __global__ void ctc_scan_kernel(const float* __restrict__ G, const int* __restri
       Ob[(long)t * Smax + s] = v;
     }
     wr[s] = v;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this lane's hand-off is in LDS (global requests stay in flight)
+    __builtin_amdgcn_s_barrier();
     float* tmp = rd; rd = wr; wr = tmp;
   }
+  __syncthreads();
   if (threadIdx.x == 0 && dir == 0) {
     // the alpha direction finished at t = Tb-1 in rd
     const float l1 = rd[S - 1];

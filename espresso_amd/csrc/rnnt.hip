@@ -141,7 +141,32 @@ __global__ void rnnt_scan_kernel(const float* __restrict__ lpb, const float* __r
   prevbuf[u] = -INFINITY;
   if (u == 0) { prevbuf[-1] = -INFINITY; curbuf[-1] = -INFINITY; prevbuf[UP] = -INFINITY; curbuf[UP] = -INFINITY; }
   __syncthreads();
+  // the two log-probabilities a cell needs do not depend on the recursion: they are requested THREE DIAGONALS AHEAD (round 6 —
+  // loaded where they were used, every diagonal paid a memory round trip inside the dependent chain: 0.5 - 0.65 ms per batch at
+  // the recipe's lattices, with only B workgroups on the device); the barrier below waits for the LDS hand-off only, so that the
+  // requests stay in flight across it
+  auto fetch = [&](int k, float& pb, float& py) {
+    pb = py = -INFINITY;
+    if (k >= ndiag) return;
+    const int d = dir ? (ndiag - 1 - k) : k;
+    const int t = d - u;
+    if (!(u <= Ub && t >= 0 && t < Tb)) return;
+    const long idx = base + (long)t * U1 + u;
+    if (!dir) {
+      if (t > 0) pb = lpb[idx - U1];   // from (t-1,u) by blank
+      if (u > 0) py = lpy[idx - 1];    // from (t,u-1) by label
+    } else {
+      pb = lpb[idx];                   // to (t+1,u) by blank — or the final blank at (Tb-1, Ub)
+      if (u < Ub) py = lpy[idx];       // to (t,u+1) by label
+    }
+  };
+  float pb, py, pb1, py1, pb2, py2;
+  fetch(0, pb, py);
+  fetch(1, pb1, py1);
+  fetch(2, pb2, py2);
   for (int k = 0; k < ndiag; ++k) {
+    float npb, npy;
+    fetch(k + 3, npb, npy);
     const int d = dir ? (ndiag - 1 - k) : k;
     const int t = d - u;
     float val = -INFINITY;
@@ -151,16 +176,16 @@ __global__ void rnnt_scan_kernel(const float* __restrict__ lpb, const float* __r
       if (!dir) {
         if (t == 0 && u == 0) val = 0.f;
         else {
-          const float a = t > 0 ? own_prev + lpb[idx - U1] : -INFINITY;            // from (t-1,u) by blank
-          const float c = u > 0 ? prevbuf[u - 1] + lpy[idx - 1] : -INFINITY;        // from (t,u-1) by label
+          const float a = t > 0 ? own_prev + pb : -INFINITY;
+          const float c = u > 0 ? prevbuf[u - 1] + py : -INFINITY;
           val = log_add(a, c);
         }
         alpha[idx] = val;
       } else {
-        if (t == Tb - 1 && u == Ub) val = lpb[idx];
+        if (t == Tb - 1 && u == Ub) val = pb;
         else {
-          const float a = t < Tb - 1 ? own_prev + lpb[idx] : -INFINITY;             // to (t+1,u) by blank
-          const float c = u < Ub ? prevbuf[u + 1] + lpy[idx] : -INFINITY;           // to (t,u+1) by label
+          const float a = t < Tb - 1 ? own_prev + pb : -INFINITY;
+          const float c = u < Ub ? prevbuf[u + 1] + py : -INFINITY;
           val = log_add(a, c);
         }
         beta[idx] = val;
@@ -168,8 +193,12 @@ __global__ void rnnt_scan_kernel(const float* __restrict__ lpb, const float* __r
       own_prev = val;
     }
     curbuf[u] = in ? val : -INFINITY;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this lane's hand-off is in LDS (global requests are NOT waited for)
+    __builtin_amdgcn_s_barrier();
     float* tmp = prevbuf; prevbuf = curbuf; curbuf = tmp;
+    pb = pb1; py = py1;
+    pb1 = pb2; py1 = py2;
+    pb2 = npb; py2 = npy;
   }
   if (dir == 1 && u == 0) loss[b] = -beta[base];  // beta(0,0) = log P(y|x)
 }
