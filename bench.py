@@ -405,6 +405,18 @@ def main(argv=None):
         dist.all_gather(each, tens)
         per_rank_ms = [float(t[0]) * 1e3 / args.steps for t in each]
         elapsed, audio = float(mx[0]), float(sm[1])
+    # hardware-queue probe verdicts of every rank (DESIGN section 0.7 of round 5: with a process group in the process HIP may deal
+    # a side stream onto the compute stream's queue; the probe rejects such candidates) — so that the first real multi-rank run
+    # shows per rank what was decided: [rejected candidates of the layer runtime's stream, unprobed flag, rejected per Python stream ...]
+    from espresso_amd import functional as F_
+    rep = F_.side_stream_probe_report()
+    probe = [[rep["layer_runtime"]["rejected"], int(rep["layer_runtime"]["unprobed"])] + [p["rejected"] for p in rep["python_streams"]]]
+    if world > 1:
+        row = torch.full((8,), -9.0, dtype=torch.float64, device=device)
+        row[: min(8, len(probe[0]))] = torch.tensor(probe[0][:8], dtype=torch.float64)
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        probe = [[int(v) for v in r.tolist() if v > -9.0] for r in rows]
     loss_stats = trainer._stats.clone()
 
     roofline = None
@@ -431,7 +443,7 @@ def main(argv=None):
         # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
         # command, tools/pmc_bench_traffic.sh; counters cannot be read from inside the process)
         traffic = None
-        tname = next((n for n in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
+        tname = next((n for n in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
                       if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n))), None)
         if tname:
             traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname))).get("hbm_bytes_per_launch")
@@ -512,7 +524,8 @@ def main(argv=None):
                        "last_loss_per_sentence": float(loss_stats[1] / max(1.0, float(loss_stats[0]))),
                        "host_enqueue_ms_per_step": host_enqueue * 1e3 / args.steps,
                        "host_enqueue_ms_fastest_step": host_step_min * 1e3,
-                       "per_rank_ms_per_step": per_rank_ms},
+                       "per_rank_ms_per_step": per_rank_ms,
+                       "side_stream_queue_probe_per_rank": probe},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "decode": decode,

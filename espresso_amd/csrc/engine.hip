@@ -141,6 +141,8 @@ extern "C" int ea_streams_share_queue(hipStream_t a, hipStream_t b) {
 }
 namespace {
 static const bool g_side_probe = [] { const char* e = getenv("EA_SIDE_STREAM_PROBE"); return !(e && e[0] == '0'); }();
+static int g_side_rejected = -1;   // candidates the probe turned down before one was accepted (-1: no side stream yet)
+static int g_side_unprobed = 0;    // 1: the accepted stream was NOT measured (probe switched off, or the eighth candidate)
 static bool side_stream_create(hipStream_t owner) {  // (current device = the owner's)
   hipStream_t rejected[8];
   int nrej = 0;
@@ -148,8 +150,11 @@ static bool side_stream_create(hipStream_t owner) {  // (current device = the ow
   for (int t = 0; t < 8; ++t) {
     hipStream_t cand = nullptr;
     if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
-    if (!g_side_probe || t == 7 || ea_streams_share_queue(owner, cand) != 1) {
+    const bool unprobed = !g_side_probe || t == 7;
+    if (unprobed || ea_streams_share_queue(owner, cand) != 1) {
       g_side.stream = cand;
+      g_side_rejected = nrej;
+      g_side_unprobed = unprobed ? 1 : 0;
       ok = true;
       break;
     }
@@ -1436,6 +1441,13 @@ int ea_decoder_layer_bwd(const EaDecoderLayer* layer, const EaLayerShape* shape,
 }
 
 }  // extern "C"
+
+// include/espresso_amd.h: what the hardware-queue probe decided for the layer runtime's side stream
+extern "C" int ea_side_stream_report(int* rejected, int* unprobed) {
+  if (rejected) *rejected = g_side_rejected;
+  if (unprobed) *unprobed = g_side_unprobed;
+  return g_side.ok ? 1 : 0;
+}
 
 // include/espresso_amd.h: seed of one dropout site of a layer call (EA_SITE_*), given EaLayerShape.seed
 extern "C" uint64_t ea_layer_dropout_seed(uint64_t layer_seed, int site) {

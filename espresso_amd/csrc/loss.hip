@@ -116,39 +116,51 @@ __global__ void ctc_scan_kernel(const float* __restrict__ G, const int* __restri
     buf0[s] = v;
     if (s < S) Ob[(long)t * Smax + s] = v;
   }
-  // the emission log-probabilities do not depend on the recursion: requested three frames ahead, and the barrier of a frame waits
+  // the emission log-probabilities do not depend on the recursion: requested four frames ahead, and the barrier of a frame waits
   // for the LDS hand-off only (round 6: __syncthreads() also drains the vector-memory counter, i.e. the prefetch AND the store of
   // the frame's row — a memory round trip per frame, 0.5 us, where the arithmetic needs 0.15)
-  auto fetch = [&](int it) -> float {
-    return (it < Tb && s < S) ? Gb[(long)(dir ? Tb - 1 - it : it) * Smax + s] : -INFINITY;
-  };
-  float lp1 = fetch(1), lp2 = fetch(2), lp3 = fetch(3);
+  // Branch-free loop body: every lane loads and stores on every frame (clamped addresses, the value selected afterwards) — with a
+  // load or store inside a divergent branch hipcc's wait-count pass loses the count and waits for vmcnt(0), i.e. for the request
+  // it has just issued.  Lanes s >= S keep -inf and store nothing.
+  const long gstep = (long)step * Smax;
+  const int sc = s < S ? s : (S - 1);
+  const int so = s < S ? s : (S - 1);
+  const float* g0 = Gb + (long)t * Smax + sc;   // row of frame `it` = g0 + it * gstep
+  auto row = [&](int it) { return g0 + (long)(it < Tb ? it : Tb - 1) * gstep; };
+  float* op = Ob + (long)t * Smax + so;
+  const bool live = s < S;
   __syncthreads();
   float* rd = buf0;
   float* wr = buf1;
   const int o1 = dir ? 1 : -1, o2 = dir ? 2 : -2;
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-  for (int it = 1; it < Tb; ++it) {
-    t += step;
-    const float lp = lp1;
-    lp1 = lp2;
-    lp2 = lp3;
-    lp3 = fetch(it + 3);
-    float v = -INFINITY;
-    if (s < S) {
-      const float a0 = rd[s];
-      const float a1 = rd[s + o1];
-      const float a2 = skip ? rd[s + o2] : -INFINITY;
-      const float m = fmaxf(a0, fmaxf(a1, a2));
-      if (m > -INFINITY)
-        v = m + LN2 * __builtin_amdgcn_logf(__builtin_amdgcn_exp2f((a0 - m) * LOG2E) + __builtin_amdgcn_exp2f((a1 - m) * LOG2E) +
-                                            __builtin_amdgcn_exp2f((a2 - m) * LOG2E)) + lp;
-      Ob[(long)t * Smax + s] = v;
-    }
+  // four registers, one per frame modulo 4, each refilled right after use with the row four frames on (no register rotation:
+  // copying a register whose load is pending is a wait for that load)
+  auto frame = [&](int it, float& q) {
+    if (it >= Tb) return;  // (uniform)
+    const float lp = q;
+    q = *row(it + 4);
+    op += gstep;
+    const float a0 = rd[s];
+    const float a1 = rd[s + o1];
+    const float a2 = skip ? rd[s + o2] : -INFINITY;
+    const float m = fmaxf(a0, fmaxf(a1, a2));
+    const float mm = m > -INFINITY ? m : 0.f;
+    float v = mm + LN2 * __builtin_amdgcn_logf(__builtin_amdgcn_exp2f((a0 - mm) * LOG2E) + __builtin_amdgcn_exp2f((a1 - mm) * LOG2E) +
+                                               __builtin_amdgcn_exp2f((a2 - mm) * LOG2E)) + lp;
+    v = (live && m > -INFINITY) ? v : -INFINITY;
+    if (live) *op = v;  // (a store under a branch only makes the wait-count pass assume it was issued: the loads stay counted)
     wr[s] = v;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this lane's hand-off is in LDS (global requests stay in flight)
     __builtin_amdgcn_s_barrier();
     float* tmp = rd; rd = wr; wr = tmp;
+  };
+  float q1 = *row(1), q2 = *row(2), q3 = *row(3), q4 = *row(4);
+  for (int it = 1; it < Tb; it += 4) {
+    frame(it, q1);
+    frame(it + 1, q2);
+    frame(it + 2, q3);
+    frame(it + 3, q4);
   }
   __syncthreads();
   if (threadIdx.x == 0 && dir == 0) {

@@ -141,64 +141,66 @@ __global__ void rnnt_scan_kernel(const float* __restrict__ lpb, const float* __r
   prevbuf[u] = -INFINITY;
   if (u == 0) { prevbuf[-1] = -INFINITY; curbuf[-1] = -INFINITY; prevbuf[UP] = -INFINITY; curbuf[UP] = -INFINITY; }
   __syncthreads();
-  // the two log-probabilities a cell needs do not depend on the recursion: they are requested THREE DIAGONALS AHEAD (round 6 —
+  // the two log-probabilities a cell needs do not depend on the recursion: they are requested FOUR DIAGONALS AHEAD (round 6 —
   // loaded where they were used, every diagonal paid a memory round trip inside the dependent chain: 0.5 - 0.65 ms per batch at
   // the recipe's lattices, with only B workgroups on the device); the barrier below waits for the LDS hand-off only, so that the
   // requests stay in flight across it
+  // (every lane loads on every diagonal from a clamped cell, the value is selected afterwards: a load inside a divergent branch makes
+  // hipcc's wait-count pass fall back to vmcnt(0), i.e. to waiting for the request it has just issued)
+  const int uc = u <= Ub ? u : Ub;
   auto fetch = [&](int k, float& pb, float& py) {
-    pb = py = -INFINITY;
-    if (k >= ndiag) return;
-    const int d = dir ? (ndiag - 1 - k) : k;
-    const int t = d - u;
-    if (!(u <= Ub && t >= 0 && t < Tb)) return;
-    const long idx = base + (long)t * U1 + u;
+    const int kk = k < ndiag ? k : ndiag - 1;
+    const int d = dir ? (ndiag - 1 - kk) : kk;
+    int t = d - uc;
+    t = t < 0 ? 0 : (t > Tb - 1 ? Tb - 1 : t);
+    const long idx = base + t * U1 + uc;
     if (!dir) {
-      if (t > 0) pb = lpb[idx - U1];   // from (t-1,u) by blank
-      if (u > 0) py = lpy[idx - 1];    // from (t,u-1) by label
+      pb = lpb[t > 0 ? idx - U1 : idx];   // from (t-1,u) by blank
+      py = lpy[uc > 0 ? idx - 1 : idx];   // from (t,u-1) by label
     } else {
-      pb = lpb[idx];                   // to (t+1,u) by blank — or the final blank at (Tb-1, Ub)
-      if (u < Ub) py = lpy[idx];       // to (t,u+1) by label
+      pb = lpb[idx];                      // to (t+1,u) by blank — or the final blank at (Tb-1, Ub)
+      py = lpy[idx];                      // to (t,u+1) by label
     }
   };
-  float pb, py, pb1, py1, pb2, py2;
-  fetch(0, pb, py);
-  fetch(1, pb1, py1);
-  fetch(2, pb2, py2);
-  for (int k = 0; k < ndiag; ++k) {
-    float npb, npy;
-    fetch(k + 3, npb, npy);
+  // four register pairs, one per diagonal modulo 4, refilled right after use with the pair of diagonal k + 4 — no register rotation:
+  // copying a register whose load is pending is a wait for that load
+  auto step = [&](int k, float& qb, float& qy) {
+    if (k >= ndiag) return;  // (uniform)
+    const float pb = qb, py = qy;
+    fetch(k + 4, qb, qy);
     const int d = dir ? (ndiag - 1 - k) : k;
     const int t = d - u;
-    float val = -INFINITY;
     const bool in = u <= Ub && t >= 0 && t < Tb;
+    float val;
+    if (!dir) {
+      const float a = t > 0 ? own_prev + pb : -INFINITY;
+      const float c = u > 0 ? prevbuf[u - 1] + py : -INFINITY;
+      val = (t == 0 && u == 0) ? 0.f : log_add(a, c);
+    } else {
+      const float a = t < Tb - 1 ? own_prev + pb : -INFINITY;
+      const float c = u < Ub ? prevbuf[u + 1] + py : -INFINITY;
+      val = (t == Tb - 1 && u == Ub) ? pb : log_add(a, c);
+    }
+    val = in ? val : -INFINITY;
     if (in) {
-      const long idx = base + (long)t * U1 + u;
-      if (!dir) {
-        if (t == 0 && u == 0) val = 0.f;
-        else {
-          const float a = t > 0 ? own_prev + pb : -INFINITY;
-          const float c = u > 0 ? prevbuf[u - 1] + py : -INFINITY;
-          val = log_add(a, c);
-        }
-        alpha[idx] = val;
-      } else {
-        if (t == Tb - 1 && u == Ub) val = pb;
-        else {
-          const float a = t < Tb - 1 ? own_prev + pb : -INFINITY;
-          const float c = u < Ub ? prevbuf[u + 1] + py : -INFINITY;
-          val = log_add(a, c);
-        }
-        beta[idx] = val;
-      }
+      (dir ? beta : alpha)[base + (long)t * U1 + u] = val;
       own_prev = val;
     }
-    curbuf[u] = in ? val : -INFINITY;
+    curbuf[u] = val;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this lane's hand-off is in LDS (global requests are NOT waited for)
     __builtin_amdgcn_s_barrier();
     float* tmp = prevbuf; prevbuf = curbuf; curbuf = tmp;
-    pb = pb1; py = py1;
-    pb1 = pb2; py1 = py2;
-    pb2 = npb; py2 = npy;
+  };
+  float b0, y0, b1, y1, b2, y2, b3, y3;
+  fetch(0, b0, y0);
+  fetch(1, b1, y1);
+  fetch(2, b2, y2);
+  fetch(3, b3, y3);
+  for (int k = 0; k < ndiag; k += 4) {
+    step(k, b0, y0);
+    step(k + 1, b1, y1);
+    step(k + 2, b2, y2);
+    step(k + 3, b3, y3);
   }
   if (dir == 1 && u == 0) loss[b] = -beta[base];  // beta(0,0) = log P(y|x)
 }

@@ -246,17 +246,36 @@ def new_side_stream(device):
     kernel on the current stream.  Blocks the host once, at set-up."""
     st = torch.cuda.Stream(device=device)
     if os.environ.get("EA_SIDE_STREAM_PROBE", "1") == "0":
+        _probe_log.append({"rejected": 0, "unprobed": True})
         return st
     from . import _lib
 
     cur = torch.cuda.current_stream(device)
     lib = _lib.lib()
+    rejected, unprobed = 0, True
     with torch.cuda.device(device):
         for _ in range(7):
             if lib.ea_streams_share_queue(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(st.cuda_stream)) != 1:
+                unprobed = False
                 break
+            rejected += 1
             st = torch.cuda.Stream(device=device)
+    _probe_log.append({"rejected": rejected, "unprobed": unprobed})
     return st
+
+
+_probe_log = []  # one verdict per stream `new_side_stream` handed out
+
+
+def side_stream_probe_report():
+    """What the hardware-queue probe decided in this process: the layer runtime's side stream (csrc/engine.hip) and every stream
+    `new_side_stream` created (Python-composed backward, transducer branches, the data-parallel communication stream)."""
+    from . import _lib
+
+    rej, unp = ctypes.c_int(-1), ctypes.c_int(0)
+    have = _lib.lib().ea_side_stream_report(ctypes.byref(rej), ctypes.byref(unp))
+    return {"layer_runtime": {"created": bool(have), "rejected": rej.value, "unprobed": bool(unp.value)},
+            "python_streams": list(_probe_log)}
 
 
 def _side_stream(device):

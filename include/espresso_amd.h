@@ -522,6 +522,11 @@ int ea_backward_flush(ea_stream_t stream);
  * that create their own side streams can do the same.  Blocks the host until `a` reaches the probe; EA_SIDE_STREAM_PROBE=0
  * disables the runtime's own use of it. */
 int ea_streams_share_queue(ea_stream_t a, ea_stream_t b);
+/* What the probe decided for the layer runtime's own side stream (created by the first backward call): returns 1 when the stream
+ * exists; *rejected = candidate streams that shared the caller's hardware queue and were turned down (-1: none created yet),
+ * *unprobed = 1 when the accepted stream was not measured (EA_SIDE_STREAM_PROBE=0, or the eighth candidate).  Reported per rank in
+ * the bench line: on a multi-rank job RCCL's streams change how HIP deals queues, so every rank's verdict should be visible. */
+int ea_side_stream_report(int* rejected, int* unprobed);
 int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
                            const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
