@@ -405,7 +405,7 @@ def main(argv=None):
         dist.all_gather(each, tens)
         per_rank_ms = [float(t[0]) * 1e3 / args.steps for t in each]
         elapsed, audio = float(mx[0]), float(sm[1])
-    # hardware-queue probe verdicts of every rank (DESIGN section 0.7 of round 5: with a process group in the process HIP may deal
+    # hardware-queue probe verdicts of every rank (with a process group in the process HIP may deal
     # a side stream onto the compute stream's queue; the probe rejects such candidates) — so that the first real multi-rank run
     # shows per rank what was decided: [rejected candidates of the layer runtime's stream, unprobed flag, rejected per Python stream ...]
     from espresso_amd import functional as F_

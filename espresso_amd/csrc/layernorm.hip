@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int rows_per_block,
     const uint8_t* __restrict__ row_zero, uint64_t seed, uint32_t thr, float inv_keep,
-    const bf16_t* __restrict__ dx_add, float* __restrict__ partial, const LnOut2 o2) {
+    const bf16_t* __restrict__ dx_add, float* __restrict__ partial, const LnOut2 o2, const int two_rows) {
   extern __shared__ float red[];  // [4][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
@@ -234,39 +234,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   const float inv_c = __builtin_amdgcn_rcpf((float)C);
-  for (int row = r0 + wave; row < r1; row += 4) {
-    // every load of the row is requested up front — the residual-path gradient too, which used to be fetched only after the two
-    // wave reductions (a second exposed round trip per row), and the padding flag last (its first use is a branch: a wait)
-    uint4 ux_[MAXC8], ua_[MAXC8];
-    float dy_[MAXC8][8];
+  struct RowIn {
+    uint4 ux[MAXC8], ua[MAXC8];
+    float dy[MAXC8][8];
+    float mean, rstd;
+    bool zero;
+  };
+  // every load of the row is requested up front — the residual-path gradient too, which used to be fetched only after the two
+  // wave reductions (a second exposed round trip per row), and the padding flag last (its first use is a branch: a wait)
+  auto load_row = [&](int row, RowIn& r) {
 #pragma unroll
     for (int i = 0; i < MAXC8; ++i) {
       const int ch = lane + 64 * i;
-      ux_[i] = ua_[i] = uint4{0, 0, 0, 0};
+      r.ux[i] = r.ua[i] = uint4{0, 0, 0, 0};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dy_[i][e] = 0.f;
+      for (int e = 0; e < 8; ++e) r.dy[i][e] = 0.f;
       if (ch < nch) {
-        ux_[i] = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
-        load8(dy + (long)row * C + ch * 8, dy_[i]);
-        if (dx_add) ua_[i] = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
+        r.ux[i] = *reinterpret_cast<const uint4*>(x + (long)row * C + ch * 8);
+        load8(dy + (long)row * C + ch * 8, r.dy[i]);
+        if (dx_add) r.ua[i] = *reinterpret_cast<const uint4*>(dx_add + (long)row * C + ch * 8);
       }
     }
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const bool zero = row_zero && row_zero[row];
+    r.mean = mean_in[row];
+    r.rstd = rstd_in[row];
+    r.zero = row_zero && row_zero[row];
+  };
+  auto process_row = [&](int row, const RowIn& r) {
+    const float mean = r.mean, rstd = r.rstd;
+    const bool zero = r.zero;
     float xh[MAXC8][8], g[MAXC8][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC8; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
-        const uint4 ux = ux_[i];
+        const uint4 ux = r.ux[i];
         const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
         float k8[8];
         if (thr) ea_keep8(seed, (uint64_t)row * C + ch * 8, thr, inv_keep, k8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
-          float dv = dy_[i][e];
+          float dv = r.dy[i][e];
           if (zero) dv = 0.f;
           if (thr) dv *= k8[e];
           const float h = (xv - mean) * rstd;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
         if (dx_add) {
-          const uint4 ua = ua_[i];
+          const uint4 ua = r.ua[i];
           const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -319,6 +328,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
           *reinterpret_cast<uint4*>(o2.out + (long)row * C + ch * 8) = u2;
         }
       }
+    }
+  };
+  if (MAXC8 == 1 && two_rows) {
+    // C <= 512: a wavefront's two rows of the block (r, r + 4) are in flight TOGETHER (round 6; the forward kernel's lesson,
+    // ln_fwd_rows_kernel): one after the other, each row was a dependent load -> reduce -> reduce -> store chain, 11.5 us for the
+    // recipe's 6 240 x 512 rows.  The rows are still accumulated in the same order: dgamma / dbeta partials are bit-identical.
+    for (int row = r0 + wave; row < r1; row += 8) {
+      RowIn ra, rb;
+      const bool two = row + 4 < r1;  // (uniform)
+      load_row(row, ra);
+      if (two) load_row(row + 4, rb);
+      process_row(row, ra);
+      if (two) process_row(row + 4, rb);
+    }
+  } else {
+    for (int row = r0 + wave; row < r1; row += 4) {
+      RowIn ra;
+      load_row(row, ra);
+      process_row(row, ra);
     }
   }
   // cross-wave reduction of dgamma/dbeta
@@ -464,11 +492,12 @@ static int ln_bwd_launch(const void* x, const void* dy, const float* gamma, cons
   if (C % 8 != 0 || C > 64 * 8 * MAXC8_LIMIT) return -2;
   const int rpb = ln_bwd_rows_per_block(M, workspace != nullptr);
   const int nblk = (M + rpb - 1) / rpb;
+  static const int two_rows = [] { const char* e = getenv("EA_LN_BWD_TWO_ROWS"); return e ? atoi(e) : 1; }();  // (diagnostic A/B switch)
   if (dy_f32) {
 #define EA_LN_BWD32(NC)                                                                                                \
   hipLaunchKernelGGL((ln_bwd_kernel<NC, float>), dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,         \
                      (const bf16_t*)x, (const float*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, C, rpb,     \
-                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace, o2)
+                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace, o2, two_rows)
     if (C <= 512) EA_LN_BWD32(1);
     else if (C <= 1024) EA_LN_BWD32(2);
     else EA_LN_BWD32(4);
@@ -479,7 +508,7 @@ static int ln_bwd_launch(const void* x, const void* dy, const float* gamma, cons
 #define EA_LN_BWD(NC)                                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<NC>), dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), stream,                \
                      (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, C, rpb,    \
-                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace, o2)
+                     row_zero, drop_seed, drop_thr, drop_scale, (const bf16_t*)dx_add, (float*)workspace, o2, two_rows)
   if (C <= 512) EA_LN_BWD(1);
   else if (C <= 1024) EA_LN_BWD(2);
   else EA_LN_BWD(4);
