@@ -261,9 +261,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16_t* __
       const int c = ch * 8 + e;
       mu[e] = mean_rstd[c]; rs[e] = mean_rstd[C + c]; ga[e] = gamma[c]; be[e] = beta[c];
     }
-    for (long m = r0 + ry; m < r1; m += lanes) {
-      const uint4 uz = *reinterpret_cast<const uint4*>(Z + m * C + ch * 8);
-      const uint4 ud = *reinterpret_cast<const uint4*>(dH + m * C + ch * 8);
+    auto accum = [&](const uint4& uz, const uint4& ud) {
       const uint32_t wz[4] = {uz.x, uz.y, uz.z, uz.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -275,6 +273,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16_t* __
         sa[e] += d;
         sb[e] += d * xh;
       }
+    };
+    // four of the thread's rows are requested together (round 6): one row per trip was a dependent 16-byte-load round trip per
+    // row — 8 trips, 16.7 us for the Conformer layer's 6 240 x 512 rows (0.8 TB/s); same accumulation order, same bits
+    constexpr int R = 4;
+    long m = r0 + ry;
+    for (; m + (long)(R - 1) * lanes < r1; m += (long)R * lanes) {
+      uint4 uz[R], ud[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        uz[r] = *reinterpret_cast<const uint4*>(Z + (m + (long)r * lanes) * C + ch * 8);
+        ud[r] = *reinterpret_cast<const uint4*>(dH + (m + (long)r * lanes) * C + ch * 8);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) accum(uz[r], ud[r]);
+    }
+    for (; m < r1; m += lanes) {
+      const uint4 uz = *reinterpret_cast<const uint4*>(Z + m * C + ch * 8);
+      const uint4 ud = *reinterpret_cast<const uint4*>(dH + m * C + ch * 8);
+      accum(uz, ud);
     }
   }
   float* mine = sm + ((long)ry * TCH + cx) * 16;
@@ -353,6 +370,20 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
   const int c0 = blockIdx.x * CT, t0 = blockIdx.y * TTILE, b = blockIdx.z;
   const long rowbase = (long)b * T;
   const bool vec = (C & 7) == 0;
+  // the GLU operands of this thread's TPT outputs are requested FIRST (round 6): loaded in the output loop at the end they were
+  // TPT dependent round trips per thread (load -> multiply -> store, one after the other): 23 us for 6 240 x 512 rows
+  bf16_t ya[TPT], yg[TPT];
+  {
+    const int cl0 = threadIdx.x & (CT - 1), grp0 = threadIdx.x >> 6;
+    const int cc = min(c0 + cl0, C - 1);
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+      const int tout = min(t0 + grp0 * TPT + j, T - 1);
+      const bf16_t* yr = Y + (rowbase + tout) * (2L * C);
+      ya[j] = yr[cc];
+      yg[j] = yr[C + cc];
+    }
+  }
   for (int i = threadIdx.x; i < ROWS * (CT / 8); i += 256) {
     const int row = i / (CT / 8), c8 = (i % (CT / 8)) * 8;
     const int tin = t0 - PAD + row;
@@ -400,9 +431,8 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
   for (int j = 0; j < TPT; ++j) {
     const int tout = t0 + grp * TPT + j;
     if (tout < T && c < C) {
-      const bf16_t* yr = Y + (rowbase + tout) * (2L * C);
-      const float a = bf2f(yr[c]);
-      const float sg = sigmoid_f(bf2f(yr[C + c]));
+      const float a = bf2f(ya[j]);
+      const float sg = sigmoid_f(bf2f(yg[j]));
       bf16_t* dyr = dY + (rowbase + tout) * (2L * C);
       dyr[c] = f2bf(acc[j] * sg);
       dyr[C + c] = f2bf(acc[j] * a * sg * (1.f - sg));
@@ -630,6 +660,7 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_wgrad_kernel(const float* __
   const int li = lane & 15, g4 = lane >> 4;
   const float invn = n > 0.f ? 1.f / n : 0.f;
   const long nblk = (npos + 31) / 32;
+  const long bmax = (npos - 1) / ((long)Fo * To);  // last utterance index (address clamp of the tap loads)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(&tile[wave][0]);
   for (int cs = 0; cs < CO; cs += 64) {
     // staging role: lane owns channels cs + 8 * (lane & 7) .. + 7 of positions (lane >> 3) + 8 * it
@@ -646,15 +677,43 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_wgrad_kernel(const float* __
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
       const long pb = blk * 32;
+      // ---- every load of the block is requested first, branch-free (clamped addresses, values selected afterwards): round 6.
+      // With the loads inside `if (p < npos)` / the tap tests, hipcc waited for each of the twelve in turn (vmcnt(0) after a
+      // divergent branch): ~15 us per 8 KB block and wavefront, 2.4 TB/s for the whole kernel with 16 wavefronts per CU.
+      uint4 uz4[4], ud4[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const long p = min(pb + prow + 8 * it, npos - 1);
+        uz4[it] = *reinterpret_cast<const uint4*>(Z + p * CO + cs + c8 * 8);
+        ud4[it] = *reinterpret_cast<const uint4*>(dH + p * CO + cs + c8 * 8);
+      }
+      int fo = (int)(pb % Fo), to = (int)((pb / Fo) % To);  // wave-uniform
+      long b = pb / ((long)Fo * To);
+      float xs[8];
+      bool xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g4 + j;
+        int f = fo + k, t = to;
+        long bb = b;
+        while (f >= Fo) { f -= Fo; ++t; }
+        while (t >= To) { t -= To; ++bb; }
+        const int tap = li < 9 ? li : 0;
+        const int ti = t * sy + tap / 3 - 1, fi = f * sx + tap % 3 - 1;
+        xv[j] = pb + k < npos && li < 9 && ti >= 0 && ti < T && fi >= 0 && fi < F;
+        // (a clamped, always valid address: its value is dropped when !xv[j])
+        const int tc = min(max(ti, 0), T - 1), fc = min(max(fi, 0), F - 1);
+        const long bc = bb < bmax ? bb : bmax;
+        xs[j] = X[(bc * T + tc) * F + fc];
+      }
       // ---- dZ of 32 positions x 64 channels -> LDS (bf16, as stored before) ----
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = prow + 8 * it;
         const long p = pb + r;
         uint4 o = make_uint4(0, 0, 0, 0);
-        if (p < npos) {
-          const uint4 uz = *reinterpret_cast<const uint4*>(Z + p * CO + cs + c8 * 8);
-          const uint4 ud = *reinterpret_cast<const uint4*>(dH + p * CO + cs + c8 * 8);
+        {
+          const uint4 uz = uz4[it], ud = ud4[it];
           const uint32_t wz[4] = {uz.x, uz.y, uz.z, uz.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
           float d[8];
 #pragma unroll
@@ -668,28 +727,16 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_wgrad_kernel(const float* __
           }
           o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);
         }
+        if (p >= npos) o = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(&tile[wave][r * 128 + (((c8 >> 1) ^ c1_sw(r)) << 5) + (c8 & 1) * 16]) = o;
       }
       // ---- B operand: X tap values of (position 8 g4 + j, column li) as bf16 hi / lo ----
-      int fo = (int)(pb % Fo), to = (int)((pb / Fo) % To);  // wave-uniform
-      long b = pb / ((long)Fo * To);
       uint32_t bh[4], bl[4];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = 8 * g4 + j;
-        int f = fo + k, t = to;
-        long bb = b;
-        while (f >= Fo) { f -= Fo; ++t; }
-        while (t >= To) { t -= To; ++bb; }
-        float x = 0.f;
-        if (pb + k < npos) {
-          if (li < 9) {
-            const int ti = t * sy + li / 3 - 1, fi = f * sx + li % 3 - 1;
-            if (ti >= 0 && ti < T && fi >= 0 && fi < F) x = X[(bb * T + ti) * F + fi];
-          } else if (li == 9) {
-            x = 1.f;
-          }
-        }
+        float x = xv[j] ? xs[j] : 0.f;
+        if (li == 9 && pb + k < npos) x = 1.f;
         const uint32_t hi = (uint32_t)f2bf(x);
         const uint32_t lo = (uint32_t)f2bf(x - __uint_as_float(hi << 16));
         if (j & 1) { bh[j >> 1] |= hi << 16; bl[j >> 1] |= lo << 16; }
