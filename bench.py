@@ -493,7 +493,11 @@ def main(argv=None):
         # emitted tokens per audio second against ~4.5 for a trained model — tools/bench_transducer_decode.py)
         # ingest: the same update step fed by speech_train.py's data path from 2 048 WAV files on local disk
         # (tools/bench_ingest.py) next to the same batches resident in HBM
-        for key, script in (("ingest", ["bench_ingest.py"]), ("config2_encdec", ["bench_encdec.py"]), ("config4_transducer", ["bench_transducer.py"]),
+        # ingest_flac (round 6): the same from FLAC files — LibriSpeech's container — decoded by csrc/ingest.hip (512 files encoded by
+        # the test-only encoder tests/flac_encode.py on the host's cores first; 24 + 6 steps)
+        for key, script in (("ingest", ["bench_ingest.py"]),
+                            ("ingest_flac", ["bench_ingest.py", "--format", "flac", "--files", "512", "--steps", "24", "--warmup", "6"]),
+                            ("config2_encdec", ["bench_encdec.py"]), ("config4_transducer", ["bench_transducer.py"]),
                             ("f3_transducer_beam_search", ["bench_transducer_decode.py", "--beam-only", "--all-utts", "--batches", "18"])):
             try:
                 out = subprocess.run([sys.executable, os.path.join(here, "tools", script[0])] + script[1:], capture_output=True, text=True,
