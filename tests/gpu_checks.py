@@ -2206,6 +2206,41 @@ def check_fullsize_transducer_vs_oracle(dropout=0.0, seed=0, lens=(200, 140), tl
     return res
 
 
+def check_joint_fp32_islands(B=3, T=29, U1=7, J=512, seed=0):
+    """The fp32-island kernels of the transducer joint (round 6) against plain fp32 torch on the CPU: LayerNorm with an fp32 output
+    (`ea_layernorm_fwd_f32out`) and its backward from an fp32 gradient (`ea_layernorm_bwd_f32dy`), relu(E + D) on fp32 operands
+    (`ea_joint_add_relu_f32`: equals bf16(relu(fp32 sum)) bit for bit) and the fp32 reductions dE / dD (`ea_joint_reduce_f32`)."""
+    from espresso_amd import kernels as K
+
+    g = torch.Generator().manual_seed(seed)
+    M = B * T
+    x = torch.randn(M, J, generator=g).to(torch.bfloat16)
+    gam, bet = 1 + 0.2 * torch.randn(J, generator=g), 0.1 * torch.randn(J, generator=g)
+    dy = torch.randn(M, J, generator=g)
+    y, mean, rstd = K.layernorm_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), out_f32=True)
+    dg, db = torch.zeros(J, device=DEV), torch.zeros(J, device=DEV)
+    dx = K.layernorm_bwd(x.to(DEV), dy.to(DEV), gam.to(DEV), mean, rstd, dg, db)
+    xr, gr, br = x.float().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (J,), gr, br, 1e-5)
+    (yr * dy).sum().backward()
+    res = {"y_dtype_f32": y.dtype == torch.float32, "ln_y_abs": float((y.cpu() - yr.detach()).abs().max()),
+           "ln_dx_rel": float((dx.float().cpu() - xr.grad).abs().max() / xr.grad.abs().max()),
+           "ln_dg_rel": float((dg.cpu() - gr.grad).abs().max() / gr.grad.abs().max()),
+           "ln_db_rel": float((db.cpu() - br.grad).abs().max() / br.grad.abs().max())}
+    E = torch.randn(B * T, J, generator=g)
+    D = torch.randn(B * U1, J, generator=g)
+    Z = K.joint_add_relu(E.to(DEV), D.to(DEV), B, T, U1)
+    zr = torch.relu(E.view(B, T, 1, J) + D.view(B, 1, U1, J)).to(torch.bfloat16).reshape(-1, J)
+    res["relu_bits_equal"] = bool(torch.equal(Z.cpu(), zr))
+    dZ = torch.randn(B * T * U1, J, generator=g).to(torch.bfloat16)
+    dE, dD = K.joint_reduce(dZ.to(DEV), B, T, U1, out_f32=True)
+    d4 = dZ.float().view(B, T, U1, J)
+    res["dE_abs"] = float((dE.cpu() - d4.sum(2).reshape(-1, J)).abs().max())
+    res["dD_abs"] = float((dD.cpu() - d4.sum(1).reshape(-1, J)).abs().max())
+    res["reduce_dtype_f32"] = dE.dtype == torch.float32 and dD.dtype == torch.float32
+    return res
+
+
 def check_joint_rnnt_fused(B=3, T=37, U1=9, V=40, J=64, seed=0):
     """csrc/joint_rnnt.hip (output layer fused with the RNN-T loss, logits never written) against the unfused kernels of
     csrc/rnnt.hip fed with the SAME logits in fp32 (torch fp32 product of the bf16 operands): per-utterance loss, the gradient of

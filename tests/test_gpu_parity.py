@@ -540,6 +540,17 @@ def test_lstm_persistent_kernels_vs_stepwise_path(shape):
         assert v < 1e-2, (k, r)
 
 
+def test_joint_fp32_island_kernels():
+    """the joint's LayerNorm outputs, their sum, the ReLU and dE / dD in fp32 (the reference's autocast run)"""
+    r = G.check_joint_fp32_islands()
+    print(r)
+    assert r["y_dtype_f32"] and r["reduce_dtype_f32"] and r["relu_bits_equal"], r
+    assert r["ln_y_abs"] < 2e-5, r                                   # fp32 output: no bf16 rounding of LayerNorm's result
+    assert r["ln_dx_rel"] < 6e-3, r                                  # dx is stored in bf16
+    assert r["ln_dg_rel"] < 1e-4 and r["ln_db_rel"] < 1e-4, r
+    assert r["dE_abs"] < 1e-4 and r["dD_abs"] < 1e-4, r              # fp32 sums of bf16 terms
+
+
 @pytest.mark.parametrize("shape", [(3, 37, 9, 40, 64), (2, 23, 7, 300, 128), (2, 50, 12, 5004, 512), (1, 300, 3, 5004, 512)])
 def test_joint_rnnt_fused_vs_unfused_kernels(shape):
     """Round 6 (VERDICT r5 missing 1): the joint's output layer fused with the RNN-T loss — the (B, T', U+1, V) logits never reach
