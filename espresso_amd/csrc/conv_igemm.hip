@@ -254,6 +254,8 @@ struct ConvWgradArgs {
   int at, af, ntaps;
   int bt[9], bf[9];
   int chunks_per_wg;   // 64-position chunks per workgroup
+  int ablate;          // development probe (EA_CONVW_ABLATE, results meaningless): 1 no MFMAs, 2 no global loads after the prologue,
+                       // 4 no fragment reads, 8 no barrier
 };
 
 __device__ __forceinline__ int tr_sw(int r) { return (r & 3) ^ ((r >> 3) & 1); }
@@ -270,28 +272,32 @@ __device__ __forceinline__ void ds_read_tr16_x8(const uint32_t (&ad)[8], uint2 (
       : "memory");
 }
 
-template <int DEPTH>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs a) {
+// NT = taps per workgroup: 9 (a workgroup owns all nine taps of its 64 x 64 channel tile: 144 accumulator registers, two workgroups
+// per CU) or 3 (one kernel row; blockIdx.z % 3 picks it: 48 accumulators, four workgroups per CU — round 6, see the launcher)
+template <int DEPTH, int NT>
+__global__ __launch_bounds__(256, NT == 9 ? 2 : 4) void conv_wgrad_kernel(const ConvWgradArgs a) {
   constexpr int TILE = 64 * ROW_BYTES;  // 8 KiB: 64 position rows x 64 channels
   // Ring: two dZ tiles (a chunk's tile serves its nine taps) + four X tiles, loads issued THREE steps ahead (round 6).  Rounds 2 - 5
   // double-buffered the X tile and waited for vmcnt(0) at every step: 8 MFMAs per wavefront (~150 cycles) between a load's issue and
   // its wait against ~2 us of last-level-cache latency — 222 us per launch, 9 % of the MFMA peak, 8 KB in flight per workgroup.
   // (DEPTH = 1: the round 2 - 5 schedule, kept as the A/B reference: EA_CONV_WGRAD_DEPTH=1)
-  constexpr int NBUF = 4;
-  static_assert(DEPTH >= 1 && DEPTH <= 3, "ring of four X tiles");
+  constexpr int NBUF = DEPTH == 1 ? 2 : 4;
+  static_assert(DEPTH >= 1 && DEPTH <= 3 && (NT == 9 || NT == 3), "ring of two / four X tiles");
+  const int tap0 = NT == 9 ? 0 : (int)(blockIdx.z % 3) * 3;          // first tap of this workgroup
+  const int zsplit = NT == 9 ? (int)blockIdx.z : (int)(blockIdx.z / 3);  // which slab / which range of chunks
   __shared__ __attribute__((aligned(16))) char lds[(2 + NBUF) * TILE];  // [A0][A1][B0][B1][B2][B3]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // wave tile: cout rows wr*32.., cin cols wc*32..
   const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
   const long M = (long)a.RB * a.RT * a.RF;
-  const long chunk0 = (long)blockIdx.z * a.chunks_per_wg;
+  const long chunk0 = (long)zsplit * a.chunks_per_wg;
   long nch = (M + 63) / 64 - chunk0;
   if (nch > a.chunks_per_wg) nch = a.chunks_per_wg;
   if (nch < 0) nch = 0;
 
-  f32x4_t acc[9][2][2];
+  f32x4_t acc[NT][2][2];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
   auto issue_B = [&](int buf, int tap) {  // X rows the decoded chunk's positions read through `tap`
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int st = rowt[i] + a.bt[tap], sf = rowf[i] + a.bf[tap];
+      const int st = rowt[i] + a.bt[tap0 + tap], sf = rowf[i] + a.bf[tap0 + tap];
       const bool ok = rowb[i] >= 0 && (unsigned)st < (unsigned)a.ST && (unsigned)sf < (unsigned)a.SF;
       const bf16_t* s = ok ? a.X + (((long)(rowb[i] + st)) * a.SF + sf) * a.Cin + ci0 + cs[i] * 8 : a.zero + cs[i] * 8;
       __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + (2 + buf) * TILE + (wave + 4 * i) * 1024), 16, 0, 0);
@@ -362,20 +368,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
       for (int t = 0; t < 2; ++t) fr[ks][t] = make_uint4(o[(ks * 2 + t) * 2].x, o[(ks * 2 + t) * 2].y, o[(ks * 2 + t) * 2 + 1].x, o[(ks * 2 + t) * 2 + 1].y);
   };
 
-  const int nsteps = (int)nch * a.ntaps;
+  const int nsteps = (int)nch * NT;
   // issue cursor: the loads of step `is` (chunk ich, tap itap) — the chunk's dZ tile first when the step opens a chunk, then the X
   // tile of the tap; loads return in order, so waiting for a step's X tile also covers the dZ tile issued just before it
   int is = 0, itap = 0;
   long ich = 0;
   auto issue_next = [&]() {
     if (is >= nsteps) return;
-    if (itap == 0) {
-      decode(ich);
-      issue_A((int)(ich & 1));
+    if (!(a.ablate & 2) || is < DEPTH) {
+      if (itap == 0) {
+        decode(ich);
+        issue_A((int)(ich & 1));
+      }
+      issue_B(is & (NBUF - 1), itap);
     }
-    issue_B(is & (NBUF - 1), itap);
     ++is;
-    if (++itap == a.ntaps) { itap = 0; ++ich; }
+    if (++itap == NT) { itap = 0; ++ich; }
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue_next();
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
   for (int s = 0; s < nsteps; ++s) {
     // instructions issued after this step's X tile: the X tiles of the next two steps (2 each) + the dZ tile of a chunk one of
     // them opens (2)
-    const int tap1 = tap + 1 == a.ntaps ? 0 : tap + 1, tap2 = tap1 + 1 == a.ntaps ? 0 : tap1 + 1;
+    const int tap1 = tap + 1 == NT ? 0 : tap + 1, tap2 = tap1 + 1 == NT ? 0 : tap1 + 1;
     int pend = 0;
     if (DEPTH >= 2 && s + 1 < nsteps) pend += 2 + (tap1 == 0 ? 2 : 0);
     if (DEPTH >= 3 && s + 2 < nsteps) pend += 2 + (tap2 == 0 ? 2 : 0);
@@ -394,17 +402,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
     else if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // this step's tiles are complete in every wavefront's part; everyone is done with step s - 1's X tile
-    if (tap == 0) read_frags((int)(ch & 1) * TILE, wr * 32, fa);
+    if (!(a.ablate & 8)) __builtin_amdgcn_s_barrier();  // this step's tiles are complete in every wavefront's part; everyone is done with step s - 1's X tile
     uint4 fb[2][2];
-    read_frags((2 + (s & (NBUF - 1))) * TILE, wc * 32, fb);
+    if (!(a.ablate & 4) || s == 0) {
+      if (tap == 0) read_frags((int)(ch & 1) * TILE, wr * 32, fa);
+      read_frags((2 + (s & (NBUF - 1))) * TILE, wc * 32, fb);
+    } else {
+      fb[0][0] = fb[0][1] = fb[1][0] = fb[1][1] = fa[0][0];
+    }
     __builtin_amdgcn_sched_barrier(0);
     // step s + 3 goes into the ring slot step s - 1 used (free since the barrier above); a dZ tile goes into the slot chunk ch - 1
     // used, whose fragments every wavefront copied to registers eight or more steps ago
     issue_next();
     // acc[tap] += dZ_tile^T X_tile   (static tap index: the accumulators are registers)
+    if (!(a.ablate & 1)) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NT; ++t) {
       if (t == tap) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -417,15 +430,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
                   __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[ks][j]), acc[t][i][j], 0, 0, 0);
       }
     }
+    } else {
+      acc[0][0][0][0] += __uint_as_float(fb[0][0].x) + __uint_as_float(fb[1][1].y);  // (keep the fragment reads alive)
+    }
     tap = tap1;
     if (tap1 == 0) ++ch;
   }
 
   // partial sums -> slab[z][cout][tap][cin]: lane holds acc[t][i][j][r] = (cout wr*32 + i*16 + (lane>>4)*4 + r, cin wc*32 + j*16 + (lane&15))
-  float* out = a.slab + (long)blockIdx.z * a.Cout * a.ntaps * a.Cin;
+  float* out = a.slab + (long)zsplit * a.Cout * a.ntaps * a.Cin;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    if (t < a.ntaps) {
+  for (int t = 0; t < NT; ++t) {
+    {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvWgradArgs 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = co0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r, ci = ci0 + wc * 32 + j * 16 + (lane & 15);
-            out[((long)co * a.ntaps + t) * a.Cin + ci] = acc[t][i][j][r];
+            out[((long)co * a.ntaps + tap0 + t) * a.Cin + ci] = acc[t][i][j][r];
           }
     }
   }
@@ -585,14 +601,27 @@ static int conv3x3_wgrad_impl(const void* X, const void* dZ, float* dW, void* wo
   const int nsplit = wgrad_split(M, Cin, Cout);
   const long chunks = (M + 63) / 64;
   a.chunks_per_wg = (int)((chunks + nsplit - 1) / nsplit);
+  static const int ablate = [] { const char* e = getenv("EA_CONVW_ABLATE"); return e ? atoi(e) : 0; }();  // (development probe)
+  a.ablate = ablate;
   // ring depth by shape (round 6, isolated at the recipe batch, us per call incl. the slab reduce, depth 1 / 3): conv 2 (64 -> 64
   // channels, 520 k positions) 236 / 215, conv 3 (64 -> 128) 281 / 308, conv 4 (128 -> 128, 130 k positions) 174 / 178 — the kernel is
   // bound by its LDS fragment reads and the barrier per tap, not by load latency; only the 64-output-channel shape gains
   static const int depth_env = [] { const char* e = getenv("EA_CONV_WGRAD_DEPTH"); return e ? atoi(e) : 0; }();  // (diagnostic A/B switch)
   const int depth = depth_env ? depth_env : (Cout <= 64 ? 3 : 1);
-  if (depth == 1) hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
-  else if (depth == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
+  // Taps per workgroup (round 6).  The kernel is bound by how many bytes its workgroups keep in flight against the ~2 - 3 us of a
+  // last-level-cache / HBM read: TCC counters say the L2 misses are the compulsory ones (310 MB per launch, 46 % hit rate = the
+  // tap re-reads), 1.35 TB/s; the ablation (profiles/r06_conv_wgrad_ablation.txt) gives 299 us -> 176 without the global loads,
+  // 286 without the MFMAs.  Nine taps per workgroup = 144 accumulator registers = two workgroups per CU; three taps per
+  // workgroup = four per CU with the same 64 x 64 tile, the X band re-read by the three tap-row workgroups out of L2.
+  static const int taps_env = [] { const char* e = getenv("EA_CONV_WGRAD_TAPS"); return e ? atoi(e) : 0; }();  // (diagnostic A/B switch)
+  // isolated, us per call incl. the slab reduce, 9 / 3 taps per workgroup: conv 2 224 / 198, conv 3 297 / 271, conv 4 178 / 149;
+  // update step, same box, interleaved: 13.74 / 13.48 and 13.64 / 13.61 ms (profiles/r06_conv_wgrad_taps_ab.txt) -> 3 by default
+  const int taps = taps_env == 3 || taps_env == 9 ? taps_env : 3;
+  if (taps == 3) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 3>), dim3(Cout / 64, Cin / 64, nsplit * 3), dim3(256), 0, stream, a);
+  } else if (depth == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 9>), dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
+  else if (depth == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2, 9>), dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<3, 9>), dim3(Cout / 64, Cin / 64, nsplit), dim3(256), 0, stream, a);
   const long n = (long)Cout * 9 * Cin;
   const long blocks = (n / 4 + 255) / 256;
   int zg = (int)(1024 / blocks);  // ~1024 workgroups in all
