@@ -33,6 +33,86 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16_t* __res
   __shared__ float sred[2][4][CT];
   const int c0 = blockIdx.x * CT, t0 = blockIdx.y * TTILE, b = blockIdx.z;
   const long rowbase = (long)b * T;
+  if ((C & 7) == 0 && c0 + CT <= C) {
+    // Round 6 fast path (full-width channel tile): the loads of all staging trips are requested first, branch-free (clamped rows,
+    // zeros selected afterwards), the gated tile is kept in LDS as the bf16 values the convolution consumes anyway, and Z leaves
+    // as 16-byte rows through LDS instead of TPT two-byte stores per thread.  Same arithmetic, same rounding points.
+    bf16_t (*sub)[CT] = reinterpret_cast<bf16_t (*)[CT]>(&su[0][0]);              // [ROWS][CT] bf16: 12 KB of the 24 KB array
+    bf16_t (*sz)[CT] = reinterpret_cast<bf16_t (*)[CT]>(&su[0][0]) + ROWS;        // [TTILE][CT] bf16 behind it: 8 KB
+    constexpr int NCH = (ROWS * (CT / 8) + 255) / 256;
+    uint4 va[NCH], vg[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int row = min(i / (CT / 8), ROWS - 1), c8 = (i % (CT / 8)) * 8;
+      const int tin = min(max(t0 - PAD + row, 0), T - 1);
+      const bf16_t* yr = Y + (rowbase + tin) * (2L * C) + c0 + c8;
+      va[k] = *reinterpret_cast<const uint4*>(yr);
+      vg[k] = *reinterpret_cast<const uint4*>(yr + C);
+    }
+    const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;
+    float wk[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) wk[k] = w[(long)(c0 + cl) * KW + k];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < ROWS * (CT / 8)) {
+        const int row = i / (CT / 8), c8 = (i % (CT / 8)) * 8;
+        const int tin = t0 - PAD + row;
+        const uint32_t aw[4] = {va[k].x, va[k].y, va[k].z, va[k].w}, gw[4] = {vg[k].x, vg[k].y, vg[k].z, vg[k].w};
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pk[e] = pack_bf2(__uint_as_float(aw[e] << 16) * sigmoid_f(__uint_as_float(gw[e] << 16)),
+                           __uint_as_float(aw[e] & 0xffff0000u) * sigmoid_f(__uint_as_float(gw[e] & 0xffff0000u)));
+        const bool inside = tin >= 0 && tin < T;
+        const uint4 u4 = inside ? make_uint4(pk[0], pk[1], pk[2], pk[3]) : make_uint4(0, 0, 0, 0);
+        if (inside && row >= PAD && row < PAD + TTILE) *reinterpret_cast<uint4*>(U + (rowbase + tin) * C + c0 + c8) = u4;
+        *reinterpret_cast<uint4*>(&sub[row][c8]) = u4;
+      }
+    }
+    __syncthreads();
+    float acc[TPT];
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < TPT + KW - 1; ++r) {
+      const float x = bf2f(sub[grp * TPT + r][cl]);
+#pragma unroll
+      for (int j = 0; j < TPT; ++j)
+        if (r - j >= 0 && r - j < KW) acc[j] += wk[r - j] * x;
+    }
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+      const int tout = t0 + grp * TPT + j;
+      const bf16_t zb = f2bf(acc[j]);
+      sz[grp * TPT + j][cl] = zb;
+      if (tout < T) {
+        const float z = bf2f(zb);
+        s += z;
+        q += z * z;
+      }
+    }
+    if (stats) {
+      sred[0][grp][cl] = s;
+      sred[1][grp][cl] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = threadIdx.x + 256 * k;  // [row][chunk]
+      const int r = i >> 3, c8 = (i & 7) * 8;
+      if (t0 + r < T) *reinterpret_cast<uint4*>(Z + (rowbase + t0 + r) * C + c0 + c8) = *reinterpret_cast<const uint4*>(&sz[r][c8]);
+    }
+    if (stats && threadIdx.x < CT) {
+      const int x = threadIdx.x;
+      atomicAdd(stats + c0 + x, (double)(sred[0][0][x] + sred[0][1][x] + sred[0][2][x] + sred[0][3][x]));
+      atomicAdd(stats + C + c0 + x, (double)(sred[1][0][x] + sred[1][1][x] + sred[1][2][x] + sred[1][3][x]));
+    }
+    return;
+  }
   // staging: 8 channels (16 bytes of a and of g) per thread and row
   const bool vec = (C & 7) == 0;
   for (int i = threadIdx.x; i < ROWS * (CT / 8); i += 256) {
@@ -361,29 +441,94 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16_t* __r
 }
 
 // dU[t] = sum_k w[k] * dZ[t + PAD - k]; then GLU backward -> dY [M][2C]   (same tiling as the forward kernel)
+// Round 6: every global access is a 16-byte vector.  The thread mapping of the convolution (one channel, TPT consecutive time steps)
+// made the GLU operands 2 x TPT two-byte loads and the result 2 x TPT two-byte stores per thread — 64 memory instructions per
+// thread for 256 bytes, and the loads sat in the output loop behind the stores (one dependent round trip per output).  Now the
+// Y tile is staged [half][t][c] in LDS with the dZ tile, each thread updates its own cells in place, and the tile leaves as
+// 16-byte rows.  Full-width tiles only (C % 64 == 0 for this block); ragged channel tiles take the scalar path below.
 template <int KW>
 __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y,
                                                                   const float* __restrict__ w, bf16_t* __restrict__ dY,
                                                                   int T, int C) {
   constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1;
-  __shared__ __attribute__((aligned(16))) float sd[ROWS][CT];
+  // one buffer, two views: [dZ tile bf16 ROWS x CT][Y / dY tile bf16 2 x TTILE x CT] (fast path) or the dZ tile in fp32 (ragged path)
+  constexpr int SDZ_BYTES = ROWS * CT * 2, SY_BYTES = 2 * TTILE * CT * 2;
+  static_assert(SDZ_BYTES % 16 == 0 && SDZ_BYTES + SY_BYTES >= ROWS * CT * 4, "views of the shared buffer");
+  __shared__ __attribute__((aligned(16))) char smem[SDZ_BYTES + SY_BYTES];
+  bf16_t (*sdz)[CT] = reinterpret_cast<bf16_t (*)[CT]>(smem);
+  bf16_t (*sy)[TTILE][CT] = reinterpret_cast<bf16_t (*)[TTILE][CT]>(smem + SDZ_BYTES);
   const int c0 = blockIdx.x * CT, t0 = blockIdx.y * TTILE, b = blockIdx.z;
   const long rowbase = (long)b * T;
-  const bool vec = (C & 7) == 0;
-  // the GLU operands of this thread's TPT outputs are requested FIRST (round 6): loaded in the output loop at the end they were
-  // TPT dependent round trips per thread (load -> multiply -> store, one after the other): 23 us for 6 240 x 512 rows
-  bf16_t ya[TPT], yg[TPT];
-  {
-    const int cl0 = threadIdx.x & (CT - 1), grp0 = threadIdx.x >> 6;
-    const int cc = min(c0 + cl0, C - 1);
+  const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  if ((C & 7) == 0 && c0 + CT <= C) {
+    // ---- all loads of the block first, branch-free (clamped rows, zeros selected afterwards) ----
+    constexpr int NDZ = (ROWS * (CT / 8) + 255) / 256;  // 16-byte chunks of the dZ tile per thread
+    uint4 vdz[NDZ], vy[4];
 #pragma unroll
-    for (int j = 0; j < TPT; ++j) {
-      const int tout = min(t0 + grp0 * TPT + j, T - 1);
-      const bf16_t* yr = Y + (rowbase + tout) * (2L * C);
-      ya[j] = yr[cc];
-      yg[j] = yr[C + cc];
+    for (int k = 0; k < NDZ; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int row = min(i / (CT / 8), ROWS - 1), c8 = (i % (CT / 8)) * 8;
+      const int tin = min(max(t0 - PAD + row, 0), T - 1);
+      vdz[k] = *reinterpret_cast<const uint4*>(dZ + (rowbase + tin) * C + c0 + c8);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 256 * k;  // [half][row][chunk]
+      const int half = i >> 9, r = (i >> 3) & 63, c8 = (i & 7) * 8;
+      const int tout = min(t0 + r, T - 1);
+      vy[k] = *reinterpret_cast<const uint4*>(Y + (rowbase + tout) * (2L * C) + (long)half * C + c0 + c8);
+    }
+    float wk[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) wk[k] = w[(long)c * KW + k];
+#pragma unroll
+    for (int k = 0; k < NDZ; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < ROWS * (CT / 8)) {
+        const int row = i / (CT / 8), c8 = (i % (CT / 8)) * 8;
+        const int tin = t0 - PAD + row;
+        *reinterpret_cast<uint4*>(&sdz[row][c8]) = (tin >= 0 && tin < T) ? vdz[k] : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      *reinterpret_cast<uint4*>(&sy[i >> 9][(i >> 3) & 63][(i & 7) * 8]) = vy[k];
+    }
+    __syncthreads();
+    float acc[TPT];
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < TPT + KW - 1; ++r) {
+      const float x = bf2f(sdz[grp * TPT + r][cl]);
+#pragma unroll
+      for (int j = 0; j < TPT; ++j) {
+        const int k = j + 2 * PAD - r;
+        if (k >= 0 && k < KW) acc[j] += wk[k] * x;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {  // this thread's own cells of the Y tile become its cells of the dY tile
+      const int r = grp * TPT + j;
+      const float av = bf2f(sy[0][r][cl]);
+      const float sg = sigmoid_f(bf2f(sy[1][r][cl]));
+      sy[0][r][cl] = f2bf(acc[j] * sg);
+      sy[1][r][cl] = f2bf(acc[j] * av * sg * (1.f - sg));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int half = i >> 9, r = (i >> 3) & 63, c8 = (i & 7) * 8;
+      if (t0 + r < T)
+        *reinterpret_cast<uint4*>(dY + (rowbase + t0 + r) * (2L * C) + (long)half * C + c0 + c8) = *reinterpret_cast<const uint4*>(&sy[half][r][c8]);
+    }
+    return;
   }
+  // ---- ragged channel tile: scalar path ----
+  float (*sdf)[CT] = reinterpret_cast<float (*)[CT]>(smem);
   for (int i = threadIdx.x; i < ROWS * (CT / 8); i += 256) {
     const int row = i / (CT / 8), c8 = (i % (CT / 8)) * 8;
     const int tin = t0 - PAD + row;
@@ -392,24 +537,12 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
     for (int e = 0; e < 8; ++e) d[e] = 0.f;
     if (tin >= 0 && tin < T && c0 + c8 < C) {
       const bf16_t* src = dZ + (rowbase + tin) * C + c0 + c8;
-      if (vec && c0 + c8 + 8 <= C) {
-        const uint4 v = *reinterpret_cast<const uint4*>(src);
-        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          d[2 * e] = __uint_as_float(wv[e] << 16);
-          d[2 * e + 1] = __uint_as_float(wv[e] & 0xffff0000u);
-        }
-      } else {
-        for (int e = 0; e < 8; ++e)
-          if (c0 + c8 + e < C) d[e] = bf2f(src[e]);
-      }
+      for (int e = 0; e < 8; ++e)
+        if (c0 + c8 + e < C) d[e] = bf2f(src[e]);
     }
-    *reinterpret_cast<float4*>(&sd[row][c8]) = make_float4(d[0], d[1], d[2], d[3]);
-    *reinterpret_cast<float4*>(&sd[row][c8 + 4]) = make_float4(d[4], d[5], d[6], d[7]);
+    *reinterpret_cast<float4*>(&sdf[row][c8]) = make_float4(d[0], d[1], d[2], d[3]);
+    *reinterpret_cast<float4*>(&sdf[row][c8 + 4]) = make_float4(d[4], d[5], d[6], d[7]);
   }
-  const int cl = threadIdx.x & (CT - 1), grp = threadIdx.x >> 6;
-  const int c = c0 + cl;
   float wk[KW];
 #pragma unroll
   for (int k = 0; k < KW; ++k) wk[k] = c < C ? w[(long)c * KW + k] : 0.f;
@@ -420,7 +553,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
   // dU[tout] needs dZ[tout + PAD - k]: LDS row (grp*TPT + j) + 2*PAD - k, i.e. tap k = j + 2*PAD - r for row offset r
 #pragma unroll
   for (int r = 0; r < TPT + KW - 1; ++r) {
-    const float x = sd[grp * TPT + r][cl];
+    const float x = sdf[grp * TPT + r][cl];
 #pragma unroll
     for (int j = 0; j < TPT; ++j) {
       const int k = j + 2 * PAD - r;
@@ -431,11 +564,12 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
   for (int j = 0; j < TPT; ++j) {
     const int tout = t0 + grp * TPT + j;
     if (tout < T && c < C) {
-      const float a = bf2f(ya[j]);
-      const float sg = sigmoid_f(bf2f(yg[j]));
+      const bf16_t* yr = Y + (rowbase + tout) * (2L * C);
+      const float av = bf2f(yr[c]);
+      const float sg = sigmoid_f(bf2f(yr[C + c]));
       bf16_t* dyr = dY + (rowbase + tout) * (2L * C);
       dyr[c] = f2bf(acc[j] * sg);
-      dyr[C + c] = f2bf(acc[j] * a * sg * (1.f - sg));
+      dyr[C + c] = f2bf(acc[j] * av * sg * (1.f - sg));
     }
   }
 }
