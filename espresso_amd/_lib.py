@@ -101,7 +101,7 @@ class EaLayerShape(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("T", ctypes.c_int), ("C", ctypes.c_int), ("H", ctypes.c_int), ("F", ctypes.c_int),
                 ("KW", ctypes.c_int), ("training", ctypes.c_int), ("p_drop", ctypes.c_float), ("p_act", ctypes.c_float),
                 ("p_attn", ctypes.c_float), ("seed", ctypes.c_uint64), ("has_attn_mask", ctypes.c_int), ("scratch_clean", ctypes.c_int),
-                ("pos_mode", ctypes.c_int), ("act", ctypes.c_int), ("S", ctypes.c_int), ("defer", ctypes.c_int)]
+                ("pos_mode", ctypes.c_int), ("act", ctypes.c_int), ("S", ctypes.c_int), ("defer", ctypes.c_int), ("wt_fresh", ctypes.c_int)]
 
 
 class EaWgradProblem(ctypes.Structure):

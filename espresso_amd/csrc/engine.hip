@@ -937,7 +937,7 @@ static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   conv_fwd(c, S.cv, sh, L->conv, S.x2, S.x3, seed + kConv);
   ffn_fwd(c, S.f2, sh, L->ffn2, S.x3, S.x4, seed + kFfn2, 0.5f, EA_ACT_SILU);
   RUN(ea_layernorm_fwd(S.x4, L->final_ln_g, L->final_ln_b, x_out, S.fmean, S.frstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
-  wt_refresh(c, L, sh);  // weights are cache-warm here; the backward of this step reads the k-contiguous copies
+  if (!sh.wt_fresh) wt_refresh(c, L, sh);  // the backward of this step reads the k-contiguous copies (wt_fresh: the caller refreshed them already, off this stream)
   return c.rc;
 }
 
@@ -1325,6 +1325,16 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
   if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
   if (join_all(stream) != 0) return -1;  // a forward reuses the scratch arena: no deferred side work may still be reading it
   return layer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
+}
+
+int ea_conformer_layer_refresh_wt(const EaConformerLayer* layer, const EaLayerShape* shape, hipStream_t stream) {
+  if (!shape_ok(*shape)) return -2;
+  Arena sc{nullptr, 0, 0};
+  Ctx c{stream, false, 0, &sc, nullptr, false};
+  EaLayerShape sh = *shape;
+  sh.training = 1;
+  wt_refresh(c, layer, sh);
+  return c.rc;
 }
 
 int ea_set_fused_predrop(int on) {

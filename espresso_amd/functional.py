@@ -1085,6 +1085,53 @@ class _LayerBinding:
             _grad_ready_callback(self.params)
 
 
+def _conformer_binding(module):
+    bind = getattr(module, "_ea_binding", None)
+    qw = module.self_attn.q_proj.weight
+    if bind is None or bind.key != (qw.data_ptr(), qw.grad.data_ptr() if qw.grad is not None else 0):
+        bind = _LayerBinding(module)
+        module._ea_binding = bind if bind.cacheable else None
+    return bind
+
+
+_WT_PREFETCH = os.environ.get("EA_WT_PREFETCH", "1") != "0"  # (A/B switch)
+
+
+def refresh_layer_transposes(layers, B, T):
+    """Before a TRAINING forward pass over native Conformer layers: the transposed (k-contiguous) copies of every layer's weights —
+    read only by the backward pass — are refreshed on the Python-side stream, under the sub-sampler's / first layers' forward
+    kernels, instead of by each layer's forward call on the compute stream (12 launches of 12 us per update step at the recipe
+    size).  Returns the event the compute stream must wait for before the backward pass (None: nothing was done).  The layers'
+    next forward call is told through `_ea_wt_fresh` (consumed there; a binding rebuilt in between invalidates it)."""
+    import ctypes
+
+    from . import _lib
+    from ._lib import EaLayerShape
+
+    layers = list(layers)
+    if not _WT_PREFETCH or not layers:
+        return None
+    dev = layers[0].ffn1.w_1.weight.device
+    if dev.type != "cuda":
+        return None
+    binds = [_conformer_binding(m) for m in layers]
+    if not all(b.cacheable for b in binds):
+        return None
+    cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    side.wait_stream(cur)  # the bf16 weight shadows were written by the optimizer step on the compute stream
+    lib = _lib.lib()
+    for m, bind in zip(layers, binds):
+        sh = EaLayerShape()
+        sh.B, sh.T, sh.C, sh.H = B, T, m.embed_dim, m.num_heads
+        sh.F = m.ffn1.w_1.weight.shape[0]
+        sh.KW = m.conv_module.depthwise_conv.weight.shape[-1]
+        sh.training = 1
+        _lib.check(lib.ea_conformer_layer_refresh_wt(ctypes.byref(bind.L), ctypes.byref(sh), ctypes.c_void_p(side.cuda_stream)),
+                   "ea_conformer_layer_refresh_wt")
+        m.__dict__["_ea_wt_fresh"] = bind
+    return side.record_event()
+
+
 class _ConformerLayerNative(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
@@ -1093,16 +1140,14 @@ class _ConformerLayerNative(torch.autograd.Function):
         from . import _lib
         from ._lib import EaLayerShape
 
-        bind = getattr(module, "_ea_binding", None)
-        qw = module.self_attn.q_proj.weight
-        if bind is None or bind.key != (qw.data_ptr(), qw.grad.data_ptr() if qw.grad is not None else 0):
-            bind = _LayerBinding(module)
-            module._ea_binding = bind if bind.cacheable else None
+        bind = _conformer_binding(module)
         sh = EaLayerShape()
         sh.B, sh.T, sh.C, sh.H = B, T, module.embed_dim, module.num_heads
         sh.F = module.ffn1.w_1.weight.shape[0]
         sh.KW = module.conv_module.depthwise_conv.weight.shape[-1]
         sh.training = int(training)
+        # (the encoder refreshed this layer's transposed weight copies on a side stream before its layer loop: refresh_layer_transposes)
+        sh.wt_fresh = int(bool(training) and module.__dict__.pop("_ea_wt_fresh", None) is bind)
         sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
         sh.seed = _layer_seed("conformer", p_drop, p_act, p_attn)
         sh.has_attn_mask = int(attn_mask is not None)

@@ -191,12 +191,19 @@ class SpeechTransformerEncoderBase(nn.Module):
         # LayerDrop (fairseq/modules/layer_drop.py:38-44: one uniform draw per layer per forward, layer kept when the draw exceeds p)
         ld = float(getattr(cfg.encoder, "layerdrop", 0.0) or 0.0)
         keep = torch.empty(len(self.layers)).uniform_() > ld if (tr and ld > 0) else None
+        wt_event = None
+        if tr and torch.is_grad_enabled() and x.is_cuda:
+            native = [l for i, l in enumerate(self.layers) if (keep is None or bool(keep[i])) and _native_conformer(l)]
+            if native:  # transposed weight copies of the backward pass: refreshed off the compute stream, under this forward pass
+                wt_event = F.refresh_layer_transposes(native, B, Tp)
         for i, layer in enumerate(self.layers):
             if keep is not None and not bool(keep[i]):
                 continue
             x = layer(x, B, Tp, key_len=key_len, attn_mask=attn_mask)
             if return_all_hiddens:
                 states.append(x)
+        if wt_event is not None:
+            torch.cuda.current_stream(x.device).wait_event(wt_event)
         if self.layer_norm is not None:
             x = F.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias)
         return x, x_lengths, padding_mask, B, Tp, states
@@ -226,6 +233,13 @@ class SpeechTransformerEncoderBase(nn.Module):
         out["encoder_states"] = [s.index_select(1, new_order) for s in encoder_out["encoder_states"]]
         out.pop("_x_bt", None)
         return out
+
+
+def _native_conformer(layer) -> bool:
+    """A Conformer layer that runs on the native layer runtime (csrc/engine.hip) with the sinusoidal relative-position table."""
+    pe = getattr(layer, "positional_embedding", [None])[0]
+    return (hasattr(layer, "conv_module") and getattr(layer, "use_native_runtime", False) and pe is not None
+            and not getattr(pe, "learnable", False))
 
 
 class SpeechTransformerEncoderForPrediction(SpeechTransformerEncoderBase):

@@ -485,6 +485,10 @@ typedef struct EaLayerShape {
    * The gradients of a deferred call are ordered on `stream` once the NEXT backward call, ea_backward_flush or any layer
    * forward call has been issued; `saved` must stay alive until then. */
   int defer;
+  /* forward only (Conformer layer, training): 1 = the k-contiguous weight copies in EaConformerLayer.wt are already fresh for this
+   * update (the caller ran ea_conformer_layer_refresh_wt after the optimizer step, typically on another stream under the
+   * sub-sampler's forward pass) - the forward call then skips its own transposes.  0 = the call refreshes them itself. */
+  int wt_fresh;
 } EaLayerShape;
 
 /* Dropout sites of a layer call (FairseqDropout calls of the reference, cited per site) and the mask stream each one uses.
@@ -528,6 +532,11 @@ int ea_streams_share_queue(ea_stream_t a, ea_stream_t b);
  * the bench line: on a multi-rank job RCCL's streams change how HIP deals queues, so every rank's verdict should be visible. */
 int ea_side_stream_report(int* rejected, int* unprobed);
 int ea_conformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes);
+/* The k-contiguous (transposed) bf16 copies of a Conformer layer's eight weight matrices, which its BACKWARD data-gradient GEMMs
+ * read (EaConformerLayer.wt): one batched transpose on `stream`.  The weights only change in the optimizer step, and nothing in the
+ * forward pass reads the copies: a caller can refresh all layers on a side stream right after the optimizer step and pass
+ * EaLayerShape.wt_fresh = 1 to the forward calls (12 launches off the compute stream per update step). */
+int ea_conformer_layer_refresh_wt(const EaConformerLayer* layer, const EaLayerShape* shape, ea_stream_t stream);
 int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
                            const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
                            void* scratch, long scratch_bytes, ea_stream_t stream);
