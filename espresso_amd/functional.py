@@ -132,6 +132,22 @@ def begin_step(device):
 
 def end_step():
     _zero_pool["live"] = False
+    join_side_streams()
+
+
+_side_pending = {}  # device -> optimizer-only work was put on the Python-side stream since the last join
+_LINEAR_WGRAD_SIDE = os.environ.get("EA_LINEAR_WGRAD_SIDE", "1") != "0"  # (A/B switch)
+
+
+def join_side_streams():
+    """The compute stream waits for optimizer-only work that `_Linear.backward` put on the Python-side stream (called by
+    `end_step()` before the optimizer reads the gradients; idempotent)."""
+    for key in [k for k, v in _side_pending.items() if v]:
+        _side_pending[key] = False
+        st = _side_streams.get(key)
+        if st is not None:
+            dev = torch.device(key)
+            torch.cuda.current_stream(dev).wait_stream(st)
 
 
 def _pool_zeros(shape, dtype, device):
@@ -216,6 +232,8 @@ class accumulating_backward:
     def __exit__(self, *exc):
         global _sink_scope
         _sink_scope -= 1
+        if _sink_scope == 0:
+            join_side_streams()  # (gradients that were accumulated on the Python-side stream are ordered on the compute stream again)
         return False
 
 
@@ -355,11 +373,26 @@ class _Linear(torch.autograd.Function):
         sW = _grad_sink(pw, N * Kin)
         sb = _grad_sink(pb, N) if ctx.has_bias else None
         if sW is not None and (sb is not None or not ctx.has_bias):
-            # a leaf parameter with its gradient buffer in place (fc_out): accumulate there, nothing returned to autograd
-            _wgrad(dy, x, M, N, Kin, ld_dy=ld, out=sW.view(N, Kin), accumulate=True)
+            # a leaf parameter with its gradient buffer in place (fc_out, fc0): accumulate there, nothing returned to autograd.
+            # Optimizer-only products: for the big projections they go to the Python-side stream (round 6: 2 x 106 us of split-K
+            # GEMM per update step were on the compute stream, in front of the data gradient the backward chain waits for);
+            # `end_step()` / the data-parallel wrapper join that stream before the gradients are used.
+            side = _side_stream(dy.device) if (_LINEAR_WGRAD_SIDE and dy.is_cuda and 2.0 * M * N * Kin >= 4e9) else None
+            if side is not None:
+                cur = torch.cuda.current_stream(dy.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    _wgrad(dy, x, M, N, Kin, ld_dy=ld, out=sW.view(N, Kin), accumulate=True)
+                    if ctx.has_bias:
+                        K.colsum(dy, sb, M, N, ld)
+                dy.record_stream(side)
+                x.record_stream(side)
+                _side_pending[str(dy.device)] = True
+            else:
+                _wgrad(dy, x, M, N, Kin, ld_dy=ld, out=sW.view(N, Kin), accumulate=True)
+                if ctx.has_bias:
+                    K.colsum(dy, sb, M, N, ld)
             dW, db = None, None
-            if ctx.has_bias:
-                K.colsum(dy, sb, M, N, ld)
         else:
             dW = _wgrad(dy, x, M, N, Kin, ld_dy=ld)
             db = None
