@@ -104,6 +104,12 @@ class EaLayerShape(ctypes.Structure):
                 ("pos_mode", ctypes.c_int), ("act", ctypes.c_int), ("S", ctypes.c_int), ("defer", ctypes.c_int), ("wt_fresh", ctypes.c_int)]
 
 
+class EaLayerChain(ctypes.Structure):
+    _fields_ = [("next", ctypes.c_void_p), ("next_saved", ctypes.c_void_p), ("next_saved_bytes", ctypes.c_long), ("ln1_done", ctypes.c_int),
+                ("prev", ctypes.c_void_p), ("prev_saved", ctypes.c_void_p), ("prev_saved_bytes", ctypes.c_long),
+                ("prev_seed", ctypes.c_uint64), ("prev_pre", ctypes.c_void_p), ("final_ln_done", ctypes.c_int), ("pre_in", ctypes.c_void_p)]
+
+
 class EaWgradProblem(ctypes.Structure):
     _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("ld_dy", ctypes.c_long), ("ld_x", ctypes.c_long),

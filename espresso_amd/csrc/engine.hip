@@ -77,6 +77,7 @@ struct Ctx {
   hipStream_t side;
   bool overlap;
   Deferred* df = nullptr;  // non-null: deferred mode (also in the sizing pass, so that both walk the arena alike)
+  const EaLayerChain* chain = nullptr;  // Conformer layer calls chained to their neighbours (ea_conformer_layer_*_chained)
 };
 
 #define RUN(call)                         \
@@ -362,14 +363,8 @@ struct Pre {
   uint64_t seed;
   float p;
 };
-static inline void ln_bwd_block(Ctx& c, const void* x, const void* dxn, const float* gamma, const float* mean, const float* rstd,
-                                void* dx, float* dg, float* db, int M, int C, const void* dx_add, const Pre& next) {
-  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
-  if (next.buf)
-    RUN(ea_layernorm_bwd_dx2(x, dxn, gamma, mean, rstd, dx, dg, db, M, C, dx_add, lnws, next.buf, next.a, next.seed, drop_thr(next.p),
-                             drop_scale(next.p), c.s));
-  else
-    RUN(ea_layernorm_bwd_dx(x, dxn, gamma, mean, rstd, dx, dg, db, M, C, nullptr, 0, 0, 1.f, dx_add, lnws, c.s));
+// dgamma / dbeta += the partial slab of a LayerNorm backward: optimizer-only, so deferred / on the side stream
+static inline void ln_param_reduce(Ctx& c, void* lnws, float* dg, float* db, int M, int C) {
   if (c.df) {
     if (c.dry) return;
     if (c.df->ln.count < EA_LNRED_MAX) {
@@ -382,6 +377,31 @@ static inline void ln_bwd_block(Ctx& c, const void* x, const void* dxn, const fl
   }
   fork(c);  // the parameter-gradient reduce only feeds the optimizer
   RUN(ea_layernorm_param_reduce(lnws, dg, db, M, C, wstream(c)));
+}
+static inline void ln_bwd_block(Ctx& c, const void* x, const void* dxn, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, float* dg, float* db, int M, int C, const void* dx_add, const Pre& next) {
+  void* lnws = ln_ws(c, M, C);  // outside RUN(): the dry (sizing) pass must count it too
+  if (next.buf)
+    RUN(ea_layernorm_bwd_dx2(x, dxn, gamma, mean, rstd, dx, dg, db, M, C, dx_add, lnws, next.buf, next.a, next.seed, drop_thr(next.p),
+                             drop_scale(next.p), c.s));
+  else
+    RUN(ea_layernorm_bwd_dx(x, dxn, gamma, mean, rstd, dx, dg, db, M, C, nullptr, 0, 0, 1.f, dx_add, lnws, c.s));
+  ln_param_reduce(c, lnws, dg, db, M, C);
+}
+// The last LayerNorm backward of a CHAINED layer call: this layer's ffn1 norm (x, dxn, dx_add as above) and, on its result, the
+// PREVIOUS layer's final norm, in one kernel.  dx receives the gradient w.r.t. the previous layer's pre-final-norm activations.
+struct ChainBwd {
+  const void* x4; const float *g, *mean, *rstd; float *dg, *db;
+  void* lnws;  // second partial slab (allocated by layer_bwd in every mode: the arena layout does not depend on chaining)
+  Pre pre;
+};
+static inline void ln_bwd2_block(Ctx& c, const void* x, const void* dxn, const float* gamma, const float* mean, const float* rstd,
+                                 void* dx, float* dg, float* db, int M, int C, const void* dx_add, const ChainBwd& cb) {
+  void* lnws = ln_ws(c, M, C);
+  RUN(ea_layernorm_bwd2_dx(x, dxn, gamma, mean, rstd, dx_add, lnws, cb.x4, cb.g, cb.mean, cb.rstd, cb.lnws, dx, M, C, cb.pre.buf, cb.pre.a,
+                           cb.pre.seed, drop_thr(cb.pre.p), drop_scale(cb.pre.p), c.s));
+  ln_param_reduce(c, lnws, dg, db, M, C);
+  ln_param_reduce(c, cb.lnws, cb.dg, cb.db, M, C);
 }
 
 // data gradient dx[M][N] = dy[M][K] W[K][N]: k-contiguous copy Wt[N][K] when available, else W read k-strided
@@ -412,11 +432,12 @@ static FfnSaved ffn_saved(Arena& sv, const EaLayerShape& sh) {
 }
 
 static void ffn_fwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaFfnParams& w, const void* x, void* y,
-                    uint64_t seed, float out_scale, int act) {
+                    uint64_t seed, float out_scale, int act, bool ln_done = false) {
   const int M = sh.B * sh.T, C = sh.C, F = sh.F;
   float *mean = f.mean, *rstd = f.rstd;
   uint16_t *xn = f.xn, *z = f.z, *h = f.h;
-  RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, xn, mean, rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  // (ln_done: the previous layer's chained call wrote xn / mean / rstd with its own final LayerNorm)
+  if (!ln_done) RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, xn, mean, rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   G g1(xn, w.w1, z, M, F, C, C, C, F);
   g1.bias(w.b1).act(act).c2(h, F).drop(sh.p_act, seed + kAct);
   gemm(c, g1);
@@ -427,7 +448,7 @@ static void ffn_fwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
 
 static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaFfnParams& w, const EaFfnGrads& gw, const void* x,
                     const void* dy, void* dx, uint64_t seed, float out_scale, int act, const uint16_t* w1t, const uint16_t* w2t,
-                    const uint16_t* pre, const Pre& next) {
+                    const uint16_t* pre, const Pre& next, const ChainBwd* chain = nullptr) {
   const int M = sh.B * sh.T, C = sh.C, F = sh.F;
   Arena& sc = *c.scratch;
   const size_t mark = sc.off;
@@ -450,7 +471,8 @@ static void ffn_bwd(Ctx& c, const FfnSaved& f, const EaLayerShape& sh, const EaF
   wgrad(c, dz, F, xn, C, gw.w1, M, F, C, gw.b1);
   uint16_t* dxn = sc.get<uint16_t>((size_t)M * C);
   dgrad(c, dz, w.w1, w1t, dxn, M, C, F);
-  ln_bwd_block(c, x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, next);
+  if (chain) ln_bwd2_block(c, x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, *chain);
+  else ln_bwd_block(c, x, dxn, w.ln_g, mean, rstd, dx, gw.ln_g, gw.ln_b, M, C, dy, next);
   release(c, mark);
 }
 
@@ -932,11 +954,19 @@ static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   const int M = sh.B * sh.T, C = sh.C;
   LayerSaved S = layer_saved(sv, sh);
   const uint64_t seed = sh.seed;
-  ffn_fwd(c, S.f1, sh, L->ffn1, x_in, S.x1, seed + kFfn1, 0.5f, EA_ACT_SILU);
+  const EaLayerChain* ch = c.chain;
+  ffn_fwd(c, S.f1, sh, L->ffn1, x_in, S.x1, seed + kFfn1, 0.5f, EA_ACT_SILU, ch && ch->ln1_done);
   attn_fwd(c, S.at, sh, L->attn, S.x1, S.x2, key_len, attn_mask, pe, seed + kAttn);
   conv_fwd(c, S.cv, sh, L->conv, S.x2, S.x3, seed + kConv);
   ffn_fwd(c, S.f2, sh, L->ffn2, S.x3, S.x4, seed + kFfn2, 0.5f, EA_ACT_SILU);
-  RUN(ea_layernorm_fwd(S.x4, L->final_ln_g, L->final_ln_b, x_out, S.fmean, S.frstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  if (ch && ch->next) {  // ... and the next layer's opening LayerNorm, written into ITS saved arena
+    Arena nsv{(char*)ch->next_saved, 0, 0};
+    const LayerSaved N = layer_saved(nsv, sh);
+    RUN(ea_layernorm_fwd2(S.x4, L->final_ln_g, L->final_ln_b, x_out, S.fmean, S.frstd, ch->next->ffn1.ln_g, ch->next->ffn1.ln_b, N.f1.xn,
+                          N.f1.mean, N.f1.rstd, M, C, 1e-5f, c.s));
+  } else {
+    RUN(ea_layernorm_fwd(S.x4, L->final_ln_g, L->final_ln_b, x_out, S.fmean, S.frstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
+  }
   if (!sh.wt_fresh) wt_refresh(c, L, sh);  // the backward of this step reads the k-contiguous copies (wt_fresh: the caller refreshed them already, off this stream)
   return c.rc;
 }
@@ -963,12 +993,27 @@ static int layer_bwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   uint16_t* pf1 = fz ? sc.get<uint16_t>((size_t)M * C) : nullptr;
   const Pre to_ffn2{pf2, 0.5f, seed + kFfn2 + kOut, sh.p_drop}, to_conv{pcv, 1.f, seed + kConv + kConvOut, sh.p_drop};
   const Pre to_attn{pat, 1.f, seed + kAttn + kAttnOut, sh.p_drop}, to_ffn1{pf1, 0.5f, seed + kFfn1 + kOut, sh.p_drop}, none{nullptr, 1.f, 0, 0.f};
-  ln_bwd_block(c, S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, to_ffn2);
+  const EaLayerChain* ch = c.chain;
+  void* lnws2 = ln_ws(c, M, C);  // (second partial slab of a chained call's closing kernel; taken in every mode)
+  if (ch && ch->final_ln_done) {  // the next layer's chained call ran this layer's final-LayerNorm backward
+    dA = (uint16_t*)dy;
+    pf2 = (uint16_t*)ch->pre_in;
+  } else {
+    ln_bwd_block(c, S.x4, dy, L->final_ln_g, S.fmean, S.frstd, dA, L->grads.final_ln_g, L->grads.final_ln_b, M, C, nullptr, to_ffn2);
+  }
+  ChainBwd cb;
+  const bool chained = ch && ch->prev;
+  if (chained) {
+    Arena psv{(char*)ch->prev_saved, 0, 0};
+    const LayerSaved P = layer_saved(psv, sh);
+    cb = ChainBwd{P.x4, ch->prev->final_ln_g, P.fmean, P.frstd, ch->prev->grads.final_ln_g, ch->prev->grads.final_ln_b, lnws2,
+                  Pre{(uint16_t*)ch->prev_pre, 0.5f, ch->prev_seed + kFfn2 + kOut, sh.p_drop}};
+  }
   const WT wt = wt_view(L, sh);
   ffn_bwd(c, S.f2, sh, L->ffn2, L->grads.ffn2, S.x3, dA, dB, seed + kFfn2, 0.5f, EA_ACT_SILU, wt.f2w1, wt.f2w2, pf2, to_conv);
   conv_bwd(c, S.cv, sh, L->conv, L->grads.conv, S.x2, dB, dC, seed + kConv, wt.pw1, wt.pw2, pcv, to_attn);
   attn_bwd(c, S.at, sh, L->attn, L->grads.attn, S.x1, dC, dD, key_len, pe, seed + kAttn, wt.wqkv, wt.wo, pat, to_ffn1);
-  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + kFfn1, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2, pf1, none);
+  ffn_bwd(c, S.f1, sh, L->ffn1, L->grads.ffn1, x_in, dD, dx, seed + kFfn1, 0.5f, EA_ACT_SILU, wt.f1w1, wt.f1w2, pf1, none, chained ? &cb : nullptr);
   if (c.df) run_deferred(c, sh.defer - 1);
   else if (c.overlap) stream_wait(c, c.s, c.side);  // join: gradients complete (and scratch reusable) once `s` passes this point
   return c.rc;
@@ -1302,7 +1347,7 @@ static bool arenas_fit(const EaLayerShape& sh, bool backward, bool overlap, long
 // fork at the end and joined by the NEXT backward call (or ea_backward_flush / any forward call).
 static int bwd_deferred(const EaConformerLayer* layer, const EaLayerShape& sh, const void* x_in, const void* dy, void* dx,
                         const int* key_len, const void* pe, float* dpe, void* saved, long saved_bytes, void* scratch,
-                        long scratch_bytes, hipStream_t stream, bool transformer) {
+                        long scratch_bytes, hipStream_t stream, bool transformer, const EaLayerChain* chain = nullptr) {
   static Deferred df;  // one process drives one GPU from one thread (the autograd engine's device thread)
   const int half = sh.defer - 1;
   const long half_bytes = (scratch_bytes / 2) & ~255L;
@@ -1312,19 +1357,38 @@ static int bwd_deferred(const EaConformerLayer* layer, const EaLayerShape& sh, c
   Ctx c{stream, false, 0, &sc, g_side.stream, true};
   df.clear();
   c.df = &df;
+  c.chain = chain;
   return transformer ? tlayer_bwd(c, layer, sh, x_in, dy, dx, key_len, pe, dpe, sv) : layer_bwd(c, layer, sh, x_in, dy, dx, key_len, pe, sv);
 }
 
-int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
-                           const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
-                           void* scratch, long scratch_bytes, hipStream_t stream) {
+// what a chained call needs beyond the plain one: narrow rows (the paired LayerNorm kernels) and neighbour arenas of full size
+static int chain_ok(const EaLayerShape& sh, const EaLayerChain* ch, bool backward) {
+  if (!ch) return 0;
+  if ((ch->next || ch->prev || ch->ln1_done || ch->final_ln_done) && sh.C > 512) return -2;
+  if (!backward && ch->next && (!ch->next_saved || !arenas_fit(sh, false, false, ch->next_saved_bytes, 1L << 60))) return -5;
+  if (backward && ch->prev && (!ch->prev_saved || !ch->prev_pre || !arenas_fit(sh, false, false, ch->prev_saved_bytes, 1L << 60))) return -5;
+  if (backward && ch->final_ln_done && !ch->pre_in) return -2;
+  return 0;
+}
+
+int ea_conformer_layer_fwd_chained(const EaConformerLayer* layer, const EaLayerShape* shape, const EaLayerChain* chain, const void* x_in,
+                                   void* x_out, const int* key_len, const float* attn_mask, const void* pe, void* saved,
+                                   long saved_bytes, void* scratch, long scratch_bytes, hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
   if (!arenas_fit(*shape, false, false, saved_bytes, scratch_bytes)) return -5;
+  if (const int rc = chain_ok(*shape, chain, false)) return rc;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, nullptr, false};
+  c.chain = chain;
   if ((attn_mask != nullptr) != (shape->has_attn_mask != 0)) return -2;
   if (join_all(stream) != 0) return -1;  // a forward reuses the scratch arena: no deferred side work may still be reading it
   return layer_fwd(c, layer, *shape, x_in, x_out, key_len, attn_mask, pe, sv);
+}
+int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, void* x_out,
+                           const int* key_len, const float* attn_mask, const void* pe, void* saved, long saved_bytes,
+                           void* scratch, long scratch_bytes, hipStream_t stream) {
+  return ea_conformer_layer_fwd_chained(layer, shape, nullptr, x_in, x_out, key_len, attn_mask, pe, saved, saved_bytes, scratch, scratch_bytes,
+                                        stream);
 }
 
 int ea_conformer_layer_refresh_wt(const EaConformerLayer* layer, const EaLayerShape* shape, hipStream_t stream) {
@@ -1349,18 +1413,26 @@ int ea_set_flash_attention(int on) {
   return old;
 }
 
-int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy, void* dx,
-                           const int* key_len, const void* pe, void* saved, long saved_bytes, void* scratch, long scratch_bytes,
-                           hipStream_t stream) {
+int ea_conformer_layer_bwd_chained(const EaConformerLayer* layer, const EaLayerShape* shape, const EaLayerChain* chain, const void* x_in,
+                                   const void* dy, void* dx, const int* key_len, const void* pe, void* saved, long saved_bytes,
+                                   void* scratch, long scratch_bytes, hipStream_t stream) {
   if (!shape_ok(*shape)) return -2;
+  if (const int rc = chain_ok(*shape, chain, true)) return rc;
   const bool ov = g_overlap_default && side_init(stream);
-  if (want_deferred(*shape, ov)) return bwd_deferred(layer, *shape, x_in, dy, dx, key_len, pe, nullptr, saved, saved_bytes, scratch, scratch_bytes, stream, false);
+  if (want_deferred(*shape, ov))
+    return bwd_deferred(layer, *shape, x_in, dy, dx, key_len, pe, nullptr, saved, saved_bytes, scratch, scratch_bytes, stream, false, chain);
   if (!arenas_fit(*shape, true, ov, saved_bytes, scratch_bytes)) return -5;
   if (join_all(stream) != 0) return -1;
   Arena sv{(char*)saved, 0, 0}, sc{(char*)scratch, 0, 0};
   Ctx c{stream, false, 0, &sc, ov ? g_side.stream : nullptr, ov};
+  c.chain = chain;
   if (ov) stream_wait(c, c.side, c.s);
   return layer_bwd(c, layer, *shape, x_in, dy, dx, key_len, pe, sv);
+}
+int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy, void* dx,
+                           const int* key_len, const void* pe, void* saved, long saved_bytes, void* scratch, long scratch_bytes,
+                           hipStream_t stream) {
+  return ea_conformer_layer_bwd_chained(layer, shape, nullptr, x_in, dy, dx, key_len, pe, saved, saved_bytes, scratch, scratch_bytes, stream);
 }
 
 int ea_transformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes) {

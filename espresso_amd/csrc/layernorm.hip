@@ -46,6 +46,49 @@ __device__ inline void store8(T* p, const float (&o)[8]) {
   }
 }
 
+// The LayerNorm backward arithmetic of eight columns, shared by ln_bwd_kernel and ln_bwd2_kernel so that the paired kernel is
+// bit-identical to the two launches it replaces: contraction is switched off and every fused multiply-add is spelled out (left to
+// the compiler, a*b+c contracts differently in the two kernels and the bf16 rounding of dx flips on ~1e-4 of the elements).
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __uint_as_float(w[e] << 16);
+    f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+}
+// xhat, g = dy * gamma; dgamma += dy * xhat, dbeta += dy; row sums s1 += g, s2 += g * xhat (this lane's share)
+__device__ __forceinline__ void ln_bwd_accum8(const uint4& ux, const float (&dv)[8], const float (&gam)[8], float mean, float rstd,
+                                              float (&dg)[8], float (&db)[8], float (&xh)[8], float (&g)[8], float& s1, float& s2) {
+#pragma clang fp contract(off)
+  float xv[8];
+  unpack8(ux, xv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float h = (xv[e] - mean) * rstd;
+    xh[e] = h;
+    dg[e] = __builtin_fmaf(dv[e], h, dg[e]);
+    db[e] = db[e] + dv[e];
+    const float gv = dv[e] * gam[e];
+    g[e] = gv;
+    s1 = s1 + gv;
+    s2 = __builtin_fmaf(gv, h, s2);
+  }
+}
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ residual-path gradient]
+__device__ __forceinline__ void ln_bwd_finish8(const float (&xh)[8], const float (&g)[8], float rstd, float s1, float s2,
+                                               const uint4* add, float (&o)[8]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = rstd * __builtin_fmaf(-xh[e], s2, g[e] - s1);
+  if (add) {
+    float a[8];
+    unpack8(*add, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = o[e] + a[e];
+  }
+}
+
 // rows are processed one per wave. C % 8 == 0 required.  MAXC8 = 16-byte chunks per lane (C <= 512*MAXC8).
 template <int MAXC8, typename TY = bf16_t>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(
@@ -197,6 +240,99 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(
   }
 }
 
+// Two LayerNorms back to back over the same rows (round 6): y1 = LN(x; g1, b1) rounded to bf16 — the output of a Conformer layer,
+// espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:143 — and y2 = LN(y1; g2, b2), the first operation of
+// the NEXT layer (fairseq/modules/conformer_layer.py:141 FeedForwardModule.layer_norm).  One launch instead of two and y1 is not read
+// back; both results are bit-identical to two ea_layernorm_fwd calls (the second norm starts from the ROUNDED y1).  C <= 512.
+template <int RW>
+__global__ __launch_bounds__(256) void ln_fwd2_rows_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ g1, const float* __restrict__ b1, bf16_t* __restrict__ y1,
+    float* __restrict__ mean1, float* __restrict__ rstd1, const float* __restrict__ g2, const float* __restrict__ b2,
+    bf16_t* __restrict__ y2, float* __restrict__ mean2, float* __restrict__ rstd2, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nch = C >> 3;
+  const bool on = lane < nch;
+  const int cl = on ? lane : 0;  // (clamped: every parameter load unconditional)
+  float ga[8], be[8], gb[8], bb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ga[e] = g1[cl * 8 + e]; be[e] = b1[cl * 8 + e];
+    gb[e] = g2[cl * 8 + e]; bb[e] = b2[cl * 8 + e];
+  }
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
+  float v[RW][8], s[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = min(row0 + r, M - 1);
+    const uint4 u = *reinterpret_cast<const uint4*>(x + (long)row * C + cl * 8);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    s[r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[r][2 * e] = on ? __uint_as_float(w[e] << 16) : 0.f;
+      v[r][2 * e + 1] = on ? __uint_as_float(w[e] & 0xffff0000u) : 0.f;
+      s[r] += v[r][2 * e] + v[r][2 * e + 1];
+    }
+  }
+  const float inv_c = __builtin_amdgcn_rcpf((float)C);
+  float mean[RW], q[RW], rs[RW];
+  // the same statistics sequence as ln_fwd_rows_kernel, run twice
+  auto stats = [&]() {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) mean[r] = wave_sum_dpp(s[r]) * inv_c;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      q[r] = 0.f;
+      if (on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[r][e] - mean[r];
+          q[r] += d * d;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) rs[r] = rsqrtf(wave_sum_dpp(q[r]) * inv_c + eps);
+  };
+  stats();
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[r][e] - mean[r]) * rs[r] * ga[e] + be[e];
+    uint4 u;
+    u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    s[r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // the second norm sees what a reader of y1 would see
+      v[r][2 * e] = on ? __uint_as_float(w[e] << 16) : 0.f;
+      v[r][2 * e + 1] = on ? __uint_as_float(w[e] & 0xffff0000u) : 0.f;
+      s[r] += v[r][2 * e] + v[r][2 * e + 1];
+    }
+    if (row < M) {
+      if (lane == 0) { mean1[row] = mean[r]; rstd1[row] = rs[r]; }
+      if (on) *reinterpret_cast<uint4*>(y1 + (long)row * C + lane * 8) = u;
+    }
+  }
+  stats();
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) continue;
+    if (lane == 0) { mean2[row] = mean[r]; rstd2[row] = rs[r]; }
+    if (!on) continue;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[r][e] - mean[r]) * rs[r] * gb[e] + bb[e];
+    uint4 u;
+    u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(y2 + (long)row * C + lane * 8) = u;
+  }
+}
+
 // Each block owns ROWS_PER_BLOCK consecutive rows (4 waves round-robin), accumulates dgamma/dbeta
 // partials per lane-column, reduces across the 4 waves through LDS and writes one partial row (or issues atomics).
 // optional second output of the backward kernel: out[i] = a * dropout(dx[i]) with its own counter-based mask (the next block's
@@ -268,25 +404,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     for (int i = 0; i < MAXC8; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
-        const uint4 ux = r.ux[i];
-        const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w};
-        float k8[8];
+        float k8[8], dv[8];
         if (thr) ea_keep8(seed, (uint64_t)row * C + ch * 8, thr, inv_keep, k8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
-          float dv = r.dy[i][e];
-          if (zero) dv = 0.f;
-          if (thr) dv *= k8[e];
-          const float h = (xv - mean) * rstd;
-          xh[i][e] = h;
-          dg[i][e] += dv * h;
-          db[i][e] += dv;
-          const float gv = dv * gam[i][e];
-          g[i][e] = gv;
-          s1 += gv;
-          s2 += gv * h;
+          dv[e] = zero ? 0.f : r.dy[i][e];
+          if (thr) dv[e] *= k8[e];
         }
+        ln_bwd_accum8(r.ux[i], dv, gam[i], mean, rstd, dg[i], db[i], xh[i], g[i], s1, s2);
       }
     }
     s1 = wave_sum_dpp(s1) * inv_c;
@@ -296,15 +421,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int ch = lane + 64 * i;
       if (ch < nch) {
         float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
-        if (dx_add) {
-          const uint4 ua = r.ua[i];
-          const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            o[e] += (e & 1) ? __uint_as_float(wa[e >> 1] & 0xffff0000u) : __uint_as_float(wa[e >> 1] << 16);
-        }
+        ln_bwd_finish8(xh[i], g[i], rstd, s1, s2, dx_add ? &r.ua[i] : nullptr, o);
         uint4 u;
         u.x = pack_bf2(o[0], o[1]);
         u.y = pack_bf2(o[2], o[3]);
@@ -312,14 +429,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         u.w = pack_bf2(o[6], o[7]);
         *reinterpret_cast<uint4*>(dx + (long)row * C + ch * 8) = u;
         if (o2.out) {
-          const uint32_t wu[4] = {u.x, u.y, u.z, u.w};
-          float p2[8], kk8[8];
+          float dr[8], p2[8], kk8[8];
+          unpack8(u, dr);  // the rounded dx
           if (o2.thr) ea_keep8(o2.seed, (uint64_t)row * C + ch * 8, o2.thr, o2.inv_keep, kk8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float dv = (e & 1) ? __uint_as_float(wu[e >> 1] & 0xffff0000u) : __uint_as_float(wu[e >> 1] << 16);  // the rounded dx
-            p2[e] = o2.a * dv * (o2.thr ? kk8[e] : 1.f);
-          }
+          for (int e = 0; e < 8; ++e) p2[e] = o2.a * dr[e] * (o2.thr ? kk8[e] : 1.f);
           uint4 u2;
           u2.x = pack_bf2(p2[0], p2[1]);
           u2.y = pack_bf2(p2[2], p2[3]);
@@ -376,6 +490,114 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       atomicAdd(dgamma + c, a);
       atomicAdd(dbeta + c, b);
     }
+  }
+}
+
+// Backward of the pair above in one pass over the rows (C <= 512):
+//   d   = bf16( LNbwd(x1, dy1; g1, mean1, rstd1) + dx_add )     (what ea_layernorm_bwd_dx stores as the next layer's input gradient)
+//   dx  = bf16( LNbwd(x2, d;   g2, mean2, rstd2) )              (the previous layer's final LayerNorm, its incoming gradient = d)
+//   out2 = a * dropout(dx)                                      (second output, as ea_layernorm_bwd_dx2)
+// with the dgamma / dbeta partials of both norms in two workspace slabs.  d never reaches memory; every rounding point of the two
+// separate launches is kept, so dx, out2 and the partials are bit-identical to them.
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(
+    const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy1, const float* __restrict__ gamma1,
+    const float* __restrict__ mean1, const float* __restrict__ rstd1, const bf16_t* __restrict__ dx_add,
+    float* __restrict__ partial1, const bf16_t* __restrict__ x2, const float* __restrict__ gamma2,
+    const float* __restrict__ mean2, const float* __restrict__ rstd2, float* __restrict__ partial2,
+    bf16_t* __restrict__ dx, int M, int C, int rows_per_block, const LnOut2 o2) {
+  extern __shared__ float red[];  // [4 waves][4 vectors][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  const bool on = lane < nch;
+  const int cl = on ? lane : 0;
+  float dg1[8], db1[8], dg2[8], db2[8], gam1[8], gam2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    dg1[e] = db1[e] = dg2[e] = db2[e] = 0.f;
+    gam1[e] = gamma1[cl * 8 + e];
+    gam2[e] = gamma2[cl * 8 + e];
+  }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  const float inv_c = __builtin_amdgcn_rcpf((float)C);
+  struct RowIn {
+    uint4 ux1, ud1, ua, ux2;
+    float m1, s1, m2, s2;
+  };
+  auto load_row = [&](int row, RowIn& r) {  // (branch-free: clamped column for the idle lanes of a narrow row)
+    const long o = (long)row * C + cl * 8;
+    r.ux1 = *reinterpret_cast<const uint4*>(x1 + o);
+    r.ud1 = *reinterpret_cast<const uint4*>(dy1 + o);
+    r.ua = *reinterpret_cast<const uint4*>(dx_add + o);
+    r.ux2 = *reinterpret_cast<const uint4*>(x2 + o);
+    r.m1 = mean1[row]; r.s1 = rstd1[row]; r.m2 = mean2[row]; r.s2 = rstd2[row];
+  };
+  // one LayerNorm backward over this lane's eight columns (the arithmetic of ln_bwd_kernel, shared helpers)
+  auto norm_bwd = [&](const uint4& ux, const float (&dv)[8], const float (&gam)[8], float mean, float rstd, float (&dg)[8],
+                      float (&db)[8], const uint4* add, float (&o)[8]) {
+    float xh[8], g[8];
+    float s1 = 0.f, s2 = 0.f;
+    if (on) {
+      ln_bwd_accum8(ux, dv, gam, mean, rstd, dg, db, xh, g, s1, s2);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xh[e] = g[e] = 0.f;
+    }
+    s1 = wave_sum_dpp(s1) * inv_c;
+    s2 = wave_sum_dpp(s2) * inv_c;
+    ln_bwd_finish8(xh, g, rstd, s1, s2, add, o);
+  };
+  auto process_row = [&](int row, const RowIn& r) {
+    float dv[8], o[8];
+    unpack8(r.ud1, dv);
+    norm_bwd(r.ux1, dv, gam1, r.m1, r.s1, dg1, db1, &r.ua, o);
+    uint4 ud;
+    ud.x = pack_bf2(o[0], o[1]); ud.y = pack_bf2(o[2], o[3]); ud.z = pack_bf2(o[4], o[5]); ud.w = pack_bf2(o[6], o[7]);
+    unpack8(ud, dv);  // the rounded gradient the second norm would have read back
+    norm_bwd(r.ux2, dv, gam2, r.m2, r.s2, dg2, db2, nullptr, o);
+    if (!on) return;
+    uint4 u;
+    u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(dx + (long)row * C + lane * 8) = u;
+    if (o2.out) {
+      float dr[8], p2[8], kk8[8];
+      unpack8(u, dr);
+      if (o2.thr) ea_keep8(o2.seed, (uint64_t)row * C + lane * 8, o2.thr, o2.inv_keep, kk8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p2[e] = o2.a * dr[e] * (o2.thr ? kk8[e] : 1.f);
+      uint4 u2;
+      u2.x = pack_bf2(p2[0], p2[1]); u2.y = pack_bf2(p2[2], p2[3]); u2.z = pack_bf2(p2[4], p2[5]); u2.w = pack_bf2(p2[6], p2[7]);
+      *reinterpret_cast<uint4*>(o2.out + (long)row * C + lane * 8) = u2;
+    }
+  };
+  for (int row = r0 + wave; row < r1; row += 8) {  // a wavefront's two rows of the block are in flight together
+    RowIn ra, rb;
+    const bool two = row + 4 < r1;  // (uniform)
+    load_row(row, ra);
+    if (two) load_row(row + 4, rb);
+    process_row(row, ra);
+    if (two) process_row(row + 4, rb);
+  }
+  if (on) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(wave * 4 + 0) * C + lane * 8 + e] = dg1[e];
+      red[(wave * 4 + 1) * C + lane * 8 + e] = db1[e];
+      red[(wave * 4 + 2) * C + lane * 8 + e] = dg2[e];
+      red[(wave * 4 + 3) * C + lane * 8 + e] = db2[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] += red[(w * 4 + k) * C + c];
+    partial1[(long)blockIdx.x * 2 * C + c] = a[0];
+    partial1[(long)blockIdx.x * 2 * C + C + c] = a[1];
+    partial2[(long)blockIdx.x * 2 * C + c] = a[2];
+    partial2[(long)blockIdx.x * 2 * C + C + c] = a[3];
   }
 }
 
@@ -514,6 +736,34 @@ static int ln_bwd_launch(const void* x, const void* dy, const float* gamma, cons
   else EA_LN_BWD(4);
 #undef EA_LN_BWD
   if (workspace && reduce_params) return ea_layernorm_param_reduce(workspace, dgamma, dbeta, M, C, stream);
+  return EA_CHECK_LAUNCH();
+}
+
+// Final LayerNorm of one Conformer layer + first LayerNorm of the next in one launch (ln_fwd2_rows_kernel above); C <= 512.
+extern "C" int ea_layernorm_fwd2(const void* x, const float* g1, const float* b1, void* y1, float* mean1, float* rstd1,
+                                 const float* g2, const float* b2, void* y2, float* mean2, float* rstd2, int M, int C, float eps,
+                                 hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 8 != 0 || C > 512) return -2;
+  if (!y1 || !y2 || !mean1 || !rstd1 || !mean2 || !rstd2) return -2;
+  hipLaunchKernelGGL((ln_fwd2_rows_kernel<4>), dim3((M + 15) / 16), dim3(256), 0, stream, (const bf16_t*)x, g1, b1, (bf16_t*)y1, mean1,
+                     rstd1, g2, b2, (bf16_t*)y2, mean2, rstd2, M, C, eps);
+  return EA_CHECK_LAUNCH();
+}
+
+// ... and the backward of the pair (ln_bwd2_kernel above): `ws1` / `ws2` receive the dgamma / dbeta partials of the two norms
+// (ea_layernorm_bwd_workspace_bytes each; fold them with ea_layernorm_param_reduce).  out2 may be NULL.
+extern "C" int ea_layernorm_bwd2_dx(const void* x1, const void* dy1, const float* gamma1, const float* mean1, const float* rstd1,
+                                    const void* dx_add, void* ws1, const void* x2, const float* gamma2, const float* mean2,
+                                    const float* rstd2, void* ws2, void* dx, int M, int C, void* out2, float a2, uint64_t seed2,
+                                    uint32_t thr2, float scale2, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (C % 8 != 0 || C > 512 || !ws1 || !ws2 || !dx_add) return -2;
+  const int rpb = ln_bwd_rows_per_block(M, true);
+  const int nblk = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(ln_bwd2_kernel, dim3(nblk), dim3(256), (size_t)16 * C * sizeof(float), stream, (const bf16_t*)x1, (const bf16_t*)dy1,
+                     gamma1, mean1, rstd1, (const bf16_t*)dx_add, (float*)ws1, (const bf16_t*)x2, gamma2, mean2, rstd2, (float*)ws2,
+                     (bf16_t*)dx, M, C, rpb, LnOut2{(bf16_t*)out2, a2, seed2, thr2, scale2});
   return EA_CHECK_LAUNCH();
 }
 

@@ -1165,13 +1165,42 @@ def refresh_layer_transposes(layers, B, T):
     return side.record_event()
 
 
+_LAYER_CHAIN = os.environ.get("EA_LAYER_CHAIN", "1") != "0"  # (A/B switch)
+
+
+def set_layer_chain(on: bool):
+    """A/B switch: chained Conformer layer calls (one kernel for layer k's final LayerNorm + layer k+1's first, both passes)."""
+    global _LAYER_CHAIN
+    _LAYER_CHAIN = bool(on)
+
+
+_chain_pre = {}
+
+
+def _chain_pre_buffer(like):
+    """The buffer a chained backward call fills for the PREVIOUS layer's ffn2 block (EaLayerChain.prev_pre).  That layer's deferred
+    side work (its weight-gradient launch reads the buffer) is only joined at the end of the backward call after its own, so the
+    buffer must outlive two more calls: three persistent buffers per shape, used in rotation — not a pooled temporary, which the
+    allocator would hand out again while the side stream is still reading it."""
+    key = (str(like.device), like.numel(), like.dtype)
+    ring = _chain_pre.get(key)
+    if ring is None:
+        ring = _chain_pre[key] = [[torch.empty_like(like) for _ in range(3)], 0]
+    ring[1] = (ring[1] + 1) % 3
+    return ring[0][ring[1]]
+
+
+def _chain_key(sh):
+    return (sh.B, sh.T, sh.C, sh.H, sh.F, sh.KW, sh.training, sh.has_attn_mask, sh.p_drop, sh.p_act, sh.p_attn)
+
+
 class _ConformerLayerNative(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
+    def forward(ctx, x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training, next_module=None):
         import ctypes
 
         from . import _lib
-        from ._lib import EaLayerShape
+        from ._lib import EaLayerChain, EaLayerShape
 
         bind = _conformer_binding(module)
         sh = EaLayerShape()
@@ -1203,11 +1232,32 @@ class _ConformerLayerNative(torch.autograd.Function):
         _scratch_forward_touch(str(x.device))  # the forward overwrites what a backward pass left in the arena
         y = torch.empty_like(x)
         stream = K._stream()
-        _lib.check(lib.ea_conformer_layer_fwd(ctypes.byref(bind.L), ctypes.byref(sh), _ptr(x), _ptr(y), _ptr(key_len), _ptr(attn_mask),
-                                              _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
-                   "ea_conformer_layer_fwd")
+        # Chained calls (EaLayerChain): the previous layer's call left this layer's first LayerNorm in the binding's arena — valid only
+        # if this call's input IS that call's output (the token keeps the tensor alive, so the address identifies it) and the arena is
+        # the one it wrote to; and this call does the same for `next_module` (the encoder passes it when the layer's output has no
+        # other consumer).
+        ch = EaLayerChain()
+        token = module.__dict__.pop("_ea_chain_in", None)
+        ctx.chain_prev = None
+        if (token is not None and token[0] is bind and saved is bind.saved_buf and token[1].data_ptr() == x.data_ptr()
+                and token[2] == _chain_key(sh)):
+            ch.ln1_done = 1
+            if needs_bwd:
+                ctx.chain_prev = token[3]  # the previous layer's autograd context (None: it records no backward)
+        if next_module is not None and _LAYER_CHAIN and sh.C <= 512 and next_module is not module:
+            nbind = _conformer_binding(next_module)
+            if nbind.cacheable and not nbind.saved_busy:
+                if nbind.saved_buf is None or nbind.saved_buf.numel() < nb_saved.value or nbind.saved_buf.device != x.device:
+                    nbind.saved_buf = torch.empty(int(nb_saved.value * 1.1) + 4096, dtype=torch.uint8, device=x.device)
+                ch.next = ctypes.addressof(nbind.L)
+                ch.next_saved, ch.next_saved_bytes = nbind.saved_buf.data_ptr(), nbind.saved_buf.numel()
+                next_module.__dict__["_ea_chain_in"] = (nbind, y, _chain_key(sh), ctx if needs_bwd else None)
+        _lib.check(lib.ea_conformer_layer_fwd_chained(ctypes.byref(bind.L), ctypes.byref(sh), ctypes.byref(ch), _ptr(x), _ptr(y), _ptr(key_len),
+                                                      _ptr(attn_mask), _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(),
+                                                      stream), "ea_conformer_layer_fwd")
         ctx.save_for_backward(x, saved, pe, key_len)
         ctx.bind, ctx.sh, ctx.nb_scratch = bind, sh, nb_scratch.value
+        ctx.chain_saved, ctx.chain_in = saved, None
         return y
 
     @staticmethod
@@ -1227,13 +1277,25 @@ class _ConformerLayerNative(torch.autograd.Function):
         dev = str(x.device)
         half = _native_bwd_begin(sh, dev, tag, deferrable=ctx.owns_arena)
         stream = K._stream()
-        _lib.check(_lib.lib().ea_conformer_layer_bwd(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), _ptr(x), _ptr(dy), _ptr(dx), _ptr(key_len),
-                                                     _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), stream),
-                   "ea_conformer_layer_bwd")
+        ch = _lib.EaLayerChain()
+        if ctx.chain_in is not None:  # the next layer's chained call already ran this layer's final-LayerNorm backward
+            ch.final_ln_done, ch.pre_in = 1, ctx.chain_in.data_ptr()
+        prev = ctx.chain_prev
+        if prev is not None and _LAYER_CHAIN and _chain_key(prev.sh) == _chain_key(sh):
+            # ... and this call ends with the previous layer's: `dx` is then the gradient w.r.t. ITS pre-final-norm activations
+            pre = _chain_pre_buffer(x)
+            ch.prev, ch.prev_saved, ch.prev_saved_bytes = ctypes.addressof(prev.bind.L), prev.chain_saved.data_ptr(), prev.chain_saved.numel()
+            ch.prev_seed, ch.prev_pre = prev.sh.seed, pre.data_ptr()
+            prev.chain_in = pre
+        ctx.chain_prev = None
+        _lib.check(_lib.lib().ea_conformer_layer_bwd_chained(ctypes.byref(ctx.bind.L), ctypes.byref(ctx.sh), ctypes.byref(ch), _ptr(x), _ptr(dy),
+                                                             _ptr(dx), _ptr(key_len), _ptr(pe), _ptr(saved), saved.numel(), _ptr(scratch),
+                                                             scratch.numel(), stream), "ea_conformer_layer_bwd")
+        ctx.chain_in = None
         if ctx.owns_arena:
             ctx.bind.saved_busy = False
         _native_bwd_end(ctx.bind, dev, half, stream)
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 11
 
 
 _scratch = {}
@@ -1539,8 +1601,10 @@ def decoder_layer_native(x, enc, bind, module, enc_len, B, U, S, p_drop, p_act, 
     return _DecoderLayerNative.apply(x, enc, bind, module, enc_len, B, U, S, p_drop, p_act, p_attn, training, act)
 
 
-def conformer_layer_native(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
-    return _ConformerLayerNative.apply(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training)
+def conformer_layer_native(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training, next_module=None):
+    """`next_module`: the native Conformer layer that consumes this call's output AND IS ITS ONLY CONSUMER (a layer stack without
+    collected hidden states): the two calls are chained (EaLayerChain in espresso_amd.h)."""
+    return _ConformerLayerNative.apply(x, module, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training, next_module)
 
 
 # ------------------------------------------------------------------------------------------------

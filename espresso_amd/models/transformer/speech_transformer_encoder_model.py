@@ -196,10 +196,14 @@ class SpeechTransformerEncoderBase(nn.Module):
             native = [l for i, l in enumerate(self.layers) if (keep is None or bool(keep[i])) and _native_conformer(l)]
             if native:  # transposed weight copies of the backward pass: refreshed off the compute stream, under this forward pass
                 wt_event = F.refresh_layer_transposes(native, B, Tp)
-        for i, layer in enumerate(self.layers):
-            if keep is not None and not bool(keep[i]):
-                continue
-            x = layer(x, B, Tp, key_len=key_len, attn_mask=attn_mask)
+        kept = [l for i, l in enumerate(self.layers) if keep is None or bool(keep[i])]
+        for i, layer in enumerate(kept):
+            nxt = kept[i + 1] if i + 1 < len(kept) else None
+            if nxt is not None and not return_all_hiddens and x.is_cuda and _native_conformer(layer) and _native_conformer(nxt):
+                # consecutive native layers and nobody else reads the output: the two calls share the LayerNorm kernel at their boundary
+                x = layer(x, B, Tp, key_len=key_len, attn_mask=attn_mask, chain_next=nxt)
+            else:
+                x = layer(x, B, Tp, key_len=key_len, attn_mask=attn_mask)
             if return_all_hiddens:
                 states.append(x)
         if wt_event is not None:

@@ -116,9 +116,10 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
 
     use_native_runtime = True  # whole layer per C-ABI call (csrc/engine.hip); False: per-kernel composition
 
-    def forward(self, x, B, T, key_len=None, attn_mask=None):
+    def forward(self, x, B, T, key_len=None, attn_mask=None, chain_next=None):
         """x: bf16 [B*T][C] (batch-major rows).  key_len: int32 [B] valid lengths or None.
-        attn_mask: fp32 additive [T][T] or None (already -1e8 / -1e4 filled as in the reference :107-110)."""
+        attn_mask: fp32 additive [T][T] or None (already -1e8 / -1e4 filled as in the reference :107-110).
+        chain_next: the native Conformer layer that is the ONLY consumer of this layer's output (F.conformer_layer_native)."""
         cfg = self.cfg
         tr = self.training
         p_drop = cfg.dropout if tr else 0.0
@@ -127,7 +128,7 @@ class ConformerWithRelativePositionalEmbeddingEncoderLayer(nn.Module):
         if (self.use_native_runtime and self.positional_embedding[0] is not None
                 and not getattr(self.positional_embedding[0], "learnable", False)):
             y = F.conformer_layer_native(x, self, key_len, attn_mask, self.positional_embedding[0].table(T, x.device), B, T,
-                                         p_drop, p_act, p_att, tr)
+                                         p_drop, p_act, p_att, tr, next_module=chain_next)
             if tr and not getattr(self, "_counters_managed", False):
                 self.conv_module.batch_norm.num_batches_tracked += 1
             return y

@@ -186,6 +186,19 @@ int ea_layernorm_param_reduce_group(const EaLnReduceGroup* group, ea_stream_t st
 int ea_layernorm_bwd_dx2(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
                          float* dgamma, float* dbeta, int M, int C, const void* dx_add, void* workspace, void* out2, float a2,
                          uint64_t seed2, uint32_t thr2, float scale2, ea_stream_t stream);
+/* Two LayerNorms back to back over the same rows, C <= 512: y1 = LN(x; g1, b1) (rounded to bf16: a Conformer layer's output,
+ * espresso/modules/conformer_with_relative_positional_embedding_encoder_layer.py:143) and y2 = LN(y1; g2, b2) (the NEXT layer's
+ * first operation, fairseq/modules/conformer_layer.py:141) in one launch — same results as two ea_layernorm_fwd calls. */
+int ea_layernorm_fwd2(const void* x, const float* g1, const float* b1, void* y1, float* mean1, float* rstd1, const float* g2,
+                      const float* b2, void* y2, float* mean2, float* rstd2, int M, int C, float eps, ea_stream_t stream);
+/* Backward of that pair in one pass: d = bf16(LNbwd(x1, dy1; gamma1, mean1, rstd1) + dx_add), dx = bf16(LNbwd(x2, d; gamma2, mean2,
+ * rstd2)), out2 = a2 * dropout(dx) (NULL: skipped) — the same values as ea_layernorm_bwd_dx followed by ea_layernorm_bwd_dx2, without
+ * writing d.  ws1 / ws2 (ea_layernorm_bwd_workspace_bytes each) receive the dgamma / dbeta partials of norm 1 (the later one in the
+ * forward) and norm 2: fold them with ea_layernorm_param_reduce. */
+int ea_layernorm_bwd2_dx(const void* x1, const void* dy1, const float* gamma1, const float* mean1, const float* rstd1,
+                         const void* dx_add, void* ws1, const void* x2, const float* gamma2, const float* mean2, const float* rstd2,
+                         void* ws2, void* dx, int M, int C, void* out2, float a2, uint64_t seed2, uint32_t thr2, float scale2,
+                         ea_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming helpers (AMP weight cast fairseq/tasks/fairseq_task.py:516; FairseqDropout backward
@@ -543,6 +556,32 @@ int ea_conformer_layer_fwd(const EaConformerLayer* layer, const EaLayerShape* sh
 int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* shape, const void* x_in, const void* dy,
                            void* dx, const int* key_len, const void* pe, void* saved, long saved_bytes, void* scratch,
                            long scratch_bytes, ea_stream_t stream);
+/* CHAINED calls over a stack of Conformer layers of one shape (C <= 512): layer k's closing LayerNorm and layer k+1's opening
+ * LayerNorm (of ffn1) touch the same rows back to back, in the forward and — mirrored — in the backward pass.  A chained call does
+ * both with one kernel (ea_layernorm_fwd2 / ea_layernorm_bwd2_dx): 2 launches and two passes over the activations fewer per layer
+ * boundary and update, results bit-identical to the plain calls.  All members may be NULL / 0 (= the plain call).
+ *   forward of layer k:    `next` / `next_saved`: the following layer and ITS saved arena; this call also writes that layer's ffn1
+ *                          LayerNorm output and statistics there.
+ *   forward of layer k+1:  `ln1_done` = 1: `saved` already holds them (the previous call was chained to this layer).
+ *   backward of layer k+1: `prev` / `prev_saved` / `prev_seed` (EaLayerShape.seed of layer k's forward) / `prev_pre` (bf16 [B*T][C]
+ *                          buffer): the call ends with layer k's final-LayerNorm backward; `dx` receives the gradient w.r.t. layer
+ *                          k's PRE-final-norm activations, `prev_pre` the 0.5 * dropout(.) copy layer k's ffn2 block starts from, and
+ *                          layer k's final_ln gradients are accumulated with this call's side work.
+ *   backward of layer k:   `final_ln_done` = 1: `dy` is that gradient and `pre_in` that copy; the call skips its final-norm backward.
+ * The caller must hand layer k+1's `dx` to layer k unchanged (layer k's output has no other consumer), and `prev_pre` must stay
+ * untouched until layer k's own side work has been joined (deferred mode: by the backward call AFTER layer k's, or by
+ * ea_backward_flush) — its weight-gradient launch reads the buffer. */
+typedef struct EaLayerChain {
+  const EaConformerLayer* next; void* next_saved; long next_saved_bytes; int ln1_done;
+  const EaConformerLayer* prev; void* prev_saved; long prev_saved_bytes; uint64_t prev_seed; void* prev_pre;
+  int final_ln_done; const void* pre_in;
+} EaLayerChain;
+int ea_conformer_layer_fwd_chained(const EaConformerLayer* layer, const EaLayerShape* shape, const EaLayerChain* chain, const void* x_in,
+                                   void* x_out, const int* key_len, const float* attn_mask, const void* pe, void* saved,
+                                   long saved_bytes, void* scratch, long scratch_bytes, ea_stream_t stream);
+int ea_conformer_layer_bwd_chained(const EaConformerLayer* layer, const EaLayerShape* shape, const EaLayerChain* chain, const void* x_in,
+                                   const void* dy, void* dx, const int* key_len, const void* pe, void* saved, long saved_bytes,
+                                   void* scratch, long scratch_bytes, ea_stream_t stream);
 /* Transformer encoder layer (pre-LN; fairseq/modules/transformer_layer.py:135-214 with the rel-pos MHA of
  * multihead_attention.py:650-907) in the same runtime: uses the `attn` and `ffn1` members (+ their grads) of EaConformerLayer;
  * `wt` (optional) holds 2*C*F + 4*C*C bf16 elements.  dpe: fp32 [2T-1][C], required iff shape->pos_mode == 1. */

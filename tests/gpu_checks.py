@@ -5,6 +5,7 @@ import math
 import os
 
 import numpy as np
+import ctypes
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -444,6 +445,101 @@ def check_deferred_backward_matches_immediate(layer_type="conformer", p_drop=0.0
         if e > worst[1]:
             worst = (n, e)
     return {"worst_grad": worst, "n": len(out[0])}
+
+
+def check_layernorm_pair_kernels(M=6240, C=512, p=0.1, seed=5):
+    """ea_layernorm_fwd2 / ea_layernorm_bwd2_dx (two LayerNorms over the same rows in one launch) against the two separate launches
+    they replace — ea_layernorm_fwd twice; ea_layernorm_bwd_dx then ea_layernorm_bwd_dx2 — on the same inputs: every output compared
+    BITWISE (both norms' statistics and outputs; the gradient, its dropped copy, both partial slabs)."""
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    st = Kk._stream()
+    dev = DEV
+    x = bf(torch.randn(M, C, generator=g) * 1.7 + 0.3).to(dev)
+    g1, b1 = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    g2, b2 = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    e16 = lambda: torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    f32 = lambda: torch.empty(M, dtype=torch.float32, device=dev)
+    # forward: separate
+    y1a, y2a, m1a, r1a, m2a, r2a = e16(), e16(), f32(), f32(), f32(), f32()
+    _lib.check(lib.ea_layernorm_fwd(P(x), P(g1), P(b1), P(y1a), P(m1a), P(r1a), M, C, 1e-5, None, 0, 0, 1.0, st), "fwd a")
+    _lib.check(lib.ea_layernorm_fwd(P(y1a), P(g2), P(b2), P(y2a), P(m2a), P(r2a), M, C, 1e-5, None, 0, 0, 1.0, st), "fwd b")
+    y1b, y2b, m1b, r1b, m2b, r2b = e16(), e16(), f32(), f32(), f32(), f32()
+    _lib.check(lib.ea_layernorm_fwd2(P(x), P(g1), P(b1), P(y1b), P(m1b), P(r1b), P(g2), P(b2), P(y2b), P(m2b), P(r2b), M, C, 1e-5, st), "fwd2")
+    eq = lambda a, b: bool(torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a.view(torch.int32),
+                                       b.view(torch.int16) if b.dtype == torch.bfloat16 else b.view(torch.int32)))
+    res = {"fwd_y1": eq(y1a, y1b), "fwd_y2": eq(y2a, y2b), "fwd_stats": eq(m1a, m1b) and eq(r1a, r1b) and eq(m2a, m2b) and eq(r2a, r2b)}
+    # backward: norm 2 first (incoming gradient dy2, residual-path gradient `add`), then norm 1 on its result
+    dy2 = bf(torch.randn(M, C, generator=g) * 0.05).to(dev)
+    add = bf(torch.randn(M, C, generator=g) * 0.05).to(dev)
+    nws = lib.ea_layernorm_bwd_workspace_bytes(M, C) // 4
+    wsa1, wsa2, wsb1, wsb2 = (torch.zeros(nws, dtype=torch.float32, device=dev) for _ in range(4))
+    dga, dba = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    d_mid, dxa, o2a = e16(), e16(), e16()
+    thr, scale = Kk.drop_params(p)
+    _lib.check(lib.ea_layernorm_bwd_dx(P(y1a), P(dy2), P(g2), P(m2a), P(r2a), P(d_mid), P(dga), P(dba), M, C, None, 0, 0, 1.0, P(add), P(wsa1), st), "bwd a")
+    _lib.check(lib.ea_layernorm_bwd_dx2(P(x), P(d_mid), P(g1), P(m1a), P(r1a), P(dxa), P(dga), P(dba), M, C, None, P(wsa2), P(o2a), 0.5, 1234 * 64 + 7,
+                                        thr, scale, st), "bwd b")
+    dxb, o2b = e16(), e16()
+    _lib.check(lib.ea_layernorm_bwd2_dx(P(y1a), P(dy2), P(g2), P(m2a), P(r2a), P(add), P(wsb1), P(x), P(g1), P(m1a), P(r1a), P(wsb2), P(dxb), M, C,
+                                        P(o2b), 0.5, 1234 * 64 + 7, thr, scale, st), "bwd2")
+    torch.cuda.synchronize()
+    res.update({"bwd_dx": eq(dxa, dxb), "bwd_out2": eq(o2a, o2b), "bwd_partials_later_norm": eq(wsa1, wsb1), "bwd_partials_earlier_norm": eq(wsa2, wsb2),
+                "dx_max_diff": float((dxa.float() - dxb.float()).abs().max()), "dx_nonzero": float(dxa.float().abs().mean()) > 0,
+                "ws_max_rel": float((wsa2 - wsb2).abs().max() / wsa2.abs().max())})
+    return res
+
+
+def check_layer_chain_matches_plain(B=8, T=1100, p_drop=0.1, embed_dim=64, heads=4, ffn=128, seed=11):
+    """Chained Conformer layer calls (EaLayerChain: layer k's final LayerNorm and layer k+1's first in one kernel, forward and backward)
+    against the plain calls, same dropout masks: identical forward output when both use the rows-at-once kernels (B*T' >= 2048 rows),
+    gradients equal up to the fp32 atomics of the parameter reductions.  Also reports how many calls were chained."""
+    from espresso_amd import functional as F
+
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    feats = torch.randn(B, T, 80, generator=gen).to(DEV)
+    lengths = torch.tensor([T - 37 * i for i in range(B)], dtype=torch.long).clamp(min=T // 3).to(DEV)
+    model = build_tiny_model("conformer", embed_dim=embed_dim, heads=heads, ffn=ffn, dropout=p_drop).to(DEV)
+    model.train()
+    runs = []
+    for chain in (True, False, False):  # (the second plain run measures the run-to-run noise of the plain path itself)
+        F.set_layer_chain(chain)
+        try:
+            for rep in range(2):
+                for p in model.parameters():
+                    p.grad = None
+                for m in model.modules():  # same BatchNorm running statistics going in
+                    if hasattr(m, "running_mean") and m.running_mean is not None:
+                        m.running_mean.zero_(); m.running_var.fill_(1.0)
+                F.set_dropout_seed(seed)
+                o = model(feats, lengths)
+                lo = o["encoder_out"][0].float()
+                with F.accumulating_backward():
+                    (lo * torch.linspace(-1, 1, lo.shape[-1], device=DEV)).sum().backward()
+            torch.cuda.synchronize()
+            runs.append((lo.detach().cpu().clone(),
+                         {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            F.set_layer_chain(True)
+    rows = int(lo.shape[0] * lo.shape[1])
+
+    def worst_diff(ga, gb):
+        worst = ("", 0.0)
+        for n in ga:
+            if (".pre_encoder.convolutions." in n and n.endswith(".bias")) or n.endswith("self_attn.k_proj.bias"):
+                continue  # true gradient exactly zero: both runs hold round-off noise there
+            e = float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-6))
+            if e > worst[1]:
+                worst = (n, e)
+        return worst
+
+    return {"rows": rows, "out_equal": bool(torch.equal(runs[0][0], runs[1][0])),
+            "out_max_diff": float((runs[0][0] - runs[1][0]).abs().max()), "worst_grad": worst_diff(runs[0][1], runs[1][1]),
+            "plain_vs_plain": worst_diff(runs[2][1], runs[1][1]), "n": len(runs[0][1])}
 
 
 def check_direct_param_grads(fixture="ref_conformer_ctc_dh64"):
