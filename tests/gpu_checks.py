@@ -542,6 +542,66 @@ def check_layer_chain_matches_plain(B=8, T=1100, p_drop=0.1, embed_dim=64, heads
             "plain_vs_plain": worst_diff(runs[2][1], runs[1][1]), "n": len(runs[0][1])}
 
 
+def check_layer_chain_fallbacks(B=8, T=1100, seed=3):
+    """The situations in which a chained call must NOT be used, or must not leak state, each against the switch-off run:
+    (a) eval under no_grad (forward chaining only) — identical logits; (b) collected hidden states (the layer outputs have a second
+    consumer: the encoder does not chain) — states and logits identical; (c) two forward passes before one backward (the second
+    finds every binding's arena busy and takes private arenas, unchained; the first pass's chained contexts are consumed later) —
+    gradients inside the plain path's own run-to-run noise."""
+    from espresso_amd import functional as F
+
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    feats = torch.randn(B, T, 80, generator=gen).to(DEV)
+    feats2 = torch.randn(B, T, 80, generator=gen).to(DEV)
+    lengths = torch.tensor([T - 41 * i for i in range(B)], dtype=torch.long).clamp(min=T // 3).to(DEV)
+    model = build_tiny_model("conformer", dropout=0.0).to(DEV)
+    res = {}
+    outs = {}
+    for chain in (True, False, False):
+        F.set_layer_chain(chain)
+        try:
+            model.eval()
+            for m in model.modules():  # (the training passes below move the running statistics)
+                if hasattr(m, "running_mean") and m.running_mean is not None:
+                    m.running_mean.zero_(); m.running_var.fill_(1.0)
+            with torch.no_grad():
+                ev = model(feats, lengths)["encoder_out"][0].float().cpu()
+                enc = model.encoder(feats, lengths, return_all_hiddens=True)
+                st = [s.float().cpu() for s in enc["encoder_states"]] + [enc["encoder_out"][0].float().cpu()]
+            model.train()
+            for m in model.modules():
+                if hasattr(m, "running_mean") and m.running_mean is not None:
+                    m.running_mean.zero_(); m.running_var.fill_(1.0)
+            for p in model.parameters():
+                p.grad = None
+            o1 = model(feats, lengths)["encoder_out"][0].float()
+            o2 = model(feats2, lengths)["encoder_out"][0].float()
+            w = torch.linspace(-1, 1, o1.shape[-1], device=DEV)
+            with F.accumulating_backward():
+                ((o1 * w).sum() + (o2 * w).sum() * 0.5).backward()
+            torch.cuda.synchronize()
+            grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+            outs.setdefault("runs", []).append((ev, st, grads, o1.detach().cpu(), o2.detach().cpu()))
+        finally:
+            F.set_layer_chain(True)
+    a, b, c = outs["runs"]
+
+    def worst(ga, gb):
+        w_ = 0.0
+        for n in ga:
+            if (".pre_encoder.convolutions." in n and n.endswith(".bias")) or n.endswith("self_attn.k_proj.bias"):
+                continue
+            w_ = max(w_, float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-6)))
+        return w_
+
+    res["eval_equal"] = bool(torch.equal(a[0], b[0]))
+    res["states_equal"] = len(a[1]) == len(b[1]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    res["n_states"] = len(a[1])
+    res["train_out_equal"] = bool(torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]))
+    res["grad_diff"], res["plain_noise"], res["n_grads"] = worst(a[2], b[2]), worst(c[2], b[2]), len(a[2])
+    return res
+
+
 def check_direct_param_grads(fixture="ref_conformer_ctc_dh64"):
     """Sub-sampler / fc_out / embedding-LayerNorm parameter gradients accumulated straight into the flat gradient buffer by the
     kernels (functional._grad_sink: no pooled temporary, no AccumulateGrad launch per parameter, the conv weight gradient

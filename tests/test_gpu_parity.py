@@ -124,6 +124,14 @@ def test_deferred_backward_matches_immediate(layer_type):
     assert r["n"] > 20 and r["worst_grad"][1] < 2e-3, r
 
 
+def test_chained_layer_calls_fall_back_cleanly():
+    """no_grad evaluation, collected hidden states, two forward passes before one backward: same results as with chaining off"""
+    r = G.check_layer_chain_fallbacks()
+    print(r)
+    assert r["eval_equal"] and r["states_equal"] and r["n_states"] >= 3 and r["train_out_equal"], r
+    assert r["n_grads"] > 40 and r["grad_diff"] < max(3 * r["plain_noise"], 2e-3), r
+
+
 @pytest.mark.parametrize("M,C", [(6240, 512), (2051, 256), (100, 64)])
 def test_layernorm_pair_kernels_bitwise(M, C):
     """one launch for two LayerNorms over the same rows == the two launches it replaces, bit for bit (forward and backward)"""
