@@ -110,6 +110,11 @@ class EaLayerChain(ctypes.Structure):
                 ("prev_seed", ctypes.c_uint64), ("prev_pre", ctypes.c_void_p), ("final_ln_done", ctypes.c_int), ("pre_in", ctypes.c_void_p)]
 
 
+class EaStackLayer(ctypes.Structure):
+    _fields_ = [("layer", ctypes.c_void_p), ("shape", EaLayerShape), ("saved", ctypes.c_void_p), ("saved_bytes", ctypes.c_long),
+                ("x_in", ctypes.c_void_p)]
+
+
 class EaWgradProblem(ctypes.Structure):
     _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("ld_dy", ctypes.c_long), ("ld_x", ctypes.c_long),

@@ -1435,6 +1435,48 @@ int ea_conformer_layer_bwd(const EaConformerLayer* layer, const EaLayerShape* sh
   return ea_conformer_layer_bwd_chained(layer, shape, nullptr, x_in, dy, dx, key_len, pe, saved, saved_bytes, scratch, scratch_bytes, stream);
 }
 
+// A stack of layers per call: the same layer calls, issued back to back from here instead of from the caller's Python loop
+// (include/espresso_amd.h: what it saves is host time).
+int ea_conformer_stack_fwd(const EaStackLayer* L, int n, void* x_out, const int* key_len, const float* attn_mask, const void* pe,
+                           void* scratch, long scratch_bytes, int chain, hipStream_t stream) {
+  if (n <= 0 || !L) return -2;
+  for (int k = 0; k < n; ++k) {
+    EaLayerChain ch;
+    memset(&ch, 0, sizeof(ch));
+    if (chain) {
+      ch.ln1_done = k > 0;
+      if (k + 1 < n) { ch.next = L[k + 1].layer; ch.next_saved = L[k + 1].saved; ch.next_saved_bytes = L[k + 1].saved_bytes; }
+    }
+    void* out = k + 1 < n ? L[k + 1].x_in : x_out;
+    const int rc = ea_conformer_layer_fwd_chained(L[k].layer, &L[k].shape, &ch, L[k].x_in, out, key_len, attn_mask, pe, L[k].saved,
+                                                  L[k].saved_bytes, scratch, scratch_bytes, stream);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+int ea_conformer_stack_bwd(const EaStackLayer* L, int n, const void* dy, void* dx, void* const* dbuf, void* const* pre,
+                           const int* key_len, const void* pe, void* scratch, long scratch_bytes, int chain, hipStream_t stream) {
+  if (n <= 0 || !L || (n > 1 && !dbuf) || (chain && n > 1 && !pre)) return -2;
+  for (int k = n - 1; k >= 0; --k) {
+    EaLayerChain ch;
+    memset(&ch, 0, sizeof(ch));
+    if (chain) {
+      if (k + 1 < n) { ch.final_ln_done = 1; ch.pre_in = pre[(k + 1) % 3]; }
+      if (k > 0) {
+        ch.prev = L[k - 1].layer; ch.prev_saved = L[k - 1].saved; ch.prev_saved_bytes = L[k - 1].saved_bytes;
+        ch.prev_seed = L[k - 1].shape.seed; ch.prev_pre = pre[k % 3];
+      }
+    }
+    const void* gin = k + 1 < n ? dbuf[(k + 1) & 1] : dy;
+    void* gout = k > 0 ? dbuf[k & 1] : dx;
+    const int rc = ea_conformer_layer_bwd_chained(L[k].layer, &L[k].shape, &ch, L[k].x_in, gin, gout, key_len, pe, L[k].saved,
+                                                  L[k].saved_bytes, scratch, scratch_bytes, stream);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 int ea_transformer_layer_workspace(const EaLayerShape* shape, long* saved_bytes, long* scratch_bytes) {
   if (!shape_ok(*shape)) return -2;
   EaConformerLayer L;

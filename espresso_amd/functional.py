@@ -1298,6 +1298,120 @@ class _ConformerLayerNative(torch.autograd.Function):
         return (dx,) + (None,) * 11
 
 
+_LAYER_STACK = os.environ.get("EA_LAYER_STACK", "1") != "0"  # (A/B switch)
+
+
+def set_layer_stack(on: bool):
+    """A/B switch: a run of native Conformer layers as ONE C call per direction (ea_conformer_stack_fwd / _bwd)."""
+    global _LAYER_STACK
+    _LAYER_STACK = bool(on)
+
+
+def conformer_stack_supported(modules, x) -> bool:
+    """Can this run of native Conformer layers go through the stack call?  Needs the bindings' own arenas (cached bindings, none
+    busy with an earlier forward that still awaits its backward), one shared positional table, and no per-layer gradient-ready
+    callback (the overlapped data-parallel wrapper launches a bucket's all-reduce as soon as ITS layers are done: that needs the
+    Python loop; on one rank nothing listens)."""
+    if not _LAYER_STACK or len(modules) < 2 or not x.is_cuda or _grad_ready_callback is not None:
+        return False
+    if len({id(m) for m in modules}) != len(modules):
+        return False
+    pe0 = modules[0].positional_embedding[0]
+    for m in modules:
+        if m.positional_embedding[0] is not pe0 or m.embed_dim != modules[0].embed_dim or m.cfg is not modules[0].cfg:
+            return False
+        bind = _conformer_binding(m)
+        if not bind.cacheable or bind.saved_busy:
+            return False
+    return True
+
+
+class _ConformerStackNative(torch.autograd.Function):
+    """n native Conformer layers, one C call per direction (include/espresso_amd.h EaStackLayer).  Same launches, dropout seeds and
+    bookkeeping as n `_ConformerLayerNative` nodes in a row."""
+
+    @staticmethod
+    def forward(ctx, x, modules, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
+        import ctypes
+
+        from . import _lib
+        from ._lib import EaLayerShape, EaStackLayer
+
+        n = len(modules)
+        lib = _lib.lib()
+        needs_bwd = ctx.needs_input_grad[0]
+        arr = (EaStackLayer * n)()
+        binds = [_conformer_binding(m) for m in modules]
+        m0 = modules[0]
+        xs = torch.empty((n - 1,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        nb_saved, nb_scratch = ctypes.c_long(0), ctypes.c_long(0)
+        for k, (m, bind) in enumerate(zip(modules, binds)):
+            sh = arr[k].shape
+            sh.B, sh.T, sh.C, sh.H = B, T, m.embed_dim, m.num_heads
+            sh.F = m.ffn1.w_1.weight.shape[0]
+            sh.KW = m.conv_module.depthwise_conv.weight.shape[-1]
+            sh.training = int(training)
+            sh.wt_fresh = int(bool(training) and m.__dict__.pop("_ea_wt_fresh", None) is bind)
+            sh.p_drop, sh.p_act, sh.p_attn = p_drop, p_act, p_attn
+            sh.seed = _layer_seed("conformer", p_drop, p_act, p_attn)
+            sh.has_attn_mask = int(attn_mask is not None)
+            if k == 0:
+                _lib.check(lib.ea_conformer_layer_workspace(ctypes.byref(sh), ctypes.byref(nb_saved), ctypes.byref(nb_scratch)), "workspace")
+            if bind.saved_buf is None or bind.saved_buf.numel() < nb_saved.value or bind.saved_buf.device != x.device:
+                bind.saved_buf = torch.empty(int(nb_saved.value * 1.1) + 4096, dtype=torch.uint8, device=x.device)
+            bind.saved_busy = bool(needs_bwd)
+            m.__dict__.pop("_ea_chain_in", None)
+            arr[k].layer = ctypes.addressof(bind.L)
+            arr[k].saved, arr[k].saved_bytes = bind.saved_buf.data_ptr(), bind.saved_buf.numel()
+            arr[k].x_in = x.data_ptr() if k == 0 else xs[k - 1].data_ptr()
+        scratch = _scratch_buffer(nb_scratch.value, x.device)
+        _scratch_forward_touch(str(x.device))
+        y = torch.empty_like(x)
+        stream = K._stream()
+        chain = int(_LAYER_CHAIN and m0.embed_dim <= 512)
+        _lib.check(lib.ea_conformer_stack_fwd(arr, n, _ptr(y), _ptr(key_len), _ptr(attn_mask), _ptr(pe), _ptr(scratch), scratch.numel(), chain,
+                                              stream), "ea_conformer_stack_fwd")
+        ctx.save_for_backward(x, xs, pe, key_len)
+        ctx.arr, ctx.binds, ctx.n, ctx.nb_scratch, ctx.chain = arr, binds, n, nb_scratch.value, chain
+        ctx.keep = [b.saved_buf for b in binds]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+
+        from . import _lib
+
+        x, xs, pe, key_len = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        n, arr = ctx.n, ctx.arr
+        scratch = _scratch_buffer(ctx.nb_scratch, x.device)
+        dev = str(x.device)
+        halves = [None] * n
+        for k in range(n - 1, -1, -1):  # the bookkeeping of n consecutive layer calls: alternating halves, clean-scratch flags
+            sh = arr[k].shape
+            tag = (scratch.data_ptr(), ctx.nb_scratch, sh.B, sh.T, sh.C, sh.H, sh.F, sh.KW, sh.training, sh.has_attn_mask,
+                   sh.p_drop > 0, sh.p_act > 0, sh.p_attn > 0)
+            halves[k] = _native_bwd_begin(sh, dev, tag, deferrable=True)
+        dbuf = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dptr = (ctypes.c_void_p * 2)(dbuf[0].data_ptr(), dbuf[1].data_ptr())
+        pre = [_chain_pre_buffer(x) for _ in range(3)] if ctx.chain else None
+        pptr = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in pre]) if pre else None
+        stream = K._stream()
+        _lib.check(_lib.lib().ea_conformer_stack_bwd(arr, n, _ptr(dy), _ptr(dx), dptr, pptr, _ptr(key_len), _ptr(pe), _ptr(scratch),
+                                                     scratch.numel(), ctx.chain, stream), "ea_conformer_stack_bwd")
+        for k in range(n - 1, -1, -1):
+            ctx.binds[k].saved_busy = False
+            _native_bwd_end(ctx.binds[k], dev, halves[k], stream)
+        return (dx,) + (None,) * 10
+
+
+def conformer_stack_native(x, modules, key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training):
+    """The layer loop over `modules` (native Conformer layers, conformer_stack_supported) as one autograd node."""
+    return _ConformerStackNative.apply(x, list(modules), key_len, attn_mask, pe, B, T, p_drop, p_act, p_attn, training)
+
+
 _scratch = {}
 _scratch_tag = {}
 

@@ -197,6 +197,19 @@ class SpeechTransformerEncoderBase(nn.Module):
             if native:  # transposed weight copies of the backward pass: refreshed off the compute stream, under this forward pass
                 wt_event = F.refresh_layer_transposes(native, B, Tp)
         kept = [l for i, l in enumerate(self.layers) if keep is None or bool(keep[i])]
+        if (not return_all_hiddens and x.is_cuda and all(_native_conformer(l) for l in kept) and F.conformer_stack_supported(kept, x)):
+            # the whole layer loop as one C call per direction (same launches; host time at small batches: functional.py)
+            l0 = kept[0]
+            c0 = l0.cfg
+            x = F.conformer_stack_native(x, kept, key_len, attn_mask, l0.positional_embedding[0].table(Tp, x.device), B, Tp,
+                                         c0.dropout if tr else 0.0, c0.activation_dropout if tr else 0.0,
+                                         c0.attention_dropout if tr else 0.0, tr)
+            if tr:
+                for l in kept:
+                    if not getattr(l, "_counters_managed", False):
+                        l.conv_module.batch_norm.num_batches_tracked += 1
+            kept = []
+        for i, layer in enumerate(kept):        kept = [l for i, l in enumerate(self.layers) if keep is None or bool(keep[i])]
         for i, layer in enumerate(kept):
             nxt = kept[i + 1] if i + 1 < len(kept) else None
             if nxt is not None and not return_all_hiddens and x.is_cuda and _native_conformer(layer) and _native_conformer(nxt):

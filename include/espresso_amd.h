@@ -582,6 +582,23 @@ int ea_conformer_layer_fwd_chained(const EaConformerLayer* layer, const EaLayerS
 int ea_conformer_layer_bwd_chained(const EaConformerLayer* layer, const EaLayerShape* shape, const EaLayerChain* chain, const void* x_in,
                                    const void* dy, void* dx, const int* key_len, const void* pe, void* saved, long saved_bytes,
                                    void* scratch, long scratch_bytes, ea_stream_t stream);
+/* A STACK of n Conformer layers of one shape in one call per direction — the layer loop of
+ * espresso/models/transformer/speech_transformer_encoder.py:374-390 and its backward.  Same launches as n chained layer calls
+ * (`chain` != 0: EaLayerChain between consecutive members; 0: plain calls); what it saves is host time: at small batches (the
+ * transducer recipe: ~1 500 rows per micro-batch) a layer call issued from the Python loop costs 142 us (forward) / 181 us (backward)
+ * of host time against 64 us for the same call issued back to back from C (cold caches after the interpreter ran;
+ * profiles/r06_transducer_host_split.txt).
+ * L[k].x_in: bf16 [B*T][C] input of layer k — for k > 0 ALSO the output buffer of layer k-1; x_out: output of the last layer.
+ * L[k].shape: the layer's own seed / wt_fresh; backward: its own `defer` (alternating halves as for consecutive plain calls) and
+ * `scratch_clean`.  Backward: dy / dx of the stack; dbuf: two bf16 [B*T][C] buffers for the gradients between layers; pre: three
+ * bf16 [B*T][C] buffers used in rotation for EaLayerChain.prev_pre (must stay untouched until ea_backward_flush / the next
+ * backward call; ignored when chain == 0).  Gradient ordering on `stream`: as after the same sequence of layer calls (the last
+ * member's deferred side work is joined by the next backward call or ea_backward_flush). */
+typedef struct EaStackLayer { const EaConformerLayer* layer; EaLayerShape shape; void* saved; long saved_bytes; void* x_in; } EaStackLayer;
+int ea_conformer_stack_fwd(const EaStackLayer* L, int n, void* x_out, const int* key_len, const float* attn_mask, const void* pe,
+                           void* scratch, long scratch_bytes, int chain, ea_stream_t stream);
+int ea_conformer_stack_bwd(const EaStackLayer* L, int n, const void* dy, void* dx, void* const* dbuf, void* const* pre,
+                           const int* key_len, const void* pe, void* scratch, long scratch_bytes, int chain, ea_stream_t stream);
 /* Transformer encoder layer (pre-LN; fairseq/modules/transformer_layer.py:135-214 with the rel-pos MHA of
  * multihead_attention.py:650-907) in the same runtime: uses the `attn` and `ffn1` members (+ their grads) of EaConformerLayer;
  * `wt` (optional) holds 2*C*F + 4*C*C bf16 elements.  dpe: fp32 [2T-1][C], required iff shape->pos_mode == 1. */

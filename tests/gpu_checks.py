@@ -542,6 +542,59 @@ def check_layer_chain_matches_plain(B=8, T=1100, p_drop=0.1, embed_dim=64, heads
             "plain_vs_plain": worst_diff(runs[2][1], runs[1][1]), "n": len(runs[0][1])}
 
 
+def check_layer_stack_matches_loop(B=8, T=1100, p_drop=0.1, seed=17):
+    """One C call per direction over the run of Conformer layers (ea_conformer_stack_fwd / _bwd) against the Python loop of layer
+    nodes: same dropout seeds in the same order, same launches — training output and eval output identical, gradients inside the
+    loop path's own run-to-run noise (BatchNorm backward sums by atomics)."""
+    from espresso_amd import functional as F
+
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    feats = torch.randn(B, T, 80, generator=gen).to(DEV)
+    lengths = torch.tensor([T - 37 * i for i in range(B)], dtype=torch.long).clamp(min=T // 3).to(DEV)
+    model = build_tiny_model("conformer", dropout=p_drop).to(DEV)
+    runs = []
+    for stack in (True, False, False):
+        F.set_layer_stack(stack)
+        try:
+            for m in model.modules():
+                if hasattr(m, "running_mean") and m.running_mean is not None:
+                    m.running_mean.zero_(); m.running_var.fill_(1.0)
+            model.eval()
+            with torch.no_grad():
+                ev = model(feats, lengths)["encoder_out"][0].float().cpu()
+            model.train()
+            for rep in range(2):
+                for p in model.parameters():
+                    p.grad = None
+                for m in model.modules():
+                    if hasattr(m, "running_mean") and m.running_mean is not None:
+                        m.running_mean.zero_(); m.running_var.fill_(1.0)
+                F.set_dropout_seed(seed)
+                lo = model(feats, lengths)["encoder_out"][0].float()
+                with F.accumulating_backward():
+                    (lo * torch.linspace(-1, 1, lo.shape[-1], device=DEV)).sum().backward()
+            torch.cuda.synchronize()
+            nbt = [int(l.conv_module.batch_norm.num_batches_tracked) for l in model.encoder.layers]
+            runs.append((lo.detach().cpu().clone(), ev,
+                         {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}, nbt))
+        finally:
+            F.set_layer_stack(True)
+
+    def worst_diff(ga, gb):
+        worst = ("", 0.0)
+        for n in ga:
+            if (".pre_encoder.convolutions." in n and n.endswith(".bias")) or n.endswith("self_attn.k_proj.bias"):
+                continue
+            e = float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-6))
+            if e > worst[1]:
+                worst = (n, e)
+        return worst
+
+    return {"out_equal": bool(torch.equal(runs[0][0], runs[1][0])), "eval_equal": bool(torch.equal(runs[0][1], runs[1][1])),
+            "worst_grad": worst_diff(runs[0][2], runs[1][2]), "loop_vs_loop": worst_diff(runs[2][2], runs[1][2]), "n": len(runs[0][2]),
+            "counters": (runs[0][3], runs[1][3])}
+
+
 def check_layer_chain_fallbacks(B=8, T=1100, seed=3):
     """The situations in which a chained call must NOT be used, or must not leak state, each against the switch-off run:
     (a) eval under no_grad (forward chaining only) — identical logits; (b) collected hidden states (the layer outputs have a second

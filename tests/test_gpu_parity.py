@@ -124,7 +124,7 @@ def test_deferred_backward_matches_immediate(layer_type):
     assert r["n"] > 20 and r["worst_grad"][1] < 2e-3, r
 
 
-def test_chained_layer_calls_fall_back_cleanly():
+def test_chained_layer_calls_fall_back_cleanly(layer_stack_mode):
     """no_grad evaluation, collected hidden states, two forward passes before one backward: same results as with chaining off"""
     r = G.check_layer_chain_fallbacks()
     print(r)
@@ -142,8 +142,26 @@ def test_layernorm_pair_kernels_bitwise(M, C):
         assert r["fwd_y1"] and r["fwd_y2"] and r["fwd_stats"], r
 
 
+@pytest.fixture(params=[True, False], ids=["stack_call", "layer_loop"])
+def layer_stack_mode(request):
+    """both host paths over a run of native Conformer layers: one C call per direction, or one autograd node per layer"""
+    from espresso_amd import functional as F
+
+    F.set_layer_stack(request.param)
+    yield request.param
+    F.set_layer_stack(True)
+
+
+def test_layer_stack_call_matches_layer_loop():
+    """ea_conformer_stack_fwd / _bwd (the layer loop inside one C call) == the Python loop of layer nodes: same seeds, same launches"""
+    r = G.check_layer_stack_matches_loop()
+    print(r)
+    assert r["out_equal"] and r["eval_equal"] and r["n"] > 40, r
+    assert r["worst_grad"][1] < max(3 * r["loop_vs_loop"][1], 2e-3), r
+
+
 @pytest.mark.parametrize("big", [True, False])
-def test_chained_layer_calls_match_plain_calls(big):
+def test_chained_layer_calls_match_plain_calls(big, layer_stack_mode):
     """layer k's final LayerNorm + layer k+1's first LayerNorm as one kernel (forward and backward) == the separate launches"""
     r = G.check_layer_chain_matches_plain(B=8 if big else 3, T=1100 if big else 300)
     print(r)
