@@ -496,7 +496,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 static int wgrad_split(long M, int Cin, int Cout) {
   const long chunks = (M + 63) / 64;
   const int blocks = (Cin / 64) * (Cout / 64);
-  long nsplit = (512 + blocks - 1) / blocks;         // 2 workgroups per CU in total
+  static const long target = [] { const char* e = getenv("EA_CONV_WGRAD_WGS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 256L; }();  // (tuning knob)
+  // 256 x 3 tap groups = 3 workgroups per CU in total.  512 (round 5, before the tap groups) and 1024 measure +0.07 ms per step, 128 the
+  // same as 256 (profiles/r06_side_kernel_grids_ab.txt): beside the compute queue a side-queue kernel should not claim every CU
+  long nsplit = (target + blocks - 1) / blocks;
   if (nsplit > chunks / 8) nsplit = chunks / 8;      // at least 8 chunks (72 tap steps) per workgroup
   if (nsplit < 1) nsplit = 1;
   return (int)nsplit;

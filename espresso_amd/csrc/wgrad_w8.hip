@@ -289,9 +289,15 @@ int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out) {
     total += ((p.N + 255) / 256) * tb.tiles_x[i];
     min_rows = p.M < min_rows ? p.M : min_rows;
   }
-  // automatic: one workgroup per CU in (about) one dispatch round, reductions long enough to amortise the 256 x 256 fp32 read-
-  // modify-write of the output — the transducer joint's slabs; the encoder layers' groups (~100 such tiles) stay with 128-row tiles
-  if (g_wgrad_w8 == 1 && !(total >= 192 && total <= 512 && min_rows >= 4096)) return 0;
+  // automatic: reductions long enough to amortise the 256 x 256 fp32 read-modify-write of the output, and at least 48 tiles.  Round 5
+  // asked for a chip-filling grid (>= 192 tiles: the transducer joint's slabs) because ALONE the encoder layers' groups (~116 tiles
+  // = 116 workgroups on 256 CUs) are slower here than on the 4-wave kernel.  But these launches never run alone: they sit on the
+  // side queue beside the compute queue's data-gradient chain, and a launch that claims every CU doubles the duration of whatever
+  // runs next to it (gemm_glds 18 -> 50 us).  On 116 CUs, one workgroup each, with a third of the operand traffic, the same group
+  // leaves 140 CUs to the compute queue: config 3 12.89 -> 12.49 ms per step, config 2 12.91 -> 12.63 (round 6,
+  // profiles/r06_side_kernel_grids_ab.txt).  Smaller row counts (config 4: ~1 500 rows) gain 1 % forced and stay with the 4-wave kernel.
+  static const int min_tiles = [] { const char* e = getenv("EA_WGRAD_W8_MIN_TILES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 48; }();  // (tuning knob)
+  if (g_wgrad_w8 == 1 && !(total >= min_tiles && total <= 512 && min_rows >= 4096)) return 0;
   for (int i = g.count; i <= EA_WGRAD_MAX; ++i) tb.start[i] = total;
   for (int i = g.count; i < EA_WGRAD_MAX; ++i) tb.tiles_x[i] = 1;
   constexpr int lds = 2 * 2 * 64 * 512;
