@@ -35,7 +35,10 @@ int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out);  
 // (round 5, same box: 14.18 ms per step with them everywhere, 13.91 without).  Thread-local: one host thread drives one stream.
 static thread_local int g_gemm_corun = 0;
 void ea_gemm_corun_hint(int on) { g_gemm_corun = on; }
-static const int g_w8_corun = [] { const char* e = getenv("EA_GEMM_W8_CORUN"); return e ? atoi(e) : 0; }();  // (diagnostic: 1 = use them there too)
+// 8-wave kernels for launches that share the device with side-queue work too (the backward's data-gradient chain): round 5 measured
+// them slower there, beside a chip-filling 4-wave weight-gradient launch; beside the 116-workgroup 8-wave one (round 6) they win:
+// 12.47 -> 12.35 ms per step (profiles/r06_side_kernel_grids_ab.txt).  EA_GEMM_W8_CORUN=0 restores the 4-wave choice.
+static const int g_w8_corun = [] { const char* e = getenv("EA_GEMM_W8_CORUN"); return e ? atoi(e) : 1; }();
 
 namespace {
 

@@ -75,9 +75,8 @@ __device__ __forceinline__ bf16x8_t wg8_sel(bool c, bf16x8_t a, bf16x8_t b) {
   __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, A_),              \
                                           __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, B_), C_, 0, 0, 0)
 
-// grid: 1-D over the tiles of all problems (tb.start); 512 threads; 128 KB of dynamic LDS (two stages)
-__global__ __launch_bounds__(512, 2) void wgrad_w8_kernel(const EaWgradGroup g, const W8WgradTable tb) {
-  extern __shared__ __attribute__((aligned(16))) char dsm[];
+// one 256 x 256 tile: `vb` = position of the tile in the launch's virtual 1-D grid of `total` tiles
+__device__ __forceinline__ void wg8_tile(const EaWgradGroup& g, const W8WgradTable& tb, const int vb, const int total, char* dsm) {
   constexpr int PITCH = 512, A_BYTES = 64 * PITCH, STAGE = 2 * A_BYTES;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -85,10 +84,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_w8_kernel(const EaWgradGroup g, 
   const int wm = wave >> 2, wn = wave & 3;  // wavefront tile: rows wm * 128 .. + 128 (columns of dy), columns wn * 64 .. + 64 (of x)
 
   int pi = 0;
-  const int total = gridDim.x, xcd = blockIdx.x & 7, xq = total >> 3, xr = total & 7;
+  const int xcd = vb & 7, xq = total >> 3, xr = total & 7;
   // workgroups go round-robin to the 8 XCDs: give every XCD a contiguous range, so that the column tiles of a row block (same dy
   // columns) and neighbouring row blocks (same x rows) of one slab meet in ONE L2
-  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (vb >> 3);
   while (pi + 1 < g.count && bid >= tb.start[pi + 1]) ++pi;
   const EaWgradProblem P = g.p[pi];
   const int local = bid - tb.start[pi];
@@ -266,6 +265,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_w8_kernel(const EaWgradGroup g, 
   }
 }
 
+// grid: 1-D, 512 threads, 128 KB of dynamic LDS (two stages).  gridDim.x == tb.start[EA_WGRAD_MAX] (the tile count): one tile per
+// workgroup.  A SMALLER grid (a multiple of 8, so that a workgroup's tiles stay on its XCD's range): every workgroup walks tiles
+// blockIdx.x, + gridDim.x, ... — for launches that run on a side queue beside the compute queue and should leave it most of the CUs.
+__global__ __launch_bounds__(512, 2) void wgrad_w8_kernel(const EaWgradGroup g, const W8WgradTable tb) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int total = tb.start[EA_WGRAD_MAX];
+  for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+    if (vb != (int)blockIdx.x) __syncthreads();  // every wavefront is done reading the previous tile's last stage
+    wg8_tile(g, tb, vb, total, dsm);
+  }
+}
+
 }  // namespace
 
 extern "C" int ea_set_wgrad_w8(int mode) {
@@ -304,7 +315,13 @@ int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out) {
   static const bool attr_ok =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_w8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   if (!attr_ok) return 0;
-  hipLaunchKernelGGL(wgrad_w8_kernel, dim3(total), dim3(512), lds, stream, g, tb);
-  if (grid_out) *grid_out = total;
+  // groups that do not fill the chip anyway (the encoder layers' ~116 tiles) run beside the compute queue's data-gradient chain, whose
+  // 8-wave GEMMs are ~200 workgroups of one per CU: capped at `cap` workgroups walking two tiles each, the launch takes twice as long
+  // on the side queue (which has the slack) and the chain's GEMMs fit the remaining CUs in ONE round.  0 = one workgroup per tile.
+  static const int cap = [] { const char* e = getenv("EA_WGRAD_W8_GRID"); return e ? atoi(e) : 0; }();
+  int grid = total;
+  if (cap > 0 && total < 192 && total > cap) grid = (cap + 7) & ~7;
+  hipLaunchKernelGGL(wgrad_w8_kernel, dim3(grid), dim3(512), lds, stream, g, tb);
+  if (grid_out) *grid_out = grid;
   return 1;
 }
