@@ -28,7 +28,7 @@
 
 // 8-wave large-tile kernels (gemm_w8.hip): takes the launch (returns 1) or leaves it to the kernels below (0)
 int ea_gemm_w8_try(const EaGemmParams& q, int nt_flag, hipStream_t stream, int* cfg_out);
-int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out);  // wgrad_w8.hip
+int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out, EaWgradGroup* rest);  // wgrad_w8.hip
 // Hint from the layer runtime (engine.hip): the launches that follow run NEXT TO side-stream work (the backward pass: grouped weight
 // gradients of 2 x 64 KB of LDS per CU).  A one-workgroup-per-CU kernel with 128 - 144 KB of LDS cannot share a CU with them: it
 // waits for both to drain and then keeps them out, so the 8-wave kernels, 10 - 15 % faster alone, lose in that half of the step
@@ -1291,13 +1291,21 @@ extern "C" int ea_wgrad_group(const EaWgradGroup* gp, hipStream_t stream) {
     hipEventRecord(pr.e0, stream);
   }
   // long reductions over chip-filling 256 x 256 tile grids (the transducer joint's slabs): the 8-wave kernel of wgrad_w8.hip
-  if (ea_wgrad_w8_try(g, stream, nullptr)) {
+  EaWgradGroup rest;
+  rest.count = 0;
+  if (const int took = ea_wgrad_w8_try(g, stream, nullptr, &rest)) {
     if (g_prof_on) {
+      for (int i = 0; i < rest.count; ++i) {  // (took == 2: the thin problems are accounted by the launch that does them)
+        pr.flops -= 2.0 * rest.p[i].M * (double)rest.p[i].N * rest.p[i].K;
+        pr.bytes -= 2.0 * rest.p[i].M * ((double)rest.p[i].N + rest.p[i].K) + 8.0 * rest.p[i].N * (double)rest.p[i].K;
+      }
       pr.bm64 = 108;
       hipEventRecord(pr.e1, stream);
       g_prof.push_back(pr);
     }
-    return EA_CHECK_LAUNCH();
+    const int rc = EA_CHECK_LAUNCH();
+    if (took == 2 && rc == 0) return ea_wgrad_group(&rest, stream);  // (thin problems only: the 8-wave kernel declines them)
+    return rc;
   }
   // rows 16-byte aligned and whole tiles readable everywhere: direct-to-LDS kernel with transposing fragment reads
   if (tr_ok) {

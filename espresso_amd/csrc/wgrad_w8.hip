@@ -285,9 +285,31 @@ extern "C" int ea_set_wgrad_w8(int mode) {
   return old;
 }
 
-// Called first by ea_wgrad_group.  Returns 1 when the group was launched here (*grid_out = workgroups), 0 to fall through.
-int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out) {
+static int wgrad_w8_launch(const EaWgradGroup& g, hipStream_t stream, int* grid_out, bool forced);
+// Called first by ea_wgrad_group.  Returns 1 when the group was launched here (*grid_out = workgroups), 0 to fall through, 2 when
+// only the THICK problems were launched here and `rest` received the thin ones (automatic mode, rest != NULL): a problem whose dW
+// has <= 64 rows (the per-head positional-projection gradients of an attention block: [64][2T'-1]) fills a quarter of a 256-row tile
+// and would hold a CU for the whole reduction all the same — 24 to 56 of a layer group's 116 to 148 workgroups; the 4-wave kernel
+// can do them on 64-row tiles in a second launch.
+int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out, EaWgradGroup* rest) {
   if (!g_wgrad_w8 || g.count <= 0) return 0;
+  // (A/B switch, default OFF: measured 12.41 / 12.43 vs 12.30 / 12.32 ms per step — the second launch walks the same 6 240 rows on a
+  // handful of workgroups and lengthens the side queue by more than the freed CUs give back; profiles/r06_side_kernel_grids_ab.txt)
+  static const bool split_thin = [] { const char* e = getenv("EA_WGRAD_W8_SPLIT_THIN"); return e && e[0] == '1'; }();
+  if (g_wgrad_w8 == 1 && rest && split_thin) {
+    EaWgradGroup thick;
+    thick.count = 0;
+    rest->count = 0;
+    for (int i = 0; i < g.count; ++i) {
+      if (g.p[i].N <= 64) rest->p[rest->count++] = g.p[i];
+      else thick.p[thick.count++] = g.p[i];
+    }
+    if (thick.count == 0) return 0;  // nothing but thin problems: not this kernel's case
+    if (rest->count > 0) return wgrad_w8_launch(thick, stream, grid_out, false) ? 2 : 0;
+  }
+  return wgrad_w8_launch(g, stream, grid_out, g_wgrad_w8 == 2);
+}
+static int wgrad_w8_launch(const EaWgradGroup& g, hipStream_t stream, int* grid_out, bool forced) {
   W8WgradTable tb;
   int total = 0;
   long min_rows = 1L << 40;
@@ -308,7 +330,7 @@ int ea_wgrad_w8_try(const EaWgradGroup& g, hipStream_t stream, int* grid_out) {
   // leaves 140 CUs to the compute queue: config 3 12.89 -> 12.49 ms per step, config 2 12.91 -> 12.63 (round 6,
   // profiles/r06_side_kernel_grids_ab.txt).  Smaller row counts (config 4: ~1 500 rows) gain 1 % forced and stay with the 4-wave kernel.
   static const int min_tiles = [] { const char* e = getenv("EA_WGRAD_W8_MIN_TILES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 48; }();  // (tuning knob)
-  if (g_wgrad_w8 == 1 && !(total >= min_tiles && total <= 512 && min_rows >= 4096)) return 0;
+  if (!forced && !(total >= min_tiles && total <= 512 && min_rows >= 4096)) return 0;
   for (int i = g.count; i <= EA_WGRAD_MAX; ++i) tb.start[i] = total;
   for (int i = g.count; i < EA_WGRAD_MAX; ++i) tb.tiles_x[i] = 1;
   constexpr int lds = 2 * 2 * 64 * 512;
