@@ -78,6 +78,8 @@ struct Ctx {
   bool overlap;
   Deferred* df = nullptr;  // non-null: deferred mode (also in the sizing pass, so that both walk the arena alike)
   const EaLayerChain* chain = nullptr;  // Conformer layer calls chained to their neighbours (ea_conformer_layer_*_chained)
+  bool bits_early = false;  // the attention block's keep-bit kernel was already launched on the side stream (start of the layer call)
+  bool pp_early = false;    // ... and its positional-table projection
 };
 
 #define RUN(call)                         \
@@ -521,6 +523,24 @@ static AttnSaved attn_saved(Arena& sv, const EaLayerShape& sh) {
   return a;
 }
 
+// attention-dropout keep bits of a fused attention block on the side stream (data independent: only the seed and the shape); the
+// side stream first waits for the main stream — an earlier backward may still be reading the buffer.  true: launched.
+static bool keep_bits_on_side(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, uint64_t seed, const EaAttnParams* w = nullptr,
+                              const void* pe = nullptr) {
+  if (!(a.bits && attn_fused(sh) && !c.dry && c.rc == 0 && g_flash_bits_side && side_init(c.s))) return false;
+  hipEvent_t e0 = g_side.ev[g_side.next];
+  g_side.next = (g_side.next + 1) % 32;
+  if (hipEventRecord(e0, c.s) != hipSuccess || hipStreamWaitEvent(g_side.stream, e0, 0) != hipSuccess) c.rc = -1;
+  RUN(ea_flash_keep_bits(a.bits, sh.H, sh.B, sh.T, seed + kProbs, drop_thr(sh.p_attn), g_side.stream));
+  if (w && pe && sh.pos_mode != 1) {  // ... and the projected positional table (weights x constant table: no activation in it either)
+    const int R = 2 * sh.T - 1, C = sh.C;
+    G gpp(pe, w->wpos, a.pp, R, C, C, C, C, C);
+    gemm_on(c, gpp, g_side.stream);
+    c.pp_early = true;
+  }
+  return true;
+}
+
 static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const EaAttnParams& w, const void* x, void* y,
                      const int* key_len, const float* attn_mask, const void* pe, uint64_t seed) {
   const int B = sh.B, T = sh.T, C = sh.C, H = sh.H, M = B * T, dh = C / H, Z = H * B, Sp = pad8(T), R = 2 * T - 1, Rp = pad8(R);
@@ -529,14 +549,9 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
   const size_t mark = sc.off;
   // attention-dropout keep bits: data independent, so the bit kernel runs on the side stream under the LayerNorm / QKV GEMM
   // of this block (the side stream first waits for the main stream: an earlier backward may still be reading the buffer)
-  bool bits_on_side = false;
-  if (a.bits && attn_fused(sh) && !c.dry && c.rc == 0 && g_flash_bits_side && side_init(c.s)) {
-    hipEvent_t e0 = g_side.ev[g_side.next];
-    g_side.next = (g_side.next + 1) % 32;
-    if (hipEventRecord(e0, c.s) != hipSuccess || hipStreamWaitEvent(g_side.stream, e0, 0) != hipSuccess) c.rc = -1;
-    RUN(ea_flash_keep_bits(a.bits, H, B, T, seed + kProbs, drop_thr(sh.p_attn), g_side.stream));
-    bits_on_side = true;
-  }
+  bool bits_on_side = c.bits_early;
+  c.bits_early = false;
+  if (!bits_on_side) bits_on_side = keep_bits_on_side(c, a, sh, seed);
   RUN(ea_layernorm_fwd(x, w.ln_g, w.ln_b, a.xn, a.mean, a.rstd, M, C, 1e-5f, nullptr, 0, 0, 1.f, c.s));
   G gq(a.xn, w.wqkv, a.qkv, M, 3 * C, C, C, C, 3 * C);
   gq.bias(w.bqkv);
@@ -555,10 +570,11 @@ static void attn_fwd(Ctx& c, const AttnSaved& a, const EaLayerShape& sh, const E
     else RUN(ea_relpos_q_prep(a.qkv, 3 * C, w.pos_u, w.pos_v, a.qu, a.qv, M, C, scaling, c.s));
   }
   if (attn_fused(sh)) {
-    if (!learned) {
+    if (!learned && !c.pp_early) {
       G gpp(pe, w.wpos, a.pp, R, C, C, C, C, C);
       gemm(c, gpp);
     }
+    c.pp_early = false;
     if (bits_on_side) {
       hipEvent_t e1 = g_side.ev[g_side.next];
       g_side.next = (g_side.next + 1) % 32;
@@ -955,6 +971,11 @@ static int layer_fwd(Ctx& c, const EaConformerLayer* L, const EaLayerShape& sh, 
   LayerSaved S = layer_saved(sv, sh);
   const uint64_t seed = sh.seed;
   const EaLayerChain* ch = c.chain;
+  // the attention block's keep bits need nothing but the seed: launched now, they run under the first feed-forward block instead of
+  // beside the QKV projection that the attention kernel also waits for (EA_KEEP_BITS_EARLY=0: in the attention block, as before)
+  static const bool bits_early = [] { const char* e = getenv("EA_KEEP_BITS_EARLY"); return !(e && e[0] == '0'); }();
+  static const bool pp_early = [] { const char* e = getenv("EA_POS_PROJ_EARLY"); return !(e && e[0] == '0'); }();
+  if (bits_early) c.bits_early = keep_bits_on_side(c, S.at, sh, seed + kAttn, pp_early ? &L->attn : nullptr, pe);
   ffn_fwd(c, S.f1, sh, L->ffn1, x_in, S.x1, seed + kFfn1, 0.5f, EA_ACT_SILU, ch && ch->ln1_done);
   attn_fwd(c, S.at, sh, L->attn, S.x1, S.x2, key_len, attn_mask, pe, seed + kAttn);
   conv_fwd(c, S.cv, sh, L->conv, S.x2, S.x3, seed + kConv);
