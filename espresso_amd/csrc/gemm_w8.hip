@@ -362,7 +362,8 @@ int w8_kind(const EaGemmParams& q) {
   if (q.q_u) {
     // (measured in the step, round 5: 35.0 us against 31.5 us for the 4-wave kernel — this launch runs next to the side stream's
     // keep-bits kernel; the specialisation stays for forced configurations)
-    if (g_gemm_w8 == 1) return -1;
+    static const bool qs = [] { const char* e = getenv("EA_GEMM_W8_QSPLIT"); return e && e[0] == '1'; }();  // (A/B switch)
+    if (g_gemm_w8 == 1 && !qs) return -1;
     return (q.aux || q.C2 || q.resid || q.drop_thr || q.act != EA_ACT_NONE || q.out_scale != 1.f) ? -1 : W8_QSPLIT;
   }
   if (q.C2) return (q.aux || q.resid) ? -1 : W8_ACT2;
