@@ -446,10 +446,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16_t* __r
 // thread for 256 bytes, and the loads sat in the output loop behind the stores (one dependent round trip per output).  Now the
 // Y tile is staged [half][t][c] in LDS with the dZ tile, each thread updates its own cells in place, and the tile leaves as
 // 16-byte rows.  Full-width tiles only (C % 64 == 0 for this block); ragged channel tiles take the scalar path below.
-template <int KW>
+// FUSE_BN (round 6): the BatchNorm + SiLU backward "apply" pass (bn_act_bwd_apply_kernel) happens while the tile is staged — the
+// block reads Z and dH (the BatchNorm's input and the incoming gradient) instead of a stored dZ, forms dZ = BN'(dH) per 16-byte
+// chunk in registers with the same arithmetic and the same bf16 rounding, feeds the convolution from LDS and ALSO stores the tile's
+// own rows of dZ (the depthwise weight gradient on the side stream reads them).  One launch and one pass over [M][C] fewer per layer.
+struct BnBwdFuse {
+  const bf16_t* Z; const bf16_t* dH; const float* mean_rstd; const float* gamma; const float* beta; const float* red; bf16_t* dZ_out;
+  float n; int act; float* dgamma; float* dbeta; float* zero_next; int zero_n;
+};
+template <int KW, bool FUSE_BN>
 __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y,
                                                                   const float* __restrict__ w, bf16_t* __restrict__ dY,
-                                                                  int T, int C) {
+                                                                  int T, int C, const BnBwdFuse fb) {
   constexpr int PAD = (KW - 1) / 2, ROWS = TTILE + KW - 1;
   // one buffer, two views: [dZ tile bf16 ROWS x CT][Y / dY tile bf16 2 x TTILE x CT] (fast path) or the dZ tile in fp32 (ragged path)
   constexpr int SDZ_BYTES = ROWS * CT * 2, SY_BYTES = 2 * TTILE * CT * 2;
@@ -464,13 +472,18 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
   if ((C & 7) == 0 && c0 + CT <= C) {
     // ---- all loads of the block first, branch-free (clamped rows, zeros selected afterwards) ----
     constexpr int NDZ = (ROWS * (CT / 8) + 255) / 256;  // 16-byte chunks of the dZ tile per thread
-    uint4 vdz[NDZ], vy[4];
+    uint4 vdz[NDZ], vy[4], vz[FUSE_BN ? NDZ : 1];
 #pragma unroll
     for (int k = 0; k < NDZ; ++k) {
       const int i = threadIdx.x + 256 * k;
       const int row = min(i / (CT / 8), ROWS - 1), c8 = (i % (CT / 8)) * 8;
       const int tin = min(max(t0 - PAD + row, 0), T - 1);
-      vdz[k] = *reinterpret_cast<const uint4*>(dZ + (rowbase + tin) * C + c0 + c8);
+      if constexpr (FUSE_BN) {
+        vz[k] = *reinterpret_cast<const uint4*>(fb.Z + (rowbase + tin) * C + c0 + c8);
+        vdz[k] = *reinterpret_cast<const uint4*>(fb.dH + (rowbase + tin) * C + c0 + c8);
+      } else {
+        vdz[k] = *reinterpret_cast<const uint4*>(dZ + (rowbase + tin) * C + c0 + c8);
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -482,6 +495,46 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_data_kernel(const bf16_t* 
     float wk[KW];
 #pragma unroll
     for (int k = 0; k < KW; ++k) wk[k] = w[(long)c * KW + k];
+    if constexpr (FUSE_BN) {
+      // a thread's chunks all sit in the same 8 channels (256 % (CT / 8) == 0): their BatchNorm constants once
+      const int cc = c0 + (threadIdx.x % (CT / 8)) * 8;
+      const float invn = fb.n > 0.f ? 1.f / fb.n : 0.f;
+      float mu[8], rs[8], ga[8], be[8], r0[8], r1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mu[e] = fb.mean_rstd[cc + e]; rs[e] = fb.mean_rstd[C + cc + e]; ga[e] = fb.gamma[cc + e]; be[e] = fb.beta[cc + e];
+        r0[e] = fb.red[cc + e] * invn; r1[e] = fb.red[C + cc + e] * invn;
+      }
+#pragma unroll
+      for (int k = 0; k < NDZ; ++k) {  // bn_act_bwd_apply_kernel's arithmetic on this chunk
+        const uint32_t wz[4] = {vz[k].x, vz[k].y, vz[k].z, vz[k].w}, wd[4] = {vdz[k].x, vdz[k].y, vdz[k].z, vdz[k].w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float z = (e & 1) ? __uint_as_float(wz[e >> 1] & 0xffff0000u) : __uint_as_float(wz[e >> 1] << 16);
+          float d = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
+          const float xh = (z - mu[e]) * rs[e];
+          const float y = xh * ga[e] + be[e];
+          d *= fb.act == 2 ? dsilu_f(y) : (fb.act == 1 ? (y > 0.f ? 1.f : 0.f) : 1.f);
+          o[e] = rs[e] * ga[e] * (d - r0[e] - xh * r1[e]);
+        }
+        vdz[k] = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+        const int i = threadIdx.x + 256 * k;
+        const int row = i / (CT / 8), c8 = (i % (CT / 8)) * 8;
+        const int tin = t0 - PAD + row;
+        if (i < ROWS * (CT / 8) && row >= PAD && row < PAD + TTILE && tin < T)  // the tile's own rows: dZ as the unfused pass stored it
+          *reinterpret_cast<uint4*>(fb.dZ_out + (rowbase + tin) * C + c0 + c8) = vdz[k];
+      }
+      if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {  // (the apply kernel's block 0: parameter gradients, next ring buffer)
+        if (fb.dgamma || fb.dbeta)
+          for (int q = threadIdx.x; q < C; q += 256) {
+            if (fb.dbeta) fb.dbeta[q] += fb.red[q];
+            if (fb.dgamma) fb.dgamma[q] += fb.red[C + q];
+          }
+        if (fb.zero_next)
+          for (int q = threadIdx.x; q < fb.zero_n; q += 256) fb.zero_next[q] = 0.f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NDZ; ++k) {
       const int i = threadIdx.x + 256 * k;
@@ -710,7 +763,12 @@ static void launch_glu_dwconv_fwd(dim3 grid, hipStream_t stream, const bf16_t* Y
 template <int KW>
 static void launch_glu_dwconv_bwd_data(dim3 grid, hipStream_t stream, const bf16_t* dZ, const bf16_t* Y, const float* w,
                                        bf16_t* dY, int T, int C) {
-  hipLaunchKernelGGL((glu_dwconv_bwd_data_kernel<KW>), grid, dim3(256), 0, stream, dZ, Y, w, dY, T, C);
+  hipLaunchKernelGGL((glu_dwconv_bwd_data_kernel<KW, false>), grid, dim3(256), 0, stream, dZ, Y, w, dY, T, C, BnBwdFuse{});
+}
+template <int KW>
+static void launch_glu_dwconv_bwd_data_bn(dim3 grid, hipStream_t stream, const bf16_t* Y, const float* w, bf16_t* dY, int T, int C,
+                                          BnBwdFuse fb) {
+  hipLaunchKernelGGL((glu_dwconv_bwd_data_kernel<KW, true>), grid, dim3(256), 0, stream, (const bf16_t*)nullptr, Y, w, dY, T, C, fb);
 }
 template <int KW>
 static void launch_dwconv_bwd_weight(dim3 grid, hipStream_t stream, const bf16_t* dZ, const bf16_t* U, float* dw, int T,
@@ -1015,6 +1073,29 @@ extern "C" int ea_glu_dwconv_bwd(const void* dZ, const void* Y, const void* U, c
   EA_KW_DISPATCH(KW, launch_glu_dwconv_bwd_data, grid, stream, (const bf16_t*)dZ, (const bf16_t*)Y, w, (bf16_t*)dY, T, C);
   if (!dw) return EA_CHECK_LAUNCH();  // data gradient only: the caller runs ea_dwconv_bwd_weight (optimizer-only) itself
   return ea_dwconv_bwd_weight(dZ, U, dw, wgrad_ws, B, T, C, KW, stream);
+}
+// ea_bn_act_bwd_fused followed by ea_glu_dwconv_bwd's data gradient with the BatchNorm "apply" pass folded into the convolution
+// kernel's tile staging (glu_dwconv_bwd_data_kernel<KW, true>): reduce launch + ONE more launch.  dZ is still written (the
+// depthwise weight gradient reads it).  Channel counts that are not a multiple of 64 take the two separate passes.
+extern "C" int ea_bn_glu_dwconv_bwd_fused(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
+                                          float* red, void* dZ, float* dgamma, float* dbeta, int act, int training, float* zero_next,
+                                          int zero_n, const void* Y, const float* w, void* dY, int B, int T, int C, int KW,
+                                          hipStream_t stream) {
+  if (B <= 0 || T <= 0) return 0;
+  const long M = (long)B * T;
+  // (A/B switch, default OFF: measured 12.04 / 12.02 ms per step fused against 12.00 / 12.01 with the two passes — the halo rows'
+  // BatchNorm arithmetic and the second operand's loads cost what the saved launch and pass gave; profiles/r06_side_kernel_grids_ab.txt)
+  static const bool fuse = [] { const char* e = getenv("EA_BN_GLU_BWD_FUSED"); return e && e[0] == '1'; }();
+  if (!fuse || C % CT != 0) {
+    const int rc = ea_bn_act_bwd_fused(Z, dH, mean_rstd, gamma, beta, red, dZ, dgamma, dbeta, M, C, act, training, zero_next, zero_n, stream);
+    return rc ? rc : ea_glu_dwconv_bwd(dZ, Y, nullptr, w, dY, nullptr, nullptr, B, T, C, KW, stream);
+  }
+  launch_bn_bwd_reduce(Z, dH, mean_rstd, gamma, beta, red, M, C, act, stream);
+  BnBwdFuse fb{(const bf16_t*)Z, (const bf16_t*)dH, mean_rstd, gamma, beta, red, (bf16_t*)dZ, training ? (float)M : 0.f, act, dgamma, dbeta,
+               zero_next, zero_n};
+  dim3 grid(C / CT, (T + TTILE - 1) / TTILE, B);
+  EA_KW_DISPATCH(KW, launch_glu_dwconv_bwd_data_bn, grid, stream, (const bf16_t*)Y, w, (bf16_t*)dY, T, C, fb);
+  return EA_CHECK_LAUNCH();
 }
 extern "C" int ea_dwconv_bwd_weight(const void* dZ, const void* U, float* dw, void* wgrad_ws, int B, int T, int C, int KW,
                                     hipStream_t stream) {

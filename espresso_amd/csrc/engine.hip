@@ -904,20 +904,21 @@ static void conv_bwd(Ctx& c, const ConvSaved& s, const EaLayerShape& sh, const E
     if (!c.dry && c.rc == 0) c.rc = hipMemsetAsync(red, 0, 2 * C * sizeof(float), c.s) == hipSuccess ? 0 : -1;
   }
   uint16_t* dZ = sc.get<uint16_t>((size_t)M * C);
+  uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
+  char* wws = sc.get<char>((size_t)ea_dwconv_wgrad_workspace_bytes(B, T, C, sh.KW));
   if (ring) {
     if (R && c.rc == 0) {
       red = R->red[R->ri];
-      RUN(ea_bn_act_bwd_fused(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, gw.bn_g, gw.bn_b, M, C, EA_ACT_SILU, sh.training,
-                              R->red[R->ri ^ 1], 2 * R->cap, c.s));
+      // BatchNorm reduce, then ONE kernel: BatchNorm apply folded into the GLU / depthwise data gradient's tile staging
+      RUN(ea_bn_glu_dwconv_bwd_fused(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, gw.bn_g, gw.bn_b, EA_ACT_SILU, sh.training, R->red[R->ri ^ 1],
+                                     2 * R->cap, s.Y, w.dw, dY, B, T, C, sh.KW, c.s));
       if (c.rc == 0) R->ri ^= 1;
       else R->dirty = true;
     }
   } else {
     RUN(ea_bn_act_bwd(s.Z, dH, s.mr, w.bn_g, w.bn_b, red, dZ, nullptr, nullptr, M, C, EA_ACT_SILU, sh.training, c.s));
+    RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, nullptr, wws, B, T, C, sh.KW, c.s));
   }
-  uint16_t* dY = sc.get<uint16_t>((size_t)M * 2 * C);
-  char* wws = sc.get<char>((size_t)ea_dwconv_wgrad_workspace_bytes(B, T, C, sh.KW));
-  RUN(ea_glu_dwconv_bwd(dZ, s.Y, s.U, w.dw, dY, nullptr, wws, B, T, C, sh.KW, c.s));
   if (c.df) {
     if (!c.dry) {
       const EaConvGrads gwv = gw;

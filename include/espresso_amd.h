@@ -339,6 +339,13 @@ int ea_bn_act_fwd_train(const void* Z, const double* stats, float* mean_rstd, fl
 int ea_bn_act_bwd_fused(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta,
                         float* red, void* dZ, float* dgamma, float* dbeta, long M, int C, int act, int training,
                         float* zero_next, int zero_n, ea_stream_t stream);
+/* ... and the same followed by ea_glu_dwconv_bwd's data gradient (dY [B*T][2C] from dZ, Y and the depthwise filter w), with the
+ * BatchNorm backward's second pass folded into the convolution kernel's tile staging: the BatchNorm reduce + ONE launch instead of
+ * reduce + apply + convolution (the Conformer convolution module's backward, fairseq/modules/conformer_layer.py:79-101).  dZ is
+ * written as before (ea_dwconv_bwd_weight reads it). */
+int ea_bn_glu_dwconv_bwd_fused(const void* Z, const void* dH, const float* mean_rstd, const float* gamma, const float* beta, float* red,
+                               void* dZ, float* dgamma, float* dbeta, int act, int training, float* zero_next, int zero_n,
+                               const void* Y, const float* w, void* dY, int B, int T, int C, int KW, ea_stream_t stream);
 /* ea_bn_act_bwd with dgamma == dbeta == NULL skips the parameter gradients; they are then taken from `red` by: */
 int ea_bn_param_grad(const float* red, float* dgamma, float* dbeta, int C, ea_stream_t stream);
 /* First sub-sampler layer (espresso/modules/speech_convolutions.py:78-102, layer 0): BatchNorm (+ activation) backward and the
