@@ -18,14 +18,14 @@ n = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
 for c in tot:
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == c and any(k in r["Kernel_Name"] for k in ("gemm_bf16_kernel", "gemm_glds_kernel", "gemm_w8_kernel", "wgrad_group_kernel", "wgrad_group_tr_kernel")):
+            if r["Counter_Name"] == c and any(k in r["Kernel_Name"] for k in ("gemm_bf16_kernel", "gemm_glds_kernel", "gemm_w8_kernel", "wgrad_group_kernel", "wgrad_group_tr_kernel", "wgrad_w8_kernel")):
                 tot[c] += float(r["Counter_Value"])
                 n[c] += 1
 assert n["FETCH_SIZE"] == n["WRITE_SIZE"] and n["FETCH_SIZE"] > 0, n
 launches = n["FETCH_SIZE"]
 read_b = 2.0 * tot["FETCH_SIZE"] * 1024.0 / launches   # gfx950: FETCH_SIZE reports half of a wide coalesced read
 write_b = tot["WRITE_SIZE"] * 1024.0 / launches
-out = {"kernel": "gemm_bf16_kernel + gemm_glds_kernel + gemm_w8_kernel + wgrad_group_tr_kernel (+ wgrad_group_kernel)", "launches": launches, "hbm_read_bytes_per_launch": read_b,
+out = {"kernel": "gemm_bf16_kernel + gemm_glds_kernel + gemm_w8_kernel + wgrad_w8_kernel + wgrad_group_tr_kernel (+ wgrad_group_kernel)", "launches": launches, "hbm_read_bytes_per_launch": read_b,
        "hbm_write_bytes_per_launch": write_b, "hbm_bytes_per_launch": read_b + write_b,
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 incl. the start-up reserve pass; "
                  "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)"}
