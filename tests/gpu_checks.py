@@ -390,6 +390,64 @@ def check_wgrad_group(seed=0, variant=0, aligned=False, tr=1):
     return {"dW_rel": worst_w, "db_rel": worst_b}
 
 
+def check_wgrad_w8_layer_group(M=4200, C=512, Fd=2048, H=8, R=519, seed=1):
+    """An encoder layer's grouped weight gradient at the size where the AUTOMATIC rule takes the 8-wave kernel (>= 48 tiles of 256 x 256,
+    >= 4096 rows; round 6): the layer's eight weight matrices plus the per-head positional-projection problems (dW of 64 rows), with
+    biases, accumulated into non-zero gradients — 8-wave (mode 1 = automatic) against the 4-wave kernel (mode 0) bit for bit, and
+    that the automatic mode really took the 8-wave kernel (the group's launch grid)."""
+    import ctypes
+
+    from espresso_amd import _lib
+    from espresso_amd import kernels as Kk
+
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Rp = (R + 7) // 8 * 8
+    # (N = dW rows = dy columns, K = dW columns = x columns, bias)
+    shapes = [(Fd, C, True), (C, Fd, True), (3 * C, C, True), (C, C, True), (2 * C, C, False), (C, C, False), (Fd, C, True), (C, Fd, True)]
+    probs = []
+    for (N, K, bias) in shapes:
+        dy = bf(torch.randn(M, N, generator=g) * 0.1).to(DEV)
+        x = bf(torch.randn(M, K, generator=g)).to(DEV)
+        probs.append((dy, N, x, K, K, torch.randn(N, K, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV) if bias else None, N, K))
+    qv = bf(torch.randn(M, C, generator=g) * 0.1).to(DEV)
+    dh = C // H
+    for h in range(H):  # thin problems: dy = 64 columns of a wider matrix, x = this head's [M][Rp] slab
+        xh = bf(torch.randn(M, Rp, generator=g)).to(DEV)
+        probs.append((qv[:, h * dh:], dh, xh, R, Rp, torch.randn(dh, Rp, generator=g).to(DEV), None, C, Rp))
+
+    def run(mode):
+        old = lib.ea_set_wgrad_w8(mode)
+        grp = _lib.EaWgradGroup()
+        grp.count = len(probs)
+        outs = []
+        for i, (dy, N, x, K, ldw, dW0, db0, ld_dy, ld_x) in enumerate(probs):
+            dW, db = dW0.clone(), (db0.clone() if db0 is not None else None)
+            q = grp.p[i]
+            q.dy, q.x, q.dW, q.dbias = dy.data_ptr(), x.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else None)
+            q.M, q.N, q.K, q.ld_dy, q.ld_x, q.ldw = M, N, K, ld_dy, ld_x, ldw
+            outs.append((dW, db))
+        try:
+            _lib.check(lib.ea_wgrad_group(ctypes.byref(grp), Kk._stream()), "ea_wgrad_group")
+            torch.cuda.synchronize()
+        finally:
+            lib.ea_set_wgrad_w8(old)
+        return outs
+
+    ref, got = run(0), run(1)
+    res = {"dW_bits_differ": 0, "db_rel": 0.0, "dW_rel_fp64": 0.0}
+    for (dy, N, x, K, ldw, dW0, db0, ld_dy, ld_x), (rW, rb), (gW, gb) in zip(probs, ref, got):
+        res["dW_bits_differ"] += int((rW[:, :K].contiguous().view(torch.int32) != gW[:, :K].contiguous().view(torch.int32)).sum())
+        if rb is not None:
+            res["db_rel"] = max(res["db_rel"], float((rb - gb).abs().max() / rb.abs().max()))
+    dy, N, x, K, ldw, dW0, db0, ld_dy, ld_x = probs[3]
+    want = dW0.double() + dy[:, :N].double().t() @ x[:, :K].double()
+    res["dW_rel_fp64"] = float((got[3][0].double() - want).abs().max() / want.abs().max())
+    tiles = sum(((N + 255) // 256) * ((K + 255) // 256) for (_, N, _, K, *_rest) in probs)
+    res["tiles_256"] = tiles
+    return res
+
+
 def check_joint_wgrad(n=20000, V=5004, J=512, seed=0):
     """functional._joint_wgrad (the transducer output layer's weight / bias gradient at recipe width: padded row pitch 5056, row
     slabs through one grouped launch, slab outputs summed) against fp64 on the same bf16 operands."""

@@ -110,6 +110,13 @@ def test_wgrad_8wave_256_tiles_bit_identical_to_4wave():
     assert r["dW_bits_differ"] == 0 and r["db_rel_vs_4wave"] < 1e-6 and r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
 
 
+def test_wgrad_8wave_automatic_rule_on_an_encoder_layer_group():
+    """the round-6 rule (>= 48 tiles, >= 4096 rows -> 8-wave kernel) on a layer-shaped group incl. the thin per-head problems"""
+    r = G.check_wgrad_w8_layer_group()
+    print(r)
+    assert r["tiles_256"] >= 48 and r["dW_bits_differ"] == 0 and r["db_rel"] < 1e-6 and r["dW_rel_fp64"] < 2e-3, r
+
+
 def test_transducer_joint_weight_gradient_at_recipe_width():
     r = G.check_joint_wgrad()
     assert r["shape_ok"] and r["dW_rel"] < 2e-3 and r["db_rel"] < 2e-3, r
