@@ -330,7 +330,11 @@ static int wgrad_w8_launch(const EaWgradGroup& g, hipStream_t stream, int* grid_
   // leaves 140 CUs to the compute queue: config 3 12.89 -> 12.49 ms per step, config 2 12.91 -> 12.63 (round 6,
   // profiles/r06_side_kernel_grids_ab.txt).  Smaller row counts (config 4: ~1 500 rows) gain 1 % forced and stay with the 4-wave kernel.
   static const int min_tiles = [] { const char* e = getenv("EA_WGRAD_W8_MIN_TILES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 48; }();  // (tuning knob)
-  if (!forced && !(total >= min_tiles && total <= 512 && min_rows >= 4096)) return 0;
+  // (second clause, round 6: the transducer recipe's encoder layers — ~116 tiles over ~1 500 rows — gain 1 % on this kernel beside the
+  // compute queue; the enc-dec recipe's decoder layers — 64 tiles, similar row counts — lose 5 %: profiles/r06_wgrad_w8_configs_ab.txt)
+  static const int small_rows_tiles = [] { const char* e = getenv("EA_WGRAD_W8_SMALL_ROWS_TILES"); return e ? atoi(e) : 80; }();
+  const bool rule = total <= 512 && ((total >= min_tiles && min_rows >= 4096) || (small_rows_tiles > 0 && total >= small_rows_tiles && min_rows >= 1024));
+  if (!forced && !rule) return 0;
   for (int i = g.count; i <= EA_WGRAD_MAX; ++i) tb.start[i] = total;
   for (int i = g.count; i < EA_WGRAD_MAX; ++i) tb.tiles_x[i] = 1;
   constexpr int lds = 2 * 2 * 64 * 512;
