@@ -795,9 +795,10 @@ extern "C" int ea_layernorm_param_reduce_group(const EaLnReduceGroup* g, hipStre
     if (nblk > maxblk) maxblk = nblk;
   }
   if (n == 0) return 0;
+  static const int rs_cap = [] { const char* e = getenv("EA_LN_REDUCE_RS"); return e ? atoi(e) : 32; }();  // (tuning knob: row splits per item)
   int rs = maxblk / 32;
   if (rs < 1) rs = 1;
-  if (rs > 32) rs = 32;
+  if (rs > rs_cap) rs = rs_cap;
   hipLaunchKernelGGL(ln_param_reduce_group_kernel, dim3((maxc2 + 63) / 64, rs, n), dim3(256), 0, stream, tb);
   return EA_CHECK_LAUNCH();
 }
