@@ -131,6 +131,8 @@ class Trainer:
             b = getattr(m, "_ea_binding", None)
             if b is not None:
                 b.saved_busy = False
+            m.__dict__.pop("_ea_chain_in", None)  # (a chained layer call whose successor never ran: drop its token and the tensors it holds)
+            m.__dict__.pop("_ea_wt_fresh", None)
         self.flat.zero_grad()
         self._stats.zero_()
         if self._stats.is_cuda:
